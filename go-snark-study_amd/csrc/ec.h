@@ -1,0 +1,254 @@
+// BN128 G1 / G2 group arithmetic for the MSM kernels, generic over the coordinate field
+// (FqTag: G1 over Fq, Fq2Tag: G2 over Fq2).
+//
+// Replaces the reference's bn128/g1.go:32-170 and bn128/g2.go:32-200 (Jacobian add-2007-bl /
+// dbl-2009-l / MSB-first double-and-add on math/big).  Device representation: buckets and
+// partial sums are XYZZ (x = X/ZZ, y = Y/ZZZ, ZZ^3 = ZZZ^2): a mixed add is 8M+2S instead of
+// 11M+5S for Jacobian+Jacobian, bases are affine.  Unlike the reference's Add (no P==Q branch,
+// g1.go:32-89) these formulas are COMPLETE: doubling and P + (-P) are handled.
+// Parity with the reference is therefore defined on the affine normal form (g1.go:157-170).
+#pragma once
+#include "fp29.h"
+#include "fq2.h"
+
+namespace gs {
+
+template <class T> struct BoundOf;
+template <class M, int B> struct BoundOf<Fe<M, B>> { static constexpr int v = B; };
+template <int B> struct BoundOf<Fq2e<B>> { static constexpr int v = B; };
+
+struct FqTag {
+  template <int B> using E = Fe<ModQ, B>;
+  static constexpr int kWords = 8;                       // canonical storage: 8 x u32 per element
+  static constexpr bool mul_ok(int a, int b) { return a * b <= 160; }
+  static constexpr bool sqr_ok(int a) { return a * a <= 160; }
+  static GS_HD E<1> one() { return fe_one<ModQ>(); }
+  template <int B> static GS_HD E<B> zero() { return fe_zero<ModQ, B>(); }
+  template <int B> static GS_HD bool limbs_all_zero(const E<B>& a) {
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) o |= a.l[i];
+    return o == 0;
+  }
+};
+
+struct Fq2Tag {
+  template <int B> using E = Fq2e<B>;
+  static constexpr int kWords = 16;
+  static constexpr bool mul_ok(int a, int b) { return a * b + a * (b + 1) <= 160 && 2 * a * b <= 160; }
+  static constexpr bool sqr_ok(int a) { return (2 * a) * (2 * a + 1) <= 160; }
+  static GS_HD E<1> one() { return fq2_one(); }
+  template <int B> static GS_HD E<B> zero() { return fq2_zero<B>(); }
+  template <int B> static GS_HD bool limbs_all_zero(const E<B>& a) {
+    return FqTag::limbs_all_zero(a.c0) && FqTag::limbs_all_zero(a.c1);
+  }
+};
+
+// bound-aware product / square: insert reduce2 at compile time where an operand is too lazy
+template <class T, class A, class Bv>
+GS_HD auto smul(const A& a, const Bv& b) {
+  constexpr int Ba = BoundOf<A>::v, Bb = BoundOf<Bv>::v;
+  if constexpr (T::mul_ok(Ba, Bb)) return mul(a, b);
+  else if constexpr (Ba >= Bb && T::mul_ok(2, Bb)) return mul(reduce2(a), b);
+  else if constexpr (T::mul_ok(Ba, 2)) return mul(a, reduce2(b));
+  else return mul(reduce2(a), reduce2(b));
+}
+template <class T, class A>
+GS_HD auto ssqr(const A& a) {
+  if constexpr (T::sqr_ok(BoundOf<A>::v)) return sqr(a);
+  else return sqr(reduce2(a));
+}
+
+// ---- point types ------------------------------------------------------------------------------
+template <class T>
+struct Affine {                       // Montgomery form, canonical; infinity = (0, 0) (not on y^2 = x^3 + b)
+  typename T::template E<1> x, y;
+};
+
+template <class T>
+struct Xyzz {                         // infinity <=> all limbs of zz are zero
+  typename T::template E<9> x;
+  typename T::template E<5> y;
+  typename T::template E<2> zz, zzz;
+};
+
+template <class T> GS_HD bool is_inf(const Affine<T>& p) { return T::limbs_all_zero(p.x) && T::limbs_all_zero(p.y); }
+template <class T> GS_HD bool is_inf(const Xyzz<T>& p) { return T::limbs_all_zero(p.zz); }
+
+template <class T>
+GS_HD Xyzz<T> xyzz_inf() {
+  Xyzz<T> r;
+  r.x = T::template zero<9>(); r.y = T::template zero<5>();
+  r.zz = T::template zero<2>(); r.zzz = T::template zero<2>();
+  return r;
+}
+
+template <class T>
+GS_HD Xyzz<T> xyzz_from_affine(const Affine<T>& a) {
+  if (is_inf(a)) return xyzz_inf<T>();
+  Xyzz<T> r;
+  r.x = relax<9>(a.x); r.y = relax<5>(a.y);
+  r.zz = relax<2>(T::one()); r.zzz = relax<2>(T::one());
+  return r;
+}
+
+// 2 * (x, y) for a finite affine point, y given with bound 2       [dbl-2008-s-1 with ZZ = ZZZ = 1]
+template <class T>
+GS_HD Xyzz<T> xyzz_dbl_affine(const typename T::template E<1>& x, const typename T::template E<2>& y) {
+  auto U = dbl(y);                                      // 4
+  auto V = ssqr<T>(U);
+  auto W = smul<T>(U, V);
+  auto S = smul<T>(x, V);
+  auto xx = ssqr<T>(x);
+  auto M = add(dbl(xx), xx);                            // 6
+  auto MM = ssqr<T>(M);
+  Xyzz<T> r;
+  auto X3 = sub(MM, dbl(S));                            // 2 + 4 + 1 = 7
+  r.x = relax<9>(X3);
+  auto t = smul<T>(M, sub(S, X3));                      // 6 x 10
+  r.y = sub(t, smul<T>(W, y));                          // 5
+  r.zz = V; r.zzz = W;
+  return r;
+}
+
+// acc += +-(x2, y2)   [madd-2008-s: 8M + 2S], complete.  negate: add -(x2, y2) instead.
+template <class T>
+GS_HD void xyzz_madd(Xyzz<T>& acc, const Affine<T>& b, bool negate = false) {
+  if (is_inf(b)) return;
+  const auto y2 = select(negate, neg(b.y), relax<2>(b.y));   // -(x,y) = (x, 2p - y)
+  if (is_inf(acc)) {
+    acc.x = relax<9>(b.x); acc.y = relax<5>(y2);
+    acc.zz = relax<2>(T::one()); acc.zzz = relax<2>(T::one());
+    return;
+  }
+  auto U2 = smul<T>(b.x, acc.zz);
+  auto S2 = smul<T>(y2, acc.zzz);
+  auto P = sub(U2, acc.x);                              // 2 + 9 + 1 = 12
+  auto R = sub(S2, acc.y);                              // 2 + 5 + 1 = 8
+  if (is_zero(P)) {
+    if (is_zero(R)) acc = xyzz_dbl_affine<T>(b.x, y2);
+    else acc = xyzz_inf<T>();
+    return;
+  }
+  auto PP = ssqr<T>(P);
+  auto PPP = smul<T>(P, PP);
+  auto Q = smul<T>(acc.x, PP);
+  auto RR = ssqr<T>(R);
+  auto X3 = sub(RR, add(PPP, dbl(Q)));                  // 2 + 6 + 1 = 9
+  auto t = smul<T>(R, sub(Q, X3));                      // 8 x 12
+  auto Y3 = sub(t, smul<T>(acc.y, PPP));                // 5
+  acc.zz = smul<T>(acc.zz, PP);
+  acc.zzz = smul<T>(acc.zzz, PPP);
+  acc.x = X3; acc.y = Y3;
+}
+
+// 2 * acc   [dbl-2008-s-1: 6M + 4S... a = 0]
+template <class T>
+GS_HD void xyzz_dbl(Xyzz<T>& acc) {
+  if (is_inf(acc)) return;
+  auto U = dbl(acc.y);                                  // 10
+  auto V = ssqr<T>(U);
+  auto W = smul<T>(U, V);
+  auto S = smul<T>(acc.x, V);
+  auto xx = ssqr<T>(acc.x);
+  auto M = add(dbl(xx), xx);                            // 6
+  auto MM = ssqr<T>(M);
+  auto X3 = sub(MM, dbl(S));                            // 7
+  auto t = smul<T>(M, sub(S, X3));
+  auto Y3 = sub(t, smul<T>(W, acc.y));                  // 5
+  acc.zz = smul<T>(V, acc.zz);
+  acc.zzz = smul<T>(W, acc.zzz);
+  acc.x = relax<9>(X3); acc.y = Y3;
+}
+
+// acc += b   [add-2008-s: 12M + 2S], complete
+template <class T>
+GS_HD void xyzz_add(Xyzz<T>& acc, const Xyzz<T>& b) {
+  if (is_inf(b)) return;
+  if (is_inf(acc)) { acc = b; return; }
+  auto U1 = smul<T>(acc.x, b.zz);
+  auto U2 = smul<T>(b.x, acc.zz);
+  auto S1 = smul<T>(acc.y, b.zzz);
+  auto S2 = smul<T>(b.y, acc.zzz);
+  auto P = sub(U2, U1);                                 // 5
+  auto R = sub(S2, S1);                                 // 5
+  if (is_zero(P)) {
+    if (is_zero(R)) xyzz_dbl(acc);
+    else acc = xyzz_inf<T>();
+    return;
+  }
+  auto PP = ssqr<T>(P);
+  auto PPP = smul<T>(P, PP);
+  auto Q = smul<T>(U1, PP);
+  auto RR = ssqr<T>(R);
+  auto X3 = sub(RR, add(PPP, dbl(Q)));                  // 9
+  auto t = smul<T>(R, sub(Q, X3));
+  auto Y3 = sub(t, smul<T>(S1, PPP));                   // 5
+  acc.zz = smul<T>(smul<T>(acc.zz, b.zz), PP);
+  acc.zzz = smul<T>(smul<T>(acc.zzz, b.zzz), PPP);
+  acc.x = X3; acc.y = Y3;
+}
+
+template <class T>
+GS_HD Xyzz<T> xyzz_neg(const Xyzz<T>& a) {
+  Xyzz<T> r = a;
+  if (!is_inf(a)) r.y = relax<5>(neg(reduce2(a.y)));    // p-bounded 3 -> fits 5
+  return r;
+}
+
+// k * p for a small non-negative integer k (bucket-reduction segment offsets)
+template <class T>
+GS_HD Xyzz<T> xyzz_mul_u32(const Xyzz<T>& p, uint32_t k) {
+  Xyzz<T> r = xyzz_inf<T>();
+  for (int bit = 31; bit >= 0; --bit) {
+    xyzz_dbl(r);
+    if ((k >> bit) & 1u) xyzz_add(r, p);
+  }
+  return r;
+}
+
+// k * p for a 256-bit scalar given as 8 little-endian u32 words (prover tail: groth16.go:253-275)
+template <class T>
+GS_HD Xyzz<T> xyzz_mul_words(const Xyzz<T>& p, const uint32_t (&k)[8]) {
+  Xyzz<T> r = xyzz_inf<T>();
+  for (int bit = 255; bit >= 0; --bit) {
+    xyzz_dbl(r);
+    if ((k[bit >> 5] >> (bit & 31)) & 1u) xyzz_add(r, p);
+  }
+  return r;
+}
+
+// XYZZ -> affine (canonical Montgomery): one field inversion           [cf. g1.go:157-170]
+template <class T>
+GS_HD Affine<T> xyzz_to_affine(const Xyzz<T>& p) {
+  Affine<T> r;
+  if (is_inf(p)) { r.x = T::template zero<1>(); r.y = T::template zero<1>(); return r; }
+  auto i3 = inv(p.zzz);                                 // 1/ZZZ
+  auto zi = smul<T>(p.zz, i3);                          // ZZ/ZZZ ; (ZZ/ZZZ)^2 = 1/ZZ
+  auto i2 = ssqr<T>(zi);
+  auto x = smul<T>(p.x, i2);
+  auto y = smul<T>(p.y, i3);
+  r.x = canon(x); r.y = canon(y);
+  return r;
+}
+
+// Jacobian (X, Y, Z) in Montgomery form -> affine: x = X/Z^2, y = Y/Z^3 (pk upload; the
+// reference keeps pk points Jacobian with Z != 1, e.g. groth16.go:139-175)
+template <class T, class EX>
+GS_HD Affine<T> jacobian_to_affine(const EX& X, const EX& Y, const EX& Z) {
+  Affine<T> r;
+  if (is_zero(Z)) { r.x = T::template zero<1>(); r.y = T::template zero<1>(); return r; }
+  auto zi = inv(Z);
+  auto zi2 = ssqr<T>(zi);
+  auto x = smul<T>(X, zi2);
+  auto y = smul<T>(Y, smul<T>(zi2, zi));
+  r.x = canon(x); r.y = canon(y);
+  return r;
+}
+
+using G1Affine = Affine<FqTag>;
+using G2Affine = Affine<Fq2Tag>;
+using G1Xyzz = Xyzz<FqTag>;
+using G2Xyzz = Xyzz<Fq2Tag>;
+
+}  // namespace gs

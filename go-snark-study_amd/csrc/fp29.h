@@ -1,0 +1,361 @@
+// BN128 prime-field arithmetic for gfx950: 9 x 29-bit limbs, Montgomery form with R = 2^261.
+//
+// Replaces (device side) the reference's fields/fq.go:32-98 (`Fq.Add/Sub/Neg/Mul/Square/
+// Inverse` on math/big) for both moduli it is used with: q (bn128/bn128.go:85) and
+// r (groth16/groth16.go:82).
+//
+// Why 29-bit limbs and not 8x32 / 4x64: measured on MI355X (tools/ubench_valu.hip,
+// profiles/r01_ubench_valu.txt) every carry-producing/consuming VALU op (v_add_co_u32,
+// v_addc_co_u32, v_lshl_add_u64) issues at HALF rate -- the same 4 cycles per wave as the
+// 32x32+64 multiply-add v_mad_u64_u32 -- so a saturated-limb Montgomery product spends more
+// issue slots on carries than on multiplies.  With 29-bit limbs a whole column of the
+// product (9 a_i*b_j + 9 m_i*p_j terms of < 2^58) is summed inside the 64-bit accumulator
+// of v_mad_u64_u32 with NO carry instructions: 162 mads + ~35 shift/mask ops per product.
+// Additions are 9 independent full-rate v_add_u32 plus a carry-save "nearly normal" fix-up.
+//
+// Invariants ("nearly normal"): limbs 0..7 < 2^29 + 8, limb 8 (top) < 2^29; the VALUE of an
+// Fe<M,B> is < B*p (B is a compile-time bound, so every formula is overflow-checked by the
+// type system: mul needs Ba*Bb <= 160 and returns a value < 2p).  Values are only made
+// canonical ([0,p)) at the C-ABI boundary.
+#pragma once
+#include <stdint.h>
+#include <hip/hip_runtime.h>
+
+#include "bn128_constants.h"
+
+#define GS_HD __host__ __device__ __forceinline__
+
+namespace gs {
+
+constexpr int NL = 9;
+constexpr int LB = 29;
+constexpr uint32_t LMASK = (1u << LB) - 1u;
+
+template <class M, int B>
+struct Fe {
+  static_assert(B >= 1 && B <= M::kMaxBiasK, "value bound out of supported range");
+  uint32_t l[NL];
+};
+
+// ---- bound bookkeeping ---------------------------------------------------------------------
+template <int BN, class M, int B>
+GS_HD Fe<M, BN> relax(const Fe<M, B>& a) {      // forget precision: B -> BN >= B (free)
+  static_assert(BN >= B, "relax can only loosen a bound");
+  Fe<M, BN> r;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) r.l[i] = a.l[i];
+  return r;
+}
+
+template <class M, int B>
+GS_HD Fe<M, B> fe_zero() {
+  Fe<M, B> r;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) r.l[i] = 0;
+  return r;
+}
+
+template <class M>
+GS_HD Fe<M, 1> fe_one() {                      // 1 in Montgomery form
+  Fe<M, 1> r;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) r.l[i] = M::one(i);
+  return r;
+}
+
+// carry-save normalisation: every limb hands its excess to the next one in parallel
+// (no ripple).  Input limbs may be anything < 2^32; output is nearly normal.
+template <class M, int B>
+GS_HD void carry_save(Fe<M, B>& x) {
+  uint32_t c[NL - 1];
+#pragma unroll
+  for (int i = 0; i < NL - 1; ++i) c[i] = x.l[i] >> LB;
+#pragma unroll
+  for (int i = 0; i < NL - 1; ++i) x.l[i] &= LMASK;
+#pragma unroll
+  for (int i = 1; i < NL; ++i) x.l[i] += c[i - 1];
+}
+
+// full (rippling) normalisation: limbs 0..7 < 2^29 exactly.
+template <class M, int B>
+GS_HD void carry_full(Fe<M, B>& x) {
+#pragma unroll
+  for (int i = 0; i < NL - 1; ++i) {
+    x.l[i + 1] += x.l[i] >> LB;
+    x.l[i] &= LMASK;
+  }
+}
+
+template <class M, int Ba, int Bb>
+GS_HD Fe<M, Ba + Bb> add(const Fe<M, Ba>& a, const Fe<M, Bb>& b) {
+  Fe<M, Ba + Bb> r;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) r.l[i] = a.l[i] + b.l[i];
+  carry_save(r);
+  return r;
+}
+
+template <class M, int B>
+GS_HD Fe<M, 2 * B> dbl(const Fe<M, B>& a) {
+  Fe<M, 2 * B> r;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) r.l[i] = a.l[i] << 1;
+  carry_save(r);
+  return r;
+}
+
+// a - b + (Bb+1) p  (always >= 0 limb-wise, see tools/gen_constants.py:bias_limbs)
+template <class M, int Ba, int Bb>
+GS_HD Fe<M, Ba + Bb + 1> sub(const Fe<M, Ba>& a, const Fe<M, Bb>& b) {
+  Fe<M, Ba + Bb + 1> r;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) r.l[i] = a.l[i] + (M::bias(Bb + 1, i) - b.l[i]);
+  carry_save(r);
+  return r;
+}
+
+// (B+1) p - a
+template <class M, int B>
+GS_HD Fe<M, B + 1> neg(const Fe<M, B>& a) {
+  Fe<M, B + 1> r;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) r.l[i] = M::bias(B + 1, i) - a.l[i];
+  carry_save(r);
+  return r;
+}
+
+// ---- Montgomery product (product scanning, reduction interleaved) ---------------------------
+// acc is the 64-bit column accumulator: each `acc += (u64)x * y` is one v_mad_u64_u32.
+template <class M>
+GS_HD void mont_low_column(uint64_t& acc, uint32_t (&m)[NL], int k) {
+  // add the m_i * p_{k-i} terms already known, derive m_k, clear the column, shift.
+#pragma unroll
+  for (int i = 0; i < NL; ++i)
+    if (i < k) acc += (uint64_t)m[i] * M::p(k - i);
+  m[k] = ((uint32_t)acc * M::kPinv29) & LMASK;
+  acc += (uint64_t)m[k] * M::p(0);
+  acc >>= LB;
+}
+
+template <class M>
+GS_HD void mont_high_column(uint64_t& acc, const uint32_t (&m)[NL], int k, uint32_t& out) {
+#pragma unroll
+  for (int i = 0; i < NL; ++i)
+    if (i >= k - (NL - 1)) acc += (uint64_t)m[i] * M::p(k - i);
+  out = (uint32_t)acc & LMASK;
+  acc >>= LB;
+}
+
+template <class M, int Ba, int Bb>
+GS_HD Fe<M, 2> mul(const Fe<M, Ba>& a, const Fe<M, Bb>& b) {
+  static_assert(Ba * Bb <= 160, "Montgomery product input bound exceeded (a*b must be < 169 p^2)");
+  uint32_t m[NL];
+  Fe<M, 2> r;
+  uint64_t acc = 0;
+#pragma unroll
+  for (int k = 0; k < NL; ++k) {
+#pragma unroll
+    for (int i = 0; i < NL; ++i)
+      if (i <= k) acc += (uint64_t)a.l[i] * b.l[k - i];
+    mont_low_column<M>(acc, m, k);
+  }
+#pragma unroll
+  for (int k = NL; k < 2 * NL - 1; ++k) {
+#pragma unroll
+    for (int i = 0; i < NL; ++i)
+      if (i >= k - (NL - 1)) acc += (uint64_t)a.l[i] * b.l[k - i];
+    mont_high_column<M>(acc, m, k, r.l[k - NL]);
+  }
+  r.l[NL - 1] = (uint32_t)acc;
+  return r;
+}
+
+template <class M, int Ba>
+GS_HD Fe<M, 2> sqr(const Fe<M, Ba>& a) {
+  static_assert(Ba * Ba <= 160, "Montgomery square input bound exceeded");
+  uint32_t m[NL], a2[NL];
+  Fe<M, 2> r;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) a2[i] = a.l[i] << 1;
+  uint64_t acc = 0;
+#pragma unroll
+  for (int k = 0; k < 2 * NL - 1; ++k) {
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const int j = k - i;
+      if (j >= 0 && j < NL && i < j) acc += (uint64_t)a2[i] * a.l[j];
+    }
+    if ((k & 1) == 0) acc += (uint64_t)a.l[k / 2] * a.l[k / 2];
+    if (k < NL) mont_low_column<M>(acc, m, k);
+    else mont_high_column<M>(acc, m, k, r.l[k - NL]);
+  }
+  r.l[NL - 1] = (uint32_t)acc;
+  return r;
+}
+
+// REDC(a*b + c*d): one reduction for a two-term dot product (Fq2 arithmetic).
+template <class M, int Ba, int Bb, int Bc, int Bd>
+GS_HD Fe<M, 2> mul_add(const Fe<M, Ba>& a, const Fe<M, Bb>& b, const Fe<M, Bc>& c, const Fe<M, Bd>& d) {
+  static_assert(Ba * Bb + Bc * Bd <= 160, "dot-product input bound exceeded");
+  uint32_t m[NL];
+  Fe<M, 2> r;
+  uint64_t acc = 0;
+#pragma unroll
+  for (int k = 0; k < 2 * NL - 1; ++k) {
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const int j = k - i;
+      if (j >= 0 && j < NL) {
+        acc += (uint64_t)a.l[i] * b.l[j];
+        acc += (uint64_t)c.l[i] * d.l[j];
+      }
+    }
+    if (k < NL) mont_low_column<M>(acc, m, k);
+    else mont_high_column<M>(acc, m, k, r.l[k - NL]);
+  }
+  r.l[NL - 1] = (uint32_t)acc;
+  return r;
+}
+
+// ---- reductions / comparisons ---------------------------------------------------------------
+// value -> value - floor(top/(p_top+1)) * p : lands in [0, 2p).
+template <class M, int B>
+GS_HD Fe<M, 2> reduce2(const Fe<M, B>& a) {
+  Fe<M, B> x = a;
+  carry_full(x);
+  // q = floor(x_top / (p_top + 1)) <= floor(x / p); x < B p  =>  q <= B-1
+  const uint32_t q = x.l[NL - 1] / (M::kTopLimb + 1u);
+  Fe<M, 2> r;
+  int32_t carry = 0;
+#pragma unroll
+  for (int i = 0; i < NL - 1; ++i) {
+    // x_i < 2^29, q*p_i < 2^35 : 64-bit signed keeps it exact
+    int64_t t = (int64_t)x.l[i] - (int64_t)((uint64_t)q * M::p(i)) + carry;
+    r.l[i] = (uint32_t)t & LMASK;
+    carry = (int32_t)(t >> LB);
+  }
+  r.l[NL - 1] = (uint32_t)((int64_t)x.l[NL - 1] - (int64_t)((uint64_t)q * M::p(NL - 1)) + carry);
+  return r;
+}
+
+// canonical representative in [0, p), fully normalised limbs (boundary / comparisons only)
+template <class M, int B>
+GS_HD Fe<M, 1> canon(const Fe<M, B>& a) {
+  Fe<M, B> x = a;
+  carry_full(x);
+  Fe<M, 1> r;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) r.l[i] = x.l[i];
+  // subtract p while >= p: at most B-1 times (B small at every call site)
+  for (int it = 0; it < B; ++it) {
+    uint32_t t[NL];
+    int32_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < NL - 1; ++i) {
+      int32_t d = (int32_t)r.l[i] - (int32_t)M::p(i) + borrow;
+      t[i] = (uint32_t)d & LMASK;
+      borrow = d >> LB;           // arithmetic shift: 0 or -1
+    }
+    int32_t top = (int32_t)r.l[NL - 1] - (int32_t)M::p(NL - 1) + borrow;
+    t[NL - 1] = (uint32_t)top;
+    const bool ge = top >= 0;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) r.l[i] = ge ? t[i] : r.l[i];
+  }
+  return r;
+}
+
+template <class M, int B>
+GS_HD bool is_zero(const Fe<M, B>& a) {        // value == 0 (mod p), exact
+  Fe<M, B> x = a;
+  carry_full(x);
+  // if x = k p then k = floor(x_top / p_top) exactly (k < p_top)
+  const uint32_t k = x.l[NL - 1] / M::kTopLimb;
+  if ((((uint32_t)(k * M::p(0))) & LMASK) != x.l[0]) return false;     // 2^-29 false-positive filter
+  uint64_t carry = 0;
+  bool eq = true;
+#pragma unroll
+  for (int i = 0; i < NL - 1; ++i) {
+    uint64_t t = (uint64_t)k * M::p(i) + carry;
+    eq = eq && (((uint32_t)t & LMASK) == x.l[i]);
+    carry = t >> LB;
+  }
+  eq = eq && ((uint32_t)((uint64_t)k * M::p(NL - 1) + carry) == x.l[NL - 1]);
+  return eq;
+}
+
+template <class M, int Ba, int Bb>
+GS_HD bool equal(const Fe<M, Ba>& a, const Fe<M, Bb>& b) { return is_zero(sub(a, b)); }
+
+template <class M, int B>
+GS_HD Fe<M, B> select(bool c, const Fe<M, B>& a, const Fe<M, B>& b) {   // c ? a : b
+  Fe<M, B> r;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) r.l[i] = c ? a.l[i] : b.l[i];
+  return r;
+}
+
+// ---- boundary conversions --------------------------------------------------------------------
+// canonical little-endian 8 x u32 (= the C ABI's 4 x u64 limbs)  <->  29-bit limbs
+// (any 256-bit input is accepted: 2^256 < 6p, hence the bound)
+template <class M>
+GS_HD Fe<M, 6> unpack32(const uint32_t (&w)[8]) {
+  Fe<M, 6> r;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    const int bit = LB * i, wi = bit >> 5, sh = bit & 31;
+    uint32_t v = w[wi] >> sh;
+    if (sh > 32 - LB && wi + 1 < 8) v |= w[wi + 1] << (32 - sh);
+    r.l[i] = v & LMASK;
+  }
+  return r;
+}
+
+template <class M>
+GS_HD void pack32(const Fe<M, 1>& a /* canonical, fully normalised */, uint32_t (&w)[8]) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int bit = 32 * j, li = bit / LB, sh = bit % LB;
+    uint32_t v = a.l[li] >> sh;
+    if (li + 1 < NL) v |= a.l[li + 1] << (LB - sh);
+    if (LB - sh + LB < 32 && li + 2 < NL) v |= a.l[li + 2] << (2 * LB - sh);
+    w[j] = v;
+  }
+}
+
+template <class M, int B>
+GS_HD Fe<M, 2> to_mont(const Fe<M, B>& a) {    // a -> a R
+  Fe<M, 1> r2;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) r2.l[i] = M::r2(i);
+  return mul(a, r2);
+}
+
+template <class M, int B>
+GS_HD Fe<M, 1> from_mont(const Fe<M, B>& a) {  // a R -> a, canonical
+  Fe<M, 1> one;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) one.l[i] = (i == 0) ? 1u : 0u;
+  return canon(mul(a, one));
+}
+
+// a^(p-2): Fermat inversion (reference: fq.go:66-67 ModInverse).  0 -> 0.
+template <class M, int B>
+GS_HD Fe<M, 2> inv(const Fe<M, B>& a) {
+  static_assert(B <= 12, "inv input bound");
+  Fe<M, 2> base = mul(a, fe_one<M>());
+  Fe<M, 2> acc = relax<2>(fe_one<M>());
+  // exponent p-2, scanned MSB first from the canonical 32-bit words
+  for (int bit = M::kBits - 1; bit >= 0; --bit) {
+    acc = sqr(acc);
+    uint32_t wv = M::p32(bit >> 5);
+    if ((bit >> 5) == 0) wv -= 2u;             // p is odd and p32(0) >= 2: no borrow
+    if ((wv >> (bit & 31)) & 1u) acc = mul(acc, base);
+  }
+  return acc;
+}
+
+using FqE = Fe<ModQ, 2>;
+using FrE = Fe<ModR, 2>;
+
+}  // namespace gs

@@ -1,0 +1,59 @@
+// Fq2 = Fq[u]/(u^2+1) on top of fp29.h.  Device replacement for the reference's
+// fields/fq2.go:37-133 (`Fq2.Add/Sub/Neg/Mul/Square/Inverse`).  The reference stores the
+// non-residue as q-1 and multiplies by it generically (bn128/bn128.go:86, fq2.go:32-34);
+// here u^2 = -1 is applied as a subtraction, and each coordinate of a product is ONE
+// Montgomery reduction of a two-term dot product (mul_add), i.e. 2 reductions per Fq2 product
+// instead of Karatsuba's 3 products + 5 add/subs.
+#pragma once
+#include "fp29.h"
+
+namespace gs {
+
+template <int B>
+struct Fq2e {
+  Fe<ModQ, B> c0, c1;      // c0 + c1 * u
+};
+
+// single-coordinate alias with the same template shape, so curve code is generic over both
+template <int B>
+using Fq1e = Fe<ModQ, B>;
+
+template <int BN, int B> GS_HD Fq2e<BN> relax(const Fq2e<B>& a) { return {relax<BN>(a.c0), relax<BN>(a.c1)}; }
+template <int Ba, int Bb> GS_HD Fq2e<Ba + Bb> add(const Fq2e<Ba>& a, const Fq2e<Bb>& b) { return {add(a.c0, b.c0), add(a.c1, b.c1)}; }
+template <int Ba, int Bb> GS_HD Fq2e<Ba + Bb + 1> sub(const Fq2e<Ba>& a, const Fq2e<Bb>& b) { return {sub(a.c0, b.c0), sub(a.c1, b.c1)}; }
+template <int B> GS_HD Fq2e<2 * B> dbl(const Fq2e<B>& a) { return {dbl(a.c0), dbl(a.c1)}; }
+template <int B> GS_HD Fq2e<B + 1> neg(const Fq2e<B>& a) { return {neg(a.c0), neg(a.c1)}; }
+template <int B> GS_HD Fq2e<2> reduce2(const Fq2e<B>& a) { return {reduce2(a.c0), reduce2(a.c1)}; }
+template <int B> GS_HD Fq2e<1> canon(const Fq2e<B>& a) { return {canon(a.c0), canon(a.c1)}; }
+template <int B> GS_HD bool is_zero(const Fq2e<B>& a) { return is_zero(a.c0) && is_zero(a.c1); }
+template <int B> GS_HD Fq2e<B> select(bool c, const Fq2e<B>& a, const Fq2e<B>& b) { return {select(c, a.c0, b.c0), select(c, a.c1, b.c1)}; }
+
+// (a0 + a1 u)(b0 + b1 u) = (a0 b0 - a1 b1) + (a0 b1 + a1 b0) u        [fq2.go:63-76]
+template <int Ba, int Bb>
+GS_HD Fq2e<2> mul(const Fq2e<Ba>& a, const Fq2e<Bb>& b) {
+  return {mul_add(a.c0, b.c0, a.c1, neg(b.c1)), mul_add(a.c0, b.c1, a.c1, b.c0)};
+}
+
+// (a0 + a1 u)^2 = (a0 + a1)(a0 - a1) + 2 a0 a1 u                       [fq2.go:118-133]
+template <int B>
+GS_HD Fq2e<2> sqr(const Fq2e<B>& a) {
+  return {mul(add(a.c0, a.c1), sub(a.c0, a.c1)), mul(dbl(a.c0), a.c1)};
+}
+
+// Fq2 element times an Fq scalar-like element (used for norm-based inversion)
+template <int Ba, int Bb>
+GS_HD Fq2e<2> mul_fq(const Fq2e<Ba>& a, const Fe<ModQ, Bb>& k) { return {mul(a.c0, k), mul(a.c1, k)}; }
+
+// 1 / (a0 + a1 u) = (a0 - a1 u) / (a0^2 + a1^2)                        [fq2.go:99-110]
+template <int B>
+GS_HD Fq2e<2> inv(const Fq2e<B>& a) {
+  Fe<ModQ, 2> n = mul_add(a.c0, a.c0, a.c1, a.c1);
+  Fe<ModQ, 2> ni = inv(n);
+  return {mul(a.c0, ni), mul(neg(a.c1), ni)};
+}
+
+template <int B> GS_HD Fq2e<B> fq2_zero() { return {fe_zero<ModQ, B>(), fe_zero<ModQ, B>()}; }
+GS_HD Fq2e<1> fq2_one() { return {fe_one<ModQ>(), fe_zero<ModQ, 1>()}; }
+GS_HD Fq1e<1> fq1_one() { return fe_one<ModQ>(); }
+
+}  // namespace gs

@@ -1,0 +1,87 @@
+"""Field arithmetic (go-snark-study_amd/csrc/fp29.h) instantiated on the HOST vs Python integers
+(= the semantics of the reference's fields/fq.go:32-98).  Same source the kernels compile."""
+import random
+
+import pytest
+
+import hostbuild
+from oracle import ref_py as O
+
+MODS = {"q": O.Q, "r": O.R}
+
+
+@pytest.fixture(scope="module")
+def exe():
+    return hostbuild.build("fp_host_test")
+
+
+def _vals(rng, p, n):
+    edge = [0, 1, 2, p - 1, p - 2, (1 << 253), (1 << 29) - 1, 1 << 29, (1 << 232) - 1, p >> 1]
+    return [rng.choice(edge) if rng.random() < 0.25 else rng.randrange(p) for _ in range(n)]
+
+
+@pytest.mark.parametrize("f", ["q", "r"])
+def test_field_ops_match_python(exe, f):
+    p = MODS[f]
+    rng = random.Random(1234 + ord(f))
+    ops = {
+        "mul": lambda a, b, c, d: a * b % p,
+        "sqr": lambda a, b, c, d: a * a % p,
+        "add": lambda a, b, c, d: (a + b) % p,
+        "sub": lambda a, b, c, d: (a - b) % p,
+        "neg": lambda a, b, c, d: (-a) % p,
+        "dbl": lambda a, b, c, d: 2 * a % p,
+        "muladd": lambda a, b, c, d: (a * b + c * d) % p,
+        "roundtrip": lambda a, b, c, d: a % p,
+        "reduce2": lambda a, b, c, d: (a + b + c) % p,
+        "chain": lambda a, b, c, d: ((2 * (((a + b) - c) * ((a - b) + 2 * d))) ** 2 - a * d) % p,
+        "lazy12": lambda a, b, c, d: ((a + b + c + d + a + c) * (a + b + c + d + d)) % p,
+    }
+    lines, want = [], []
+    for op, fn in ops.items():
+        for _ in range(300):
+            a, b, c, d = _vals(rng, p, 4)
+            lines.append("%s %s %x %x %x %x" % (f, op, a, b, c, d))
+            want.append(fn(a, b, c, d))
+    got = hostbuild.run_lines(exe, lines)
+    for line, g, w in zip(lines, got, want):
+        assert int(g, 16) == w, line
+
+
+@pytest.mark.parametrize("f", ["q", "r"])
+def test_noncanonical_inputs_are_reduced(exe, f):
+    p = MODS[f]
+    rng = random.Random(99)
+    lines, want = [], []
+    for _ in range(200):
+        a, b = rng.randrange(1 << 256), rng.randrange(1 << 256)
+        lines.append("%s mul %x %x 0 0" % (f, a, b))
+        want.append(a * b % p)
+    got = hostbuild.run_lines(exe, lines)
+    assert [int(g, 16) for g in got] == want
+
+
+@pytest.mark.parametrize("f", ["q", "r"])
+def test_inverse_fermat(exe, f):
+    p = MODS[f]
+    rng = random.Random(7)
+    vals = [1, 2, p - 1] + [rng.randrange(1, p) for _ in range(40)]
+    got = hostbuild.run_lines(exe, ["%s inv %x 0 0 0" % (f, a) for a in vals])
+    for a, g in zip(vals, got):
+        assert int(g, 16) == pow(a, -1, p)
+    assert int(hostbuild.run_lines(exe, ["%s inv 0 0 0 0" % f])[0], 16) == 0
+
+
+@pytest.mark.parametrize("f", ["q", "r"])
+def test_is_zero_exact(exe, f):
+    p = MODS[f]
+    rng = random.Random(5)
+    lines, want = [], []
+    for _ in range(300):
+        a = rng.randrange(p)
+        k = rng.random()
+        b = a if k < 0.4 else rng.randrange(p)
+        c = (a + b) % p if rng.random() < 0.5 else rng.randrange(p)
+        lines.append("%s iszero %x %x %x 0" % (f, a, b, c))
+        want.append(("1" if a == b else "0") + ("1" if (a + b - c) % p == 0 else "0"))
+    assert hostbuild.run_lines(exe, lines) == want
