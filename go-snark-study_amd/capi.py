@@ -1,0 +1,294 @@
+"""ctypes binding of include/gosnark_hip.h (the same C ABI a cgo binding would use)."""
+import ctypes
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+_LOCK = threading.Lock()
+_INIT_DEVICE = None
+
+u64p = ctypes.POINTER(ctypes.c_uint64)
+u32p = ctypes.POINTER(ctypes.c_uint32)
+intp = ctypes.POINTER(ctypes.c_int)
+Handle = ctypes.c_uint64
+
+
+class GosnarkHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libgosnark_hip: status %d: %s" % (code, msg))
+        self.code = code
+
+
+class Timing(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_float) for n in
+                ("total_ms", "plan_ms", "accumulate_ms", "reduce_ms", "poly_ms", "h2d_ms")]
+
+
+def lib_path():
+    return os.path.join(_HERE, "libgosnark_hip.so")
+
+
+# name -> (argtypes); every function returns int status unless listed in _NONSTATUS
+_SIGS = {
+    "gs_init": [intp, ctypes.c_int],
+    "gs_free": [Handle],
+    "gs_len": [Handle, ctypes.POINTER(ctypes.c_size_t)],
+    "gs_g1_upload": [u64p, ctypes.c_size_t, ctypes.POINTER(Handle)],
+    "gs_g2_upload": [u64p, ctypes.c_size_t, ctypes.POINTER(Handle)],
+    "gs_g1_download": [Handle, u64p, ctypes.c_size_t],
+    "gs_g2_download": [Handle, u64p, ctypes.c_size_t],
+    "gs_g1_fixed_base": [u64p, ctypes.c_size_t, ctypes.POINTER(Handle)],
+    "gs_g2_fixed_base": [u64p, ctypes.c_size_t, ctypes.POINTER(Handle)],
+    "gs_scalars_upload": [u64p, ctypes.c_size_t, ctypes.POINTER(Handle)],
+    "gs_scalars_download": [Handle, u64p, ctypes.c_size_t],
+    "gs_msm_g1": [Handle, u64p, ctypes.c_size_t, ctypes.c_size_t, u64p, intp],
+    "gs_msm_g2": [Handle, u64p, ctypes.c_size_t, ctypes.c_size_t, u64p, intp],
+    "gs_msm_g1_resident": [Handle, ctypes.c_size_t, Handle, ctypes.c_size_t, ctypes.c_size_t, u64p, intp],
+    "gs_msm_g2_resident": [Handle, ctypes.c_size_t, Handle, ctypes.c_size_t, ctypes.c_size_t, u64p, intp],
+    "gs_g1_sum_affine": [u64p, intp, ctypes.c_size_t, u64p, intp],
+    "gs_g2_sum_affine": [u64p, intp, ctypes.c_size_t, u64p, intp],
+    "gs_poly_mul": [u64p, ctypes.c_size_t, u64p, ctypes.c_size_t, u64p],
+    "gs_poly_div": [u64p, ctypes.c_size_t, u64p, ctypes.c_size_t, u64p, u64p],
+    "gs_poly_add": [u64p, ctypes.c_size_t, u64p, ctypes.c_size_t, u64p],
+    "gs_poly_sub": [u64p, ctypes.c_size_t, u64p, ctypes.c_size_t, u64p],
+    "gs_poly_eval": [u64p, ctypes.c_size_t, u64p, u64p],
+    "gs_lagrange_interpolation": [u64p, ctypes.c_size_t, u64p],
+    "gs_zpoly": [ctypes.c_size_t, u64p],
+    "gs_r1cs_to_px": [ctypes.c_size_t, ctypes.c_size_t, u32p, u32p, u64p, u32p, u32p, u64p, u32p, u32p, u64p,
+                      u64p, u64p, u64p, u64p, u64p],
+    "gs_groth16_pk_create": [Handle, Handle, Handle, Handle, Handle, u64p, u64p, u64p, u64p, u64p,
+                             u64p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, ctypes.POINTER(Handle)],
+    "gs_groth16_prove": [Handle, u64p, ctypes.c_size_t, u64p, ctypes.c_size_t, u64p, u64p, u64p, intp],
+    "gs_groth16_prove_resident": [Handle, Handle, Handle, u64p, u64p, u64p, intp],
+    "gs_pinocchio_pk_create": [Handle, Handle, Handle, Handle, Handle, Handle, Handle, Handle, u64p,
+                               ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, ctypes.POINTER(Handle)],
+    "gs_pinocchio_prove": [Handle, u64p, ctypes.c_size_t, u64p, ctypes.c_size_t, u64p, intp],
+    "gs_last_timing": [ctypes.POINTER(Timing)],
+    "gs_set_window_bits": [ctypes.c_int],
+}
+EXPORTS = sorted(list(_SIGS) + ["gs_shutdown", "gs_last_error", "gs_version"])
+
+
+def load_library():
+    """dlopen libgosnark_hip.so (built by `make -C go-snark-study_amd/csrc` / __graft_entry__.build()).
+    Fails loudly when it is missing: there is no other implementation to fall back to."""
+    global _LIB
+    with _LOCK:
+        if _LIB is not None:
+            return _LIB
+        path = lib_path()
+        if not os.path.exists(path):
+            raise GosnarkHipError(-1, "%s not found: build it with __graft_entry__.build() "
+                                  "(hipcc --offload-arch=gfx950); there is no CPU fallback" % path)
+        lib = ctypes.CDLL(path)
+        missing = [n for n in EXPORTS if not hasattr(lib, n)]
+        if missing:
+            raise GosnarkHipError(-1, "%s lacks symbols declared in include/gosnark_hip.h: %s" % (path, missing))
+        for name, args in _SIGS.items():
+            fn = getattr(lib, name)
+            fn.argtypes = args
+            fn.restype = ctypes.c_int
+        lib.gs_last_error.restype = ctypes.c_char_p
+        lib.gs_version.restype = ctypes.c_char_p
+        lib.gs_shutdown.restype = None
+        _LIB = lib
+        return lib
+
+
+def check(status):
+    if status != 0:
+        raise GosnarkHipError(status, load_library().gs_last_error().decode("utf-8", "replace"))
+
+
+def init(device=None):
+    """gs_init on `device` (default: LOCAL_RANK or 0).  One process drives one GPU."""
+    global _INIT_DEVICE
+    lib = load_library()
+    if device is None:
+        device = int(os.environ.get("LOCAL_RANK", "0"))
+    if _INIT_DEVICE == device:
+        return
+    arr = (ctypes.c_int * 1)(device)
+    check(lib.gs_init(arr, 1))
+    _INIT_DEVICE = device
+
+
+def version():
+    return load_library().gs_version().decode()
+
+
+# ---- integer <-> limb array helpers -------------------------------------------------------------
+def ints_to_u64(vals, words=4):
+    """list of non-negative Python ints -> np.uint64 array [len, words] (little-endian limbs)."""
+    nbytes = 8 * words
+    buf = b"".join(int(v).to_bytes(nbytes, "little") for v in vals)
+    return np.frombuffer(buf, dtype="<u8").reshape(len(vals), words).copy()
+
+
+def u64_to_ints(arr, words=4):
+    a = np.ascontiguousarray(arr, dtype="<u8").reshape(-1, words)
+    raw = a.tobytes()
+    nbytes = 8 * words
+    return [int.from_bytes(raw[i * nbytes:(i + 1) * nbytes], "little") for i in range(a.shape[0])]
+
+
+def ptr64(a):
+    if a is None:
+        return None
+    assert a.dtype == np.uint64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(u64p)
+
+
+def ptr32(a):
+    assert a.dtype == np.uint32 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(u32p)
+
+
+def g1_points_to_u64(points):
+    """[(X, Y, Z), ...] Jacobian ints -> [n, 12] uint64"""
+    flat = [c for p in points for c in p]
+    return ints_to_u64(flat).reshape(len(points), 12)
+
+
+def g2_points_to_u64(points):
+    """[((X0,X1),(Y0,Y1),(Z0,Z1)), ...] -> [n, 24] uint64"""
+    flat = [c for p in points for xy in p for c in xy]
+    return ints_to_u64(flat).reshape(len(points), 24)
+
+
+class DeviceHandle:
+    """RAII wrapper of a gs_handle."""
+
+    def __init__(self, h):
+        self.h = int(h)
+
+    def free(self):
+        if self.h:
+            lib = load_library()
+            lib.gs_free(Handle(self.h))
+            self.h = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    def __len__(self):
+        n = ctypes.c_size_t(0)
+        check(load_library().gs_len(Handle(self.h), ctypes.byref(n)))
+        return n.value
+
+
+def _upload(fname, arr, n):
+    init()
+    h = Handle(0)
+    check(getattr(load_library(), fname)(ptr64(arr), n, ctypes.byref(h)))
+    return DeviceHandle(h.value)
+
+
+def g1_upload(points_u64):
+    a = np.ascontiguousarray(points_u64, dtype=np.uint64).reshape(-1, 12)
+    return _upload("gs_g1_upload", a, a.shape[0])
+
+
+def g2_upload(points_u64):
+    a = np.ascontiguousarray(points_u64, dtype=np.uint64).reshape(-1, 24)
+    return _upload("gs_g2_upload", a, a.shape[0])
+
+
+def scalars_upload(s_u64):
+    a = np.ascontiguousarray(s_u64, dtype=np.uint64).reshape(-1, 4)
+    return _upload("gs_scalars_upload", a, a.shape[0])
+
+
+def g1_fixed_base(s_u64):
+    a = np.ascontiguousarray(s_u64, dtype=np.uint64).reshape(-1, 4)
+    return _upload("gs_g1_fixed_base", a, a.shape[0])
+
+
+def g2_fixed_base(s_u64):
+    a = np.ascontiguousarray(s_u64, dtype=np.uint64).reshape(-1, 4)
+    return _upload("gs_g2_fixed_base", a, a.shape[0])
+
+
+def g1_download(handle):
+    n = len(handle)
+    out = np.zeros((n, 12), dtype=np.uint64)
+    check(load_library().gs_g1_download(Handle(handle.h), ptr64(out), n))
+    return out
+
+
+def g2_download(handle):
+    n = len(handle)
+    out = np.zeros((n, 24), dtype=np.uint64)
+    check(load_library().gs_g2_download(Handle(handle.h), ptr64(out), n))
+    return out
+
+
+def scalars_download(handle):
+    n = len(handle)
+    out = np.zeros((n, 4), dtype=np.uint64)
+    check(load_library().gs_scalars_download(Handle(handle.h), ptr64(out), n))
+    return out
+
+
+def _affine_result(out, inf, g2):
+    if inf.value:
+        return None
+    v = u64_to_ints(out)
+    return ((v[0], v[1]), (v[2], v[3])) if g2 else (v[0], v[1])
+
+
+def msm(bases, scalars_u64, off=0, g2=False):
+    """sum_i scalars[i] * bases[off+i] -> affine (x, y) / ((x0,x1),(y0,y1)) ints, None = infinity."""
+    s = np.ascontiguousarray(scalars_u64, dtype=np.uint64).reshape(-1, 4)
+    out = np.zeros(16 if g2 else 8, dtype=np.uint64)
+    inf = ctypes.c_int(0)
+    fn = load_library().gs_msm_g2 if g2 else load_library().gs_msm_g1
+    check(fn(Handle(bases.h), ptr64(s), off, s.shape[0], ptr64(out), ctypes.byref(inf)))
+    return _affine_result(out, inf, g2)
+
+
+def msm_resident(bases, scalars, n, off=0, soff=0, g2=False):
+    out = np.zeros(16 if g2 else 8, dtype=np.uint64)
+    inf = ctypes.c_int(0)
+    fn = load_library().gs_msm_g2_resident if g2 else load_library().gs_msm_g1_resident
+    check(fn(Handle(bases.h), off, Handle(scalars.h), soff, n, ptr64(out), ctypes.byref(inf)))
+    return _affine_result(out, inf, g2)
+
+
+def sum_affine(points, g2=False):
+    """points: list of affine tuples or None (infinity) -> affine sum."""
+    n = len(points)
+    words = 4 if g2 else 2
+    flat, infs = [], []
+    for p in points:
+        if p is None:
+            flat += [0] * words
+            infs.append(1)
+        else:
+            flat += ([p[0][0], p[0][1], p[1][0], p[1][1]] if g2 else [p[0], p[1]])
+            infs.append(0)
+    arr = ints_to_u64(flat).reshape(n, 4 * words) if n else np.zeros((0, 4 * words), dtype=np.uint64)
+    ia = (ctypes.c_int * max(n, 1))(*infs)
+    out = np.zeros(16 if g2 else 8, dtype=np.uint64)
+    inf = ctypes.c_int(0)
+    fn = load_library().gs_g2_sum_affine if g2 else load_library().gs_g1_sum_affine
+    init()
+    check(fn(ptr64(arr), ia, n, ptr64(out), ctypes.byref(inf)))
+    return _affine_result(out, inf, g2)
+
+
+def last_timing():
+    t = Timing()
+    check(load_library().gs_last_timing(ctypes.byref(t)))
+    return {n: getattr(t, n) for n, _ in Timing._fields_}
+
+
+def set_window_bits(c):
+    init()
+    check(load_library().gs_set_window_bits(int(c)))

@@ -1,0 +1,281 @@
+// extern "C" surface of libgosnark_hip.so (declared in include/gosnark_hip.h).
+#include <algorithm>
+#include <vector>
+
+#include "msm.h"
+#include "point_io.h"
+#include "runtime.h"
+
+using namespace gs;
+
+namespace {
+
+
+template <class T>
+int upload_bases(Ctx& c, Kind kind, const uint64_t* jac, size_t n, gs_handle* out) {
+  if (!out || (n && !jac)) return fail(GS_ERR_ARG, "null argument");
+  if (n >= (1ull << 31)) return fail(GS_ERR_ARG, "too many points");
+  constexpr size_t cw = T::kWords;
+  auto b = std::make_unique<Bases>(kind);
+  b->n = n;
+  b->buf.alloc(std::max<size_t>(n, 1) * 2 * cw * 4);
+  if (n) {
+    DevBuf tmp(n * 3 * cw * 4);
+    GS_HIP(hipMemcpyAsync(tmp.p, jac, n * 3 * cw * 4, hipMemcpyHostToDevice, c.stream));
+    if (kind == Kind::G1Bases) jacobian_to_affine_g1(c, tmp.as<uint32_t>(), (uint32_t)n, b->buf.as<uint32_t>());
+    else jacobian_to_affine_g2(c, tmp.as<uint32_t>(), (uint32_t)n, b->buf.as<uint32_t>());
+    GS_HIP(hipStreamSynchronize(c.stream));
+  }
+  *out = c.put(std::move(b));
+  return GS_OK;
+}
+
+template <class T>
+int download_bases(Ctx& c, Kind kind, gs_handle h, uint64_t* jac, size_t n) {
+  Bases* b = c.get<Bases>(h, kind);
+  if (!b) return fail(GS_ERR_ARG, "bad base handle");
+  if (n != b->n || (n && !jac)) return fail(GS_ERR_ARG, "size mismatch");
+  if (!n) return GS_OK;
+  constexpr size_t cw = T::kWords;
+  DevBuf tmp(n * 3 * cw * 4);
+  if (kind == Kind::G1Bases) affine_to_jacobian_std_g1(c, b->buf.as<uint32_t>(), (uint32_t)n, tmp.as<uint32_t>());
+  else affine_to_jacobian_std_g2(c, b->buf.as<uint32_t>(), (uint32_t)n, tmp.as<uint32_t>());
+  GS_HIP(hipMemcpyAsync(jac, tmp.p, n * 3 * cw * 4, hipMemcpyDeviceToHost, c.stream));
+  GS_HIP(hipStreamSynchronize(c.stream));
+  return GS_OK;
+}
+
+template <class T>
+int fixed_base_api(Ctx& c, Kind kind, const uint64_t* scalars, size_t n, gs_handle* out) {
+  if (!out || (n && !scalars)) return fail(GS_ERR_ARG, "null argument");
+  if (n >= (1ull << 31)) return fail(GS_ERR_ARG, "too many scalars");
+  constexpr size_t cw = T::kWords;
+  auto b = std::make_unique<Bases>(kind);
+  b->n = n;
+  b->buf.alloc(std::max<size_t>(n, 1) * 2 * cw * 4);
+  if (n) {
+    DevBuf tmp(n * 32);
+    GS_HIP(hipMemcpyAsync(tmp.p, scalars, n * 32, hipMemcpyHostToDevice, c.stream));
+    if (kind == Kind::G1Bases) fixed_base_g1(c, tmp.as<uint32_t>(), (uint32_t)n, b->buf.as<uint32_t>());
+    else fixed_base_g2(c, tmp.as<uint32_t>(), (uint32_t)n, b->buf.as<uint32_t>());
+    GS_HIP(hipStreamSynchronize(c.stream));
+  }
+  *out = c.put(std::move(b));
+  return GS_OK;
+}
+
+// one MSM over resident scalars
+template <class T>
+int msm_resident(Ctx& c, Kind kind, gs_handle hb, size_t off, const uint32_t* scalars_dev, size_t n,
+                 uint64_t* out_affine, int* is_inf) {
+  Bases* b = c.get<Bases>(hb, kind);
+  if (!b) return fail(GS_ERR_ARG, "bad base handle");
+  if (!out_affine || !is_inf) return fail(GS_ERR_ARG, "null output");
+  if (off > b->n || n > b->n - off) return fail(GS_ERR_ARG, "term range [%zu, %zu) exceeds the %zu resident points", off, off + n, b->n);
+  constexpr size_t aw = 2 * T::kWords;
+  PhaseTimer total(c.stream);
+  MsmPlan plan;
+  {
+    PhaseTimer tp(c.stream);
+    build_plan(c, 0, scalars_dev, (uint32_t)n, plan);
+    tp.stop();
+    c.timing.plan_ms += tp.ms();
+  }
+  std::vector<const uint32_t*> bases{b->buf.as<uint32_t>() + off * aw};
+  bool inf;
+  if constexpr (T::kWords == 8) {
+    std::vector<G1Xyzz> r;
+    msm_run_g1(c, plan, bases, r);
+    inf = g1_to_affine_std(r[0], out_affine);
+  } else {
+    std::vector<G2Xyzz> r;
+    msm_run_g2(c, plan, bases, r);
+    inf = g2_to_affine_std(r[0], out_affine);
+  }
+  *is_inf = inf ? 1 : 0;
+  total.stop();
+  c.timing.total_ms += total.ms();
+  return GS_OK;
+}
+
+template <class T>
+int msm_host_scalars(Ctx& c, Kind kind, gs_handle hb, const uint64_t* scalars, size_t off, size_t n,
+                     uint64_t* out_affine, int* is_inf) {
+  if (n && !scalars) return fail(GS_ERR_ARG, "null scalars");
+  if (n >= (1ull << 31)) return fail(GS_ERR_ARG, "too many terms");
+  reset_timing(c);
+  c.ws_misc.ensure(std::max<size_t>(n, 1) * 32);
+  if (n) {
+    PhaseTimer th(c.stream);
+    GS_HIP(hipMemcpyAsync(c.ws_misc.p, scalars, n * 32, hipMemcpyHostToDevice, c.stream));
+    th.stop();
+    c.timing.h2d_ms += th.ms();
+  }
+  return msm_resident<T>(c, kind, hb, off, c.ws_misc.as<uint32_t>(), n, out_affine, is_inf);
+}
+
+template <class T>
+int sum_affine(const uint64_t* pts, const int* inf, size_t n, uint64_t* out, int* is_inf) {
+  if ((n && (!pts || !inf)) || !out || !is_inf) return fail(GS_ERR_ARG, "null argument");
+  constexpr int cw = T::kWords;     // u32 words per coordinate = u64 words per point half... (2*cw u32 per point)
+  Xyzz<T> acc = xyzz_inf<T>();
+  for (size_t i = 0; i < n; ++i) {
+    if (inf[i]) continue;
+    const uint32_t* p = reinterpret_cast<const uint32_t*>(pts) + i * 2 * cw;
+    Affine<T> a;
+    a.x = canon(PointIO<T>::load_std(p));
+    a.y = canon(PointIO<T>::load_std(p + cw));
+    xyzz_madd(acc, a, false);
+  }
+  bool r;
+  if constexpr (T::kWords == 8) r = g1_to_affine_std(acc, out); else r = g2_to_affine_std(acc, out);
+  *is_inf = r ? 1 : 0;
+  return GS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* gs_version(void) { return "gosnark-hip 0.1 gfx950 (9x29-bit Montgomery, XYZZ Pippenger)"; }
+const char* gs_last_error(void) { return last_error_ref().c_str(); }
+
+int gs_init(const int* devices, int ndev) {
+  return guarded([&](Ctx& c) -> int {
+    if (ndev != 1 || !devices) return fail(GS_ERR_ARG, "gs_init: exactly one device per process (got ndev=%d)", ndev);
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0)
+      return fail(GS_ERR_NO_DEVICE, "no HIP device visible (%s); libgosnark_hip has no CPU path", e == hipSuccess ? "count=0" : hipGetErrorString(e));
+    if (devices[0] < 0 || devices[0] >= count) return fail(GS_ERR_ARG, "device %d out of range (0..%d)", devices[0], count - 1);
+    hipDeviceProp_t prop;
+    GS_HIP(hipGetDeviceProperties(&prop, devices[0]));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+      return fail(GS_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 (MI355X) only", devices[0], prop.gcnArchName);
+    GS_HIP(hipSetDevice(devices[0]));
+    if (c.ready && c.device != devices[0]) return fail(GS_ERR_ARG, "already initialised on device %d", c.device);
+    if (!c.ready) {
+      GS_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+      c.device = devices[0];
+      c.ready = true;
+    }
+    return GS_OK;
+  }, false);
+}
+
+void gs_shutdown(void) {
+  Ctx& c = ctx();
+  std::lock_guard<std::mutex> lk(c.mu);
+  if (!c.ready) return;
+  (void)hipStreamSynchronize(c.stream);
+  c.objs.clear();
+  c.ready = false;
+}
+
+int gs_free(gs_handle h) {
+  return guarded([&](Ctx& c) -> int {
+    if (!c.objs.erase(h)) return fail(GS_ERR_ARG, "gs_free: unknown handle %llu", (unsigned long long)h);
+    return GS_OK;
+  });
+}
+
+int gs_len(gs_handle h, size_t* out) {
+  return guarded([&](Ctx& c) -> int {
+    auto it = c.objs.find(h);
+    if (it == c.objs.end() || !out) return fail(GS_ERR_ARG, "gs_len: bad handle");
+    switch (it->second->kind) {
+      case Kind::G1Bases: case Kind::G2Bases: *out = static_cast<Bases*>(it->second.get())->n; return GS_OK;
+      case Kind::Scalars: *out = static_cast<Scalars*>(it->second.get())->n; return GS_OK;
+      default: return fail(GS_ERR_ARG, "gs_len: handle has no length");
+    }
+  });
+}
+
+int gs_g1_upload(const uint64_t* jac, size_t n, gs_handle* out) {
+  return guarded([&](Ctx& c) { return upload_bases<FqTag>(c, Kind::G1Bases, jac, n, out); });
+}
+int gs_g2_upload(const uint64_t* jac, size_t n, gs_handle* out) {
+  return guarded([&](Ctx& c) { return upload_bases<Fq2Tag>(c, Kind::G2Bases, jac, n, out); });
+}
+int gs_g1_download(gs_handle h, uint64_t* jac, size_t n) {
+  return guarded([&](Ctx& c) { return download_bases<FqTag>(c, Kind::G1Bases, h, jac, n); });
+}
+int gs_g2_download(gs_handle h, uint64_t* jac, size_t n) {
+  return guarded([&](Ctx& c) { return download_bases<Fq2Tag>(c, Kind::G2Bases, h, jac, n); });
+}
+int gs_g1_fixed_base(const uint64_t* s, size_t n, gs_handle* out) {
+  return guarded([&](Ctx& c) { return fixed_base_api<FqTag>(c, Kind::G1Bases, s, n, out); });
+}
+int gs_g2_fixed_base(const uint64_t* s, size_t n, gs_handle* out) {
+  return guarded([&](Ctx& c) { return fixed_base_api<Fq2Tag>(c, Kind::G2Bases, s, n, out); });
+}
+
+int gs_scalars_upload(const uint64_t* s, size_t n, gs_handle* out) {
+  return guarded([&](Ctx& c) -> int {
+    if (!out || (n && !s)) return fail(GS_ERR_ARG, "null argument");
+    if (n >= (1ull << 31)) return fail(GS_ERR_ARG, "too many scalars");
+    auto o = std::make_unique<Scalars>();
+    o->n = n;
+    o->buf.alloc(std::max<size_t>(n, 1) * 32);
+    if (n) GS_HIP(hipMemcpy(o->buf.p, s, n * 32, hipMemcpyHostToDevice));
+    *out = c.put(std::move(o));
+    return GS_OK;
+  });
+}
+int gs_scalars_download(gs_handle h, uint64_t* out, size_t n) {
+  return guarded([&](Ctx& c) -> int {
+    Scalars* s = c.get<Scalars>(h, Kind::Scalars);
+    if (!s || n != s->n || (n && !out)) return fail(GS_ERR_ARG, "gs_scalars_download: bad handle or size");
+    GS_HIP(hipStreamSynchronize(c.stream));
+    if (n) GS_HIP(hipMemcpy(out, s->buf.p, n * 32, hipMemcpyDeviceToHost));
+    return GS_OK;
+  });
+}
+
+int gs_msm_g1(gs_handle bases, const uint64_t* scalars, size_t off, size_t n, uint64_t out_affine[8], int* is_inf) {
+  return guarded([&](Ctx& c) { return msm_host_scalars<FqTag>(c, Kind::G1Bases, bases, scalars, off, n, out_affine, is_inf); });
+}
+int gs_msm_g2(gs_handle bases, const uint64_t* scalars, size_t off, size_t n, uint64_t out_affine[16], int* is_inf) {
+  return guarded([&](Ctx& c) { return msm_host_scalars<Fq2Tag>(c, Kind::G2Bases, bases, scalars, off, n, out_affine, is_inf); });
+}
+int gs_msm_g1_resident(gs_handle bases, size_t off, gs_handle scalars, size_t soff, size_t n, uint64_t out_affine[8], int* is_inf) {
+  return guarded([&](Ctx& c) -> int {
+    Scalars* s = c.get<Scalars>(scalars, Kind::Scalars);
+    if (!s || soff > s->n || n > s->n - soff) return fail(GS_ERR_ARG, "bad scalar handle or range");
+    reset_timing(c);
+    return msm_resident<FqTag>(c, Kind::G1Bases, bases, off, s->buf.as<uint32_t>() + soff * 8, n, out_affine, is_inf);
+  });
+}
+int gs_msm_g2_resident(gs_handle bases, size_t off, gs_handle scalars, size_t soff, size_t n, uint64_t out_affine[16], int* is_inf) {
+  return guarded([&](Ctx& c) -> int {
+    Scalars* s = c.get<Scalars>(scalars, Kind::Scalars);
+    if (!s || soff > s->n || n > s->n - soff) return fail(GS_ERR_ARG, "bad scalar handle or range");
+    reset_timing(c);
+    return msm_resident<Fq2Tag>(c, Kind::G2Bases, bases, off, s->buf.as<uint32_t>() + soff * 8, n, out_affine, is_inf);
+  });
+}
+
+int gs_g1_sum_affine(const uint64_t* pts, const int* inf, size_t n, uint64_t out[8], int* is_inf) {
+  return guarded([&](Ctx&) { return sum_affine<FqTag>(pts, inf, n, out, is_inf); });
+}
+int gs_g2_sum_affine(const uint64_t* pts, const int* inf, size_t n, uint64_t out[16], int* is_inf) {
+  return guarded([&](Ctx&) { return sum_affine<Fq2Tag>(pts, inf, n, out, is_inf); });
+}
+
+int gs_last_timing(gs_timing* out) {
+  return guarded([&](Ctx& c) -> int {
+    if (!out) return fail(GS_ERR_ARG, "null");
+    *out = c.timing;
+    return GS_OK;
+  });
+}
+
+int gs_set_window_bits(int cbits) {
+  return guarded([&](Ctx& c) -> int {
+    if (cbits != 0 && (cbits < 2 || cbits > 20)) return fail(GS_ERR_ARG, "window bits must be 0 (auto) or 2..20");
+    c.window_bits = cbits;
+    return GS_OK;
+  });
+}
+
+}  // extern "C"

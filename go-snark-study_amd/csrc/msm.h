@@ -1,0 +1,53 @@
+// Internal C++ interface of the MSM engine (implemented in msm.hip).
+#pragma once
+#include <vector>
+
+#include "ec.h"
+#include "runtime.h"
+
+namespace gs {
+
+struct PlanBuffers {             // grow-only device workspaces owned by a plan slot
+  DevBuf hist, offsets, cursor, entries, tiles, total;
+};
+
+struct MsmPlan {                 // digits of one scalar vector, bucket-sorted (device resident)
+  uint32_t n = 0;
+  int c = 0, W = 0, L = 0;
+  uint32_t B = 0;                // buckets per window
+  uint32_t nbuckets = 0;         // W * B
+  const uint32_t* offsets = nullptr;   // nbuckets + 1
+  const uint32_t* entries = nullptr;
+};
+
+int choose_window_bits(uint32_t n, int forced);
+
+// scalars_dev: n x 8 u32 words (standard form, any 256-bit value).  slot: 0/1 (two plans may be alive)
+void build_plan(Ctx& c, int slot, const uint32_t* scalars_dev, uint32_t n, MsmPlan& plan);
+
+// One launch sequence for up to 8 base arrays sharing a plan.  bases[i] points at the packed affine
+// point of term 0.  Results: XYZZ (Montgomery) on the host, after the serial Horner combination.
+void msm_run_g1(Ctx& c, const MsmPlan& plan, const std::vector<const uint32_t*>& bases, std::vector<G1Xyzz>& out);
+void msm_run_g2(Ctx& c, const MsmPlan& plan, const std::vector<const uint32_t*>& bases, std::vector<G2Xyzz>& out);
+
+// base-array helpers (device)
+void jacobian_to_affine_g1(Ctx& c, const uint32_t* jac_dev, uint32_t n, uint32_t* out_dev);
+void jacobian_to_affine_g2(Ctx& c, const uint32_t* jac_dev, uint32_t n, uint32_t* out_dev);
+void affine_to_jacobian_std_g1(Ctx& c, const uint32_t* aff_dev, uint32_t n, uint32_t* out_dev);
+void affine_to_jacobian_std_g2(Ctx& c, const uint32_t* aff_dev, uint32_t n, uint32_t* out_dev);
+void fixed_base_g1(Ctx& c, const uint32_t* scalars_dev, uint32_t n, uint32_t* out_dev);
+void fixed_base_g2(Ctx& c, const uint32_t* scalars_dev, uint32_t n, uint32_t* out_dev);
+
+// ---- host-side serial helpers (same __host__ __device__ arithmetic as the kernels) ----------------
+// standard-form words <-> Montgomery host values
+G1Affine g1_affine_from_jacobian_std(const uint64_t jac[12]);
+G2Affine g2_affine_from_jacobian_std(const uint64_t jac[24]);
+// XYZZ -> affine standard words ([x,y] = 8 words / [x0,x1,y0,y1] = 16 words); returns is_inf
+bool g1_to_affine_std(const G1Xyzz& p, uint64_t out[8]);
+bool g2_to_affine_std(const G2Xyzz& p, uint64_t out[16]);
+// k * P with a 256-bit scalar in ABI words (reduced mod r first)
+G1Xyzz g1_mul_scalar(const G1Xyzz& p, const uint64_t k[4]);
+G2Xyzz g2_mul_scalar(const G2Xyzz& p, const uint64_t k[4]);
+void fr_canon_words(const uint64_t k[4], uint32_t out[8]);
+
+}  // namespace gs

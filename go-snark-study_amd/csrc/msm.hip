@@ -1,0 +1,190 @@
+// MSM engine: host orchestration of the kernels in msm_kernels.h + the O(1) serial combination.
+#include "msm.h"
+
+#include <algorithm>
+
+#include "msm_kernels.h"
+
+namespace gs {
+
+static_assert(sizeof(G1Xyzz) == PointIO<FqTag>::kXyzzWords * 4, "G1 XYZZ must be raw limbs");
+static_assert(sizeof(G2Xyzz) == PointIO<Fq2Tag>::kXyzzWords * 4, "G2 XYZZ must be raw limbs");
+
+static inline dim3 grid1(size_t n, int block = 256) { return dim3((unsigned)((n + block - 1) / block)); }
+
+int choose_window_bits(uint32_t n, int forced) {
+  if (forced >= 2 && forced <= 20) return forced;
+  int lg = 0;
+  while ((1u << (lg + 1)) <= n) ++lg;                 // floor(log2 n), n >= 1
+  int c = lg - 3;
+  return std::max(3, std::min(16, c));
+}
+
+static void exclusive_scan(Ctx& c, PlanBuffers& pb, const uint32_t* in, uint32_t* out, uint32_t n) {
+  const uint32_t ntiles = (n + kScanTile - 1) / kScanTile;
+  pb.tiles.ensure((size_t)ntiles * 4);
+  pb.total.ensure(4);
+  hipLaunchKernelGGL(k_scan_tiles, dim3(ntiles), dim3(kScanBlock), 0, c.stream, in, out, pb.tiles.as<uint32_t>(), n);
+  hipLaunchKernelGGL(k_scan_tile_sums, dim3(1), dim3(1024), 0, c.stream, pb.tiles.as<uint32_t>(), ntiles, pb.total.as<uint32_t>());
+  hipLaunchKernelGGL(k_scan_add, dim3(ntiles), dim3(kScanBlock), 0, c.stream, out, pb.tiles.as<uint32_t>(), n);
+}
+
+static PlanBuffers g_plan_slots[2];
+
+void build_plan(Ctx& c, int slot, const uint32_t* scalars_dev, uint32_t n, MsmPlan& plan) {
+  PlanBuffers& pb = g_plan_slots[slot & 1];
+  plan.n = n;
+  plan.c = choose_window_bits(n, c.window_bits);
+  plan.W = 254 / plan.c + 1;
+  plan.B = 1u << (plan.c - 1);
+  plan.L = (int)std::min<uint32_t>(8u, plan.B);
+  plan.nbuckets = (uint32_t)plan.W * plan.B;
+  const size_t ncount = (size_t)plan.nbuckets + 1;
+  pb.hist.ensure(ncount * 4);
+  pb.offsets.ensure(ncount * 4);
+  pb.cursor.ensure(ncount * 4);
+  pb.entries.ensure((size_t)n * plan.W * 4 + 16);
+  PlanParams pp{n, plan.c, plan.W, plan.B};
+  GS_HIP(hipMemsetAsync(pb.hist.p, 0, ncount * 4, c.stream));
+  if (n > 0) hipLaunchKernelGGL(k_digit_count, grid1(n), dim3(256), 0, c.stream, scalars_dev, pp, pb.hist.as<uint32_t>());
+  exclusive_scan(c, pb, pb.hist.as<uint32_t>(), pb.offsets.as<uint32_t>(), (uint32_t)ncount);
+  GS_HIP(hipMemcpyAsync(pb.cursor.p, pb.offsets.p, ncount * 4, hipMemcpyDeviceToDevice, c.stream));
+  if (n > 0) hipLaunchKernelGGL(k_digit_scatter, grid1(n), dim3(256), 0, c.stream, scalars_dev, pp, pb.cursor.as<uint32_t>(), pb.entries.as<uint32_t>());
+  GS_HIP(hipGetLastError());
+  plan.offsets = pb.offsets.as<uint32_t>();
+  plan.entries = pb.entries.as<uint32_t>();
+}
+
+// sum_w 2^(c w) S_w on the host core
+template <class T>
+static Xyzz<T> horner_host(const Xyzz<T>* sums, int W, int cbits) {
+  Xyzz<T> acc = sums[W - 1];
+  for (int w = W - 2; w >= 0; --w) {
+    for (int k = 0; k < cbits; ++k) xyzz_dbl(acc);
+    xyzz_add(acc, sums[w]);
+  }
+  return acc;
+}
+
+template <class T>
+static void msm_run(Ctx& c, const MsmPlan& plan, const std::vector<const uint32_t*>& bases, std::vector<Xyzz<T>>& out, int ws_base) {
+  const int njobs = (int)bases.size();
+  out.assign(njobs, xyzz_inf<T>());
+  if (njobs == 0 || plan.n == 0) return;
+  if (njobs > kMaxJobs) throw HipError{hipErrorInvalidValue, "too many MSM jobs", __LINE__};
+  constexpr size_t pw = PointIO<T>::kXyzzWords;
+  const uint32_t chunks_per_window = plan.B / (uint32_t)plan.L;
+  const uint32_t nchunks = chunks_per_window * (uint32_t)plan.W;
+  AccJobs jobs{};
+  for (int j = 0; j < njobs; ++j) {
+    DevBuf& bk = c.ws_buckets[(ws_base + j) % 8];
+    DevBuf& ch = c.ws_chunks[(ws_base + j) % 8];
+    bk.ensure((size_t)plan.nbuckets * pw * 4);
+    ch.ensure((size_t)nchunks * pw * 4);
+    jobs.j[j] = AccJob{bases[j], bk.as<uint32_t>(), ch.as<uint32_t>()};
+  }
+  PhaseTimer tacc(c.stream);
+  hipLaunchKernelGGL(k_bucket_accumulate<T>, dim3((plan.nbuckets + 255) / 256, njobs), dim3(256), 0, c.stream,
+                     jobs, plan.offsets, plan.entries, plan.nbuckets);
+  tacc.stop();
+  PhaseTimer tred(c.stream);
+  hipLaunchKernelGGL(k_bucket_reduce<T>, dim3((nchunks + 255) / 256, njobs), dim3(256), 0, c.stream,
+                     jobs, plan.B, plan.L, nchunks);
+  for (uint32_t half = chunks_per_window / 2; half >= 1; half /= 2) {
+    const uint32_t work = (uint32_t)plan.W * half;
+    hipLaunchKernelGGL(k_fold<T>, dim3((work + 255) / 256, njobs), dim3(256), 0, c.stream,
+                       jobs, (uint32_t)plan.W, chunks_per_window, half);
+  }
+  c.ws_winsums.ensure((size_t)njobs * plan.W * pw * 4);
+  hipLaunchKernelGGL(k_gather_window_sums<T>, dim3(plan.W, njobs), dim3(64), 0, c.stream,
+                     jobs, chunks_per_window, plan.W, c.ws_winsums.as<uint32_t>());
+  GS_HIP(hipGetLastError());
+  std::vector<Xyzz<T>> sums((size_t)njobs * plan.W);
+  GS_HIP(hipMemcpyAsync(sums.data(), c.ws_winsums.p, sums.size() * sizeof(Xyzz<T>), hipMemcpyDeviceToHost, c.stream));
+  tred.stop();
+  GS_HIP(hipStreamSynchronize(c.stream));
+  c.timing.accumulate_ms += tacc.ms();
+  c.timing.reduce_ms += tred.ms();
+  for (int j = 0; j < njobs; ++j) out[j] = horner_host<T>(sums.data() + (size_t)j * plan.W, plan.W, plan.c);
+}
+
+void msm_run_g1(Ctx& c, const MsmPlan& plan, const std::vector<const uint32_t*>& bases, std::vector<G1Xyzz>& out) {
+  msm_run<FqTag>(c, plan, bases, out, 0);
+}
+void msm_run_g2(Ctx& c, const MsmPlan& plan, const std::vector<const uint32_t*>& bases, std::vector<G2Xyzz>& out) {
+  msm_run<Fq2Tag>(c, plan, bases, out, 4);
+}
+
+void jacobian_to_affine_g1(Ctx& c, const uint32_t* jac, uint32_t n, uint32_t* out) {
+  if (n) hipLaunchKernelGGL(k_jacobian_to_affine<FqTag>, grid1(n), dim3(256), 0, c.stream, jac, n, out);
+  GS_HIP(hipGetLastError());
+}
+void jacobian_to_affine_g2(Ctx& c, const uint32_t* jac, uint32_t n, uint32_t* out) {
+  if (n) hipLaunchKernelGGL(k_jacobian_to_affine<Fq2Tag>, grid1(n), dim3(256), 0, c.stream, jac, n, out);
+  GS_HIP(hipGetLastError());
+}
+void affine_to_jacobian_std_g1(Ctx& c, const uint32_t* aff, uint32_t n, uint32_t* out) {
+  if (n) hipLaunchKernelGGL(k_affine_to_jacobian_std<FqTag>, grid1(n), dim3(256), 0, c.stream, aff, n, out);
+  GS_HIP(hipGetLastError());
+}
+void affine_to_jacobian_std_g2(Ctx& c, const uint32_t* aff, uint32_t n, uint32_t* out) {
+  if (n) hipLaunchKernelGGL(k_affine_to_jacobian_std<Fq2Tag>, grid1(n), dim3(256), 0, c.stream, aff, n, out);
+  GS_HIP(hipGetLastError());
+}
+
+template <class T>
+static void fixed_base(Ctx& c, DevBuf& table, const uint32_t* scalars, uint32_t n, uint32_t* out) {
+  if (table.p == nullptr) {
+    table.alloc((size_t)256 * PointIO<T>::kAffineWords * 4);
+    hipLaunchKernelGGL(k_build_pow2_table<T>, dim3(1), dim3(64), 0, c.stream, table.as<uint32_t>());
+  }
+  if (n) hipLaunchKernelGGL(k_fixed_base_mul<T>, grid1(n), dim3(256), 0, c.stream, scalars, n, table.as<uint32_t>(), out);
+  GS_HIP(hipGetLastError());
+}
+void fixed_base_g1(Ctx& c, const uint32_t* s, uint32_t n, uint32_t* out) { fixed_base<FqTag>(c, c.g1_pow2, s, n, out); }
+void fixed_base_g2(Ctx& c, const uint32_t* s, uint32_t n, uint32_t* out) { fixed_base<Fq2Tag>(c, c.g2_pow2, s, n, out); }
+
+// ---- host-side serial helpers ---------------------------------------------------------------------------
+void fr_canon_words(const uint64_t k[4], uint32_t out[8]) {
+  uint32_t t[8];
+  for (int i = 0; i < 4; ++i) { t[2 * i] = (uint32_t)k[i]; t[2 * i + 1] = (uint32_t)(k[i] >> 32); }
+  scalar_canon(t);
+  for (int i = 0; i < 8; ++i) out[i] = t[i];
+}
+
+template <class T>
+static Affine<T> affine_from_jac_std(const uint64_t* jac) {
+  constexpr int cw = PointIO<T>::kCoordWords;
+  const uint32_t* p = reinterpret_cast<const uint32_t*>(jac);
+  auto X = PointIO<T>::load_std(p), Y = PointIO<T>::load_std(p + cw), Z = PointIO<T>::load_std(p + 2 * cw);
+  return jacobian_to_affine<T>(X, Y, Z);
+}
+G1Affine g1_affine_from_jacobian_std(const uint64_t jac[12]) { return affine_from_jac_std<FqTag>(jac); }
+G2Affine g2_affine_from_jacobian_std(const uint64_t jac[24]) { return affine_from_jac_std<Fq2Tag>(jac); }
+
+template <class T>
+static bool to_affine_std(const Xyzz<T>& p, uint64_t* out) {
+  constexpr int cw = PointIO<T>::kCoordWords;
+  uint32_t* o = reinterpret_cast<uint32_t*>(out);
+  memset(o, 0, 2 * cw * 4);
+  if (is_inf(p)) return true;
+  Affine<T> a = xyzz_to_affine(p);
+  PointIO<T>::store_std(o, a.x);
+  PointIO<T>::store_std(o + cw, a.y);
+  return false;
+}
+bool g1_to_affine_std(const G1Xyzz& p, uint64_t out[8]) { return to_affine_std<FqTag>(p, out); }
+bool g2_to_affine_std(const G2Xyzz& p, uint64_t out[16]) { return to_affine_std<Fq2Tag>(p, out); }
+
+G1Xyzz g1_mul_scalar(const G1Xyzz& p, const uint64_t k[4]) {
+  uint32_t w[8];
+  fr_canon_words(k, w);
+  return xyzz_mul_words(p, w);
+}
+G2Xyzz g2_mul_scalar(const G2Xyzz& p, const uint64_t k[4]) {
+  uint32_t w[8];
+  fr_canon_words(k, w);
+  return xyzz_mul_words(p, w);
+}
+
+}  // namespace gs

@@ -1,0 +1,286 @@
+// Pippenger multi-scalar multiplication kernels for gfx950 (G1 and G2 via the field tag T).
+//
+// Replaces the reference's prover loops `acc = Add(acc, MulScalar(base[i], scalar[i]))`
+// (groth16/groth16.go:243-250,269-271; snark.go:265-286; bn128/g1.go:140-155, g2.go:142-181):
+// per term ~254 doublings + ~127 additions there, W = ceil(254/c) mixed additions here.
+//
+// Pipeline (all on the library stream, no host round trips):
+//   plan (once per scalar vector, shared by every base array multiplied by it):
+//     k_digit_count   scalars -> signed c-bit digits, histogram per (window, bucket)
+//     scan            exclusive prefix sum -> bucket offsets
+//     k_digit_scatter point index (sign in bit 31) into its bucket's slot (counting sort)
+//   per base array:
+//     k_bucket_accumulate  one thread per bucket: XYZZ += +-affine base  (8M+2S each)   <- dominant
+//     k_bucket_reduce      per chunk of L buckets: sum_j (b0+j+1) * bucket -> one point
+//     k_fold               pairwise folding of the chunk points -> one point per window
+//     k_horner_finish      sum_w 2^(cw) S_w, to affine, from Montgomery, canonical words
+//
+// HBM layout: bases are AoS packed canonical Montgomery words (G1: 16 x u32 = 64 B/point,
+// G2: 128 B), so a bucket thread gathers each point with 4 (8) 16-byte loads; scalars are the
+// ABI's 8 x u32 words, read fully coalesced; buckets are raw 29-bit limbs (36 / 72 words).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ec.h"
+#include "point_io.h"
+
+namespace gs {
+
+struct PlanParams {
+  uint32_t n;        // scalars
+  int c;             // window bits
+  int W;             // windows = floor(254 / c) + 1
+  uint32_t B;        // buckets per window = 2^(c-1)   (digits are signed: [-B, B])
+};
+
+// signed digit of window w with the running carry (digit in [-B, B], never 0 <-> skipped)
+GS_HD int32_t next_digit(const uint32_t (&k)[8], const PlanParams& pp, int w, uint32_t& carry) {
+  uint32_t raw = scalar_bits(k, w * pp.c, pp.c) + carry;
+  if (raw > pp.B) { carry = 1; return (int32_t)raw - (int32_t)(2u * pp.B); }
+  carry = 0;
+  return (int32_t)raw;
+}
+
+__global__ void __launch_bounds__(256) k_digit_count(const uint32_t* __restrict__ scalars, PlanParams pp,
+                                                      uint32_t* __restrict__ hist) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= pp.n) return;
+  uint32_t k[8];
+  const uint4* s4 = reinterpret_cast<const uint4*>(scalars + (size_t)i * 8);
+  uint4 lo = s4[0], hi = s4[1];
+  k[0] = lo.x; k[1] = lo.y; k[2] = lo.z; k[3] = lo.w; k[4] = hi.x; k[5] = hi.y; k[6] = hi.z; k[7] = hi.w;
+  scalar_canon(k);
+  uint32_t carry = 0;
+  for (int w = 0; w < pp.W; ++w) {
+    int32_t d = next_digit(k, pp, w, carry);
+    if (d != 0) {
+      uint32_t b = (uint32_t)(d < 0 ? -d : d) - 1u;
+      atomicAdd(&hist[(size_t)w * pp.B + b], 1u);
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) k_digit_scatter(const uint32_t* __restrict__ scalars, PlanParams pp,
+                                                        uint32_t* __restrict__ cursor, uint32_t* __restrict__ entries) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= pp.n) return;
+  uint32_t k[8];
+  const uint4* s4 = reinterpret_cast<const uint4*>(scalars + (size_t)i * 8);
+  uint4 lo = s4[0], hi = s4[1];
+  k[0] = lo.x; k[1] = lo.y; k[2] = lo.z; k[3] = lo.w; k[4] = hi.x; k[5] = hi.y; k[6] = hi.z; k[7] = hi.w;
+  scalar_canon(k);
+  uint32_t carry = 0;
+  for (int w = 0; w < pp.W; ++w) {
+    int32_t d = next_digit(k, pp, w, carry);
+    if (d != 0) {
+      uint32_t b = (uint32_t)(d < 0 ? -d : d) - 1u;
+      uint32_t pos = atomicAdd(&cursor[(size_t)w * pp.B + b], 1u);
+      entries[pos] = i | (d < 0 ? kSignBit : 0u);
+    }
+  }
+}
+
+// ---- exclusive scan over uint32 (three small kernels) ----------------------------------------------
+constexpr int kScanBlock = 256;
+constexpr int kScanPerThread = 8;
+constexpr int kScanTile = kScanBlock * kScanPerThread;
+
+__global__ void __launch_bounds__(kScanBlock) k_scan_tiles(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
+                                                            uint32_t* __restrict__ tile_sums, uint32_t n) {
+  __shared__ uint32_t sh[kScanBlock];
+  const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * kScanPerThread;
+  uint32_t v[kScanPerThread], sum = 0;
+#pragma unroll
+  for (int j = 0; j < kScanPerThread; ++j) { v[j] = (base + j < n) ? in[base + j] : 0u; sum += v[j]; }
+  sh[threadIdx.x] = sum;
+  __syncthreads();
+  for (int off = 1; off < kScanBlock; off <<= 1) {     // Hillis-Steele inclusive scan of thread sums
+    uint32_t t = (threadIdx.x >= (uint32_t)off) ? sh[threadIdx.x - off] : 0u;
+    __syncthreads();
+    sh[threadIdx.x] += t;
+    __syncthreads();
+  }
+  uint32_t run = sh[threadIdx.x] - sum;                // exclusive prefix of this thread within the tile
+#pragma unroll
+  for (int j = 0; j < kScanPerThread; ++j) { if (base + j < n) out[base + j] = run; run += v[j]; }
+  if (threadIdx.x == kScanBlock - 1) tile_sums[blockIdx.x] = sh[threadIdx.x];
+}
+
+__global__ void __launch_bounds__(1024) k_scan_tile_sums(uint32_t* __restrict__ tile_sums, uint32_t ntiles, uint32_t* __restrict__ total) {
+  // single block: sequential-per-thread chunks + block scan; ntiles <= 1024 * 64
+  __shared__ uint32_t sh[1024];
+  const uint32_t per = (ntiles + 1023u) / 1024u;
+  const uint32_t b0 = threadIdx.x * per;
+  uint32_t sum = 0;
+  for (uint32_t j = 0; j < per; ++j) if (b0 + j < ntiles) sum += tile_sums[b0 + j];
+  sh[threadIdx.x] = sum;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    uint32_t t = (threadIdx.x >= (uint32_t)off) ? sh[threadIdx.x - off] : 0u;
+    __syncthreads();
+    sh[threadIdx.x] += t;
+    __syncthreads();
+  }
+  uint32_t run = sh[threadIdx.x] - sum;
+  for (uint32_t j = 0; j < per; ++j) if (b0 + j < ntiles) { uint32_t t = tile_sums[b0 + j]; tile_sums[b0 + j] = run; run += t; }
+  if (threadIdx.x == 1023) *total = sh[1023];
+}
+
+__global__ void __launch_bounds__(kScanBlock) k_scan_add(uint32_t* __restrict__ out, const uint32_t* __restrict__ tile_sums, uint32_t n) {
+  const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * kScanPerThread;
+  const uint32_t add = tile_sums[blockIdx.x];
+#pragma unroll
+  for (int j = 0; j < kScanPerThread; ++j) if (base + j < n) out[base + j] += add;
+}
+
+// ---- bucket accumulation (dominant kernel) ---------------------------------------------------------
+// One thread per bucket; its entries are contiguous in `entries`.  grid.y = base array (job).
+struct AccJob {
+  const uint32_t* bases;      // packed affine, already offset to the first term's point
+  uint32_t* buckets;          // nbuckets * kXyzzWords
+  uint32_t* chunks;           // (W * B / L) * kXyzzWords : per-chunk weighted sums, folded in place
+};
+constexpr int kMaxJobs = 8;
+struct AccJobs { AccJob j[kMaxJobs]; };
+
+template <class T>
+__global__ void __launch_bounds__(256) k_bucket_accumulate(AccJobs jobs, const uint32_t* __restrict__ offsets,
+                                                            const uint32_t* __restrict__ entries, uint32_t nbuckets) {
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nbuckets) return;
+  const AccJob job = jobs.j[blockIdx.y];
+  const uint32_t beg = offsets[b], end = offsets[b + 1];
+  Xyzz<T> acc = xyzz_inf<T>();
+  for (uint32_t e = beg; e < end; ++e) {
+    const uint32_t v = entries[e];
+    const uint32_t idx = v & ~kSignBit;
+    const Affine<T> p = PointIO<T>::load_affine(job.bases + (size_t)idx * PointIO<T>::kAffineWords);
+    xyzz_madd(acc, p, (v & kSignBit) != 0);
+  }
+  store_xyzz<T>(job.buckets + (size_t)b * PointIO<T>::kXyzzWords, acc);
+}
+
+// ---- bucket reduction -------------------------------------------------------------------------------
+// thread t of window w owns buckets [t*L, (t+1)*L): returns sum_j (t*L + j + 1) * bucket[t*L + j]
+template <class T>
+__global__ void __launch_bounds__(256) k_bucket_reduce(AccJobs jobs, uint32_t B, int L, uint32_t nchunks_total) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;     // chunk index over all windows
+  if (t >= nchunks_total) return;
+  const AccJob job = jobs.j[blockIdx.y];
+  const uint32_t chunks_per_window = B / (uint32_t)L;
+  const uint32_t w = t / chunks_per_window, tw = t % chunks_per_window;
+  const uint32_t b0 = tw * (uint32_t)L;                          // first bucket (0-based) of the chunk, weight b0+1
+  const uint32_t* src = job.buckets + ((size_t)w * B + b0) * PointIO<T>::kXyzzWords;
+  Xyzz<T> run = xyzz_inf<T>(), acc = xyzz_inf<T>();
+  for (int j = L - 1; j >= 0; --j) {
+    Xyzz<T> bk = load_xyzz<T>(src + (size_t)j * PointIO<T>::kXyzzWords);
+    xyzz_add(run, bk);
+    xyzz_add(acc, run);
+  }
+  // acc = sum_j (j+1) bucket_j ; add b0 * run
+  if (b0 != 0 && !is_inf(run)) {
+    Xyzz<T> off = xyzz_mul_u32(run, b0);
+    xyzz_add(acc, off);
+  }
+  store_xyzz<T>(job.chunks + (size_t)t * PointIO<T>::kXyzzWords, acc);
+}
+
+// pts[seg * seglen + i] += pts[seg * seglen + i + half]  for i < half, all segments at once
+template <class T>
+__global__ void __launch_bounds__(256) k_fold(AccJobs jobs, uint32_t nseg, uint32_t seglen, uint32_t half) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= nseg * half) return;
+  const uint32_t seg = g / half, i = g % half;
+  uint32_t* base = jobs.j[blockIdx.y].chunks + ((size_t)seg * seglen + i) * PointIO<T>::kXyzzWords;
+  Xyzz<T> a = load_xyzz<T>(base);
+  Xyzz<T> b = load_xyzz<T>(base + (size_t)half * PointIO<T>::kXyzzWords);
+  xyzz_add(a, b);
+  store_xyzz<T>(base, a);
+}
+
+// gather the W window sums (first point of each folded segment) of every job into one
+// contiguous buffer [job][w] for a single D2H copy; the O(W*c) serial Horner combination
+// sum_w 2^(cw) S_w runs on the host core (msm_host.h): a lone wave retires one 254-step
+// doubling chain in ~2.5 ms, a CPU core in ~0.2 ms.
+template <class T>
+__global__ void k_gather_window_sums(AccJobs jobs, uint32_t seglen, int W, uint32_t* __restrict__ out) {
+  const uint32_t job = blockIdx.y, w = blockIdx.x;
+  const uint32_t* src = jobs.j[job].chunks + (size_t)w * seglen * PointIO<T>::kXyzzWords;
+  uint32_t* dst = out + ((size_t)job * W + w) * PointIO<T>::kXyzzWords;
+  for (int i = threadIdx.x; i < PointIO<T>::kXyzzWords; i += blockDim.x) dst[i] = src[i];
+}
+
+// ---- base-array preparation ----------------------------------------------------------------------------
+// Jacobian standard-form triples -> packed canonical Montgomery affine       [g1.go:157-170]
+template <class T>
+__global__ void __launch_bounds__(256) k_jacobian_to_affine(const uint32_t* __restrict__ jac, uint32_t n, uint32_t* __restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  constexpr int cw = PointIO<T>::kCoordWords;
+  const uint32_t* p = jac + (size_t)i * 3 * cw;
+  auto X = PointIO<T>::load_std(p), Y = PointIO<T>::load_std(p + cw), Z = PointIO<T>::load_std(p + 2 * cw);
+  Affine<T> a = jacobian_to_affine<T>(X, Y, Z);
+  PointIO<T>::store_affine(out + (size_t)i * PointIO<T>::kAffineWords, a);
+}
+
+// packed affine -> standard-form Jacobian triple [x, y, 1] / [0, 0, 0]
+template <class T>
+__global__ void __launch_bounds__(256) k_affine_to_jacobian_std(const uint32_t* __restrict__ aff, uint32_t n, uint32_t* __restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  constexpr int cw = PointIO<T>::kCoordWords;
+  Affine<T> a = PointIO<T>::load_affine(aff + (size_t)i * PointIO<T>::kAffineWords);
+  uint32_t* o = out + (size_t)i * 3 * cw;
+  for (int k = 0; k < 3 * cw; ++k) o[k] = 0;
+  if (is_inf(a)) return;
+  PointIO<T>::store_std(o, a.x);
+  PointIO<T>::store_std(o + cw, a.y);
+  o[2 * cw] = 1u;
+}
+
+// fixed-base batch: out[i] = k_i * G.  `table` holds 2^j * G (affine, packed) for j = 0..255.
+template <class T>
+__global__ void __launch_bounds__(256) k_fixed_base_mul(const uint32_t* __restrict__ scalars, uint32_t n,
+                                                         const uint32_t* __restrict__ table, uint32_t* __restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t k[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) k[j] = scalars[(size_t)i * 8 + j];
+  scalar_canon(k);
+  Xyzz<T> acc = xyzz_inf<T>();
+  for (int bit = 0; bit < 254; ++bit) {
+    if ((k[bit >> 5] >> (bit & 31)) & 1u) {
+      Affine<T> p = PointIO<T>::load_affine(table + (size_t)bit * PointIO<T>::kAffineWords);
+      xyzz_madd(acc, p, false);
+    }
+  }
+  Affine<T> a = xyzz_to_affine(acc);
+  PointIO<T>::store_affine(out + (size_t)i * PointIO<T>::kAffineWords, a);
+}
+
+// table[j] = 2^j * G, j < 256 (single thread; runs once per process)
+template <class T>
+__global__ void k_build_pow2_table(uint32_t* __restrict__ table) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  Affine<T> g;
+  if constexpr (PointIO<T>::kAffineWords == 16) {
+#pragma unroll
+    for (int i = 0; i < NL; ++i) { g.x.l[i] = Gen::g1x(i); g.y.l[i] = Gen::g1y(i); }
+  } else {
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      g.x.c0.l[i] = Gen::g2x0(i); g.x.c1.l[i] = Gen::g2x1(i);
+      g.y.c0.l[i] = Gen::g2y0(i); g.y.c1.l[i] = Gen::g2y1(i);
+    }
+  }
+  Xyzz<T> acc = xyzz_from_affine(g);
+  for (int j = 0; j < 256; ++j) {
+    Affine<T> a = xyzz_to_affine(acc);
+    PointIO<T>::store_affine(table + (size_t)j * PointIO<T>::kAffineWords, a);
+    xyzz_dbl(acc);
+  }
+}
+
+}  // namespace gs

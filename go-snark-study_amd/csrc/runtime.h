@@ -1,0 +1,159 @@
+// Host runtime of libgosnark_hip.so: device context, error reporting, handle table, workspace pool.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/gosnark_hip.h"
+
+namespace gs {
+
+// ---- errors -------------------------------------------------------------------------------------
+inline std::string& last_error_ref() {
+  static thread_local std::string e;
+  return e;
+}
+inline int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  last_error_ref() = buf;
+  return code;
+}
+struct HipError {
+  hipError_t e;
+  const char* what;
+  int line;
+};
+#define GS_HIP(x)                                              \
+  do {                                                         \
+    hipError_t _e = (x);                                       \
+    if (_e != hipSuccess) throw ::gs::HipError{_e, #x, __LINE__}; \
+  } while (0)
+
+// ---- device buffers -------------------------------------------------------------------------------
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  DevBuf() = default;
+  explicit DevBuf(size_t n) { alloc(n); }
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; o.bytes = 0; }
+  DevBuf& operator=(DevBuf&& o) noexcept {
+    if (this != &o) { release(); p = o.p; bytes = o.bytes; o.p = nullptr; o.bytes = 0; }
+    return *this;
+  }
+  ~DevBuf() { release(); }
+  void alloc(size_t n) {
+    release();
+    if (n == 0) n = 16;
+    GS_HIP(hipMalloc(&p, n));
+    bytes = n;
+  }
+  void ensure(size_t n) { if (n > bytes) alloc(n + n / 8); }      // grow-only workspace
+  void release() { if (p) { (void)hipFree(p); p = nullptr; bytes = 0; } }
+  template <class U> U* as() const { return reinterpret_cast<U*>(p); }
+};
+
+// ---- handle table ---------------------------------------------------------------------------------
+enum class Kind : uint32_t { G1Bases = 1, G2Bases, Scalars, GrothPk, PinocchioPk };
+
+struct Object {
+  Kind kind;
+  virtual ~Object() = default;
+  explicit Object(Kind k) : kind(k) {}
+};
+
+struct Bases : Object {          // packed affine Montgomery points, resident
+  DevBuf buf;
+  size_t n = 0;
+  explicit Bases(Kind k) : Object(k) {}
+};
+struct Scalars : Object {        // n x 8 u32 words, standard form, resident
+  DevBuf buf;
+  size_t n = 0;
+  Scalars() : Object(Kind::Scalars) {}
+};
+
+struct Ctx {
+  int device = -1;
+  bool ready = false;
+  hipStream_t stream = nullptr;
+  std::mutex mu;
+  uint64_t next_handle = 1;
+  std::unordered_map<uint64_t, std::unique_ptr<Object>> objs;
+  int window_bits = 0;           // 0 = auto
+  gs_timing timing{};
+  // reusable workspaces (grow-only)
+  DevBuf ws_hist, ws_offsets, ws_cursor, ws_entries, ws_tiles, ws_total;
+  DevBuf ws_buckets[8], ws_chunks[8], ws_winsums;
+  DevBuf ws_misc;
+  DevBuf g1_pow2, g2_pow2;       // 2^j * G tables (lazy)
+  std::vector<hipEvent_t> events;
+
+  template <class O> O* get(gs_handle h, Kind k) {
+    auto it = objs.find(h);
+    if (it == objs.end() || it->second->kind != k) return nullptr;
+    return static_cast<O*>(it->second.get());
+  }
+  gs_handle put(std::unique_ptr<Object> o) {
+    uint64_t h = next_handle++;
+    objs[h] = std::move(o);
+    return h;
+  }
+};
+
+inline Ctx& ctx() {
+  static Ctx c;
+  return c;
+}
+
+// every entry point: lock, check init, translate exceptions into status codes
+template <class F>
+int guarded(F&& f, bool need_init = true) {
+  Ctx& c = ctx();
+  std::lock_guard<std::mutex> lk(c.mu);
+  if (need_init && !c.ready) return fail(GS_ERR_NOT_INIT, "gs_init has not been called (or failed)");
+  try {
+    return f(c);
+  } catch (const HipError& e) {
+    return fail(GS_ERR_HIP, "HIP error %d (%s) at %s line %d", (int)e.e, hipGetErrorString(e.e), e.what, e.line);
+  } catch (const std::bad_alloc&) {
+    return fail(GS_ERR_HIP, "host allocation failed");
+  } catch (const std::exception& e) {
+    return fail(GS_ERR_ARG, "%s", e.what());
+  }
+}
+inline void reset_timing(Ctx& c) { c.timing = gs_timing{}; }
+
+// RAII event timer on the library stream
+struct PhaseTimer {
+  hipEvent_t a, b;
+  hipStream_t s;
+  explicit PhaseTimer(hipStream_t st) : s(st) {
+    GS_HIP(hipEventCreate(&a));
+    GS_HIP(hipEventCreate(&b));
+    GS_HIP(hipEventRecord(a, s));
+  }
+  void stop() { GS_HIP(hipEventRecord(b, s)); }
+  float ms() {
+    float m = 0;
+    GS_HIP(hipEventSynchronize(b));
+    GS_HIP(hipEventElapsedTime(&m, a, b));
+    return m;
+  }
+  ~PhaseTimer() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); }
+};
+
+}  // namespace gs

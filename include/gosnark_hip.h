@@ -1,0 +1,186 @@
+/* gosnark_hip.h -- C ABI of libgosnark_hip.so: the MI355X (gfx950) prover hot path of
+ * arnaucube/go-snark-study.
+ *
+ * The reference has no FFI or plugin seam (pure Go on math/big); the drop-in boundary is the
+ * pair of Go functions
+ *     groth16.GenerateProofs(circuit, pk, w, px) (Proof, error)     groth16/groth16.go:225-278
+ *     snark.GenerateProofs  (circuit, pk, w, px) (Proof, error)     snark.go:254-289
+ * plus the finer seams they are built from (bn128/g1.go:140 MulScalar + :32 Add loops,
+ * bn128/g2.go:142/:32, r1csqap/r1csqap.go:57-216).  A cgo binding (go/gosnarkhip, shown in
+ * INTEGRATION.md) flattens the Go structs and calls the entry points below; each entry point
+ * cites the reference code it replaces.
+ *
+ * Conventions
+ *  - Field elements (Fq and Fr): 4 x uint64_t little-endian limbs, STANDARD (non-Montgomery)
+ *    form, i.e. exactly big.Int.Bits() of the reference value padded to 4 words.  Scalars and
+ *    polynomial coefficients may be any value < 2^256; they are reduced mod r on the device.
+ *  - G1 points: Jacobian triples [X, Y, Z] = 12 words, as the reference stores them
+ *    ([3]*big.Int, bn128/g1.go:9-12).  G2 points: [[X0,X1],[Y0,Y1],[Z0,Z1]] = 24 words
+ *    ([3][2]*big.Int, bn128/g2.go:9-12).  Z == 0 means infinity (g1.go:28-30).
+ *  - Results are returned in AFFINE normal form [x, y, 1] (g1.go:157-170 / g2.go:183-200) with
+ *    an is-infinity flag; the reference's raw Jacobian Z depends on its exact double/add order
+ *    and cannot be reproduced by a bucket method.  Infinity is [0, 0, 0].
+ *  - Every function returns 0 on success or a negative gs_status; gs_last_error() gives the
+ *    message (thread-local).  Nothing falls back to a CPU path: without a usable gfx950
+ *    device every compute call fails with GS_ERR_NO_DEVICE.
+ *  - The library copies caller buffers during the call and never retains host pointers
+ *    (cgo pointer rule).  Device memory lives behind opaque handles freed by gs_free().
+ *  - One context per process and device (one process per GPU); calls are serialised on an
+ *    internal mutex, safe to call from several goroutines/threads.
+ */
+#ifndef GOSNARK_HIP_H
+#define GOSNARK_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
+
+typedef uint64_t gs_handle;
+
+typedef enum {
+  GS_OK = 0,
+  GS_ERR_NO_DEVICE = -1,   /* no gfx950 device / HIP runtime unusable */
+  GS_ERR_HIP = -2,         /* a HIP call or kernel failed */
+  GS_ERR_ARG = -3,         /* bad argument (null pointer, size mismatch, bad handle) */
+  GS_ERR_SHAPE = -4,       /* instance violates the reference's shape contract */
+  GS_ERR_NOT_INIT = -5
+} gs_status;
+
+/* ---- lifetime ------------------------------------------------------------------------- */
+/* Select the device this process drives (devices[0]; ndev must be 1: one process per GPU). */
+int gs_init(const int* devices, int ndev);
+void gs_shutdown(void);
+const char* gs_last_error(void);
+/* ABI/version string, e.g. "gosnark-hip 0.1 gfx950". */
+const char* gs_version(void);
+int gs_free(gs_handle h);
+
+/* ---- resident base-point arrays (proving-key material) --------------------------------- */
+/* Upload n Jacobian points, convert to Montgomery affine on the device (x = X/Z^2, y = Y/Z^3,
+ * bn128/g1.go:157-170), keep them resident.  Replaces the per-call big.Int traffic of
+ * pk.G1.At / pk.G1.BACGamma / pk.BACDelta / pk.PowersTauDelta (groth16.go:15-32). */
+int gs_g1_upload(const uint64_t* jacobian /* n x 12 */, size_t n, gs_handle* out);
+/* Same for G2 arrays, e.g. pk.G2.BACGamma (groth16.go:29), snark Pk.B (snark.go:19). */
+int gs_g2_upload(const uint64_t* jacobian /* n x 24 */, size_t n, gs_handle* out);
+/* Number of points behind a base handle (or coefficients behind a scalar handle). */
+int gs_len(gs_handle h, size_t* out);
+/* Read points back as affine Jacobian triples [x, y, 1] / [0,0,0] (testing / serialisation). */
+int gs_g1_download(gs_handle bases, uint64_t* jacobian /* n x 12 */, size_t n);
+int gs_g2_download(gs_handle bases, uint64_t* jacobian /* n x 24 */, size_t n);
+
+/* Fixed-base batch: out[i] = k[i] * G  for the G1 / G2 generator (bn128.go:52-83); the hot
+ * loop of groth16.GenerateTrustedSetup (groth16.go:139-175, `MulScalar(Utils.Bn.G1.G, ...)`)
+ * and what the synthetic proving keys of bench.py are built with. */
+int gs_g1_fixed_base(const uint64_t* scalars /* n x 4 */, size_t n, gs_handle* out);
+int gs_g2_fixed_base(const uint64_t* scalars /* n x 4 */, size_t n, gs_handle* out);
+
+/* ---- resident scalar vectors ------------------------------------------------------------- */
+int gs_scalars_upload(const uint64_t* scalars /* n x 4 */, size_t n, gs_handle* out);
+int gs_scalars_download(gs_handle scalars, uint64_t* out /* n x 4 */, size_t n);
+
+/* ---- multi-scalar multiplication ----------------------------------------------------------
+ * out = sum_{i<n} scalars[i] * bases[off + i]: replaces the loop
+ *     acc = G1.Add(acc, G1.MulScalar(bases[i], scalars[i]))
+ * of groth16.go:243-250,269-271 / snark.go:265-286 (bn128/g1.go:140-155 + :32-89) by a signed-
+ * digit Pippenger bucket method.  out_affine = [x, y] (8 words); *is_inf set when the sum is
+ * the identity (then out is all zero). */
+int gs_msm_g1(gs_handle bases, const uint64_t* scalars /* n x 4 */, size_t off, size_t n,
+              uint64_t out_affine[8], int* is_inf);
+/* G2 flavour (bn128/g2.go:142-181 + :32-89); out_affine = [x0, x1, y0, y1] (16 words). */
+int gs_msm_g2(gs_handle bases, const uint64_t* scalars /* n x 4 */, size_t off, size_t n,
+              uint64_t out_affine[16], int* is_inf);
+/* Same with the scalars already resident (handle from gs_scalars_upload / a poly result);
+ * soff = first scalar used.  This is what bench.py times. */
+int gs_msm_g1_resident(gs_handle bases, size_t off, gs_handle scalars, size_t soff, size_t n,
+                       uint64_t out_affine[8], int* is_inf);
+int gs_msm_g2_resident(gs_handle bases, size_t off, gs_handle scalars, size_t soff, size_t n,
+                       uint64_t out_affine[16], int* is_inf);
+/* Sum of n points given as affine [x,y] pairs with infinity flags (multi-GPU combine of the
+ * per-rank partial sums): out = sum_i pts[i]. */
+int gs_g1_sum_affine(const uint64_t* pts /* n x 8 */, const int* inf, size_t n, uint64_t out_affine[8], int* is_inf);
+int gs_g2_sum_affine(const uint64_t* pts /* n x 16 */, const int* inf, size_t n, uint64_t out_affine[16], int* is_inf);
+
+/* ---- polynomial field over Fr (r1csqap/r1csqap.go) ---------------------------------------- */
+/* PolynomialField.Mul (r1csqap.go:57-67): out has na + nb - 1 coefficients. */
+int gs_poly_mul(const uint64_t* a, size_t na, const uint64_t* b, size_t nb, uint64_t* out);
+/* PolynomialField.Div (r1csqap.go:70-84): quotient (na - nb + 1 coefficients) and, if rem is
+ * not NULL, remainder (nb - 1 coefficients).  Requires na >= nb >= 1 and b[nb-1] != 0. */
+int gs_poly_div(const uint64_t* a, size_t na, const uint64_t* b, size_t nb, uint64_t* quo, uint64_t* rem);
+/* PolynomialField.Add / Sub (r1csqap.go:94-115): out has max(na, nb) coefficients. */
+int gs_poly_add(const uint64_t* a, size_t na, const uint64_t* b, size_t nb, uint64_t* out);
+int gs_poly_sub(const uint64_t* a, size_t na, const uint64_t* b, size_t nb, uint64_t* out);
+/* PolynomialField.Eval (r1csqap.go:118-126). */
+int gs_poly_eval(const uint64_t* v, size_t n, const uint64_t x[4], uint64_t out[4]);
+/* PolynomialField.LagrangeInterpolation (r1csqap.go:150-158): n values at nodes 1..n ->
+ * n coefficients.  Mathematically exact for every n (the reference's NewPolZeroAt overflows a
+ * Go int for n >= 22, r1csqap.go:130-136; equal results for n <= 21). */
+int gs_lagrange_interpolation(const uint64_t* values, size_t n, uint64_t* coeffs);
+/* Z(x) = prod_{i=1}^{deg} (x - i): deg + 1 coefficients (r1csqap.go:177-186, groth16.go:122-131). */
+int gs_zpoly(size_t deg, uint64_t* out);
+/* Sparse R1CS -> P(x): the scalable replacement of R1CSToQAP + CombinePolynomials
+ * (r1csqap.go:161-210).  A, B, C in CSR over n constraints x m variables (row_ptr n+1,
+ * col idx, val nnz x 4); w: m scalars.  Outputs ax, bx, cx (n coeffs each, may be NULL) and
+ * px = ax*bx - cx (2n - 1 coeffs). */
+int gs_r1cs_to_px(size_t n, size_t m,
+                  const uint32_t* a_rowptr, const uint32_t* a_col, const uint64_t* a_val,
+                  const uint32_t* b_rowptr, const uint32_t* b_col, const uint64_t* b_val,
+                  const uint32_t* c_rowptr, const uint32_t* c_col, const uint64_t* c_val,
+                  const uint64_t* w, uint64_t* ax, uint64_t* bx, uint64_t* cx, uint64_t* px);
+
+/* ---- Groth16 prover (groth16/groth16.go) --------------------------------------------------- */
+/* Device-resident proving key: groth16.Pk (groth16.go:15-32).  At, BACGamma (G1), BACDelta:
+ * m points; G2 BACGamma: m points; PowersTauDelta: len(Z) points; single points as Jacobian
+ * triples; Z: nz coefficients (monic).  npublic = circuit.NPublic. */
+int gs_groth16_pk_create(gs_handle g1_at, gs_handle g1_bacgamma, gs_handle g2_bacgamma,
+                         gs_handle bacdelta, gs_handle powers_tau_delta,
+                         const uint64_t g1_alpha[12], const uint64_t g1_beta[12], const uint64_t g1_delta[12],
+                         const uint64_t g2_beta[24], const uint64_t g2_delta[24],
+                         const uint64_t* z, size_t nz, size_t nvars, size_t npublic, gs_handle* out);
+/* groth16.GenerateProofs (groth16.go:225-278) with the randomness injected: r, s are what
+ * Utils.FqR.Rand() would have returned (:231-238).  out_proof = PiA [x,y] (8 words) |
+ * PiB [x0,x1,y0,y1] (16) | PiC [x,y] (8); inf[3] flags.  Requires len(w) == nvars and
+ * npx - nz + 1 <= len(PowersTauDelta) (the reference indexes PowersTauDelta[i] for
+ * i < len(hx), :269-271). */
+int gs_groth16_prove(gs_handle pk, const uint64_t* w, size_t nw, const uint64_t* px, size_t npx,
+                     const uint64_t r[4], const uint64_t s[4], uint64_t out_proof[32], int inf[3]);
+/* Same with w and px already resident (gs_scalars_upload); what bench.py times. */
+int gs_groth16_prove_resident(gs_handle pk, gs_handle w, gs_handle px,
+                              const uint64_t r[4], const uint64_t s[4], uint64_t out_proof[32], int inf[3]);
+
+/* ---- Pinocchio prover (snark.go) ------------------------------------------------------------ */
+/* snark.Pk (snark.go:16-26): A, Ap, Bp, C, Cp, Kp: m G1 points; B: m G2 points; G1T: len(Z). */
+int gs_pinocchio_pk_create(gs_handle a, gs_handle ap, gs_handle b_g2, gs_handle bp, gs_handle c, gs_handle cp,
+                           gs_handle kp, gs_handle g1t, const uint64_t* z, size_t nz,
+                           size_t nvars, size_t npublic, gs_handle* out);
+/* snark.GenerateProofs (snark.go:254-289).  out_proof = PiA | PiAp | PiB(16) | PiBp | PiC |
+ * PiCp | PiH | PiKp = 7*8 + 16 = 72 words; inf[8] in that order. */
+int gs_pinocchio_prove(gs_handle pk, const uint64_t* w, size_t nw, const uint64_t* px, size_t npx,
+                       uint64_t out_proof[72], int inf[8]);
+
+/* ---- timing of the last prove / msm call (device time, HIP events on the library stream) --- */
+typedef struct {
+  float total_ms;        /* all device work of the call */
+  float plan_ms;         /* scalar digit extraction + bucket sort */
+  float accumulate_ms;   /* bucket accumulation kernels (dominant) */
+  float reduce_ms;       /* bucket reduction + window combination + normalisation */
+  float poly_ms;         /* H(x) = P(x)/Z(x) stage */
+  float h2d_ms;          /* host-to-device copies inside the call */
+} gs_timing;
+int gs_last_timing(gs_timing* out);
+
+/* Tunables (0 = automatic): Pippenger window bits. */
+int gs_set_window_bits(int c);
+
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
+#ifdef __cplusplus
+}
+#endif
+#endif /* GOSNARK_HIP_H */

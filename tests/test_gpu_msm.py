@@ -1,0 +1,177 @@
+"""-m gpu parity: HIP Pippenger MSM (through the C ABI) vs the oracles, affine normal form.
+
+Oracle = literal restatement of `acc = Add(acc, MulScalar(base_i, k_i))`
+(groth16.go:243-250 / g1.go:140-155 / g2.go:142-181): oracle/ref_py.py for tiny n,
+oracle/gs_oracle.c beyond.  Bit-exact on the affine coordinates (integers mod q)."""
+import random
+
+import numpy as np
+import pytest
+
+import gosnark_amd
+from gosnark_amd import capi
+import gpu_util as U
+from oracle import c_oracle as C
+from oracle import ref_py as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _init():
+    capi.init()
+    yield
+    capi.set_window_bits(0)
+
+
+def test_upload_download_affine_normal_form():
+    rng = random.Random(21)
+    pts = [U.rand_g1_jac(rng, 0.2) for _ in range(37)]
+    h = capi.g1_upload(capi.g1_points_to_u64(pts))
+    back = capi.u64_to_ints(capi.g1_download(h))
+    for i, p in enumerate(pts):
+        got = tuple(back[3 * i:3 * i + 3])
+        aff = O.G1.Affine(p)
+        assert got == ((0, 0, 0) if aff is None else (aff[0], aff[1], 1))
+    pts2 = [U.rand_g2_jac(rng, 0.2) for _ in range(9)]
+    h2 = capi.g2_upload(capi.g2_points_to_u64(pts2))
+    back = capi.u64_to_ints(capi.g2_download(h2))
+    for i, p in enumerate(pts2):
+        got = back[6 * i:6 * i + 6]
+        aff = O.G2.Affine(p)
+        want = [0] * 6 if aff is None else [aff[0][0], aff[0][1], aff[1][0], aff[1][1], 1, 0]
+        assert got == want
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 7, 64])
+def test_g1_msm_small_vs_python_oracle(n):
+    rng = random.Random(100 + n)
+    pts = [U.rand_g1_jac(rng, 0.15) for _ in range(n)]
+    ks = [rng.choice([0, 1, 2, O.R - 1]) if rng.random() < 0.3 else rng.randrange(O.R) for _ in range(n)]
+    h = capi.g1_upload(capi.g1_points_to_u64(pts))
+    got = capi.msm(h, capi.ints_to_u64(ks) if n else np.zeros((0, 4), dtype=np.uint64))
+    assert got == U.ref_msm_affine(O.G1, pts, ks)
+
+
+@pytest.mark.parametrize("n", [1, 5, 33])
+def test_g2_msm_small_vs_python_oracle(n):
+    rng = random.Random(200 + n)
+    pts = [U.rand_g2_jac(rng, 0.15) for _ in range(n)]
+    ks = [rng.choice([0, 1, O.R - 1]) if rng.random() < 0.3 else rng.randrange(O.R) for _ in range(n)]
+    h = capi.g2_upload(capi.g2_points_to_u64(pts))
+    assert capi.msm(h, capi.ints_to_u64(ks), g2=True) == U.ref_msm_affine(O.G2, pts, ks)
+
+
+def test_g1_msm_degenerate_inputs_complete_addition():
+    """Same base several times, P and -P, all-equal scalars: buckets see P+P and P+(-P), which the
+    reference's Add cannot handle (g1.go:32-89); the kernels must."""
+    p = O.G1.MulScalar(O.G1_GEN, 987654321)
+    q = O.G1.Neg(p)
+    pts = [p, p, p, q, p, q, q, p]
+    ks = [5, 5, 5, 5, 7, 7, 3, O.R - 2]
+    h = capi.g1_upload(capi.g1_points_to_u64(pts))
+    assert capi.msm(h, capi.ints_to_u64(ks)) == U.ref_msm_affine(O.G1, pts, ks)
+    # everything cancels -> infinity
+    assert capi.msm(h, capi.ints_to_u64([9, 0, 0, 9, 0, 0, 0, 0])) is None
+    # non-canonical scalars (>= r) are reduced mod r
+    big = [O.R + 5, 2 * O.R + 1, (1 << 256) - 1, 0, 0, 0, 0, 0]
+    assert capi.msm(h, capi.ints_to_u64(big)) == U.ref_msm_affine(O.G1, pts, big)
+
+
+@pytest.mark.parametrize("c", [3, 7, 11, 16])
+def test_g1_msm_every_window_width(c):
+    rng = random.Random(300 + c)
+    n = 200
+    pts = [U.rand_g1_jac(rng, 0.05) for _ in range(n)]
+    ks = U.u64_rows_to_ints(U.rand_scalars_u64(n, 300 + c))
+    h = capi.g1_upload(capi.g1_points_to_u64(pts))
+    capi.set_window_bits(c)
+    try:
+        got = capi.msm(h, capi.ints_to_u64(ks))
+    finally:
+        capi.set_window_bits(0)
+    want = C.g1_affine(C.g1_msm_naive(capi.g1_points_to_u64(pts), capi.ints_to_u64(ks)))
+    assert got == want
+
+
+def test_g1_msm_offset_and_ragged_ranges():
+    rng = random.Random(41)
+    n = 300
+    pts = [U.rand_g1_jac(rng) for _ in range(n)]
+    arr = capi.g1_points_to_u64(pts)
+    h = capi.g1_upload(arr)
+    ks = U.rand_scalars_u64(n, 41)
+    for off, cnt in ((0, 300), (1, 299), (123, 100), (299, 1), (300, 0)):
+        got = capi.msm(h, ks[:cnt], off=off)
+        want = C.g1_affine(C.g1_msm_naive(arr[off:off + cnt], ks[:cnt])) if cnt else None
+        assert got == want, (off, cnt)
+    with pytest.raises(capi.GosnarkHipError):
+        capi.msm(h, ks[:10], off=295)
+
+
+@pytest.mark.parametrize("logn", [10, 12])
+def test_g1_msm_vs_c_oracle(logn):
+    n = 1 << logn
+    ks = U.rand_scalars_u64(n, 500 + logn)
+    bases = capi.g1_fixed_base(U.rand_scalars_u64(n, 600 + logn))      # uniform random group elements
+    arr = capi.g1_download(bases)
+    got = capi.msm(bases, ks)
+    assert got == C.g1_affine(C.g1_msm_naive(arr, ks, threads=8))
+
+
+def test_g2_msm_vs_c_oracle():
+    n = 1 << 10
+    ks = U.rand_scalars_u64(n, 700)
+    bases = capi.g2_fixed_base(U.rand_scalars_u64(n, 701))
+    arr = capi.g2_download(bases)
+    got = capi.msm(bases, ks, g2=True)
+    assert got == C.g2_affine(C.g2_msm_naive(arr, ks, threads=8))
+
+
+def test_fixed_base_equals_reference_mulscalar():
+    """gs_g1_fixed_base / gs_g2_fixed_base vs MulScalar(G, k) (groth16.go:139-175 hot loop)."""
+    ks = [0, 1, 2, 77, O.R - 1, 0x1234567890abcdef1234567890abcdef]
+    h = capi.g1_fixed_base(capi.ints_to_u64(ks))
+    back = capi.u64_to_ints(capi.g1_download(h))
+    for i, k in enumerate(ks):
+        aff = O.G1.Affine(O.G1.MulScalar(O.G1_GEN, k))
+        assert tuple(back[3 * i:3 * i + 3]) == ((0, 0, 0) if aff is None else (aff[0], aff[1], 1))
+    # bn128/g1_test.go:29-30
+    assert back[9:11] == [0x2f978c0ab89ebaa576866706b14787f360c4d6c3869efe5a72f7c3651a72ff00,
+                          0x12e4ba7f0edca8b4fa668fe153aebd908d322dc26ad964d4cd314795844b62b2]
+    h2 = capi.g2_fixed_base(capi.ints_to_u64(ks[:4]))
+    back = capi.u64_to_ints(capi.g2_download(h2))
+    for i, k in enumerate(ks[:4]):
+        aff = O.G2.Affine(O.G2.MulScalar(O.G2_GEN, k))
+        want = [0] * 6 if aff is None else [aff[0][0], aff[0][1], aff[1][0], aff[1][1], 1, 0]
+        assert back[6 * i:6 * i + 6] == want
+
+
+@pytest.mark.parametrize("logn", [16, 20])
+def test_g1_msm_full_size_linearity(logn):
+    """Size-independent property at BASELINE sizes: with bases P_i = k_i G,
+    sum_i s_i P_i == (sum_i s_i k_i mod r) G  (checked through the fixed-base path)."""
+    n = 1 << logn
+    k = U.rand_scalars_u64(n, 800 + logn)
+    s = U.rand_scalars_u64(n, 900 + logn)
+    bases = capi.g1_fixed_base(k)
+    got = capi.msm(bases, s)
+    ki, si = U.u64_rows_to_ints(k), U.u64_rows_to_ints(s)
+    dot = sum(a * b for a, b in zip(ki, si)) % O.R
+    want = O.G1.Affine(O.G1.MulScalar(O.G1_GEN, dot))
+    assert got == want
+
+
+def test_sum_affine_combines_partial_sums():
+    rng = random.Random(77)
+    parts = [O.G1.Affine(U.rand_g1_jac(rng)) for _ in range(7)] + [None]
+    acc = O.G1_ZERO
+    for p in parts:
+        if p is not None:
+            acc = O.G1.Add(acc, (p[0], p[1], 1))
+    assert capi.sum_affine(parts) == O.G1.Affine(acc)
+    parts2 = [O.G2.Affine(U.rand_g2_jac(rng)) for _ in range(3)]
+    acc = O.G2_ZERO
+    for p in parts2:
+        acc = O.G2.Add(acc, (p[0], p[1], (1, 0)))
+    assert capi.sum_affine(parts2, g2=True) == O.G2.Affine(acc)
