@@ -1,0 +1,42 @@
+"""Mirror of the reference's bn128.G1 / bn128.G2 seams used by the prover loops
+(bn128/g1.go:140 MulScalar + :32 Add; bn128/g2.go:142 / :32), backed by the HIP MSM kernels.
+Points are Jacobian tuples of Python ints exactly like the reference's [3]*big.Int /
+[3][2]*big.Int; results come back in the affine normal form [x, y, 1]."""
+from . import capi
+
+G1_ZERO = (0, 0, 0)
+G2_ZERO = ((0, 0), (0, 0), (0, 0))
+
+
+class _Group:
+    def __init__(self, g2):
+        self.g2 = g2
+
+    def _upload(self, pts):
+        return capi.g2_upload(capi.g2_points_to_u64(pts)) if self.g2 else capi.g1_upload(capi.g1_points_to_u64(pts))
+
+    def _jac(self, aff):
+        if aff is None:
+            return G2_ZERO if self.g2 else G1_ZERO
+        return (aff[0], aff[1], (1, 0)) if self.g2 else (aff[0], aff[1], 1)
+
+    def MSM(self, points, scalars):
+        """sum_i MulScalar(points[i], scalars[i]) -- the loop of groth16.go:243-250."""
+        if not points:
+            return self._jac(None)
+        h = self._upload(points)
+        return self._jac(capi.msm(h, capi.ints_to_u64(scalars), g2=self.g2))
+
+    def MulScalar(self, p, e):               # g1.go:140-155 / g2.go:142-181
+        return self.MSM([p], [abs(e)])
+
+    def Add(self, p1, p2):                   # g1.go:32-89 / g2.go:32-89 (complete here)
+        return self.MSM([p1, p2], [1, 1])
+
+    def Affine(self, p):                     # g1.go:157-170 / g2.go:183-200
+        q = self.MSM([p], [1])
+        return None if q == self._jac(None) else (q[0], q[1])
+
+
+G1 = _Group(False)
+G2 = _Group(True)

@@ -9,6 +9,7 @@ namespace gs {
 
 struct PlanBuffers {             // grow-only device workspaces owned by a plan slot
   DevBuf hist, offsets, cursor, entries, tiles, total;
+  DevBuf nseg, seg_off, item_bucket, heavy_list, counters;
 };
 
 struct MsmPlan {                 // digits of one scalar vector, bucket-sorted (device resident)
@@ -18,6 +19,12 @@ struct MsmPlan {                 // digits of one scalar vector, bucket-sorted (
   uint32_t nbuckets = 0;         // W * B
   const uint32_t* offsets = nullptr;   // nbuckets + 1
   const uint32_t* entries = nullptr;
+  uint32_t S = 0;                      // max entries per bucket segment
+  uint32_t nitems = 0;                 // total segments (>= nbuckets)
+  uint32_t nheavy = 0;                 // buckets split into > 1 segment
+  const uint32_t* seg_off = nullptr;   // nbuckets + 1
+  const uint32_t* item_bucket = nullptr;
+  const uint32_t* heavy_list = nullptr;
 };
 
 int choose_window_bits(uint32_t n, int forced);

@@ -53,6 +53,29 @@ void build_plan(Ctx& c, int slot, const uint32_t* scalars_dev, uint32_t n, MsmPl
   GS_HIP(hipGetLastError());
   plan.offsets = pb.offsets.as<uint32_t>();
   plan.entries = pb.entries.as<uint32_t>();
+  // segmentation: cap the work of one accumulate thread at S entries
+  plan.S = std::max<uint32_t>(64u, 4u * (uint32_t)(((size_t)n + plan.B - 1) / plan.B));
+  pb.nseg.ensure(ncount * 4);
+  pb.seg_off.ensure(ncount * 4);
+  pb.counters.ensure(16);
+  hipLaunchKernelGGL(k_seg_count, grid1(ncount), dim3(256), 0, c.stream, plan.offsets, plan.nbuckets, plan.S, pb.nseg.as<uint32_t>());
+  exclusive_scan(c, pb, pb.nseg.as<uint32_t>(), pb.seg_off.as<uint32_t>(), (uint32_t)ncount);
+  const size_t max_items = (size_t)plan.nbuckets + ((size_t)n * plan.W) / plan.S + 1;
+  pb.item_bucket.ensure(max_items * 4);
+  pb.heavy_list.ensure(((size_t)n * plan.W / plan.S + 2) * 4);
+  GS_HIP(hipMemsetAsync(pb.counters.p, 0, 16, c.stream));
+  hipLaunchKernelGGL(k_seg_expand, grid1(plan.nbuckets), dim3(256), 0, c.stream, pb.seg_off.as<uint32_t>(), plan.nbuckets,
+                     pb.item_bucket.as<uint32_t>(), pb.heavy_list.as<uint32_t>(), pb.counters.as<uint32_t>());
+  GS_HIP(hipGetLastError());
+  uint32_t host_counts[2] = {0, 0};
+  GS_HIP(hipMemcpyAsync(&host_counts[0], pb.seg_off.as<uint32_t>() + plan.nbuckets, 4, hipMemcpyDeviceToHost, c.stream));
+  GS_HIP(hipMemcpyAsync(&host_counts[1], pb.counters.p, 4, hipMemcpyDeviceToHost, c.stream));
+  GS_HIP(hipStreamSynchronize(c.stream));
+  plan.nitems = host_counts[0];
+  plan.nheavy = host_counts[1];
+  plan.seg_off = pb.seg_off.as<uint32_t>();
+  plan.item_bucket = pb.item_bucket.as<uint32_t>();
+  plan.heavy_list = pb.heavy_list.as<uint32_t>();
 }
 
 // sum_w 2^(c w) S_w on the host core
@@ -79,17 +102,20 @@ static void msm_run(Ctx& c, const MsmPlan& plan, const std::vector<const uint32_
   for (int j = 0; j < njobs; ++j) {
     DevBuf& bk = c.ws_buckets[(ws_base + j) % 8];
     DevBuf& ch = c.ws_chunks[(ws_base + j) % 8];
-    bk.ensure((size_t)plan.nbuckets * pw * 4);
+    bk.ensure((size_t)plan.nitems * pw * 4);
     ch.ensure((size_t)nchunks * pw * 4);
     jobs.j[j] = AccJob{bases[j], bk.as<uint32_t>(), ch.as<uint32_t>()};
   }
   PhaseTimer tacc(c.stream);
-  hipLaunchKernelGGL(k_bucket_accumulate<T>, dim3((plan.nbuckets + 255) / 256, njobs), dim3(256), 0, c.stream,
-                     jobs, plan.offsets, plan.entries, plan.nbuckets);
+  hipLaunchKernelGGL(k_bucket_accumulate<T>, dim3((plan.nitems + 255) / 256, njobs), dim3(256), 0, c.stream,
+                     jobs, plan.offsets, plan.entries, plan.seg_off, plan.item_bucket, plan.nitems, plan.S);
+  if (plan.nheavy)
+    hipLaunchKernelGGL(k_heavy_combine<T>, dim3(plan.nheavy, njobs), dim3(kHeavyBlock), 0, c.stream,
+                       jobs, plan.seg_off, plan.heavy_list);
   tacc.stop();
   PhaseTimer tred(c.stream);
   hipLaunchKernelGGL(k_bucket_reduce<T>, dim3((nchunks + 255) / 256, njobs), dim3(256), 0, c.stream,
-                     jobs, plan.B, plan.L, nchunks);
+                     jobs, plan.seg_off, plan.B, plan.L, nchunks);
   for (uint32_t half = chunks_per_window / 2; half >= 1; half /= 2) {
     const uint32_t work = (uint32_t)plan.W * half;
     hipLaunchKernelGGL(k_fold<T>, dim3((work + 255) / 256, njobs), dim3(256), 0, c.stream,

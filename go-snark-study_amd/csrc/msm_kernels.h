@@ -9,11 +9,13 @@
 //     k_digit_count   scalars -> signed c-bit digits, histogram per (window, bucket)
 //     scan            exclusive prefix sum -> bucket offsets
 //     k_digit_scatter point index (sign in bit 31) into its bucket's slot (counting sort)
+//     k_seg_count/expand   split buckets with > S entries into segments (load balance)
 //   per base array:
-//     k_bucket_accumulate  one thread per bucket: XYZZ += +-affine base  (8M+2S each)   <- dominant
+//     k_bucket_accumulate  one thread per bucket segment: XYZZ += +-affine base (8M+2S)  <- dominant
+//     k_heavy_combine      one block per split bucket: tree-sum of its segment partials
 //     k_bucket_reduce      per chunk of L buckets: sum_j (b0+j+1) * bucket -> one point
 //     k_fold               pairwise folding of the chunk points -> one point per window
-//     k_horner_finish      sum_w 2^(cw) S_w, to affine, from Montgomery, canonical words
+//     k_gather_window_sums -> host: Horner sum_w 2^(cw) S_w, to affine, from Montgomery
 //
 // HBM layout: bases are AoS packed canonical Montgomery words (G1: 16 x u32 = 64 B/point,
 // G2: 128 B), so a bucket thread gathers each point with 4 (8) 16-byte loads; scalars are the
@@ -134,11 +136,35 @@ __global__ void __launch_bounds__(kScanBlock) k_scan_add(uint32_t* __restrict__ 
   for (int j = 0; j < kScanPerThread; ++j) if (base + j < n) out[base + j] += add;
 }
 
+// ---- bucket segmentation (load balance for skewed scalar distributions) -----------------------------
+// A bucket with more than S entries is split into ceil(cnt/S) segments, each accumulated by its own
+// thread; the segment partials of such "heavy" buckets are then tree-reduced by one block per bucket.
+// (Uniform scalars with c chosen for n give ~all buckets one segment; 0/1-heavy witnesses and the
+// short top window do not.)  Every bucket owns >= 1 item so that item order == bucket order.
+__global__ void __launch_bounds__(256) k_seg_count(const uint32_t* __restrict__ offsets, uint32_t nbuckets, uint32_t S,
+                                                    uint32_t* __restrict__ nseg) {
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b > nbuckets) return;
+  if (b == nbuckets) { nseg[b] = 0; return; }
+  const uint32_t cnt = offsets[b + 1] - offsets[b];
+  nseg[b] = cnt <= S ? 1u : (cnt + S - 1) / S;
+}
+
+__global__ void __launch_bounds__(256) k_seg_expand(const uint32_t* __restrict__ seg_off, uint32_t nbuckets,
+                                                     uint32_t* __restrict__ item_bucket, uint32_t* __restrict__ heavy_list,
+                                                     uint32_t* __restrict__ heavy_count) {
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nbuckets) return;
+  const uint32_t beg = seg_off[b], end = seg_off[b + 1];
+  for (uint32_t i = beg; i < end; ++i) item_bucket[i] = b;
+  if (end - beg > 1) heavy_list[atomicAdd(heavy_count, 1u)] = b;
+}
+
 // ---- bucket accumulation (dominant kernel) ---------------------------------------------------------
 // One thread per bucket; its entries are contiguous in `entries`.  grid.y = base array (job).
 struct AccJob {
   const uint32_t* bases;      // packed affine, already offset to the first term's point
-  uint32_t* buckets;          // nbuckets * kXyzzWords
+  uint32_t* buckets;          // nitems * kXyzzWords: per-segment partial sums; bucket b lives at seg_off[b]
   uint32_t* chunks;           // (W * B / L) * kXyzzWords : per-chunk weighted sums, folded in place
 };
 constexpr int kMaxJobs = 8;
@@ -146,11 +172,18 @@ struct AccJobs { AccJob j[kMaxJobs]; };
 
 template <class T>
 __global__ void __launch_bounds__(256) k_bucket_accumulate(AccJobs jobs, const uint32_t* __restrict__ offsets,
-                                                            const uint32_t* __restrict__ entries, uint32_t nbuckets) {
-  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= nbuckets) return;
+                                                            const uint32_t* __restrict__ entries,
+                                                            const uint32_t* __restrict__ seg_off,
+                                                            const uint32_t* __restrict__ item_bucket,
+                                                            uint32_t nitems, uint32_t S) {
+  const uint32_t it = blockIdx.x * blockDim.x + threadIdx.x;
+  if (it >= nitems) return;
   const AccJob job = jobs.j[blockIdx.y];
-  const uint32_t beg = offsets[b], end = offsets[b + 1];
+  const uint32_t b = item_bucket[it];
+  const uint32_t seg = it - seg_off[b];
+  const uint32_t bend = offsets[b + 1];
+  const uint32_t beg = offsets[b] + seg * S;
+  const uint32_t end = (seg_off[b + 1] - seg_off[b] == 1u) ? bend : min(beg + S, bend);
   Xyzz<T> acc = xyzz_inf<T>();
   for (uint32_t e = beg; e < end; ++e) {
     const uint32_t v = entries[e];
@@ -158,23 +191,52 @@ __global__ void __launch_bounds__(256) k_bucket_accumulate(AccJobs jobs, const u
     const Affine<T> p = PointIO<T>::load_affine(job.bases + (size_t)idx * PointIO<T>::kAffineWords);
     xyzz_madd(acc, p, (v & kSignBit) != 0);
   }
-  store_xyzz<T>(job.buckets + (size_t)b * PointIO<T>::kXyzzWords, acc);
+  store_xyzz<T>(job.buckets + (size_t)it * PointIO<T>::kXyzzWords, acc);
+}
+
+// one block per heavy bucket: partials[seg_off[b] .. seg_off[b+1]) -> partials[seg_off[b]]
+constexpr int kHeavyBlock = 128;
+template <class T>
+__global__ void __launch_bounds__(kHeavyBlock) k_heavy_combine(AccJobs jobs, const uint32_t* __restrict__ seg_off,
+                                                                const uint32_t* __restrict__ heavy_list) {
+  constexpr int pw = PointIO<T>::kXyzzWords;
+  __shared__ uint32_t sh[kHeavyBlock * pw];
+  const AccJob job = jobs.j[blockIdx.y];
+  const uint32_t b = heavy_list[blockIdx.x];
+  const uint32_t beg = seg_off[b], end = seg_off[b + 1];
+  Xyzz<T> acc = xyzz_inf<T>();
+  for (uint32_t i = beg + threadIdx.x; i < end; i += kHeavyBlock) {
+    Xyzz<T> p = load_xyzz<T>(job.buckets + (size_t)i * pw);
+    xyzz_add(acc, p);
+  }
+  store_xyzz<T>(sh + threadIdx.x * pw, acc);
+  __syncthreads();
+  for (int half = kHeavyBlock / 2; half >= 1; half >>= 1) {
+    if ((int)threadIdx.x < half) {
+      Xyzz<T> o = load_xyzz<T>(sh + (threadIdx.x + half) * pw);
+      xyzz_add(acc, o);
+      store_xyzz<T>(sh + threadIdx.x * pw, acc);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) store_xyzz<T>(job.buckets + (size_t)beg * pw, acc);
 }
 
 // ---- bucket reduction -------------------------------------------------------------------------------
 // thread t of window w owns buckets [t*L, (t+1)*L): returns sum_j (t*L + j + 1) * bucket[t*L + j]
 template <class T>
-__global__ void __launch_bounds__(256) k_bucket_reduce(AccJobs jobs, uint32_t B, int L, uint32_t nchunks_total) {
+__global__ void __launch_bounds__(256) k_bucket_reduce(AccJobs jobs, const uint32_t* __restrict__ seg_off,
+                                                        uint32_t B, int L, uint32_t nchunks_total) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;     // chunk index over all windows
   if (t >= nchunks_total) return;
   const AccJob job = jobs.j[blockIdx.y];
   const uint32_t chunks_per_window = B / (uint32_t)L;
   const uint32_t w = t / chunks_per_window, tw = t % chunks_per_window;
   const uint32_t b0 = tw * (uint32_t)L;                          // first bucket (0-based) of the chunk, weight b0+1
-  const uint32_t* src = job.buckets + ((size_t)w * B + b0) * PointIO<T>::kXyzzWords;
+  const uint32_t* so = seg_off + ((size_t)w * B + b0);
   Xyzz<T> run = xyzz_inf<T>(), acc = xyzz_inf<T>();
   for (int j = L - 1; j >= 0; --j) {
-    Xyzz<T> bk = load_xyzz<T>(src + (size_t)j * PointIO<T>::kXyzzWords);
+    Xyzz<T> bk = load_xyzz<T>(job.buckets + (size_t)so[j] * PointIO<T>::kXyzzWords);
     xyzz_add(run, bk);
     xyzz_add(acc, run);
   }

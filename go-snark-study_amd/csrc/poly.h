@@ -1,0 +1,49 @@
+// Internal C++ interface of the Fr polynomial engine (implemented in poly.hip).
+// All pointers are DEVICE pointers to packed elements (8 x u32 words each, value < 2^256).
+#pragma once
+#include "fp29.h"
+#include "runtime.h"
+
+namespace gs {
+
+enum class Form { Std, Mont };
+
+// smallest power of two >= n (n >= 1) and its log2
+int ceil_log2(size_t n);
+
+// Forward NTT of `total` = 2^logt elements, as total / 2^logm independent transforms of size 2^logm
+// (natural order in, bit-reversed out).  In place.
+void ntt_forward(Ctx& c, uint32_t* data, int logt, int logm);
+// Inverse of the above (bit-reversed in, natural out), WITHOUT the 1/N scaling.
+void ntt_inverse_unscaled(Ctx& c, uint32_t* data, int logt, int logm);
+
+// out (na + nb - 1 coefficients) = a * b.  fa/fb: form of the inputs; the output is Montgomery iff
+// both inputs are, standard otherwise.  out may not alias the inputs.  out_cap >= na + nb - 1.
+void poly_mul_dev(Ctx& c, const uint32_t* a, size_t na, Form fa, const uint32_t* b, size_t nb, Form fb, uint32_t* out);
+
+// g = 1 / f mod x^k for f given in MONTGOMERY form (nf coefficients, f[0] != 0); g Montgomery, k coeffs.
+void poly_inv_series_dev(Ctx& c, const uint32_t* f_mont, size_t nf, size_t k, uint32_t* g_mont);
+
+// Cached divisor for repeated quotients by the same monic-or-not polynomial b (e.g. pk.Z):
+struct Divisor {
+  size_t nb = 0;
+  DevBuf b_std;            // nb coefficients, standard form (for remainders)
+  size_t k = 0;            // inverse series known to this many coefficients
+  DevBuf inv_rev_mont;     // 1 / rev(b) mod x^k, Montgomery
+  int logn_spec = 0;       // spectrum cached for NTT size 2^logn_spec (0 = none)
+  size_t k_spec = 0;
+  DevBuf inv_spec;         // NTT of inv_rev_mont[:k_spec] zero padded (bit-reversed order)
+};
+void divisor_init(Ctx& c, Divisor& d, const uint32_t* b_std_dev, size_t nb);
+// quo (na - nb + 1 coefficients, standard form, values < 2r) = floor(a / b); a standard form.
+void poly_quotient_dev(Ctx& c, Divisor& d, const uint32_t* a_std, size_t na, uint32_t* quo_std);
+
+void poly_addsub_dev(Ctx& c, const uint32_t* a, size_t na, const uint32_t* b, size_t nb, bool subtract, uint32_t* out);
+void poly_canon_dev(Ctx& c, uint32_t* x, size_t n, int mode /* 0 canon, 1 to-Montgomery, 2 from-Montgomery */);
+// out[0] = sum_i v[i] x^i (standard in, canonical standard out); x given as ABI words
+void poly_eval_dev(Ctx& c, const uint32_t* v_std, size_t n, const uint64_t x[4], uint32_t* out_dev);
+
+// host-side Fr helpers (same arithmetic as the kernels)
+Fe<ModR, 2> fr_from_words_mont(const uint64_t w[4]);
+
+}  // namespace gs

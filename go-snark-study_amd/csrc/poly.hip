@@ -1,0 +1,227 @@
+// Fr polynomial engine: host orchestration of poly_kernels.h.
+#include "poly.h"
+
+#include <algorithm>
+
+#include "poly_kernels.h"
+
+namespace gs {
+
+static inline dim3 grid1(size_t n, int block = 256) { return dim3((unsigned)((n + block - 1) / block)); }
+
+int ceil_log2(size_t n) {
+  int l = 0;
+  while (((size_t)1 << l) < n) ++l;
+  return l;
+}
+
+static FrConst to_const(const Fe<ModR, 2>& a) {
+  FrConst c;
+  for (int i = 0; i < NL; ++i) c.l[i] = a.l[i];
+  return c;
+}
+Fe<ModR, 2> fr_from_words_mont(const uint64_t w[4]) {
+  uint32_t u[8];
+  for (int i = 0; i < 4; ++i) { u[2 * i] = (uint32_t)w[i]; u[2 * i + 1] = (uint32_t)(w[i] >> 32); }
+  return to_mont(unpack32<ModR>(u));
+}
+static Fe<ModR, 2> fr_small_mont(uint64_t v) {
+  uint64_t w[4] = {v, 0, 0, 0};
+  return fr_from_words_mont(w);
+}
+
+// ---- twiddle tables ---------------------------------------------------------------------------------
+struct Twiddles {
+  int logn = 0;              // tables serve transforms up to 2^logn
+  DevBuf fwd, inv;           // omega^i, omega^-i for i < 2^(logn-1)
+};
+static Twiddles g_tw;
+
+static void ensure_twiddles(Ctx& c, int logn) {
+  if (logn <= g_tw.logn) return;
+  if (logn > ModR::kTwoAdicity) throw HipError{hipErrorInvalidValue, "NTT size exceeds the 2-adicity of Fr (2^28)", __LINE__};
+  logn = std::max(logn, 16);
+  const uint32_t half = 1u << (logn - 1);
+  // omega_{2^logn} = omega_{2^28}^(2^(28-logn))
+  Fe<ModR, 2> w, wi;
+  for (int i = 0; i < NL; ++i) { w.l[i] = ModR::omega28_mont(i); wi.l[i] = ModR::omega28_inv_mont(i); }
+  for (int i = 0; i < ModR::kTwoAdicity - logn; ++i) { w = sqr(w); wi = sqr(wi); }
+  g_tw.fwd.alloc((size_t)half * 32);
+  g_tw.inv.alloc((size_t)half * 32);
+  hipLaunchKernelGGL(k_twiddle_gen, grid1(half), dim3(256), 0, c.stream, g_tw.fwd.as<uint32_t>(), half, to_const(w));
+  hipLaunchKernelGGL(k_twiddle_gen, grid1(half), dim3(256), 0, c.stream, g_tw.inv.as<uint32_t>(), half, to_const(wi));
+  GS_HIP(hipGetLastError());
+  g_tw.logn = logn;
+}
+
+void ntt_forward(Ctx& c, uint32_t* data, int logt, int logm) {
+  if (logm == 0) return;
+  ensure_twiddles(c, logm);
+  const uint32_t nb = 1u << (logt - 1);
+  for (int s = logm - 1; s >= 0; --s) {              // half = 2^s
+    const uint32_t half = 1u << s;
+    const uint32_t stride = (1u << (g_tw.logn - 1)) / half;
+    hipLaunchKernelGGL(k_ntt_dif_stage, grid1(nb), dim3(256), 0, c.stream, data, half, g_tw.fwd.as<uint32_t>(), stride, nb);
+  }
+  GS_HIP(hipGetLastError());
+}
+
+void ntt_inverse_unscaled(Ctx& c, uint32_t* data, int logt, int logm) {
+  if (logm == 0) return;
+  ensure_twiddles(c, logm);
+  const uint32_t nb = 1u << (logt - 1);
+  for (int s = 0; s < logm; ++s) {
+    const uint32_t half = 1u << s;
+    const uint32_t stride = (1u << (g_tw.logn - 1)) / half;
+    hipLaunchKernelGGL(k_ntt_dit_stage, grid1(nb), dim3(256), 0, c.stream, data, half, g_tw.inv.as<uint32_t>(), stride, nb);
+  }
+  GS_HIP(hipGetLastError());
+}
+
+// scale constant s such that mont_mul(y, s) = y * 2^-logn * R^extra   (extra = 0 or 1)
+static FrConst inv_n_const(int logn, int extra_r) {
+  Fe<ModR, 2> v = inv(fr_small_mont(1ull << logn));          // (1/N) R
+  Fe<ModR, 1> r2;
+  for (int i = 0; i < NL; ++i) r2.l[i] = ModR::r2(i);
+  for (int i = 0; i < extra_r; ++i) v = mul(v, r2);          // * R
+  return to_const(v);
+}
+
+static void copy_padded(Ctx& c, const uint32_t* src, size_t n, uint32_t* dst, size_t total) {
+  GS_HIP(hipMemcpyAsync(dst, src, n * 32, hipMemcpyDeviceToDevice, c.stream));
+  if (total > n) GS_HIP(hipMemsetAsync(dst + n * 8, 0, (total - n) * 32, c.stream));
+}
+
+static DevBuf g_ws_a, g_ws_b, g_ws_c, g_ws_d;
+
+void poly_mul_dev(Ctx& c, const uint32_t* a, size_t na, Form fa, const uint32_t* b, size_t nb, Form fb, uint32_t* out) {
+  if (na == 0 || nb == 0) return;
+  const size_t nr = na + nb - 1;
+  const int logn = ceil_log2(nr);
+  const size_t N = (size_t)1 << logn;
+  // mont*mont -> mont needs 1/N ; std*mont -> std needs 1/N ; std*std -> (ab/R) needs R/N
+  const int extra = (fa == Form::Std && fb == Form::Std) ? 1 : 0;
+  g_ws_a.ensure(N * 32);
+  g_ws_b.ensure(N * 32);
+  uint32_t* A = g_ws_a.as<uint32_t>();
+  uint32_t* B = g_ws_b.as<uint32_t>();
+  copy_padded(c, a, na, A, N);
+  copy_padded(c, b, nb, B, N);
+  ntt_forward(c, A, logn, logn);
+  ntt_forward(c, B, logn, logn);
+  hipLaunchKernelGGL(k_pw_mul, grid1(N), dim3(256), 0, c.stream, A, B, A, (uint32_t)N);
+  ntt_inverse_unscaled(c, A, logn, logn);
+  hipLaunchKernelGGL(k_pw_mul_const, grid1(nr), dim3(256), 0, c.stream, A, inv_n_const(logn, extra), out, (uint32_t)nr);
+  GS_HIP(hipGetLastError());
+}
+
+void poly_inv_series_dev(Ctx& c, const uint32_t* f, size_t nf, size_t k, uint32_t* g) {
+  // Newton: g <- g (2 - f g) mod x^(2t), starting from g = 1/f0 mod x
+  Fe<ModR, 6> f0v;
+  uint32_t f0w[8];
+  GS_HIP(hipMemcpyAsync(f0w, f, 32, hipMemcpyDeviceToHost, c.stream));
+  GS_HIP(hipStreamSynchronize(c.stream));
+  f0v = unpack32<ModR>(f0w);
+  if (is_zero(f0v)) throw HipError{hipErrorInvalidValue, "series inverse of a polynomial with zero constant term", __LINE__};
+  Fe<ModR, 2> g0 = inv(reduce2(f0v));                  // Montgomery in, Montgomery out
+  uint32_t g0w[8];
+  {
+    Fe<ModR, 1> cg = canon(g0);
+    pack32<ModR>(cg, g0w);
+  }
+  GS_HIP(hipMemcpyAsync(g, g0w, 32, hipMemcpyHostToDevice, c.stream));
+  GS_HIP(hipStreamSynchronize(c.stream));
+  const FrConst two = to_const(fr_small_mont(2));
+  size_t t = 1;
+  while (t < k) {
+    const size_t t2 = std::min(2 * t, k);
+    const size_t fl = std::min(nf, t2);
+    // e = f[:t2] * g[:t] (length fl + t - 1), keep the first t2 coefficients
+    g_ws_c.ensure((std::max(fl, t2) + t) * 32);
+    g_ws_d.ensure((t2 + t) * 32);
+    uint32_t* E = g_ws_c.as<uint32_t>();
+    uint32_t* U = g_ws_d.as<uint32_t>();
+    poly_mul_dev(c, f, fl, Form::Mont, g, t, Form::Mont, E);
+    const size_t el = std::min(fl + t - 1, t2);
+    hipLaunchKernelGGL(k_two_minus, grid1(t2), dim3(256), 0, c.stream, E, two, U, (uint32_t)el, (uint32_t)t2);
+    // g_new = g * u mod x^t2
+    poly_mul_dev(c, g, t, Form::Mont, U, t2, Form::Mont, E);
+    GS_HIP(hipMemcpyAsync(g, E, t2 * 32, hipMemcpyDeviceToDevice, c.stream));
+    t = t2;
+  }
+  GS_HIP(hipGetLastError());
+}
+
+void divisor_init(Ctx& c, Divisor& d, const uint32_t* b_std_dev, size_t nb) {
+  d.nb = nb;
+  d.b_std.alloc(nb * 32);
+  GS_HIP(hipMemcpyAsync(d.b_std.p, b_std_dev, nb * 32, hipMemcpyDeviceToDevice, c.stream));
+  d.k = 0;
+  d.logn_spec = 0;
+  d.k_spec = 0;
+}
+
+static void divisor_ensure(Ctx& c, Divisor& d, size_t k) {
+  if (k <= d.k) return;
+  // f = rev(b) in Montgomery form, only the first min(nb, k) coefficients matter
+  const size_t fl = std::min(d.nb, k);
+  DevBuf f(fl * 32);
+  hipLaunchKernelGGL(k_copy_reversed, grid1(fl), dim3(256), 0, c.stream, d.b_std.as<uint32_t>(), (uint32_t)(d.nb - fl), (uint32_t)fl,
+                     f.as<uint32_t>(), (uint32_t)fl);
+  poly_canon_dev(c, f.as<uint32_t>(), fl, 1);
+  d.inv_rev_mont.alloc(k * 32);
+  poly_inv_series_dev(c, f.as<uint32_t>(), fl, k, d.inv_rev_mont.as<uint32_t>());
+  GS_HIP(hipStreamSynchronize(c.stream));
+  d.k = k;
+  d.logn_spec = 0;
+}
+
+void poly_quotient_dev(Ctx& c, Divisor& d, const uint32_t* a, size_t na, uint32_t* quo) {
+  if (na < d.nb) return;
+  const size_t k = na - d.nb + 1;
+  divisor_ensure(c, d, k);
+  const int logn = ceil_log2(2 * k - 1);
+  const size_t N = (size_t)1 << logn;
+  if (d.logn_spec != logn || d.k_spec != k) {
+    d.inv_spec.alloc(N * 32);
+    copy_padded(c, d.inv_rev_mont.as<uint32_t>(), k, d.inv_spec.as<uint32_t>(), N);
+    ntt_forward(c, d.inv_spec.as<uint32_t>(), logn, logn);
+    d.logn_spec = logn;
+    d.k_spec = k;
+  }
+  g_ws_a.ensure(N * 32);
+  uint32_t* A = g_ws_a.as<uint32_t>();
+  // A = rev(a)[:k] = a[na-1], a[na-2], ..., a[na-k]  zero padded to N   (standard form)
+  hipLaunchKernelGGL(k_copy_reversed, grid1(N), dim3(256), 0, c.stream, a, (uint32_t)(na - k), (uint32_t)k, A, (uint32_t)N);
+  ntt_forward(c, A, logn, logn);
+  hipLaunchKernelGGL(k_pw_mul, grid1(N), dim3(256), 0, c.stream, A, d.inv_spec.as<uint32_t>(), A, (uint32_t)N);
+  ntt_inverse_unscaled(c, A, logn, logn);
+  // scale by 1/N and un-reverse the first k coefficients: quo[i] = A[k-1-i] / N
+  g_ws_b.ensure(k * 32);
+  hipLaunchKernelGGL(k_copy_reversed, grid1(k), dim3(256), 0, c.stream, A, 0u, (uint32_t)k, g_ws_b.as<uint32_t>(), (uint32_t)k);
+  hipLaunchKernelGGL(k_pw_mul_const, grid1(k), dim3(256), 0, c.stream, g_ws_b.as<uint32_t>(), inv_n_const(logn, 0), quo, (uint32_t)k);
+  GS_HIP(hipGetLastError());
+}
+
+void poly_addsub_dev(Ctx& c, const uint32_t* a, size_t na, const uint32_t* b, size_t nb, bool subtract, uint32_t* out) {
+  const size_t n = std::max(na, nb);
+  if (n) hipLaunchKernelGGL(k_addsub, grid1(n), dim3(256), 0, c.stream, a, (uint32_t)na, b, (uint32_t)nb, subtract ? 1 : 0, out, (uint32_t)n);
+  GS_HIP(hipGetLastError());
+}
+
+void poly_canon_dev(Ctx& c, uint32_t* x, size_t n, int mode) {
+  if (n) hipLaunchKernelGGL(k_convert, grid1(n), dim3(256), 0, c.stream, x, (uint32_t)n, mode);
+  GS_HIP(hipGetLastError());
+}
+
+void poly_eval_dev(Ctx& c, const uint32_t* v, size_t n, const uint64_t x[4], uint32_t* out_dev) {
+  const uint32_t nchunks = (uint32_t)((n + kEvalChunk - 1) / kEvalChunk);
+  if (nchunks == 0) { GS_HIP(hipMemsetAsync(out_dev, 0, 32, c.stream)); return; }
+  g_ws_c.ensure((size_t)nchunks * 32);
+  hipLaunchKernelGGL(k_eval_chunks, grid1(nchunks), dim3(256), 0, c.stream, v, (uint32_t)n, to_const(fr_from_words_mont(x)),
+                     g_ws_c.as<uint32_t>(), nchunks);
+  hipLaunchKernelGGL(k_sum_block, dim3(1), dim3(256), 0, c.stream, g_ws_c.as<uint32_t>(), nchunks, out_dev);
+  GS_HIP(hipGetLastError());
+}
+
+}  // namespace gs

@@ -1,0 +1,189 @@
+// Fr polynomial kernels for gfx950: radix-2 NTT stages (batched), point-wise products, series
+// helpers.  Replaces the reference's dense big.Int polynomial arithmetic
+// (r1csqap/r1csqap.go:57-126: schoolbook Mul O(n^2), long Div O(n^3), Eval with Exp per term).
+//
+// Element format in HBM: 8 x u32 words, value < 2^256 (any representative of the residue; the
+// kernels keep values < 2r).  The NTT is linear, so data may be in standard OR Montgomery form:
+// twiddles are always Montgomery, and mont_mul(x, w R) = x w preserves the form of x.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "fp29.h"
+
+namespace gs {
+
+using Fr6 = Fe<ModR, 6>;     // anything loaded from memory (2^256 < 6 r)
+using Fr2 = Fe<ModR, 2>;
+
+GS_HD Fr6 load_fr(const uint32_t* p) {
+  const uint4* q = reinterpret_cast<const uint4*>(p);
+  const uint4 lo = q[0], hi = q[1];
+  uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  return unpack32<ModR>(w);
+}
+// store a value < 2r (fully carried, not necessarily canonical)
+GS_HD void store_fr(uint32_t* p, const Fr2& a) {
+  Fr2 x = a;
+  carry_full(x);
+  Fe<ModR, 1> y;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) y.l[i] = x.l[i];
+  uint32_t w[8];
+  pack32<ModR>(y, w);
+  uint4* q = reinterpret_cast<uint4*>(p);
+  q[0] = make_uint4(w[0], w[1], w[2], w[3]);
+  q[1] = make_uint4(w[4], w[5], w[6], w[7]);
+}
+GS_HD void store_fr_canon(uint32_t* p, const Fe<ModR, 1>& a) {
+  uint32_t w[8];
+  pack32<ModR>(a, w);
+  uint4* q = reinterpret_cast<uint4*>(p);
+  q[0] = make_uint4(w[0], w[1], w[2], w[3]);
+  q[1] = make_uint4(w[4], w[5], w[6], w[7]);
+}
+
+struct FrConst { uint32_t l[NL]; };      // kernel-argument form of an Fr element (Montgomery limbs)
+GS_HD Fr2 from_const(const FrConst& c) {
+  Fr2 r;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) r.l[i] = c.l[i];
+  return r;
+}
+
+// tw[i] = omega^i (Montgomery), i < count, omega given as a constant
+__global__ void __launch_bounds__(256) k_twiddle_gen(uint32_t* __restrict__ tw, uint32_t count, FrConst omega) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  Fr2 base = from_const(omega), acc = relax<2>(fe_one<ModR>());
+  for (uint32_t e = i; e != 0; e >>= 1) {
+    if (e & 1u) acc = mul(acc, base);
+    base = sqr(base);
+  }
+  store_fr_canon(tw + (size_t)i * 8, canon(acc));
+}
+
+// decimation-in-frequency stage (forward): natural order in, bit-reversed out after all stages.
+// butterfly t: blk = t / half, j = t % half; (a, b) -> (a + b, (a - b) * w^(j * tw_stride))
+__global__ void __launch_bounds__(256) k_ntt_dif_stage(uint32_t* __restrict__ x, uint32_t half, const uint32_t* __restrict__ tw,
+                                                        uint32_t tw_stride, uint32_t nbutterflies) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nbutterflies) return;
+  const uint32_t blk = t / half, j = t - blk * half;
+  uint32_t* p0 = x + ((size_t)blk * 2 * half + j) * 8;
+  uint32_t* p1 = p0 + (size_t)half * 8;
+  const Fr6 a = load_fr(p0), b = load_fr(p1);
+  const Fr6 w = load_fr(tw + (size_t)j * tw_stride * 8);
+  store_fr(p0, reduce2(add(a, b)));
+  store_fr(p1, mul(sub(a, b), w));
+}
+
+// decimation-in-time stage (inverse): bit-reversed in, natural out.  (a, b) -> (a + b w, a - b w)
+__global__ void __launch_bounds__(256) k_ntt_dit_stage(uint32_t* __restrict__ x, uint32_t half, const uint32_t* __restrict__ tw,
+                                                        uint32_t tw_stride, uint32_t nbutterflies) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nbutterflies) return;
+  const uint32_t blk = t / half, j = t - blk * half;
+  uint32_t* p0 = x + ((size_t)blk * 2 * half + j) * 8;
+  uint32_t* p1 = p0 + (size_t)half * 8;
+  const Fr6 a = load_fr(p0), b = load_fr(p1);
+  const Fr6 w = load_fr(tw + (size_t)j * tw_stride * 8);
+  const Fr2 bw = mul(b, w);
+  store_fr(p0, reduce2(add(a, bw)));
+  store_fr(p1, reduce2(sub(a, bw)));
+}
+
+// out[i] = a[i] * b[i] (Montgomery product: a b / R)
+__global__ void __launch_bounds__(256) k_pw_mul(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b,
+                                                 uint32_t* __restrict__ out, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  store_fr(out + (size_t)i * 8, mul(load_fr(a + (size_t)i * 8), load_fr(b + (size_t)i * 8)));
+}
+// out[i] = a[i] * k
+__global__ void __launch_bounds__(256) k_pw_mul_const(const uint32_t* __restrict__ a, FrConst k, uint32_t* __restrict__ out, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  store_fr(out + (size_t)i * 8, mul(load_fr(a + (size_t)i * 8), from_const(k)));
+}
+// out[i] = a[i] +- b[i]; missing tails are zero (lengths na, nb; out has max(na, nb))
+__global__ void __launch_bounds__(256) k_addsub(const uint32_t* __restrict__ a, uint32_t na, const uint32_t* __restrict__ b, uint32_t nb,
+                                                 int subtract, uint32_t* __restrict__ out, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const Fr6 x = (i < na) ? load_fr(a + (size_t)i * 8) : fe_zero<ModR, 6>();
+  const Fr6 y = (i < nb) ? load_fr(b + (size_t)i * 8) : fe_zero<ModR, 6>();
+  if (subtract) store_fr(out + (size_t)i * 8, reduce2(sub(x, y)));
+  else store_fr(out + (size_t)i * 8, reduce2(add(x, y)));
+}
+// dst[i] = src[first + count - 1 - i] for i < count, 0 for count <= i < total
+__global__ void __launch_bounds__(256) k_copy_reversed(const uint32_t* __restrict__ src, uint32_t first, uint32_t count,
+                                                        uint32_t* __restrict__ dst, uint32_t total) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  uint4* d = reinterpret_cast<uint4*>(dst + (size_t)i * 8);
+  if (i < count) {
+    const uint4* s = reinterpret_cast<const uint4*>(src + (size_t)(first + count - 1 - i) * 8);
+    d[0] = s[0]; d[1] = s[1];
+  } else {
+    d[0] = make_uint4(0, 0, 0, 0); d[1] = d[0];
+  }
+}
+// in place: x[i] -> canonical representative in [0, r); optional Montgomery conversions
+// mode 0: canon only, 1: to Montgomery (x R), 2: from Montgomery (x / R)
+__global__ void __launch_bounds__(256) k_convert(uint32_t* __restrict__ x, uint32_t n, int mode) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const Fr6 v = load_fr(x + (size_t)i * 8);
+  if (mode == 1) store_fr_canon(x + (size_t)i * 8, canon(to_mont(v)));
+  else if (mode == 2) store_fr_canon(x + (size_t)i * 8, from_mont(v));
+  else store_fr_canon(x + (size_t)i * 8, canon(v));
+}
+// Newton step helper: u = 2 - e  (coefficient-wise: u_0 = two - e_0, u_i = -e_i), i < n
+__global__ void __launch_bounds__(256) k_two_minus(const uint32_t* __restrict__ e, FrConst two, uint32_t* __restrict__ out, uint32_t n, uint32_t total) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  if (i >= n) { store_fr(out + (size_t)i * 8, fe_zero<ModR, 2>()); return; }
+  const Fr6 v = load_fr(e + (size_t)i * 8);
+  if (i == 0) store_fr(out, reduce2(sub(from_const(two), v)));
+  else store_fr(out + (size_t)i * 8, reduce2(neg(v)));
+}
+
+// ---- evaluation: sum_i v_i x^i  (r1csqap.go:118-126) ------------------------------------------------
+constexpr int kEvalChunk = 64;
+// partial[t] = x^(t*chunk) * sum_{i<chunk} v[t*chunk+i] x^i      (v standard form, x Montgomery -> standard)
+__global__ void __launch_bounds__(256) k_eval_chunks(const uint32_t* __restrict__ v, uint32_t n, FrConst xm, uint32_t* __restrict__ partial, uint32_t nchunks) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nchunks) return;
+  const Fr2 x = from_const(xm);
+  const uint32_t beg = t * kEvalChunk, end = min(n, beg + kEvalChunk);
+  Fr2 acc = fe_zero<ModR, 2>();
+  for (uint32_t i = end; i > beg; --i) acc = reduce2(add(mul(acc, x), load_fr(v + (size_t)(i - 1) * 8)));
+  Fr2 base = x, p = relax<2>(fe_one<ModR>());
+  for (uint32_t e = beg; e != 0; e >>= 1) { if (e & 1u) p = mul(p, base); base = sqr(base); }
+  // acc is standard form, p is Montgomery: product is standard form
+  store_fr(partial + (size_t)t * 8, mul(acc, p));
+}
+// single block: out[0] = sum partial[i]
+__global__ void __launch_bounds__(256) k_sum_block(const uint32_t* __restrict__ partial, uint32_t n, uint32_t* __restrict__ out) {
+  __shared__ uint32_t sh[256 * NL];
+  Fr2 acc = fe_zero<ModR, 2>();
+  for (uint32_t i = threadIdx.x; i < n; i += 256) acc = reduce2(add(acc, load_fr(partial + (size_t)i * 8)));
+#pragma unroll
+  for (int k = 0; k < NL; ++k) sh[threadIdx.x * NL + k] = acc.l[k];
+  __syncthreads();
+  for (int half = 128; half >= 1; half >>= 1) {
+    if ((int)threadIdx.x < half) {
+      Fr2 o;
+#pragma unroll
+      for (int k = 0; k < NL; ++k) o.l[k] = sh[(threadIdx.x + half) * NL + k];
+      acc = reduce2(add(acc, o));
+#pragma unroll
+      for (int k = 0; k < NL; ++k) sh[threadIdx.x * NL + k] = acc.l[k];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) store_fr_canon(out, canon(acc));
+}
+
+}  // namespace gs

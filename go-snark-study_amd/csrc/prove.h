@@ -1,0 +1,27 @@
+// Internal: device-resident proving keys and the prover drivers (implemented in prove.hip).
+#pragma once
+#include "msm.h"
+#include "poly.h"
+#include "runtime.h"
+
+namespace gs {
+
+struct GrothPkObj : Object {      // groth16.Pk (groth16/groth16.go:15-32), resident
+  size_t nvars = 0, npublic = 0, nz = 0, nptd = 0;
+  DevBuf at, bacgamma1, bacdelta, ptd;     // packed affine G1 (owned copies)
+  DevBuf bacgamma2;                        // packed affine G2
+  G1Affine alpha, beta, delta;             // host, Montgomery
+  G2Affine beta2, delta2;
+  Divisor z;                               // pk.Z with cached 1/rev(Z) series + spectrum
+  GrothPkObj() : Object(Kind::GrothPk) {}
+};
+
+struct PinocchioPkObj : Object {  // snark.Pk (snark.go:16-26), resident
+  size_t nvars = 0, npublic = 0, nz = 0, ng1t = 0;
+  DevBuf a, ap, bp, c, cp, kp, g1t;        // packed affine G1
+  DevBuf b2;                               // packed affine G2
+  Divisor z;
+  PinocchioPkObj() : Object(Kind::PinocchioPk) {}
+};
+
+}  // namespace gs

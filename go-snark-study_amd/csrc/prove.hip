@@ -1,0 +1,363 @@
+// Groth16 / Pinocchio provers on top of the MSM and polynomial engines, plus the extern "C"
+// polynomial entry points.  Replaces groth16.GenerateProofs (groth16/groth16.go:225-278) and
+// snark.GenerateProofs (snark.go:254-289).
+#include "prove.h"
+
+#include <algorithm>
+#include <vector>
+
+#include "point_io.h"
+
+using namespace gs;
+
+namespace {
+
+constexpr size_t kG1Aff = 16, kG2Aff = 32;      // u32 words per packed affine point
+
+// copy n packed points [off, off+n) of a base handle into an owned buffer
+void copy_points(Ctx& c, const Bases* b, size_t words, DevBuf& dst) {
+  dst.alloc(std::max<size_t>(b->n, 1) * words * 4);
+  if (b->n) GS_HIP(hipMemcpyAsync(dst.p, b->buf.p, b->n * words * 4, hipMemcpyDeviceToDevice, c.stream));
+}
+
+struct DevScalars {            // a resident scalar vector used by a prove call (not owned)
+  const uint32_t* p;
+  size_t n;
+};
+
+// hx = floor(px / Z) on the device, returned as a workspace pointer (standard form, nz-dependent length)
+DevBuf g_hx;
+
+size_t quotient_len(size_t npx, size_t nz) { return npx >= nz ? npx - nz + 1 : 0; }
+
+int groth16_prove_impl(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, const uint64_t r[4], const uint64_t s[4],
+                       uint64_t out_proof[32], int inf[3]) {
+  if (w.n != pk->nvars) return fail(GS_ERR_SHAPE, "len(w) = %zu but the key has %zu variables", w.n, pk->nvars);
+  const size_t nh = quotient_len(px.n, pk->nz);
+  if (nh > pk->nptd)
+    return fail(GS_ERR_SHAPE, "len(hx) = len(px) - len(Z) + 1 = %zu exceeds len(PowersTauDelta) = %zu (groth16.go:269-271)", nh, pk->nptd);
+  PhaseTimer total(c.stream);
+  // --- H(x) = P(x) / Z(x)   (groth16.go:266) -------------------------------------------------------
+  {
+    PhaseTimer tp(c.stream);
+    g_hx.ensure(std::max<size_t>(nh, 1) * 32);
+    if (nh) poly_quotient_dev(c, pk->z, px.p, px.n, g_hx.as<uint32_t>());
+    tp.stop();
+    c.timing.poly_ms += tp.ms();
+  }
+  // --- the five MSMs (groth16.go:243-250, 269-271) --------------------------------------------------
+  MsmPlan plan_w, plan_h;
+  {
+    PhaseTimer tp(c.stream);
+    build_plan(c, 0, w.p, (uint32_t)w.n, plan_w);
+    build_plan(c, 1, g_hx.as<uint32_t>(), (uint32_t)nh, plan_h);
+    tp.stop();
+    c.timing.plan_ms += tp.ms();
+  }
+  std::vector<G1Xyzz> g1w, g1h;
+  std::vector<G2Xyzz> g2w;
+  // BACDelta's first npublic+1 entries are forced to infinity at key creation, so the reference's
+  // loop from NPublic+1 (:248-250) equals a full-range MSM sharing w's plan.
+  msm_run_g1(c, plan_w, {pk->at.as<uint32_t>(), pk->bacgamma1.as<uint32_t>(), pk->bacdelta.as<uint32_t>()}, g1w);
+  msm_run_g2(c, plan_w, {pk->bacgamma2.as<uint32_t>()}, g2w);
+  msm_run_g1(c, plan_h, {pk->ptd.as<uint32_t>()}, g1h);
+  // --- O(1) tail on the host core (groth16.go:253-275) ----------------------------------------------
+  G1Xyzz delta = xyzz_from_affine(pk->delta);
+  G2Xyzz delta2 = xyzz_from_affine(pk->delta2);
+  G1Xyzz piA = g1w[0];
+  xyzz_madd(piA, pk->alpha);                                   // + alpha          :253
+  G1Xyzz rdelta = g1_mul_scalar(delta, r);
+  xyzz_add(piA, rdelta);                                       // + r delta        :254-255
+  G1Xyzz piB1 = g1w[1];
+  xyzz_madd(piB1, pk->beta);                                   // + beta           :259
+  G1Xyzz sdelta = g1_mul_scalar(delta, s);
+  xyzz_add(piB1, sdelta);                                      // + s delta        :261-262
+  G2Xyzz piB = g2w[0];
+  xyzz_madd(piB, pk->beta2);                                   // + beta2          :260
+  G2Xyzz sdelta2 = g2_mul_scalar(delta2, s);
+  xyzz_add(piB, sdelta2);                                      // + s delta2       :263-264
+  G1Xyzz piC = g1w[2];
+  xyzz_add(piC, g1h[0]);                                       // + sum h_i PTD_i  :269-271
+  G1Xyzz sA = g1_mul_scalar(piA, s);
+  xyzz_add(piC, sA);                                           // + s piA          :272
+  G1Xyzz rB = g1_mul_scalar(piB1, r);
+  xyzz_add(piC, rB);                                           // + r piB1         :273
+  // - (r s) delta = -(s (r delta))                                                  :274-275
+  G1Xyzz rsdelta = g1_mul_scalar(rdelta, s);
+  xyzz_add(piC, xyzz_neg(rsdelta));
+  inf[0] = g1_to_affine_std(piA, out_proof) ? 1 : 0;
+  inf[1] = g2_to_affine_std(piB, out_proof + 8) ? 1 : 0;
+  inf[2] = g1_to_affine_std(piC, out_proof + 24) ? 1 : 0;
+  total.stop();
+  c.timing.total_ms += total.ms();
+  return GS_OK;
+}
+
+int pinocchio_prove_impl(Ctx& c, PinocchioPkObj* pk, DevScalars w, DevScalars px, uint64_t out[72], int inf[8]) {
+  if (w.n != pk->nvars) return fail(GS_ERR_SHAPE, "len(w) = %zu but the key has %zu variables", w.n, pk->nvars);
+  const size_t nh = quotient_len(px.n, pk->nz);
+  if (nh > pk->ng1t) return fail(GS_ERR_SHAPE, "len(hx) = %zu exceeds len(G1T) = %zu (snark.go:284-286)", nh, pk->ng1t);
+  PhaseTimer total(c.stream);
+  {
+    PhaseTimer tp(c.stream);
+    g_hx.ensure(std::max<size_t>(nh, 1) * 32);
+    if (nh) poly_quotient_dev(c, pk->z, px.p, px.n, g_hx.as<uint32_t>());          // snark.go:280
+    tp.stop();
+    c.timing.poly_ms += tp.ms();
+  }
+  MsmPlan plan_w, plan_h;
+  {
+    PhaseTimer tp(c.stream);
+    build_plan(c, 0, w.p, (uint32_t)w.n, plan_w);
+    build_plan(c, 1, g_hx.as<uint32_t>(), (uint32_t)nh, plan_h);
+    tp.stop();
+    c.timing.plan_ms += tp.ms();
+  }
+  std::vector<G1Xyzz> g1w, g1h;
+  std::vector<G2Xyzz> g2w;
+  // A and Ap run over i > NPublic only (snark.go:265-268): their first npublic+1 points were forced
+  // to infinity at key creation; Bp, C, Cp, Kp and B run over all variables (:270-278).
+  msm_run_g1(c, plan_w, {pk->a.as<uint32_t>(), pk->ap.as<uint32_t>(), pk->bp.as<uint32_t>(), pk->c.as<uint32_t>(),
+                         pk->cp.as<uint32_t>(), pk->kp.as<uint32_t>()}, g1w);
+  msm_run_g2(c, plan_w, {pk->b2.as<uint32_t>()}, g2w);
+  msm_run_g1(c, plan_h, {pk->g1t.as<uint32_t>()}, g1h);                            // :284-286
+  // output order: PiA | PiAp | PiB | PiBp | PiC | PiCp | PiH | PiKp
+  inf[0] = g1_to_affine_std(g1w[0], out) ? 1 : 0;
+  inf[1] = g1_to_affine_std(g1w[1], out + 8) ? 1 : 0;
+  inf[2] = g2_to_affine_std(g2w[0], out + 16) ? 1 : 0;
+  inf[3] = g1_to_affine_std(g1w[2], out + 32) ? 1 : 0;
+  inf[4] = g1_to_affine_std(g1w[3], out + 40) ? 1 : 0;
+  inf[5] = g1_to_affine_std(g1w[4], out + 48) ? 1 : 0;
+  inf[6] = g1_to_affine_std(g1h[0], out + 56) ? 1 : 0;
+  inf[7] = g1_to_affine_std(g1w[5], out + 64) ? 1 : 0;
+  total.stop();
+  c.timing.total_ms += total.ms();
+  return GS_OK;
+}
+
+// zero the first `count` packed points (-> infinity)
+void force_infinity(Ctx& c, DevBuf& pts, size_t count, size_t words) {
+  if (count) GS_HIP(hipMemsetAsync(pts.p, 0, count * words * 4, c.stream));
+}
+
+// upload host scalars into a scratch buffer
+DevBuf g_up_w, g_up_px, g_up_a, g_up_b, g_up_o;
+const uint32_t* upload_tmp(Ctx& c, DevBuf& buf, const uint64_t* host, size_t n) {
+  buf.ensure(std::max<size_t>(n, 1) * 32);
+  if (n) {
+    PhaseTimer th(c.stream);
+    GS_HIP(hipMemcpyAsync(buf.p, host, n * 32, hipMemcpyHostToDevice, c.stream));
+    th.stop();
+    c.timing.h2d_ms += th.ms();
+  }
+  return buf.as<uint32_t>();
+}
+void download(Ctx& c, uint64_t* host, const void* dev, size_t n) {
+  if (n) GS_HIP(hipMemcpyAsync(host, dev, n * 32, hipMemcpyDeviceToHost, c.stream));
+  GS_HIP(hipStreamSynchronize(c.stream));
+}
+
+}  // namespace
+
+extern "C" {
+
+// ---- polynomial field ------------------------------------------------------------------------------------
+int gs_poly_mul(const uint64_t* a, size_t na, const uint64_t* b, size_t nb, uint64_t* out) {
+  return guarded([&](Ctx& c) -> int {
+    if (!a || !b || !out || na == 0 || nb == 0) return fail(GS_ERR_ARG, "gs_poly_mul: empty or null operand");
+    if (na + nb > (1ull << 27)) return fail(GS_ERR_ARG, "gs_poly_mul: product too large");
+    const uint32_t* da = upload_tmp(c, g_up_a, a, na);
+    const uint32_t* db = upload_tmp(c, g_up_b, b, nb);
+    const size_t nr = na + nb - 1;
+    g_up_o.ensure(nr * 32);
+    poly_mul_dev(c, da, na, Form::Std, db, nb, Form::Std, g_up_o.as<uint32_t>());
+    poly_canon_dev(c, g_up_o.as<uint32_t>(), nr, 0);
+    download(c, out, g_up_o.p, nr);
+    return GS_OK;
+  });
+}
+
+int gs_poly_div(const uint64_t* a, size_t na, const uint64_t* b, size_t nb, uint64_t* quo, uint64_t* rem) {
+  return guarded([&](Ctx& c) -> int {
+    if (!a || !b || !quo || nb == 0 || na < nb) return fail(GS_ERR_ARG, "gs_poly_div: need len(a) >= len(b) >= 1");
+    bool lead_zero = true;
+    for (int i = 0; i < 4; ++i) lead_zero = lead_zero && b[4 * (nb - 1) + i] == 0;
+    if (lead_zero) return fail(GS_ERR_ARG, "gs_poly_div: leading coefficient of the divisor is zero");
+    const uint32_t* da = upload_tmp(c, g_up_a, a, na);
+    const uint32_t* db = upload_tmp(c, g_up_b, b, nb);
+    Divisor d;
+    divisor_init(c, d, db, nb);
+    const size_t nq = na - nb + 1;
+    g_up_o.ensure((nq + na + nb) * 32);
+    uint32_t* q = g_up_o.as<uint32_t>();
+    poly_quotient_dev(c, d, da, na, q);
+    if (rem && nb > 1) {
+      // rem = (a - q b) mod x^(nb-1)        (r1csqap.go:70-84 returns the final `rem`)
+      uint32_t* qb = q + nq * 8;
+      poly_mul_dev(c, q, nq, Form::Std, db, nb, Form::Std, qb);
+      uint32_t* rr = qb + (nq + nb) * 8 - 8 * 0;
+      (void)rr;
+      DevBuf rbuf((nb - 1) * 32);
+      poly_addsub_dev(c, da, nb - 1, qb, nb - 1, true, rbuf.as<uint32_t>());
+      poly_canon_dev(c, rbuf.as<uint32_t>(), nb - 1, 0);
+      GS_HIP(hipMemcpyAsync(rem, rbuf.p, (nb - 1) * 32, hipMemcpyDeviceToHost, c.stream));
+      GS_HIP(hipStreamSynchronize(c.stream));
+    }
+    poly_canon_dev(c, q, nq, 0);
+    download(c, quo, q, nq);
+    return GS_OK;
+  });
+}
+
+static int addsub_api(const uint64_t* a, size_t na, const uint64_t* b, size_t nb, uint64_t* out, bool sub) {
+  return guarded([&](Ctx& c) -> int {
+    if ((na && !a) || (nb && !b) || !out) return fail(GS_ERR_ARG, "null operand");
+    const size_t n = std::max(na, nb);
+    if (n == 0) return GS_OK;
+    const uint32_t* da = upload_tmp(c, g_up_a, a, na);
+    const uint32_t* db = upload_tmp(c, g_up_b, b, nb);
+    g_up_o.ensure(n * 32);
+    poly_addsub_dev(c, da, na, db, nb, sub, g_up_o.as<uint32_t>());
+    poly_canon_dev(c, g_up_o.as<uint32_t>(), n, 0);
+    download(c, out, g_up_o.p, n);
+    return GS_OK;
+  });
+}
+int gs_poly_add(const uint64_t* a, size_t na, const uint64_t* b, size_t nb, uint64_t* out) { return addsub_api(a, na, b, nb, out, false); }
+int gs_poly_sub(const uint64_t* a, size_t na, const uint64_t* b, size_t nb, uint64_t* out) { return addsub_api(a, na, b, nb, out, true); }
+
+int gs_poly_eval(const uint64_t* v, size_t n, const uint64_t x[4], uint64_t out[4]) {
+  return guarded([&](Ctx& c) -> int {
+    if ((n && !v) || !x || !out) return fail(GS_ERR_ARG, "null operand");
+    const uint32_t* dv = upload_tmp(c, g_up_a, v, n);
+    g_up_o.ensure(32);
+    poly_eval_dev(c, dv, n, x, g_up_o.as<uint32_t>());
+    download(c, out, g_up_o.p, 1);
+    return GS_OK;
+  });
+}
+
+// ---- Groth16 ----------------------------------------------------------------------------------------------
+int gs_groth16_pk_create(gs_handle g1_at, gs_handle g1_bacgamma, gs_handle g2_bacgamma, gs_handle bacdelta, gs_handle ptd,
+                         const uint64_t g1_alpha[12], const uint64_t g1_beta[12], const uint64_t g1_delta[12],
+                         const uint64_t g2_beta[24], const uint64_t g2_delta[24], const uint64_t* z, size_t nz,
+                         size_t nvars, size_t npublic, gs_handle* out) {
+  return guarded([&](Ctx& c) -> int {
+    Bases* at = c.get<Bases>(g1_at, Kind::G1Bases);
+    Bases* b1 = c.get<Bases>(g1_bacgamma, Kind::G1Bases);
+    Bases* b2 = c.get<Bases>(g2_bacgamma, Kind::G2Bases);
+    Bases* cd = c.get<Bases>(bacdelta, Kind::G1Bases);
+    Bases* pt = c.get<Bases>(ptd, Kind::G1Bases);
+    if (!at || !b1 || !b2 || !cd || !pt) return fail(GS_ERR_ARG, "gs_groth16_pk_create: bad base handle");
+    if (!g1_alpha || !g1_beta || !g1_delta || !g2_beta || !g2_delta || !z || !out || nz == 0) return fail(GS_ERR_ARG, "null argument");
+    if (at->n != nvars || b1->n != nvars || b2->n != nvars || cd->n != nvars)
+      return fail(GS_ERR_SHAPE, "At/BACGamma/BACDelta must have NVars = %zu points (got %zu/%zu/%zu/%zu)", nvars, at->n, b1->n, b2->n, cd->n);
+    if (npublic + 1 > nvars) return fail(GS_ERR_SHAPE, "NPublic + 1 > NVars");
+    bool lead_zero = true;
+    for (int i = 0; i < 4; ++i) lead_zero = lead_zero && z[4 * (nz - 1) + i] == 0;
+    if (lead_zero) return fail(GS_ERR_ARG, "leading coefficient of Z is zero");
+    auto pk = std::make_unique<GrothPkObj>();
+    pk->nvars = nvars; pk->npublic = npublic; pk->nz = nz; pk->nptd = pt->n;
+    copy_points(c, at, kG1Aff, pk->at);
+    copy_points(c, b1, kG1Aff, pk->bacgamma1);
+    copy_points(c, cd, kG1Aff, pk->bacdelta);
+    copy_points(c, pt, kG1Aff, pk->ptd);
+    copy_points(c, b2, kG2Aff, pk->bacgamma2);
+    force_infinity(c, pk->bacdelta, npublic + 1, kG1Aff);          // groth16.go:177-180 / :248
+    pk->alpha = g1_affine_from_jacobian_std(g1_alpha);
+    pk->beta = g1_affine_from_jacobian_std(g1_beta);
+    pk->delta = g1_affine_from_jacobian_std(g1_delta);
+    pk->beta2 = g2_affine_from_jacobian_std(g2_beta);
+    pk->delta2 = g2_affine_from_jacobian_std(g2_delta);
+    const uint32_t* dz = upload_tmp(c, g_up_a, z, nz);
+    divisor_init(c, pk->z, dz, nz);
+    GS_HIP(hipStreamSynchronize(c.stream));
+    *out = c.put(std::move(pk));
+    return GS_OK;
+  });
+}
+
+int gs_groth16_prove(gs_handle hpk, const uint64_t* w, size_t nw, const uint64_t* px, size_t npx,
+                     const uint64_t r[4], const uint64_t s[4], uint64_t out_proof[32], int inf[3]) {
+  return guarded([&](Ctx& c) -> int {
+    GrothPkObj* pk = c.get<GrothPkObj>(hpk, Kind::GrothPk);
+    if (!pk) return fail(GS_ERR_ARG, "gs_groth16_prove: bad proving-key handle");
+    if (!w || !px || !r || !s || !out_proof || !inf) return fail(GS_ERR_ARG, "null argument");
+    reset_timing(c);
+    DevScalars dw{upload_tmp(c, g_up_w, w, nw), nw};
+    DevScalars dp{upload_tmp(c, g_up_px, px, npx), npx};
+    return groth16_prove_impl(c, pk, dw, dp, r, s, out_proof, inf);
+  });
+}
+
+int gs_groth16_prove_resident(gs_handle hpk, gs_handle hw, gs_handle hpx, const uint64_t r[4], const uint64_t s[4],
+                              uint64_t out_proof[32], int inf[3]) {
+  return guarded([&](Ctx& c) -> int {
+    GrothPkObj* pk = c.get<GrothPkObj>(hpk, Kind::GrothPk);
+    Scalars* w = c.get<Scalars>(hw, Kind::Scalars);
+    Scalars* px = c.get<Scalars>(hpx, Kind::Scalars);
+    if (!pk || !w || !px) return fail(GS_ERR_ARG, "gs_groth16_prove_resident: bad handle");
+    if (!r || !s || !out_proof || !inf) return fail(GS_ERR_ARG, "null argument");
+    reset_timing(c);
+    return groth16_prove_impl(c, pk, DevScalars{w->buf.as<uint32_t>(), w->n}, DevScalars{px->buf.as<uint32_t>(), px->n}, r, s, out_proof, inf);
+  });
+}
+
+// ---- Pinocchio ----------------------------------------------------------------------------------------------
+int gs_pinocchio_pk_create(gs_handle a, gs_handle ap, gs_handle b_g2, gs_handle bp, gs_handle cc, gs_handle cp, gs_handle kp,
+                           gs_handle g1t, const uint64_t* z, size_t nz, size_t nvars, size_t npublic, gs_handle* out) {
+  return guarded([&](Ctx& c) -> int {
+    Bases* A = c.get<Bases>(a, Kind::G1Bases);
+    Bases* Ap = c.get<Bases>(ap, Kind::G1Bases);
+    Bases* B = c.get<Bases>(b_g2, Kind::G2Bases);
+    Bases* Bp = c.get<Bases>(bp, Kind::G1Bases);
+    Bases* C = c.get<Bases>(cc, Kind::G1Bases);
+    Bases* Cp = c.get<Bases>(cp, Kind::G1Bases);
+    Bases* Kp = c.get<Bases>(kp, Kind::G1Bases);
+    Bases* T = c.get<Bases>(g1t, Kind::G1Bases);
+    if (!A || !Ap || !B || !Bp || !C || !Cp || !Kp || !T) return fail(GS_ERR_ARG, "gs_pinocchio_pk_create: bad base handle");
+    if (!z || !out || nz == 0) return fail(GS_ERR_ARG, "null argument");
+    for (Bases* x : {A, Ap, B, Bp, C, Cp, Kp})
+      if (x->n != nvars) return fail(GS_ERR_SHAPE, "every per-variable key array must have NVars = %zu points (got %zu)", nvars, x->n);
+    if (npublic + 1 > nvars) return fail(GS_ERR_SHAPE, "NPublic + 1 > NVars");
+    auto pk = std::make_unique<PinocchioPkObj>();
+    pk->nvars = nvars; pk->npublic = npublic; pk->nz = nz; pk->ng1t = T->n;
+    copy_points(c, A, kG1Aff, pk->a);
+    copy_points(c, Ap, kG1Aff, pk->ap);
+    copy_points(c, Bp, kG1Aff, pk->bp);
+    copy_points(c, C, kG1Aff, pk->c);
+    copy_points(c, Cp, kG1Aff, pk->cp);
+    copy_points(c, Kp, kG1Aff, pk->kp);
+    copy_points(c, T, kG1Aff, pk->g1t);
+    copy_points(c, B, kG2Aff, pk->b2);
+    force_infinity(c, pk->a, npublic + 1, kG1Aff);                 // snark.go:265
+    force_infinity(c, pk->ap, npublic + 1, kG1Aff);
+    const uint32_t* dz = upload_tmp(c, g_up_a, z, nz);
+    divisor_init(c, pk->z, dz, nz);
+    GS_HIP(hipStreamSynchronize(c.stream));
+    *out = c.put(std::move(pk));
+    return GS_OK;
+  });
+}
+
+int gs_pinocchio_prove(gs_handle hpk, const uint64_t* w, size_t nw, const uint64_t* px, size_t npx, uint64_t out_proof[72], int inf[8]) {
+  return guarded([&](Ctx& c) -> int {
+    PinocchioPkObj* pk = c.get<PinocchioPkObj>(hpk, Kind::PinocchioPk);
+    if (!pk) return fail(GS_ERR_ARG, "gs_pinocchio_prove: bad proving-key handle");
+    if (!w || !px || !out_proof || !inf) return fail(GS_ERR_ARG, "null argument");
+    reset_timing(c);
+    DevScalars dw{upload_tmp(c, g_up_w, w, nw), nw};
+    DevScalars dp{upload_tmp(c, g_up_px, px, npx), npx};
+    return pinocchio_prove_impl(c, pk, dw, dp, out_proof, inf);
+  });
+}
+
+// ---- not yet device-accelerated in this round: declared, fail loudly -------------------------------------------
+int gs_lagrange_interpolation(const uint64_t*, size_t, uint64_t*) { return fail(GS_ERR_ARG, "gs_lagrange_interpolation: not implemented yet"); }
+int gs_zpoly(size_t, uint64_t*) { return fail(GS_ERR_ARG, "gs_zpoly: not implemented yet"); }
+int gs_r1cs_to_px(size_t, size_t, const uint32_t*, const uint32_t*, const uint64_t*, const uint32_t*, const uint32_t*, const uint64_t*,
+                  const uint32_t*, const uint32_t*, const uint64_t*, const uint64_t*, uint64_t*, uint64_t*, uint64_t*, uint64_t*) {
+  return fail(GS_ERR_ARG, "gs_r1cs_to_px: not implemented yet");
+}
+
+}  // extern "C"

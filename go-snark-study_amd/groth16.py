@@ -1,0 +1,126 @@
+"""Mirror of the reference's groth16 prover interface (groth16/groth16.go) on the HIP library.
+
+    pk = groth16.Pk(...)                      # same fields as groth16.go:15-32
+    proof = groth16.GenerateProofs(circuit, pk, w, px)            # groth16.go:225
+    proof = groth16.GenerateProofsWithRS(circuit, pk, w, px, r, s)   # randomness injected
+
+Values are Python ints / tuples shaped like the reference's big.Int structures.  Proof elements
+are returned in the affine normal form [x, y, 1] (infinity = all zero)."""
+import os
+
+import numpy as np
+
+from . import capi
+
+R = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+
+
+class Circuit:
+    """The fields of circuitcompiler.Circuit the prover reads (circuit.go:12-26; groth16.go:243,248)."""
+
+    def __init__(self, NVars, NPublic):
+        self.NVars = NVars
+        self.NPublic = NPublic
+
+
+class Pk:
+    """groth16.Pk (groth16.go:15-32)."""
+
+    def __init__(self, BACDelta, Z, G1_Alpha, G1_Beta, G1_Delta, G1_At, G1_BACGamma,
+                 G2_Beta, G2_Delta, G2_BACGamma, PowersTauDelta, G2_Gamma=None):
+        self.BACDelta, self.Z = BACDelta, Z
+        self.G1_Alpha, self.G1_Beta, self.G1_Delta = G1_Alpha, G1_Beta, G1_Delta
+        self.G1_At, self.G1_BACGamma = G1_At, G1_BACGamma
+        self.G2_Beta, self.G2_Gamma, self.G2_Delta = G2_Beta, G2_Gamma, G2_Delta
+        self.G2_BACGamma = G2_BACGamma
+        self.PowersTauDelta = PowersTauDelta
+        self._dev = None
+
+
+class Proof:
+    """groth16.Proof (groth16.go:61-65)."""
+
+    def __init__(self, PiA, PiB, PiC):
+        self.PiA, self.PiB, self.PiC = PiA, PiB, PiC
+
+
+class DevicePk:
+    """Proving key resident in HBM (upload + affine-normalise once per circuit, SURVEY hard part 4)."""
+
+    def __init__(self, handle, nvars, npublic, keep):
+        self.handle, self.nvars, self.npublic, self._keep = handle, nvars, npublic, keep
+
+
+def device_pk_from_handles(at, bacgamma1, bacgamma2, bacdelta, ptd, alpha, beta, delta, beta2, delta2, z_u64, nvars, npublic):
+    """Assemble a DevicePk from already-resident base arrays (capi.DeviceHandle) and Jacobian int tuples."""
+    import ctypes
+    capi.init()
+    h = capi.Handle(0)
+    a = capi.g1_points_to_u64([alpha, beta, delta])
+    b = capi.g2_points_to_u64([beta2, delta2])
+    z = np.ascontiguousarray(z_u64, dtype=np.uint64).reshape(-1, 4)
+    capi.check(capi.load_library().gs_groth16_pk_create(
+        capi.Handle(at.h), capi.Handle(bacgamma1.h), capi.Handle(bacgamma2.h), capi.Handle(bacdelta.h), capi.Handle(ptd.h),
+        capi.ptr64(a[0]), capi.ptr64(a[1]), capi.ptr64(a[2]), capi.ptr64(b[0]), capi.ptr64(b[1]),
+        capi.ptr64(z), z.shape[0], nvars, npublic, ctypes.byref(h)))
+    return DevicePk(capi.DeviceHandle(h.value), nvars, npublic, None)
+
+
+def UploadPk(pk, circuit):
+    """Additive extension: make pk resident.  Cached on the Pk object."""
+    if pk._dev is not None:
+        return pk._dev
+    at = capi.g1_upload(capi.g1_points_to_u64(pk.G1_At))
+    b1 = capi.g1_upload(capi.g1_points_to_u64(pk.G1_BACGamma))
+    b2 = capi.g2_upload(capi.g2_points_to_u64(pk.G2_BACGamma))
+    cd = capi.g1_upload(capi.g1_points_to_u64(pk.BACDelta))
+    pt = capi.g1_upload(capi.g1_points_to_u64(pk.PowersTauDelta))
+    pk._dev = device_pk_from_handles(at, b1, b2, cd, pt, pk.G1_Alpha, pk.G1_Beta, pk.G1_Delta, pk.G2_Beta, pk.G2_Delta,
+                                     capi.ints_to_u64([z % R for z in pk.Z]), circuit.NVars, circuit.NPublic)
+    return pk._dev
+
+
+def _proof_from_words(out, inf):
+    v = capi.u64_to_ints(out)
+    PiA = (0, 0, 0) if inf[0] else (v[0], v[1], 1)
+    PiB = ((0, 0), (0, 0), (0, 0)) if inf[1] else ((v[2], v[3]), (v[4], v[5]), (1, 0))
+    PiC = (0, 0, 0) if inf[2] else (v[6], v[7], 1)
+    return Proof(PiA, PiB, PiC)
+
+
+def FqRRand():
+    """Utils.FqR.Rand (fields/fq.go:116-132): 30 random bytes, big-endian, mod r."""
+    return int.from_bytes(os.urandom(30), "big") % R
+
+
+def GenerateProofsWithRS(circuit, pk, w, px, r, s):
+    """groth16.go:225-278 with r, s given instead of drawn at :231-238."""
+    import ctypes
+    dev = pk if isinstance(pk, DevicePk) else UploadPk(pk, circuit)
+    # scalars are not canonical in the reference (SURVEY hard part 6): reduce mod r, reject negatives
+    if any(x < 0 for x in w):
+        raise ValueError("negative witness values are not supported (the reference drops the sign, fq.go:138-140)")
+    wa = capi.ints_to_u64([x % R for x in w])
+    pa = capi.ints_to_u64([x % R for x in px])
+    out = np.zeros(32, dtype=np.uint64)
+    inf = (ctypes.c_int * 3)()
+    rs = capi.ints_to_u64([r % R, s % R])
+    capi.check(capi.load_library().gs_groth16_prove(capi.Handle(dev.handle.h), capi.ptr64(wa), len(w), capi.ptr64(pa), len(px),
+                                                    capi.ptr64(rs[0]), capi.ptr64(rs[1]), capi.ptr64(out), inf))
+    return _proof_from_words(out, inf)
+
+
+def GenerateProofs(circuit, pk, w, px):
+    """groth16.GenerateProofs(circuit, pk, w, px) (groth16.go:225)."""
+    return GenerateProofsWithRS(circuit, pk, w, px, FqRRand(), FqRRand())
+
+
+def prove_resident(dev_pk, w_handle, px_handle, r, s):
+    """Inputs already resident in HBM (what bench.py times)."""
+    import ctypes
+    out = np.zeros(32, dtype=np.uint64)
+    inf = (ctypes.c_int * 3)()
+    rs = capi.ints_to_u64([r % R, s % R])
+    capi.check(capi.load_library().gs_groth16_prove_resident(capi.Handle(dev_pk.handle.h), capi.Handle(w_handle.h), capi.Handle(px_handle.h),
+                                                             capi.ptr64(rs[0]), capi.ptr64(rs[1]), capi.ptr64(out), inf))
+    return _proof_from_words(out, inf)

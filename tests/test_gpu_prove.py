@@ -1,0 +1,165 @@
+"""-m gpu parity: Groth16 / Pinocchio provers and the Fr polynomial kernels through the C ABI vs
+ * the reference's own compiled prover (tests/golden/wasm_*.json) -- affine normal form,
+ * the oracles (ref_py / gs_oracle.c) on seeded random instances,
+ * the reference's polynomial test vectors (r1csqap_test.go)."""
+import random
+
+import numpy as np
+import pytest
+
+import gosnark_amd
+from gosnark_amd import capi, groth16, snark, r1csqap
+import golden_util as GU
+import gpu_util as U
+from oracle import c_oracle as C
+from oracle import ref_py as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _init():
+    capi.init()
+
+
+def jac_affine_g1(p):
+    a = O.G1.Affine(p)
+    return (0, 0, 0) if a is None else (a[0], a[1], 1)
+
+
+def jac_affine_g2(p):
+    a = O.G2.Affine(p)
+    return ((0, 0), (0, 0), (0, 0)) if a is None else (a[0], a[1], (1, 0))
+
+
+def mk_groth_pk(opk):
+    return groth16.Pk(BACDelta=opk.BACDelta, Z=opk.Z, G1_Alpha=opk.G1_Alpha, G1_Beta=opk.G1_Beta, G1_Delta=opk.G1_Delta,
+                      G1_At=opk.G1_At, G1_BACGamma=opk.G1_BACGamma, G2_Beta=opk.G2_Beta, G2_Delta=opk.G2_Delta,
+                      G2_BACGamma=opk.G2_BACGamma, PowersTauDelta=opk.PowersTauDelta)
+
+
+@pytest.mark.parametrize("name", ["groth_x3", "groth_rand_m9", "groth_rand_m17"])
+def test_groth16_proof_equals_reference_wasm_affine(name):
+    """Same pk, w, px, r, s as the reference's compiled prover -> identical affine proof elements."""
+    rec = GU.load(name)
+    opk = GU.groth_pk(rec["setup"])
+    r, s = GU.rs_from_stream(rec["rand"])
+    circ = groth16.Circuit(rec["circuit"]["NVars"], rec["circuit"]["NPublic"])
+    proof = groth16.GenerateProofsWithRS(circ, mk_groth_pk(opk), rec["w"], rec["px"], r, s)
+    assert proof.PiA == jac_affine_g1(GU.g1(rec["proof"]["PiA"]))
+    assert proof.PiB == jac_affine_g2(GU.g2(rec["proof"]["PiB"]))
+    assert proof.PiC == jac_affine_g1(GU.g1(rec["proof"]["PiC"]))
+
+
+@pytest.mark.parametrize("name", ["pinocchio_x3_fixture", "pinocchio_rand_m9"])
+def test_pinocchio_proof_equals_reference_wasm_affine(name):
+    rec = GU.load(name)
+    opk = GU.pinocchio_pk(rec["setup"])
+    circ = snark.Circuit(rec["circuit"]["NVars"], rec["circuit"]["NPublic"])
+    pk = snark.Pk(G1T=opk.G1T, A=opk.A, B=opk.B, C=opk.C, Kp=opk.Kp, Ap=opk.Ap, Bp=opk.Bp, Cp=opk.Cp, Z=opk.Z)
+    proof = snark.GenerateProofs(circ, pk, rec["w"], rec["px"])
+    for k in ("PiA", "PiAp", "PiBp", "PiC", "PiCp", "PiH", "PiKp"):
+        assert getattr(proof, k) == jac_affine_g1(GU.g1(rec["proof"][k])), k
+    assert proof.PiB == jac_affine_g2(GU.g2(rec["proof"]["PiB"]))
+
+
+def test_groth16_random_instance_vs_python_oracle_m33():
+    """Seeded instance beyond the goldens (m = 33, n = 32, inexact division)."""
+    rng = random.Random(4242)
+    m, n = 33, 32
+    opk = O.GrothPk()
+    z = [1]
+    for i in range(1, m - 1):
+        z = O.PF.Mul(z, [O.FR.Neg(i), 1])
+    opk.Z = z
+    opk.G1_Alpha, opk.G1_Beta, opk.G1_Delta = (U.rand_g1_jac(rng) for _ in range(3))
+    opk.G2_Beta, opk.G2_Delta = U.rand_g2_jac(rng), U.rand_g2_jac(rng)
+    opk.G1_At = [U.rand_g1_jac(rng, 0.1) for _ in range(m)]
+    opk.G1_BACGamma = [U.rand_g1_jac(rng, 0.1) for _ in range(m)]
+    opk.G2_BACGamma = [U.rand_g2_jac(rng, 0.1) for _ in range(m)]
+    # BACDelta[0..NPublic] deliberately NOT infinity: the reference never reads them (groth16.go:248)
+    opk.BACDelta = [U.rand_g1_jac(rng) for _ in range(m)]
+    opk.PowersTauDelta = [U.rand_g1_jac(rng) for _ in range(len(z))]
+    w = [1] + [rng.randrange(O.R) for _ in range(m - 1)]
+    px = [rng.randrange(O.R) for _ in range(2 * n - 1)]
+    r, s = rng.randrange(O.R), rng.randrange(O.R)
+    want = O.groth16_GenerateProofs(m, 1, opk, w, px, r, s)
+    got = groth16.GenerateProofsWithRS(groth16.Circuit(m, 1), mk_groth_pk(opk), w, px, r, s)
+    assert got.PiA == jac_affine_g1(want[0])
+    assert got.PiB == jac_affine_g2(want[1])
+    assert got.PiC == jac_affine_g1(want[2])
+
+
+def test_prover_rejects_shape_violations():
+    rec = GU.load("groth_x3")
+    opk = GU.groth_pk(rec["setup"])
+    circ = groth16.Circuit(8, 1)
+    pk = mk_groth_pk(opk)
+    with pytest.raises(capi.GosnarkHipError):
+        groth16.GenerateProofsWithRS(circ, pk, rec["w"][:-1], rec["px"], 1, 2)
+    with pytest.raises(capi.GosnarkHipError):       # len(hx) would exceed len(PowersTauDelta)
+        groth16.GenerateProofsWithRS(circ, pk, rec["w"], rec["px"] + [1, 2, 3], 1, 2)
+
+
+# ---- polynomial field (r1csqap/r1csqap_test.go) -------------------------------------------------------
+def test_poly_reference_vectors():
+    PF = r1csqap.PolynomialField()
+    a, b = [1, 0, 5], [3, 0, 1]
+    assert PF.Mul(a, b) == [3, 0, 16, 0, 5]                       # r1csqap_test.go:59-62
+    q, rem = PF.Div([3, 0, 16, 0, 5], b)                          # :64-67
+    assert q == a and rem == [0, 0]
+    assert PF.Add(a, b) == [4, 0, 6]                              # :69-71
+    assert PF.Sub(a, b) == [O.R - 2, 0, 4]                        # :73-77
+    assert PF.Eval([1, 2, 3], 5) == 86
+
+
+@pytest.mark.parametrize("na,nb", [(1, 1), (2, 1), (13, 7), (64, 64), (257, 100), (1000, 999)])
+def test_poly_mul_div_vs_c_oracle(na, nb):
+    rng = random.Random(na * 1000 + nb)
+    PF = r1csqap.PolynomialField()
+    a = [rng.randrange(O.R) for _ in range(na)]
+    b = [rng.randrange(O.R) for _ in range(nb)]
+    b[-1] = b[-1] or 1
+    assert PF.Mul(a, b) == C.poly_mul(a, b)
+    q, rem = PF.Div(a, b)
+    cq, cr = C.poly_div(a, b)
+    assert q == cq and rem == cr
+    x = rng.randrange(O.R)
+    assert PF.Eval(a, x) == C.poly_eval(a, x)
+    assert PF.Add(a, b) == O.PF.Add(a, b) and PF.Sub(b, a) == O.PF.Sub(b, a)
+
+
+def test_poly_div_x3_px_by_z_exact():
+    """groth16_test.go:78-86: px / Z has zero remainder, hx * Z == px, len(hx) = len(px) - len(Z) + 1."""
+    rec = GU.load("pinocchio_x3_fixture")
+    z = GU.pinocchio_pk(rec["setup"]).Z
+    PF = r1csqap.PolynomialField()
+    hx, rem = PF.Div(rec["px"], z)
+    assert all(x == 0 for x in rem) and len(hx) == len(rec["px"]) - len(z) + 1
+    assert PF.Mul(hx, z) == rec["px"]
+    assert hx == O.PF.DivisorPolynomial(rec["px"], z)
+
+
+def test_poly_quotient_large_roundtrip():
+    """Size-independent property at 2^16: (q * b + r) / b == q with deg r < deg b."""
+    n = 1 << 16
+    q = U.rand_scalars_u64(n, 31)
+    b = U.rand_scalars_u64(n, 32)
+    lib = capi.load_library()
+    prod = np.zeros((2 * n - 1, 4), dtype=np.uint64)
+    capi.check(lib.gs_poly_mul(capi.ptr64(q), n, capi.ptr64(b), n, capi.ptr64(prod)))
+    rsmall = U.rand_scalars_u64(n - 1, 33)
+    tot = np.zeros((2 * n - 1, 4), dtype=np.uint64)
+    capi.check(lib.gs_poly_add(capi.ptr64(prod), 2 * n - 1, capi.ptr64(rsmall), n - 1, capi.ptr64(tot)))
+    q2 = np.zeros((n, 4), dtype=np.uint64)
+    r2 = np.zeros((n - 1, 4), dtype=np.uint64)
+    capi.check(lib.gs_poly_div(capi.ptr64(tot), 2 * n - 1, capi.ptr64(b), n, capi.ptr64(q2), capi.ptr64(r2)))
+    assert np.array_equal(q2, q) and np.array_equal(r2, rsmall)
+    # and a 2^12 slice against the C oracle's long division
+    m = 1 << 12
+    cq, cr = C.poly_div_u64(tot[:2 * m - 1], b[:m])
+    q3 = np.zeros((m, 4), dtype=np.uint64)
+    r3 = np.zeros((m - 1, 4), dtype=np.uint64)
+    capi.check(lib.gs_poly_div(capi.ptr64(np.ascontiguousarray(tot[:2 * m - 1])), 2 * m - 1, capi.ptr64(np.ascontiguousarray(b[:m])), m,
+                               capi.ptr64(q3), capi.ptr64(r3)))
+    assert np.array_equal(q3, cq) and np.array_equal(r3, cr)
