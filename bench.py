@@ -1,0 +1,175 @@
+#!/usr/bin/env python
+"""bench.py -- Groth16 prove throughput (constraints/s) of the HIP prover on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--log2n 20] [--workload prove|msm_g1|msm_sharded]
+
+A "step" is one full groth16.GenerateProofs (groth16/groth16.go:225-278: H(x) = P(x)/Z(x), the
+five MSMs, the O(1) tail) over a synthetic instance with n = 2^log2n constraints, m = n + 1
+variables, NPublic = 1 (BASELINE.json configs[2]); the proving key, w and px are resident in HBM
+before the timed region.  N > 1 (launched by torch.distributed.run, one rank per GPU): every rank
+proves its own independent instance of the same size -- the batch-of-proofs partition of
+BASELINE.json configs[4]; no data-path collective -- so scaling is weak and `value` is
+N * n * K / (max-over-ranks time).  `--workload msm_sharded` instead shards ONE G1 MSM of
+N * 2^log2n terms across the ranks with an all-gather of the per-rank partial points
+(configs[3]).
+
+Prints ONE JSON line on rank 0 (contract in the task statement), including
+  roofline:     the dominant kernel (G1 bucket accumulation) against the HBM roofline,
+  cpu_baseline: the reference algorithm (oracle/gs_oracle.c: naive MulScalar/Add loops + schoolbook
+                Div) timed on ONE host core on a bounded sample (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+import gosnark_amd  # noqa: F401
+from gosnark_amd import capi, groth16, synth
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+G1_TERM_BYTES = 96             # 32 B scalar + 64 B affine base per G1 MSM term
+G2_TERM_BYTES = 160
+R = groth16.R
+
+
+def cpu_baseline(log2n_sample, seed):
+    """The reference algorithm on one host core: sum_i MulScalar(base_i, w_i) loops
+    (groth16.go:243-250,269-271 / g1.go:140-155 + :32-89) and schoolbook Div (r1csqap.go:70-84),
+    via oracle/gs_oracle.c, on an instance with 2^log2n_sample constraints."""
+    from oracle import c_oracle as C            # checker/baseline only; never on the product path
+    n = 1 << log2n_sample
+    m = n + 1
+    inst = synth.random_instance(n, seed)       # device arrays -> downloaded Jacobian copies for the CPU
+    g1 = {k: capi.g1_download(inst.g1[k]) for k in ("at", "bacgamma", "bacdelta", "ptd")}
+    g2 = capi.g2_download(inst.g2_bacgamma)
+    w, px, z = inst.w_host, inst.px_host, inst.z_host
+    t0 = time.perf_counter()
+    hx, _ = C.poly_div_u64(px, z)
+    C.g1_msm_naive(g1["at"], w)
+    C.g1_msm_naive(g1["bacgamma"], w)
+    C.g2_msm_naive(g2, w)
+    C.g1_msm_naive(g1["bacdelta"][2:], w[2:])
+    C.g1_msm_naive(g1["ptd"][:hx.shape[0]], hx)
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "constraints/s", "cores": 1, "kind": "port",
+            "sample": "full Groth16 prove at n=2^%d constraints (4 G1 + 1 G2 naive double-and-add MSMs of ~n terms "
+                      "+ schoolbook Div), oracle/gs_oracle.c, 1 thread, %.1f s" % (log2n_sample, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--log2n", type=int, default=20)
+    ap.add_argument("--workload", default="prove", choices=["prove", "msm_g1", "msm_sharded"])
+    ap.add_argument("--cpu-log2n", type=int, default=13, help="constraints of the CPU-baseline sample (0 = skip)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus))
+        raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: there is no CPU path for the product code")
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    capi.init(local)
+
+    n = 1 << args.log2n
+    seed = 0x5EED0002 + rank
+    if args.workload == "prove":
+        inst = synth.random_instance(n, seed)
+        pk = inst.device_pk()
+        r_, s_ = synth.field_elems(2, seed ^ 0xABCDEF, R)
+
+        def step():
+            return groth16.prove_resident(pk, inst.w, inst.px, r_, s_)
+        units_per_step = n
+        workload = "groth16_prove_2^%d_constraints_per_gpu" % args.log2n
+    else:
+        from gosnark_amd import parallel
+        nterms = n
+        bases = capi.g1_fixed_base(synth.scalars_u64(nterms, seed))
+        sc = capi.scalars_upload(synth.scalars_u64(nterms, seed + 77))
+        if args.workload == "msm_g1":
+            def step():
+                return capi.msm_resident(bases, sc, nterms)
+        else:
+            def step():
+                return parallel.msm_g1_sharded(bases, sc, nterms)
+        units_per_step = nterms
+        workload = ("g1_msm_2^%d_terms_per_gpu" % args.log2n) + ("_allgather_partials" if args.workload == "msm_sharded" else "")
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    tm_acc = {"acc_g1_ms": 0.0, "acc_g1_launches": 0, "acc_g1_terms": 0, "acc_g2_ms": 0.0, "acc_g2_terms": 0,
+              "total_ms": 0.0, "plan_ms": 0.0, "accumulate_ms": 0.0, "reduce_ms": 0.0, "poly_ms": 0.0}
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        tm = capi.last_timing()      # HIP-event timings recorded on the library's stream inside the call
+        for k in tm_acc:
+            tm_acc[k] += tm[k]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        value = units_per_step * world * args.steps / elapsed
+        launches = max(tm_acc["acc_g1_launches"], 1)
+        avg_launch_s = tm_acc["acc_g1_ms"] / launches * 1e-3
+        bytes_per_launch = G1_TERM_BYTES * tm_acc["acc_g1_terms"] / launches
+        achieved = bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+        out = {
+            "metric": "Groth16 constraints/sec (prove) at 2^%d R1CS" % args.log2n if args.workload == "prove" else "G1-MSM terms/sec",
+            "value": value,
+            "unit": "constraints/s" if args.workload == "prove" else "terms/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u32 (9x29-bit Montgomery limbs of the 254-bit BN128 fields)", "data": "synthetic",
+            "config": {"workload": workload, "constraints": n, "variables": n + 1, "npublic": 1,
+                       "parallelism": "independent proofs, one per GPU" if args.workload == "prove" else args.workload,
+                       "instance": inst.describe() if args.workload == "prove" else "uniform random scalars, bases k_i*G"},
+            "roofline": {"bound": "hbm", "kernel": "k_bucket_accumulate<G1>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "avg_launch_ms": avg_launch_s * 1e3, "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "note": "integer-issue bound (254-bit modular arithmetic on 32-bit VALU), see DESIGN.md"},
+            "device_ms_per_step": {k: tm_acc[k] / args.steps for k in ("total_ms", "poly_ms", "plan_ms", "accumulate_ms", "reduce_ms", "acc_g1_ms", "acc_g2_ms")},
+        }
+        if world == 1 and args.cpu_log2n > 0:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_log2n, seed + 1000)
+            if args.workload != "prove":
+                out["cpu_baseline"]["note"] = "baseline is the Groth16 prove sample; 1 constraint ~ 4 G1 + 1 G2 terms"
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

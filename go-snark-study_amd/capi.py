@@ -23,8 +23,10 @@ class GosnarkHipError(RuntimeError):
 
 
 class Timing(ctypes.Structure):
-    _fields_ = [(n, ctypes.c_float) for n in
-                ("total_ms", "plan_ms", "accumulate_ms", "reduce_ms", "poly_ms", "h2d_ms")]
+    _fields_ = ([(n, ctypes.c_float) for n in
+                 ("total_ms", "plan_ms", "accumulate_ms", "reduce_ms", "poly_ms", "h2d_ms", "acc_g1_ms", "acc_g2_ms")]
+                + [("acc_g1_launches", ctypes.c_uint32), ("acc_g2_launches", ctypes.c_uint32),
+                   ("acc_g1_terms", ctypes.c_uint64), ("acc_g2_terms", ctypes.c_uint64)])
 
 
 def lib_path():
@@ -80,6 +82,13 @@ def load_library():
         if _LIB is not None:
             return _LIB
         path = lib_path()
+        try:
+            # torch ships its own libamdhip64/libhsa-runtime64 (same sonames as /opt/rocm's): when a process
+            # uses both torch and this library (bench.py, smoke()), torch's copies must be the ones that get
+            # loaded first, otherwise two HSA runtimes end up in the process and device discovery fails.
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         if not os.path.exists(path):
             raise GosnarkHipError(-1, "%s not found: build it with __graft_entry__.build() "
                                   "(hipcc --offload-arch=gfx950); there is no CPU fallback" % path)
@@ -278,7 +287,6 @@ def sum_affine(points, g2=False):
     out = np.zeros(16 if g2 else 8, dtype=np.uint64)
     inf = ctypes.c_int(0)
     fn = load_library().gs_g2_sum_affine if g2 else load_library().gs_g1_sum_affine
-    init()
     check(fn(ptr64(arr), ia, n, ptr64(out), ctypes.byref(inf)))
     return _affine_result(out, inf, g2)
 
@@ -292,3 +300,11 @@ def last_timing():
 def set_window_bits(c):
     init()
     check(load_library().gs_set_window_bits(int(c)))
+
+
+def zpoly(deg):
+    """Z(x) = prod_{i=1}^{deg} (x - i) as a [deg+1, 4] uint64 array (gs_zpoly)."""
+    init()
+    out = np.zeros((deg + 1, 4), dtype=np.uint64)
+    check(load_library().gs_zpoly(deg, ptr64(out)))
+    return out

@@ -256,10 +256,10 @@ int gs_msm_g2_resident(gs_handle bases, size_t off, gs_handle scalars, size_t so
 }
 
 int gs_g1_sum_affine(const uint64_t* pts, const int* inf, size_t n, uint64_t out[8], int* is_inf) {
-  return guarded([&](Ctx&) { return sum_affine<FqTag>(pts, inf, n, out, is_inf); });
+  return guarded([&](Ctx&) { return sum_affine<FqTag>(pts, inf, n, out, is_inf); }, false);   // host arithmetic: no device needed
 }
 int gs_g2_sum_affine(const uint64_t* pts, const int* inf, size_t n, uint64_t out[16], int* is_inf) {
-  return guarded([&](Ctx&) { return sum_affine<Fq2Tag>(pts, inf, n, out, is_inf); });
+  return guarded([&](Ctx&) { return sum_affine<Fq2Tag>(pts, inf, n, out, is_inf); }, false);
 }
 
 int gs_last_timing(gs_timing* out) {

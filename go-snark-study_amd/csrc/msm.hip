@@ -107,8 +107,10 @@ static void msm_run(Ctx& c, const MsmPlan& plan, const std::vector<const uint32_
     jobs.j[j] = AccJob{bases[j], bk.as<uint32_t>(), ch.as<uint32_t>()};
   }
   PhaseTimer tacc(c.stream);
+  PhaseTimer tker(c.stream);
   hipLaunchKernelGGL(k_bucket_accumulate<T>, dim3((plan.nitems + 255) / 256, njobs), dim3(256), 0, c.stream,
                      jobs, plan.offsets, plan.entries, plan.seg_off, plan.item_bucket, plan.nitems, plan.S);
+  tker.stop();
   if (plan.nheavy)
     hipLaunchKernelGGL(k_heavy_combine<T>, dim3(plan.nheavy, njobs), dim3(kHeavyBlock), 0, c.stream,
                        jobs, plan.seg_off, plan.heavy_list);
@@ -130,6 +132,11 @@ static void msm_run(Ctx& c, const MsmPlan& plan, const std::vector<const uint32_
   tred.stop();
   GS_HIP(hipStreamSynchronize(c.stream));
   c.timing.accumulate_ms += tacc.ms();
+  if constexpr (PointIO<T>::kAffineWords == 16) {
+    c.timing.acc_g1_ms += tker.ms(); c.timing.acc_g1_launches += 1; c.timing.acc_g1_terms += (uint64_t)plan.n * njobs;
+  } else {
+    c.timing.acc_g2_ms += tker.ms(); c.timing.acc_g2_launches += 1; c.timing.acc_g2_terms += (uint64_t)plan.n * njobs;
+  }
   c.timing.reduce_ms += tred.ms();
   for (int j = 0; j < njobs; ++j) out[j] = horner_host<T>(sums.data() + (size_t)j * plan.W, plan.W, plan.c);
 }

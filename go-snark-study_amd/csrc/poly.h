@@ -38,6 +38,9 @@ void divisor_init(Ctx& c, Divisor& d, const uint32_t* b_std_dev, size_t nb);
 // quo (na - nb + 1 coefficients, standard form, values < 2r) = floor(a / b); a standard form.
 void poly_quotient_dev(Ctx& c, Divisor& d, const uint32_t* a_std, size_t na, uint32_t* quo_std);
 
+// Z(x) = prod_{i=1}^{deg} (x - i), deg + 1 canonical standard-form coefficients (subproduct tree of NTT products)
+void zpoly_dev(Ctx& c, size_t deg, uint32_t* out_std);
+
 void poly_addsub_dev(Ctx& c, const uint32_t* a, size_t na, const uint32_t* b, size_t nb, bool subtract, uint32_t* out);
 void poly_canon_dev(Ctx& c, uint32_t* x, size_t n, int mode /* 0 canon, 1 to-Montgomery, 2 from-Montgomery */);
 // out[0] = sum_i v[i] x^i (standard in, canonical standard out); x given as ABI words

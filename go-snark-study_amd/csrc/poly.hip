@@ -203,6 +203,37 @@ void poly_quotient_dev(Ctx& c, Divisor& d, const uint32_t* a, size_t na, uint32_
   GS_HIP(hipGetLastError());
 }
 
+// Z(x) = prod_{i=1}^{deg} (x - i): deg + 1 coefficients, canonical standard form.
+void zpoly_dev(Ctx& c, size_t deg, uint32_t* out_std) {
+  if (deg == 0) {
+    uint32_t w[8] = {1, 0, 0, 0, 0, 0, 0, 0};
+    GS_HIP(hipMemcpyAsync(out_std, w, 32, hipMemcpyHostToDevice, c.stream));
+    GS_HIP(hipStreamSynchronize(c.stream));
+    return;
+  }
+  const int L = ceil_log2(deg);                              // 2^L >= deg leaves (the extra ones are the factor x)
+  const size_t total = (size_t)1 << L, pad = total - deg;
+  DevBuf cur(total * 32), nxt(total * 32), wide(2 * total * 32);
+  hipLaunchKernelGGL(k_zp_leaves, grid1(total), dim3(256), 0, c.stream, cur.as<uint32_t>(), (uint32_t)deg, (uint32_t)total);
+  for (int j = 0; j < L; ++j) {                              // blocks of d = 2^j low coefficients -> blocks of 2d
+    const uint32_t d = 1u << j;
+    hipLaunchKernelGGL(k_expand_blocks, grid1(2 * total), dim3(256), 0, c.stream, cur.as<uint32_t>(), wide.as<uint32_t>(), d, (uint32_t)(2 * total));
+    ntt_forward(c, wide.as<uint32_t>(), L + 1, j + 1);
+    hipLaunchKernelGGL(k_pw_mul_pairs, grid1(total), dim3(256), 0, c.stream, wide.as<uint32_t>(), nxt.as<uint32_t>(), 2 * d, (uint32_t)total);
+    ntt_inverse_unscaled(c, nxt.as<uint32_t>(), L, j + 1);
+    hipLaunchKernelGGL(k_monic_combine, grid1(total), dim3(256), 0, c.stream, nxt.as<uint32_t>(), cur.as<uint32_t>(), inv_n_const(j + 1, 0),
+                       wide.as<uint32_t>(), d, (uint32_t)total);
+    GS_HIP(hipMemcpyAsync(cur.p, wide.p, total * 32, hipMemcpyDeviceToDevice, c.stream));
+  }
+  GS_HIP(hipGetLastError());
+  // cur = low 2^L coefficients of x^pad * Z (Montgomery); Z[k] = cur[k + pad] for k < deg, Z[deg] = 1
+  poly_canon_dev(c, cur.as<uint32_t>(), total, 2);
+  if (deg > 0) GS_HIP(hipMemcpyAsync(out_std, cur.as<uint32_t>() + pad * 8, deg * 32, hipMemcpyDeviceToDevice, c.stream));
+  uint32_t w[8] = {1, 0, 0, 0, 0, 0, 0, 0};
+  GS_HIP(hipMemcpyAsync(out_std + deg * 8, w, 32, hipMemcpyHostToDevice, c.stream));
+  GS_HIP(hipStreamSynchronize(c.stream));
+}
+
 void poly_addsub_dev(Ctx& c, const uint32_t* a, size_t na, const uint32_t* b, size_t nb, bool subtract, uint32_t* out) {
   const size_t n = std::max(na, nb);
   if (n) hipLaunchKernelGGL(k_addsub, grid1(n), dim3(256), 0, c.stream, a, (uint32_t)na, b, (uint32_t)nb, subtract ? 1 : 0, out, (uint32_t)n);

@@ -149,6 +149,52 @@ __global__ void __launch_bounds__(256) k_two_minus(const uint32_t* __restrict__ 
   else store_fr(out + (size_t)i * 8, reduce2(neg(v)));
 }
 
+// ---- subproduct tree of monic polynomials with the leading 1 implicit ------------------------------------
+// (Z(x) = prod (x - i), r1csqap.go:177-186 / groth16.go:122-131, built by pairwise NTT products instead of
+// the reference's m-2 schoolbook multiplications by a linear factor.)
+// leaves: out[i] = -(i + 1) for i < deg, 0 (factor x) for deg <= i < total; Montgomery form.
+__global__ void __launch_bounds__(256) k_zp_leaves(uint32_t* __restrict__ out, uint32_t deg, uint32_t total) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  if (i >= deg) { store_fr(out + (size_t)i * 8, fe_zero<ModR, 2>()); return; }
+  uint32_t w[8] = {i + 1u, 0, 0, 0, 0, 0, 0, 0};
+  store_fr_canon(out + (size_t)i * 8, canon(neg(to_mont(unpack32<ModR>(w)))));
+}
+// dst[blk * 2d + t] = t < d ? src[blk * d + t] : 0          (blocks of d -> zero-padded blocks of 2d)
+__global__ void __launch_bounds__(256) k_expand_blocks(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, uint32_t d, uint32_t total2) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total2) return;
+  const uint32_t blk = i / (2 * d), t = i - blk * 2 * d;
+  uint4* q = reinterpret_cast<uint4*>(dst + (size_t)i * 8);
+  if (t < d) {
+    const uint4* s = reinterpret_cast<const uint4*>(src + ((size_t)blk * d + t) * 8);
+    q[0] = s[0]; q[1] = s[1];
+  } else {
+    q[0] = make_uint4(0, 0, 0, 0); q[1] = q[0];
+  }
+}
+// out[p * d2 + t] = buf[(2p) * d2 + t] * buf[(2p + 1) * d2 + t]       (spectra of adjacent blocks)
+__global__ void __launch_bounds__(256) k_pw_mul_pairs(const uint32_t* __restrict__ buf, uint32_t* __restrict__ out, uint32_t d2, uint32_t total) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const uint32_t p = i / d2, t = i - p * d2;
+  const uint32_t* a = buf + ((size_t)(2 * p) * d2 + t) * 8;
+  store_fr(out + (size_t)i * 8, mul(load_fr(a), load_fr(a + (size_t)d2 * 8)));
+}
+// (x^d + a)(x^d + b) = x^2d + [a b + x^d (a + b)]:  out[p*2d + t] = prod[p*2d + t] * scale + (t >= d ? a[t-d] + b[t-d] : 0)
+__global__ void __launch_bounds__(256) k_monic_combine(const uint32_t* __restrict__ prod, const uint32_t* __restrict__ src, FrConst scale,
+                                                        uint32_t* __restrict__ out, uint32_t d, uint32_t total) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const uint32_t p = i / (2 * d), t = i - p * 2 * d;
+  Fr2 v = mul(load_fr(prod + (size_t)i * 8), from_const(scale));
+  if (t >= d) {
+    const uint32_t* a = src + ((size_t)(2 * p) * d + (t - d)) * 8;
+    v = reduce2(add(v, add(load_fr(a), load_fr(a + (size_t)d * 8))));
+  }
+  store_fr(out + (size_t)i * 8, v);
+}
+
 // ---- evaluation: sum_i v_i x^i  (r1csqap.go:118-126) ------------------------------------------------
 constexpr int kEvalChunk = 64;
 // partial[t] = x^(t*chunk) * sum_{i<chunk} v[t*chunk+i] x^i      (v standard form, x Montgomery -> standard)

@@ -354,7 +354,16 @@ int gs_pinocchio_prove(gs_handle hpk, const uint64_t* w, size_t nw, const uint64
 
 // ---- not yet device-accelerated in this round: declared, fail loudly -------------------------------------------
 int gs_lagrange_interpolation(const uint64_t*, size_t, uint64_t*) { return fail(GS_ERR_ARG, "gs_lagrange_interpolation: not implemented yet"); }
-int gs_zpoly(size_t, uint64_t*) { return fail(GS_ERR_ARG, "gs_zpoly: not implemented yet"); }
+int gs_zpoly(size_t deg, uint64_t* out) {
+  return guarded([&](Ctx& c) -> int {
+    if (!out) return fail(GS_ERR_ARG, "gs_zpoly: null output");
+    if (deg >= (1ull << 27)) return fail(GS_ERR_ARG, "gs_zpoly: degree too large");
+    g_up_o.ensure((deg + 1) * 32);
+    zpoly_dev(c, deg, g_up_o.as<uint32_t>());
+    download(c, out, g_up_o.p, deg + 1);
+    return GS_OK;
+  });
+}
 int gs_r1cs_to_px(size_t, size_t, const uint32_t*, const uint32_t*, const uint64_t*, const uint32_t*, const uint32_t*, const uint64_t*,
                   const uint32_t*, const uint32_t*, const uint64_t*, const uint64_t*, uint64_t*, uint64_t*, uint64_t*, uint64_t*) {
   return fail(GS_ERR_ARG, "gs_r1cs_to_px: not implemented yet");

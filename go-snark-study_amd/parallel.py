@@ -1,0 +1,85 @@
+"""Multi-GPU layer: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI on the
+GPU box, "gloo" in the CPU tests).
+
+An MSM is a sum over independent terms (groth16.go:243-250,269-271), so it shards by contiguous term
+range: every rank runs the whole Pippenger pipeline on its resident shard and emits ONE partial point;
+the only exchange is an all-gather of those partials (72 B per G1 point, 136 B per G2 point per rank:
+affine words + an infinity flag) followed by world-1 local curve additions -- RCCL has no curve-point
+reduction operator, so a literal all-reduce cannot add them.  Batches of independent
+proofs (BASELINE configs[4]) need no collective at all: see bench.py."""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import capi
+
+
+def shard_range(n, world, rank):
+    """Contiguous term range [lo, hi) of `rank` (first n % world ranks get one extra term)."""
+    q, rem = divmod(n, world)
+    lo = rank * q + min(rank, rem)
+    return lo, lo + q + (1 if rank < rem else 0)
+
+
+def _encode(point, g2):
+    words = 16 if g2 else 8
+    buf = np.zeros(words + 1, dtype=np.uint64)
+    if point is None:
+        buf[words] = 1
+    else:
+        flat = [point[0][0], point[0][1], point[1][0], point[1][1]] if g2 else [point[0], point[1]]
+        buf[:words] = capi.ints_to_u64(flat).reshape(-1)
+    return buf
+
+
+def _decode(buf, g2):
+    words = 16 if g2 else 8
+    if int(buf[words]) != 0:
+        return None
+    v = capi.u64_to_ints(buf[:words])
+    return ((v[0], v[1]), (v[2], v[3])) if g2 else (v[0], v[1])
+
+
+def allgather_points(partials, g2_flags, group=None):
+    """partials: this rank's affine points (tuples / None = infinity), g2_flags[i] tells the group of
+    partials[i].  ONE all-gather of the packed bytes; returns per_rank[rank][i]."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    packed = np.concatenate([_encode(p, g2) for p, g2 in zip(partials, g2_flags)]).view(np.uint8)
+    if world == 1:
+        gathered = [packed]
+    else:
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+        mine = torch.from_numpy(packed.copy()).to(dev)
+        outs = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(outs, mine, group=group)
+        gathered = [o.cpu().numpy() for o in outs]
+    res = []
+    for raw in gathered:
+        words = raw.view(np.uint64)
+        pts, pos = [], 0
+        for g2 in g2_flags:
+            k = (16 if g2 else 8) + 1
+            pts.append(_decode(words[pos:pos + k], g2))
+            pos += k
+        res.append(pts)
+    return res
+
+
+def combine_partials(per_rank, g2_flags):
+    """Sum the ranks' partial points element-wise with the library's complete curve addition."""
+    return [capi.sum_affine([per_rank[r][i] for r in range(len(per_rank))], g2=g2) for i, g2 in enumerate(g2_flags)]
+
+
+def msm_sharded(local_partial, g2=False, group=None):
+    """Finish a term-sharded MSM: `local_partial` is this rank's sum over its shard."""
+    per_rank = allgather_points([local_partial], [g2], group)
+    return combine_partials(per_rank, [g2])[0]
+
+
+def msm_g1_sharded(bases, scalars, n_local, group=None):
+    """Each rank holds `n_local` resident bases/scalars (its shard of the global term range)."""
+    return msm_sharded(capi.msm_resident(bases, scalars, n_local), False, group)
+
+
+def msm_g2_sharded(bases, scalars, n_local, group=None):
+    return msm_sharded(capi.msm_resident(bases, scalars, n_local, g2=True), True, group)

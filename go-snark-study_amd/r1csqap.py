@@ -64,7 +64,4 @@ class PolynomialField:
 
 def ZPoly(deg):
     """Z(x) = prod_{i=1}^{deg} (x - i)  (r1csqap.go:177-186 / groth16.go:122-131)."""
-    capi.init()
-    out = np.zeros((deg + 1, 4), dtype=np.uint64)
-    capi.check(capi.load_library().gs_zpoly(deg, capi.ptr64(out)))
-    return capi.u64_to_ints(out)
+    return capi.u64_to_ints(capi.zpoly(deg))

@@ -1,0 +1,89 @@
+"""Deterministic synthetic Groth16 instances for bench.py and the large-size parity tests
+(SURVEY.md 8d).  Everything heavy is produced on the device through the C ABI (fixed-base batch
+multiplication = the hot loop of groth16.GenerateTrustedSetup, groth16.go:139-175)."""
+import numpy as np
+
+from . import capi, groth16
+
+R = groth16.R
+_R_LIMBS = [(R >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)]
+
+
+def scalars_u64(n, seed):
+    """n uniform elements of [0, r) as an [n, 4] uint64 array (vectorised rejection sampling)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    out = np.zeros((n, 4), dtype=np.uint64)
+    todo = np.arange(n)
+    while todo.size:
+        cand = rng.integers(0, 2**64, size=(todo.size, 4), dtype=np.uint64)
+        cand[:, 3] &= np.uint64(0x3FFFFFFFFFFFFFFF)
+        lt = np.zeros(todo.size, dtype=bool)
+        eq = np.ones(todo.size, dtype=bool)
+        for i in (3, 2, 1, 0):
+            lt |= eq & (cand[:, i] < np.uint64(_R_LIMBS[i]))
+            eq &= cand[:, i] == np.uint64(_R_LIMBS[i])
+        out[todo[lt]] = cand[lt]
+        todo = todo[~lt]
+    return out
+
+
+def field_elems(n, seed, modulus=R):
+    return [int(x) % modulus for x in capi.u64_to_ints(scalars_u64(n, seed))]
+
+
+def _jac_g1(row):
+    v = capi.u64_to_ints(row)
+    return (v[0], v[1], v[2])
+
+
+def _jac_g2(row):
+    v = capi.u64_to_ints(row)
+    return ((v[0], v[1]), (v[2], v[3]), (v[4], v[5]))
+
+
+class RandomInstance:
+    """A Groth16 instance of the reference's shape (m = n + 1, NPublic = 1, len(Z) = len(hx) = n =
+    len(PowersTauDelta), len(px) = 2n - 1) whose key points are k_i * G for seeded
+    uniform k_i and whose w / px are seeded uniform field elements.  The arithmetic the prover performs
+    is that of a real instance of this size (px / Z leaves a remainder, which groth16.go:266 discards)."""
+
+    def __init__(self, n, seed):
+        self.n, self.m, self.seed = n, n + 1, seed
+        m = self.m
+        self.g1 = {
+            "at": capi.g1_fixed_base(scalars_u64(m, seed + 1)),
+            "bacgamma": capi.g1_fixed_base(scalars_u64(m, seed + 2)),
+            "bacdelta": capi.g1_fixed_base(scalars_u64(m, seed + 3)),
+            "ptd": capi.g1_fixed_base(scalars_u64(n, seed + 4)),
+        }
+        self.g2_bacgamma = capi.g2_fixed_base(scalars_u64(m, seed + 5))
+        singles1 = capi.g1_download(capi.g1_fixed_base(scalars_u64(3, seed + 6)))
+        singles2 = capi.g2_download(capi.g2_fixed_base(scalars_u64(2, seed + 7)))
+        self.alpha, self.beta, self.delta = (_jac_g1(singles1[i]) for i in range(3))
+        self.beta2, self.delta2 = (_jac_g2(singles2[i]) for i in range(2))
+        self.w_host = scalars_u64(m, seed + 8)
+        self.w_host[0] = (1, 0, 0, 0)
+        self.px_host = scalars_u64(2 * n - 1, seed + 9)
+        self.z_host = self._z()
+        self.w = capi.scalars_upload(self.w_host)
+        self.px = capi.scalars_upload(self.px_host)
+        self._pk = None
+
+    def _z(self):
+        """Z(x) = prod_{i=1}^{m-2} (x - i) (groth16.go:122-131): n coefficients."""
+        return capi.zpoly(self.m - 2)
+
+    def device_pk(self):
+        if self._pk is None:
+            self._pk = groth16.device_pk_from_handles(
+                self.g1["at"], self.g1["bacgamma"], self.g2_bacgamma, self.g1["bacdelta"], self.g1["ptd"],
+                self.alpha, self.beta, self.delta, self.beta2, self.delta2, self.z_host, self.m, 1)
+        return self._pk
+
+    def describe(self):
+        return ("key points k_i*G (seeded uniform k_i), w and px seeded uniform in [0,r), "
+                "Z = prod_{i=1..m-2}(x-i); seed 0x%X" % self.seed)
+
+
+def random_instance(n, seed):
+    return RandomInstance(n, seed)

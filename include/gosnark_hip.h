@@ -171,6 +171,12 @@ typedef struct {
   float reduce_ms;       /* bucket reduction + window combination + normalisation */
   float poly_ms;         /* H(x) = P(x)/Z(x) stage */
   float h2d_ms;          /* host-to-device copies inside the call */
+  /* the dominant kernel alone (k_bucket_accumulate), summed over its launches in the call: */
+  float acc_g1_ms;       /* G1 bucket-accumulation launches */
+  float acc_g2_ms;       /* G2 bucket-accumulation launches */
+  uint32_t acc_g1_launches, acc_g2_launches;
+  uint64_t acc_g1_terms; /* (terms x base arrays) those G1 launches consumed */
+  uint64_t acc_g2_terms;
 } gs_timing;
 int gs_last_timing(gs_timing* out);
 

@@ -163,3 +163,64 @@ def test_poly_quotient_large_roundtrip():
     capi.check(lib.gs_poly_div(capi.ptr64(np.ascontiguousarray(tot[:2 * m - 1])), 2 * m - 1, capi.ptr64(np.ascontiguousarray(b[:m])), m,
                                capi.ptr64(q3), capi.ptr64(r3)))
     assert np.array_equal(q3, cq) and np.array_equal(r3, cr)
+
+
+@pytest.mark.parametrize("deg", [0, 1, 2, 3, 6, 7, 8, 9, 31, 100, 1000])
+def test_zpoly_vs_reference_product(deg):
+    """Z(x) = prod_{i=1}^{deg}(x - i) built as the reference does (groth16.go:122-131: repeated Mul by
+    [-i, 1]) equals the device subproduct tree."""
+    z = [1]
+    for i in range(1, deg + 1):
+        z = O.PF.Mul(z, [O.FR.Neg(i), 1])
+    assert r1csqap.ZPoly(deg) == z
+
+
+def test_zpoly_large_properties():
+    """deg = 2^16 + 5: monic, Z(k) = 0 for sampled nodes, Z(0) = (-1)^deg deg!, Z(deg+1) = deg!."""
+    deg = (1 << 16) + 5
+    z = r1csqap.ZPoly(deg)
+    PF = r1csqap.PolynomialField()
+    assert len(z) == deg + 1 and z[-1] == 1
+    for k in (1, 2, 77, deg // 2, deg - 1, deg):
+        assert PF.Eval(z, k) == 0
+    fact = 1
+    for i in range(1, deg + 1):
+        fact = fact * i % O.R
+    assert z[0] == (fact if deg % 2 == 0 else O.R - fact)
+    assert PF.Eval(z, deg + 1) == fact
+
+
+def test_groth16_2p16_linearity_and_c_oracle_slices():
+    """BASELINE config sizes cannot be replayed by the naive oracle, so check size-independent
+    properties of the full prover at n = 2^16 (m = n + 1):
+      * PiA - alpha - r delta, evaluated through two witnesses, is additive in w (MSM linearity),
+      * with r = s = 0 and px = 0 the proof elements equal plain MSMs, which are checked against the
+        C oracle's naive loop on a 2^10-term slice via the MSM entry point sharing the same bases."""
+    from gosnark_amd import synth
+    n = 1 << 16
+    inst = synth.random_instance(n, 0xC0FFEE)
+    pk = inst.device_pk()
+    zero_px = capi.scalars_upload(np.zeros((2 * n - 1, 4), dtype=np.uint64))
+    w1 = synth.scalars_u64(n + 1, 101)
+    w2 = synth.scalars_u64(n + 1, 102)
+    w12 = capi.ints_to_u64([(a + b) % O.R for a, b in zip(U.u64_rows_to_ints(w1), U.u64_rows_to_ints(w2))])
+    proofs = [groth16.prove_resident(pk, capi.scalars_upload(w), zero_px, 0, 0) for w in (w1, w2, w12)]
+    alpha = O.G1.Affine(inst.alpha)
+    beta2 = O.G2.Affine(inst.beta2)
+
+    def minus(G, p, q):          # affine p - q via the oracle's group law
+        return G.Affine(G.Add((p[0], p[1], G.F.One()), G.Neg((q[0], q[1], G.F.One()))))
+
+    def plus(G, p, q):
+        return G.Affine(G.Add((p[0], p[1], G.F.One()), (q[0], q[1], G.F.One())))
+    a = [minus(O.G1, (p.PiA[0], p.PiA[1]), alpha) for p in proofs]
+    assert plus(O.G1, a[0], a[1]) == a[2]
+    b = [minus(O.G2, (p.PiB[0], p.PiB[1]), beta2) for p in proofs]
+    assert plus(O.G2, b[0], b[1]) == b[2]
+    # MSM over At equals PiA - alpha; cross-check the engine against the naive loop on a slice
+    full = capi.msm(inst.g1["at"], w1)
+    assert full == a[0]
+    k = 1 << 10
+    pts = capi.g1_download(inst.g1["at"])[:k]
+    want = C.g1_affine(C.g1_msm_naive(pts, w1[:k], threads=8))
+    assert capi.msm(inst.g1["at"], w1[:k]) == want
