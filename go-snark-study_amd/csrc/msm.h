@@ -8,8 +8,8 @@
 namespace gs {
 
 struct PlanBuffers {             // grow-only device workspaces owned by a plan slot
-  DevBuf hist, offsets, cursor, entries, tiles, total;
-  DevBuf nseg, seg_off, item_bucket, heavy_list, counters;
+  DevBuf digits, hist, totals, offsets, entries, tiles, total;
+  DevBuf chunk_bucket, heavy_list, counters;
 };
 
 struct MsmPlan {                 // digits of one scalar vector, bucket-sorted (device resident)
@@ -17,14 +17,12 @@ struct MsmPlan {                 // digits of one scalar vector, bucket-sorted (
   int c = 0, W = 0, L = 0;
   uint32_t B = 0;                // buckets per window
   uint32_t nbuckets = 0;         // W * B
-  const uint32_t* offsets = nullptr;   // nbuckets + 1
+  uint32_t maxchunks = 0;        // upper bound of the number of 32-entry chunks (the exact count stays on the device)
+  const uint32_t* offsets = nullptr;        // nbuckets + 1 (offsets[nbuckets] = number of entries)
   const uint32_t* entries = nullptr;
-  uint32_t S = 0;                      // max entries per bucket segment
-  uint32_t nitems = 0;                 // total segments (>= nbuckets)
-  uint32_t nheavy = 0;                 // buckets split into > 1 segment
-  const uint32_t* seg_off = nullptr;   // nbuckets + 1
-  const uint32_t* item_bucket = nullptr;
+  const uint32_t* chunk_bucket = nullptr;   // maxchunks
   const uint32_t* heavy_list = nullptr;
+  const uint32_t* heavy_count = nullptr;
 };
 
 int choose_window_bits(uint32_t n, int forced);

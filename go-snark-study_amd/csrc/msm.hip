@@ -13,7 +13,7 @@ static_assert(sizeof(G2Xyzz) == PointIO<Fq2Tag>::kXyzzWords * 4, "G2 XYZZ must b
 static inline dim3 grid1(size_t n, int block = 256) { return dim3((unsigned)((n + block - 1) / block)); }
 
 int choose_window_bits(uint32_t n, int forced) {
-  if (forced >= 2 && forced <= 20) return forced;
+  if (forced >= 2 && forced <= 16) return forced;
   int lg = 0;
   while ((1u << (lg + 1)) <= n) ++lg;                 // floor(log2 n), n >= 1
   int c = lg - 3;
@@ -39,43 +39,50 @@ void build_plan(Ctx& c, int slot, const uint32_t* scalars_dev, uint32_t n, MsmPl
   plan.B = 1u << (plan.c - 1);
   plan.L = (int)std::min<uint32_t>(8u, plan.B);
   plan.nbuckets = (uint32_t)plan.W * plan.B;
+  plan.maxchunks = (uint32_t)(((size_t)n * plan.W + kChunk - 1) / kChunk) + 1;
   const size_t ncount = (size_t)plan.nbuckets + 1;
-  pb.hist.ensure(ncount * 4);
+  PlanParams pp{};
+  pp.n = n; pp.c = plan.c; pp.W = plan.W; pp.B = plan.B;
+  pp.S = std::max<uint32_t>(1u, std::min<uint32_t>(16u, (n + 16383u) / 16384u));
+  pp.slice = (n + pp.S - 1) / pp.S;
+  pp.stride = (n + 63u) & ~63u;
+  pb.digits.ensure((size_t)std::max<uint32_t>(pp.stride, 64u) * plan.W * 2);
+  pb.hist.ensure((size_t)plan.nbuckets * pp.S * 4);
+  pb.totals.ensure(ncount * 4);
   pb.offsets.ensure(ncount * 4);
-  pb.cursor.ensure(ncount * 4);
-  pb.entries.ensure((size_t)n * plan.W * 4 + 16);
-  PlanParams pp{n, plan.c, plan.W, plan.B};
-  GS_HIP(hipMemsetAsync(pb.hist.p, 0, ncount * 4, c.stream));
-  if (n > 0) hipLaunchKernelGGL(k_digit_count, grid1(n), dim3(256), 0, c.stream, scalars_dev, pp, pb.hist.as<uint32_t>());
-  exclusive_scan(c, pb, pb.hist.as<uint32_t>(), pb.offsets.as<uint32_t>(), (uint32_t)ncount);
-  GS_HIP(hipMemcpyAsync(pb.cursor.p, pb.offsets.p, ncount * 4, hipMemcpyDeviceToDevice, c.stream));
-  if (n > 0) hipLaunchKernelGGL(k_digit_scatter, grid1(n), dim3(256), 0, c.stream, scalars_dev, pp, pb.cursor.as<uint32_t>(), pb.entries.as<uint32_t>());
+  pb.entries.ensure(((size_t)plan.maxchunks + 1) * kChunk * 4);
+  pb.chunk_bucket.ensure((size_t)plan.maxchunks * 4);
+  pb.heavy_list.ensure((size_t)kMaxHeavy * 4);
+  pb.counters.ensure(16);
+  const size_t lds = (size_t)plan.B * 4;
+  static bool lds_attr_set = false;
+  if (!lds_attr_set) {       // B <= 2^15 counters = 128 KiB of the CU's 160 KiB LDS
+    GS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hist), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    GS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    lds_attr_set = true;
+  }
+  GS_HIP(hipMemsetAsync(pb.totals.as<uint32_t>() + plan.nbuckets, 0, 4, c.stream));
+  GS_HIP(hipMemsetAsync(pb.counters.p, 0, 16, c.stream));
+  if (n > 0) {
+    hipLaunchKernelGGL(k_digits, grid1(n), dim3(256), 0, c.stream, scalars_dev, pp, pb.digits.as<uint16_t>());
+    hipLaunchKernelGGL(k_hist, dim3(plan.W, pp.S), dim3(kSortBlock), lds, c.stream, pb.digits.as<uint16_t>(), pp, pb.hist.as<uint32_t>());
+    hipLaunchKernelGGL(k_colscan, grid1(plan.nbuckets), dim3(256), 0, c.stream, pb.hist.as<uint32_t>(), pp, pb.totals.as<uint32_t>());
+  } else {
+    GS_HIP(hipMemsetAsync(pb.totals.p, 0, ncount * 4, c.stream));
+  }
+  exclusive_scan(c, pb, pb.totals.as<uint32_t>(), pb.offsets.as<uint32_t>(), (uint32_t)ncount);
+  if (n > 0) {
+    hipLaunchKernelGGL(k_scatter, dim3(plan.W, pp.S), dim3(kSortBlock), lds, c.stream, pb.digits.as<uint16_t>(), pp, pb.hist.as<uint32_t>(),
+                       pb.offsets.as<uint32_t>(), pb.entries.as<uint32_t>());
+    hipLaunchKernelGGL(k_chunk_map, grid1(plan.nbuckets), dim3(256), 0, c.stream, pb.offsets.as<uint32_t>(), plan.nbuckets,
+                       pb.chunk_bucket.as<uint32_t>(), pb.heavy_list.as<uint32_t>(), pb.counters.as<uint32_t>());
+  }
   GS_HIP(hipGetLastError());
   plan.offsets = pb.offsets.as<uint32_t>();
   plan.entries = pb.entries.as<uint32_t>();
-  // segmentation: cap the work of one accumulate thread at S entries
-  plan.S = std::max<uint32_t>(64u, 4u * (uint32_t)(((size_t)n + plan.B - 1) / plan.B));
-  pb.nseg.ensure(ncount * 4);
-  pb.seg_off.ensure(ncount * 4);
-  pb.counters.ensure(16);
-  hipLaunchKernelGGL(k_seg_count, grid1(ncount), dim3(256), 0, c.stream, plan.offsets, plan.nbuckets, plan.S, pb.nseg.as<uint32_t>());
-  exclusive_scan(c, pb, pb.nseg.as<uint32_t>(), pb.seg_off.as<uint32_t>(), (uint32_t)ncount);
-  const size_t max_items = (size_t)plan.nbuckets + ((size_t)n * plan.W) / plan.S + 1;
-  pb.item_bucket.ensure(max_items * 4);
-  pb.heavy_list.ensure(((size_t)n * plan.W / plan.S + 2) * 4);
-  GS_HIP(hipMemsetAsync(pb.counters.p, 0, 16, c.stream));
-  hipLaunchKernelGGL(k_seg_expand, grid1(plan.nbuckets), dim3(256), 0, c.stream, pb.seg_off.as<uint32_t>(), plan.nbuckets,
-                     pb.item_bucket.as<uint32_t>(), pb.heavy_list.as<uint32_t>(), pb.counters.as<uint32_t>());
-  GS_HIP(hipGetLastError());
-  uint32_t host_counts[2] = {0, 0};
-  GS_HIP(hipMemcpyAsync(&host_counts[0], pb.seg_off.as<uint32_t>() + plan.nbuckets, 4, hipMemcpyDeviceToHost, c.stream));
-  GS_HIP(hipMemcpyAsync(&host_counts[1], pb.counters.p, 4, hipMemcpyDeviceToHost, c.stream));
-  GS_HIP(hipStreamSynchronize(c.stream));
-  plan.nitems = host_counts[0];
-  plan.nheavy = host_counts[1];
-  plan.seg_off = pb.seg_off.as<uint32_t>();
-  plan.item_bucket = pb.item_bucket.as<uint32_t>();
+  plan.chunk_bucket = pb.chunk_bucket.as<uint32_t>();
   plan.heavy_list = pb.heavy_list.as<uint32_t>();
+  plan.heavy_count = pb.counters.as<uint32_t>();
 }
 
 // sum_w 2^(c w) S_w on the host core
@@ -102,22 +109,23 @@ static void msm_run(Ctx& c, const MsmPlan& plan, const std::vector<const uint32_
   for (int j = 0; j < njobs; ++j) {
     DevBuf& bk = c.ws_buckets[(ws_base + j) % 8];
     DevBuf& ch = c.ws_chunks[(ws_base + j) % 8];
-    bk.ensure((size_t)plan.nitems * pw * 4);
+    DevBuf& pt = c.ws_partials[(ws_base + j) % 8];
+    bk.ensure((size_t)plan.nbuckets * pw * 4);
     ch.ensure((size_t)nchunks * pw * 4);
-    jobs.j[j] = AccJob{bases[j], bk.as<uint32_t>(), ch.as<uint32_t>()};
+    pt.ensure((size_t)plan.maxchunks * 2 * pw * 4);
+    jobs.j[j] = AccJob{bases[j], bk.as<uint32_t>(), pt.as<uint32_t>(), pt.as<uint32_t>() + (size_t)plan.maxchunks * pw, ch.as<uint32_t>()};
   }
   PhaseTimer tacc(c.stream);
   PhaseTimer tker(c.stream);
-  hipLaunchKernelGGL(k_bucket_accumulate<T>, dim3((plan.nitems + 255) / 256, njobs), dim3(256), 0, c.stream,
-                     jobs, plan.offsets, plan.entries, plan.seg_off, plan.item_bucket, plan.nitems, plan.S);
+  hipLaunchKernelGGL(k_bucket_accumulate<T>, dim3((plan.maxchunks + 255) / 256, njobs), dim3(256), 0, c.stream,
+                     jobs, plan.offsets, plan.entries, plan.chunk_bucket, plan.nbuckets);
   tker.stop();
-  if (plan.nheavy)
-    hipLaunchKernelGGL(k_heavy_combine<T>, dim3(plan.nheavy, njobs), dim3(kHeavyBlock), 0, c.stream,
-                       jobs, plan.seg_off, plan.heavy_list);
+  hipLaunchKernelGGL(k_heavy_combine<T>, dim3(64, njobs), dim3(kHeavyBlock), 0, c.stream,
+                     jobs, plan.offsets, plan.heavy_list, plan.heavy_count);
   tacc.stop();
   PhaseTimer tred(c.stream);
   hipLaunchKernelGGL(k_bucket_reduce<T>, dim3((nchunks + 255) / 256, njobs), dim3(256), 0, c.stream,
-                     jobs, plan.seg_off, plan.B, plan.L, nchunks);
+                     jobs, plan.offsets, plan.B, plan.L, nchunks);
   for (uint32_t half = chunks_per_window / 2; half >= 1; half /= 2) {
     const uint32_t work = (uint32_t)plan.W * half;
     hipLaunchKernelGGL(k_fold<T>, dim3((work + 255) / 256, njobs), dim3(256), 0, c.stream,

@@ -5,14 +5,16 @@
 // per term ~254 doublings + ~127 additions there, W = ceil(254/c) mixed additions here.
 //
 // Pipeline (all on the library stream, no host round trips):
-//   plan (once per scalar vector, shared by every base array multiplied by it):
-//     k_digit_count   scalars -> signed c-bit digits, histogram per (window, bucket)
-//     scan            exclusive prefix sum -> bucket offsets
-//     k_digit_scatter point index (sign in bit 31) into its bucket's slot (counting sort)
-//     k_seg_count/expand   split buckets with > S entries into segments (load balance)
+//   plan (once per scalar vector, shared by every base array multiplied by it; no host round trip):
+//     k_digits        scalars -> signed c-bit digit matrix (u16)
+//     k_hist          per (window, slice) workgroup: bucket histogram in LDS (128 KiB of the 160 KiB)
+//     k_colscan+scan  exclusive prefix sums -> bucket offsets, per-slice cursors
+//     k_scatter       counting sort with LDS cursors: entries[] = term index (sign in bit 31) grouped by bucket
+//     k_chunk_map     cut the sorted entry list into equal chunks of 32 entries (load balance)
 //   per base array:
-//     k_bucket_accumulate  one thread per bucket segment: XYZZ += +-affine base (8M+2S)  <- dominant
-//     k_heavy_combine      one block per split bucket: tree-sum of its segment partials
+//     k_bucket_accumulate  one thread per CHUNK: XYZZ += +-affine base (8M+2S), flushing at bucket
+//                          boundaries; cut buckets leave head/tail partials                      <- dominant
+//     k_heavy_combine      block-wide tree-sum for buckets cut into many chunks
 //     k_bucket_reduce      per chunk of L buckets: sum_j (b0+j+1) * bucket -> one point
 //     k_fold               pairwise folding of the chunk points -> one point per window
 //     k_gather_window_sums -> host: Horner sum_w 2^(cw) S_w, to affine, from Montgomery
@@ -31,12 +33,15 @@ namespace gs {
 
 struct PlanParams {
   uint32_t n;        // scalars
-  int c;             // window bits
+  int c;             // window bits (<= 16: a signed digit fits a u16)
   int W;             // windows = floor(254 / c) + 1
-  uint32_t B;        // buckets per window = 2^(c-1)   (digits are signed: [-B, B])
+  uint32_t B;        // buckets per window = 2^(c-1)   (digits are signed: [-B+1, B])
+  uint32_t S;        // slices of the scalar vector (one histogram/scatter workgroup per (window, slice))
+  uint32_t slice;    // scalars per slice
+  uint32_t stride;   // row stride of the digit matrix (elements)
 };
 
-// signed digit of window w with the running carry (digit in [-B, B], never 0 <-> skipped)
+// signed digit of window w with the running carry (digit in [-B+1, B]; 0 <-> the term is skipped in that window)
 GS_HD int32_t next_digit(const uint32_t (&k)[8], const PlanParams& pp, int w, uint32_t& carry) {
   uint32_t raw = scalar_bits(k, w * pp.c, pp.c) + carry;
   if (raw > pp.B) { carry = 1; return (int32_t)raw - (int32_t)(2u * pp.B); }
@@ -44,8 +49,8 @@ GS_HD int32_t next_digit(const uint32_t (&k)[8], const PlanParams& pp, int w, ui
   return (int32_t)raw;
 }
 
-__global__ void __launch_bounds__(256) k_digit_count(const uint32_t* __restrict__ scalars, PlanParams pp,
-                                                      uint32_t* __restrict__ hist) {
+// ---- plan, step 1: scalars -> digit matrix digits[w][i] = d + B - 1 (u16), read once, coalesced --------------
+__global__ void __launch_bounds__(256) k_digits(const uint32_t* __restrict__ scalars, PlanParams pp, uint16_t* __restrict__ digits) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= pp.n) return;
   uint32_t k[8];
@@ -55,29 +60,59 @@ __global__ void __launch_bounds__(256) k_digit_count(const uint32_t* __restrict_
   scalar_canon(k);
   uint32_t carry = 0;
   for (int w = 0; w < pp.W; ++w) {
-    int32_t d = next_digit(k, pp, w, carry);
-    if (d != 0) {
-      uint32_t b = (uint32_t)(d < 0 ? -d : d) - 1u;
-      atomicAdd(&hist[(size_t)w * pp.B + b], 1u);
-    }
+    const int32_t d = next_digit(k, pp, w, carry);
+    digits[(size_t)w * pp.stride + i] = (uint16_t)(d + (int32_t)pp.B - 1);
   }
 }
 
-__global__ void __launch_bounds__(256) k_digit_scatter(const uint32_t* __restrict__ scalars, PlanParams pp,
-                                                        uint32_t* __restrict__ cursor, uint32_t* __restrict__ entries) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= pp.n) return;
-  uint32_t k[8];
-  const uint4* s4 = reinterpret_cast<const uint4*>(scalars + (size_t)i * 8);
-  uint4 lo = s4[0], hi = s4[1];
-  k[0] = lo.x; k[1] = lo.y; k[2] = lo.z; k[3] = lo.w; k[4] = hi.x; k[5] = hi.y; k[6] = hi.z; k[7] = hi.w;
-  scalar_canon(k);
-  uint32_t carry = 0;
-  for (int w = 0; w < pp.W; ++w) {
-    int32_t d = next_digit(k, pp, w, carry);
+// ---- plan, step 2: per-(window, slice) bucket histogram in LDS (B counters <= 128 KiB of the CU's 160 KiB) -----
+// grid = (W, S): blockIdx.x = window, so that all slices of a window run on XCD (w % 8) and the window's
+// 4n-byte region of `entries` is assembled in ONE L2 by the scatter pass below.
+constexpr int kSortBlock = 1024;
+__global__ void __launch_bounds__(kSortBlock) k_hist(const uint16_t* __restrict__ digits, PlanParams pp, uint32_t* __restrict__ hist) {
+  extern __shared__ uint32_t sh[];
+  const uint32_t w = blockIdx.x, s = blockIdx.y;
+  for (uint32_t b = threadIdx.x; b < pp.B; b += kSortBlock) sh[b] = 0;
+  __syncthreads();
+  const uint32_t lo = s * pp.slice, hi = min(pp.n, lo + pp.slice);
+  const uint16_t* row = digits + (size_t)w * pp.stride;
+  const int32_t zero = (int32_t)pp.B - 1;
+  for (uint32_t i = lo + threadIdx.x; i < hi; i += kSortBlock) {
+    const int32_t d = (int32_t)row[i] - zero;
+    if (d != 0) atomicAdd(&sh[(uint32_t)(d < 0 ? -d : d) - 1u], 1u);
+  }
+  __syncthreads();
+  uint32_t* out = hist + ((size_t)w * pp.S + s) * pp.B;
+  for (uint32_t b = threadIdx.x; b < pp.B; b += kSortBlock) out[b] = sh[b];
+}
+
+// hist[w][s][b] -> exclusive prefix over s (in place); totals[w*B + b] = sum over s
+__global__ void __launch_bounds__(256) k_colscan(uint32_t* __restrict__ hist, PlanParams pp, uint32_t* __restrict__ totals) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= (uint32_t)pp.W * pp.B) return;
+  const uint32_t w = g / pp.B, b = g - w * pp.B;
+  uint32_t* col = hist + (size_t)w * pp.S * pp.B + b;
+  uint32_t run = 0;
+  for (uint32_t s = 0; s < pp.S; ++s) { const uint32_t t = col[(size_t)s * pp.B]; col[(size_t)s * pp.B] = run; run += t; }
+  totals[g] = run;
+}
+
+// ---- plan, step 4: counting-sort scatter; cursors live in LDS, entries[pos] = term index | sign -----------------
+__global__ void __launch_bounds__(kSortBlock) k_scatter(const uint16_t* __restrict__ digits, PlanParams pp, const uint32_t* __restrict__ hist,
+                                                         const uint32_t* __restrict__ offsets, uint32_t* __restrict__ entries) {
+  extern __shared__ uint32_t sh[];
+  const uint32_t w = blockIdx.x, s = blockIdx.y;
+  const uint32_t* pre = hist + ((size_t)w * pp.S + s) * pp.B;
+  const uint32_t* off = offsets + (size_t)w * pp.B;
+  for (uint32_t b = threadIdx.x; b < pp.B; b += kSortBlock) sh[b] = off[b] + pre[b];
+  __syncthreads();
+  const uint32_t lo = s * pp.slice, hi = min(pp.n, lo + pp.slice);
+  const uint16_t* row = digits + (size_t)w * pp.stride;
+  const int32_t zero = (int32_t)pp.B - 1;
+  for (uint32_t i = lo + threadIdx.x; i < hi; i += kSortBlock) {
+    const int32_t d = (int32_t)row[i] - zero;
     if (d != 0) {
-      uint32_t b = (uint32_t)(d < 0 ? -d : d) - 1u;
-      uint32_t pos = atomicAdd(&cursor[(size_t)w * pp.B + b], 1u);
+      const uint32_t pos = atomicAdd(&sh[(uint32_t)(d < 0 ? -d : d) - 1u], 1u);
       entries[pos] = i | (d < 0 ? kSignBit : 0u);
     }
   }
@@ -136,36 +171,39 @@ __global__ void __launch_bounds__(kScanBlock) k_scan_add(uint32_t* __restrict__ 
   for (int j = 0; j < kScanPerThread; ++j) if (base + j < n) out[base + j] += add;
 }
 
-// ---- bucket segmentation (load balance for skewed scalar distributions) -----------------------------
-// A bucket with more than S entries is split into ceil(cnt/S) segments, each accumulated by its own
-// thread; the segment partials of such "heavy" buckets are then tree-reduced by one block per bucket.
-// (Uniform scalars with c chosen for n give ~all buckets one segment; 0/1-heavy witnesses and the
-// short top window do not.)  Every bucket owns >= 1 item so that item order == bucket order.
-__global__ void __launch_bounds__(256) k_seg_count(const uint32_t* __restrict__ offsets, uint32_t nbuckets, uint32_t S,
-                                                    uint32_t* __restrict__ nseg) {
-  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b > nbuckets) return;
-  if (b == nbuckets) { nseg[b] = 0; return; }
-  const uint32_t cnt = offsets[b + 1] - offsets[b];
-  nseg[b] = cnt <= S ? 1u : (cnt + S - 1) / S;
-}
+// ---- chunk map (load balance) ------------------------------------------------------------------------------
+// The sorted entry list is cut into chunks of kChunk entries, ONE accumulate thread per chunk, whatever the
+// bucket sizes are (uniform scalars: Poisson-sized buckets; real witnesses: 0/1-heavy ones).  A bucket that is
+// cut by chunk boundaries is summed from per-chunk partials:  sum_{t = first}^{last-1} tail[t] + head[last].
+// chunk_bucket[t] = bucket holding entry t*kChunk.  Buckets cut into more than kHeavySpan + 1 pieces are listed
+// for a block-wide tree combine (k_heavy_combine), the others are combined by whoever reads them.
+constexpr uint32_t kChunk = 32;
+constexpr uint32_t kHeavySpan = 8;
+constexpr uint32_t kMaxHeavy = 1u << 16;
 
-__global__ void __launch_bounds__(256) k_seg_expand(const uint32_t* __restrict__ seg_off, uint32_t nbuckets,
-                                                     uint32_t* __restrict__ item_bucket, uint32_t* __restrict__ heavy_list,
-                                                     uint32_t* __restrict__ heavy_count) {
+__global__ void __launch_bounds__(256) k_chunk_map(const uint32_t* __restrict__ offsets, uint32_t nbuckets,
+                                                    uint32_t* __restrict__ chunk_bucket, uint32_t* __restrict__ heavy_list,
+                                                    uint32_t* __restrict__ heavy_count) {
   const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= nbuckets) return;
-  const uint32_t beg = seg_off[b], end = seg_off[b + 1];
-  for (uint32_t i = beg; i < end; ++i) item_bucket[i] = b;
-  if (end - beg > 1) heavy_list[atomicAdd(heavy_count, 1u)] = b;
+  const uint32_t o0 = offsets[b], o1 = offsets[b + 1];
+  if (o1 == o0) return;
+  const uint32_t t0 = (o0 + kChunk - 1) / kChunk, t1 = (o1 + kChunk - 1) / kChunk;   // chunks starting inside [o0, o1)
+  for (uint32_t t = t0; t < t1; ++t) chunk_bucket[t] = b;
+  if ((o1 - 1) / kChunk - o0 / kChunk > kHeavySpan) {
+    const uint32_t slot = atomicAdd(heavy_count, 1u);
+    if (slot < kMaxHeavy) heavy_list[slot] = b;
+  }
 }
 
 // ---- bucket accumulation (dominant kernel) ---------------------------------------------------------
-// One thread per bucket; its entries are contiguous in `entries`.  grid.y = base array (job).
+// grid.y = base array (job): up to 8 arrays share one plan (Groth16: At, BACGamma, BACDelta on w's plan).
 struct AccJob {
   const uint32_t* bases;      // packed affine, already offset to the first term's point
-  uint32_t* buckets;          // nitems * kXyzzWords: per-segment partial sums; bucket b lives at seg_off[b]
-  uint32_t* chunks;           // (W * B / L) * kXyzzWords : per-chunk weighted sums, folded in place
+  uint32_t* buckets;          // nbuckets * kXyzzWords: buckets that live inside one chunk (or were tree-combined)
+  uint32_t* heads;            // maxchunks * kXyzzWords: partial of the bucket that began in an earlier chunk and ends here
+  uint32_t* tails;            // maxchunks * kXyzzWords: partial of the bucket that continues into the next chunk
+  uint32_t* chunks;           // (W * B / L) * kXyzzWords : per-chunk weighted sums of the reducer, folded in place
 };
 constexpr int kMaxJobs = 8;
 struct AccJobs { AccJob j[kMaxJobs]; };
@@ -173,59 +211,95 @@ struct AccJobs { AccJob j[kMaxJobs]; };
 template <class T>
 __global__ void __launch_bounds__(256) k_bucket_accumulate(AccJobs jobs, const uint32_t* __restrict__ offsets,
                                                             const uint32_t* __restrict__ entries,
-                                                            const uint32_t* __restrict__ seg_off,
-                                                            const uint32_t* __restrict__ item_bucket,
-                                                            uint32_t nitems, uint32_t S) {
-  const uint32_t it = blockIdx.x * blockDim.x + threadIdx.x;
-  if (it >= nitems) return;
+                                                            const uint32_t* __restrict__ chunk_bucket, uint32_t nbuckets) {
+  constexpr int pw = PointIO<T>::kXyzzWords;
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t total = offsets[nbuckets];
+  const uint32_t beg = t * kChunk;
+  if (beg >= total) return;
+  const uint32_t end = min(beg + kChunk, total);
   const AccJob job = jobs.j[blockIdx.y];
-  const uint32_t b = item_bucket[it];
-  const uint32_t seg = it - seg_off[b];
-  const uint32_t bend = offsets[b + 1];
-  const uint32_t beg = offsets[b] + seg * S;
-  const uint32_t end = (seg_off[b + 1] - seg_off[b] == 1u) ? bend : min(beg + S, bend);
+  uint32_t b = chunk_bucket[t];
+  uint32_t bend = offsets[b + 1];
+  bool started_before = offsets[b] < beg;
   Xyzz<T> acc = xyzz_inf<T>();
-  for (uint32_t e = beg; e < end; ++e) {
-    const uint32_t v = entries[e];
-    const uint32_t idx = v & ~kSignBit;
-    const Affine<T> p = PointIO<T>::load_affine(job.bases + (size_t)idx * PointIO<T>::kAffineWords);
-    xyzz_madd(acc, p, (v & kSignBit) != 0);
+  const uint4* e4 = reinterpret_cast<const uint4*>(entries + beg);      // beg is a multiple of 32 entries = 128 B
+  for (uint32_t e = beg; e < end; e += 4) {
+    const uint4 q = e4[(e - beg) >> 2];
+    const uint32_t vv[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (e + u < end) {
+        if (e + u >= bend) {                                            // bucket b is complete
+          store_xyzz<T>((started_before ? job.heads + (size_t)t * pw : job.buckets + (size_t)b * pw), acc);
+          started_before = false;
+          acc = xyzz_inf<T>();
+          do { ++b; bend = offsets[b + 1]; } while (bend <= e + u);
+        }
+        const uint32_t v = vv[u];
+        const Affine<T> p = PointIO<T>::load_affine(job.bases + (size_t)(v & ~kSignBit) * PointIO<T>::kAffineWords);
+        xyzz_madd(acc, p, (v & kSignBit) != 0);
+      }
+    }
   }
-  store_xyzz<T>(job.buckets + (size_t)it * PointIO<T>::kXyzzWords, acc);
+  uint32_t* dst = (bend > end) ? job.tails + (size_t)t * pw
+                               : (started_before ? job.heads + (size_t)t * pw : job.buckets + (size_t)b * pw);
+  store_xyzz<T>(dst, acc);
 }
 
-// one block per heavy bucket: partials[seg_off[b] .. seg_off[b+1]) -> partials[seg_off[b]]
+// the sum of bucket b, wherever its pieces are
+template <class T>
+GS_HD Xyzz<T> load_bucket(const AccJob& job, const uint32_t* __restrict__ offsets, uint32_t b) {
+  constexpr int pw = PointIO<T>::kXyzzWords;
+  const uint32_t o0 = offsets[b], o1 = offsets[b + 1];
+  if (o1 == o0) return xyzz_inf<T>();
+  const uint32_t tf = o0 / kChunk, tl = (o1 - 1) / kChunk;
+  if (tf == tl || tl - tf > kHeavySpan) return load_xyzz<T>(job.buckets + (size_t)b * pw);
+  Xyzz<T> acc = load_xyzz<T>(job.heads + (size_t)tl * pw);
+  for (uint32_t t = tf; t < tl; ++t) {
+    const Xyzz<T> p = load_xyzz<T>(job.tails + (size_t)t * pw);
+    xyzz_add(acc, p);
+  }
+  return acc;
+}
+
+// one block per heavy bucket (grid-stride over the device-side list): tails[first..last) + heads[last] -> buckets[b]
 constexpr int kHeavyBlock = 128;
 template <class T>
-__global__ void __launch_bounds__(kHeavyBlock) k_heavy_combine(AccJobs jobs, const uint32_t* __restrict__ seg_off,
-                                                                const uint32_t* __restrict__ heavy_list) {
+__global__ void __launch_bounds__(kHeavyBlock) k_heavy_combine(AccJobs jobs, const uint32_t* __restrict__ offsets,
+                                                                const uint32_t* __restrict__ heavy_list,
+                                                                const uint32_t* __restrict__ heavy_count) {
   constexpr int pw = PointIO<T>::kXyzzWords;
   __shared__ uint32_t sh[kHeavyBlock * pw];
   const AccJob job = jobs.j[blockIdx.y];
-  const uint32_t b = heavy_list[blockIdx.x];
-  const uint32_t beg = seg_off[b], end = seg_off[b + 1];
-  Xyzz<T> acc = xyzz_inf<T>();
-  for (uint32_t i = beg + threadIdx.x; i < end; i += kHeavyBlock) {
-    Xyzz<T> p = load_xyzz<T>(job.buckets + (size_t)i * pw);
-    xyzz_add(acc, p);
-  }
-  store_xyzz<T>(sh + threadIdx.x * pw, acc);
-  __syncthreads();
-  for (int half = kHeavyBlock / 2; half >= 1; half >>= 1) {
-    if ((int)threadIdx.x < half) {
-      Xyzz<T> o = load_xyzz<T>(sh + (threadIdx.x + half) * pw);
-      xyzz_add(acc, o);
-      store_xyzz<T>(sh + threadIdx.x * pw, acc);
+  const uint32_t nheavy = min(*heavy_count, kMaxHeavy);
+  for (uint32_t h = blockIdx.x; h < nheavy; h += gridDim.x) {
+    const uint32_t b = heavy_list[h];
+    const uint32_t tf = offsets[b] / kChunk, tl = (offsets[b + 1] - 1) / kChunk;
+    Xyzz<T> acc = xyzz_inf<T>();
+    for (uint32_t t = tf + threadIdx.x; t <= tl; t += kHeavyBlock) {
+      const Xyzz<T> p = load_xyzz<T>((t == tl ? job.heads : job.tails) + (size_t)t * pw);
+      xyzz_add(acc, p);
     }
+    store_xyzz<T>(sh + threadIdx.x * pw, acc);
+    __syncthreads();
+    for (int half = kHeavyBlock / 2; half >= 1; half >>= 1) {
+      if ((int)threadIdx.x < half) {
+        Xyzz<T> o = load_xyzz<T>(sh + (threadIdx.x + half) * pw);
+        xyzz_add(acc, o);
+        store_xyzz<T>(sh + threadIdx.x * pw, acc);
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) store_xyzz<T>(job.buckets + (size_t)b * pw, acc);
     __syncthreads();
   }
-  if (threadIdx.x == 0) store_xyzz<T>(job.buckets + (size_t)beg * pw, acc);
 }
 
 // ---- bucket reduction -------------------------------------------------------------------------------
 // thread t of window w owns buckets [t*L, (t+1)*L): returns sum_j (t*L + j + 1) * bucket[t*L + j]
 template <class T>
-__global__ void __launch_bounds__(256) k_bucket_reduce(AccJobs jobs, const uint32_t* __restrict__ seg_off,
+__global__ void __launch_bounds__(256) k_bucket_reduce(AccJobs jobs, const uint32_t* __restrict__ offsets,
                                                         uint32_t B, int L, uint32_t nchunks_total) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;     // chunk index over all windows
   if (t >= nchunks_total) return;
@@ -233,10 +307,10 @@ __global__ void __launch_bounds__(256) k_bucket_reduce(AccJobs jobs, const uint3
   const uint32_t chunks_per_window = B / (uint32_t)L;
   const uint32_t w = t / chunks_per_window, tw = t % chunks_per_window;
   const uint32_t b0 = tw * (uint32_t)L;                          // first bucket (0-based) of the chunk, weight b0+1
-  const uint32_t* so = seg_off + ((size_t)w * B + b0);
+  const uint32_t gb = w * B + b0;
   Xyzz<T> run = xyzz_inf<T>(), acc = xyzz_inf<T>();
   for (int j = L - 1; j >= 0; --j) {
-    Xyzz<T> bk = load_xyzz<T>(job.buckets + (size_t)so[j] * PointIO<T>::kXyzzWords);
+    Xyzz<T> bk = load_bucket<T>(job, offsets, gb + (uint32_t)j);
     xyzz_add(run, bk);
     xyzz_add(acc, run);
   }
@@ -263,7 +337,7 @@ __global__ void __launch_bounds__(256) k_fold(AccJobs jobs, uint32_t nseg, uint3
 
 // gather the W window sums (first point of each folded segment) of every job into one
 // contiguous buffer [job][w] for a single D2H copy; the O(W*c) serial Horner combination
-// sum_w 2^(cw) S_w runs on the host core (msm_host.h): a lone wave retires one 254-step
+// sum_w 2^(cw) S_w runs on the host core (msm.hip): a lone wave retires one 254-step
 // doubling chain in ~2.5 ms, a CPU core in ~0.2 ms.
 template <class T>
 __global__ void k_gather_window_sums(AccJobs jobs, uint32_t seglen, int W, uint32_t* __restrict__ out) {

@@ -97,7 +97,7 @@ struct Ctx {
   gs_timing timing{};
   // reusable workspaces (grow-only)
   DevBuf ws_hist, ws_offsets, ws_cursor, ws_entries, ws_tiles, ws_total;
-  DevBuf ws_buckets[8], ws_chunks[8], ws_winsums;
+  DevBuf ws_buckets[8], ws_chunks[8], ws_partials[8], ws_winsums;
   DevBuf ws_misc;
   DevBuf g1_pow2, g2_pow2;       // 2^j * G tables (lazy)
   std::vector<hipEvent_t> events;

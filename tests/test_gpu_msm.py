@@ -175,3 +175,31 @@ def test_sum_affine_combines_partial_sums():
     for p in parts2:
         acc = O.G2.Add(acc, (p[0], p[1], (1, 0)))
     assert capi.sum_affine(parts2, g2=True) == O.G2.Affine(acc)
+
+
+@pytest.mark.parametrize("g2", [False, True])
+def test_msm_skewed_witness_heavy_buckets(g2):
+    """Real witnesses are dominated by 0/1 and small values (boolean constraints): a few buckets then hold
+    thousands of entries and are cut across many 32-entry chunks (partials + block-wide tree combine),
+    while most buckets are empty.  8192 terms, 60 % ones, 20 % zeros, 10 % r-1, rest uniform -- vs the C
+    oracle's naive loop over the very same points."""
+    n = 1 << 13
+    rng = random.Random(9090 + g2)
+    uni = U.u64_rows_to_ints(U.rand_scalars_u64(n, 77))
+    ks = []
+    for i in range(n):
+        x = rng.random()
+        ks.append(1 if x < 0.6 else 0 if x < 0.8 else O.R - 1 if x < 0.9 else uni[i])
+    ks = capi.ints_to_u64(ks)
+    if g2:
+        bases = capi.g2_fixed_base(U.rand_scalars_u64(n, 78))
+        want = C.g2_affine(C.g2_msm_naive(capi.g2_download(bases), ks, threads=8))
+    else:
+        bases = capi.g1_fixed_base(U.rand_scalars_u64(n, 78))
+        want = C.g1_affine(C.g1_msm_naive(capi.g1_download(bases), ks, threads=8))
+    for c in (0, 5, 13):
+        capi.set_window_bits(c)
+        try:
+            assert capi.msm(bases, ks, g2=g2) == want, c
+        finally:
+            capi.set_window_bits(0)
