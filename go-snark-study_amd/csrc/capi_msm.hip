@@ -72,7 +72,12 @@ int msm_resident(Ctx& c, Kind kind, gs_handle hb, size_t off, const uint32_t* sc
   if (!b) return fail(GS_ERR_ARG, "bad base handle");
   if (!out_affine || !is_inf) return fail(GS_ERR_ARG, "null output");
   if (off > b->n || n > b->n - off) return fail(GS_ERR_ARG, "term range [%zu, %zu) exceeds the %zu resident points", off, off + n, b->n);
-  constexpr size_t aw = 2 * T::kWords;
+  // window table of this base array for the width the plan will use (built on first use, kept resident)
+  if (!b->table) b->table = std::make_shared<BaseTable>();
+  BaseTable* tab = static_cast<BaseTable*>(b->table.get());
+  const int cbits = choose_window_bits((uint32_t)n, c.window_bits);
+  if constexpr (T::kWords == 8) ensure_table_g1(c, *tab, b->buf.as<uint32_t>(), b->n, cbits);
+  else ensure_table_g2(c, *tab, b->buf.as<uint32_t>(), b->n, cbits);
   PhaseTimer total(c.stream);
   MsmPlan plan;
   {
@@ -81,7 +86,7 @@ int msm_resident(Ctx& c, Kind kind, gs_handle hb, size_t off, const uint32_t* sc
     tp.stop();
     c.timing.plan_ms += tp.ms();
   }
-  std::vector<const uint32_t*> bases{b->buf.as<uint32_t>() + off * aw};
+  std::vector<MsmBase> bases{MsmBase{tab, off}};
   bool inf;
   if constexpr (T::kWords == 8) {
     std::vector<G1Xyzz> r;

@@ -14,7 +14,7 @@ struct PlanBuffers {             // grow-only device workspaces owned by a plan 
 
 struct MsmPlan {                 // digits of one scalar vector, bucket-sorted (device resident)
   uint32_t n = 0;
-  int c = 0, W = 0, L = 0;
+  int c = 0, W = 0;
   uint32_t B = 0;                // buckets per window
   uint32_t nbuckets = 0;         // W * B
   uint32_t maxchunks = 0;        // upper bound of the number of 32-entry chunks (the exact count stays on the device)
@@ -27,13 +27,29 @@ struct MsmPlan {                 // digits of one scalar vector, bucket-sorted (
 
 int choose_window_bits(uint32_t n, int forced);
 
+// Window table of a base array: rows[j][i] = 2^(c j) * P_i (packed affine), j < W = 254 / c + 1.
+struct BaseTable {
+  DevBuf rows;
+  size_t n = 0;
+  int c = 0, W = 0;
+};
+// (Re)build `t` for window width c from row 0 (`row0` = packed affine points; pass nullptr to rebuild from the
+// table's own row 0).  No-op when the table already matches.
+void ensure_table_g1(Ctx& c, BaseTable& t, const uint32_t* row0, size_t n, int cbits);
+void ensure_table_g2(Ctx& c, BaseTable& t, const uint32_t* row0, size_t n, int cbits);
+
+struct MsmBase {                 // one job of an MSM launch: a window table and the first term's offset in it
+  const BaseTable* table;
+  size_t off;
+};
+
 // scalars_dev: n x 8 u32 words (standard form, any 256-bit value).  slot: 0/1 (two plans may be alive)
 void build_plan(Ctx& c, int slot, const uint32_t* scalars_dev, uint32_t n, MsmPlan& plan);
 
-// One launch sequence for up to 8 base arrays sharing a plan.  bases[i] points at the packed affine
-// point of term 0.  Results: XYZZ (Montgomery) on the host, after the serial Horner combination.
-void msm_run_g1(Ctx& c, const MsmPlan& plan, const std::vector<const uint32_t*>& bases, std::vector<G1Xyzz>& out);
-void msm_run_g2(Ctx& c, const MsmPlan& plan, const std::vector<const uint32_t*>& bases, std::vector<G2Xyzz>& out);
+// One launch sequence for up to 8 base arrays sharing a plan (their tables must have been built for plan.c).
+// Results: XYZZ (Montgomery) on the host.
+void msm_run_g1(Ctx& c, const MsmPlan& plan, const std::vector<MsmBase>& bases, std::vector<G1Xyzz>& out);
+void msm_run_g2(Ctx& c, const MsmPlan& plan, const std::vector<MsmBase>& bases, std::vector<G2Xyzz>& out);
 
 // base-array helpers (device)
 void jacobian_to_affine_g1(Ctx& c, const uint32_t* jac_dev, uint32_t n, uint32_t* out_dev);

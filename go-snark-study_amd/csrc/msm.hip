@@ -13,11 +13,11 @@ static_assert(sizeof(G2Xyzz) == PointIO<Fq2Tag>::kXyzzWords * 4, "G2 XYZZ must b
 static inline dim3 grid1(size_t n, int block = 256) { return dim3((unsigned)((n + block - 1) / block)); }
 
 int choose_window_bits(uint32_t n, int forced) {
-  if (forced >= 2 && forced <= 16) return forced;
+  if (forced >= 8 && forced <= 16) return forced;
   int lg = 0;
   while ((1u << (lg + 1)) <= n) ++lg;                 // floor(log2 n), n >= 1
-  int c = lg - 3;
-  return std::max(3, std::min(16, c));
+  // with window tables the accumulation costs n * W(c) additions and the reduction only 2^(c-1) buckets
+  return std::max(8, std::min(16, lg));
 }
 
 static void exclusive_scan(Ctx& c, PlanBuffers& pb, const uint32_t* in, uint32_t* out, uint32_t n) {
@@ -37,7 +37,6 @@ void build_plan(Ctx& c, int slot, const uint32_t* scalars_dev, uint32_t n, MsmPl
   plan.c = choose_window_bits(n, c.window_bits);
   plan.W = 254 / plan.c + 1;
   plan.B = 1u << (plan.c - 1);
-  plan.L = (int)std::min<uint32_t>(8u, plan.B);
   plan.nbuckets = (uint32_t)plan.W * plan.B;
   plan.maxchunks = (uint32_t)(((size_t)n * plan.W + kChunk - 1) / kChunk) + 1;
   const size_t ncount = (size_t)plan.nbuckets + 1;
@@ -85,58 +84,63 @@ void build_plan(Ctx& c, int slot, const uint32_t* scalars_dev, uint32_t n, MsmPl
   plan.heavy_count = pb.counters.as<uint32_t>();
 }
 
-// sum_w 2^(c w) S_w on the host core
 template <class T>
-static Xyzz<T> horner_host(const Xyzz<T>* sums, int W, int cbits) {
-  Xyzz<T> acc = sums[W - 1];
-  for (int w = W - 2; w >= 0; --w) {
-    for (int k = 0; k < cbits; ++k) xyzz_dbl(acc);
-    xyzz_add(acc, sums[w]);
-  }
-  return acc;
+static void ensure_table(Ctx& c, BaseTable& t, const uint32_t* row0, size_t n, int cbits) {
+  if (t.c == cbits && t.n == n && t.rows.p) return;
+  constexpr size_t aw = PointIO<T>::kAffineWords;
+  const int W = 254 / cbits + 1;
+  DevBuf fresh(std::max<size_t>(n, 1) * W * aw * 4);
+  const uint32_t* src = row0 ? row0 : t.rows.as<uint32_t>();
+  if (!src || (!row0 && t.n != n)) throw HipError{hipErrorInvalidValue, "window table rebuild without its points", __LINE__};
+  if (n) hipLaunchKernelGGL(k_build_table<T>, grid1(n), dim3(256), 0, c.stream, src, (uint32_t)n, cbits, W, fresh.as<uint32_t>());
+  GS_HIP(hipGetLastError());
+  GS_HIP(hipStreamSynchronize(c.stream));       // the old rows (possibly the source) are released below
+  t.rows = std::move(fresh);
+  t.n = n; t.c = cbits; t.W = W;
 }
+void ensure_table_g1(Ctx& c, BaseTable& t, const uint32_t* row0, size_t n, int cbits) { ensure_table<FqTag>(c, t, row0, n, cbits); }
+void ensure_table_g2(Ctx& c, BaseTable& t, const uint32_t* row0, size_t n, int cbits) { ensure_table<Fq2Tag>(c, t, row0, n, cbits); }
 
 template <class T>
-static void msm_run(Ctx& c, const MsmPlan& plan, const std::vector<const uint32_t*>& bases, std::vector<Xyzz<T>>& out, int ws_base) {
+static void msm_run(Ctx& c, const MsmPlan& plan, const std::vector<MsmBase>& bases, std::vector<Xyzz<T>>& out, int ws_base) {
   const int njobs = (int)bases.size();
   out.assign(njobs, xyzz_inf<T>());
   if (njobs == 0 || plan.n == 0) return;
   if (njobs > kMaxJobs) throw HipError{hipErrorInvalidValue, "too many MSM jobs", __LINE__};
   constexpr size_t pw = PointIO<T>::kXyzzWords;
-  const uint32_t chunks_per_window = plan.B / (uint32_t)plan.L;
-  const uint32_t nchunks = chunks_per_window * (uint32_t)plan.W;
+  constexpr size_t aw = PointIO<T>::kAffineWords;
+  const int L = (int)std::max<uint32_t>(1u, std::min<uint32_t>(8u, plan.B / kReduceBlock));
+  const uint32_t nblk = (plan.B + kReduceBlock * L - 1) / (kReduceBlock * L);
   AccJobs jobs{};
+  c.ws_winsums.ensure((size_t)njobs * nblk * 2 * pw * 4);
   for (int j = 0; j < njobs; ++j) {
+    const BaseTable* t = bases[j].table;
+    if (!t || t->c != plan.c || bases[j].off + plan.n > t->n)
+      throw HipError{hipErrorInvalidValue, "MSM base table does not match the plan", __LINE__};
     DevBuf& bk = c.ws_buckets[(ws_base + j) % 8];
-    DevBuf& ch = c.ws_chunks[(ws_base + j) % 8];
+    DevBuf& mg = c.ws_chunks[(ws_base + j) % 8];
     DevBuf& pt = c.ws_partials[(ws_base + j) % 8];
     bk.ensure((size_t)plan.nbuckets * pw * 4);
-    ch.ensure((size_t)nchunks * pw * 4);
+    mg.ensure((size_t)plan.B * pw * 4);
     pt.ensure((size_t)plan.maxchunks * 2 * pw * 4);
-    jobs.j[j] = AccJob{bases[j], bk.as<uint32_t>(), pt.as<uint32_t>(), pt.as<uint32_t>() + (size_t)plan.maxchunks * pw, ch.as<uint32_t>()};
+    jobs.j[j] = AccJob{t->rows.as<uint32_t>() + bases[j].off * aw, (uint32_t)t->n, bk.as<uint32_t>(), pt.as<uint32_t>(),
+                       pt.as<uint32_t>() + (size_t)plan.maxchunks * pw, mg.as<uint32_t>(),
+                       c.ws_winsums.as<uint32_t>() + (size_t)j * nblk * 2 * pw};
   }
   PhaseTimer tacc(c.stream);
   PhaseTimer tker(c.stream);
   hipLaunchKernelGGL(k_bucket_accumulate<T>, dim3((plan.maxchunks + 255) / 256, njobs), dim3(256), 0, c.stream,
-                     jobs, plan.offsets, plan.entries, plan.chunk_bucket, plan.nbuckets);
+                     jobs, plan.offsets, plan.entries, plan.chunk_bucket, plan.nbuckets, plan.c - 1);
   tker.stop();
   hipLaunchKernelGGL(k_heavy_combine<T>, dim3(64, njobs), dim3(kHeavyBlock), 0, c.stream,
                      jobs, plan.offsets, plan.heavy_list, plan.heavy_count);
   tacc.stop();
   PhaseTimer tred(c.stream);
-  hipLaunchKernelGGL(k_bucket_reduce<T>, dim3((nchunks + 255) / 256, njobs), dim3(256), 0, c.stream,
-                     jobs, plan.offsets, plan.B, plan.L, nchunks);
-  for (uint32_t half = chunks_per_window / 2; half >= 1; half /= 2) {
-    const uint32_t work = (uint32_t)plan.W * half;
-    hipLaunchKernelGGL(k_fold<T>, dim3((work + 255) / 256, njobs), dim3(256), 0, c.stream,
-                       jobs, (uint32_t)plan.W, chunks_per_window, half);
-  }
-  c.ws_winsums.ensure((size_t)njobs * plan.W * pw * 4);
-  hipLaunchKernelGGL(k_gather_window_sums<T>, dim3(plan.W, njobs), dim3(64), 0, c.stream,
-                     jobs, chunks_per_window, plan.W, c.ws_winsums.as<uint32_t>());
+  hipLaunchKernelGGL(k_window_merge<T>, dim3((plan.B + 255) / 256, njobs), dim3(256), 0, c.stream, jobs, plan.offsets, plan.B, plan.W);
+  hipLaunchKernelGGL(k_block_reduce<T>, dim3(nblk, njobs), dim3(kReduceBlock), 0, c.stream, jobs, plan.B, L);
   GS_HIP(hipGetLastError());
-  std::vector<Xyzz<T>> sums((size_t)njobs * plan.W);
-  GS_HIP(hipMemcpyAsync(sums.data(), c.ws_winsums.p, sums.size() * sizeof(Xyzz<T>), hipMemcpyDeviceToHost, c.stream));
+  std::vector<Xyzz<T>> pairs((size_t)njobs * nblk * 2);
+  GS_HIP(hipMemcpyAsync(pairs.data(), c.ws_winsums.p, pairs.size() * sizeof(Xyzz<T>), hipMemcpyDeviceToHost, c.stream));
   tred.stop();
   GS_HIP(hipStreamSynchronize(c.stream));
   c.timing.accumulate_ms += tacc.ms();
@@ -146,13 +150,25 @@ static void msm_run(Ctx& c, const MsmPlan& plan, const std::vector<const uint32_
     c.timing.acc_g2_ms += tker.ms(); c.timing.acc_g2_launches += 1; c.timing.acc_g2_terms += (uint64_t)plan.n * njobs;
   }
   c.timing.reduce_ms += tred.ms();
-  for (int j = 0; j < njobs; ++j) out[j] = horner_host<T>(sums.data() + (size_t)j * plan.W, plan.W, plan.c);
+  // result = sum_blk A_blk + (256 L) * sum_blk blk * S_blk           (<= 16 pairs per job: host core)
+  const uint32_t span = (uint32_t)kReduceBlock * (uint32_t)L;
+  for (int j = 0; j < njobs; ++j) {
+    const Xyzz<T>* pr = pairs.data() + (size_t)j * nblk * 2;
+    Xyzz<T> run = xyzz_inf<T>(), tot = xyzz_inf<T>(), sumA = xyzz_inf<T>();
+    for (uint32_t blk = nblk; blk-- > 0;) {
+      xyzz_add(sumA, pr[2 * blk]);
+      if (blk >= 1) { xyzz_add(run, pr[2 * blk + 1]); xyzz_add(tot, run); }
+    }
+    for (uint32_t s2 = span; s2 > 1; s2 >>= 1) xyzz_dbl(tot);
+    xyzz_add(sumA, tot);
+    out[j] = sumA;
+  }
 }
 
-void msm_run_g1(Ctx& c, const MsmPlan& plan, const std::vector<const uint32_t*>& bases, std::vector<G1Xyzz>& out) {
+void msm_run_g1(Ctx& c, const MsmPlan& plan, const std::vector<MsmBase>& bases, std::vector<G1Xyzz>& out) {
   msm_run<FqTag>(c, plan, bases, out, 0);
 }
-void msm_run_g2(Ctx& c, const MsmPlan& plan, const std::vector<const uint32_t*>& bases, std::vector<G2Xyzz>& out) {
+void msm_run_g2(Ctx& c, const MsmPlan& plan, const std::vector<MsmBase>& bases, std::vector<G2Xyzz>& out) {
   msm_run<Fq2Tag>(c, plan, bases, out, 4);
 }
 

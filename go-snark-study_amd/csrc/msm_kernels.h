@@ -11,13 +11,13 @@
 //     k_colscan+scan  exclusive prefix sums -> bucket offsets, per-slice cursors
 //     k_scatter       counting sort with LDS cursors: entries[] = term index (sign in bit 31) grouped by bucket
 //     k_chunk_map     cut the sorted entry list into equal chunks of 32 entries (load balance)
-//   per base array:
-//     k_bucket_accumulate  one thread per CHUNK: XYZZ += +-affine base (8M+2S), flushing at bucket
+//   per base array (each has a resident window table rows[j][i] = 2^(c j) P_i):
+//     k_bucket_accumulate  one thread per CHUNK: XYZZ += +-affine table point (8M+2S), flushing at bucket
 //                          boundaries; cut buckets leave head/tail partials                      <- dominant
 //     k_heavy_combine      block-wide tree-sum for buckets cut into many chunks
-//     k_bucket_reduce      per chunk of L buckets: sum_j (b0+j+1) * bucket -> one point
-//     k_fold               pairwise folding of the chunk points -> one point per window
-//     k_gather_window_sums -> host: Horner sum_w 2^(cw) S_w, to affine, from Montgomery
+//     k_window_merge       merged[b] = sum over the W windows of bucket (w, b)
+//     k_block_reduce       sum_b (b+1) merged[b] per 2048-bucket workgroup (running sums + LDS scan)
+//   host: adds the <= 16 workgroup pairs, converts to affine / from Montgomery
 //
 // HBM layout: bases are AoS packed canonical Montgomery words (G1: 16 x u32 = 64 B/point,
 // G2: 128 B), so a bucket thread gathers each point with 4 (8) 16-byte loads; scalars are the
@@ -199,11 +199,13 @@ __global__ void __launch_bounds__(256) k_chunk_map(const uint32_t* __restrict__ 
 // ---- bucket accumulation (dominant kernel) ---------------------------------------------------------
 // grid.y = base array (job): up to 8 arrays share one plan (Groth16: At, BACGamma, BACDelta on w's plan).
 struct AccJob {
-  const uint32_t* bases;      // packed affine, already offset to the first term's point
-  uint32_t* buckets;          // nbuckets * kXyzzWords: buckets that live inside one chunk (or were tree-combined)
+  const uint32_t* table;      // window table rows[j][i] = 2^(c j) * P_i, packed affine, already offset to term 0's point
+  uint32_t row_stride;        // points per table row
+  uint32_t* buckets;          // nbuckets * kXyzzWords: (window, bucket) sums that live inside one chunk (or were tree-combined)
   uint32_t* heads;            // maxchunks * kXyzzWords: partial of the bucket that began in an earlier chunk and ends here
   uint32_t* tails;            // maxchunks * kXyzzWords: partial of the bucket that continues into the next chunk
-  uint32_t* chunks;           // (W * B / L) * kXyzzWords : per-chunk weighted sums of the reducer, folded in place
+  uint32_t* merged;           // B * kXyzzWords: bucket sums over all windows
+  uint32_t* out;              // nblocks * 2 * kXyzzWords: per reduce-workgroup (A, S) pairs
 };
 constexpr int kMaxJobs = 8;
 struct AccJobs { AccJob j[kMaxJobs]; };
@@ -211,8 +213,9 @@ struct AccJobs { AccJob j[kMaxJobs]; };
 template <class T>
 __global__ void __launch_bounds__(256) k_bucket_accumulate(AccJobs jobs, const uint32_t* __restrict__ offsets,
                                                             const uint32_t* __restrict__ entries,
-                                                            const uint32_t* __restrict__ chunk_bucket, uint32_t nbuckets) {
+                                                            const uint32_t* __restrict__ chunk_bucket, uint32_t nbuckets, int cshift) {
   constexpr int pw = PointIO<T>::kXyzzWords;
+  constexpr int aw = PointIO<T>::kAffineWords;
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t total = offsets[nbuckets];
   const uint32_t beg = t * kChunk;
@@ -222,6 +225,8 @@ __global__ void __launch_bounds__(256) k_bucket_accumulate(AccJobs jobs, const u
   uint32_t b = chunk_bucket[t];
   uint32_t bend = offsets[b + 1];
   bool started_before = offsets[b] < beg;
+  // the digit of window w multiplies 2^(c w) P_i: row w of the table, so every window feeds the SAME bucket set
+  const uint32_t* row = job.table + (size_t)(b >> cshift) * job.row_stride * aw;
   Xyzz<T> acc = xyzz_inf<T>();
   const uint4* e4 = reinterpret_cast<const uint4*>(entries + beg);      // beg is a multiple of 32 entries = 128 B
   for (uint32_t e = beg; e < end; e += 4) {
@@ -235,9 +240,10 @@ __global__ void __launch_bounds__(256) k_bucket_accumulate(AccJobs jobs, const u
           started_before = false;
           acc = xyzz_inf<T>();
           do { ++b; bend = offsets[b + 1]; } while (bend <= e + u);
+          row = job.table + (size_t)(b >> cshift) * job.row_stride * aw;
         }
         const uint32_t v = vv[u];
-        const Affine<T> p = PointIO<T>::load_affine(job.bases + (size_t)(v & ~kSignBit) * PointIO<T>::kAffineWords);
+        const Affine<T> p = PointIO<T>::load_affine(row + (size_t)(v & ~kSignBit) * aw);
         xyzz_madd(acc, p, (v & kSignBit) != 0);
       }
     }
@@ -296,55 +302,93 @@ __global__ void __launch_bounds__(kHeavyBlock) k_heavy_combine(AccJobs jobs, con
   }
 }
 
-// ---- bucket reduction -------------------------------------------------------------------------------
-// thread t of window w owns buckets [t*L, (t+1)*L): returns sum_j (t*L + j + 1) * bucket[t*L + j]
+// ---- window merge + bucket reduction -------------------------------------------------------------------
+// merged[b] = sum_w bucket[w][b]: thanks to the window tables all W digit positions share one bucket set, so
+// the result is simply sum_b (b + 1) * merged[b] -- no per-window reduction and no Horner recombination.
 template <class T>
-__global__ void __launch_bounds__(256) k_bucket_reduce(AccJobs jobs, const uint32_t* __restrict__ offsets,
-                                                        uint32_t B, int L, uint32_t nchunks_total) {
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;     // chunk index over all windows
-  if (t >= nchunks_total) return;
+__global__ void __launch_bounds__(256) k_window_merge(AccJobs jobs, const uint32_t* __restrict__ offsets, uint32_t B, int W) {
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
   const AccJob job = jobs.j[blockIdx.y];
-  const uint32_t chunks_per_window = B / (uint32_t)L;
-  const uint32_t w = t / chunks_per_window, tw = t % chunks_per_window;
-  const uint32_t b0 = tw * (uint32_t)L;                          // first bucket (0-based) of the chunk, weight b0+1
-  const uint32_t gb = w * B + b0;
+  Xyzz<T> acc = load_bucket<T>(job, offsets, b);
+  for (int w = 1; w < W; ++w) {
+    const Xyzz<T> p = load_bucket<T>(job, offsets, (uint32_t)w * B + b);
+    xyzz_add(acc, p);
+  }
+  store_xyzz<T>(job.merged + (size_t)b * PointIO<T>::kXyzzWords, acc);
+}
+
+// One workgroup of 256 threads reduces 256 * L consecutive buckets to the pair
+//   A = sum_j (j + 1) * merged[base + j],  S = sum_j merged[base + j]        (j local to the workgroup)
+// thread t: running sums over its L buckets -> (acc_t, run_t); suffix scan of run_t in LDS gives
+// R_t = sum_{t' >= t} run_t', and sum_t t * run_t = sum_{t >= 1} R_t; then a tree sum.  The host adds the
+// (at most 16) pairs: result = sum_blk A_blk + 256 L * sum_blk blk * S_blk.
+constexpr int kReduceBlock = 256;
+template <class T>
+__global__ void __launch_bounds__(kReduceBlock) k_block_reduce(AccJobs jobs, uint32_t B, int L) {
+  constexpr int pw = PointIO<T>::kXyzzWords;
+  __shared__ uint32_t sh[kReduceBlock * pw];
+  const AccJob job = jobs.j[blockIdx.y];
+  const uint32_t t = threadIdx.x;
+  const uint32_t base = (blockIdx.x * kReduceBlock + t) * (uint32_t)L;
   Xyzz<T> run = xyzz_inf<T>(), acc = xyzz_inf<T>();
   for (int j = L - 1; j >= 0; --j) {
-    Xyzz<T> bk = load_bucket<T>(job, offsets, gb + (uint32_t)j);
-    xyzz_add(run, bk);
+    if (base + (uint32_t)j < B) {
+      const Xyzz<T> bk = load_xyzz<T>(job.merged + (size_t)(base + (uint32_t)j) * pw);
+      xyzz_add(run, bk);
+    }
     xyzz_add(acc, run);
   }
-  // acc = sum_j (j+1) bucket_j ; add b0 * run
-  if (b0 != 0 && !is_inf(run)) {
-    Xyzz<T> off = xyzz_mul_u32(run, b0);
-    xyzz_add(acc, off);
+  // suffix (inclusive) scan of run over the workgroup
+  Xyzz<T> R = run;
+  store_xyzz<T>(sh + t * pw, R);
+  __syncthreads();
+  for (int off = 1; off < kReduceBlock; off <<= 1) {
+    Xyzz<T> o = xyzz_inf<T>();
+    const bool has = t + (uint32_t)off < (uint32_t)kReduceBlock;
+    if (has) o = load_xyzz<T>(sh + (t + off) * pw);
+    __syncthreads();
+    if (has) { xyzz_add(R, o); store_xyzz<T>(sh + t * pw, R); }
+    __syncthreads();
   }
-  store_xyzz<T>(job.chunks + (size_t)t * PointIO<T>::kXyzzWords, acc);
+  // value_t = acc_t + L * R_t (t >= 1), acc_0 for t = 0
+  if (t == 0) store_xyzz<T>(job.out + ((size_t)blockIdx.x * 2 + 1) * pw, R);     // S = R_0
+  __syncthreads();
+  if (t >= 1) {
+    for (int l = L; l > 1; l >>= 1) xyzz_dbl(R);
+    xyzz_add(acc, R);
+  }
+  store_xyzz<T>(sh + t * pw, acc);
+  __syncthreads();
+  for (int half = kReduceBlock / 2; half >= 1; half >>= 1) {
+    if ((int)t < half) {
+      const Xyzz<T> o = load_xyzz<T>(sh + (t + half) * pw);
+      xyzz_add(acc, o);
+      store_xyzz<T>(sh + t * pw, acc);
+    }
+    __syncthreads();
+  }
+  if (t == 0) store_xyzz<T>(job.out + (size_t)blockIdx.x * 2 * pw, acc);          // A
 }
 
-// pts[seg * seglen + i] += pts[seg * seglen + i + half]  for i < half, all segments at once
+// ---- window tables ----------------------------------------------------------------------------------------
+// rows[j][i] = 2^(c j) * P_i for j < W, packed affine.  Built once per (base array, c) and kept in HBM: a
+// 2^20-point G1 array costs 64 MiB per row, 1 GiB for c = 16 -- the trade the 288 GB of HBM3E is there for.
 template <class T>
-__global__ void __launch_bounds__(256) k_fold(AccJobs jobs, uint32_t nseg, uint32_t seglen, uint32_t half) {
-  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= nseg * half) return;
-  const uint32_t seg = g / half, i = g % half;
-  uint32_t* base = jobs.j[blockIdx.y].chunks + ((size_t)seg * seglen + i) * PointIO<T>::kXyzzWords;
-  Xyzz<T> a = load_xyzz<T>(base);
-  Xyzz<T> b = load_xyzz<T>(base + (size_t)half * PointIO<T>::kXyzzWords);
-  xyzz_add(a, b);
-  store_xyzz<T>(base, a);
-}
-
-// gather the W window sums (first point of each folded segment) of every job into one
-// contiguous buffer [job][w] for a single D2H copy; the O(W*c) serial Horner combination
-// sum_w 2^(cw) S_w runs on the host core (msm.hip): a lone wave retires one 254-step
-// doubling chain in ~2.5 ms, a CPU core in ~0.2 ms.
-template <class T>
-__global__ void k_gather_window_sums(AccJobs jobs, uint32_t seglen, int W, uint32_t* __restrict__ out) {
-  const uint32_t job = blockIdx.y, w = blockIdx.x;
-  const uint32_t* src = jobs.j[job].chunks + (size_t)w * seglen * PointIO<T>::kXyzzWords;
-  uint32_t* dst = out + ((size_t)job * W + w) * PointIO<T>::kXyzzWords;
-  for (int i = threadIdx.x; i < PointIO<T>::kXyzzWords; i += blockDim.x) dst[i] = src[i];
+__global__ void __launch_bounds__(256) k_build_table(const uint32_t* __restrict__ row0, uint32_t n, int c, int W, uint32_t* __restrict__ rows) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  constexpr int aw = PointIO<T>::kAffineWords;
+  Affine<T> a = PointIO<T>::load_affine(row0 + (size_t)i * aw);
+  if (rows != row0) PointIO<T>::store_affine(rows + (size_t)i * aw, a);
+  for (int j = 1; j < W; ++j) {
+    if (!is_inf(a)) {
+      Xyzz<T> x = xyzz_dbl_affine<T>(a.x, relax<2>(a.y));
+      for (int k = 1; k < c; ++k) xyzz_dbl(x);
+      a = xyzz_to_affine(x);
+    }
+    PointIO<T>::store_affine(rows + ((size_t)j * n + i) * aw, a);
+  }
 }
 
 // ---- base-array preparation ----------------------------------------------------------------------------

@@ -10,6 +10,7 @@ struct GrothPkObj : Object {      // groth16.Pk (groth16/groth16.go:15-32), resi
   size_t nvars = 0, npublic = 0, nz = 0, nptd = 0;
   DevBuf at, bacgamma1, bacdelta, ptd;     // packed affine G1 (owned copies)
   DevBuf bacgamma2;                        // packed affine G2
+  BaseTable t_at, t_bacgamma1, t_bacdelta, t_ptd, t_bacgamma2;   // their window tables (built on the first prove)
   G1Affine alpha, beta, delta;             // host, Montgomery
   G2Affine beta2, delta2;
   Divisor z;                               // pk.Z with cached 1/rev(Z) series + spectrum
@@ -20,6 +21,7 @@ struct PinocchioPkObj : Object {  // snark.Pk (snark.go:16-26), resident
   size_t nvars = 0, npublic = 0, nz = 0, ng1t = 0;
   DevBuf a, ap, bp, c, cp, kp, g1t;        // packed affine G1
   DevBuf b2;                               // packed affine G2
+  BaseTable t_a, t_ap, t_bp, t_c, t_cp, t_kp, t_g1t, t_b2;
   Divisor z;
   PinocchioPkObj() : Object(Kind::PinocchioPk) {}
 };

@@ -46,6 +46,14 @@ int groth16_prove_impl(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, cons
     c.timing.poly_ms += tp.ms();
   }
   // --- the five MSMs (groth16.go:243-250, 269-271) --------------------------------------------------
+  {
+    const int cw = choose_window_bits((uint32_t)w.n, c.window_bits), ch = choose_window_bits((uint32_t)std::max<size_t>(nh, 1), c.window_bits);
+    ensure_table_g1(c, pk->t_at, pk->at.as<uint32_t>(), pk->nvars, cw);
+    ensure_table_g1(c, pk->t_bacgamma1, pk->bacgamma1.as<uint32_t>(), pk->nvars, cw);
+    ensure_table_g1(c, pk->t_bacdelta, pk->bacdelta.as<uint32_t>(), pk->nvars, cw);
+    ensure_table_g2(c, pk->t_bacgamma2, pk->bacgamma2.as<uint32_t>(), pk->nvars, cw);
+    ensure_table_g1(c, pk->t_ptd, pk->ptd.as<uint32_t>(), pk->nptd, ch);
+  }
   MsmPlan plan_w, plan_h;
   {
     PhaseTimer tp(c.stream);
@@ -58,9 +66,9 @@ int groth16_prove_impl(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, cons
   std::vector<G2Xyzz> g2w;
   // BACDelta's first npublic+1 entries are forced to infinity at key creation, so the reference's
   // loop from NPublic+1 (:248-250) equals a full-range MSM sharing w's plan.
-  msm_run_g1(c, plan_w, {pk->at.as<uint32_t>(), pk->bacgamma1.as<uint32_t>(), pk->bacdelta.as<uint32_t>()}, g1w);
-  msm_run_g2(c, plan_w, {pk->bacgamma2.as<uint32_t>()}, g2w);
-  msm_run_g1(c, plan_h, {pk->ptd.as<uint32_t>()}, g1h);
+  msm_run_g1(c, plan_w, {MsmBase{&pk->t_at, 0}, MsmBase{&pk->t_bacgamma1, 0}, MsmBase{&pk->t_bacdelta, 0}}, g1w);
+  msm_run_g2(c, plan_w, {MsmBase{&pk->t_bacgamma2, 0}}, g2w);
+  msm_run_g1(c, plan_h, {MsmBase{&pk->t_ptd, 0}}, g1h);
   // --- O(1) tail on the host core (groth16.go:253-275) ----------------------------------------------
   G1Xyzz delta = xyzz_from_affine(pk->delta);
   G2Xyzz delta2 = xyzz_from_affine(pk->delta2);
@@ -105,6 +113,17 @@ int pinocchio_prove_impl(Ctx& c, PinocchioPkObj* pk, DevScalars w, DevScalars px
     tp.stop();
     c.timing.poly_ms += tp.ms();
   }
+  {
+    const int cw = choose_window_bits((uint32_t)w.n, c.window_bits), ch = choose_window_bits((uint32_t)std::max<size_t>(nh, 1), c.window_bits);
+    ensure_table_g1(c, pk->t_a, pk->a.as<uint32_t>(), pk->nvars, cw);
+    ensure_table_g1(c, pk->t_ap, pk->ap.as<uint32_t>(), pk->nvars, cw);
+    ensure_table_g1(c, pk->t_bp, pk->bp.as<uint32_t>(), pk->nvars, cw);
+    ensure_table_g1(c, pk->t_c, pk->c.as<uint32_t>(), pk->nvars, cw);
+    ensure_table_g1(c, pk->t_cp, pk->cp.as<uint32_t>(), pk->nvars, cw);
+    ensure_table_g1(c, pk->t_kp, pk->kp.as<uint32_t>(), pk->nvars, cw);
+    ensure_table_g2(c, pk->t_b2, pk->b2.as<uint32_t>(), pk->nvars, cw);
+    ensure_table_g1(c, pk->t_g1t, pk->g1t.as<uint32_t>(), pk->ng1t, ch);
+  }
   MsmPlan plan_w, plan_h;
   {
     PhaseTimer tp(c.stream);
@@ -117,10 +136,10 @@ int pinocchio_prove_impl(Ctx& c, PinocchioPkObj* pk, DevScalars w, DevScalars px
   std::vector<G2Xyzz> g2w;
   // A and Ap run over i > NPublic only (snark.go:265-268): their first npublic+1 points were forced
   // to infinity at key creation; Bp, C, Cp, Kp and B run over all variables (:270-278).
-  msm_run_g1(c, plan_w, {pk->a.as<uint32_t>(), pk->ap.as<uint32_t>(), pk->bp.as<uint32_t>(), pk->c.as<uint32_t>(),
-                         pk->cp.as<uint32_t>(), pk->kp.as<uint32_t>()}, g1w);
-  msm_run_g2(c, plan_w, {pk->b2.as<uint32_t>()}, g2w);
-  msm_run_g1(c, plan_h, {pk->g1t.as<uint32_t>()}, g1h);                            // :284-286
+  msm_run_g1(c, plan_w, {MsmBase{&pk->t_a, 0}, MsmBase{&pk->t_ap, 0}, MsmBase{&pk->t_bp, 0}, MsmBase{&pk->t_c, 0},
+                         MsmBase{&pk->t_cp, 0}, MsmBase{&pk->t_kp, 0}}, g1w);
+  msm_run_g2(c, plan_w, {MsmBase{&pk->t_b2, 0}}, g2w);
+  msm_run_g1(c, plan_h, {MsmBase{&pk->t_g1t, 0}}, g1h);                            // :284-286
   // output order: PiA | PiAp | PiB | PiBp | PiC | PiCp | PiH | PiKp
   inf[0] = g1_to_affine_std(g1w[0], out) ? 1 : 0;
   inf[1] = g1_to_affine_std(g1w[1], out + 8) ? 1 : 0;

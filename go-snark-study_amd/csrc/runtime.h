@@ -75,9 +75,10 @@ struct Object {
   explicit Object(Kind k) : kind(k) {}
 };
 
-struct Bases : Object {          // packed affine Montgomery points, resident
+struct Bases : Object {          // packed affine Montgomery points, resident (+ their lazily built window table)
   DevBuf buf;
   size_t n = 0;
+  std::shared_ptr<void> table;   // gs::BaseTable (msm.h), created on first MSM use
   explicit Bases(Kind k) : Object(k) {}
 };
 struct Scalars : Object {        // n x 8 u32 words, standard form, resident
