@@ -97,6 +97,7 @@ int msm_resident(Ctx& c, Kind kind, gs_handle hb, size_t off, const uint32_t* sc
     msm_run_g2(c, plan, bases, r);
     inf = g2_to_affine_std(r[0], out_affine);
   }
+  GS_HIP(hipStreamSynchronize(c.stream));
   *is_inf = inf ? 1 : 0;
   total.stop();
   c.timing.total_ms += total.ms();
@@ -160,7 +161,11 @@ int gs_init(const int* devices, int ndev) {
     GS_HIP(hipSetDevice(devices[0]));
     if (c.ready && c.device != devices[0]) return fail(GS_ERR_ARG, "already initialised on device %d", c.device);
     if (!c.ready) {
-      GS_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+      GS_HIP(hipStreamCreateWithFlags(&c.main_stream, hipStreamNonBlocking));
+      GS_HIP(hipStreamCreateWithFlags(&c.aux_stream[0], hipStreamNonBlocking));
+      GS_HIP(hipStreamCreateWithFlags(&c.aux_stream[1], hipStreamNonBlocking));
+      for (auto& p : c.pinned) GS_HIP(hipHostMalloc(&p, Ctx::kPinnedBytes, hipHostMallocDefault));
+      c.stream = c.main_stream;
       c.device = devices[0];
       c.ready = true;
     }

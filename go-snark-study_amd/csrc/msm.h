@@ -47,7 +47,22 @@ struct MsmBase {                 // one job of an MSM launch: a window table and
 void build_plan(Ctx& c, int slot, const uint32_t* scalars_dev, uint32_t n, MsmPlan& plan);
 
 // One launch sequence for up to 8 base arrays sharing a plan (their tables must have been built for plan.c).
-// Results: XYZZ (Montgomery) on the host.
+// msm_enqueue_* only ENQUEUES on c.stream (kernels + the async download of the <= 16 workgroup pairs per
+// job into pinned slot `slot`), so several MSM groups can be in flight on different streams; after that
+// stream has been synchronised, msm_finish_* adds the pairs on the host core and books the timings.
+// ws_base: first of the 8 workspace sets to use (groups in flight together must not share sets).
+struct MsmPending {
+  int njobs = 0, L = 1, slot = 0;
+  uint32_t nblk = 0, n = 0;
+  bool g2 = false;
+  std::shared_ptr<PhaseTimer> tacc, tker, tred;
+};
+// tail_stream: where the window merge / reduction / download go (nullptr = c.stream)
+void msm_enqueue_g1(Ctx& c, const MsmPlan& plan, const std::vector<MsmBase>& bases, int ws_base, int slot, MsmPending& p, hipStream_t tail_stream = nullptr);
+void msm_enqueue_g2(Ctx& c, const MsmPlan& plan, const std::vector<MsmBase>& bases, int ws_base, int slot, MsmPending& p, hipStream_t tail_stream = nullptr);
+void msm_finish_g1(Ctx& c, const MsmPending& p, std::vector<G1Xyzz>& out);
+void msm_finish_g2(Ctx& c, const MsmPending& p, std::vector<G2Xyzz>& out);
+// enqueue + synchronise + finish on c.stream
 void msm_run_g1(Ctx& c, const MsmPlan& plan, const std::vector<MsmBase>& bases, std::vector<G1Xyzz>& out);
 void msm_run_g2(Ctx& c, const MsmPlan& plan, const std::vector<MsmBase>& bases, std::vector<G2Xyzz>& out);
 

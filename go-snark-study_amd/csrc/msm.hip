@@ -102,17 +102,23 @@ void ensure_table_g1(Ctx& c, BaseTable& t, const uint32_t* row0, size_t n, int c
 void ensure_table_g2(Ctx& c, BaseTable& t, const uint32_t* row0, size_t n, int cbits) { ensure_table<Fq2Tag>(c, t, row0, n, cbits); }
 
 template <class T>
-static void msm_run(Ctx& c, const MsmPlan& plan, const std::vector<MsmBase>& bases, std::vector<Xyzz<T>>& out, int ws_base) {
+static void msm_enqueue(Ctx& c, const MsmPlan& plan, const std::vector<MsmBase>& bases, int ws_base, int slot, MsmPending& p,
+                        hipStream_t tail_stream) {
   const int njobs = (int)bases.size();
-  out.assign(njobs, xyzz_inf<T>());
-  if (njobs == 0 || plan.n == 0) return;
+  p = MsmPending{};
+  p.njobs = njobs; p.slot = slot; p.n = plan.n; p.g2 = PointIO<T>::kAffineWords == 32;
+  if (njobs == 0 || plan.n == 0) { p.njobs = plan.n == 0 ? -njobs : 0; return; }
   if (njobs > kMaxJobs) throw HipError{hipErrorInvalidValue, "too many MSM jobs", __LINE__};
   constexpr size_t pw = PointIO<T>::kXyzzWords;
   constexpr size_t aw = PointIO<T>::kAffineWords;
   const int L = (int)std::max<uint32_t>(1u, std::min<uint32_t>(8u, plan.B / kReduceBlock));
   const uint32_t nblk = (plan.B + kReduceBlock * L - 1) / (kReduceBlock * L);
+  p.L = L; p.nblk = nblk;
+  const size_t out_bytes = (size_t)njobs * nblk * 2 * pw * 4;
+  if (out_bytes > Ctx::kPinnedBytes) throw HipError{hipErrorInvalidValue, "MSM result staging too small", __LINE__};
   AccJobs jobs{};
-  c.ws_winsums.ensure((size_t)njobs * nblk * 2 * pw * 4);
+  DevBuf& outb = c.ws_out[ws_base % 8];
+  outb.ensure(out_bytes);
   for (int j = 0; j < njobs; ++j) {
     const BaseTable* t = bases[j].table;
     if (!t || t->c != plan.c || bases[j].off + plan.n > t->n)
@@ -125,37 +131,48 @@ static void msm_run(Ctx& c, const MsmPlan& plan, const std::vector<MsmBase>& bas
     pt.ensure((size_t)plan.maxchunks * 2 * pw * 4);
     jobs.j[j] = AccJob{t->rows.as<uint32_t>() + bases[j].off * aw, (uint32_t)t->n, bk.as<uint32_t>(), pt.as<uint32_t>(),
                        pt.as<uint32_t>() + (size_t)plan.maxchunks * pw, mg.as<uint32_t>(),
-                       c.ws_winsums.as<uint32_t>() + (size_t)j * nblk * 2 * pw};
+                       outb.as<uint32_t>() + (size_t)j * nblk * 2 * pw};
   }
-  PhaseTimer tacc(c.stream);
-  PhaseTimer tker(c.stream);
+  p.tacc = std::make_shared<PhaseTimer>(c.stream);
+  p.tker = std::make_shared<PhaseTimer>(c.stream);
   hipLaunchKernelGGL(k_bucket_accumulate<T>, dim3((plan.maxchunks + 255) / 256, njobs), dim3(256), 0, c.stream,
                      jobs, plan.offsets, plan.entries, plan.chunk_bucket, plan.nbuckets, plan.c - 1);
-  tker.stop();
+  p.tker->stop();
   hipLaunchKernelGGL(k_heavy_combine<T>, dim3(64, njobs), dim3(kHeavyBlock), 0, c.stream,
                      jobs, plan.offsets, plan.heavy_list, plan.heavy_count);
-  tacc.stop();
-  PhaseTimer tred(c.stream);
-  hipLaunchKernelGGL(k_window_merge<T>, dim3((plan.B + 255) / 256, njobs), dim3(256), 0, c.stream, jobs, plan.offsets, plan.B, plan.W);
-  hipLaunchKernelGGL(k_block_reduce<T>, dim3(nblk, njobs), dim3(kReduceBlock), 0, c.stream, jobs, plan.B, L);
-  GS_HIP(hipGetLastError());
-  std::vector<Xyzz<T>> pairs((size_t)njobs * nblk * 2);
-  GS_HIP(hipMemcpyAsync(pairs.data(), c.ws_winsums.p, pairs.size() * sizeof(Xyzz<T>), hipMemcpyDeviceToHost, c.stream));
-  tred.stop();
-  GS_HIP(hipStreamSynchronize(c.stream));
-  c.timing.accumulate_ms += tacc.ms();
-  if constexpr (PointIO<T>::kAffineWords == 16) {
-    c.timing.acc_g1_ms += tker.ms(); c.timing.acc_g1_launches += 1; c.timing.acc_g1_terms += (uint64_t)plan.n * njobs;
-  } else {
-    c.timing.acc_g2_ms += tker.ms(); c.timing.acc_g2_launches += 1; c.timing.acc_g2_terms += (uint64_t)plan.n * njobs;
+  p.tacc->stop();
+  // the latency-bound tail may run on another stream, in the shadow of the next group's accumulation
+  hipStream_t ts = tail_stream ? tail_stream : c.stream;
+  if (ts != c.stream) {
+    hipEvent_t ev;
+    GS_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    GS_HIP(hipEventRecord(ev, c.stream));
+    GS_HIP(hipStreamWaitEvent(ts, ev, 0));
+    GS_HIP(hipEventDestroy(ev));       // released by the runtime once it has fired
   }
-  c.timing.reduce_ms += tred.ms();
+  p.tred = std::make_shared<PhaseTimer>(ts);
+  hipLaunchKernelGGL(k_window_merge<T>, dim3((plan.B + 255) / 256, njobs), dim3(256), 0, ts, jobs, plan.offsets, plan.B, plan.W);
+  hipLaunchKernelGGL(k_block_reduce<T>, dim3(nblk, njobs), dim3(kReduceBlock), 0, ts, jobs, plan.B, L);
+  GS_HIP(hipGetLastError());
+  GS_HIP(hipMemcpyAsync(c.pinned[slot], outb.p, out_bytes, hipMemcpyDeviceToHost, ts));
+  p.tred->stop();
+}
+
+template <class T>
+static void msm_finish(Ctx& c, const MsmPending& p, std::vector<Xyzz<T>>& out) {
+  if (p.njobs <= 0) { out.assign(-p.njobs, xyzz_inf<T>()); return; }
+  out.assign(p.njobs, xyzz_inf<T>());
+  c.timing.accumulate_ms += p.tacc->ms();
+  if (!p.g2) { c.timing.acc_g1_ms += p.tker->ms(); c.timing.acc_g1_launches += 1; c.timing.acc_g1_terms += (uint64_t)p.n * p.njobs; }
+  else { c.timing.acc_g2_ms += p.tker->ms(); c.timing.acc_g2_launches += 1; c.timing.acc_g2_terms += (uint64_t)p.n * p.njobs; }
+  c.timing.reduce_ms += p.tred->ms();
   // result = sum_blk A_blk + (256 L) * sum_blk blk * S_blk           (<= 16 pairs per job: host core)
-  const uint32_t span = (uint32_t)kReduceBlock * (uint32_t)L;
-  for (int j = 0; j < njobs; ++j) {
-    const Xyzz<T>* pr = pairs.data() + (size_t)j * nblk * 2;
+  const Xyzz<T>* pairs = static_cast<const Xyzz<T>*>(c.pinned[p.slot]);
+  const uint32_t span = (uint32_t)kReduceBlock * (uint32_t)p.L;
+  for (int j = 0; j < p.njobs; ++j) {
+    const Xyzz<T>* pr = pairs + (size_t)j * p.nblk * 2;
     Xyzz<T> run = xyzz_inf<T>(), tot = xyzz_inf<T>(), sumA = xyzz_inf<T>();
-    for (uint32_t blk = nblk; blk-- > 0;) {
+    for (uint32_t blk = p.nblk; blk-- > 0;) {
       xyzz_add(sumA, pr[2 * blk]);
       if (blk >= 1) { xyzz_add(run, pr[2 * blk + 1]); xyzz_add(tot, run); }
     }
@@ -165,11 +182,25 @@ static void msm_run(Ctx& c, const MsmPlan& plan, const std::vector<MsmBase>& bas
   }
 }
 
+void msm_enqueue_g1(Ctx& c, const MsmPlan& plan, const std::vector<MsmBase>& bases, int ws_base, int slot, MsmPending& p, hipStream_t tail) {
+  msm_enqueue<FqTag>(c, plan, bases, ws_base, slot, p, tail);
+}
+void msm_enqueue_g2(Ctx& c, const MsmPlan& plan, const std::vector<MsmBase>& bases, int ws_base, int slot, MsmPending& p, hipStream_t tail) {
+  msm_enqueue<Fq2Tag>(c, plan, bases, ws_base, slot, p, tail);
+}
+void msm_finish_g1(Ctx& c, const MsmPending& p, std::vector<G1Xyzz>& out) { msm_finish<FqTag>(c, p, out); }
+void msm_finish_g2(Ctx& c, const MsmPending& p, std::vector<G2Xyzz>& out) { msm_finish<Fq2Tag>(c, p, out); }
 void msm_run_g1(Ctx& c, const MsmPlan& plan, const std::vector<MsmBase>& bases, std::vector<G1Xyzz>& out) {
-  msm_run<FqTag>(c, plan, bases, out, 0);
+  MsmPending p;
+  msm_enqueue<FqTag>(c, plan, bases, 0, 0, p, nullptr);
+  GS_HIP(hipStreamSynchronize(c.stream));
+  msm_finish<FqTag>(c, p, out);
 }
 void msm_run_g2(Ctx& c, const MsmPlan& plan, const std::vector<MsmBase>& bases, std::vector<G2Xyzz>& out) {
-  msm_run<Fq2Tag>(c, plan, bases, out, 4);
+  MsmPending p;
+  msm_enqueue<Fq2Tag>(c, plan, bases, 4, 0, p, nullptr);
+  GS_HIP(hipStreamSynchronize(c.stream));
+  msm_finish<Fq2Tag>(c, p, out);
 }
 
 void jacobian_to_affine_g1(Ctx& c, const uint32_t* jac, uint32_t n, uint32_t* out) {

@@ -30,22 +30,42 @@ DevBuf g_hx;
 
 size_t quotient_len(size_t npx, size_t nz) { return npx >= nz ? npx - nz + 1 : 0; }
 
+// Stream layout of one proof (all device work is enqueued before the host waits once):
+//   main  : plan(w) -> accumulate G1 x3 over w -> accumulate G2 over w -> [wait plan(h)] accumulate G1 over h -> its tail
+//   aux 0 : the tails (window merge, reduction, download) of the two w groups, each after its accumulation
+//   aux 1 : H(x) = P(x)/Z(x) -> plan(h)
+// The ALU-bound accumulation kernels run back to back on one stream (they would only fight for the
+// instruction cache if overlapped), and everything latency- or bandwidth-bound runs in their shadow.
+struct Fork {
+  Ctx& c;
+  hipEvent_t start, planw, planh, done[2];
+  explicit Fork(Ctx& ctx_) : c(ctx_) {
+    GS_HIP(hipEventCreateWithFlags(&start, hipEventDisableTiming));
+    GS_HIP(hipEventCreateWithFlags(&planw, hipEventDisableTiming));
+    GS_HIP(hipEventCreateWithFlags(&planh, hipEventDisableTiming));
+    for (auto& e : done) GS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    GS_HIP(hipEventRecord(start, c.main_stream));
+    for (auto s : c.aux_stream) GS_HIP(hipStreamWaitEvent(s, start, 0));
+  }
+  void join() {           // main waits for both aux streams, host waits for main
+    for (int i = 0; i < 2; ++i) {
+      GS_HIP(hipEventRecord(done[i], c.aux_stream[i]));
+      GS_HIP(hipStreamWaitEvent(c.main_stream, done[i], 0));
+    }
+    GS_HIP(hipStreamSynchronize(c.main_stream));
+  }
+  ~Fork() {
+    (void)hipEventDestroy(start); (void)hipEventDestroy(planw); (void)hipEventDestroy(planh);
+    for (auto& e : done) (void)hipEventDestroy(e);
+  }
+};
+
 int groth16_prove_impl(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, const uint64_t r[4], const uint64_t s[4],
                        uint64_t out_proof[32], int inf[3]) {
   if (w.n != pk->nvars) return fail(GS_ERR_SHAPE, "len(w) = %zu but the key has %zu variables", w.n, pk->nvars);
   const size_t nh = quotient_len(px.n, pk->nz);
   if (nh > pk->nptd)
     return fail(GS_ERR_SHAPE, "len(hx) = len(px) - len(Z) + 1 = %zu exceeds len(PowersTauDelta) = %zu (groth16.go:269-271)", nh, pk->nptd);
-  PhaseTimer total(c.stream);
-  // --- H(x) = P(x) / Z(x)   (groth16.go:266) -------------------------------------------------------
-  {
-    PhaseTimer tp(c.stream);
-    g_hx.ensure(std::max<size_t>(nh, 1) * 32);
-    if (nh) poly_quotient_dev(c, pk->z, px.p, px.n, g_hx.as<uint32_t>());
-    tp.stop();
-    c.timing.poly_ms += tp.ms();
-  }
-  // --- the five MSMs (groth16.go:243-250, 269-271) --------------------------------------------------
   {
     const int cw = choose_window_bits((uint32_t)w.n, c.window_bits), ch = choose_window_bits((uint32_t)std::max<size_t>(nh, 1), c.window_bits);
     ensure_table_g1(c, pk->t_at, pk->at.as<uint32_t>(), pk->nvars, cw);
@@ -53,36 +73,61 @@ int groth16_prove_impl(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, cons
     ensure_table_g1(c, pk->t_bacdelta, pk->bacdelta.as<uint32_t>(), pk->nvars, cw);
     ensure_table_g2(c, pk->t_bacgamma2, pk->bacgamma2.as<uint32_t>(), pk->nvars, cw);
     ensure_table_g1(c, pk->t_ptd, pk->ptd.as<uint32_t>(), pk->nptd, ch);
+    g_hx.ensure(std::max<size_t>(nh, 1) * 32);
   }
+  PhaseTimer total(c.main_stream);
+  Fork fork(c);
   MsmPlan plan_w, plan_h;
-  {
-    PhaseTimer tp(c.stream);
-    build_plan(c, 0, w.p, (uint32_t)w.n, plan_w);
+  MsmPending pend_g1w, pend_g2w, pend_h;
+  std::shared_ptr<PhaseTimer> tpoly, tplanw, tplanh;
+  {                                                              // aux 1: H(x), plan(h)
+    StreamScope sc(c, c.aux_stream[1]);
+    tpoly = std::make_shared<PhaseTimer>(c.stream);
+    if (nh) poly_quotient_dev(c, pk->z, px.p, px.n, g_hx.as<uint32_t>());      // groth16.go:266
+    tpoly->stop();
+    tplanh = std::make_shared<PhaseTimer>(c.stream);
     build_plan(c, 1, g_hx.as<uint32_t>(), (uint32_t)nh, plan_h);
-    tp.stop();
-    c.timing.plan_ms += tp.ms();
+    tplanh->stop();
+    GS_HIP(hipEventRecord(fork.planh, c.stream));
   }
-  std::vector<G1Xyzz> g1w, g1h;
-  std::vector<G2Xyzz> g2w;
-  // BACDelta's first npublic+1 entries are forced to infinity at key creation, so the reference's
-  // loop from NPublic+1 (:248-250) equals a full-range MSM sharing w's plan.
-  msm_run_g1(c, plan_w, {MsmBase{&pk->t_at, 0}, MsmBase{&pk->t_bacgamma1, 0}, MsmBase{&pk->t_bacdelta, 0}}, g1w);
-  msm_run_g2(c, plan_w, {MsmBase{&pk->t_bacgamma2, 0}}, g2w);
-  msm_run_g1(c, plan_h, {MsmBase{&pk->t_ptd, 0}}, g1h);
-  // --- O(1) tail on the host core (groth16.go:253-275) ----------------------------------------------
+  {                                                              // main: plan(w), then the accumulations back to back
+    StreamScope sc(c, c.main_stream);
+    tplanw = std::make_shared<PhaseTimer>(c.stream);
+    build_plan(c, 0, w.p, (uint32_t)w.n, plan_w);
+    tplanw->stop();
+    // BACDelta's first npublic+1 entries are forced to infinity at key creation, so the reference's
+    // loop from NPublic+1 (:248-250) equals a full-range MSM sharing w's plan.
+    msm_enqueue_g1(c, plan_w, {MsmBase{&pk->t_at, 0}, MsmBase{&pk->t_bacgamma1, 0}, MsmBase{&pk->t_bacdelta, 0}}, 0, 0, pend_g1w,
+                   c.aux_stream[0]);
+    msm_enqueue_g2(c, plan_w, {MsmBase{&pk->t_bacgamma2, 0}}, 4, 1, pend_g2w, c.aux_stream[0]);
+    GS_HIP(hipStreamWaitEvent(c.stream, fork.planh, 0));
+    msm_enqueue_g1(c, plan_h, {MsmBase{&pk->t_ptd, 0}}, 3, 2, pend_h);          // :269-271
+  }
+  // --- host work that needs no MSM result, done while the device runs (groth16.go:254-264, 274) ------
   G1Xyzz delta = xyzz_from_affine(pk->delta);
   G2Xyzz delta2 = xyzz_from_affine(pk->delta2);
+  G1Xyzz rdelta = g1_mul_scalar(delta, r);
+  G1Xyzz sdelta = g1_mul_scalar(delta, s);
+  G2Xyzz sdelta2 = g2_mul_scalar(delta2, s);
+  G1Xyzz rsdelta = g1_mul_scalar(rdelta, s);
+  fork.join();
+  total.stop();
+  std::vector<G1Xyzz> g1w, g1h;
+  std::vector<G2Xyzz> g2w;
+  msm_finish_g1(c, pend_g1w, g1w);
+  msm_finish_g2(c, pend_g2w, g2w);
+  msm_finish_g1(c, pend_h, g1h);
+  c.timing.poly_ms += tpoly->ms();
+  c.timing.plan_ms += tplanw->ms() + tplanh->ms();
+  // --- O(1) tail on the host core (groth16.go:253-275) ----------------------------------------------
   G1Xyzz piA = g1w[0];
   xyzz_madd(piA, pk->alpha);                                   // + alpha          :253
-  G1Xyzz rdelta = g1_mul_scalar(delta, r);
   xyzz_add(piA, rdelta);                                       // + r delta        :254-255
   G1Xyzz piB1 = g1w[1];
   xyzz_madd(piB1, pk->beta);                                   // + beta           :259
-  G1Xyzz sdelta = g1_mul_scalar(delta, s);
   xyzz_add(piB1, sdelta);                                      // + s delta        :261-262
   G2Xyzz piB = g2w[0];
   xyzz_madd(piB, pk->beta2);                                   // + beta2          :260
-  G2Xyzz sdelta2 = g2_mul_scalar(delta2, s);
   xyzz_add(piB, sdelta2);                                      // + s delta2       :263-264
   G1Xyzz piC = g1w[2];
   xyzz_add(piC, g1h[0]);                                       // + sum h_i PTD_i  :269-271
@@ -90,13 +135,10 @@ int groth16_prove_impl(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, cons
   xyzz_add(piC, sA);                                           // + s piA          :272
   G1Xyzz rB = g1_mul_scalar(piB1, r);
   xyzz_add(piC, rB);                                           // + r piB1         :273
-  // - (r s) delta = -(s (r delta))                                                  :274-275
-  G1Xyzz rsdelta = g1_mul_scalar(rdelta, s);
-  xyzz_add(piC, xyzz_neg(rsdelta));
+  xyzz_add(piC, xyzz_neg(rsdelta));                            // - (r s) delta    :274-275
   inf[0] = g1_to_affine_std(piA, out_proof) ? 1 : 0;
   inf[1] = g2_to_affine_std(piB, out_proof + 8) ? 1 : 0;
   inf[2] = g1_to_affine_std(piC, out_proof + 24) ? 1 : 0;
-  total.stop();
   c.timing.total_ms += total.ms();
   return GS_OK;
 }
@@ -105,14 +147,6 @@ int pinocchio_prove_impl(Ctx& c, PinocchioPkObj* pk, DevScalars w, DevScalars px
   if (w.n != pk->nvars) return fail(GS_ERR_SHAPE, "len(w) = %zu but the key has %zu variables", w.n, pk->nvars);
   const size_t nh = quotient_len(px.n, pk->nz);
   if (nh > pk->ng1t) return fail(GS_ERR_SHAPE, "len(hx) = %zu exceeds len(G1T) = %zu (snark.go:284-286)", nh, pk->ng1t);
-  PhaseTimer total(c.stream);
-  {
-    PhaseTimer tp(c.stream);
-    g_hx.ensure(std::max<size_t>(nh, 1) * 32);
-    if (nh) poly_quotient_dev(c, pk->z, px.p, px.n, g_hx.as<uint32_t>());          // snark.go:280
-    tp.stop();
-    c.timing.poly_ms += tp.ms();
-  }
   {
     const int cw = choose_window_bits((uint32_t)w.n, c.window_bits), ch = choose_window_bits((uint32_t)std::max<size_t>(nh, 1), c.window_bits);
     ensure_table_g1(c, pk->t_a, pk->a.as<uint32_t>(), pk->nvars, cw);
@@ -123,23 +157,45 @@ int pinocchio_prove_impl(Ctx& c, PinocchioPkObj* pk, DevScalars w, DevScalars px
     ensure_table_g1(c, pk->t_kp, pk->kp.as<uint32_t>(), pk->nvars, cw);
     ensure_table_g2(c, pk->t_b2, pk->b2.as<uint32_t>(), pk->nvars, cw);
     ensure_table_g1(c, pk->t_g1t, pk->g1t.as<uint32_t>(), pk->ng1t, ch);
+    g_hx.ensure(std::max<size_t>(nh, 1) * 32);
   }
+  PhaseTimer total(c.main_stream);
+  Fork fork(c);
   MsmPlan plan_w, plan_h;
+  MsmPending pend_g1w, pend_g2w, pend_h;
+  std::shared_ptr<PhaseTimer> tpoly, tplanw, tplanh;
   {
-    PhaseTimer tp(c.stream);
-    build_plan(c, 0, w.p, (uint32_t)w.n, plan_w);
+    StreamScope sc(c, c.aux_stream[1]);
+    tpoly = std::make_shared<PhaseTimer>(c.stream);
+    if (nh) poly_quotient_dev(c, pk->z, px.p, px.n, g_hx.as<uint32_t>());      // snark.go:280
+    tpoly->stop();
+    tplanh = std::make_shared<PhaseTimer>(c.stream);
     build_plan(c, 1, g_hx.as<uint32_t>(), (uint32_t)nh, plan_h);
-    tp.stop();
-    c.timing.plan_ms += tp.ms();
+    tplanh->stop();
+    GS_HIP(hipEventRecord(fork.planh, c.stream));
   }
+  {
+    StreamScope sc(c, c.main_stream);
+    tplanw = std::make_shared<PhaseTimer>(c.stream);
+    build_plan(c, 0, w.p, (uint32_t)w.n, plan_w);
+    tplanw->stop();
+    // A and Ap run over i > NPublic only (snark.go:265-268): their first npublic+1 points were forced
+    // to infinity at key creation; Bp, C, Cp, Kp and B run over all variables (:270-278).
+    msm_enqueue_g1(c, plan_w, {MsmBase{&pk->t_a, 0}, MsmBase{&pk->t_ap, 0}, MsmBase{&pk->t_bp, 0}, MsmBase{&pk->t_c, 0},
+                               MsmBase{&pk->t_cp, 0}, MsmBase{&pk->t_kp, 0}}, 0, 0, pend_g1w, c.aux_stream[0]);
+    msm_enqueue_g2(c, plan_w, {MsmBase{&pk->t_b2, 0}}, 6, 1, pend_g2w, c.aux_stream[0]);
+    GS_HIP(hipStreamWaitEvent(c.stream, fork.planh, 0));
+    msm_enqueue_g1(c, plan_h, {MsmBase{&pk->t_g1t, 0}}, 7, 2, pend_h);         // :284-286
+  }
+  fork.join();
+  total.stop();
   std::vector<G1Xyzz> g1w, g1h;
   std::vector<G2Xyzz> g2w;
-  // A and Ap run over i > NPublic only (snark.go:265-268): their first npublic+1 points were forced
-  // to infinity at key creation; Bp, C, Cp, Kp and B run over all variables (:270-278).
-  msm_run_g1(c, plan_w, {MsmBase{&pk->t_a, 0}, MsmBase{&pk->t_ap, 0}, MsmBase{&pk->t_bp, 0}, MsmBase{&pk->t_c, 0},
-                         MsmBase{&pk->t_cp, 0}, MsmBase{&pk->t_kp, 0}}, g1w);
-  msm_run_g2(c, plan_w, {MsmBase{&pk->t_b2, 0}}, g2w);
-  msm_run_g1(c, plan_h, {MsmBase{&pk->t_g1t, 0}}, g1h);                            // :284-286
+  msm_finish_g1(c, pend_g1w, g1w);
+  msm_finish_g2(c, pend_g2w, g2w);
+  msm_finish_g1(c, pend_h, g1h);
+  c.timing.poly_ms += tpoly->ms();
+  c.timing.plan_ms += tplanw->ms() + tplanh->ms();
   // output order: PiA | PiAp | PiB | PiBp | PiC | PiCp | PiH | PiKp
   inf[0] = g1_to_affine_std(g1w[0], out) ? 1 : 0;
   inf[1] = g1_to_affine_std(g1w[1], out + 8) ? 1 : 0;
@@ -149,7 +205,6 @@ int pinocchio_prove_impl(Ctx& c, PinocchioPkObj* pk, DevScalars w, DevScalars px
   inf[5] = g1_to_affine_std(g1w[4], out + 48) ? 1 : 0;
   inf[6] = g1_to_affine_std(g1h[0], out + 56) ? 1 : 0;
   inf[7] = g1_to_affine_std(g1w[5], out + 64) ? 1 : 0;
-  total.stop();
   c.timing.total_ms += total.ms();
   return GS_OK;
 }

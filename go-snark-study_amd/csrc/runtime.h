@@ -90,7 +90,10 @@ struct Scalars : Object {        // n x 8 u32 words, standard form, resident
 struct Ctx {
   int device = -1;
   bool ready = false;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;   // the stream every engine function enqueues on (switched by StreamScope)
+  hipStream_t main_stream = nullptr, aux_stream[2] = {nullptr, nullptr};
+  void* pinned[3] = {nullptr, nullptr, nullptr};     // host staging for the per-stream result downloads
+  static constexpr size_t kPinnedBytes = 256 * 1024;
   std::mutex mu;
   uint64_t next_handle = 1;
   std::unordered_map<uint64_t, std::unique_ptr<Object>> objs;
@@ -98,7 +101,7 @@ struct Ctx {
   gs_timing timing{};
   // reusable workspaces (grow-only)
   DevBuf ws_hist, ws_offsets, ws_cursor, ws_entries, ws_tiles, ws_total;
-  DevBuf ws_buckets[8], ws_chunks[8], ws_partials[8], ws_winsums;
+  DevBuf ws_buckets[8], ws_chunks[8], ws_partials[8], ws_out[8];
   DevBuf ws_misc;
   DevBuf g1_pow2, g2_pow2;       // 2^j * G tables (lazy)
   std::vector<hipEvent_t> events;
@@ -137,6 +140,14 @@ int guarded(F&& f, bool need_init = true) {
   }
 }
 inline void reset_timing(Ctx& c) { c.timing = gs_timing{}; }
+
+// run a section of engine calls on another stream of the context
+struct StreamScope {
+  Ctx& c;
+  hipStream_t saved;
+  StreamScope(Ctx& ctx_, hipStream_t s) : c(ctx_), saved(ctx_.stream) { c.stream = s; }
+  ~StreamScope() { c.stream = saved; }
+};
 
 // RAII event timer on the library stream
 struct PhaseTimer {
