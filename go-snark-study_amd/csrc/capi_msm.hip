@@ -71,6 +71,7 @@ int msm_resident(Ctx& c, Kind kind, gs_handle hb, size_t off, const uint32_t* sc
   Bases* b = c.get<Bases>(hb, kind);
   if (!b) return fail(GS_ERR_ARG, "bad base handle");
   if (!out_affine || !is_inf) return fail(GS_ERR_ARG, "null output");
+  if (n > (size_t)kIndexMask) return fail(GS_ERR_ARG, "at most 2^26 - 1 terms per MSM call (shard larger sums)");
   if (off > b->n || n > b->n - off) return fail(GS_ERR_ARG, "term range [%zu, %zu) exceeds the %zu resident points", off, off + n, b->n);
   // window table of this base array for the width the plan will use (built on first use, kept resident)
   if (!b->table) b->table = std::make_shared<BaseTable>();
@@ -162,8 +163,21 @@ int gs_init(const int* devices, int ndev) {
     if (c.ready && c.device != devices[0]) return fail(GS_ERR_ARG, "already initialised on device %d", c.device);
     if (!c.ready) {
       GS_HIP(hipStreamCreateWithFlags(&c.main_stream, hipStreamNonBlocking));
-      GS_HIP(hipStreamCreateWithFlags(&c.aux_stream[0], hipStreamNonBlocking));
-      GS_HIP(hipStreamCreateWithFlags(&c.aux_stream[1], hipStreamNonBlocking));
+      // The aux streams carry the latency-/bandwidth-bound shadow work of a proof (NTT passes, plan kernels,
+      // bucket combine / reduction tails).  They are confined to every 8th CU (32 of 256, 4 per XCD): an
+      // EC-arithmetic wave needs 150-256 VGPRs, so wherever it lands it evicts an accumulation wave; the
+      // mask keeps that displacement off 7/8 of the chip.  GS_AUX_CU_STRIDE=0 disables the mask.
+      {
+        int stride = 8;
+        if (const char* e = getenv("GS_AUX_CU_STRIDE")) stride = atoi(e);
+        uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const int ncu = std::min(256, prop.multiProcessorCount);
+        if (stride > 0) for (int i = 0; i < ncu; i += stride) mask[i >> 5] |= 1u << (i & 31);
+        for (auto& a : c.aux_stream) {
+          if (stride > 0) GS_HIP(hipExtStreamCreateWithCUMask(&a, 8, mask));
+          else GS_HIP(hipStreamCreateWithFlags(&a, hipStreamNonBlocking));
+        }
+      }
       for (auto& p : c.pinned) GS_HIP(hipHostMalloc(&p, Ctx::kPinnedBytes, hipHostMallocDefault));
       c.stream = c.main_stream;
       c.device = devices[0];

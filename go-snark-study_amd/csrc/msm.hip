@@ -37,7 +37,7 @@ void build_plan(Ctx& c, int slot, const uint32_t* scalars_dev, uint32_t n, MsmPl
   plan.c = choose_window_bits(n, c.window_bits);
   plan.W = 254 / plan.c + 1;
   plan.B = 1u << (plan.c - 1);
-  plan.nbuckets = (uint32_t)plan.W * plan.B;
+  plan.nbuckets = plan.B;                      // one bucket set for all windows (window tables)
   plan.maxchunks = (uint32_t)(((size_t)n * plan.W + kChunk - 1) / kChunk) + 1;
   const size_t ncount = (size_t)plan.nbuckets + 1;
   PlanParams pp{};
@@ -46,7 +46,7 @@ void build_plan(Ctx& c, int slot, const uint32_t* scalars_dev, uint32_t n, MsmPl
   pp.slice = (n + pp.S - 1) / pp.S;
   pp.stride = (n + 63u) & ~63u;
   pb.digits.ensure((size_t)std::max<uint32_t>(pp.stride, 64u) * plan.W * 2);
-  pb.hist.ensure((size_t)plan.nbuckets * pp.S * 4);
+  pb.hist.ensure((size_t)plan.B * plan.W * pp.S * 4);
   pb.totals.ensure(ncount * 4);
   pb.offsets.ensure(ncount * 4);
   pb.entries.ensure(((size_t)plan.maxchunks + 1) * kChunk * 4);
@@ -65,7 +65,7 @@ void build_plan(Ctx& c, int slot, const uint32_t* scalars_dev, uint32_t n, MsmPl
   if (n > 0) {
     hipLaunchKernelGGL(k_digits, grid1(n), dim3(256), 0, c.stream, scalars_dev, pp, pb.digits.as<uint16_t>());
     hipLaunchKernelGGL(k_hist, dim3(plan.W, pp.S), dim3(kSortBlock), lds, c.stream, pb.digits.as<uint16_t>(), pp, pb.hist.as<uint32_t>());
-    hipLaunchKernelGGL(k_colscan, grid1(plan.nbuckets), dim3(256), 0, c.stream, pb.hist.as<uint32_t>(), pp, pb.totals.as<uint32_t>());
+    hipLaunchKernelGGL(k_colscan, grid1(plan.B), dim3(256), 0, c.stream, pb.hist.as<uint32_t>(), pp, pb.totals.as<uint32_t>());
   } else {
     GS_HIP(hipMemsetAsync(pb.totals.p, 0, ncount * 4, c.stream));
   }
@@ -136,9 +136,9 @@ static void msm_enqueue(Ctx& c, const MsmPlan& plan, const std::vector<MsmBase>&
   p.tacc = std::make_shared<PhaseTimer>(c.stream);
   p.tker = std::make_shared<PhaseTimer>(c.stream);
   hipLaunchKernelGGL(k_bucket_accumulate<T>, dim3((plan.maxchunks + 255) / 256, njobs), dim3(256), 0, c.stream,
-                     jobs, plan.offsets, plan.entries, plan.chunk_bucket, plan.nbuckets, plan.c - 1);
+                     jobs, plan.offsets, plan.entries, plan.chunk_bucket, plan.nbuckets);
   p.tker->stop();
-  hipLaunchKernelGGL(k_heavy_combine<T>, dim3(64, njobs), dim3(kHeavyBlock), 0, c.stream,
+  hipLaunchKernelGGL(k_heavy_combine<T>, dim3(1024, njobs), dim3(kHeavyBlock), 0, c.stream,
                      jobs, plan.offsets, plan.heavy_list, plan.heavy_count);
   p.tacc->stop();
   // the latency-bound tail may run on another stream, in the shadow of the next group's accumulation
@@ -151,7 +151,7 @@ static void msm_enqueue(Ctx& c, const MsmPlan& plan, const std::vector<MsmBase>&
     GS_HIP(hipEventDestroy(ev));       // released by the runtime once it has fired
   }
   p.tred = std::make_shared<PhaseTimer>(ts);
-  hipLaunchKernelGGL(k_window_merge<T>, dim3((plan.B + 255) / 256, njobs), dim3(256), 0, ts, jobs, plan.offsets, plan.B, plan.W);
+  hipLaunchKernelGGL(k_bucket_combine<T>, dim3((plan.B + 255) / 256, njobs), dim3(256), 0, ts, jobs, plan.offsets, plan.B);
   hipLaunchKernelGGL(k_block_reduce<T>, dim3(nblk, njobs), dim3(kReduceBlock), 0, ts, jobs, plan.B, L);
   GS_HIP(hipGetLastError());
   GS_HIP(hipMemcpyAsync(c.pinned[slot], outb.p, out_bytes, hipMemcpyDeviceToHost, ts));

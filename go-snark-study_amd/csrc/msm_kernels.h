@@ -15,7 +15,7 @@
 //     k_bucket_accumulate  one thread per CHUNK: XYZZ += +-affine table point (8M+2S), flushing at bucket
 //                          boundaries; cut buckets leave head/tail partials                      <- dominant
 //     k_heavy_combine      block-wide tree-sum for buckets cut into many chunks
-//     k_window_merge       merged[b] = sum over the W windows of bucket (w, b)
+//     k_bucket_combine     merged[b] = sum of the chunk partials of bucket b
 //     k_block_reduce       sum_b (b+1) merged[b] per 2048-bucket workgroup (running sums + LDS scan)
 //   host: adds the <= 16 workgroup pairs, converts to affine / from Montgomery
 //
@@ -86,25 +86,27 @@ __global__ void __launch_bounds__(kSortBlock) k_hist(const uint16_t* __restrict_
   for (uint32_t b = threadIdx.x; b < pp.B; b += kSortBlock) out[b] = sh[b];
 }
 
-// hist[w][s][b] -> exclusive prefix over s (in place); totals[w*B + b] = sum over s
+// hist[q][b], q = w*S + s  ->  exclusive prefix over q (in place); totals[b] = sum over q.
+// (All windows share one bucket set -- see the window tables below -- so a bucket's entries are the
+// concatenation of its (window, slice) runs.)
 __global__ void __launch_bounds__(256) k_colscan(uint32_t* __restrict__ hist, PlanParams pp, uint32_t* __restrict__ totals) {
-  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= (uint32_t)pp.W * pp.B) return;
-  const uint32_t w = g / pp.B, b = g - w * pp.B;
-  uint32_t* col = hist + (size_t)w * pp.S * pp.B + b;
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= pp.B) return;
+  uint32_t* col = hist + b;
+  const uint32_t nq = (uint32_t)pp.W * pp.S;
   uint32_t run = 0;
-  for (uint32_t s = 0; s < pp.S; ++s) { const uint32_t t = col[(size_t)s * pp.B]; col[(size_t)s * pp.B] = run; run += t; }
-  totals[g] = run;
+  for (uint32_t q = 0; q < nq; ++q) { const uint32_t t = col[(size_t)q * pp.B]; col[(size_t)q * pp.B] = run; run += t; }
+  totals[b] = run;
 }
 
-// ---- plan, step 4: counting-sort scatter; cursors live in LDS, entries[pos] = term index | sign -----------------
+// ---- plan, step 4: counting-sort scatter; cursors live in LDS ------------------------------------------------
+// entry = sign (bit 31) | window (bits 30..26) | term index (bits 25..0)
 __global__ void __launch_bounds__(kSortBlock) k_scatter(const uint16_t* __restrict__ digits, PlanParams pp, const uint32_t* __restrict__ hist,
                                                          const uint32_t* __restrict__ offsets, uint32_t* __restrict__ entries) {
   extern __shared__ uint32_t sh[];
   const uint32_t w = blockIdx.x, s = blockIdx.y;
   const uint32_t* pre = hist + ((size_t)w * pp.S + s) * pp.B;
-  const uint32_t* off = offsets + (size_t)w * pp.B;
-  for (uint32_t b = threadIdx.x; b < pp.B; b += kSortBlock) sh[b] = off[b] + pre[b];
+  for (uint32_t b = threadIdx.x; b < pp.B; b += kSortBlock) sh[b] = offsets[b] + pre[b];
   __syncthreads();
   const uint32_t lo = s * pp.slice, hi = min(pp.n, lo + pp.slice);
   const uint16_t* row = digits + (size_t)w * pp.stride;
@@ -113,7 +115,7 @@ __global__ void __launch_bounds__(kSortBlock) k_scatter(const uint16_t* __restri
     const int32_t d = (int32_t)row[i] - zero;
     if (d != 0) {
       const uint32_t pos = atomicAdd(&sh[(uint32_t)(d < 0 ? -d : d) - 1u], 1u);
-      entries[pos] = i | (d < 0 ? kSignBit : 0u);
+      entries[pos] = i | (w << kWindowShift) | (d < 0 ? kSignBit : 0u);
     }
   }
 }
@@ -178,7 +180,7 @@ __global__ void __launch_bounds__(kScanBlock) k_scan_add(uint32_t* __restrict__ 
 // chunk_bucket[t] = bucket holding entry t*kChunk.  Buckets cut into more than kHeavySpan + 1 pieces are listed
 // for a block-wide tree combine (k_heavy_combine), the others are combined by whoever reads them.
 constexpr uint32_t kChunk = 32;
-constexpr uint32_t kHeavySpan = 8;
+constexpr uint32_t kHeavySpan = 64;
 constexpr uint32_t kMaxHeavy = 1u << 16;
 
 __global__ void __launch_bounds__(256) k_chunk_map(const uint32_t* __restrict__ offsets, uint32_t nbuckets,
@@ -210,10 +212,16 @@ struct AccJob {
 constexpr int kMaxJobs = 8;
 struct AccJobs { AccJob j[kMaxJobs]; };
 
+// waves per SIMD the register allocator must allow: G1 needs ~150 VGPRs (3 waves), G2 must fit 256 (2 waves;
+// left alone it takes 264 and drops to ONE wave per SIMD, which halves the v_mad_u64_u32 issue rate)
+template <class T> struct AccTuning;
+template <> struct AccTuning<FqTag> { static constexpr int kMinWaves = 3; static constexpr bool kRegisterPrefetch = true; };
+template <> struct AccTuning<Fq2Tag> { static constexpr int kMinWaves = 2; static constexpr bool kRegisterPrefetch = false; };
+
 template <class T>
-__global__ void __launch_bounds__(256) k_bucket_accumulate(AccJobs jobs, const uint32_t* __restrict__ offsets,
+__global__ void __launch_bounds__(256, AccTuning<T>::kMinWaves) k_bucket_accumulate(AccJobs jobs, const uint32_t* __restrict__ offsets,
                                                             const uint32_t* __restrict__ entries,
-                                                            const uint32_t* __restrict__ chunk_bucket, uint32_t nbuckets, int cshift) {
+                                                            const uint32_t* __restrict__ chunk_bucket, uint32_t nbuckets) {
   constexpr int pw = PointIO<T>::kXyzzWords;
   constexpr int aw = PointIO<T>::kAffineWords;
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -225,28 +233,45 @@ __global__ void __launch_bounds__(256) k_bucket_accumulate(AccJobs jobs, const u
   uint32_t b = chunk_bucket[t];
   uint32_t bend = offsets[b + 1];
   bool started_before = offsets[b] < beg;
-  // the digit of window w multiplies 2^(c w) P_i: row w of the table, so every window feeds the SAME bucket set
-  const uint32_t* row = job.table + (size_t)(b >> cshift) * job.row_stride * aw;
   Xyzz<T> acc = xyzz_inf<T>();
   const uint4* e4 = reinterpret_cast<const uint4*>(entries + beg);      // beg is a multiple of 32 entries = 128 B
-  for (uint32_t e = beg; e < end; e += 4) {
-    const uint4 q = e4[(e - beg) >> 2];
-    const uint32_t vv[4] = {q.x, q.y, q.z, q.w};
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      if (e + u < end) {
-        if (e + u >= bend) {                                            // bucket b is complete
-          store_xyzz<T>((started_before ? job.heads + (size_t)t * pw : job.buckets + (size_t)b * pw), acc);
-          started_before = false;
-          acc = xyzz_inf<T>();
-          do { ++b; bend = offsets[b + 1]; } while (bend <= e + u);
-          row = job.table + (size_t)(b >> cshift) * job.row_stride * aw;
-        }
-        const uint32_t v = vv[u];
-        const Affine<T> p = PointIO<T>::load_affine(row + (size_t)(v & ~kSignBit) * aw);
-        xyzz_madd(acc, p, (v & kSignBit) != 0);
-      }
+  // Software pipeline: the table point of entry e+1 is requested before the 8M+2S of entry e, so the random
+  // 64/128-byte gather (HBM miss ~900 cycles) is covered by ~4000 cycles of arithmetic of the same wave.
+  // G1 keeps the whole next point in registers; G2 (register-bound) only touches its cache line.
+  constexpr bool kPre = AccTuning<T>::kRegisterPrefetch;
+  uint4 q = e4[0];
+  uint32_t v = q.x;
+  uint32_t nb = b;                                                       // bucket of entry `v`
+  // the digit of window w multiplies 2^(c w) P_i = row w of the table: every window feeds the SAME bucket set
+  const uint32_t* np = job.table + ((size_t)((v >> kWindowShift) & 31u) * job.row_stride + (v & kIndexMask)) * aw;
+  RawAffine<T> nextp;
+  uint32_t touch = 0;
+  if constexpr (kPre) nextp = load_raw_affine<T>(np);
+  for (uint32_t e = beg; e < end; ++e) {
+    const uint32_t cur = v;
+    const uint32_t* cp = np;
+    RawAffine<T> curp;
+    if constexpr (kPre) curp = nextp;
+    if (e >= bend) {                                                     // bucket b is complete
+      store_xyzz<T>((started_before ? job.heads + (size_t)t * pw : job.buckets + (size_t)b * pw), acc);
+      started_before = false;
+      acc = xyzz_inf<T>();
+      b = nb; bend = offsets[b + 1];
     }
+    if (e + 1 < end) {                                                   // issue the next gather
+      const uint32_t k = (e + 1 - beg) & 3u;
+      if (k == 0) q = e4[(e + 1 - beg) >> 2];
+      v = k == 0 ? q.x : k == 1 ? q.y : k == 2 ? q.z : q.w;
+      uint32_t nbend = offsets[nb + 1];
+      while (nbend <= e + 1) { ++nb; nbend = offsets[nb + 1]; }
+      np = job.table + ((size_t)((v >> kWindowShift) & 31u) * job.row_stride + (v & kIndexMask)) * aw;
+      if constexpr (kPre) nextp = load_raw_affine<T>(np);
+      else touch = *np;
+    }
+    if constexpr (!kPre) curp = load_raw_affine<T>(cp);
+    const Affine<T> p = unpack_affine<T>(curp);
+    xyzz_madd(acc, p, (cur & kSignBit) != 0);
+    if constexpr (!kPre) asm volatile("" ::"v"(touch));                  // keep the touch load alive until here
   }
   uint32_t* dst = (bend > end) ? job.tails + (size_t)t * pw
                                : (started_before ? job.heads + (size_t)t * pw : job.buckets + (size_t)b * pw);
@@ -302,20 +327,16 @@ __global__ void __launch_bounds__(kHeavyBlock) k_heavy_combine(AccJobs jobs, con
   }
 }
 
-// ---- window merge + bucket reduction -------------------------------------------------------------------
-// merged[b] = sum_w bucket[w][b]: thanks to the window tables all W digit positions share one bucket set, so
-// the result is simply sum_b (b + 1) * merged[b] -- no per-window reduction and no Horner recombination.
+// ---- bucket combine + reduction ---------------------------------------------------------------------------
+// merged[b] = the pieces of bucket b (it spans ~ n W / (B * kChunk) chunks).  Thanks to the window tables all W
+// digit positions share one bucket set, so the MSM is simply sum_b (b + 1) * merged[b]: no per-window
+// reduction and no Horner recombination.
 template <class T>
-__global__ void __launch_bounds__(256) k_window_merge(AccJobs jobs, const uint32_t* __restrict__ offsets, uint32_t B, int W) {
+__global__ void __launch_bounds__(256) k_bucket_combine(AccJobs jobs, const uint32_t* __restrict__ offsets, uint32_t B) {
   const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   const AccJob job = jobs.j[blockIdx.y];
-  Xyzz<T> acc = load_bucket<T>(job, offsets, b);
-  for (int w = 1; w < W; ++w) {
-    const Xyzz<T> p = load_bucket<T>(job, offsets, (uint32_t)w * B + b);
-    xyzz_add(acc, p);
-  }
-  store_xyzz<T>(job.merged + (size_t)b * PointIO<T>::kXyzzWords, acc);
+  store_xyzz<T>(job.merged + (size_t)b * PointIO<T>::kXyzzWords, load_bucket<T>(job, offsets, b));
 }
 
 // One workgroup of 256 threads reduces 256 * L consecutive buckets to the pair

@@ -7,7 +7,9 @@
 
 namespace gs {
 
-constexpr uint32_t kSignBit = 0x80000000u;
+constexpr uint32_t kSignBit = 0x80000000u;      // bucket entries: sign | window (5 bits) | term index (26 bits)
+constexpr int kWindowShift = 26;
+constexpr uint32_t kIndexMask = (1u << kWindowShift) - 1u;
 
 // ---- packed memory formats ---------------------------------------------------------------------
 // canonical Montgomery coordinate <-> 8 words
@@ -78,6 +80,24 @@ template <> struct PointIO<Fq2Tag> {
   }
   static constexpr int kCoordWords = 16;
 };
+
+// packed affine point as raw 16-byte words (software-pipelined gathers: load now, unpack after the wait)
+template <class T> struct RawAffine { uint4 q[PointIO<T>::kAffineWords / 4]; };
+template <class T>
+GS_HD RawAffine<T> load_raw_affine(const uint32_t* p) {
+  RawAffine<T> r;
+  const uint4* s4 = reinterpret_cast<const uint4*>(p);
+#pragma unroll
+  for (int i = 0; i < PointIO<T>::kAffineWords / 4; ++i) r.q[i] = s4[i];
+  return r;
+}
+template <class T>
+GS_HD Affine<T> unpack_affine(const RawAffine<T>& r) {
+  uint32_t w[PointIO<T>::kAffineWords];
+#pragma unroll
+  for (int i = 0; i < PointIO<T>::kAffineWords / 4; ++i) { w[4 * i] = r.q[i].x; w[4 * i + 1] = r.q[i].y; w[4 * i + 2] = r.q[i].z; w[4 * i + 3] = r.q[i].w; }
+  return PointIO<T>::load_affine(w);
+}
 
 template <class T>
 GS_HD Xyzz<T> load_xyzz(const uint32_t* p) {

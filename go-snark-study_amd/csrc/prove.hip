@@ -80,16 +80,6 @@ int groth16_prove_impl(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, cons
   MsmPlan plan_w, plan_h;
   MsmPending pend_g1w, pend_g2w, pend_h;
   std::shared_ptr<PhaseTimer> tpoly, tplanw, tplanh;
-  {                                                              // aux 1: H(x), plan(h)
-    StreamScope sc(c, c.aux_stream[1]);
-    tpoly = std::make_shared<PhaseTimer>(c.stream);
-    if (nh) poly_quotient_dev(c, pk->z, px.p, px.n, g_hx.as<uint32_t>());      // groth16.go:266
-    tpoly->stop();
-    tplanh = std::make_shared<PhaseTimer>(c.stream);
-    build_plan(c, 1, g_hx.as<uint32_t>(), (uint32_t)nh, plan_h);
-    tplanh->stop();
-    GS_HIP(hipEventRecord(fork.planh, c.stream));
-  }
   {                                                              // main: plan(w), then the accumulations back to back
     StreamScope sc(c, c.main_stream);
     tplanw = std::make_shared<PhaseTimer>(c.stream);
@@ -100,6 +90,19 @@ int groth16_prove_impl(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, cons
     msm_enqueue_g1(c, plan_w, {MsmBase{&pk->t_at, 0}, MsmBase{&pk->t_bacgamma1, 0}, MsmBase{&pk->t_bacdelta, 0}}, 0, 0, pend_g1w,
                    c.aux_stream[0]);
     msm_enqueue_g2(c, plan_w, {MsmBase{&pk->t_bacgamma2, 0}}, 4, 1, pend_g2w, c.aux_stream[0]);
+  }
+  {                                                              // aux 1: H(x), plan(h)
+    StreamScope sc(c, c.aux_stream[1]);
+    tpoly = std::make_shared<PhaseTimer>(c.stream);
+    if (nh) poly_quotient_dev(c, pk->z, px.p, px.n, g_hx.as<uint32_t>());      // groth16.go:266
+    tpoly->stop();
+    tplanh = std::make_shared<PhaseTimer>(c.stream);
+    build_plan(c, 1, g_hx.as<uint32_t>(), (uint32_t)nh, plan_h);
+    tplanh->stop();
+    GS_HIP(hipEventRecord(fork.planh, c.stream));
+  }
+  {                                                              // main again: sum h_i PTD_i once plan(h) exists
+    StreamScope sc(c, c.main_stream);
     GS_HIP(hipStreamWaitEvent(c.stream, fork.planh, 0));
     msm_enqueue_g1(c, plan_h, {MsmBase{&pk->t_ptd, 0}}, 3, 2, pend_h);          // :269-271
   }
@@ -165,6 +168,17 @@ int pinocchio_prove_impl(Ctx& c, PinocchioPkObj* pk, DevScalars w, DevScalars px
   MsmPending pend_g1w, pend_g2w, pend_h;
   std::shared_ptr<PhaseTimer> tpoly, tplanw, tplanh;
   {
+    StreamScope sc(c, c.main_stream);
+    tplanw = std::make_shared<PhaseTimer>(c.stream);
+    build_plan(c, 0, w.p, (uint32_t)w.n, plan_w);
+    tplanw->stop();
+    // A and Ap run over i > NPublic only (snark.go:265-268): their first npublic+1 points were forced
+    // to infinity at key creation; Bp, C, Cp, Kp and B run over all variables (:270-278).
+    msm_enqueue_g1(c, plan_w, {MsmBase{&pk->t_a, 0}, MsmBase{&pk->t_ap, 0}, MsmBase{&pk->t_bp, 0}, MsmBase{&pk->t_c, 0},
+                               MsmBase{&pk->t_cp, 0}, MsmBase{&pk->t_kp, 0}}, 0, 0, pend_g1w, c.aux_stream[0]);
+    msm_enqueue_g2(c, plan_w, {MsmBase{&pk->t_b2, 0}}, 6, 1, pend_g2w, c.aux_stream[0]);
+  }
+  {
     StreamScope sc(c, c.aux_stream[1]);
     tpoly = std::make_shared<PhaseTimer>(c.stream);
     if (nh) poly_quotient_dev(c, pk->z, px.p, px.n, g_hx.as<uint32_t>());      // snark.go:280
@@ -176,14 +190,6 @@ int pinocchio_prove_impl(Ctx& c, PinocchioPkObj* pk, DevScalars w, DevScalars px
   }
   {
     StreamScope sc(c, c.main_stream);
-    tplanw = std::make_shared<PhaseTimer>(c.stream);
-    build_plan(c, 0, w.p, (uint32_t)w.n, plan_w);
-    tplanw->stop();
-    // A and Ap run over i > NPublic only (snark.go:265-268): their first npublic+1 points were forced
-    // to infinity at key creation; Bp, C, Cp, Kp and B run over all variables (:270-278).
-    msm_enqueue_g1(c, plan_w, {MsmBase{&pk->t_a, 0}, MsmBase{&pk->t_ap, 0}, MsmBase{&pk->t_bp, 0}, MsmBase{&pk->t_c, 0},
-                               MsmBase{&pk->t_cp, 0}, MsmBase{&pk->t_kp, 0}}, 0, 0, pend_g1w, c.aux_stream[0]);
-    msm_enqueue_g2(c, plan_w, {MsmBase{&pk->t_b2, 0}}, 6, 1, pend_g2w, c.aux_stream[0]);
     GS_HIP(hipStreamWaitEvent(c.stream, fork.planh, 0));
     msm_enqueue_g1(c, plan_h, {MsmBase{&pk->t_g1t, 0}}, 7, 2, pend_h);         // :284-286
   }
