@@ -16,6 +16,9 @@ int ceil_log2(size_t n);
 void ntt_forward(Ctx& c, uint32_t* data, int logt, int logm);
 // Inverse of the above (bit-reversed in, natural out), WITHOUT the 1/N scaling.
 void ntt_inverse_unscaled(Ctx& c, uint32_t* data, int logt, int logm);
+// the same for any element count that is a multiple of 2^logm
+void ntt_forward_n(Ctx& c, uint32_t* data, size_t total, int logm);
+void ntt_inverse_unscaled_n(Ctx& c, uint32_t* data, size_t total, int logm);
 
 // out (na + nb - 1 coefficients) = a * b.  fa/fb: form of the inputs; the output is Montgomery iff
 // both inputs are, standard otherwise.  out may not alias the inputs.  out_cap >= na + nb - 1.
@@ -40,6 +43,13 @@ void poly_quotient_dev(Ctx& c, Divisor& d, const uint32_t* a_std, size_t na, uin
 
 // Z(x) = prod_{i=1}^{deg} (x - i), deg + 1 canonical standard-form coefficients (subproduct tree of NTT products)
 void zpoly_dev(Ctx& c, size_t deg, uint32_t* out_std);
+
+// Lagrange interpolation on the nodes 1..n of nvec value vectors (nvec x n, standard form) -> nvec x n coefficients
+// (standard form, values < 2r); O(n log^2 n) on a cached subproduct tree.
+void interpolate_dev(Ctx& c, const uint32_t* values_std, size_t n, size_t nvec, uint32_t* coeffs_std);
+// CSR sparse matrix (standard-form values) times a Montgomery-form vector -> standard-form vector
+void spmv_dev(Ctx& c, const uint32_t* rowptr, const uint32_t* col, const uint32_t* val_std, const uint32_t* x_mont, size_t nrows, size_t ncols,
+              uint32_t* out_std);
 
 void poly_addsub_dev(Ctx& c, const uint32_t* a, size_t na, const uint32_t* b, size_t nb, bool subtract, uint32_t* out);
 void poly_canon_dev(Ctx& c, uint32_t* x, size_t n, int mode /* 0 canon, 1 to-Montgomery, 2 from-Montgomery */);

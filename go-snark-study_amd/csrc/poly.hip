@@ -54,10 +54,13 @@ static void ensure_twiddles(Ctx& c, int logn) {
   g_tw.logn = logn;
 }
 
-void ntt_forward(Ctx& c, uint32_t* data, int logt, int logm) {
+void ntt_forward(Ctx& c, uint32_t* data, int logt, int logm) { ntt_forward_n(c, data, (size_t)1 << logt, logm); }
+void ntt_inverse_unscaled(Ctx& c, uint32_t* data, int logt, int logm) { ntt_inverse_unscaled_n(c, data, (size_t)1 << logt, logm); }
+
+void ntt_forward_n(Ctx& c, uint32_t* data, size_t total, int logm) {
   if (logm == 0) return;
   ensure_twiddles(c, logm);
-  const uint32_t nb = 1u << (logt - 1);
+  const uint32_t nb = (uint32_t)(total / 2);
   for (int s = logm - 1; s >= 0; --s) {              // half = 2^s
     const uint32_t half = 1u << s;
     const uint32_t stride = (1u << (g_tw.logn - 1)) / half;
@@ -66,10 +69,10 @@ void ntt_forward(Ctx& c, uint32_t* data, int logt, int logm) {
   GS_HIP(hipGetLastError());
 }
 
-void ntt_inverse_unscaled(Ctx& c, uint32_t* data, int logt, int logm) {
+void ntt_inverse_unscaled_n(Ctx& c, uint32_t* data, size_t total, int logm) {
   if (logm == 0) return;
   ensure_twiddles(c, logm);
-  const uint32_t nb = 1u << (logt - 1);
+  const uint32_t nb = (uint32_t)(total / 2);
   for (int s = 0; s < logm; ++s) {
     const uint32_t half = 1u << s;
     const uint32_t stride = (1u << (g_tw.logn - 1)) / half;
@@ -203,35 +206,128 @@ void poly_quotient_dev(Ctx& c, Divisor& d, const uint32_t* a, size_t na, uint32_
   GS_HIP(hipGetLastError());
 }
 
+// ---- subproduct tree over the nodes 1..n (r1csqap.go's interpolation nodes) ---------------------------------------
+// Level j holds 2^(L-j) monic polynomials of degree d = 2^j (low d coefficients, leading 1 implicit); the leaves are
+// (x - i) for i = 1..n and the factor x for the padding up to 2^L.  Kept per n (two most recent): the spectra of every
+// level (NTT of the zero-padded blocks, 2^(L+1) elements per level -- 1.3 GB at n = 2^20, which is what the HBM is for),
+// the root, and the barycentric weights 1 / M'(j).
+struct NodeTree {
+  size_t n = 0, total = 0, pad = 0;
+  int L = 0;
+  std::vector<DevBuf> mspec;     // level j < L: spectra of the 2d-padded blocks, Montgomery, bit-reversed within each 2d block
+  DevBuf root;                   // low 2^L coefficients of x^pad * prod_{i=1}^{n} (x - i), Montgomery
+  DevBuf weights;                // n elements, Montgomery: 1 / prod_{k != j} (j - k), nodes j = 1..n
+  uint64_t stamp = 0;
+};
+static NodeTree g_trees[2];
+static uint64_t g_tree_clock = 0;
+
+static void build_weights(Ctx& c, NodeTree& t) {
+  // 1 / M'(j) = (-1)^(n-j) / ((j-1)! (n-j)!)        [cf. NewPolZeroAt's divisor, r1csqap.go:130-136, without its int overflow]
+  const size_t n = t.n;
+  std::vector<Fe<ModR, 2>> invf(n);                  // invf[k] = 1 / k!
+  Fe<ModR, 2> f = relax<2>(fe_one<ModR>());
+  for (size_t k = 1; k < n; ++k) f = mul(f, fr_small_mont(k));
+  Fe<ModR, 2> inv_top = inv(f);                      // 1 / (n-1)!
+  for (size_t k = n; k-- > 0;) { invf[k] = inv_top; if (k) inv_top = mul(inv_top, fr_small_mont(k)); }
+  std::vector<uint32_t> w(n * 8);
+  for (size_t j = 1; j <= n; ++j) {
+    Fe<ModR, 2> v = mul(invf[j - 1], invf[n - j]);
+    Fe<ModR, 1> cv = ((n - j) & 1) ? canon(neg(v)) : canon(v);
+    uint32_t words[8];
+    pack32<ModR>(cv, words);
+    memcpy(&w[(j - 1) * 8], words, 32);
+  }
+  t.weights.alloc(std::max<size_t>(n, 1) * 32);
+  GS_HIP(hipMemcpyAsync(t.weights.p, w.data(), n * 32, hipMemcpyHostToDevice, c.stream));
+  GS_HIP(hipStreamSynchronize(c.stream));
+}
+
+static NodeTree& ensure_tree(Ctx& c, size_t n, bool need_weights) {
+  NodeTree* t = nullptr;
+  for (auto& x : g_trees) if (x.n == n && x.root.p) t = &x;
+  if (!t) {
+    t = (g_trees[0].stamp <= g_trees[1].stamp) ? &g_trees[0] : &g_trees[1];
+    *t = NodeTree{};
+    t->n = n;
+    t->L = ceil_log2(std::max<size_t>(n, 1));
+    t->total = (size_t)1 << t->L;
+    t->pad = t->total - n;
+    const size_t total = t->total;
+    DevBuf cur(total * 32), nxt(total * 32);
+    hipLaunchKernelGGL(k_zp_leaves, grid1(total), dim3(256), 0, c.stream, cur.as<uint32_t>(), (uint32_t)n, (uint32_t)total);
+    t->mspec.resize(t->L);
+    for (int j = 0; j < t->L; ++j) {                           // blocks of d = 2^j low coefficients -> blocks of 2d
+      const uint32_t d = 1u << j;
+      DevBuf& wide = t->mspec[j];
+      wide.alloc(2 * total * 32);
+      hipLaunchKernelGGL(k_expand_blocks, grid1(2 * total), dim3(256), 0, c.stream, cur.as<uint32_t>(), wide.as<uint32_t>(), d, (uint32_t)(2 * total));
+      ntt_forward(c, wide.as<uint32_t>(), t->L + 1, j + 1);
+      hipLaunchKernelGGL(k_pw_mul_pairs, grid1(total), dim3(256), 0, c.stream, wide.as<uint32_t>(), nxt.as<uint32_t>(), 2 * d, (uint32_t)total);
+      ntt_inverse_unscaled(c, nxt.as<uint32_t>(), t->L, j + 1);
+      // (x^d + a)(x^d + b): low 2d coefficients = a b + x^d (a + b)
+      DevBuf out(total * 32);
+      hipLaunchKernelGGL(k_monic_combine, grid1(total), dim3(256), 0, c.stream, nxt.as<uint32_t>(), cur.as<uint32_t>(), inv_n_const(j + 1, 0),
+                         out.as<uint32_t>(), d, (uint32_t)total);
+      GS_HIP(hipStreamSynchronize(c.stream));
+      cur = std::move(out);
+    }
+    GS_HIP(hipGetLastError());
+    GS_HIP(hipStreamSynchronize(c.stream));
+    t->root = std::move(cur);
+  }
+  if (need_weights && !t->weights.p) build_weights(c, *t);
+  t->stamp = ++g_tree_clock;
+  return *t;
+}
+
 // Z(x) = prod_{i=1}^{deg} (x - i): deg + 1 coefficients, canonical standard form.
 void zpoly_dev(Ctx& c, size_t deg, uint32_t* out_std) {
-  if (deg == 0) {
-    uint32_t w[8] = {1, 0, 0, 0, 0, 0, 0, 0};
-    GS_HIP(hipMemcpyAsync(out_std, w, 32, hipMemcpyHostToDevice, c.stream));
-    GS_HIP(hipStreamSynchronize(c.stream));
-    return;
+  const uint32_t one[8] = {1, 0, 0, 0, 0, 0, 0, 0};
+  if (deg > 0) {
+    NodeTree& t = ensure_tree(c, deg, false);
+    // root = low 2^L coefficients of x^pad * Z (Montgomery); Z[k] = root[k + pad] for k < deg, Z[deg] = 1
+    GS_HIP(hipMemcpyAsync(out_std, t.root.as<uint32_t>() + t.pad * 8, deg * 32, hipMemcpyDeviceToDevice, c.stream));
+    poly_canon_dev(c, out_std, deg, 2);
   }
-  const int L = ceil_log2(deg);                              // 2^L >= deg leaves (the extra ones are the factor x)
-  const size_t total = (size_t)1 << L, pad = total - deg;
-  DevBuf cur(total * 32), nxt(total * 32), wide(2 * total * 32);
-  hipLaunchKernelGGL(k_zp_leaves, grid1(total), dim3(256), 0, c.stream, cur.as<uint32_t>(), (uint32_t)deg, (uint32_t)total);
-  for (int j = 0; j < L; ++j) {                              // blocks of d = 2^j low coefficients -> blocks of 2d
+  GS_HIP(hipMemcpyAsync(out_std + deg * 8, one, 32, hipMemcpyHostToDevice, c.stream));
+  GS_HIP(hipStreamSynchronize(c.stream));
+}
+
+// Lagrange interpolation on the nodes 1..n of `nvec` value vectors at once (values: nvec x n, standard form) ->
+// coefficients (nvec x n, standard form, < 2r).  p(x) = sum_j v_j / M'(j) * M(x) / (x - j), evaluated bottom-up on the
+// node tree:  P_node = P_left * M_right + P_right * M_left   (r1csqap.go:150-158 computes the same polynomial in O(n^3)).
+void interpolate_dev(Ctx& c, const uint32_t* values_std, size_t n, size_t nvec, uint32_t* coeffs_std) {
+  if (n == 0 || nvec == 0) return;
+  NodeTree& t = ensure_tree(c, n, true);
+  const size_t total = t.total, all = total * nvec;
+  DevBuf cur(all * 32), wide(2 * all * 32), nxt(all * 32);
+  hipLaunchKernelGGL(k_interp_leaves, grid1(all), dim3(256), 0, c.stream, values_std, t.weights.as<uint32_t>(), (uint32_t)n, (uint32_t)total,
+                     (uint32_t)nvec, cur.as<uint32_t>());
+  for (int j = 0; j < t.L; ++j) {
     const uint32_t d = 1u << j;
-    hipLaunchKernelGGL(k_expand_blocks, grid1(2 * total), dim3(256), 0, c.stream, cur.as<uint32_t>(), wide.as<uint32_t>(), d, (uint32_t)(2 * total));
-    ntt_forward(c, wide.as<uint32_t>(), L + 1, j + 1);
-    hipLaunchKernelGGL(k_pw_mul_pairs, grid1(total), dim3(256), 0, c.stream, wide.as<uint32_t>(), nxt.as<uint32_t>(), 2 * d, (uint32_t)total);
-    ntt_inverse_unscaled(c, nxt.as<uint32_t>(), L, j + 1);
-    hipLaunchKernelGGL(k_monic_combine, grid1(total), dim3(256), 0, c.stream, nxt.as<uint32_t>(), cur.as<uint32_t>(), inv_n_const(j + 1, 0),
-                       wide.as<uint32_t>(), d, (uint32_t)total);
-    GS_HIP(hipMemcpyAsync(cur.p, wide.p, total * 32, hipMemcpyDeviceToDevice, c.stream));
+    hipLaunchKernelGGL(k_expand_blocks, grid1(2 * all), dim3(256), 0, c.stream, cur.as<uint32_t>(), wide.as<uint32_t>(), d, (uint32_t)(2 * all));
+    ntt_forward_n(c, wide.as<uint32_t>(), 2 * all, j + 1);
+    hipLaunchKernelGGL(k_pw_cross, grid1(all), dim3(256), 0, c.stream, wide.as<uint32_t>(), t.mspec[j].as<uint32_t>(), nxt.as<uint32_t>(), 2 * d,
+                       (uint32_t)(total / (2 * d)), (uint32_t)all);
+    ntt_inverse_unscaled_n(c, nxt.as<uint32_t>(), all, j + 1);
+    // P_L (x^d + m_R) + P_R (x^d + m_L) = [P_L m_R + P_R m_L] + x^d (P_L + P_R)
+    hipLaunchKernelGGL(k_monic_combine, grid1(all), dim3(256), 0, c.stream, nxt.as<uint32_t>(), cur.as<uint32_t>(), inv_n_const(j + 1, 0),
+                       wide.as<uint32_t>(), d, (uint32_t)all);
+    GS_HIP(hipMemcpyAsync(cur.p, wide.p, all * 32, hipMemcpyDeviceToDevice, c.stream));
   }
   GS_HIP(hipGetLastError());
-  // cur = low 2^L coefficients of x^pad * Z (Montgomery); Z[k] = cur[k + pad] for k < deg, Z[deg] = 1
-  poly_canon_dev(c, cur.as<uint32_t>(), total, 2);
-  if (deg > 0) GS_HIP(hipMemcpyAsync(out_std, cur.as<uint32_t>() + pad * 8, deg * 32, hipMemcpyDeviceToDevice, c.stream));
-  uint32_t w[8] = {1, 0, 0, 0, 0, 0, 0, 0};
-  GS_HIP(hipMemcpyAsync(out_std + deg * 8, w, 32, hipMemcpyHostToDevice, c.stream));
+  // cur[k] = x^pad * p_k(x): coefficients pad .. pad + n - 1
+  for (size_t k = 0; k < nvec; ++k)
+    GS_HIP(hipMemcpyAsync(coeffs_std + k * n * 8, cur.as<uint32_t>() + (k * total + t.pad) * 8, n * 32, hipMemcpyDeviceToDevice, c.stream));
   GS_HIP(hipStreamSynchronize(c.stream));
+}
+
+// out[row] = sum_k val[k] * x[col[k]] over Fr; CSR with values and x in standard form; out standard (< 2r)
+void spmv_dev(Ctx& c, const uint32_t* rowptr, const uint32_t* col, const uint32_t* val_std, const uint32_t* x_mont, size_t nrows, size_t ncols,
+              uint32_t* out_std) {
+  if (nrows) hipLaunchKernelGGL(k_spmv, grid1(nrows), dim3(256), 0, c.stream, rowptr, col, val_std, x_mont, (uint32_t)nrows, (uint32_t)ncols, out_std);
+  GS_HIP(hipGetLastError());
 }
 
 void poly_addsub_dev(Ctx& c, const uint32_t* a, size_t na, const uint32_t* b, size_t nb, bool subtract, uint32_t* out) {

@@ -195,6 +195,40 @@ __global__ void __launch_bounds__(256) k_monic_combine(const uint32_t* __restric
   store_fr(out + (size_t)i * 8, v);
 }
 
+// interpolation tree step: out[p*d2 + t] = PL * mR + PR * mL on the spectra of adjacent blocks (one reduction for the
+// two-term dot product); the m spectra repeat every `mblocks` pairs (several value vectors share one node tree).
+__global__ void __launch_bounds__(256) k_pw_cross(const uint32_t* __restrict__ pspec, const uint32_t* __restrict__ mspec, uint32_t* __restrict__ out,
+                                                   uint32_t d2, uint32_t mpairs, uint32_t total) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const uint32_t p = i / d2, t = i - p * d2;
+  const uint32_t* pl = pspec + ((size_t)(2 * p) * d2 + t) * 8;
+  const uint32_t* ml = mspec + ((size_t)(2 * (p % mpairs)) * d2 + t) * 8;
+  store_fr(out + (size_t)i * 8, mul_add(load_fr(pl), load_fr(ml + (size_t)d2 * 8), load_fr(pl + (size_t)d2 * 8), load_fr(ml)));
+}
+// leaves of the interpolation tree: out[k*total + j] = values[k*n + j] * weights[j] for j < n, 0 for the padding nodes
+__global__ void __launch_bounds__(256) k_interp_leaves(const uint32_t* __restrict__ values, const uint32_t* __restrict__ weights, uint32_t n,
+                                                        uint32_t total, uint32_t nvec, uint32_t* __restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total * nvec) return;
+  const uint32_t k = i / total, j = i - k * total;
+  if (j >= n) { store_fr(out + (size_t)i * 8, fe_zero<ModR, 2>()); return; }
+  store_fr(out + (size_t)i * 8, mul(load_fr(values + ((size_t)k * n + j) * 8), load_fr(weights + (size_t)j * 8)));
+}
+// sparse matrix (CSR, values in standard form) times a Montgomery-form vector: out[row] = sum_k val[k] * x[col[k]] (standard)
+__global__ void __launch_bounds__(256) k_spmv(const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ col, const uint32_t* __restrict__ val,
+                                               const uint32_t* __restrict__ x_mont, uint32_t nrows, uint32_t ncols, uint32_t* __restrict__ out) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= nrows) return;
+  Fr2 acc = fe_zero<ModR, 2>();
+  for (uint32_t k = rowptr[r]; k < rowptr[r + 1]; ++k) {
+    const uint32_t cidx = col[k];
+    if (cidx >= ncols) continue;                       // validated on the host; never trust an index on the device
+    acc = reduce2(add(acc, mul(load_fr(val + (size_t)k * 8), load_fr(x_mont + (size_t)cidx * 8))));
+  }
+  store_fr(out + (size_t)r * 8, acc);
+}
+
 // ---- evaluation: sum_i v_i x^i  (r1csqap.go:118-126) ------------------------------------------------
 constexpr int kEvalChunk = 64;
 // partial[t] = x^(t*chunk) * sum_{i<chunk} v[t*chunk+i] x^i      (v standard form, x Montgomery -> standard)

@@ -432,21 +432,85 @@ int gs_pinocchio_prove(gs_handle hpk, const uint64_t* w, size_t nw, const uint64
   });
 }
 
-// ---- not yet device-accelerated in this round: declared, fail loudly -------------------------------------------
-int gs_lagrange_interpolation(const uint64_t*, size_t, uint64_t*) { return fail(GS_ERR_ARG, "gs_lagrange_interpolation: not implemented yet"); }
+// PolynomialField.LagrangeInterpolation (r1csqap.go:150-158): n values at the nodes 1..n -> n coefficients.
+int gs_lagrange_interpolation(const uint64_t* values, size_t n, uint64_t* coeffs) {
+  return guarded([&](Ctx& c) -> int {
+    if (n == 0) return GS_OK;
+    if (!values || !coeffs) return fail(GS_ERR_ARG, "gs_lagrange_interpolation: null argument");
+    if (n >= (1ull << 26)) return fail(GS_ERR_ARG, "gs_lagrange_interpolation: too many nodes");
+    const uint32_t* dv = upload_tmp(c, g_up_a, values, n);
+    g_up_o.ensure(n * 32);
+    interpolate_dev(c, dv, n, 1, g_up_o.as<uint32_t>());
+    poly_canon_dev(c, g_up_o.as<uint32_t>(), n, 0);
+    download(c, coeffs, g_up_o.p, n);
+    return GS_OK;
+  });
+}
+
 int gs_zpoly(size_t deg, uint64_t* out) {
   return guarded([&](Ctx& c) -> int {
     if (!out) return fail(GS_ERR_ARG, "gs_zpoly: null output");
-    if (deg >= (1ull << 27)) return fail(GS_ERR_ARG, "gs_zpoly: degree too large");
+    if (deg >= (1ull << 26)) return fail(GS_ERR_ARG, "gs_zpoly: degree too large");
     g_up_o.ensure((deg + 1) * 32);
     zpoly_dev(c, deg, g_up_o.as<uint32_t>());
     download(c, out, g_up_o.p, deg + 1);
     return GS_OK;
   });
 }
-int gs_r1cs_to_px(size_t, size_t, const uint32_t*, const uint32_t*, const uint64_t*, const uint32_t*, const uint32_t*, const uint64_t*,
-                  const uint32_t*, const uint32_t*, const uint64_t*, const uint64_t*, uint64_t*, uint64_t*, uint64_t*, uint64_t*) {
-  return fail(GS_ERR_ARG, "gs_r1cs_to_px: not implemented yet");
+
+// Sparse R1CS + witness -> ax, bx, cx, px = ax * bx - cx: the scalable replacement of the dense
+// R1CSToQAP + CombinePolynomials pair (r1csqap.go:161-210).  CombinePolynomials' ax = sum_i w_i alpha_i(x) is the
+// interpolant of the values (A w)_j at the nodes j = 1..n, so the m x n coefficient matrices are never formed.
+int gs_r1cs_to_px(size_t n, size_t m,
+                  const uint32_t* a_rowptr, const uint32_t* a_col, const uint64_t* a_val,
+                  const uint32_t* b_rowptr, const uint32_t* b_col, const uint64_t* b_val,
+                  const uint32_t* c_rowptr, const uint32_t* c_col, const uint64_t* c_val,
+                  const uint64_t* w, uint64_t* ax, uint64_t* bx, uint64_t* cx, uint64_t* px) {
+  return guarded([&](Ctx& c) -> int {
+    if (n == 0 || m == 0) return fail(GS_ERR_ARG, "gs_r1cs_to_px: empty system");
+    if (!a_rowptr || !b_rowptr || !c_rowptr || !w || !px) return fail(GS_ERR_ARG, "gs_r1cs_to_px: null argument");
+    if (n >= (1ull << 26) || m >= (1ull << 31)) return fail(GS_ERR_ARG, "gs_r1cs_to_px: system too large");
+    const uint32_t* rp[3] = {a_rowptr, b_rowptr, c_rowptr};
+    const uint32_t* cl[3] = {a_col, b_col, c_col};
+    const uint64_t* vl[3] = {a_val, b_val, c_val};
+    for (int k = 0; k < 3; ++k) {                      // validate the CSR structure on the host
+      if (rp[k][0] != 0) return fail(GS_ERR_ARG, "gs_r1cs_to_px: row_ptr[0] must be 0");
+      for (size_t r = 0; r < n; ++r) if (rp[k][r + 1] < rp[k][r]) return fail(GS_ERR_ARG, "gs_r1cs_to_px: row_ptr not monotone");
+      const size_t nnz = rp[k][n];
+      if (nnz && (!cl[k] || !vl[k])) return fail(GS_ERR_ARG, "gs_r1cs_to_px: null column/value array");
+      for (size_t e = 0; e < nnz; ++e) if (cl[k][e] >= m) return fail(GS_ERR_ARG, "gs_r1cs_to_px: column index %u >= m = %zu", cl[k][e], m);
+    }
+    DevBuf wm(m * 32), vals(3 * n * 32), coef(3 * n * 32);
+    GS_HIP(hipMemcpyAsync(wm.p, w, m * 32, hipMemcpyHostToDevice, c.stream));
+    poly_canon_dev(c, wm.as<uint32_t>(), m, 1);                                 // w -> Montgomery
+    for (int k = 0; k < 3; ++k) {
+      const size_t nnz = rp[k][n];
+      DevBuf drp((n + 1) * 4), dcl(std::max<size_t>(nnz, 1) * 4), dvl(std::max<size_t>(nnz, 1) * 32);
+      GS_HIP(hipMemcpyAsync(drp.p, rp[k], (n + 1) * 4, hipMemcpyHostToDevice, c.stream));
+      if (nnz) {
+        GS_HIP(hipMemcpyAsync(dcl.p, cl[k], nnz * 4, hipMemcpyHostToDevice, c.stream));
+        GS_HIP(hipMemcpyAsync(dvl.p, vl[k], nnz * 32, hipMemcpyHostToDevice, c.stream));
+      }
+      spmv_dev(c, drp.as<uint32_t>(), dcl.as<uint32_t>(), dvl.as<uint32_t>(), wm.as<uint32_t>(), n, m, vals.as<uint32_t>() + k * n * 8);
+      GS_HIP(hipStreamSynchronize(c.stream));
+    }
+    interpolate_dev(c, vals.as<uint32_t>(), n, 3, coef.as<uint32_t>());
+    uint32_t* A = coef.as<uint32_t>();
+    uint32_t* B = A + n * 8;
+    uint32_t* C = B + n * 8;
+    const size_t npx = 2 * n - 1;
+    DevBuf prod(npx * 32), pxd(npx * 32);
+    poly_mul_dev(c, A, n, Form::Std, B, n, Form::Std, prod.as<uint32_t>());
+    poly_addsub_dev(c, prod.as<uint32_t>(), npx, C, n, true, pxd.as<uint32_t>());
+    poly_canon_dev(c, pxd.as<uint32_t>(), npx, 0);
+    poly_canon_dev(c, A, 3 * n, 0);
+    if (ax) GS_HIP(hipMemcpyAsync(ax, A, n * 32, hipMemcpyDeviceToHost, c.stream));
+    if (bx) GS_HIP(hipMemcpyAsync(bx, B, n * 32, hipMemcpyDeviceToHost, c.stream));
+    if (cx) GS_HIP(hipMemcpyAsync(cx, C, n * 32, hipMemcpyDeviceToHost, c.stream));
+    GS_HIP(hipMemcpyAsync(px, pxd.p, npx * 32, hipMemcpyDeviceToHost, c.stream));
+    GS_HIP(hipStreamSynchronize(c.stream));
+    return GS_OK;
+  });
 }
 
 }  // extern "C"

@@ -61,6 +61,62 @@ class PolynomialField:
     def DivisorPolynomial(self, px, z):      # r1csqap.go:213-216
         return self.Div(px, z)[0]
 
+    def R1CSToQAP(self, a, b, c):            # r1csqap.go:161-188 (dense n x m matrices, small instances)
+        """-> (alphas, betas, gammas, z): per variable the interpolant of its column over the nodes 1..n."""
+        def cols(mat):
+            n, m = len(mat), len(mat[0])
+            return [self.LagrangeInterpolation([mat[j][i] for j in range(n)]) for i in range(m)]
+        alphas, betas, gammas = cols(a), cols(b), cols(c)
+        return alphas, betas, gammas, ZPoly(len(alphas) - 2)      # r1csqap.go:177-186: degree len(alphas) - 2
+
+    def CombinePolynomials(self, r, ap, bp, cp):   # r1csqap.go:191-210
+        def comb(polys):
+            acc = [0] * len(polys[0])
+            for ri, poly in zip(r, polys):
+                for k, coef in enumerate(poly):
+                    acc[k] = (acc[k] + ri * coef) % R
+            return acc
+        ax, bx, cx = comb(ap), comb(bp), comb(cp)
+        px = self.Sub(self.Mul(ax, bx), cx)
+        return ax, bx, cx, px
+
+
+def csr_from_rows(rows):
+    """rows: list (one per constraint) of {variable index: coefficient} -> (row_ptr uint32, col uint32, val [nnz,4] uint64)."""
+    rowptr = np.zeros(len(rows) + 1, dtype=np.uint32)
+    cols, vals = [], []
+    for j, row in enumerate(rows):
+        for k in sorted(row):
+            cols.append(k)
+            vals.append(row[k] % R)
+        rowptr[j + 1] = len(cols)
+    col = np.asarray(cols, dtype=np.uint32) if cols else np.zeros(0, dtype=np.uint32)
+    val = capi.ints_to_u64(vals) if vals else np.zeros((0, 4), dtype=np.uint64)
+    return rowptr, col, val
+
+
+def ComputePx(a_csr, b_csr, c_csr, w_u64, nvars):
+    """Sparse R1CS (three CSR triples over n constraints x nvars variables) + witness ([nvars,4] uint64) ->
+    (ax, bx, cx, px) as uint64 limb arrays: the scalable form of R1CSToQAP + CombinePolynomials (gs_r1cs_to_px)."""
+    capi.init()
+    n = a_csr[0].shape[0] - 1
+    w = np.ascontiguousarray(w_u64, dtype=np.uint64).reshape(-1, 4)
+    assert w.shape[0] == nvars
+    out = [np.zeros((n, 4), dtype=np.uint64) for _ in range(3)] + [np.zeros((2 * n - 1, 4), dtype=np.uint64)]
+    args = []
+    for rp, cl, vl in (a_csr, b_csr, c_csr):
+        rp = np.ascontiguousarray(rp, dtype=np.uint32)
+        cl = np.ascontiguousarray(cl, dtype=np.uint32)
+        vl = np.ascontiguousarray(vl, dtype=np.uint64).reshape(-1, 4)
+        if cl.size == 0:
+            cl, vl = np.zeros(1, dtype=np.uint32), np.zeros((1, 4), dtype=np.uint64)
+        args += [rp, cl, vl]
+    capi.check(capi.load_library().gs_r1cs_to_px(
+        n, nvars, capi.ptr32(args[0]), capi.ptr32(args[1]), capi.ptr64(args[2]), capi.ptr32(args[3]), capi.ptr32(args[4]), capi.ptr64(args[5]),
+        capi.ptr32(args[6]), capi.ptr32(args[7]), capi.ptr64(args[8]), capi.ptr64(w),
+        capi.ptr64(out[0]), capi.ptr64(out[1]), capi.ptr64(out[2]), capi.ptr64(out[3])))
+    return tuple(out)
+
 
 def ZPoly(deg):
     """Z(x) = prod_{i=1}^{deg} (x - i)  (r1csqap.go:177-186 / groth16.go:122-131)."""

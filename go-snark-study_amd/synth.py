@@ -87,3 +87,63 @@ class RandomInstance:
 
 def random_instance(n, seed):
     return RandomInstance(n, seed)
+
+
+def sqchain_r1cs(n, x):
+    """SURVEY 8d's synthetic circuit: variables [one, s_1 = x (public), s_2 .. s_n] (m = n + 1, NPublic = 1);
+    constraint k = 1..n-1:  s_k * s_k = s_{k+1} - k * one;  constraint n:  one * one = one.
+    Returns (a_csr, b_csr, c_csr, w [m,4] uint64); nnz: A = n, B = n, C = 2n - 1 (k = 0 entries are dropped)."""
+    from . import r1csqap
+    m = n + 1
+    wit = [1, x % R]
+    for k in range(1, n):
+        wit.append((wit[k] * wit[k] + k) % R)
+    idx = np.arange(n, dtype=np.uint32)
+    one = np.zeros((n, 4), dtype=np.uint64)
+    one[:, 0] = 1
+    rowptr = np.arange(n + 1, dtype=np.uint32)
+    a_col = idx + 1
+    a_col[n - 1] = 0                                  # last constraint: one * one = one
+    a = (rowptr, a_col.copy(), one)
+    b = (rowptr, a_col.copy(), one.copy())
+    # C rows: k = 1..n-1 -> {s_{k+1}: 1, one: -k}; row n -> {one: 1}
+    c_rowptr = np.zeros(n + 1, dtype=np.uint32)
+    c_rowptr[1:n] = 2 * np.arange(1, n, dtype=np.uint32)
+    c_rowptr[n] = 2 * (n - 1) + 1
+    c_col = np.zeros(2 * (n - 1) + 1, dtype=np.uint32)
+    c_val = np.zeros((2 * (n - 1) + 1, 4), dtype=np.uint64)
+    ks = np.arange(1, n, dtype=np.uint64)
+    c_col[0:2 * (n - 1):2] = 0                        # the `one` entry first (columns sorted)
+    c_col[1:2 * (n - 1):2] = np.arange(2, n + 1, dtype=np.uint32)
+    negk = capi.ints_to_u64([(R - int(k)) % R for k in ks]) if n > 1 else np.zeros((0, 4), dtype=np.uint64)
+    c_val[0:2 * (n - 1):2] = negk
+    c_val[1:2 * (n - 1):2, 0] = 1
+    c_col[2 * (n - 1)] = 0
+    c_val[2 * (n - 1), 0] = 1
+    c = (c_rowptr, c_col, c_val)
+    return a, b, c, capi.ints_to_u64(wit)
+
+
+class SqchainInstance(RandomInstance):
+    """RandomInstance whose w / px come from a SATISFIED R1CS (the sqchain circuit): px is produced on the device from
+    the sparse system (gs_r1cs_to_px) and is exactly divisible by Z, as in a real proof.  The key points remain
+    k_i * G for seeded k_i (a structured trusted setup is SURVEY 8f item 1)."""
+
+    def __init__(self, n, seed):
+        from . import r1csqap
+        super().__init__(n, seed)
+        x = field_elems(1, seed + 10)[0]
+        a, b, c, w = sqchain_r1cs(n, x)
+        self.r1cs = (a, b, c)
+        self.w_host = w
+        self.ax_host, self.bx_host, self.cx_host, self.px_host = r1csqap.ComputePx(a, b, c, w, self.m)
+        self.w = capi.scalars_upload(self.w_host)
+        self.px = capi.scalars_upload(self.px_host)
+
+    def describe(self):
+        return ("sqchain(n) R1CS (s_k^2 = s_{k+1} - k), satisfying witness, px = A(x)B(x) - C(x) from the sparse system on the "
+                "device (exactly divisible by Z); key points k_i*G for seeded uniform k_i; seed 0x%X" % self.seed)
+
+
+def sqchain_instance(n, seed):
+    return SqchainInstance(n, seed)

@@ -224,3 +224,73 @@ def test_groth16_2p16_linearity_and_c_oracle_slices():
     pts = capi.g1_download(inst.g1["at"])[:k]
     want = C.g1_affine(C.g1_msm_naive(pts, w1[:k], threads=8))
     assert capi.msm(inst.g1["at"], w1[:k]) == want
+
+
+# ---- interpolation / sparse R1CS -> P(x)  (r1csqap.go:129-210) ----------------------------------------------
+def test_lagrange_reference_vectors():
+    """r1csqap_test.go:107-112: interpolation through the nodes 1..n reproduces the values; and the reference's own
+    (n <= 21, before its Go-int overflow) result from the C oracle."""
+    PF = r1csqap.PolynomialField()
+    for v in ([1], [5, 7], [0, 0, 0, 5], [3, 1, 4, 1, 5, 9, 2, 6]):
+        coef = PF.LagrangeInterpolation(v)
+        assert coef == C.lagrange(v)
+        for j, val in enumerate(v):
+            assert PF.Eval(coef, j + 1) == val % O.R
+
+
+@pytest.mark.parametrize("n", [2, 3, 17, 21, 33, 100, 257])
+def test_lagrange_vs_c_oracle(n):
+    rng = random.Random(700 + n)
+    v = [rng.randrange(O.R) for _ in range(n)]
+    assert r1csqap.PolynomialField().LagrangeInterpolation(v) == C.lagrange(v)
+
+
+def test_r1cs_to_qap_x3_circuit_matches_reference_flow():
+    """circuit_test.go / r1csqap_test.go:114-174 flow on the x^3 + x + 5 R1CS: R1CSToQAP + CombinePolynomials (dense,
+    reference semantics, python oracle) == device mirror == the sparse ComputePx path; px / Z is exact."""
+    a = [[0, 0, 1, 0, 0, 0, 0, 0], [0, 0, 0, 1, 0, 0, 0, 0], [0, 0, 1, 0, 1, 0, 0, 0], [5, 0, 0, 0, 0, 1, 0, 0], [0, 0, 0, 0, 0, 0, 1, 0], [0, 1, 0, 0, 0, 0, 0, 0], [1, 0, 0, 0, 0, 0, 0, 0]]
+    b = [[0, 0, 1, 0, 0, 0, 0, 0], [0, 0, 1, 0, 0, 0, 0, 0], [1, 0, 0, 0, 0, 0, 0, 0], [1, 0, 0, 0, 0, 0, 0, 0], [1, 0, 0, 0, 0, 0, 0, 0], [1, 0, 0, 0, 0, 0, 0, 0], [1, 0, 0, 0, 0, 0, 0, 0]]
+    c = [[0, 0, 0, 1, 0, 0, 0, 0], [0, 0, 0, 0, 1, 0, 0, 0], [0, 0, 0, 0, 0, 1, 0, 0], [0, 0, 0, 0, 0, 0, 1, 0], [0, 1, 0, 0, 0, 0, 0, 0], [0, 0, 0, 0, 0, 0, 1, 0], [1, 0, 0, 0, 0, 0, 0, 0]]
+    w = list(O.X3_WITNESS)
+    # the witness must satisfy the system for the division to be exact
+    for ra, rb, rc in zip(a, b, c):
+        dot = lambda row: sum(x * y for x, y in zip(row, w)) % O.R   # noqa: E731
+        assert dot(ra) * dot(rb) % O.R == dot(rc)
+    PF = r1csqap.PolynomialField()
+    al, be, ga, z = PF.R1CSToQAP(a, b, c)
+    oal, obe, oga, oz = O.PF.R1CSToQAP(a, b, c)
+    assert (al, be, ga, z) == (oal, obe, oga, oz)
+    ax, bx, cx, px = PF.CombinePolynomials(w, al, be, ga)
+    assert (ax, bx, cx, px) == tuple(O.PF.CombinePolynomials(w, oal, obe, oga))
+    rows = lambda mat: [{k: v for k, v in enumerate(row) if v} for row in mat]   # noqa: E731
+    sa, sb, sc, spx = r1csqap.ComputePx(r1csqap.csr_from_rows(rows(a)), r1csqap.csr_from_rows(rows(b)), r1csqap.csr_from_rows(rows(c)),
+                                        capi.ints_to_u64(w), len(w))
+    assert U.u64_rows_to_ints(sa) == ax and U.u64_rows_to_ints(sb) == bx and U.u64_rows_to_ints(sc) == cx
+    assert U.u64_rows_to_ints(spx) == px
+    hx, rem = PF.Div(px, z)
+    assert all(v == 0 for v in rem) and len(hx) == len(px) - len(z) + 1
+
+
+@pytest.mark.parametrize("logn", [5, 12, 16])
+def test_sqchain_px_is_exactly_divisible(logn):
+    """The synthetic sqchain(n) circuit: px from the sparse system vanishes on all n nodes, i.e. px = hx * Z'
+    with Z' = prod_{i=1}^{n}(x - i), and the interpolants reproduce (A w)_j at sampled nodes."""
+    from gosnark_amd import synth
+    n = 1 << logn
+    a, b, c, w = synth.sqchain_r1cs(n, 123456789)
+    ax, bx, cx, px = r1csqap.ComputePx(a, b, c, w, n + 1)
+    wi = U.u64_rows_to_ints(w)
+    PF = r1csqap.PolynomialField()
+    axi = U.u64_rows_to_ints(ax)
+    for j in (1, 2, n // 2, n - 1, n):
+        want = wi[j] if j < n else 1                       # (A w)_j = s_j, last row: one
+        assert PF.Eval(axi, j) == want
+    zfull = capi.zpoly(n)                                  # all n nodes
+    lib = capi.load_library()
+    q = np.zeros((n - 1, 4), dtype=np.uint64)
+    rem = np.zeros((n, 4), dtype=np.uint64)
+    capi.check(lib.gs_poly_div(capi.ptr64(px), 2 * n - 1, capi.ptr64(zfull), n + 1, capi.ptr64(q), capi.ptr64(rem)))
+    assert not rem.any()
+    if logn <= 12:                                         # the C oracle's O(n^2) long division agrees on the quotient
+        cq, cr = C.poly_div_u64(px, zfull)
+        assert np.array_equal(cq, q) and not cr.any()
