@@ -71,6 +71,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log2n", type=int, default=20)
     ap.add_argument("--workload", default="prove", choices=["prove", "msm_g1", "msm_sharded"])
+    ap.add_argument("--instance", default="sqchain", choices=["sqchain", "random"],
+                    help="sqchain: satisfied synthetic R1CS, px built on the device from the sparse system (SURVEY 8d); "
+                         "random: uniform w / px")
     ap.add_argument("--cpu-log2n", type=int, default=13, help="constraints of the CPU-baseline sample (0 = skip)")
     args = ap.parse_args()
 
@@ -92,7 +95,7 @@ def main():
     n = 1 << args.log2n
     seed = 0x5EED0002 + rank
     if args.workload == "prove":
-        inst = synth.random_instance(n, seed)
+        inst = synth.sqchain_instance(n, seed) if args.instance == "sqchain" else synth.random_instance(n, seed)
         pk = inst.device_pk()
         r_, s_ = synth.field_elems(2, seed ^ 0xABCDEF, R)
 

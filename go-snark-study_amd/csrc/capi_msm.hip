@@ -1,5 +1,6 @@
 // extern "C" surface of libgosnark_hip.so (declared in include/gosnark_hip.h).
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 #include "msm.h"
@@ -181,6 +182,8 @@ int gs_init(const int* devices, int ndev) {
       for (auto& p : c.pinned) GS_HIP(hipHostMalloc(&p, Ctx::kPinnedBytes, hipHostMallocDefault));
       c.stream = c.main_stream;
       c.device = devices[0];
+      static bool registered = false;
+      if (!registered) { atexit([] { process_exiting() = true; }); registered = true; }
       c.ready = true;
     }
     return GS_OK;

@@ -41,6 +41,13 @@ struct HipError {
     if (_e != hipSuccess) throw ::gs::HipError{_e, #x, __LINE__}; \
   } while (0)
 
+// set by an atexit handler registered in gs_init: static DevBuf destructors that run during process teardown must
+// not call into a HIP runtime that may already be gone (seen as a crash in __cxa_finalize under rocprofv3)
+inline bool& process_exiting() {
+  static bool v = false;
+  return v;
+}
+
 // ---- device buffers -------------------------------------------------------------------------------
 struct DevBuf {
   void* p = nullptr;
@@ -62,7 +69,7 @@ struct DevBuf {
     bytes = n;
   }
   void ensure(size_t n) { if (n > bytes) alloc(n + n / 8); }      // grow-only workspace
-  void release() { if (p) { (void)hipFree(p); p = nullptr; bytes = 0; } }
+  void release() { if (p) { if (!process_exiting()) (void)hipFree(p); p = nullptr; bytes = 0; } }
   template <class U> U* as() const { return reinterpret_cast<U*>(p); }
 };
 
