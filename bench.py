@@ -141,6 +141,21 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    host_ms = None
+    if rank == 0 and world == 1 and args.workload == "prove":
+        # the boundary also accepts HOST buffers (gs_groth16_prove): w (32 B x m) and px (32 B x (2n-1)) then cross PCIe
+        # inside the call.  Reported beside the resident-input figure, never as `value`.
+        lib = capi.load_library()
+        import ctypes
+        outp = np.zeros(32, dtype=np.uint64)
+        infp = (ctypes.c_int * 3)()
+        rs = capi.ints_to_u64([r_, s_])
+        th = time.perf_counter()
+        for _ in range(3):
+            capi.check(lib.gs_groth16_prove(capi.Handle(pk.handle.h), capi.ptr64(inst.w_host), inst.w_host.shape[0], capi.ptr64(inst.px_host),
+                                            inst.px_host.shape[0], capi.ptr64(rs[0]), capi.ptr64(rs[1]), capi.ptr64(outp), infp))
+        host_ms = (time.perf_counter() - th) / 3 * 1e3
+
     if rank == 0:
         value = units_per_step * world * args.steps / elapsed
         launches = max(tm_acc["acc_g1_launches"], 1)
@@ -164,6 +179,16 @@ def main():
                          "note": "integer-issue bound (254-bit modular arithmetic on 32-bit VALU), see DESIGN.md"},
             "device_ms_per_step": {k: tm_acc[k] / args.steps for k in ("total_ms", "poly_ms", "plan_ms", "accumulate_ms", "reduce_ms", "acc_g1_ms", "acc_g2_ms")},
         }
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                pmc = json.load(f).get(workload)
+            if pmc:        # measured offline with rocprofv3 --pmc (bench.py cannot attach counters to itself)
+                out["roofline"]["traffic"] = pmc["fetch_bytes_per_launch_raw"] + pmc["write_bytes_per_launch_raw"]
+                out["roofline"]["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, raw counters)"
+        except OSError:
+            pass
+        if host_ms is not None:
+            out["host_buffers_ms_per_step"] = host_ms
         if world == 1 and args.cpu_log2n > 0:
             out["cpu_baseline"] = cpu_baseline(args.cpu_log2n, seed + 1000)
             if args.workload != "prove":

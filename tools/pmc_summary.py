@@ -1,0 +1,17 @@
+"""Per-kernel average of one rocprofv3 PMC counter (counter_collection.csv) -- dev tool."""
+import collections
+import csv
+import sys
+
+rows = list(csv.DictReader(open(sys.argv[1])))
+want = sys.argv[2]
+acc = collections.defaultdict(lambda: [0, 0.0])
+for r in rows:
+    if r.get("Counter_Name") != want:
+        continue
+    k = r["Kernel_Name"].split("(")[0]
+    acc[k][0] += 1
+    acc[k][1] += float(r["Counter_Value"])
+print("kernel, dispatches, avg %s per dispatch (counter units: KB)" % want)
+for k, (n, v) in sorted(acc.items(), key=lambda kv: -kv[1][1])[:14]:
+    print("%-60s %5d %14.1f" % (k[:60], n, v / n))
