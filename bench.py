@@ -71,9 +71,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log2n", type=int, default=20)
     ap.add_argument("--workload", default="prove", choices=["prove", "msm_g1", "msm_sharded"])
-    ap.add_argument("--instance", default="sqchain", choices=["sqchain", "random"],
-                    help="sqchain: satisfied synthetic R1CS, px built on the device from the sparse system (SURVEY 8d); "
-                         "random: uniform w / px")
+    ap.add_argument("--instance", default="setup", choices=["setup", "sqchain", "random"],
+                    help="setup: sqchain R1CS + structured trusted setup on the device + px from the sparse system (a complete, "
+                         "checkable instance, SURVEY 8d); sqchain: same R1CS with key points k_i*G; random: uniform w / px")
+    ap.add_argument("--no-check", action="store_true", help="skip the closed-form proof check of the `setup` instance")
     ap.add_argument("--cpu-log2n", type=int, default=13, help="constraints of the CPU-baseline sample (0 = skip)")
     args = ap.parse_args()
 
@@ -95,7 +96,8 @@ def main():
     n = 1 << args.log2n
     seed = 0x5EED0002 + rank
     if args.workload == "prove":
-        inst = synth.sqchain_instance(n, seed) if args.instance == "sqchain" else synth.random_instance(n, seed)
+        inst = (synth.sqchain_setup_instance(n, seed) if args.instance == "setup" else
+                synth.sqchain_instance(n, seed) if args.instance == "sqchain" else synth.random_instance(n, seed))
         pk = inst.device_pk()
         r_, s_ = synth.field_elems(2, seed ^ 0xABCDEF, R)
 
@@ -141,6 +143,18 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    proof_check = None
+    if rank == 0 and args.workload == "prove" and args.instance == "setup" and not args.no_check:
+        # outside the timed region: the toxic values of the synthetic setup are known, so the proof is known in closed form
+        from oracle import c_oracle as C, ref_py as O          # checker only
+        pr = step()
+        ea, eb, ec = inst.expected_proof_scalars(r_, s_)
+        ok = ((pr.PiA[0], pr.PiA[1]) == C.g1_affine(C.g1_mul_scalar(O.G1_GEN, ea)) and
+              (pr.PiB[0], pr.PiB[1]) == C.g2_affine(C.g2_mul_scalar(O.G2_GEN, eb)) and
+              (pr.PiC[0], pr.PiC[1]) == C.g1_affine(C.g1_mul_scalar(O.G1_GEN, ec)))
+        if not ok:
+            raise SystemExit("bench.py: the proof of the benchmarked instance does not match its closed form")
+        proof_check = "PiA, PiB, PiC equal a*G1, b*G2, c*G1 for the closed-form (a, b, c) derived from the setup's toxic values"
     host_ms = None
     if rank == 0 and world == 1 and args.workload == "prove":
         # the boundary also accepts HOST buffers (gs_groth16_prove): w (32 B x m) and px (32 B x (2n-1)) then cross PCIe
@@ -189,6 +203,8 @@ def main():
             pass
         if host_ms is not None:
             out["host_buffers_ms_per_step"] = host_ms
+        if proof_check:
+            out["proof_check"] = proof_check
         if world == 1 and args.cpu_log2n > 0:
             out["cpu_baseline"] = cpu_baseline(args.cpu_log2n, seed + 1000)
             if args.workload != "prove":

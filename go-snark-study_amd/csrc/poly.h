@@ -58,5 +58,17 @@ void poly_eval_dev(Ctx& c, const uint32_t* v_std, size_t n, const uint64_t x[4],
 
 // host-side Fr helpers (same arithmetic as the kernels)
 Fe<ModR, 2> fr_from_words_mont(const uint64_t w[4]);
+void fr_words_from_mont(const Fe<ModR, 2>& a, uint64_t out[4]);
+void fr_mul_words(const uint64_t a[4], const uint64_t b[4], uint64_t out[4]);
+void fr_inv_words(const uint64_t a[4], uint64_t out[4]);
+bool fr_is_zero_words(const uint64_t a[4]);
+void fr_falling_product_words(const uint64_t x[4], size_t count, uint64_t out[4]);     // prod_{k=1}^{count} (x - k)
+
+// trusted-setup building blocks (setup.hip)
+const uint32_t* interpolation_weights_dev(Ctx& c, size_t n);                           // 1 / M'(j), nodes 1..n, Montgomery
+void lagrange_at_dev(Ctx& c, size_t n, const uint64_t tau[4], const uint64_t mtau[4], uint32_t* out_mont);   // L_j(tau), j = 1..n
+void setup_scalars_dev(Ctx& c, const uint32_t* at, const uint32_t* bt, const uint32_t* ct, size_t m, size_t npublic, const uint64_t kalpha[4],
+                       const uint64_t kbeta[4], const uint64_t inv_delta[4], const uint64_t inv_gamma[4], uint32_t* cd, uint32_t* ic);
+void scaled_powers_dev(Ctx& c, const uint64_t base[4], const uint64_t scale_std[4], size_t count, uint32_t* out_std);
 
 }  // namespace gs

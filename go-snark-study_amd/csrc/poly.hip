@@ -323,6 +323,57 @@ void interpolate_dev(Ctx& c, const uint32_t* values_std, size_t n, size_t nvec, 
   GS_HIP(hipStreamSynchronize(c.stream));
 }
 
+const uint32_t* interpolation_weights_dev(Ctx& c, size_t n) { return ensure_tree(c, n, true).weights.as<uint32_t>(); }
+
+static FrConst fr_const_from_words(const uint64_t w[4]) { return to_const(fr_from_words_mont(w)); }
+
+void lagrange_at_dev(Ctx& c, size_t n, const uint64_t tau[4], const uint64_t mtau[4], uint32_t* out_mont) {
+  const uint32_t* wts = interpolation_weights_dev(c, n);
+  if (n) hipLaunchKernelGGL(k_lagrange_at, grid1(n), dim3(256), 0, c.stream, wts, (uint32_t)n, fr_const_from_words(tau), fr_const_from_words(mtau), out_mont);
+  GS_HIP(hipGetLastError());
+}
+
+void setup_scalars_dev(Ctx& c, const uint32_t* at, const uint32_t* bt, const uint32_t* ct, size_t m, size_t npublic, const uint64_t kalpha[4],
+                       const uint64_t kbeta[4], const uint64_t inv_delta[4], const uint64_t inv_gamma[4], uint32_t* cd, uint32_t* ic) {
+  const uint64_t one[4] = {1, 0, 0, 0};
+  if (m) hipLaunchKernelGGL(k_setup_scalars, grid1(m), dim3(256), 0, c.stream, at, bt, ct, (uint32_t)m, (uint32_t)npublic, fr_const_from_words(kalpha),
+                            fr_const_from_words(kbeta), fr_const_from_words(inv_delta), fr_const_from_words(inv_gamma), fr_const_from_words(one), cd, ic);
+  GS_HIP(hipGetLastError());
+}
+
+void scaled_powers_dev(Ctx& c, const uint64_t base[4], const uint64_t scale_std[4], size_t count, uint32_t* out_std) {
+  // scale is passed in STANDARD limbs (not converted): acc starts as the raw value, Montgomery products by base keep it standard
+  FrConst sc;
+  uint32_t u[8];
+  for (int i = 0; i < 4; ++i) { u[2 * i] = (uint32_t)scale_std[i]; u[2 * i + 1] = (uint32_t)(scale_std[i] >> 32); }
+  const Fe<ModR, 6> raw = unpack32<ModR>(u);
+  for (int i = 0; i < NL; ++i) sc.l[i] = raw.l[i];
+  if (count) hipLaunchKernelGGL(k_scaled_powers, grid1(count), dim3(256), 0, c.stream, out_std, (uint32_t)count, fr_const_from_words(base), sc);
+  GS_HIP(hipGetLastError());
+}
+
+// ---- host-side Fr arithmetic on ABI words (setup constants, toxic-value bookkeeping) ---------------------------------
+void fr_words_from_mont(const Fe<ModR, 2>& a, uint64_t out[4]) {
+  uint32_t w[8];
+  pack32<ModR>(from_mont(a), w);
+  for (int i = 0; i < 4; ++i) out[i] = (uint64_t)w[2 * i] | ((uint64_t)w[2 * i + 1] << 32);
+}
+void fr_mul_words(const uint64_t a[4], const uint64_t b[4], uint64_t out[4]) { fr_words_from_mont(mul(fr_from_words_mont(a), fr_from_words_mont(b)), out); }
+void fr_inv_words(const uint64_t a[4], uint64_t out[4]) { fr_words_from_mont(inv(fr_from_words_mont(a)), out); }
+bool fr_is_zero_words(const uint64_t a[4]) { return is_zero(fr_from_words_mont(a)); }
+// prod_{k=1}^{count} (x - k)
+void fr_falling_product_words(const uint64_t x[4], size_t count, uint64_t out[4]) {
+  const Fe<ModR, 2> xm = fr_from_words_mont(x);
+  Fe<ModR, 2> acc = relax<2>(fe_one<ModR>());
+  Fe<ModR, 2> k = fe_zero<ModR, 2>();
+  const Fe<ModR, 1> one = fe_one<ModR>();
+  for (size_t i = 1; i <= count; ++i) {
+    k = reduce2(add(k, one));
+    acc = mul(acc, sub(xm, k));
+  }
+  fr_words_from_mont(acc, out);
+}
+
 // out[row] = sum_k val[k] * x[col[k]] over Fr; CSR with values and x in standard form; out standard (< 2r)
 void spmv_dev(Ctx& c, const uint32_t* rowptr, const uint32_t* col, const uint32_t* val_std, const uint32_t* x_mont, size_t nrows, size_t ncols,
               uint32_t* out_std) {

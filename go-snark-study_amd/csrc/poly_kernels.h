@@ -229,6 +229,46 @@ __global__ void __launch_bounds__(256) k_spmv(const uint32_t* __restrict__ rowpt
   store_fr(out + (size_t)r * 8, acc);
 }
 
+// ---- trusted setup helpers (groth16.go:94-222 on a sparse R1CS) ---------------------------------------------------
+// Lagrange basis at tau over the nodes 1..n:  L_j(tau) = M(tau) * w_j / (tau - j),  w_j = 1 / M'(j)   (Montgomery out)
+__global__ void __launch_bounds__(256) k_lagrange_at(const uint32_t* __restrict__ weights, uint32_t n, FrConst tau, FrConst mtau,
+                                                      uint32_t* __restrict__ out) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  uint32_t w[8] = {j + 1u, 0, 0, 0, 0, 0, 0, 0};
+  const Fr2 d = reduce2(sub(from_const(tau), to_mont(unpack32<ModR>(w))));         // tau - (j + 1)
+  const Fr2 v = mul(mul(from_const(mtau), load_fr(weights + (size_t)j * 8)), inv(d));
+  store_fr_canon(out + (size_t)j * 8, canon(v));
+}
+// per variable i: cd[i] = (kbeta at_i + kalpha bt_i + ct_i) / kdelta for i > npublic, 0 otherwise   (BACDelta scalars,
+// groth16.go:181-200) and ic[i] = (...) / kgamma for i <= npublic (Vk.IC, :202-219).  at/bt/ct standard form; the
+// constants are Montgomery, so every product stays in standard form.
+__global__ void __launch_bounds__(256) k_setup_scalars(const uint32_t* __restrict__ at, const uint32_t* __restrict__ bt, const uint32_t* __restrict__ ct,
+                                                        uint32_t m, uint32_t npublic, FrConst kalpha, FrConst kbeta, FrConst inv_delta,
+                                                        FrConst inv_gamma, FrConst one_m, uint32_t* __restrict__ cd, uint32_t* __restrict__ ic) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  const Fr2 t = mul_add(load_fr(at + (size_t)i * 8), from_const(kbeta), load_fr(bt + (size_t)i * 8), from_const(kalpha));
+  const Fr2 u = reduce2(add(t, mul(load_fr(ct + (size_t)i * 8), from_const(one_m))));
+  if (i > npublic) {
+    store_fr_canon(cd + (size_t)i * 8, canon(mul(u, from_const(inv_delta))));
+  } else {
+    store_fr_canon(cd + (size_t)i * 8, canon(fe_zero<ModR, 2>()));
+    store_fr_canon(ic + (size_t)i * 8, canon(mul(u, from_const(inv_gamma))));
+  }
+}
+// out[i] = scale * base^i (standard form out when `scale` is standard and base Montgomery): PowersTauDelta scalars :139-149
+__global__ void __launch_bounds__(256) k_scaled_powers(uint32_t* __restrict__ out, uint32_t count, FrConst base_m, FrConst scale) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  Fr2 b = from_const(base_m), acc = from_const(scale);
+  for (uint32_t e = i; e != 0; e >>= 1) {
+    if (e & 1u) acc = mul(acc, b);
+    b = sqr(b);
+  }
+  store_fr_canon(out + (size_t)i * 8, canon(acc));
+}
+
 // ---- evaluation: sum_i v_i x^i  (r1csqap.go:118-126) ------------------------------------------------
 constexpr int kEvalChunk = 64;
 // partial[t] = x^(t*chunk) * sum_{i<chunk} v[t*chunk+i] x^i      (v standard form, x Montgomery -> standard)

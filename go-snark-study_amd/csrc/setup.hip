@@ -1,0 +1,188 @@
+// groth16.GenerateTrustedSetup (groth16/groth16.go:94-222) for a SPARSE R1CS, on the device.
+//
+// The reference evaluates every dense QAP polynomial at tau (3 m Evals of n coefficients, each with an Exp per term)
+// and encrypts the values with ~5 m naive MulScalar(G, .) calls.  Here:
+//   L_j(tau), j = 1..n           Lagrange basis at tau over the interpolation nodes (barycentric weights from the
+//                                cached node tree, one Fermat inversion per node, all in one kernel)
+//   at_i = sum_j A[j][i] L_j     transposed sparse mat-vec (CSC built on the host in O(nnz)), likewise bt_i, ct_i
+//   scalars of every key array   (kernels k_setup_scalars / k_scaled_powers)
+//   points                       fixed-base batch multiplication (k_fixed_base_mul, 2^j G tables)
+// and the result is a resident proving key (same object gs_groth16_pk_create builds) plus the verification key.
+#include <algorithm>
+#include <vector>
+
+#include "point_io.h"
+#include "prove.h"
+
+using namespace gs;
+
+namespace {
+
+struct HostCsc {
+  std::vector<uint32_t> colptr, rowidx;
+  std::vector<uint64_t> vals;
+};
+
+// CSR (n rows x m columns) -> CSC; returns an error string or nullptr
+const char* csr_to_csc(size_t n, size_t m, const uint32_t* rowptr, const uint32_t* col, const uint64_t* val, HostCsc& out) {
+  if (rowptr[0] != 0) return "row_ptr[0] must be 0";
+  for (size_t r = 0; r < n; ++r) if (rowptr[r + 1] < rowptr[r]) return "row_ptr not monotone";
+  const size_t nnz = rowptr[n];
+  if (nnz && (!col || !val)) return "null column/value array";
+  out.colptr.assign(m + 1, 0);
+  for (size_t e = 0; e < nnz; ++e) {
+    if (col[e] >= m) return "column index out of range";
+    out.colptr[col[e] + 1]++;
+  }
+  for (size_t i = 0; i < m; ++i) out.colptr[i + 1] += out.colptr[i];
+  out.rowidx.resize(std::max<size_t>(nnz, 1));
+  out.vals.resize(std::max<size_t>(nnz, 1) * 4);
+  std::vector<uint32_t> cur(out.colptr.begin(), out.colptr.end() - 1);
+  for (size_t r = 0; r < n; ++r)
+    for (uint32_t e = rowptr[r]; e < rowptr[r + 1]; ++e) {
+      const uint32_t pos = cur[col[e]]++;
+      out.rowidx[pos] = (uint32_t)r;
+      memcpy(&out.vals[(size_t)pos * 4], &val[(size_t)e * 4], 32);
+    }
+  return nullptr;
+}
+
+// per-variable evaluations x_i = sum_j M[j][i] * L_j : transposed SpMV through the CSC
+void eval_columns(Ctx& c, const HostCsc& csc, size_t n, size_t m, const uint32_t* lag_mont, uint32_t* out_std) {
+  const size_t nnz = csc.colptr[m];
+  DevBuf cp((m + 1) * 4), ri(std::max<size_t>(nnz, 1) * 4), vl(std::max<size_t>(nnz, 1) * 32);
+  GS_HIP(hipMemcpyAsync(cp.p, csc.colptr.data(), (m + 1) * 4, hipMemcpyHostToDevice, c.stream));
+  if (nnz) {
+    GS_HIP(hipMemcpyAsync(ri.p, csc.rowidx.data(), nnz * 4, hipMemcpyHostToDevice, c.stream));
+    GS_HIP(hipMemcpyAsync(vl.p, csc.vals.data(), nnz * 32, hipMemcpyHostToDevice, c.stream));
+  }
+  spmv_dev(c, cp.as<uint32_t>(), ri.as<uint32_t>(), vl.as<uint32_t>(), lag_mont, m, n, out_std);
+  GS_HIP(hipStreamSynchronize(c.stream));
+}
+
+template <class T>
+Affine<T> download_point(Ctx& c, const uint32_t* packed_dev) {
+  uint32_t w[PointIO<T>::kAffineWords];
+  GS_HIP(hipMemcpyAsync(w, packed_dev, sizeof w, hipMemcpyDeviceToHost, c.stream));
+  GS_HIP(hipStreamSynchronize(c.stream));
+  return PointIO<T>::load_affine(w);
+}
+
+}  // namespace
+
+extern "C" {
+
+int gs_groth16_setup(size_t n, size_t m, size_t npublic,
+                     const uint32_t* a_rowptr, const uint32_t* a_col, const uint64_t* a_val,
+                     const uint32_t* b_rowptr, const uint32_t* b_col, const uint64_t* b_val,
+                     const uint32_t* c_rowptr, const uint32_t* c_col, const uint64_t* c_val,
+                     const uint64_t toxic[20], gs_handle* pk_out, uint64_t* vk_out) {
+  return guarded([&](Ctx& c) -> int {
+    if (!a_rowptr || !b_rowptr || !c_rowptr || !toxic || !pk_out) return fail(GS_ERR_ARG, "gs_groth16_setup: null argument");
+    if (n == 0 || m < 2 || npublic + 1 > m) return fail(GS_ERR_SHAPE, "gs_groth16_setup: need n >= 1, m >= 2, NPublic + 1 <= m");
+    if (n >= (1ull << 26) || m >= (1ull << 26)) return fail(GS_ERR_ARG, "gs_groth16_setup: system too large");
+    // the prover indexes PowersTauDelta[i] for i < len(hx) = 2n - 1 - (m - 1) + 1 (groth16.go:269-271): m in {n+1, n+2}
+    if (2 * n + 1 < m || 2 * n - m + 1 > m - 1) return fail(GS_ERR_SHAPE, "gs_groth16_setup: len(hx) = 2n - m + 1 would exceed len(PowersTauDelta) = m - 1 (SURVEY fact 8)");
+    const uint64_t* T = toxic;
+    const uint64_t* Kalpha = toxic + 4;
+    const uint64_t* Kbeta = toxic + 8;
+    const uint64_t* Kgamma = toxic + 12;
+    const uint64_t* Kdelta = toxic + 16;
+    if (fr_is_zero_words(Kgamma) || fr_is_zero_words(Kdelta)) return fail(GS_ERR_ARG, "gs_groth16_setup: gamma and delta must be invertible");
+    HostCsc ca, cb, cc;
+    if (const char* e = csr_to_csc(n, m, a_rowptr, a_col, a_val, ca)) return fail(GS_ERR_ARG, "gs_groth16_setup: A: %s", e);
+    if (const char* e = csr_to_csc(n, m, b_rowptr, b_col, b_val, cb)) return fail(GS_ERR_ARG, "gs_groth16_setup: B: %s", e);
+    if (const char* e = csr_to_csc(n, m, c_rowptr, c_col, c_val, cc)) return fail(GS_ERR_ARG, "gs_groth16_setup: C: %s", e);
+    // M(tau) = prod_{k=1}^{n} (tau - k) and Z(tau) = prod_{k=1}^{m-2} (tau - k)                 [groth16.go:122-133]
+    uint64_t mt[4], zt[4], inv_delta[4], inv_gamma[4], zt_inv_delta[4];
+    fr_falling_product_words(T, n, mt);
+    fr_falling_product_words(T, m - 2, zt);
+    if (fr_is_zero_words(mt)) return fail(GS_ERR_ARG, "gs_groth16_setup: tau collides with an interpolation node");
+    fr_inv_words(Kdelta, inv_delta);
+    fr_inv_words(Kgamma, inv_gamma);
+    fr_mul_words(inv_delta, zt, zt_inv_delta);
+    // --- evaluations at tau ---------------------------------------------------------------------------------
+    DevBuf lag(n * 32), at(m * 32), bt(m * 32), ct(m * 32), cd(m * 32), ic(m * 32), pw(std::max<size_t>(m - 1, 1) * 32);
+    lagrange_at_dev(c, n, T, mt, lag.as<uint32_t>());
+    eval_columns(c, ca, n, m, lag.as<uint32_t>(), at.as<uint32_t>());           // at_i = alphas[i](tau)   :163
+    eval_columns(c, cb, n, m, lag.as<uint32_t>(), bt.as<uint32_t>());           // bt_i                    :167
+    eval_columns(c, cc, n, m, lag.as<uint32_t>(), ct.as<uint32_t>());           // ct_i                    :185
+    poly_canon_dev(c, at.as<uint32_t>(), m, 0);
+    poly_canon_dev(c, bt.as<uint32_t>(), m, 0);
+    setup_scalars_dev(c, at.as<uint32_t>(), bt.as<uint32_t>(), ct.as<uint32_t>(), m, npublic, Kalpha, Kbeta, inv_delta, inv_gamma,
+                      cd.as<uint32_t>(), ic.as<uint32_t>());
+    scaled_powers_dev(c, T, zt_inv_delta, m - 1, pw.as<uint32_t>());            // tau^i Z(tau) / delta    :139-149
+    // --- encryption: k * G batches --------------------------------------------------------------------------
+    auto pk = std::make_unique<GrothPkObj>();
+    pk->nvars = m; pk->npublic = npublic; pk->nz = m - 1; pk->nptd = m - 1;
+    pk->at.alloc(m * 64); pk->bacgamma1.alloc(m * 64); pk->bacdelta.alloc(m * 64); pk->ptd.alloc(std::max<size_t>(m - 1, 1) * 64);
+    pk->bacgamma2.alloc(m * 128);
+    fixed_base_g1(c, at.as<uint32_t>(), (uint32_t)m, pk->at.as<uint32_t>());                    // Pk.G1.At        :164-165
+    fixed_base_g1(c, bt.as<uint32_t>(), (uint32_t)m, pk->bacgamma1.as<uint32_t>());             // Pk.G1.BACGamma  :168,171
+    fixed_base_g2(c, bt.as<uint32_t>(), (uint32_t)m, pk->bacgamma2.as<uint32_t>());             // Pk.G2.BACGamma  :169,173
+    fixed_base_g1(c, cd.as<uint32_t>(), (uint32_t)m, pk->bacdelta.as<uint32_t>());              // Pk.BACDelta     :177-200 (i <= NPublic: infinity)
+    fixed_base_g1(c, pw.as<uint32_t>(), (uint32_t)(m - 1), pk->ptd.as<uint32_t>());             // PowersTauDelta  :139-149
+    // single points: alpha, beta, delta in G1; beta, gamma, delta in G2                          :151-160
+    DevBuf s1(3 * 32), s2(3 * 32), p1(3 * 64), p2(3 * 128);
+    uint64_t h1[12], h2[12];
+    memcpy(h1, Kalpha, 32); memcpy(h1 + 4, Kbeta, 32); memcpy(h1 + 8, Kdelta, 32);
+    memcpy(h2, Kbeta, 32); memcpy(h2 + 4, Kgamma, 32); memcpy(h2 + 8, Kdelta, 32);
+    GS_HIP(hipMemcpyAsync(s1.p, h1, 96, hipMemcpyHostToDevice, c.stream));
+    GS_HIP(hipMemcpyAsync(s2.p, h2, 96, hipMemcpyHostToDevice, c.stream));
+    fixed_base_g1(c, s1.as<uint32_t>(), 3, p1.as<uint32_t>());
+    fixed_base_g2(c, s2.as<uint32_t>(), 3, p2.as<uint32_t>());
+    pk->alpha = download_point<FqTag>(c, p1.as<uint32_t>());
+    pk->beta = download_point<FqTag>(c, p1.as<uint32_t>() + 16);
+    pk->delta = download_point<FqTag>(c, p1.as<uint32_t>() + 32);
+    pk->beta2 = download_point<Fq2Tag>(c, p2.as<uint32_t>());
+    pk->delta2 = download_point<Fq2Tag>(c, p2.as<uint32_t>() + 64);
+    // Pk.Z                                                                                       :122-131
+    DevBuf zc((m - 1) * 32);
+    zpoly_dev(c, m - 2, zc.as<uint32_t>());
+    divisor_init(c, pk->z, zc.as<uint32_t>(), m - 1);
+    // --- verification key (alpha | beta2 | gamma2 | delta2 | IC[0..NPublic]) as affine Jacobian triples --------
+    if (vk_out) {
+      const size_t nic = npublic + 1;
+      DevBuf icp(nic * 64), j1((1 + nic) * 96), j2(3 * 192);
+      fixed_base_g1(c, ic.as<uint32_t>(), (uint32_t)nic, icp.as<uint32_t>());                   // Vk.IC           :202-219
+      affine_to_jacobian_std_g1(c, p1.as<uint32_t>(), 1, j1.as<uint32_t>());
+      affine_to_jacobian_std_g1(c, icp.as<uint32_t>(), (uint32_t)nic, j1.as<uint32_t>() + 24);
+      affine_to_jacobian_std_g2(c, p2.as<uint32_t>(), 3, j2.as<uint32_t>());
+      GS_HIP(hipMemcpyAsync(vk_out, j1.p, 96, hipMemcpyDeviceToHost, c.stream));
+      GS_HIP(hipMemcpyAsync(vk_out + 12, j2.p, 3 * 192, hipMemcpyDeviceToHost, c.stream));
+      GS_HIP(hipMemcpyAsync(vk_out + 12 + 72, j1.as<uint32_t>() + 24, nic * 96, hipMemcpyDeviceToHost, c.stream));
+    }
+    GS_HIP(hipStreamSynchronize(c.stream));
+    *pk_out = c.put(std::move(pk));
+    return GS_OK;
+  });
+}
+
+int gs_groth16_pk_export(gs_handle hpk, int which, uint64_t* jacobian, size_t count) {
+  return guarded([&](Ctx& c) -> int {
+    GrothPkObj* pk = c.get<GrothPkObj>(hpk, Kind::GrothPk);
+    if (!pk) return fail(GS_ERR_ARG, "gs_groth16_pk_export: bad proving-key handle");
+    const DevBuf* src = nullptr;
+    size_t have = pk->nvars;
+    bool g2 = false;
+    switch (which) {
+      case 0: src = &pk->at; break;
+      case 1: src = &pk->bacgamma1; break;
+      case 2: src = &pk->bacgamma2; g2 = true; break;
+      case 3: src = &pk->bacdelta; break;
+      case 4: src = &pk->ptd; have = pk->nptd; break;
+      default: return fail(GS_ERR_ARG, "gs_groth16_pk_export: which must be 0..4");
+    }
+    if (count != have || (count && !jacobian)) return fail(GS_ERR_ARG, "gs_groth16_pk_export: array has %zu points, asked for %zu", have, count);
+    if (!count) return GS_OK;
+    const size_t words = g2 ? 48 : 24;
+    DevBuf tmp(count * words * 4);
+    if (g2) affine_to_jacobian_std_g2(c, src->as<uint32_t>(), (uint32_t)count, tmp.as<uint32_t>());
+    else affine_to_jacobian_std_g1(c, src->as<uint32_t>(), (uint32_t)count, tmp.as<uint32_t>());
+    GS_HIP(hipMemcpyAsync(jacobian, tmp.p, count * words * 4, hipMemcpyDeviceToHost, c.stream));
+    GS_HIP(hipStreamSynchronize(c.stream));
+    return GS_OK;
+  });
+}
+
+}  // extern "C"

@@ -66,6 +66,56 @@ def device_pk_from_handles(at, bacgamma1, bacgamma2, bacdelta, ptd, alpha, beta,
     return DevicePk(capi.DeviceHandle(h.value), nvars, npublic, None)
 
 
+class Vk:
+    """groth16.Vk (groth16.go:33-43): affine Jacobian tuples."""
+
+    def __init__(self, IC, G1_Alpha, G2_Beta, G2_Gamma, G2_Delta):
+        self.IC, self.G1_Alpha, self.G2_Beta, self.G2_Gamma, self.G2_Delta = IC, G1_Alpha, G2_Beta, G2_Gamma, G2_Delta
+
+
+def GenerateTrustedSetupSparse(n, nvars, npublic, a_csr, b_csr, c_csr, toxic):
+    """groth16.GenerateTrustedSetup (groth16.go:94-222) on a sparse R1CS with the toxic scalars
+    (T, Kalpha, Kbeta, Kgamma, Kdelta) injected instead of drawn at :99-119.  Everything heavy runs on the device
+    (gs_groth16_setup); returns (DevicePk resident in HBM, Vk)."""
+    import ctypes
+    capi.init()
+    args = []
+    for rp, cl, vl in (a_csr, b_csr, c_csr):
+        rp = np.ascontiguousarray(rp, dtype=np.uint32)
+        cl = np.ascontiguousarray(cl, dtype=np.uint32)
+        vl = np.ascontiguousarray(vl, dtype=np.uint64).reshape(-1, 4)
+        if cl.size == 0:
+            cl, vl = np.zeros(1, dtype=np.uint32), np.zeros((1, 4), dtype=np.uint64)
+        args += [rp, cl, vl]
+    tox = capi.ints_to_u64([t % R for t in toxic]).reshape(-1)
+    vk = np.zeros(12 + 72 + 12 * (npublic + 1), dtype=np.uint64)
+    h = capi.Handle(0)
+    capi.check(capi.load_library().gs_groth16_setup(
+        n, nvars, npublic, capi.ptr32(args[0]), capi.ptr32(args[1]), capi.ptr64(args[2]), capi.ptr32(args[3]), capi.ptr32(args[4]),
+        capi.ptr64(args[5]), capi.ptr32(args[6]), capi.ptr32(args[7]), capi.ptr64(args[8]), capi.ptr64(tox), ctypes.byref(h), capi.ptr64(vk)))
+    v = capi.u64_to_ints(vk)
+    g1 = lambda o: (v[o], v[o + 1], v[o + 2])                               # noqa: E731
+    g2 = lambda o: ((v[o], v[o + 1]), (v[o + 2], v[o + 3]), (v[o + 4], v[o + 5]))   # noqa: E731
+    vkey = Vk(IC=[g1(21 + 3 * i) for i in range(npublic + 1)], G1_Alpha=g1(0), G2_Beta=g2(3), G2_Gamma=g2(9), G2_Delta=g2(15))
+    return DevicePk(capi.DeviceHandle(h.value), nvars, npublic, None), vkey
+
+
+PK_ARRAYS = {"G1_At": 0, "G1_BACGamma": 1, "G2_BACGamma": 2, "BACDelta": 3, "PowersTauDelta": 4}
+
+
+def ExportPkArray(dev_pk, name):
+    """One array of a resident key as affine Jacobian int tuples (testing / serialisation)."""
+    which = PK_ARRAYS[name]
+    count = dev_pk.nvars if which != 4 else dev_pk.nvars - 1
+    words = 24 if which == 2 else 12
+    out = np.zeros((count, words), dtype=np.uint64)
+    capi.check(capi.load_library().gs_groth16_pk_export(capi.Handle(dev_pk.handle.h), which, capi.ptr64(out), count))
+    v = capi.u64_to_ints(out)
+    if which == 2:
+        return [((v[6 * i], v[6 * i + 1]), (v[6 * i + 2], v[6 * i + 3]), (v[6 * i + 4], v[6 * i + 5])) for i in range(count)]
+    return [(v[3 * i], v[3 * i + 1], v[3 * i + 2]) for i in range(count)]
+
+
 def UploadPk(pk, circuit):
     """Additive extension: make pk resident.  Cached on the Pk object."""
     if pk._dev is not None:

@@ -147,3 +147,88 @@ class SqchainInstance(RandomInstance):
 
 def sqchain_instance(n, seed):
     return SqchainInstance(n, seed)
+
+
+class SqchainSetupInstance:
+    """A COMPLETE synthetic Groth16 instance: the sqchain(n) R1CS, a satisfying witness, a structured
+    trusted setup built on the device from seeded toxic values (gs_groth16_setup = groth16.go:94-222), and px from the
+    sparse system.  Because the toxic values are known, the proof the prover must emit is known in closed form
+    (expected_proof_scalars) -- an end-to-end check at sizes no reference implementation can replay."""
+
+    def __init__(self, n, seed):
+        from . import r1csqap
+        self.n, self.m, self.seed = n, n + 1, seed
+        self.toxic = field_elems(5, seed + 20)
+        x = field_elems(1, seed + 10)[0]
+        a, b, c, w = sqchain_r1cs(n, x)
+        self.r1cs = (a, b, c)
+        self.w_host = w
+        self._pk, self.vk = groth16.GenerateTrustedSetupSparse(n, self.m, 1, a, b, c, self.toxic)
+        self.ax_host, self.bx_host, self.cx_host, self.px_host = r1csqap.ComputePx(a, b, c, w, self.m)
+        self.w = capi.scalars_upload(self.w_host)
+        self.px = capi.scalars_upload(self.px_host)
+
+    def device_pk(self):
+        return self._pk
+
+    def describe(self):
+        return ("sqchain(n) R1CS (s_k^2 = s_{k+1} - k), satisfying witness, structured trusted setup on the device from seeded "
+                "toxic values (gs_groth16_setup), px = A(x)B(x) - C(x) from the sparse system; seed 0x%X" % self.seed)
+
+    def expected_proof_scalars(self, r, s):
+        """Discrete logs (to the base G1 / G2 generators) of the proof elements groth16.go:243-275 must produce:
+           a = A(tau) + Kalpha + r Kdelta,  b = B(tau) + Kbeta + s Kdelta,
+           c = [ sum_{i>l} w_i (Kbeta a_i + Kalpha b_i + c_i)(tau) + A(tau) B(tau) - C(tau) ] / Kdelta + s a + r b - r s Kdelta
+        with A(tau) = sum_j (A w)_j L_j(tau) over the nodes 1..n (H Z = A B - C because the witness satisfies the R1CS)."""
+        n, m = self.n, self.m
+        T, Ka, Kb, Kg, Kd = self.toxic
+        w = capi.u64_to_ints(self.w_host)
+        # L_j(tau) = M(tau) / ((tau - j) M'(j)),  M'(j) = (-1)^(n-j) (j-1)! (n-j)!
+        fact = [1] * (n + 1)
+        for k in range(1, n + 1):
+            fact[k] = fact[k - 1] * k % R
+        den = []
+        mt = 1
+        for j in range(1, n + 1):
+            mt = mt * (T - j) % R
+            d = (T - j) * fact[j - 1] % R * fact[n - j] % R
+            den.append(d if (n - j) % 2 == 0 else R - d)
+        pre = [1] * (n + 1)
+        for i, d in enumerate(den):
+            pre[i + 1] = pre[i] * d % R
+        inv = pow(pre[n], R - 2, R)
+        lag = [0] * n
+        for i in range(n - 1, -1, -1):
+            lag[i] = mt * (inv * pre[i] % R) % R
+            inv = inv * den[i] % R
+
+        def rows(csr):
+            rp, cl, vl = csr
+            vals = capi.u64_to_ints(vl)
+            return rp, cl, vals
+        sums, lows = [], []
+        for csr in self.r1cs:
+            rp, cl, vals = rows(csr)
+            tot, low = 0, [0, 0]
+            for j in range(n):
+                acc = 0
+                for e in range(int(rp[j]), int(rp[j + 1])):
+                    k = int(cl[e])
+                    acc += vals[e] * w[k]
+                    if k <= 1:
+                        low[k] = (low[k] + vals[e] * lag[j]) % R       # a_i(tau) for i <= NPublic
+                tot = (tot + acc % R * lag[j]) % R
+            sums.append(tot)
+            lows.append(low)
+        At, Bt, Ct = sums
+        a = (At + Ka + r * Kd) % R
+        b = (Bt + Kb + s * Kd) % R
+        priv = (Kb * At + Ka * Bt + Ct) % R
+        for i in (0, 1):                                              # subtract the public part (i <= NPublic = 1)
+            priv = (priv - w[i] * (Kb * lows[0][i] + Ka * lows[1][i] + lows[2][i])) % R
+        c = ((priv + At * Bt - Ct) * pow(Kd, R - 2, R) + s * a + r * b - r * s % R * Kd) % R
+        return a, b, c
+
+
+def sqchain_setup_instance(n, seed):
+    return SqchainSetupInstance(n, seed)

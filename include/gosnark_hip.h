@@ -153,6 +153,22 @@ int gs_groth16_prove(gs_handle pk, const uint64_t* w, size_t nw, const uint64_t*
 int gs_groth16_prove_resident(gs_handle pk, gs_handle w, gs_handle px,
                               const uint64_t r[4], const uint64_t s[4], uint64_t out_proof[32], int inf[3]);
 
+/* groth16.GenerateTrustedSetup (groth16.go:94-222) for a SPARSE R1CS (A, B, C in CSR over n constraints x m
+ * variables, as gs_r1cs_to_px), with the five toxic scalars injected (what Utils.FqR.Rand() returned at :99-119):
+ * toxic = T | Kalpha | Kbeta | Kgamma | Kdelta (5 x 4 words).  Builds the proving key directly on the device --
+ * Lagrange basis at tau over the nodes 1..n, transposed sparse mat-vecs for the per-variable evaluations, fixed-base
+ * batch multiplications -- and returns it resident in *pk_out (same object as gs_groth16_pk_create).  If vk_out is not
+ * NULL it receives the verification key as affine Jacobian triples: G1.Alpha (12 words) | G2.Beta (24) | G2.Gamma (24)
+ * | G2.Delta (24) | IC[0..npublic] (12 each).  Shape contract: m in {n+1, n+2}. */
+int gs_groth16_setup(size_t n, size_t m, size_t npublic,
+                     const uint32_t* a_rowptr, const uint32_t* a_col, const uint64_t* a_val,
+                     const uint32_t* b_rowptr, const uint32_t* b_col, const uint64_t* b_val,
+                     const uint32_t* c_rowptr, const uint32_t* c_col, const uint64_t* c_val,
+                     const uint64_t toxic[20], gs_handle* pk_out, uint64_t* vk_out);
+/* Read one array of a resident Groth16 key back as affine Jacobian triples: which = 0 G1.At, 1 G1.BACGamma,
+ * 2 G2.BACGamma (24 words per point), 3 BACDelta, 4 PowersTauDelta.  count must equal the array length. */
+int gs_groth16_pk_export(gs_handle pk, int which, uint64_t* jacobian, size_t count);
+
 /* ---- Pinocchio prover (snark.go) ------------------------------------------------------------ */
 /* snark.Pk (snark.go:16-26): A, Ap, Bp, C, Cp, Kp: m G1 points; B: m G2 points; G1T: len(Z). */
 int gs_pinocchio_pk_create(gs_handle a, gs_handle ap, gs_handle b_g2, gs_handle bp, gs_handle c, gs_handle cp,

@@ -294,3 +294,53 @@ def test_sqchain_px_is_exactly_divisible(logn):
     if logn <= 12:                                         # the C oracle's O(n^2) long division agrees on the quotient
         cq, cr = C.poly_div_u64(px, zfull)
         assert np.array_equal(cq, q) and not cr.any()
+
+
+# ---- trusted setup on the device (groth16.go:94-222) ------------------------------------------------------------------
+X3_A = [[0, 0, 1, 0, 0, 0, 0, 0], [0, 0, 0, 1, 0, 0, 0, 0], [0, 0, 1, 0, 1, 0, 0, 0], [5, 0, 0, 0, 0, 1, 0, 0], [0, 0, 0, 0, 0, 0, 1, 0], [0, 1, 0, 0, 0, 0, 0, 0], [1, 0, 0, 0, 0, 0, 0, 0]]
+X3_B = [[0, 0, 1, 0, 0, 0, 0, 0], [0, 0, 1, 0, 0, 0, 0, 0], [1, 0, 0, 0, 0, 0, 0, 0], [1, 0, 0, 0, 0, 0, 0, 0], [1, 0, 0, 0, 0, 0, 0, 0], [1, 0, 0, 0, 0, 0, 0, 0], [1, 0, 0, 0, 0, 0, 0, 0]]
+X3_C = [[0, 0, 0, 1, 0, 0, 0, 0], [0, 0, 0, 0, 1, 0, 0, 0], [0, 0, 0, 0, 0, 1, 0, 0], [0, 0, 0, 0, 0, 0, 1, 0], [0, 1, 0, 0, 0, 0, 0, 0], [0, 0, 0, 0, 0, 0, 1, 0], [1, 0, 0, 0, 0, 0, 0, 0]]
+
+
+def test_trusted_setup_equals_reference_on_x3_circuit():
+    """gs_groth16_setup on the sparse x^3 + x + 5 R1CS == the reference's GenerateTrustedSetup (python oracle, dense QAP
+    from R1CSToQAP) with the same toxic values: every proving-key array, the single points and the verification key."""
+    rng = random.Random(2024)
+    toxic = tuple(rng.randrange(1, O.R) for _ in range(5))
+    al, be, ga, _ = O.PF.R1CSToQAP(X3_A, X3_B, X3_C)
+    opk, ovk = O.groth16_GenerateTrustedSetup(8, 1, al, be, ga, toxic)
+    rows = lambda mat: [{k: v for k, v in enumerate(row) if v} for row in mat]   # noqa: E731
+    dpk, vk = groth16.GenerateTrustedSetupSparse(7, 8, 1, r1csqap.csr_from_rows(rows(X3_A)), r1csqap.csr_from_rows(rows(X3_B)),
+                                                  r1csqap.csr_from_rows(rows(X3_C)), toxic)
+    for name, ref in (("G1_At", opk.G1_At), ("G1_BACGamma", opk.G1_BACGamma), ("BACDelta", opk.BACDelta), ("PowersTauDelta", opk.PowersTauDelta)):
+        assert groth16.ExportPkArray(dpk, name) == [jac_affine_g1(p) for p in ref], name
+    assert groth16.ExportPkArray(dpk, "G2_BACGamma") == [jac_affine_g2(p) for p in opk.G2_BACGamma]
+    assert vk.G1_Alpha == jac_affine_g1(ovk.G1_Alpha) and vk.G2_Beta == jac_affine_g2(ovk.G2_Beta)
+    assert vk.G2_Gamma == jac_affine_g2(ovk.G2_Gamma) and vk.G2_Delta == jac_affine_g2(ovk.G2_Delta)
+    assert vk.IC == [jac_affine_g1(p) for p in ovk.IC]
+    # and a proof with that resident key equals the oracle prover on the oracle's key (alpha/beta/delta singles included)
+    w = list(O.X3_WITNESS)
+    _, _, _, px = O.PF.CombinePolynomials(w, al, be, ga)
+    r, s = rng.randrange(O.R), rng.randrange(O.R)
+    want = O.groth16_GenerateProofs(8, 1, opk, w, px, r, s)
+    got = groth16.GenerateProofsWithRS(groth16.Circuit(8, 1), dpk, w, px, r, s)
+    assert got.PiA == jac_affine_g1(want[0]) and got.PiB == jac_affine_g2(want[1]) and got.PiC == jac_affine_g1(want[2])
+
+
+@pytest.mark.parametrize("logn", [4, 10, 16])
+def test_full_pipeline_proof_matches_closed_form_from_toxic_values(logn):
+    """End to end at sizes the reference cannot replay: sparse R1CS -> device trusted setup -> px on the device ->
+    prove.  With the toxic scalars known, groth16.go:243-275 must output PiA = a G1, PiB = b G2, PiC = c G1 for the
+    closed-form (a, b, c) of synth.SqchainSetupInstance.expected_proof_scalars; the generator multiples come from the
+    C oracle's MulScalar."""
+    from gosnark_amd import synth
+    inst = synth.sqchain_setup_instance(1 << logn, 0xBEEF00 + logn)
+    r, s = synth.field_elems(2, 4040 + logn)
+    proof = groth16.prove_resident(inst.device_pk(), inst.w, inst.px, r, s)
+    a, b, c = inst.expected_proof_scalars(r, s)
+    wa = C.g1_affine(C.g1_mul_scalar(O.G1_GEN, a))
+    wb = C.g2_affine(C.g2_mul_scalar(O.G2_GEN, b))
+    wc = C.g1_affine(C.g1_mul_scalar(O.G1_GEN, c))
+    assert (proof.PiA[0], proof.PiA[1]) == wa
+    assert (proof.PiB[0], proof.PiB[1]) == wb
+    assert (proof.PiC[0], proof.PiC[1]) == wc
