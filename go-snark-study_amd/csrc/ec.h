@@ -22,6 +22,7 @@ struct FqTag {
   static constexpr int kWords = 8;                       // canonical storage: 8 x u32 per element
   static constexpr bool mul_ok(int a, int b) { return a * b <= 160; }
   static constexpr bool sqr_ok(int a) { return a * a <= 160; }
+  static constexpr bool mul_sub_ok(int a, int b, int c, int d) { return a * b + (c + 1) * d <= 160; }
   static GS_HD E<1> one() { return fe_one<ModQ>(); }
   template <int B> static GS_HD E<B> zero() { return fe_zero<ModQ, B>(); }
   template <int B> static GS_HD bool limbs_all_zero(const E<B>& a) {
@@ -37,6 +38,7 @@ struct Fq2Tag {
   static constexpr int kWords = 16;
   static constexpr bool mul_ok(int a, int b) { return a * b + a * (b + 1) <= 160 && 2 * a * b <= 160; }
   static constexpr bool sqr_ok(int a) { return (2 * a) * (2 * a + 1) <= 160; }
+  static constexpr bool mul_sub_ok(int a, int b, int c, int d) { return a * b + (a + 1) * b + (c + 1) * d + (c + 1) * d <= 160; }
   static GS_HD E<1> one() { return fq2_one(); }
   template <int B> static GS_HD E<B> zero() { return fq2_zero<B>(); }
   template <int B> static GS_HD bool limbs_all_zero(const E<B>& a) {
@@ -52,6 +54,15 @@ GS_HD auto smul(const A& a, const Bv& b) {
   else if constexpr (Ba >= Bb && T::mul_ok(2, Bb)) return mul(reduce2(a), b);
   else if constexpr (T::mul_ok(Ba, 2)) return mul(a, reduce2(b));
   else return mul(reduce2(a), reduce2(b));
+}
+// bound-aware a*b - c*d with a single reduction per coordinate (reduce2 inserted where the dot product would overflow)
+template <class T, class A, class Bv, class Cv, class Dv>
+GS_HD auto smul_sub(const A& a, const Bv& b, const Cv& c, const Dv& d) {
+  constexpr int Ba = BoundOf<A>::v, Bb = BoundOf<Bv>::v, Bc = BoundOf<Cv>::v, Bd = BoundOf<Dv>::v;
+  if constexpr (T::mul_sub_ok(Ba, Bb, Bc, Bd)) return mul_sub(a, b, c, d);
+  else if constexpr (T::mul_sub_ok(2, Bb, Bc, Bd)) return mul_sub(reduce2(a), b, c, d);
+  else if constexpr (T::mul_sub_ok(2, 2, Bc, Bd)) return mul_sub(reduce2(a), reduce2(b), c, d);
+  else return mul_sub(reduce2(a), reduce2(b), reduce2(c), reduce2(d));
 }
 template <class T, class A>
 GS_HD auto ssqr(const A& a) {
@@ -135,11 +146,10 @@ GS_HD void xyzz_madd(Xyzz<T>& acc, const Affine<T>& b, bool negate = false) {
   auto Q = smul<T>(acc.x, PP);
   auto RR = ssqr<T>(R);
   auto X3 = sub(RR, add(PPP, dbl(Q)));                  // 2 + 6 + 1 = 9
-  auto t = smul<T>(R, sub(Q, X3));                      // 8 x 12
-  auto Y3 = sub(t, smul<T>(acc.y, PPP));                // 5
+  auto Y3 = smul_sub<T>(R, sub(Q, X3), acc.y, PPP);     // R (Q - X3) - Y1 PPP, one reduction per coordinate
   acc.zz = smul<T>(acc.zz, PP);
   acc.zzz = smul<T>(acc.zzz, PPP);
-  acc.x = X3; acc.y = Y3;
+  acc.x = X3; acc.y = relax<5>(Y3);
 }
 
 // 2 * acc   [dbl-2008-s-1: 6M + 4S... a = 0]
@@ -182,8 +192,7 @@ GS_HD void xyzz_add(Xyzz<T>& acc, const Xyzz<T>& b) {
   auto Q = smul<T>(U1, PP);
   auto RR = ssqr<T>(R);
   auto X3 = sub(RR, add(PPP, dbl(Q)));                  // 9
-  auto t = smul<T>(R, sub(Q, X3));
-  auto Y3 = sub(t, smul<T>(S1, PPP));                   // 5
+  auto Y3 = relax<5>(smul_sub<T>(R, sub(Q, X3), S1, PPP));
   acc.zz = smul<T>(smul<T>(acc.zz, b.zz), PP);
   acc.zzz = smul<T>(smul<T>(acc.zzz, b.zzz), PPP);
   acc.x = X3; acc.y = Y3;

@@ -217,6 +217,39 @@ GS_HD Fe<M, 2> mul_add(const Fe<M, Ba>& a, const Fe<M, Bb>& b, const Fe<M, Bc>& 
   return r;
 }
 
+// REDC(a*b + c*d + e*f + g*h): one reduction for a four-term dot product (fused Fq2 expressions).
+template <class M, int Ba, int Bb, int Bc, int Bd, int Be, int Bf, int Bg, int Bh>
+GS_HD Fe<M, 2> dot4(const Fe<M, Ba>& a, const Fe<M, Bb>& b, const Fe<M, Bc>& c, const Fe<M, Bd>& d,
+                    const Fe<M, Be>& e, const Fe<M, Bf>& f, const Fe<M, Bg>& g, const Fe<M, Bh>& h) {
+  static_assert(Ba * Bb + Bc * Bd + Be * Bf + Bg * Bh <= 160, "dot-product input bound exceeded");
+  uint32_t m[NL];
+  Fe<M, 2> r;
+  uint64_t acc = 0;
+#pragma unroll
+  for (int k = 0; k < 2 * NL - 1; ++k) {
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const int j = k - i;
+      if (j >= 0 && j < NL) {
+        acc += (uint64_t)a.l[i] * b.l[j];
+        acc += (uint64_t)c.l[i] * d.l[j];
+        acc += (uint64_t)e.l[i] * f.l[j];
+        acc += (uint64_t)g.l[i] * h.l[j];
+      }
+    }
+    if (k < NL) mont_low_column<M>(acc, m, k);
+    else mont_high_column<M>(acc, m, k, r.l[k - NL]);
+  }
+  r.l[NL - 1] = (uint32_t)acc;
+  return r;
+}
+
+// a*b - c*d with one reduction
+template <class M, int Ba, int Bb, int Bc, int Bd>
+GS_HD Fe<M, 2> mul_sub(const Fe<M, Ba>& a, const Fe<M, Bb>& b, const Fe<M, Bc>& c, const Fe<M, Bd>& d) {
+  return mul_add(a, b, neg(c), d);
+}
+
 // ---- reductions / comparisons ---------------------------------------------------------------
 // value -> value - floor(top/(p_top+1)) * p : lands in [0, 2p).
 template <class M, int B>

@@ -34,6 +34,16 @@ GS_HD Fq2e<2> mul(const Fq2e<Ba>& a, const Fq2e<Bb>& b) {
   return {mul_add(a.c0, b.c0, a.c1, neg(b.c1)), mul_add(a.c0, b.c1, a.c1, b.c0)};
 }
 
+// a*b - c*d with ONE reduction per coordinate (four-term dot products): 2 x 405 mads instead of 2 x 486
+template <int Ba, int Bb, int Bc, int Bd>
+GS_HD Fq2e<2> mul_sub(const Fq2e<Ba>& a, const Fq2e<Bb>& b, const Fq2e<Bc>& c, const Fq2e<Bd>& d) {
+  const auto na1 = neg(a.c1);
+  const auto nc0 = neg(c.c0);
+  const auto nc1 = neg(c.c1);
+  // re: a0 b0 - a1 b1 - c0 d0 + c1 d1      im: a0 b1 + a1 b0 - c0 d1 - c1 d0
+  return {dot4(a.c0, b.c0, na1, b.c1, nc0, d.c0, c.c1, d.c1), dot4(a.c0, b.c1, a.c1, b.c0, nc0, d.c1, nc1, d.c0)};
+}
+
 // (a0 + a1 u)^2 = (a0 + a1)(a0 - a1) + 2 a0 a1 u                       [fq2.go:118-133]
 template <int B>
 GS_HD Fq2e<2> sqr(const Fq2e<B>& a) {
