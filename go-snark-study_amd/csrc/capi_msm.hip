@@ -174,8 +174,10 @@ int gs_init(const int* devices, int ndev) {
         uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         const int ncu = std::min(256, prop.multiProcessorCount);
         if (stride > 0) for (int i = 0; i < ncu; i += stride) mask[i >> 5] |= 1u << (i & 31);
+        const bool no_overlap = getenv("GS_NO_OVERLAP") != nullptr;      // debugging aid: everything on the main stream
         for (auto& a : c.aux_stream) {
-          if (stride > 0) GS_HIP(hipExtStreamCreateWithCUMask(&a, 8, mask));
+          if (no_overlap) a = c.main_stream;
+          else if (stride > 0) GS_HIP(hipExtStreamCreateWithCUMask(&a, 8, mask));
           else GS_HIP(hipStreamCreateWithFlags(&a, hipStreamNonBlocking));
         }
       }

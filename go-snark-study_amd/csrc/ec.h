@@ -227,6 +227,22 @@ GS_HD Xyzz<T> xyzz_mul_words(const Xyzz<T>& p, const uint32_t (&k)[8]) {
   return r;
 }
 
+// the same with a fixed 4-bit window (host-side prover tail: 64 windows of 4 doublings + 1 table addition)
+template <class T>
+GS_HD Xyzz<T> xyzz_mul_words_w4(const Xyzz<T>& p, const uint32_t (&k)[8]) {
+  Xyzz<T> tab[16];
+  tab[0] = xyzz_inf<T>();
+  tab[1] = p;
+  for (int i = 2; i < 16; ++i) { tab[i] = tab[i - 1]; xyzz_add(tab[i], p); }
+  Xyzz<T> r = xyzz_inf<T>();
+  for (int nib = 63; nib >= 0; --nib) {
+    for (int d = 0; d < 4; ++d) xyzz_dbl(r);
+    const uint32_t v = (k[nib >> 3] >> ((nib & 7) * 4)) & 15u;
+    if (v) xyzz_add(r, tab[v]);
+  }
+  return r;
+}
+
 // XYZZ -> affine (canonical Montgomery): one field inversion           [cf. g1.go:157-170]
 template <class T>
 GS_HD Affine<T> xyzz_to_affine(const Xyzz<T>& p) {

@@ -2,6 +2,7 @@
 #include "msm.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "msm_kernels.h"
 
@@ -135,8 +136,10 @@ static void msm_enqueue(Ctx& c, const MsmPlan& plan, const std::vector<MsmBase>&
   }
   p.tacc = std::make_shared<PhaseTimer>(c.stream);
   p.tker = std::make_shared<PhaseTimer>(c.stream);
-  hipLaunchKernelGGL(k_bucket_accumulate<T>, dim3((plan.maxchunks + 255) / 256, njobs), dim3(256), 0, c.stream,
-                     jobs, plan.offsets, plan.entries, plan.chunk_bucket, plan.nbuckets);
+  static const int repeat = getenv("GS_REPEAT_ACC") ? atoi(getenv("GS_REPEAT_ACC")) : 1;    // clock/power experiments only
+  for (int rep = 0; rep < repeat; ++rep)
+    hipLaunchKernelGGL(k_bucket_accumulate<T>, dim3((plan.maxchunks + 255) / 256, njobs), dim3(256), 0, c.stream,
+                       jobs, plan.offsets, plan.entries, plan.chunk_bucket, plan.nbuckets);
   p.tker->stop();
   hipLaunchKernelGGL(k_heavy_combine<T>, dim3(1024, njobs), dim3(kHeavyBlock), 0, c.stream,
                      jobs, plan.offsets, plan.heavy_list, plan.heavy_count);
@@ -267,12 +270,12 @@ bool g2_to_affine_std(const G2Xyzz& p, uint64_t out[16]) { return to_affine_std<
 G1Xyzz g1_mul_scalar(const G1Xyzz& p, const uint64_t k[4]) {
   uint32_t w[8];
   fr_canon_words(k, w);
-  return xyzz_mul_words(p, w);
+  return xyzz_mul_words_w4(p, w);
 }
 G2Xyzz g2_mul_scalar(const G2Xyzz& p, const uint64_t k[4]) {
   uint32_t w[8];
   fr_canon_words(k, w);
-  return xyzz_mul_words(p, w);
+  return xyzz_mul_words_w4(p, w);
 }
 
 }  // namespace gs

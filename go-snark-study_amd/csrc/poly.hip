@@ -2,6 +2,7 @@
 #include "poly.h"
 
 #include <algorithm>
+#include <vector>
 
 #include "poly_kernels.h"
 
@@ -57,27 +58,40 @@ static void ensure_twiddles(Ctx& c, int logn) {
 void ntt_forward(Ctx& c, uint32_t* data, int logt, int logm) { ntt_forward_n(c, data, (size_t)1 << logt, logm); }
 void ntt_inverse_unscaled(Ctx& c, uint32_t* data, int logt, int logm) { ntt_inverse_unscaled_n(c, data, (size_t)1 << logt, logm); }
 
-void ntt_forward_n(Ctx& c, uint32_t* data, size_t total, int logm) {
-  if (logm == 0) return;
-  ensure_twiddles(c, logm);
-  const uint32_t nb = (uint32_t)(total / 2);
-  for (int s = logm - 1; s >= 0; --s) {              // half = 2^s
-    const uint32_t half = 1u << s;
-    const uint32_t stride = (1u << (g_tw.logn - 1)) / half;
-    hipLaunchKernelGGL(k_ntt_dif_stage, grid1(nb), dim3(256), 0, c.stream, data, half, g_tw.fwd.as<uint32_t>(), stride, nb);
+// pass schedule: the lowest min(7, logm) stages form the contiguous s_lo = 0 pass, the stages above are cut into
+// passes of <= 7 from the top; every upper pass has s_lo >= 7, so its tiles can take C = 8..128 consecutive columns.
+struct NttPass { int s_lo, k, clog; uint32_t ntiles; };
+static std::vector<NttPass> ntt_schedule(size_t total, int logm) {
+  std::vector<NttPass> v;                      // in DIF (forward) order: top stages first
+  const int low = std::min(kNttMaxStages, logm);
+  int hi = logm;
+  while (hi > low) {
+    const int k = std::min(kNttMaxStages, hi - low);
+    const int s_lo = hi - k;
+    const int clog = std::min(kNttTileLog - k, s_lo);
+    v.push_back(NttPass{s_lo, k, clog, (uint32_t)(total >> (k + clog))});
+    hi = s_lo;
   }
+  int clog = kNttTileLog - low;                // s_lo = 0 pass: C adjacent contiguous groups of 2^low
+  while (clog > 0 && ((total >> low) & (((size_t)1 << clog) - 1))) --clog;
+  v.push_back(NttPass{0, low, clog, (uint32_t)(total >> (low + clog))});
+  return v;
+}
+
+void ntt_forward_n(Ctx& c, uint32_t* data, size_t total, int logm) {
+  if (logm == 0 || total == 0) return;
+  ensure_twiddles(c, logm);
+  for (const NttPass& p : ntt_schedule(total, logm))
+    hipLaunchKernelGGL(k_ntt_pass<false>, dim3(p.ntiles), dim3(256), 0, c.stream, data, g_tw.fwd.as<uint32_t>(), g_tw.logn, p.s_lo, p.k, p.clog);
   GS_HIP(hipGetLastError());
 }
 
 void ntt_inverse_unscaled_n(Ctx& c, uint32_t* data, size_t total, int logm) {
-  if (logm == 0) return;
+  if (logm == 0 || total == 0) return;
   ensure_twiddles(c, logm);
-  const uint32_t nb = (uint32_t)(total / 2);
-  for (int s = 0; s < logm; ++s) {
-    const uint32_t half = 1u << s;
-    const uint32_t stride = (1u << (g_tw.logn - 1)) / half;
-    hipLaunchKernelGGL(k_ntt_dit_stage, grid1(nb), dim3(256), 0, c.stream, data, half, g_tw.inv.as<uint32_t>(), stride, nb);
-  }
+  const std::vector<NttPass> sched = ntt_schedule(total, logm);
+  for (auto it = sched.rbegin(); it != sched.rend(); ++it)
+    hipLaunchKernelGGL(k_ntt_pass<true>, dim3(it->ntiles), dim3(256), 0, c.stream, data, g_tw.inv.as<uint32_t>(), g_tw.logn, it->s_lo, it->k, it->clog);
   GS_HIP(hipGetLastError());
 }
 

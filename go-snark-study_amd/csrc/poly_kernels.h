@@ -93,6 +93,74 @@ __global__ void __launch_bounds__(256) k_ntt_dit_stage(uint32_t* __restrict__ x,
   store_fr(p1, reduce2(sub(a, bw)));
 }
 
+// ---- fused NTT pass: k consecutive radix-2 stages on a 1024-element tile held in LDS ---------------------------------
+// One workgroup loads a tile of R = 2^k rows x C = 2^clog columns (rows are the indices that differ in bits
+// [s_lo, s_lo + k), columns are consecutive low indices -- or, for the s_lo = 0 pass, C adjacent contiguous groups),
+// converts once to 29-bit limbs, runs the k butterfly stages out of LDS (limb-major layout: conflict-free for the unit-
+// stride column index) and writes the tile back: a 2^21-point transform moves 3 x 128 MiB instead of 21 x 128 MiB.
+constexpr int kNttTileLog = 10;
+constexpr int kNttTile = 1 << kNttTileLog;
+constexpr int kNttMaxStages = 7;
+
+template <bool kInverse>
+__global__ void __launch_bounds__(256) k_ntt_pass(uint32_t* __restrict__ x, const uint32_t* __restrict__ tw, int tw_logn, int s_lo, int k, int clog) {
+  __shared__ uint32_t sh[NL * kNttTile];
+  const uint32_t R = 1u << k, C = 1u << clog, E = R << clog;
+  const uint32_t tile = blockIdx.x;
+  size_t base;                       // global index of (q = 0, c = 0)
+  uint32_t qstride, cstride;         // index = base + q * qstride + c * cstride
+  if (s_lo == 0) { base = (size_t)tile * E; qstride = 1; cstride = R; }
+  else {
+    const uint32_t chunks = (1u << s_lo) >> clog;
+    const uint32_t hi = tile / chunks, lc = tile - hi * chunks;
+    base = ((size_t)hi << (s_lo + k)) + ((size_t)lc << clog); qstride = 1u << s_lo; cstride = 1;
+  }
+  // load: memory-contiguous index fastest across threads
+  for (uint32_t e = threadIdx.x; e < E; e += 256) {
+    uint32_t q, cc;
+    if (s_lo == 0) { q = e & (R - 1); cc = e >> k; } else { cc = e & (C - 1); q = e >> clog; }
+    const Fr2 v = reduce2(load_fr(x + (base + (size_t)q * qstride + (size_t)cc * cstride) * 8));
+    const uint32_t le = (q << clog) + cc;
+#pragma unroll
+    for (int l = 0; l < NL; ++l) sh[l * kNttTile + le] = v.l[l];
+  }
+  __syncthreads();
+  for (int step = 0; step < k; ++step) {
+    const int b = kInverse ? step : k - 1 - step;          // DIF runs the stages downwards, DIT upwards
+    const int s = s_lo + b;
+    for (uint32_t u = threadIdx.x; u < E / 2; u += 256) {
+      const uint32_t cc = u & (C - 1), qq = u >> clog;
+      const uint32_t q0 = ((qq >> b) << (b + 1)) | (qq & ((1u << b) - 1u));
+      const uint32_t e0 = (q0 << clog) + cc, e1 = e0 + ((1u << b) << clog);
+      const size_t gi = base + (size_t)q0 * qstride + (size_t)cc * cstride;
+      const uint32_t j = (uint32_t)gi & ((1u << s) - 1u);
+      const Fr6 w = load_fr(tw + ((size_t)j << (tw_logn - 1 - s)) * 8);
+      Fr2 a, bb;
+#pragma unroll
+      for (int l = 0; l < NL; ++l) { a.l[l] = sh[l * kNttTile + e0]; bb.l[l] = sh[l * kNttTile + e1]; }
+      Fr2 o0, o1;
+      if constexpr (kInverse) {
+        const Fr2 t = mul(bb, w);
+        o0 = reduce2(add(a, t)); o1 = reduce2(sub(a, t));
+      } else {
+        o0 = reduce2(add(a, bb)); o1 = mul(sub(a, bb), w);
+      }
+#pragma unroll
+      for (int l = 0; l < NL; ++l) { sh[l * kNttTile + e0] = o0.l[l]; sh[l * kNttTile + e1] = o1.l[l]; }
+    }
+    __syncthreads();
+  }
+  for (uint32_t e = threadIdx.x; e < E; e += 256) {
+    uint32_t q, cc;
+    if (s_lo == 0) { q = e & (R - 1); cc = e >> k; } else { cc = e & (C - 1); q = e >> clog; }
+    const uint32_t le = (q << clog) + cc;
+    Fr2 v;
+#pragma unroll
+    for (int l = 0; l < NL; ++l) v.l[l] = sh[l * kNttTile + le];
+    store_fr(x + (base + (size_t)q * qstride + (size_t)cc * cstride) * 8, v);
+  }
+}
+
 // out[i] = a[i] * b[i] (Montgomery product: a b / R)
 __global__ void __launch_bounds__(256) k_pw_mul(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b,
                                                  uint32_t* __restrict__ out, uint32_t n) {

@@ -4,6 +4,7 @@
 #include "prove.h"
 
 #include <algorithm>
+#include <future>
 #include <vector>
 
 #include "point_io.h"
@@ -109,10 +110,12 @@ int groth16_prove_impl(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, cons
   // --- host work that needs no MSM result, done while the device runs (groth16.go:254-264, 274) ------
   G1Xyzz delta = xyzz_from_affine(pk->delta);
   G2Xyzz delta2 = xyzz_from_affine(pk->delta2);
+  auto f_sdelta2 = std::async(std::launch::async, [&] { return g2_mul_scalar(delta2, s); });
+  auto f_sdelta = std::async(std::launch::async, [&] { return g1_mul_scalar(delta, s); });
   G1Xyzz rdelta = g1_mul_scalar(delta, r);
-  G1Xyzz sdelta = g1_mul_scalar(delta, s);
-  G2Xyzz sdelta2 = g2_mul_scalar(delta2, s);
   G1Xyzz rsdelta = g1_mul_scalar(rdelta, s);
+  G1Xyzz sdelta = f_sdelta.get();
+  G2Xyzz sdelta2 = f_sdelta2.get();
   fork.join();
   total.stop();
   std::vector<G1Xyzz> g1w, g1h;
@@ -134,9 +137,10 @@ int groth16_prove_impl(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, cons
   xyzz_add(piB, sdelta2);                                      // + s delta2       :263-264
   G1Xyzz piC = g1w[2];
   xyzz_add(piC, g1h[0]);                                       // + sum h_i PTD_i  :269-271
-  G1Xyzz sA = g1_mul_scalar(piA, s);
+  auto f_rB = std::async(std::launch::async, [&] { return g1_mul_scalar(piB1, r); });      // two host cores for the two
+  G1Xyzz sA = g1_mul_scalar(piA, s);                                                       // result-dependent products
   xyzz_add(piC, sA);                                           // + s piA          :272
-  G1Xyzz rB = g1_mul_scalar(piB1, r);
+  G1Xyzz rB = f_rB.get();
   xyzz_add(piC, rB);                                           // + r piB1         :273
   xyzz_add(piC, xyzz_neg(rsdelta));                            // - (r s) delta    :274-275
   inf[0] = g1_to_affine_std(piA, out_proof) ? 1 : 0;
