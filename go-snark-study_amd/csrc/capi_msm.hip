@@ -164,21 +164,18 @@ int gs_init(const int* devices, int ndev) {
     if (c.ready && c.device != devices[0]) return fail(GS_ERR_ARG, "already initialised on device %d", c.device);
     if (!c.ready) {
       GS_HIP(hipStreamCreateWithFlags(&c.main_stream, hipStreamNonBlocking));
-      // The aux streams carry the latency-/bandwidth-bound shadow work of a proof (NTT passes, plan kernels,
-      // bucket combine / reduction tails).  They are confined to every 8th CU (32 of 256, 4 per XCD): an
-      // EC-arithmetic wave needs 150-256 VGPRs, so wherever it lands it evicts an accumulation wave; the
-      // mask keeps that displacement off 7/8 of the chip.  GS_AUX_CU_STRIDE=0 disables the mask.
+      // The aux streams carry the latency-/bandwidth-bound shadow work of a proof (NTT passes, plan kernels, bucket
+      // combine / reduction tails) next to the ALU-bound accumulations on the main stream.  They get the HIGHEST queue
+      // priority: their kernels are short but hard to place (k_hist wants 128 KiB of LDS and 16 wave slots of one CU),
+      // and a starved plan(h) would stall the last accumulation (seen in profiles/r01c_prove_step_timeline.txt).
       {
-        int stride = 8;
-        if (const char* e = getenv("GS_AUX_CU_STRIDE")) stride = atoi(e);
-        uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        const int ncu = std::min(256, prop.multiProcessorCount);
-        if (stride > 0) for (int i = 0; i < ncu; i += stride) mask[i >> 5] |= 1u << (i & 31);
+        int least = 0, greatest = 0;
+        GS_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
         const bool no_overlap = getenv("GS_NO_OVERLAP") != nullptr;      // debugging aid: everything on the main stream
+        const bool no_prio = getenv("GS_NO_PRIORITY") != nullptr;
         for (auto& a : c.aux_stream) {
           if (no_overlap) a = c.main_stream;
-          else if (stride > 0) GS_HIP(hipExtStreamCreateWithCUMask(&a, 8, mask));
-          else GS_HIP(hipStreamCreateWithFlags(&a, hipStreamNonBlocking));
+          else GS_HIP(hipStreamCreateWithPriority(&a, hipStreamNonBlocking, no_prio ? least : greatest));
         }
       }
       for (auto& p : c.pinned) GS_HIP(hipHostMalloc(&p, Ctx::kPinnedBytes, hipHostMallocDefault));

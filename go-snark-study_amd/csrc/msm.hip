@@ -136,10 +136,8 @@ static void msm_enqueue(Ctx& c, const MsmPlan& plan, const std::vector<MsmBase>&
   }
   p.tacc = std::make_shared<PhaseTimer>(c.stream);
   p.tker = std::make_shared<PhaseTimer>(c.stream);
-  static const int repeat = getenv("GS_REPEAT_ACC") ? atoi(getenv("GS_REPEAT_ACC")) : 1;    // clock/power experiments only
-  for (int rep = 0; rep < repeat; ++rep)
-    hipLaunchKernelGGL(k_bucket_accumulate<T>, dim3((plan.maxchunks + 255) / 256, njobs), dim3(256), 0, c.stream,
-                       jobs, plan.offsets, plan.entries, plan.chunk_bucket, plan.nbuckets);
+  hipLaunchKernelGGL(k_bucket_accumulate<T>, dim3((plan.maxchunks + 255) / 256, njobs), dim3(256), 0, c.stream,
+                     jobs, plan.offsets, plan.entries, plan.chunk_bucket, plan.nbuckets);
   p.tker->stop();
   hipLaunchKernelGGL(k_heavy_combine<T>, dim3(1024, njobs), dim3(kHeavyBlock), 0, c.stream,
                      jobs, plan.offsets, plan.heavy_list, plan.heavy_count);

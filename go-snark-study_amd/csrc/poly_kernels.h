@@ -1,4 +1,4 @@
-// Fr polynomial kernels for gfx950: radix-2 NTT stages (batched), point-wise products, series
+// Fr polynomial kernels for gfx950: fused radix-2 NTT passes (batched), point-wise products, series
 // helpers.  Replaces the reference's dense big.Int polynomial arithmetic
 // (r1csqap/r1csqap.go:57-126: schoolbook Mul O(n^2), long Div O(n^3), Eval with Exp per term).
 //
@@ -61,36 +61,6 @@ __global__ void __launch_bounds__(256) k_twiddle_gen(uint32_t* __restrict__ tw, 
     base = sqr(base);
   }
   store_fr_canon(tw + (size_t)i * 8, canon(acc));
-}
-
-// decimation-in-frequency stage (forward): natural order in, bit-reversed out after all stages.
-// butterfly t: blk = t / half, j = t % half; (a, b) -> (a + b, (a - b) * w^(j * tw_stride))
-__global__ void __launch_bounds__(256) k_ntt_dif_stage(uint32_t* __restrict__ x, uint32_t half, const uint32_t* __restrict__ tw,
-                                                        uint32_t tw_stride, uint32_t nbutterflies) {
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= nbutterflies) return;
-  const uint32_t blk = t / half, j = t - blk * half;
-  uint32_t* p0 = x + ((size_t)blk * 2 * half + j) * 8;
-  uint32_t* p1 = p0 + (size_t)half * 8;
-  const Fr6 a = load_fr(p0), b = load_fr(p1);
-  const Fr6 w = load_fr(tw + (size_t)j * tw_stride * 8);
-  store_fr(p0, reduce2(add(a, b)));
-  store_fr(p1, mul(sub(a, b), w));
-}
-
-// decimation-in-time stage (inverse): bit-reversed in, natural out.  (a, b) -> (a + b w, a - b w)
-__global__ void __launch_bounds__(256) k_ntt_dit_stage(uint32_t* __restrict__ x, uint32_t half, const uint32_t* __restrict__ tw,
-                                                        uint32_t tw_stride, uint32_t nbutterflies) {
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= nbutterflies) return;
-  const uint32_t blk = t / half, j = t - blk * half;
-  uint32_t* p0 = x + ((size_t)blk * 2 * half + j) * 8;
-  uint32_t* p1 = p0 + (size_t)half * 8;
-  const Fr6 a = load_fr(p0), b = load_fr(p1);
-  const Fr6 w = load_fr(tw + (size_t)j * tw_stride * 8);
-  const Fr2 bw = mul(b, w);
-  store_fr(p0, reduce2(add(a, bw)));
-  store_fr(p1, reduce2(sub(a, bw)));
 }
 
 // ---- fused NTT pass: k consecutive radix-2 stages on a 1024-element tile held in LDS ---------------------------------

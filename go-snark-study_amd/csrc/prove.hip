@@ -4,6 +4,7 @@
 #include "prove.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <future>
 #include <vector>
 
@@ -32,14 +33,14 @@ DevBuf g_hx;
 size_t quotient_len(size_t npx, size_t nz) { return npx >= nz ? npx - nz + 1 : 0; }
 
 // Stream layout of one proof (all device work is enqueued before the host waits once):
-//   main  : plan(w) -> accumulate G1 x3 over w -> accumulate G2 over w -> [wait plan(h)] accumulate G1 over h -> its tail
-//   aux 0 : the tails (window merge, reduction, download) of the two w groups, each after its accumulation
+//   main  : plan(w) -> accumulate G2 over w -> accumulate G1 x3 over w -> [wait plan(h)] accumulate G1 over h -> its tail
+//   aux 0 / aux 2 : the tails (bucket combine, reduction, download) of the G2 / G1 groups over w, each after its accumulation
 //   aux 1 : H(x) = P(x)/Z(x) -> plan(h)
 // The ALU-bound accumulation kernels run back to back on one stream (they would only fight for the
 // instruction cache if overlapped), and everything latency- or bandwidth-bound runs in their shadow.
 struct Fork {
   Ctx& c;
-  hipEvent_t start, planw, planh, done[2];
+  hipEvent_t start, planw, planh, done[3];
   explicit Fork(Ctx& ctx_) : c(ctx_) {
     GS_HIP(hipEventCreateWithFlags(&start, hipEventDisableTiming));
     GS_HIP(hipEventCreateWithFlags(&planw, hipEventDisableTiming));
@@ -48,8 +49,8 @@ struct Fork {
     GS_HIP(hipEventRecord(start, c.main_stream));
     for (auto s : c.aux_stream) GS_HIP(hipStreamWaitEvent(s, start, 0));
   }
-  void join() {           // main waits for both aux streams, host waits for main
-    for (int i = 0; i < 2; ++i) {
+  void join() {           // main waits for the aux streams, host waits for main
+    for (int i = 0; i < 3; ++i) {
       GS_HIP(hipEventRecord(done[i], c.aux_stream[i]));
       GS_HIP(hipStreamWaitEvent(c.main_stream, done[i], 0));
     }
@@ -88,9 +89,11 @@ int groth16_prove_impl(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, cons
     tplanw->stop();
     // BACDelta's first npublic+1 entries are forced to infinity at key creation, so the reference's
     // loop from NPublic+1 (:248-250) equals a full-range MSM sharing w's plan.
-    msm_enqueue_g1(c, plan_w, {MsmBase{&pk->t_at, 0}, MsmBase{&pk->t_bacgamma1, 0}, MsmBase{&pk->t_bacdelta, 0}}, 0, 0, pend_g1w,
-                   c.aux_stream[0]);
+    // G2 first: its accumulation (2 waves/SIMD, 256 VGPRs) is the one a foreign wave hurts most, so it runs while only the
+    // cheap H(x)/plan(h) kernels are in flight; its long combine/reduce tail then hides behind the G1 accumulations.
     msm_enqueue_g2(c, plan_w, {MsmBase{&pk->t_bacgamma2, 0}}, 4, 1, pend_g2w, c.aux_stream[0]);
+    msm_enqueue_g1(c, plan_w, {MsmBase{&pk->t_at, 0}, MsmBase{&pk->t_bacgamma1, 0}, MsmBase{&pk->t_bacdelta, 0}}, 0, 0, pend_g1w,
+                   c.aux_stream[2]);
   }
   {                                                              // aux 1: H(x), plan(h)
     StreamScope sc(c, c.aux_stream[1]);
@@ -179,7 +182,7 @@ int pinocchio_prove_impl(Ctx& c, PinocchioPkObj* pk, DevScalars w, DevScalars px
     // A and Ap run over i > NPublic only (snark.go:265-268): their first npublic+1 points were forced
     // to infinity at key creation; Bp, C, Cp, Kp and B run over all variables (:270-278).
     msm_enqueue_g1(c, plan_w, {MsmBase{&pk->t_a, 0}, MsmBase{&pk->t_ap, 0}, MsmBase{&pk->t_bp, 0}, MsmBase{&pk->t_c, 0},
-                               MsmBase{&pk->t_cp, 0}, MsmBase{&pk->t_kp, 0}}, 0, 0, pend_g1w, c.aux_stream[0]);
+                               MsmBase{&pk->t_cp, 0}, MsmBase{&pk->t_kp, 0}}, 0, 0, pend_g1w, c.aux_stream[2]);
     msm_enqueue_g2(c, plan_w, {MsmBase{&pk->t_b2, 0}}, 6, 1, pend_g2w, c.aux_stream[0]);
   }
   {

@@ -98,7 +98,7 @@ struct Ctx {
   int device = -1;
   bool ready = false;
   hipStream_t stream = nullptr;   // the stream every engine function enqueues on (switched by StreamScope)
-  hipStream_t main_stream = nullptr, aux_stream[2] = {nullptr, nullptr};
+  hipStream_t main_stream = nullptr, aux_stream[3] = {nullptr, nullptr, nullptr};
   void* pinned[3] = {nullptr, nullptr, nullptr};     // host staging for the per-stream result downloads
   static constexpr size_t kPinnedBytes = 256 * 1024;
   std::mutex mu;
