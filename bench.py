@@ -70,7 +70,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log2n", type=int, default=20)
-    ap.add_argument("--workload", default="prove", choices=["prove", "msm_g1", "msm_sharded"])
+    ap.add_argument("--workload", default="prove", choices=["prove", "prove_sharded", "msm_g1", "msm_sharded"],
+                    help="prove: one independent proof per GPU (weak scaling, the default the driver runs); prove_sharded: ONE proof "
+                         "whose MSM term ranges are split over the ranks (strong scaling, all-gather of 5 partial points)")
     ap.add_argument("--instance", default="setup", choices=["setup", "sqchain", "random"],
                     help="setup: sqchain R1CS + structured trusted setup on the device + px from the sparse system (a complete, "
                          "checkable instance, SURVEY 8d); sqchain: same R1CS with key points k_i*G; random: uniform w / px")
@@ -94,7 +96,10 @@ def main():
     capi.init(local)
 
     n = 1 << args.log2n
-    seed = 0x5EED0002 + rank
+    seed = 0x5EED0002 + (0 if args.workload == "prove_sharded" else rank)
+    sharded = args.workload == "prove_sharded"
+    if sharded:
+        args.workload = "prove"
     if args.workload == "prove":
         inst = (synth.sqchain_setup_instance(n, seed) if args.instance == "setup" else
                 synth.sqchain_instance(n, seed) if args.instance == "sqchain" else synth.random_instance(n, seed))
@@ -102,9 +107,11 @@ def main():
         r_, s_ = synth.field_elems(2, seed ^ 0xABCDEF, R)
 
         def step():
+            if sharded:
+                return groth16.prove_sharded(pk, inst.w, inst.px, r_, s_)
             return groth16.prove_resident(pk, inst.w, inst.px, r_, s_)
         units_per_step = n
-        workload = "groth16_prove_2^%d_constraints_per_gpu" % args.log2n
+        workload = ("groth16_prove_2^%d_constraints_sharded_over_all_gpus" if sharded else "groth16_prove_2^%d_constraints_per_gpu") % args.log2n
     else:
         from gosnark_amd import parallel
         nterms = n
@@ -171,7 +178,7 @@ def main():
         host_ms = (time.perf_counter() - th) / 3 * 1e3
 
     if rank == 0:
-        value = units_per_step * world * args.steps / elapsed
+        value = units_per_step * (1 if sharded else world) * args.steps / elapsed
         launches = max(tm_acc["acc_g1_launches"], 1)
         avg_launch_s = tm_acc["acc_g1_ms"] / launches * 1e-3
         bytes_per_launch = G1_TERM_BYTES * tm_acc["acc_g1_terms"] / launches
@@ -182,10 +189,11 @@ def main():
             "unit": "constraints/s" if args.workload == "prove" else "terms/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None,
             "dtype": "u32 (9x29-bit Montgomery limbs of the 254-bit BN128 fields)", "data": "synthetic",
             "config": {"workload": workload, "constraints": n, "variables": n + 1, "npublic": 1,
-                       "parallelism": "independent proofs, one per GPU" if args.workload == "prove" else args.workload,
+                       "parallelism": ("one proof, MSM term ranges sharded over the ranks, all-gather of 5 partial points" if sharded else
+                                       "independent proofs, one per GPU") if args.workload == "prove" else args.workload,
                        "instance": inst.describe() if args.workload == "prove" else "uniform random scalars, bases k_i*G"},
             "roofline": {"bound": "hbm", "kernel": "k_bucket_accumulate<G1>", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,

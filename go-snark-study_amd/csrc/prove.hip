@@ -62,14 +62,33 @@ struct Fork {
   }
 };
 
-int groth16_prove_impl(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, const uint64_t r[4], const uint64_t s[4],
-                       uint64_t out_proof[32], int inf[3]) {
+// The five raw MSM results of a proof, before the O(1) tail.
+struct GrothSums {
+  G1Xyzz at, bacgamma1, bacdelta, h;
+  G2Xyzz bacgamma2;
+};
+
+// Shard of the term ranges this call sums over (multi-GPU: rank k of N takes [k/N, (k+1)/N) of both ranges).
+struct Shard { size_t index = 0, count = 1; };
+static void shard_range(size_t n, const Shard& sh, size_t& lo, size_t& hi) {
+  const size_t q = n / sh.count, rem = n % sh.count;
+  lo = sh.index * q + std::min(sh.index, rem);
+  hi = lo + q + (sh.index < rem ? 1 : 0);
+}
+
+void groth16_tail(GrothPkObj* pk, const GrothSums& sums, const uint64_t r[4], const uint64_t s[4], uint64_t out_proof[32], int inf[3]);
+
+int groth16_sums_impl(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, const Shard& shard, GrothSums& sums) {
   if (w.n != pk->nvars) return fail(GS_ERR_SHAPE, "len(w) = %zu but the key has %zu variables", w.n, pk->nvars);
   const size_t nh = quotient_len(px.n, pk->nz);
   if (nh > pk->nptd)
     return fail(GS_ERR_SHAPE, "len(hx) = len(px) - len(Z) + 1 = %zu exceeds len(PowersTauDelta) = %zu (groth16.go:269-271)", nh, pk->nptd);
+  size_t wlo, whi, hlo, hhi;
+  shard_range(w.n, shard, wlo, whi);
+  shard_range(nh, shard, hlo, hhi);
   {
-    const int cw = choose_window_bits((uint32_t)w.n, c.window_bits), ch = choose_window_bits((uint32_t)std::max<size_t>(nh, 1), c.window_bits);
+    const int cw = choose_window_bits((uint32_t)std::max<size_t>(whi - wlo, 1), c.window_bits);
+    const int ch = choose_window_bits((uint32_t)std::max<size_t>(hhi - hlo, 1), c.window_bits);
     ensure_table_g1(c, pk->t_at, pk->at.as<uint32_t>(), pk->nvars, cw);
     ensure_table_g1(c, pk->t_bacgamma1, pk->bacgamma1.as<uint32_t>(), pk->nvars, cw);
     ensure_table_g1(c, pk->t_bacdelta, pk->bacdelta.as<uint32_t>(), pk->nvars, cw);
@@ -85,14 +104,14 @@ int groth16_prove_impl(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, cons
   {                                                              // main: plan(w), then the accumulations back to back
     StreamScope sc(c, c.main_stream);
     tplanw = std::make_shared<PhaseTimer>(c.stream);
-    build_plan(c, 0, w.p, (uint32_t)w.n, plan_w);
+    build_plan(c, 0, w.p + wlo * 8, (uint32_t)(whi - wlo), plan_w);
     tplanw->stop();
     // BACDelta's first npublic+1 entries are forced to infinity at key creation, so the reference's
     // loop from NPublic+1 (:248-250) equals a full-range MSM sharing w's plan.
     // G2 first: its accumulation (2 waves/SIMD, 256 VGPRs) is the one a foreign wave hurts most, so it runs while only the
     // cheap H(x)/plan(h) kernels are in flight; its long combine/reduce tail then hides behind the G1 accumulations.
-    msm_enqueue_g2(c, plan_w, {MsmBase{&pk->t_bacgamma2, 0}}, 4, 1, pend_g2w, c.aux_stream[0]);
-    msm_enqueue_g1(c, plan_w, {MsmBase{&pk->t_at, 0}, MsmBase{&pk->t_bacgamma1, 0}, MsmBase{&pk->t_bacdelta, 0}}, 0, 0, pend_g1w,
+    msm_enqueue_g2(c, plan_w, {MsmBase{&pk->t_bacgamma2, wlo}}, 4, 1, pend_g2w, c.aux_stream[0]);
+    msm_enqueue_g1(c, plan_w, {MsmBase{&pk->t_at, wlo}, MsmBase{&pk->t_bacgamma1, wlo}, MsmBase{&pk->t_bacdelta, wlo}}, 0, 0, pend_g1w,
                    c.aux_stream[2]);
   }
   {                                                              // aux 1: H(x), plan(h)
@@ -101,24 +120,15 @@ int groth16_prove_impl(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, cons
     if (nh) poly_quotient_dev(c, pk->z, px.p, px.n, g_hx.as<uint32_t>());      // groth16.go:266
     tpoly->stop();
     tplanh = std::make_shared<PhaseTimer>(c.stream);
-    build_plan(c, 1, g_hx.as<uint32_t>(), (uint32_t)nh, plan_h);
+    build_plan(c, 1, g_hx.as<uint32_t>() + hlo * 8, (uint32_t)(hhi - hlo), plan_h);
     tplanh->stop();
     GS_HIP(hipEventRecord(fork.planh, c.stream));
   }
   {                                                              // main again: sum h_i PTD_i once plan(h) exists
     StreamScope sc(c, c.main_stream);
     GS_HIP(hipStreamWaitEvent(c.stream, fork.planh, 0));
-    msm_enqueue_g1(c, plan_h, {MsmBase{&pk->t_ptd, 0}}, 3, 2, pend_h);          // :269-271
+    msm_enqueue_g1(c, plan_h, {MsmBase{&pk->t_ptd, hlo}}, 3, 2, pend_h);        // :269-271
   }
-  // --- host work that needs no MSM result, done while the device runs (groth16.go:254-264, 274) ------
-  G1Xyzz delta = xyzz_from_affine(pk->delta);
-  G2Xyzz delta2 = xyzz_from_affine(pk->delta2);
-  auto f_sdelta2 = std::async(std::launch::async, [&] { return g2_mul_scalar(delta2, s); });
-  auto f_sdelta = std::async(std::launch::async, [&] { return g1_mul_scalar(delta, s); });
-  G1Xyzz rdelta = g1_mul_scalar(delta, r);
-  G1Xyzz rsdelta = g1_mul_scalar(rdelta, s);
-  G1Xyzz sdelta = f_sdelta.get();
-  G2Xyzz sdelta2 = f_sdelta2.get();
   fork.join();
   total.stop();
   std::vector<G1Xyzz> g1w, g1h;
@@ -128,28 +138,63 @@ int groth16_prove_impl(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, cons
   msm_finish_g1(c, pend_h, g1h);
   c.timing.poly_ms += tpoly->ms();
   c.timing.plan_ms += tplanw->ms() + tplanh->ms();
-  // --- O(1) tail on the host core (groth16.go:253-275) ----------------------------------------------
-  G1Xyzz piA = g1w[0];
+  c.timing.total_ms += total.ms();
+  sums.at = g1w[0]; sums.bacgamma1 = g1w[1]; sums.bacdelta = g1w[2]; sums.h = g1h[0]; sums.bacgamma2 = g2w[0];
+  return GS_OK;
+}
+
+// --- the O(1) tail on host cores (groth16.go:253-275) ----------------------------------------------------
+struct GrothTailPre {             // the products that need no MSM result (computed while the device runs)
+  std::future<G2Xyzz> sdelta2;
+  std::future<G1Xyzz> sdelta;
+  G1Xyzz rdelta, rsdelta;
+};
+static void groth16_tail_pre(GrothPkObj* pk, const uint64_t r[4], const uint64_t s[4], GrothTailPre& pre) {
+  const G1Xyzz delta = xyzz_from_affine(pk->delta);
+  const G2Xyzz delta2 = xyzz_from_affine(pk->delta2);
+  pre.sdelta2 = std::async(std::launch::async, [delta2, s] { return g2_mul_scalar(delta2, s); });
+  pre.sdelta = std::async(std::launch::async, [delta, s] { return g1_mul_scalar(delta, s); });
+  pre.rdelta = g1_mul_scalar(delta, r);
+  pre.rsdelta = g1_mul_scalar(pre.rdelta, s);
+}
+static void groth16_tail_post(GrothPkObj* pk, const GrothSums& sums, GrothTailPre& pre, const uint64_t r[4], const uint64_t s[4],
+                              uint64_t out_proof[32], int inf[3]) {
+  G1Xyzz piA = sums.at;
   xyzz_madd(piA, pk->alpha);                                   // + alpha          :253
-  xyzz_add(piA, rdelta);                                       // + r delta        :254-255
-  G1Xyzz piB1 = g1w[1];
+  xyzz_add(piA, pre.rdelta);                                   // + r delta        :254-255
+  G1Xyzz piB1 = sums.bacgamma1;
   xyzz_madd(piB1, pk->beta);                                   // + beta           :259
-  xyzz_add(piB1, sdelta);                                      // + s delta        :261-262
-  G2Xyzz piB = g2w[0];
+  xyzz_add(piB1, pre.sdelta.get());                            // + s delta        :261-262
+  G2Xyzz piB = sums.bacgamma2;
   xyzz_madd(piB, pk->beta2);                                   // + beta2          :260
-  xyzz_add(piB, sdelta2);                                      // + s delta2       :263-264
-  G1Xyzz piC = g1w[2];
-  xyzz_add(piC, g1h[0]);                                       // + sum h_i PTD_i  :269-271
-  auto f_rB = std::async(std::launch::async, [&] { return g1_mul_scalar(piB1, r); });      // two host cores for the two
-  G1Xyzz sA = g1_mul_scalar(piA, s);                                                       // result-dependent products
+  xyzz_add(piB, pre.sdelta2.get());                            // + s delta2       :263-264
+  G1Xyzz piC = sums.bacdelta;
+  xyzz_add(piC, sums.h);                                       // + sum h_i PTD_i  :269-271
+  auto f_rB = std::async(std::launch::async, [piB1, r] { return g1_mul_scalar(piB1, r); });   // two host cores for the two
+  G1Xyzz sA = g1_mul_scalar(piA, s);                                                          // result-dependent products
   xyzz_add(piC, sA);                                           // + s piA          :272
-  G1Xyzz rB = f_rB.get();
-  xyzz_add(piC, rB);                                           // + r piB1         :273
-  xyzz_add(piC, xyzz_neg(rsdelta));                            // - (r s) delta    :274-275
+  xyzz_add(piC, f_rB.get());                                   // + r piB1         :273
+  xyzz_add(piC, xyzz_neg(pre.rsdelta));                        // - (r s) delta    :274-275
   inf[0] = g1_to_affine_std(piA, out_proof) ? 1 : 0;
   inf[1] = g2_to_affine_std(piB, out_proof + 8) ? 1 : 0;
   inf[2] = g1_to_affine_std(piC, out_proof + 24) ? 1 : 0;
-  c.timing.total_ms += total.ms();
+}
+void groth16_tail(GrothPkObj* pk, const GrothSums& sums, const uint64_t r[4], const uint64_t s[4], uint64_t out_proof[32], int inf[3]) {
+  GrothTailPre pre;
+  groth16_tail_pre(pk, r, s, pre);
+  groth16_tail_post(pk, sums, pre, r, s, out_proof, inf);
+}
+
+int groth16_prove_impl(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, const uint64_t r[4], const uint64_t s[4],
+                       uint64_t out_proof[32], int inf[3]) {
+  // the result-independent tail products run on other host cores while this thread enqueues and waits for the device
+  GrothTailPre pre;
+  std::future<void> fpre = std::async(std::launch::async, [&] { groth16_tail_pre(pk, r, s, pre); });
+  GrothSums sums;
+  const int rc = groth16_sums_impl(c, pk, w, px, Shard{}, sums);
+  fpre.get();
+  if (rc != GS_OK) return rc;
+  groth16_tail_post(pk, sums, pre, r, s, out_proof, inf);
   return GS_OK;
 }
 
@@ -387,6 +432,60 @@ int gs_groth16_prove_resident(gs_handle hpk, gs_handle hw, gs_handle hpx, const 
     if (!r || !s || !out_proof || !inf) return fail(GS_ERR_ARG, "null argument");
     reset_timing(c);
     return groth16_prove_impl(c, pk, DevScalars{w->buf.as<uint32_t>(), w->n}, DevScalars{px->buf.as<uint32_t>(), px->n}, r, s, out_proof, inf);
+  });
+}
+
+// Sharded proving: the five raw sums over this rank's term ranges, as affine points.
+int gs_groth16_prove_partials(gs_handle hpk, gs_handle hw, gs_handle hpx, size_t shard_index, size_t shard_count,
+                              uint64_t out_sums[48], int inf[5]) {
+  return guarded([&](Ctx& c) -> int {
+    GrothPkObj* pk = c.get<GrothPkObj>(hpk, Kind::GrothPk);
+    Scalars* w = c.get<Scalars>(hw, Kind::Scalars);
+    Scalars* px = c.get<Scalars>(hpx, Kind::Scalars);
+    if (!pk || !w || !px) return fail(GS_ERR_ARG, "gs_groth16_prove_partials: bad handle");
+    if (!out_sums || !inf || shard_count == 0 || shard_index >= shard_count) return fail(GS_ERR_ARG, "gs_groth16_prove_partials: bad shard or null output");
+    reset_timing(c);
+    GrothSums sums;
+    Shard sh; sh.index = shard_index; sh.count = shard_count;
+    const int rc = groth16_sums_impl(c, pk, DevScalars{w->buf.as<uint32_t>(), w->n}, DevScalars{px->buf.as<uint32_t>(), px->n}, sh, sums);
+    if (rc != GS_OK) return rc;
+    inf[0] = g1_to_affine_std(sums.at, out_sums) ? 1 : 0;
+    inf[1] = g1_to_affine_std(sums.bacgamma1, out_sums + 8) ? 1 : 0;
+    inf[2] = g2_to_affine_std(sums.bacgamma2, out_sums + 16) ? 1 : 0;
+    inf[3] = g1_to_affine_std(sums.bacdelta, out_sums + 32) ? 1 : 0;
+    inf[4] = g1_to_affine_std(sums.h, out_sums + 40) ? 1 : 0;
+    return GS_OK;
+  });
+}
+
+// ... and the O(1) tail of groth16.go:253-275 on the combined sums (same layout as gs_groth16_prove_partials emits).
+int gs_groth16_finish(gs_handle hpk, const uint64_t sums_in[48], const int inf_in[5], const uint64_t r[4], const uint64_t s[4],
+                      uint64_t out_proof[32], int inf[3]) {
+  return guarded([&](Ctx& c) -> int {
+    GrothPkObj* pk = c.get<GrothPkObj>(hpk, Kind::GrothPk);
+    if (!pk) return fail(GS_ERR_ARG, "gs_groth16_finish: bad proving-key handle");
+    if (!sums_in || !inf_in || !r || !s || !out_proof || !inf) return fail(GS_ERR_ARG, "null argument");
+    auto g1 = [&](const uint64_t* p, int isinf) -> G1Xyzz {
+      if (isinf) return xyzz_inf<FqTag>();
+      const uint32_t* w32 = reinterpret_cast<const uint32_t*>(p);
+      G1Affine a;
+      a.x = canon(PointIO<FqTag>::load_std(w32)); a.y = canon(PointIO<FqTag>::load_std(w32 + 8));
+      return xyzz_from_affine(a);
+    };
+    GrothSums sums;
+    sums.at = g1(sums_in, inf_in[0]);
+    sums.bacgamma1 = g1(sums_in + 8, inf_in[1]);
+    if (inf_in[2]) sums.bacgamma2 = xyzz_inf<Fq2Tag>();
+    else {
+      const uint32_t* w32 = reinterpret_cast<const uint32_t*>(sums_in + 16);
+      G2Affine a;
+      a.x = canon(PointIO<Fq2Tag>::load_std(w32)); a.y = canon(PointIO<Fq2Tag>::load_std(w32 + 16));
+      sums.bacgamma2 = xyzz_from_affine(a);
+    }
+    sums.bacdelta = g1(sums_in + 32, inf_in[3]);
+    sums.h = g1(sums_in + 40, inf_in[4]);
+    groth16_tail(pk, sums, r, s, out_proof, inf);
+    return GS_OK;
   });
 }
 

@@ -174,3 +174,54 @@ def prove_resident(dev_pk, w_handle, px_handle, r, s):
     capi.check(capi.load_library().gs_groth16_prove_resident(capi.Handle(dev_pk.handle.h), capi.Handle(w_handle.h), capi.Handle(px_handle.h),
                                                              capi.ptr64(rs[0]), capi.ptr64(rs[1]), capi.ptr64(out), inf))
     return _proof_from_words(out, inf)
+
+
+def prove_partials(dev_pk, w_handle, px_handle, shard_index, shard_count):
+    """This rank's five raw MSM sums (gs_groth16_prove_partials): [At, G1.BACGamma, G2.BACGamma, BACDelta, h.PTD] as affine
+    points / None, plus the g2 flags parallel.allgather_points wants."""
+    import ctypes
+    out = np.zeros(48, dtype=np.uint64)
+    inf = (ctypes.c_int * 5)()
+    capi.check(capi.load_library().gs_groth16_prove_partials(capi.Handle(dev_pk.handle.h), capi.Handle(w_handle.h), capi.Handle(px_handle.h),
+                                                             shard_index, shard_count, capi.ptr64(out), inf))
+    v = capi.u64_to_ints(out)
+    pts = [None if inf[0] else (v[0], v[1]), None if inf[1] else (v[2], v[3]),
+           None if inf[2] else ((v[4], v[5]), (v[6], v[7])), None if inf[3] else (v[8], v[9]), None if inf[4] else (v[10], v[11])]
+    return pts, SUM_IS_G2
+
+
+SUM_IS_G2 = [False, False, True, False, False]
+
+
+def finish(dev_pk, sums, r, s):
+    """gs_groth16_finish: the O(1) tail of groth16.go:253-275 on the (combined) five sums."""
+    import ctypes
+    flat, infs = [], []
+    for p, g2 in zip(sums, SUM_IS_G2):
+        words = 4 if g2 else 2
+        if p is None:
+            flat += [0] * words
+            infs.append(1)
+        else:
+            flat += ([p[0][0], p[0][1], p[1][0], p[1][1]] if g2 else [p[0], p[1]])
+            infs.append(0)
+    arr = capi.ints_to_u64(flat).reshape(-1)
+    ia = (ctypes.c_int * 5)(*infs)
+    out = np.zeros(32, dtype=np.uint64)
+    inf = (ctypes.c_int * 3)()
+    rs = capi.ints_to_u64([r % R, s % R])
+    capi.check(capi.load_library().gs_groth16_finish(capi.Handle(dev_pk.handle.h), capi.ptr64(arr), ia, capi.ptr64(rs[0]), capi.ptr64(rs[1]),
+                                                     capi.ptr64(out), inf))
+    return _proof_from_words(out, inf)
+
+
+def prove_sharded(dev_pk, w_handle, px_handle, r, s, group=None):
+    """One proof over all ranks of `group` (one process per GPU): local sums over this rank's term ranges -> ONE all-gather of
+    the 5 partial points per rank -> local combination -> tail.  Every rank returns the same Proof."""
+    import torch.distributed as dist
+    from . import parallel
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    pts, flags = prove_partials(dev_pk, w_handle, px_handle, rank, world)
+    per_rank = parallel.allgather_points(pts, flags, group)
+    return finish(dev_pk, parallel.combine_partials(per_rank, flags), r, s)

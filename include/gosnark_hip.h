@@ -153,6 +153,17 @@ int gs_groth16_prove(gs_handle pk, const uint64_t* w, size_t nw, const uint64_t*
 int gs_groth16_prove_resident(gs_handle pk, gs_handle w, gs_handle px,
                               const uint64_t r[4], const uint64_t s[4], uint64_t out_proof[32], int inf[3]);
 
+/* One proof over several GPUs: every rank holds the key and the resident w / px, takes shard `shard_index` of
+ * `shard_count` of the term ranges (contiguous, first ranges one longer when they do not divide), computes H(x) locally
+ * (the polynomial stage is replicated) and returns its five raw MSM sums as affine points:
+ * out_sums = At (8 words) | G1.BACGamma (8) | G2.BACGamma (16) | BACDelta (8) | PowersTauDelta.h (8); inf[5] in that order.
+ * The ranks exchange these 416-byte records (ncclAllGather as bytes), add them with gs_g1_sum_affine / gs_g2_sum_affine
+ * and call gs_groth16_finish, which applies the O(1) tail of groth16.go:253-275. */
+int gs_groth16_prove_partials(gs_handle pk, gs_handle w, gs_handle px, size_t shard_index, size_t shard_count,
+                              uint64_t out_sums[48], int inf[5]);
+int gs_groth16_finish(gs_handle pk, const uint64_t sums[48], const int inf_in[5], const uint64_t r[4], const uint64_t s[4],
+                      uint64_t out_proof[32], int inf[3]);
+
 /* groth16.GenerateTrustedSetup (groth16.go:94-222) for a SPARSE R1CS (A, B, C in CSR over n constraints x m
  * variables, as gs_r1cs_to_px), with the five toxic scalars injected (what Utils.FqR.Rand() returned at :99-119):
  * toxic = T | Kalpha | Kbeta | Kgamma | Kdelta (5 x 4 words).  Builds the proving key directly on the device --

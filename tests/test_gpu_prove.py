@@ -344,3 +344,22 @@ def test_full_pipeline_proof_matches_closed_form_from_toxic_values(logn):
     assert (proof.PiA[0], proof.PiA[1]) == wa
     assert (proof.PiB[0], proof.PiB[1]) == wb
     assert (proof.PiC[0], proof.PiC[1]) == wc
+
+
+@pytest.mark.parametrize("shards", [1, 2, 3, 8])
+def test_sharded_prove_equals_single_device_prove(shards):
+    """SURVEY 8e on one device: the proof assembled from `shards` logical ranks (gs_groth16_prove_partials per shard, the
+    library's host-side complete addition for the exchange step, gs_groth16_finish) equals gs_groth16_prove_resident."""
+    from gosnark_amd import synth
+    n = 1 << 12
+    inst = synth.sqchain_setup_instance(n, 0x5A5A)
+    pk = inst.device_pk()
+    r, s = synth.field_elems(2, 99)
+    want = groth16.prove_resident(pk, inst.w, inst.px, r, s)
+    parts = [groth16.prove_partials(pk, inst.w, inst.px, k, shards)[0] for k in range(shards)]
+    combined = [capi.sum_affine([parts[k][i] for k in range(shards)], g2=g2) for i, g2 in enumerate(groth16.SUM_IS_G2)]
+    got = groth16.finish(pk, combined, r, s)
+    assert (got.PiA, got.PiB, got.PiC) == (want.PiA, want.PiB, want.PiC)
+    # world size 1 through the torch.distributed-shaped entry point
+    one = groth16.prove_sharded(pk, inst.w, inst.px, r, s)
+    assert (one.PiA, one.PiB, one.PiC) == (want.PiA, want.PiB, want.PiC)

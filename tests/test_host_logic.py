@@ -1,0 +1,69 @@
+"""CPU-only checks of the host-side logic around the C ABI (no GPU, no compute calls): limb packing, CSR builders,
+the sqchain synthetic circuit of SURVEY.md 8d and the reference-shaped containers."""
+import numpy as np
+
+import gosnark_amd  # noqa: F401
+from gosnark_amd import capi, r1csqap, synth
+from oracle import ref_py as O
+
+
+def test_limb_packing_roundtrip_matches_big_int_bits():
+    vals = [0, 1, O.R - 1, O.Q - 1, (1 << 256) - 1, 0x0123456789ABCDEF0FEDCBA987654321]
+    arr = capi.ints_to_u64(vals)
+    assert arr.shape == (len(vals), 4) and arr.dtype == np.uint64
+    assert capi.u64_to_ints(arr) == vals
+    # little-endian 64-bit words, exactly big.Int.Bits() padded to 4
+    assert [int(x) for x in arr[5]] == [0x0FEDCBA987654321, 0x0123456789ABCDEF, 0, 0]
+    g1 = capi.g1_points_to_u64([(1, 2, 3)])
+    assert g1.shape == (1, 12) and int(g1[0, 0]) == 1 and int(g1[0, 4]) == 2 and int(g1[0, 8]) == 3
+    g2 = capi.g2_points_to_u64([((1, 2), (3, 4), (5, 6))])
+    assert g2.shape == (1, 24) and [int(g2[0, 4 * i]) for i in range(6)] == [1, 2, 3, 4, 5, 6]
+
+
+def test_csr_from_rows():
+    rp, cl, vl = r1csqap.csr_from_rows([{2: 5, 0: 1}, {}, {1: -1}])
+    assert list(rp) == [0, 2, 2, 3] and list(cl) == [0, 2, 1]
+    assert capi.u64_to_ints(vl) == [1, 5, O.R - 1]
+
+
+def _dense(csr, n, m):
+    rp, cl, vl = csr
+    vals = capi.u64_to_ints(vl)
+    mat = [[0] * m for _ in range(n)]
+    for j in range(n):
+        for e in range(int(rp[j]), int(rp[j + 1])):
+            mat[j][int(cl[e])] = vals[e]
+    return mat
+
+
+def test_sqchain_circuit_is_satisfied_and_shaped_like_the_survey_says():
+    for n in (1, 2, 8, 24):
+        a, b, c, w = synth.sqchain_r1cs(n, 987654321)
+        m = n + 1
+        wi = capi.u64_to_ints(w)
+        assert len(wi) == m and wi[0] == 1 and wi[1] == 987654321
+        A, B, C = (_dense(x, n, m) for x in (a, b, c))
+        dot = lambda row: sum(x * y for x, y in zip(row, wi)) % O.R   # noqa: E731
+        for j in range(n):
+            assert dot(A[j]) * dot(B[j]) % O.R == dot(C[j]), (n, j)
+        assert int(a[0][n]) == n and int(b[0][n]) == n and int(c[0][n]) == 2 * n - 1      # nnz: A = n, B = n, C = 2n - 1
+        if n >= 2:
+            assert wi[2] == (wi[1] * wi[1] + 1) % O.R          # s_2 = s_1^2 + 1
+        # the reference's dense flow accepts it (n <= 21: before NewPolZeroAt's int overflow): px / Z leaves no remainder
+        if 2 <= n <= 8:
+            al, be, ga, z = O.PF.R1CSToQAP(A, B, C)
+            _, _, _, px = O.PF.CombinePolynomials(wi, al, be, ga)
+            hx, rem = O.PF.Div(px, z)
+            assert all(v == 0 for v in rem) and len(px) == 2 * n - 1 and len(z) == m - 1 and len(hx) == n
+
+
+def test_reference_shaped_containers():
+    from gosnark_amd import groth16, snark
+    circ = groth16.Circuit(8, 1)
+    assert (circ.NVars, circ.NPublic) == (8, 1)
+    pk = groth16.Pk(BACDelta=[], Z=[1], G1_Alpha=(0, 0, 0), G1_Beta=(0, 0, 0), G1_Delta=(0, 0, 0), G1_At=[], G1_BACGamma=[],
+                    G2_Beta=None, G2_Delta=None, G2_BACGamma=[], PowersTauDelta=[])
+    assert pk._dev is None
+    assert snark.Proof.FIELDS == ("PiA", "PiAp", "PiB", "PiBp", "PiC", "PiCp", "PiH", "PiKp")     # snark.go:59-69
+    r = groth16.FqRRand()
+    assert 0 <= r < O.R and r < (1 << 240)                       # 30 random bytes (fields/fq.go:116-132)
