@@ -70,6 +70,9 @@ _SIGS = {
     "gs_groth16_setup": [ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, u32p, u32p, u64p, u32p, u32p, u64p, u32p, u32p, u64p,
                          u64p, ctypes.POINTER(Handle), u64p],
     "gs_groth16_pk_export": [Handle, ctypes.c_int, u64p, ctypes.c_size_t],
+    "gs_pinocchio_setup": [ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, u32p, u32p, u64p, u32p, u32p, u64p, u32p, u32p, u64p,
+                           u64p, ctypes.POINTER(Handle), u64p],
+    "gs_pinocchio_pk_export": [Handle, ctypes.c_int, u64p, ctypes.c_size_t],
     "gs_pinocchio_pk_create": [Handle, Handle, Handle, Handle, Handle, Handle, Handle, Handle, u64p,
                                ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, ctypes.POINTER(Handle)],
     "gs_pinocchio_prove": [Handle, u64p, ctypes.c_size_t, u64p, ctypes.c_size_t, u64p, intp],

@@ -69,6 +69,10 @@ const uint32_t* interpolation_weights_dev(Ctx& c, size_t n);                    
 void lagrange_at_dev(Ctx& c, size_t n, const uint64_t tau[4], const uint64_t mtau[4], uint32_t* out_mont);   // L_j(tau), j = 1..n
 void setup_scalars_dev(Ctx& c, const uint32_t* at, const uint32_t* bt, const uint32_t* ct, size_t m, size_t npublic, const uint64_t kalpha[4],
                        const uint64_t kbeta[4], const uint64_t inv_delta[4], const uint64_t inv_gamma[4], uint32_t* cd, uint32_t* ic);
+// out[0..6] = sa, sb, sc, sap, sbp, scp, skp (standard form), see k_pinocchio_scalars
+void pinocchio_scalars_dev(Ctx& c, const uint32_t* at, const uint32_t* bt, const uint32_t* ct, size_t m, const uint64_t rhoa[4], const uint64_t rhob[4],
+                           const uint64_t rhoc[4], const uint64_t ka[4], const uint64_t kb[4], const uint64_t kc[4], const uint64_t kbeta[4],
+                           uint32_t* const out[7]);
 void scaled_powers_dev(Ctx& c, const uint64_t base[4], const uint64_t scale_std[4], size_t count, uint32_t* out_std);
 
 }  // namespace gs

@@ -355,6 +355,15 @@ void setup_scalars_dev(Ctx& c, const uint32_t* at, const uint32_t* bt, const uin
   GS_HIP(hipGetLastError());
 }
 
+void pinocchio_scalars_dev(Ctx& c, const uint32_t* at, const uint32_t* bt, const uint32_t* ct, size_t m, const uint64_t rhoa[4], const uint64_t rhob[4],
+                           const uint64_t rhoc[4], const uint64_t ka[4], const uint64_t kb[4], const uint64_t kc[4], const uint64_t kbeta[4],
+                           uint32_t* const out[7]) {
+  PinoConsts k{fr_const_from_words(rhoa), fr_const_from_words(rhob), fr_const_from_words(rhoc), fr_const_from_words(ka), fr_const_from_words(kb),
+               fr_const_from_words(kc), fr_const_from_words(kbeta)};
+  if (m) hipLaunchKernelGGL(k_pinocchio_scalars, grid1(m), dim3(256), 0, c.stream, at, bt, ct, (uint32_t)m, k, out[0], out[1], out[2], out[3], out[4], out[5], out[6]);
+  GS_HIP(hipGetLastError());
+}
+
 void scaled_powers_dev(Ctx& c, const uint64_t base[4], const uint64_t scale_std[4], size_t count, uint32_t* out_std) {
   // scale is passed in STANDARD limbs (not converted): acc starts as the raw value, Montgomery products by base keep it standard
   FrConst sc;

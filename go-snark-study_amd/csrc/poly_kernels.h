@@ -295,6 +295,28 @@ __global__ void __launch_bounds__(256) k_setup_scalars(const uint32_t* __restric
     store_fr_canon(ic + (size_t)i * 8, canon(mul(u, from_const(inv_gamma))));
   }
 }
+// Pinocchio key scalars (snark.go:178-216), per variable i, from at/bt/ct (standard form; constants Montgomery):
+//   sa = rhoA at, sb = rhoB bt, sc = rhoC ct, sap = ka sa, sbp = kb sb, scp = kc sc, skp = kbeta (sa + sb + sc)
+struct PinoConsts { FrConst rhoa, rhob, rhoc, ka, kb, kc, kbeta; };
+__global__ void __launch_bounds__(256) k_pinocchio_scalars(const uint32_t* __restrict__ at, const uint32_t* __restrict__ bt, const uint32_t* __restrict__ ct,
+                                                            uint32_t m, PinoConsts k, uint32_t* __restrict__ sa, uint32_t* __restrict__ sb,
+                                                            uint32_t* __restrict__ sc, uint32_t* __restrict__ sap, uint32_t* __restrict__ sbp,
+                                                            uint32_t* __restrict__ scp, uint32_t* __restrict__ skp) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  const size_t o = (size_t)i * 8;
+  const Fr2 a = mul(load_fr(at + o), from_const(k.rhoa));
+  const Fr2 b = mul(load_fr(bt + o), from_const(k.rhob));
+  const Fr2 c = mul(load_fr(ct + o), from_const(k.rhoc));
+  store_fr_canon(sa + o, canon(a));
+  store_fr_canon(sb + o, canon(b));
+  store_fr_canon(sc + o, canon(c));
+  store_fr_canon(sap + o, canon(mul(a, from_const(k.ka))));
+  store_fr_canon(sbp + o, canon(mul(b, from_const(k.kb))));
+  store_fr_canon(scp + o, canon(mul(c, from_const(k.kc))));
+  store_fr_canon(skp + o, canon(mul(reduce2(add(add(a, b), c)), from_const(k.kbeta))));
+}
+
 // out[i] = scale * base^i (standard form out when `scale` is standard and base Montgomery): PowersTauDelta scalars :139-149
 __global__ void __launch_bounds__(256) k_scaled_powers(uint32_t* __restrict__ out, uint32_t count, FrConst base_m, FrConst scale) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;

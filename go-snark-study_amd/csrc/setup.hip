@@ -60,6 +60,10 @@ void eval_columns(Ctx& c, const HostCsc& csc, size_t n, size_t m, const uint32_t
   GS_HIP(hipStreamSynchronize(c.stream));
 }
 
+void force_infinity_points(Ctx& c, DevBuf& pts, size_t count, size_t words) {
+  if (count) GS_HIP(hipMemsetAsync(pts.p, 0, count * words * 4, c.stream));
+}
+
 template <class T>
 Affine<T> download_point(Ctx& c, const uint32_t* packed_dev) {
   uint32_t w[PointIO<T>::kAffineWords];
@@ -158,6 +162,91 @@ int gs_groth16_setup(size_t n, size_t m, size_t npublic,
   });
 }
 
+// snark.GenerateTrustedSetup (snark.go:98-251) for a sparse R1CS, toxic = T | Ka | Kb | Kc | Kbeta | Kgamma | RhoA | RhoB.
+int gs_pinocchio_setup(size_t n, size_t m, size_t npublic,
+                       const uint32_t* a_rowptr, const uint32_t* a_col, const uint64_t* a_val,
+                       const uint32_t* b_rowptr, const uint32_t* b_col, const uint64_t* b_val,
+                       const uint32_t* c_rowptr, const uint32_t* c_col, const uint64_t* c_val,
+                       const uint64_t toxic[32], gs_handle* pk_out, uint64_t* vk_out) {
+  return guarded([&](Ctx& c) -> int {
+    if (!a_rowptr || !b_rowptr || !c_rowptr || !toxic || !pk_out) return fail(GS_ERR_ARG, "gs_pinocchio_setup: null argument");
+    if (n == 0 || m < 2 || npublic + 1 > m) return fail(GS_ERR_SHAPE, "gs_pinocchio_setup: need n >= 1, m >= 2, NPublic + 1 <= m");
+    if (n >= (1ull << 26) || m >= (1ull << 26)) return fail(GS_ERR_ARG, "gs_pinocchio_setup: system too large");
+    if (m < n + 1 || m > 2 * n + 1) return fail(GS_ERR_SHAPE, "gs_pinocchio_setup: need n + 1 <= m <= 2n + 1 (len(hx) must fit len(G1T), snark.go:284-286)");
+    const uint64_t *T = toxic, *Ka = toxic + 4, *Kb = toxic + 8, *Kc = toxic + 12, *Kbeta = toxic + 16, *Kgamma = toxic + 20, *RhoA = toxic + 24,
+                   *RhoB = toxic + 28;
+    HostCsc ca, cb, cc;
+    if (const char* e = csr_to_csc(n, m, a_rowptr, a_col, a_val, ca)) return fail(GS_ERR_ARG, "gs_pinocchio_setup: A: %s", e);
+    if (const char* e = csr_to_csc(n, m, b_rowptr, b_col, b_val, cb)) return fail(GS_ERR_ARG, "gs_pinocchio_setup: B: %s", e);
+    if (const char* e = csr_to_csc(n, m, c_rowptr, c_col, c_val, cc)) return fail(GS_ERR_ARG, "gs_pinocchio_setup: C: %s", e);
+    uint64_t mt[4], zt[4], rhoc[4], kbg[4], rhoczt[4];
+    fr_falling_product_words(T, n, mt);
+    fr_falling_product_words(T, m - 2, zt);
+    if (fr_is_zero_words(mt)) return fail(GS_ERR_ARG, "gs_pinocchio_setup: tau collides with an interpolation node");
+    fr_mul_words(RhoA, RhoB, rhoc);                       // :149
+    fr_mul_words(Kbeta, Kgamma, kbg);                     // :172
+    fr_mul_words(rhoc, zt, rhoczt);                       // :233-235
+    DevBuf lag(n * 32), at(m * 32), bt(m * 32), ct(m * 32), sc[7], pw((m - 1) * 32);
+    lagrange_at_dev(c, n, T, mt, lag.as<uint32_t>());
+    eval_columns(c, ca, n, m, lag.as<uint32_t>(), at.as<uint32_t>());
+    eval_columns(c, cb, n, m, lag.as<uint32_t>(), bt.as<uint32_t>());
+    eval_columns(c, cc, n, m, lag.as<uint32_t>(), ct.as<uint32_t>());
+    uint32_t* outs[7];
+    for (int i = 0; i < 7; ++i) { sc[i].alloc(m * 32); outs[i] = sc[i].as<uint32_t>(); }
+    pinocchio_scalars_dev(c, at.as<uint32_t>(), bt.as<uint32_t>(), ct.as<uint32_t>(), m, RhoA, RhoB, rhoc, Ka, Kb, Kc, Kbeta, outs);
+    const uint64_t one[4] = {1, 0, 0, 0};
+    scaled_powers_dev(c, T, one, m - 1, pw.as<uint32_t>());                          // G1T_i = tau^i G1      :239-247
+    auto pk = std::make_unique<PinocchioPkObj>();
+    pk->nvars = m; pk->npublic = npublic; pk->nz = m - 1; pk->ng1t = m - 1;
+    DevBuf* g1dst[7] = {&pk->a, nullptr, &pk->c, &pk->ap, &pk->bp, &pk->cp, &pk->kp};   // sb -> B lives in G2
+    for (int i = 0; i < 7; ++i) {
+      if (!g1dst[i]) continue;
+      g1dst[i]->alloc(m * 64);
+      fixed_base_g1(c, outs[i], (uint32_t)m, g1dst[i]->as<uint32_t>());
+    }
+    pk->b2.alloc(m * 128);
+    fixed_base_g2(c, outs[1], (uint32_t)m, pk->b2.as<uint32_t>());                   // Pk.B                 :192-194
+    pk->g1t.alloc((m - 1) * 64);
+    fixed_base_g1(c, pw.as<uint32_t>(), (uint32_t)(m - 1), pk->g1t.as<uint32_t>());
+    DevBuf zc((m - 1) * 32);
+    zpoly_dev(c, m - 2, zc.as<uint32_t>());
+    divisor_init(c, pk->z, zc.as<uint32_t>(), m - 1);
+    if (vk_out) {
+      // Vka (G2) | Vkb (G1) | Vkc (G2) | G1Kbg | G2Kbg | G2Kg | Vkz | IC[0..NPublic]       :162-175, 186-188, 236
+      const size_t nic = npublic + 1;
+      uint64_t s1h[8], s2h[20];
+      memcpy(s1h, Kb, 32); memcpy(s1h + 4, kbg, 32);
+      memcpy(s2h, Ka, 32); memcpy(s2h + 4, Kc, 32); memcpy(s2h + 8, kbg, 32); memcpy(s2h + 12, Kgamma, 32); memcpy(s2h + 16, rhoczt, 32);
+      DevBuf s1(64), s2(160), p1((2 + nic) * 64), p2(5 * 128), j1((2 + nic) * 96), j2(5 * 192);
+      GS_HIP(hipMemcpyAsync(s1.p, s1h, 64, hipMemcpyHostToDevice, c.stream));
+      GS_HIP(hipMemcpyAsync(s2.p, s2h, 160, hipMemcpyHostToDevice, c.stream));
+      fixed_base_g1(c, s1.as<uint32_t>(), 2, p1.as<uint32_t>());
+      GS_HIP(hipMemcpyAsync(p1.as<uint32_t>() + 32, pk->a.p, nic * 64, hipMemcpyDeviceToDevice, c.stream));    // IC = A[0..NPublic]
+      fixed_base_g2(c, s2.as<uint32_t>(), 5, p2.as<uint32_t>());
+      affine_to_jacobian_std_g1(c, p1.as<uint32_t>(), (uint32_t)(2 + nic), j1.as<uint32_t>());
+      affine_to_jacobian_std_g2(c, p2.as<uint32_t>(), 5, j2.as<uint32_t>());
+      uint32_t* o = reinterpret_cast<uint32_t*>(vk_out);
+      const uint32_t* J1 = j1.as<uint32_t>();
+      const uint32_t* J2 = j2.as<uint32_t>();
+      auto cp = [&](uint32_t* dst, const uint32_t* src, size_t words) { GS_HIP(hipMemcpyAsync(dst, src, words * 4, hipMemcpyDeviceToHost, c.stream)); };
+      cp(o, J2, 48);                    // Vka
+      cp(o + 48, J1, 24);               // Vkb
+      cp(o + 72, J2 + 48, 48);          // Vkc
+      cp(o + 120, J1 + 24, 24);         // G1Kbg
+      cp(o + 144, J2 + 96, 48);         // G2Kbg
+      cp(o + 192, J2 + 144, 48);        // G2Kg
+      cp(o + 240, J2 + 192, 48);        // Vkz
+      cp(o + 288, J1 + 48, nic * 24);   // IC
+      GS_HIP(hipStreamSynchronize(c.stream));
+    }
+    force_infinity_points(c, pk->a, npublic + 1, 16);                               // the prover sums A, Ap over i > NPublic (snark.go:265)
+    force_infinity_points(c, pk->ap, npublic + 1, 16);
+    GS_HIP(hipStreamSynchronize(c.stream));
+    *pk_out = c.put(std::move(pk));
+    return GS_OK;
+  });
+}
+
 int gs_groth16_pk_export(gs_handle hpk, int which, uint64_t* jacobian, size_t count) {
   return guarded([&](Ctx& c) -> int {
     GrothPkObj* pk = c.get<GrothPkObj>(hpk, Kind::GrothPk);
@@ -179,6 +268,26 @@ int gs_groth16_pk_export(gs_handle hpk, int which, uint64_t* jacobian, size_t co
     DevBuf tmp(count * words * 4);
     if (g2) affine_to_jacobian_std_g2(c, src->as<uint32_t>(), (uint32_t)count, tmp.as<uint32_t>());
     else affine_to_jacobian_std_g1(c, src->as<uint32_t>(), (uint32_t)count, tmp.as<uint32_t>());
+    GS_HIP(hipMemcpyAsync(jacobian, tmp.p, count * words * 4, hipMemcpyDeviceToHost, c.stream));
+    GS_HIP(hipStreamSynchronize(c.stream));
+    return GS_OK;
+  });
+}
+
+int gs_pinocchio_pk_export(gs_handle hpk, int which, uint64_t* jacobian, size_t count) {
+  return guarded([&](Ctx& c) -> int {
+    PinocchioPkObj* pk = c.get<PinocchioPkObj>(hpk, Kind::PinocchioPk);
+    if (!pk) return fail(GS_ERR_ARG, "gs_pinocchio_pk_export: bad proving-key handle");
+    const DevBuf* arr[8] = {&pk->a, &pk->ap, &pk->b2, &pk->bp, &pk->c, &pk->cp, &pk->kp, &pk->g1t};
+    if (which < 0 || which > 7) return fail(GS_ERR_ARG, "gs_pinocchio_pk_export: which must be 0..7");
+    const bool g2 = which == 2;
+    const size_t have = which == 7 ? pk->ng1t : pk->nvars;
+    if (count != have || (count && !jacobian)) return fail(GS_ERR_ARG, "gs_pinocchio_pk_export: array has %zu points, asked for %zu", have, count);
+    if (!count) return GS_OK;
+    const size_t words = g2 ? 48 : 24;
+    DevBuf tmp(count * words * 4);
+    if (g2) affine_to_jacobian_std_g2(c, arr[which]->as<uint32_t>(), (uint32_t)count, tmp.as<uint32_t>());
+    else affine_to_jacobian_std_g1(c, arr[which]->as<uint32_t>(), (uint32_t)count, tmp.as<uint32_t>());
     GS_HIP(hipMemcpyAsync(jacobian, tmp.p, count * words * 4, hipMemcpyDeviceToHost, c.stream));
     GS_HIP(hipStreamSynchronize(c.stream));
     return GS_OK;

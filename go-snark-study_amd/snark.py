@@ -43,7 +43,7 @@ def UploadPk(pk, circuit):
 
 def GenerateProofs(circuit, pk, w, px):
     """snark.GenerateProofs(circuit, pk, w, px) (snark.go:254-289).  Deterministic."""
-    dev = UploadPk(pk, circuit)
+    dev = pk if isinstance(pk, DevicePk) else UploadPk(pk, circuit)
     if any(x < 0 for x in w):
         raise ValueError("negative witness values are not supported")
     wa = capi.ints_to_u64([x % R for x in w])
@@ -62,3 +62,59 @@ def GenerateProofs(circuit, pk, w, px):
             res[k] = (0, 0, 0) if inf[i] else (v[pos], v[pos + 1], 1)
             pos += 2
     return Proof(**res)
+
+
+class Vk:
+    """snark.Vk (snark.go:28-38): affine Jacobian tuples."""
+    FIELDS = ("Vka", "Vkb", "Vkc", "G1Kbg", "G2Kbg", "G2Kg", "Vkz")
+
+    def __init__(self, IC, **kw):
+        self.IC = IC
+        for k in self.FIELDS:
+            setattr(self, k, kw[k])
+
+
+PK_ARRAYS = {"A": 0, "Ap": 1, "B": 2, "Bp": 3, "C": 4, "Cp": 5, "Kp": 6, "G1T": 7}
+
+
+class DevicePk:
+    def __init__(self, handle, nvars, npublic):
+        self.h, self.handle, self.nvars, self.npublic = handle.h, handle, nvars, npublic
+
+
+def GenerateTrustedSetupSparse(n, nvars, npublic, a_csr, b_csr, c_csr, toxic):
+    """snark.GenerateTrustedSetup (snark.go:98-251) on a sparse R1CS, toxic = (T, Ka, Kb, Kc, Kbeta, Kgamma, RhoA, RhoB)
+    injected instead of drawn at :114-148; runs on the device (gs_pinocchio_setup).  -> (DevicePk, Vk)."""
+    capi.init()
+    args = []
+    for rp, cl, vl in (a_csr, b_csr, c_csr):
+        rp = np.ascontiguousarray(rp, dtype=np.uint32)
+        cl = np.ascontiguousarray(cl, dtype=np.uint32)
+        vl = np.ascontiguousarray(vl, dtype=np.uint64).reshape(-1, 4)
+        if cl.size == 0:
+            cl, vl = np.zeros(1, dtype=np.uint32), np.zeros((1, 4), dtype=np.uint64)
+        args += [rp, cl, vl]
+    tox = capi.ints_to_u64([t % R for t in toxic]).reshape(-1)
+    vk = np.zeros(4 * (72 + 6 * (npublic + 1)), dtype=np.uint64)          # 288 u32 words + IC, as u64 limbs
+    h = capi.Handle(0)
+    capi.check(capi.load_library().gs_pinocchio_setup(
+        n, nvars, npublic, capi.ptr32(args[0]), capi.ptr32(args[1]), capi.ptr64(args[2]), capi.ptr32(args[3]), capi.ptr32(args[4]),
+        capi.ptr64(args[5]), capi.ptr32(args[6]), capi.ptr32(args[7]), capi.ptr64(args[8]), capi.ptr64(tox), ctypes.byref(h), capi.ptr64(vk)))
+    v = capi.u64_to_ints(vk)
+    g1 = lambda o: (v[o], v[o + 1], v[o + 2])                                           # noqa: E731
+    g2 = lambda o: ((v[o], v[o + 1]), (v[o + 2], v[o + 3]), (v[o + 4], v[o + 5]))       # noqa: E731
+    vkey = Vk(IC=[g1(36 + 3 * i) for i in range(npublic + 1)], Vka=g2(0), Vkb=g1(6), Vkc=g2(9), G1Kbg=g1(15), G2Kbg=g2(18), G2Kg=g2(24),
+              Vkz=g2(30))
+    return DevicePk(capi.DeviceHandle(h.value), nvars, npublic), vkey
+
+
+def ExportPkArray(dev_pk, name):
+    which = PK_ARRAYS[name]
+    count = dev_pk.nvars - 1 if which == 7 else dev_pk.nvars
+    words = 24 if which == 2 else 12
+    out = np.zeros((count, words), dtype=np.uint64)
+    capi.check(capi.load_library().gs_pinocchio_pk_export(capi.Handle(dev_pk.h), which, capi.ptr64(out), count))
+    v = capi.u64_to_ints(out)
+    if which == 2:
+        return [((v[6 * i], v[6 * i + 1]), (v[6 * i + 2], v[6 * i + 3]), (v[6 * i + 4], v[6 * i + 5])) for i in range(count)]
+    return [(v[3 * i], v[3 * i + 1], v[3 * i + 2]) for i in range(count)]

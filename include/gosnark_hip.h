@@ -176,6 +176,18 @@ int gs_groth16_setup(size_t n, size_t m, size_t npublic,
                      const uint32_t* b_rowptr, const uint32_t* b_col, const uint64_t* b_val,
                      const uint32_t* c_rowptr, const uint32_t* c_col, const uint64_t* c_val,
                      const uint64_t toxic[20], gs_handle* pk_out, uint64_t* vk_out);
+/* snark.GenerateTrustedSetup (snark.go:98-251) for a sparse R1CS; toxic = T | Ka | Kb | Kc | Kbeta | Kgamma | RhoA | RhoB
+ * (8 x 4 words; RhoC = RhoA RhoB, :149).  *pk_out: resident Pinocchio key (as gs_pinocchio_pk_create builds).  vk_out
+ * (may be NULL), affine Jacobian triples: Vka (24 words, G2) | Vkb (12) | Vkc (24) | G1Kbg (12) | G2Kbg (24) | G2Kg (24)
+ * | Vkz (24) | IC[0..npublic] (12 each). */
+int gs_pinocchio_setup(size_t n, size_t m, size_t npublic,
+                       const uint32_t* a_rowptr, const uint32_t* a_col, const uint64_t* a_val,
+                       const uint32_t* b_rowptr, const uint32_t* b_col, const uint64_t* b_val,
+                       const uint32_t* c_rowptr, const uint32_t* c_col, const uint64_t* c_val,
+                       const uint64_t toxic[32], gs_handle* pk_out, uint64_t* vk_out);
+/* Read one array of a resident Pinocchio key back (which = 0 A, 1 Ap, 2 B (G2, 24 words per point), 3 Bp, 4 C, 5 Cp,
+ * 6 Kp, 7 G1T).  Note A and Ap hold infinity for i <= NPublic (what the prover sums, snark.go:265). */
+int gs_pinocchio_pk_export(gs_handle pk, int which, uint64_t* jacobian, size_t count);
 /* Read one array of a resident Groth16 key back as affine Jacobian triples: which = 0 G1.At, 1 G1.BACGamma,
  * 2 G2.BACGamma (24 words per point), 3 BACDelta, 4 PowersTauDelta.  count must equal the array length. */
 int gs_groth16_pk_export(gs_handle pk, int which, uint64_t* jacobian, size_t count);

@@ -161,8 +161,28 @@ def job_pinocchio_rand(m, seed):
                 rand=None, verify=[])
 
 
+def job_pinocchio_x3_setup():
+    """snark.GenerateTrustedSetup restated (oracle) on x^3+x+5 with toxic X_k = bytes((i*k+9)&0xff for i<30) mod r,
+    k in (3,5,7,11,13,17,19,23); the reference proves with that key and its own VerifyProof must accept [35], reject [34]."""
+    toxic = tuple(int.from_bytes(bytes((i * k + 9) & 0xff for i in range(30)), "big") % O.R
+                  for k in (3, 5, 7, 11, 13, 17, 19, 23))
+    alphas, betas, gammas, _ = O.PF.R1CSToQAP(O.X3_R1CS_A, O.X3_R1CS_B, O.X3_R1CS_C)
+    _, _, _, px = O.PF.CombinePolynomials(O.X3_WITNESS, alphas, betas, gammas)
+    pk, vk = O.snark_GenerateTrustedSetup(8, 1, alphas, betas, gammas, toxic)
+    d = {"Pk": {"G1T": [s3(p) for p in pk.G1T], "A": [s3(p) for p in pk.A], "B": [s32(p) for p in pk.B],
+                "C": [s3(p) for p in pk.C], "Kp": [s3(p) for p in pk.Kp], "Ap": [s3(p) for p in pk.Ap],
+                "Bp": [s3(p) for p in pk.Bp], "Cp": [s3(p) for p in pk.Cp], "Z": [str(x) for x in pk.Z]},
+         "Vk": {"Vka": s32(vk.Vka), "Vkb": s3(vk.Vkb), "Vkc": s32(vk.Vkc), "IC": [s3(p) for p in vk.IC],
+                "G1Kbg": s3(vk.G1Kbg), "G2Kbg": s32(vk.G2Kbg), "G2Kg": s32(vk.G2Kg), "Vkz": s32(vk.Vkz)}}
+    return dict(name="pinocchio_x3_setup", kind="pinocchio",
+                circuit=circuit_text(8, 1, (O.X3_R1CS_A, O.X3_R1CS_B, O.X3_R1CS_C)),
+                setup=json.dumps(d), px=json.dumps([str(x) for x in px]), inputs=inputs_text(O.X3_WITNESS, 1),
+                rand=None, verify=["[35]", "[34]"], toxic=[str(t) for t in toxic])
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    only = set(sys.argv[1:])
     jobs = [
         dict(name="pinocchio_x3_fixture", kind="fixture", inputs='{"Private":[3],"Public":[35]}',
              verify=["[35]", "[34]"]),
@@ -170,7 +190,10 @@ def main():
         job_groth_rand(9, 1009),
         job_groth_rand(17, 1017),
         job_pinocchio_rand(9, 2009),
+        job_pinocchio_x3_setup(),
     ]
+    if only:
+        jobs = [j for j in jobs if j["name"] in only]
     with tempfile.TemporaryDirectory() as td:
         jp, op = os.path.join(td, "jobs.json"), os.path.join(td, "out.json")
         with open(jp, "w") as f:

@@ -363,3 +363,55 @@ def test_sharded_prove_equals_single_device_prove(shards):
     # world size 1 through the torch.distributed-shaped entry point
     one = groth16.prove_sharded(pk, inst.w, inst.px, r, s)
     assert (one.PiA, one.PiB, one.PiC) == (want.PiA, want.PiB, want.PiC)
+
+
+def _x3_csr():
+    rows = lambda mat: [{k: v for k, v in enumerate(row) if v} for row in mat]   # noqa: E731
+    return tuple(r1csqap.csr_from_rows(rows(m)) for m in (O.X3_R1CS_A, O.X3_R1CS_B, O.X3_R1CS_C))
+
+
+def test_device_groth16_setup_equals_the_key_the_reference_verifier_accepted():
+    """Golden `groth_x3`: its key came from the recorded toxic recipe and the reference's own grothVerifyProofs accepted a
+    proof made with it.  gs_groth16_setup with the same toxic values must rebuild exactly that key (affine)."""
+    rec = GU.load("groth_x3")
+    assert [v["result"] for v in rec["verify"]] == ["true", "false"]
+    toxic = tuple(int.from_bytes(bytes((i * k + 7) & 0xff for i in range(30)), "big") % O.R for k in (3, 5, 7, 11, 13))
+    a, b, c = _x3_csr()
+    dpk, vk = groth16.GenerateTrustedSetupSparse(7, 8, 1, a, b, c, toxic)
+    opk = GU.groth_pk(rec["setup"])
+    for name, ref in (("G1_At", opk.G1_At), ("G1_BACGamma", opk.G1_BACGamma), ("BACDelta", opk.BACDelta), ("PowersTauDelta", opk.PowersTauDelta)):
+        assert groth16.ExportPkArray(dpk, name) == [jac_affine_g1(p) for p in ref], name
+    assert groth16.ExportPkArray(dpk, "G2_BACGamma") == [jac_affine_g2(p) for p in opk.G2_BACGamma]
+    svk = rec["setup"]["Vk"]
+    assert vk.IC == [jac_affine_g1(GU.g1(p)) for p in svk["IC"]]
+    assert vk.G1_Alpha == jac_affine_g1(GU.g1(svk["G1"]["Alpha"])) and vk.G2_Gamma == jac_affine_g2(GU.g2(svk["G2"]["Gamma"]))
+    # and the proof with the device-built key equals the reference prover's proof
+    r, s = GU.rs_from_stream(rec["rand"])
+    proof = groth16.GenerateProofsWithRS(groth16.Circuit(8, 1), dpk, rec["w"], rec["px"], r, s)
+    assert proof.PiA == jac_affine_g1(GU.g1(rec["proof"]["PiA"])) and proof.PiC == jac_affine_g1(GU.g1(rec["proof"]["PiC"]))
+    assert proof.PiB == jac_affine_g2(GU.g2(rec["proof"]["PiB"]))
+
+
+def test_device_pinocchio_setup_equals_the_key_the_reference_verifier_accepted():
+    """Golden `pinocchio_x3_setup` (reference VerifyProof: true / false): gs_pinocchio_setup rebuilds that key from the toxic
+    recipe, and the proof made with the device-built key equals the reference prover's proof."""
+    rec = GU.load("pinocchio_x3_setup")
+    assert [v["result"] for v in rec["verify"]] == ["true", "false"]
+    toxic = tuple(int.from_bytes(bytes((i * k + 9) & 0xff for i in range(30)), "big") % O.R for k in (3, 5, 7, 11, 13, 17, 19, 23))
+    a, b, c = _x3_csr()
+    dpk, vk = snark.GenerateTrustedSetupSparse(7, 8, 1, a, b, c, toxic)
+    spk, svk = rec["setup"]["Pk"], rec["setup"]["Vk"]
+    for k in ("Bp", "C", "Cp", "Kp", "G1T"):
+        assert snark.ExportPkArray(dpk, k) == [jac_affine_g1(GU.g1(p)) for p in spk[k]], k
+    for k in ("A", "Ap"):        # resident A / Ap carry infinity for i <= NPublic (what snark.go:265 sums)
+        want = [jac_affine_g1(GU.g1(p)) for p in spk[k]]
+        assert snark.ExportPkArray(dpk, k) == [(0, 0, 0)] * 2 + want[2:], k
+    assert snark.ExportPkArray(dpk, "B") == [jac_affine_g2(GU.g2(p)) for p in spk["B"]]
+    assert vk.IC == [jac_affine_g1(GU.g1(p)) for p in svk["IC"]]
+    assert vk.Vkb == jac_affine_g1(GU.g1(svk["Vkb"])) and vk.G1Kbg == jac_affine_g1(GU.g1(svk["G1Kbg"]))
+    for k in ("Vka", "Vkc", "G2Kbg", "G2Kg", "Vkz"):
+        assert getattr(vk, k) == jac_affine_g2(GU.g2(svk[k])), k
+    proof = snark.GenerateProofs(snark.Circuit(8, 1), dpk, rec["w"], rec["px"])
+    for k in ("PiA", "PiAp", "PiBp", "PiC", "PiCp", "PiH", "PiKp"):
+        assert getattr(proof, k) == jac_affine_g1(GU.g1(rec["proof"][k])), k
+    assert proof.PiB == jac_affine_g2(GU.g2(rec["proof"]["PiB"]))
