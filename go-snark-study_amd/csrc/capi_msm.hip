@@ -298,7 +298,7 @@ int gs_last_timing(gs_timing* out) {
 
 int gs_set_window_bits(int cbits) {
   return guarded([&](Ctx& c) -> int {
-    if (cbits != 0 && (cbits < 2 || cbits > 16)) return fail(GS_ERR_ARG, "window bits must be 0 (auto) or 2..16");
+    if (cbits != 0 && (cbits < 8 || cbits > 17)) return fail(GS_ERR_ARG, "window bits must be 0 (auto) or 8..17");
     c.window_bits = cbits;
     return GS_OK;
   });

@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <future>
 
 #include "msm_kernels.h"
 
@@ -14,10 +15,12 @@ static_assert(sizeof(G2Xyzz) == PointIO<Fq2Tag>::kXyzzWords * 4, "G2 XYZZ must b
 static inline dim3 grid1(size_t n, int block = 256) { return dim3((unsigned)((n + block - 1) / block)); }
 
 int choose_window_bits(uint32_t n, int forced) {
-  if (forced >= 8 && forced <= 16) return forced;
+  if (forced >= 8 && forced <= 17) return forced;
   int lg = 0;
   while ((1u << (lg + 1)) <= n) ++lg;                 // floor(log2 n), n >= 1
   // with window tables the accumulation costs n * W(c) additions and the reduction only 2^(c-1) buckets
+  // c = 17 (2^16 buckets, u16-pair LDS counters) is supported and tested but measured no faster at 2^20 (15 instead of
+  // 16 additions per term, paid back by a slower sort and the same number of wave rounds), so 16 stays the default cap
   return std::max(8, std::min(16, lg));
 }
 
@@ -43,10 +46,12 @@ void build_plan(Ctx& c, int slot, const uint32_t* scalars_dev, uint32_t n, MsmPl
   const size_t ncount = (size_t)plan.nbuckets + 1;
   PlanParams pp{};
   pp.n = n; pp.c = plan.c; pp.W = plan.W; pp.B = plan.B;
-  pp.S = std::max<uint32_t>(1u, std::min<uint32_t>(16u, (n + 16383u) / 16384u));
+  pp.packed = plan.B > 32768u ? 1u : 0u;                  // c = 17: u16-pair counters, so a slice may hold at most 65535 scalars
+  pp.S = pp.packed ? std::max<uint32_t>(1u, (n + 65534u) / 65535u)
+                   : std::max<uint32_t>(1u, std::min<uint32_t>(16u, (n + 16383u) / 16384u));
   pp.slice = (n + pp.S - 1) / pp.S;
   pp.stride = (n + 63u) & ~63u;
-  pb.digits.ensure((size_t)std::max<uint32_t>(pp.stride, 64u) * plan.W * 2);
+  pb.digits.ensure((size_t)std::max<uint32_t>(pp.stride, 64u) * plan.W * sizeof(digit_t));
   pb.hist.ensure((size_t)plan.B * plan.W * pp.S * 4);
   pb.totals.ensure(ncount * 4);
   pb.offsets.ensure(ncount * 4);
@@ -54,7 +59,7 @@ void build_plan(Ctx& c, int slot, const uint32_t* scalars_dev, uint32_t n, MsmPl
   pb.chunk_bucket.ensure((size_t)plan.maxchunks * 4);
   pb.heavy_list.ensure((size_t)kMaxHeavy * 4);
   pb.counters.ensure(16);
-  const size_t lds = (size_t)plan.B * 4;
+  const size_t lds = pp.packed ? (size_t)plan.B * 2 : (size_t)plan.B * 4;
   static bool lds_attr_set = false;
   if (!lds_attr_set) {       // B <= 2^15 counters = 128 KiB of the CU's 160 KiB LDS
     GS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hist), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
@@ -64,15 +69,15 @@ void build_plan(Ctx& c, int slot, const uint32_t* scalars_dev, uint32_t n, MsmPl
   GS_HIP(hipMemsetAsync(pb.totals.as<uint32_t>() + plan.nbuckets, 0, 4, c.stream));
   GS_HIP(hipMemsetAsync(pb.counters.p, 0, 16, c.stream));
   if (n > 0) {
-    hipLaunchKernelGGL(k_digits, grid1(n), dim3(256), 0, c.stream, scalars_dev, pp, pb.digits.as<uint16_t>());
-    hipLaunchKernelGGL(k_hist, dim3(plan.W, pp.S), dim3(kSortBlock), lds, c.stream, pb.digits.as<uint16_t>(), pp, pb.hist.as<uint32_t>());
+    hipLaunchKernelGGL(k_digits, grid1(n), dim3(256), 0, c.stream, scalars_dev, pp, pb.digits.as<digit_t>());
+    hipLaunchKernelGGL(k_hist, dim3(plan.W, pp.S), dim3(kSortBlock), lds, c.stream, pb.digits.as<digit_t>(), pp, pb.hist.as<uint32_t>());
     hipLaunchKernelGGL(k_colscan, grid1(plan.B), dim3(256), 0, c.stream, pb.hist.as<uint32_t>(), pp, pb.totals.as<uint32_t>());
   } else {
     GS_HIP(hipMemsetAsync(pb.totals.p, 0, ncount * 4, c.stream));
   }
   exclusive_scan(c, pb, pb.totals.as<uint32_t>(), pb.offsets.as<uint32_t>(), (uint32_t)ncount);
   if (n > 0) {
-    hipLaunchKernelGGL(k_scatter, dim3(plan.W, pp.S), dim3(kSortBlock), lds, c.stream, pb.digits.as<uint16_t>(), pp, pb.hist.as<uint32_t>(),
+    hipLaunchKernelGGL(k_scatter, dim3(plan.W, pp.S), dim3(kSortBlock), lds, c.stream, pb.digits.as<digit_t>(), pp, pb.hist.as<uint32_t>(),
                        pb.offsets.as<uint32_t>(), pb.entries.as<uint32_t>());
     hipLaunchKernelGGL(k_chunk_map, grid1(plan.nbuckets), dim3(256), 0, c.stream, pb.offsets.as<uint32_t>(), plan.nbuckets,
                        pb.chunk_bucket.as<uint32_t>(), pb.heavy_list.as<uint32_t>(), pb.counters.as<uint32_t>());
@@ -159,28 +164,37 @@ static void msm_enqueue(Ctx& c, const MsmPlan& plan, const std::vector<MsmBase>&
   p.tred->stop();
 }
 
+// host side of an MSM group: books the device timings (serial), then adds the <= 16 workgroup pairs of every job --
+// result = sum_blk A_blk + (256 L) * sum_blk blk * S_blk -- one host core per job.
+template <class T>
+static Xyzz<T> sum_pairs(const Xyzz<T>* pr, uint32_t nblk, int L) {
+  Xyzz<T> run = xyzz_inf<T>(), tot = xyzz_inf<T>(), sumA = xyzz_inf<T>();
+  for (uint32_t blk = nblk; blk-- > 0;) {
+    xyzz_add(sumA, pr[2 * blk]);
+    if (blk >= 1) { xyzz_add(run, pr[2 * blk + 1]); xyzz_add(tot, run); }
+  }
+  for (uint32_t s2 = (uint32_t)kReduceBlock * (uint32_t)L; s2 > 1; s2 >>= 1) xyzz_dbl(tot);
+  xyzz_add(sumA, tot);
+  return sumA;
+}
+
 template <class T>
 static void msm_finish(Ctx& c, const MsmPending& p, std::vector<Xyzz<T>>& out) {
   if (p.njobs <= 0) { out.assign(-p.njobs, xyzz_inf<T>()); return; }
   out.assign(p.njobs, xyzz_inf<T>());
-  c.timing.accumulate_ms += p.tacc->ms();
-  if (!p.g2) { c.timing.acc_g1_ms += p.tker->ms(); c.timing.acc_g1_launches += 1; c.timing.acc_g1_terms += (uint64_t)p.n * p.njobs; }
-  else { c.timing.acc_g2_ms += p.tker->ms(); c.timing.acc_g2_launches += 1; c.timing.acc_g2_terms += (uint64_t)p.n * p.njobs; }
-  c.timing.reduce_ms += p.tred->ms();
-  // result = sum_blk A_blk + (256 L) * sum_blk blk * S_blk           (<= 16 pairs per job: host core)
-  const Xyzz<T>* pairs = static_cast<const Xyzz<T>*>(c.pinned[p.slot]);
-  const uint32_t span = (uint32_t)kReduceBlock * (uint32_t)p.L;
-  for (int j = 0; j < p.njobs; ++j) {
-    const Xyzz<T>* pr = pairs + (size_t)j * p.nblk * 2;
-    Xyzz<T> run = xyzz_inf<T>(), tot = xyzz_inf<T>(), sumA = xyzz_inf<T>();
-    for (uint32_t blk = p.nblk; blk-- > 0;) {
-      xyzz_add(sumA, pr[2 * blk]);
-      if (blk >= 1) { xyzz_add(run, pr[2 * blk + 1]); xyzz_add(tot, run); }
-    }
-    for (uint32_t s2 = span; s2 > 1; s2 >>= 1) xyzz_dbl(tot);
-    xyzz_add(sumA, tot);
-    out[j] = sumA;
+  {
+    std::lock_guard<std::mutex> lk(c.timing_mu);
+    c.timing.accumulate_ms += p.tacc->ms();
+    if (!p.g2) { c.timing.acc_g1_ms += p.tker->ms(); c.timing.acc_g1_launches += 1; c.timing.acc_g1_terms += (uint64_t)p.n * p.njobs; }
+    else { c.timing.acc_g2_ms += p.tker->ms(); c.timing.acc_g2_launches += 1; c.timing.acc_g2_terms += (uint64_t)p.n * p.njobs; }
+    c.timing.reduce_ms += p.tred->ms();
   }
+  const Xyzz<T>* pairs = static_cast<const Xyzz<T>*>(c.pinned[p.slot]);
+  std::vector<std::future<Xyzz<T>>> fut;
+  for (int j = 1; j < p.njobs; ++j)
+    fut.push_back(std::async(std::launch::async, [=] { return sum_pairs<T>(pairs + (size_t)j * p.nblk * 2, p.nblk, p.L); }));
+  out[0] = sum_pairs<T>(pairs, p.nblk, p.L);
+  for (int j = 1; j < p.njobs; ++j) out[j] = fut[j - 1].get();
 }
 
 void msm_enqueue_g1(Ctx& c, const MsmPlan& plan, const std::vector<MsmBase>& bases, int ws_base, int slot, MsmPending& p, hipStream_t tail) {

@@ -7,7 +7,7 @@
 // Pipeline (all on the library stream, no host round trips):
 //   plan (once per scalar vector, shared by every base array multiplied by it; no host round trip):
 //     k_digits        scalars -> signed c-bit digit matrix (u16)
-//     k_hist          per (window, slice) workgroup: bucket histogram in LDS (128 KiB of the 160 KiB)
+//     k_hist          per (window, slice) workgroup: bucket histogram in LDS (128 KiB of the 160 KiB; u16 pairs for c = 17)
 //     k_colscan+scan  exclusive prefix sums -> bucket offsets, per-slice cursors
 //     k_scatter       counting sort with LDS cursors: entries[] = term index (sign in bit 31) grouped by bucket
 //     k_chunk_map     cut the sorted entry list into equal chunks of 32 entries (load balance)
@@ -33,12 +33,13 @@ namespace gs {
 
 struct PlanParams {
   uint32_t n;        // scalars
-  int c;             // window bits (<= 16: a signed digit fits a u16)
+  int c;             // window bits (<= 17)
   int W;             // windows = floor(254 / c) + 1
   uint32_t B;        // buckets per window = 2^(c-1)   (digits are signed: [-B+1, B])
   uint32_t S;        // slices of the scalar vector (one histogram/scatter workgroup per (window, slice))
   uint32_t slice;    // scalars per slice
   uint32_t stride;   // row stride of the digit matrix (elements)
+  uint32_t packed;   // 1: LDS counters are u16 pairs (B = 2^16 buckets, c = 17); slices hold <= 65535 scalars
 };
 
 // signed digit of window w with the running carry (digit in [-B+1, B]; 0 <-> the term is skipped in that window)
@@ -49,8 +50,9 @@ GS_HD int32_t next_digit(const uint32_t (&k)[8], const PlanParams& pp, int w, ui
   return (int32_t)raw;
 }
 
-// ---- plan, step 1: scalars -> digit matrix digits[w][i] = d + B - 1 (u16), read once, coalesced --------------
-__global__ void __launch_bounds__(256) k_digits(const uint32_t* __restrict__ scalars, PlanParams pp, uint16_t* __restrict__ digits) {
+// ---- plan, step 1: scalars -> digit matrix digits[w][i] = d + B - 1, read once, coalesced ------------------------
+using digit_t = uint32_t;
+__global__ void __launch_bounds__(256) k_digits(const uint32_t* __restrict__ scalars, PlanParams pp, digit_t* __restrict__ digits) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= pp.n) return;
   uint32_t k[8];
@@ -61,7 +63,7 @@ __global__ void __launch_bounds__(256) k_digits(const uint32_t* __restrict__ sca
   uint32_t carry = 0;
   for (int w = 0; w < pp.W; ++w) {
     const int32_t d = next_digit(k, pp, w, carry);
-    digits[(size_t)w * pp.stride + i] = (uint16_t)(d + (int32_t)pp.B - 1);
+    digits[(size_t)w * pp.stride + i] = (digit_t)(d + (int32_t)pp.B - 1);
   }
 }
 
@@ -69,21 +71,30 @@ __global__ void __launch_bounds__(256) k_digits(const uint32_t* __restrict__ sca
 // grid = (W, S): blockIdx.x = window, so that all slices of a window run on XCD (w % 8) and the window's
 // 4n-byte region of `entries` is assembled in ONE L2 by the scatter pass below.
 constexpr int kSortBlock = 1024;
-__global__ void __launch_bounds__(kSortBlock) k_hist(const uint16_t* __restrict__ digits, PlanParams pp, uint32_t* __restrict__ hist) {
+// LDS counter access: plain u32 counters (B <= 2^15), or u16 pairs packed in u32 words (B = 2^16: 128 KiB again)
+GS_HD uint32_t packed_inc(uint32_t b) { return (b & 1u) ? 0x10000u : 1u; }
+GS_HD uint32_t packed_get(uint32_t word, uint32_t b) { return (b & 1u) ? (word >> 16) : (word & 0xffffu); }
+
+__global__ void __launch_bounds__(kSortBlock) k_hist(const digit_t* __restrict__ digits, PlanParams pp, uint32_t* __restrict__ hist) {
   extern __shared__ uint32_t sh[];
   const uint32_t w = blockIdx.x, s = blockIdx.y;
-  for (uint32_t b = threadIdx.x; b < pp.B; b += kSortBlock) sh[b] = 0;
+  const uint32_t nwords = pp.packed ? pp.B / 2 : pp.B;
+  for (uint32_t b = threadIdx.x; b < nwords; b += kSortBlock) sh[b] = 0;
   __syncthreads();
   const uint32_t lo = s * pp.slice, hi = min(pp.n, lo + pp.slice);
-  const uint16_t* row = digits + (size_t)w * pp.stride;
+  const digit_t* row = digits + (size_t)w * pp.stride;
   const int32_t zero = (int32_t)pp.B - 1;
   for (uint32_t i = lo + threadIdx.x; i < hi; i += kSortBlock) {
     const int32_t d = (int32_t)row[i] - zero;
-    if (d != 0) atomicAdd(&sh[(uint32_t)(d < 0 ? -d : d) - 1u], 1u);
+    if (d != 0) {
+      const uint32_t b = (uint32_t)(d < 0 ? -d : d) - 1u;
+      if (pp.packed) atomicAdd(&sh[b >> 1], packed_inc(b));
+      else atomicAdd(&sh[b], 1u);
+    }
   }
   __syncthreads();
   uint32_t* out = hist + ((size_t)w * pp.S + s) * pp.B;
-  for (uint32_t b = threadIdx.x; b < pp.B; b += kSortBlock) out[b] = sh[b];
+  for (uint32_t b = threadIdx.x; b < pp.B; b += kSortBlock) out[b] = pp.packed ? packed_get(sh[b >> 1], b) : sh[b];
 }
 
 // hist[q][b], q = w*S + s  ->  exclusive prefix over q (in place); totals[b] = sum over q.
@@ -101,20 +112,24 @@ __global__ void __launch_bounds__(256) k_colscan(uint32_t* __restrict__ hist, Pl
 
 // ---- plan, step 4: counting-sort scatter; cursors live in LDS ------------------------------------------------
 // entry = sign (bit 31) | window (bits 30..26) | term index (bits 25..0)
-__global__ void __launch_bounds__(kSortBlock) k_scatter(const uint16_t* __restrict__ digits, PlanParams pp, const uint32_t* __restrict__ hist,
+__global__ void __launch_bounds__(kSortBlock) k_scatter(const digit_t* __restrict__ digits, PlanParams pp, const uint32_t* __restrict__ hist,
                                                          const uint32_t* __restrict__ offsets, uint32_t* __restrict__ entries) {
   extern __shared__ uint32_t sh[];
   const uint32_t w = blockIdx.x, s = blockIdx.y;
   const uint32_t* pre = hist + ((size_t)w * pp.S + s) * pp.B;
-  for (uint32_t b = threadIdx.x; b < pp.B; b += kSortBlock) sh[b] = offsets[b] + pre[b];
+  if (pp.packed) { for (uint32_t b = threadIdx.x; b < pp.B / 2; b += kSortBlock) sh[b] = 0; }       // local u16 counters; bases stay in L2
+  else { for (uint32_t b = threadIdx.x; b < pp.B; b += kSortBlock) sh[b] = offsets[b] + pre[b]; }    // full u32 cursors in LDS
   __syncthreads();
   const uint32_t lo = s * pp.slice, hi = min(pp.n, lo + pp.slice);
-  const uint16_t* row = digits + (size_t)w * pp.stride;
+  const digit_t* row = digits + (size_t)w * pp.stride;
   const int32_t zero = (int32_t)pp.B - 1;
   for (uint32_t i = lo + threadIdx.x; i < hi; i += kSortBlock) {
     const int32_t d = (int32_t)row[i] - zero;
     if (d != 0) {
-      const uint32_t pos = atomicAdd(&sh[(uint32_t)(d < 0 ? -d : d) - 1u], 1u);
+      const uint32_t b = (uint32_t)(d < 0 ? -d : d) - 1u;
+      uint32_t pos;
+      if (pp.packed) pos = offsets[b] + pre[b] + packed_get(atomicAdd(&sh[b >> 1], packed_inc(b)), b);
+      else pos = atomicAdd(&sh[b], 1u);
       entries[pos] = i | (w << kWindowShift) | (d < 0 ? kSignBit : 0u);
     }
   }

@@ -133,9 +133,12 @@ int groth16_sums_impl(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, const
   total.stop();
   std::vector<G1Xyzz> g1w, g1h;
   std::vector<G2Xyzz> g2w;
-  msm_finish_g1(c, pend_g1w, g1w);
-  msm_finish_g2(c, pend_g2w, g2w);
-  msm_finish_g1(c, pend_h, g1h);
+  {                                                              // the host-side pair sums of the three groups, on separate cores
+    auto f2 = std::async(std::launch::async, [&] { msm_finish_g2(c, pend_g2w, g2w); });
+    auto fh = std::async(std::launch::async, [&] { msm_finish_g1(c, pend_h, g1h); });
+    msm_finish_g1(c, pend_g1w, g1w);
+    f2.get(); fh.get();
+  }
   c.timing.poly_ms += tpoly->ms();
   c.timing.plan_ms += tplanw->ms() + tplanh->ms();
   c.timing.total_ms += total.ms();
@@ -249,9 +252,12 @@ int pinocchio_prove_impl(Ctx& c, PinocchioPkObj* pk, DevScalars w, DevScalars px
   total.stop();
   std::vector<G1Xyzz> g1w, g1h;
   std::vector<G2Xyzz> g2w;
-  msm_finish_g1(c, pend_g1w, g1w);
-  msm_finish_g2(c, pend_g2w, g2w);
-  msm_finish_g1(c, pend_h, g1h);
+  {                                                              // the host-side pair sums of the three groups, on separate cores
+    auto f2 = std::async(std::launch::async, [&] { msm_finish_g2(c, pend_g2w, g2w); });
+    auto fh = std::async(std::launch::async, [&] { msm_finish_g1(c, pend_h, g1h); });
+    msm_finish_g1(c, pend_g1w, g1w);
+    f2.get(); fh.get();
+  }
   c.timing.poly_ms += tpoly->ms();
   c.timing.plan_ms += tplanw->ms() + tplanh->ms();
   // output order: PiA | PiAp | PiB | PiBp | PiC | PiCp | PiH | PiKp

@@ -106,6 +106,7 @@ struct Ctx {
   std::unordered_map<uint64_t, std::unique_ptr<Object>> objs;
   int window_bits = 0;           // 0 = auto
   gs_timing timing{};
+  std::mutex timing_mu;          // msm_finish of several groups may run on different host threads
   // reusable workspaces (grow-only)
   DevBuf ws_hist, ws_offsets, ws_cursor, ws_entries, ws_tiles, ws_total;
   DevBuf ws_buckets[8], ws_chunks[8], ws_partials[8], ws_out[8];

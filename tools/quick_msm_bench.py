@@ -18,7 +18,7 @@ for g2 in (False, True):
         bases = (capi.g2_fixed_base if g2 else capi.g1_fixed_base)(k)
         tfb = time.time() - t0
         s = capi.scalars_upload(U.rand_scalars_u64(n, 2))
-        for cbits in ([0] if logn < 20 else [0, 14, 15]):
+        for cbits in ([0] if logn < 20 else [0, 16, 15]):
             capi.set_window_bits(cbits)
             capi.msm_resident(bases, s, n, g2=g2)
             t0 = time.time()
