@@ -40,6 +40,27 @@ G2_TERM_BYTES = 160
 R = groth16.R
 
 
+def cpu_baseline_all_cores(log2n_sample, seed):
+    """Same algorithm with the term ranges of every MSM split over all host threads (oracle_msm_naive_mt); the reference
+    itself is single-threaded (no goroutines), so this is an upper bound on what its algorithm gets from the host."""
+    from oracle import c_oracle as C
+    threads = os.cpu_count() or 1
+    n = 1 << log2n_sample
+    inst = synth.random_instance(n, seed)
+    g1 = {k: capi.g1_download(inst.g1[k]) for k in ("at", "bacgamma", "bacdelta", "ptd")}
+    g2 = capi.g2_download(inst.g2_bacgamma)
+    w, hx = inst.w_host, inst.px_host[:n]          # the O(n^2) schoolbook Div is left out here (it does not thread)
+    t0 = time.perf_counter()
+    C.g1_msm_naive(g1["at"], w, threads=threads)
+    C.g1_msm_naive(g1["bacgamma"], w, threads=threads)
+    C.g2_msm_naive(g2, w, threads=threads)
+    C.g1_msm_naive(g1["bacdelta"][2:], w[2:], threads=threads)
+    C.g1_msm_naive(g1["ptd"], hx, threads=threads)
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "constraints/s", "cores": threads, "kind": "port",
+            "sample": "the five naive MSMs of a Groth16 prove at n=2^%d (no Div), term ranges over %d threads, %.2f s" % (log2n_sample, threads, dt)}
+
+
 def cpu_baseline(log2n_sample, seed):
     """The reference algorithm on one host core: sum_i MulScalar(base_i, w_i) loops
     (groth16.go:243-250,269-271 / g1.go:140-155 + :32-89) and schoolbook Div (r1csqap.go:70-84),
@@ -198,7 +219,12 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_bucket_accumulate<G1>", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "avg_launch_ms": avg_launch_s * 1e3, "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "note": "integer-issue bound (254-bit modular arithmetic on 32-bit VALU), see DESIGN.md"},
+                         "note": "integer-issue bound (254-bit modular arithmetic on 32-bit VALU): PMC evidence in "
+                                 "profiles/r01c_pmc_sq_accumulate_g1.txt (VALU ~96 % busy), see DESIGN.md section 5"},
+            "roofline_whole_step": {"bound": "hbm", "algorithmic_bytes_per_step": (672 * n if args.workload == "prove" else G1_TERM_BYTES * n),
+                                    "achieved": (672 * n if args.workload == "prove" else G1_TERM_BYTES * n) / (elapsed / args.steps) / 1e9,
+                                    "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                    "note": "SURVEY 8d: 672 B per constraint per proof (544 n MSM + 128 n H stage), wall time per step"},
             "device_ms_per_step": {k: tm_acc[k] / args.steps for k in ("total_ms", "poly_ms", "plan_ms", "accumulate_ms", "reduce_ms", "acc_g1_ms", "acc_g2_ms")},
         }
         try:
@@ -215,6 +241,7 @@ def main():
             out["proof_check"] = proof_check
         if world == 1 and args.cpu_log2n > 0:
             out["cpu_baseline"] = cpu_baseline(args.cpu_log2n, seed + 1000)
+            out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(args.cpu_log2n + 3, seed + 2000)
             if args.workload != "prove":
                 out["cpu_baseline"]["note"] = "baseline is the Groth16 prove sample; 1 constraint ~ 4 G1 + 1 G2 terms"
         print(json.dumps(out), flush=True)
