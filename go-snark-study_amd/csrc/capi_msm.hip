@@ -194,6 +194,7 @@ void gs_shutdown(void) {
   std::lock_guard<std::mutex> lk(c.mu);
   if (!c.ready) return;
   (void)hipStreamSynchronize(c.stream);
+  for (auto& f : c.inflight) f.reset();
   c.objs.clear();
   c.ready = false;
 }
@@ -293,7 +294,7 @@ int gs_last_timing(gs_timing* out) {
     if (!out) return fail(GS_ERR_ARG, "null");
     *out = c.timing;
     return GS_OK;
-  });
+  }, true, true);
 }
 
 int gs_set_window_bits(int cbits) {

@@ -33,10 +33,10 @@ static void exclusive_scan(Ctx& c, PlanBuffers& pb, const uint32_t* in, uint32_t
   hipLaunchKernelGGL(k_scan_add, dim3(ntiles), dim3(kScanBlock), 0, c.stream, out, pb.tiles.as<uint32_t>(), n);
 }
 
-static PlanBuffers g_plan_slots[2];
+static PlanBuffers g_plan_slots[4];          // (w, h) x (two proofs in flight)
 
 void build_plan(Ctx& c, int slot, const uint32_t* scalars_dev, uint32_t n, MsmPlan& plan) {
-  PlanBuffers& pb = g_plan_slots[slot & 1];
+  PlanBuffers& pb = g_plan_slots[slot & 3];
   plan.n = n;
   plan.c = choose_window_bits(n, c.window_bits);
   plan.W = 254 / plan.c + 1;
@@ -123,15 +123,15 @@ static void msm_enqueue(Ctx& c, const MsmPlan& plan, const std::vector<MsmBase>&
   const size_t out_bytes = (size_t)njobs * nblk * 2 * pw * 4;
   if (out_bytes > Ctx::kPinnedBytes) throw HipError{hipErrorInvalidValue, "MSM result staging too small", __LINE__};
   AccJobs jobs{};
-  DevBuf& outb = c.ws_out[ws_base % 8];
+  DevBuf& outb = c.ws_out[ws_base % 16];
   outb.ensure(out_bytes);
   for (int j = 0; j < njobs; ++j) {
     const BaseTable* t = bases[j].table;
     if (!t || t->c != plan.c || bases[j].off + plan.n > t->n)
       throw HipError{hipErrorInvalidValue, "MSM base table does not match the plan", __LINE__};
-    DevBuf& bk = c.ws_buckets[(ws_base + j) % 8];
-    DevBuf& mg = c.ws_chunks[(ws_base + j) % 8];
-    DevBuf& pt = c.ws_partials[(ws_base + j) % 8];
+    DevBuf& bk = c.ws_buckets[(ws_base + j) % 16];
+    DevBuf& mg = c.ws_chunks[(ws_base + j) % 16];
+    DevBuf& pt = c.ws_partials[(ws_base + j) % 16];
     bk.ensure((size_t)plan.nbuckets * pw * 4);
     mg.ensure((size_t)plan.B * pw * 4);
     pt.ensure((size_t)plan.maxchunks * 2 * pw * 4);

@@ -78,7 +78,41 @@ static void shard_range(size_t n, const Shard& sh, size_t& lo, size_t& hi) {
 
 void groth16_tail(GrothPkObj* pk, const GrothSums& sums, const uint64_t r[4], const uint64_t s[4], uint64_t out_proof[32], int inf[3]);
 
-int groth16_sums_impl(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, const Shard& shard, GrothSums& sums) {
+// One proof in flight.  Two may be outstanding (parity 0 / 1 own disjoint plan buffers, bucket workspaces and pinned result
+// slots), so the plan and accumulations of proof k+1 are enqueued behind proof k's last accumulation and run while proof
+// k's combine/reduce tails, its result download and its host-side tail are still in progress.
+struct GrothTailPre {             // the tail products that need no MSM result (computed while the device runs)
+  std::future<G2Xyzz> sdelta2;
+  std::future<G1Xyzz> sdelta;
+  G1Xyzz rdelta, rsdelta;
+};
+struct GrothInFlight : InFlightBase {
+  GrothPkObj* pk = nullptr;
+  uint64_t r[4] = {0, 0, 0, 0}, s[4] = {0, 0, 0, 0};
+  bool with_tail = false;
+  hipEvent_t planh = nullptr, done_main = nullptr, done_aux0 = nullptr, done_aux2 = nullptr;
+  std::unique_ptr<PhaseTimer> total;
+  MsmPending pend_g1w, pend_g2w, pend_h;
+  std::shared_ptr<PhaseTimer> tpoly, tplanw, tplanh;
+  GrothTailPre pre;
+  std::future<void> fpre;
+  GrothInFlight() {
+    GS_HIP(hipEventCreateWithFlags(&planh, hipEventDisableTiming));
+    GS_HIP(hipEventCreateWithFlags(&done_main, hipEventDisableTiming));
+    GS_HIP(hipEventCreateWithFlags(&done_aux0, hipEventDisableTiming));
+    GS_HIP(hipEventCreateWithFlags(&done_aux2, hipEventDisableTiming));
+  }
+  ~GrothInFlight() override {
+    if (fpre.valid()) fpre.wait();
+    for (hipEvent_t e : {planh, done_main, done_aux0, done_aux2}) if (e) (void)hipEventDestroy(e);
+  }
+};
+
+static void groth16_tail_pre(GrothPkObj* pk, const uint64_t r[4], const uint64_t s[4], GrothTailPre& pre);
+
+// Enqueue every device operation of one proof (no host wait).  `wait_inputs`: w / px were uploaded on the main stream
+// in this call, so the aux streams must order themselves behind that point.
+int groth16_enqueue(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, const Shard& shard, int parity, bool wait_inputs, GrothInFlight& st) {
   if (w.n != pk->nvars) return fail(GS_ERR_SHAPE, "len(w) = %zu but the key has %zu variables", w.n, pk->nvars);
   const size_t nh = quotient_len(px.n, pk->nz);
   if (nh > pk->nptd)
@@ -96,62 +130,80 @@ int groth16_sums_impl(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, const
     ensure_table_g1(c, pk->t_ptd, pk->ptd.as<uint32_t>(), pk->nptd, ch);
     g_hx.ensure(std::max<size_t>(nh, 1) * 32);
   }
-  PhaseTimer total(c.main_stream);
-  Fork fork(c);
+  st.pk = pk;
+  st.total = std::make_unique<PhaseTimer>(c.main_stream);
+  if (wait_inputs) {
+    hipEvent_t start;
+    GS_HIP(hipEventCreateWithFlags(&start, hipEventDisableTiming));
+    GS_HIP(hipEventRecord(start, c.main_stream));
+    for (auto a : c.aux_stream) GS_HIP(hipStreamWaitEvent(a, start, 0));
+    GS_HIP(hipEventDestroy(start));
+  }
+  const int ws = 8 * parity, pin = 3 * parity;
   MsmPlan plan_w, plan_h;
-  MsmPending pend_g1w, pend_g2w, pend_h;
-  std::shared_ptr<PhaseTimer> tpoly, tplanw, tplanh;
   {                                                              // main: plan(w), then the accumulations back to back
     StreamScope sc(c, c.main_stream);
-    tplanw = std::make_shared<PhaseTimer>(c.stream);
-    build_plan(c, 0, w.p + wlo * 8, (uint32_t)(whi - wlo), plan_w);
-    tplanw->stop();
+    st.tplanw = std::make_shared<PhaseTimer>(c.stream);
+    build_plan(c, 0 + 2 * parity, w.p + wlo * 8, (uint32_t)(whi - wlo), plan_w);
+    st.tplanw->stop();
     // BACDelta's first npublic+1 entries are forced to infinity at key creation, so the reference's
     // loop from NPublic+1 (:248-250) equals a full-range MSM sharing w's plan.
     // G2 first: its accumulation (2 waves/SIMD, 256 VGPRs) is the one a foreign wave hurts most, so it runs while only the
     // cheap H(x)/plan(h) kernels are in flight; its long combine/reduce tail then hides behind the G1 accumulations.
-    msm_enqueue_g2(c, plan_w, {MsmBase{&pk->t_bacgamma2, wlo}}, 4, 1, pend_g2w, c.aux_stream[0]);
-    msm_enqueue_g1(c, plan_w, {MsmBase{&pk->t_at, wlo}, MsmBase{&pk->t_bacgamma1, wlo}, MsmBase{&pk->t_bacdelta, wlo}}, 0, 0, pend_g1w,
-                   c.aux_stream[2]);
+    msm_enqueue_g2(c, plan_w, {MsmBase{&pk->t_bacgamma2, wlo}}, ws + 4, pin + 1, st.pend_g2w, c.aux_stream[0]);
+    msm_enqueue_g1(c, plan_w, {MsmBase{&pk->t_at, wlo}, MsmBase{&pk->t_bacgamma1, wlo}, MsmBase{&pk->t_bacdelta, wlo}}, ws + 0, pin + 0,
+                   st.pend_g1w, c.aux_stream[2]);
   }
   {                                                              // aux 1: H(x), plan(h)
     StreamScope sc(c, c.aux_stream[1]);
-    tpoly = std::make_shared<PhaseTimer>(c.stream);
+    st.tpoly = std::make_shared<PhaseTimer>(c.stream);
     if (nh) poly_quotient_dev(c, pk->z, px.p, px.n, g_hx.as<uint32_t>());      // groth16.go:266
-    tpoly->stop();
-    tplanh = std::make_shared<PhaseTimer>(c.stream);
-    build_plan(c, 1, g_hx.as<uint32_t>() + hlo * 8, (uint32_t)(hhi - hlo), plan_h);
-    tplanh->stop();
-    GS_HIP(hipEventRecord(fork.planh, c.stream));
+    st.tpoly->stop();
+    st.tplanh = std::make_shared<PhaseTimer>(c.stream);
+    build_plan(c, 1 + 2 * parity, g_hx.as<uint32_t>() + hlo * 8, (uint32_t)(hhi - hlo), plan_h);
+    st.tplanh->stop();
+    GS_HIP(hipEventRecord(st.planh, c.stream));
   }
   {                                                              // main again: sum h_i PTD_i once plan(h) exists
     StreamScope sc(c, c.main_stream);
-    GS_HIP(hipStreamWaitEvent(c.stream, fork.planh, 0));
-    msm_enqueue_g1(c, plan_h, {MsmBase{&pk->t_ptd, hlo}}, 3, 2, pend_h);        // :269-271
+    GS_HIP(hipStreamWaitEvent(c.stream, st.planh, 0));
+    msm_enqueue_g1(c, plan_h, {MsmBase{&pk->t_ptd, hlo}}, ws + 3, pin + 2, st.pend_h);        // :269-271
   }
-  fork.join();
-  total.stop();
+  st.total->stop();
+  GS_HIP(hipEventRecord(st.done_main, c.main_stream));
+  GS_HIP(hipEventRecord(st.done_aux0, c.aux_stream[0]));
+  GS_HIP(hipEventRecord(st.done_aux2, c.aux_stream[2]));
+  return GS_OK;
+}
+
+// Wait for that proof's device work (only its own events: later proofs keep running) and add up the results.
+int groth16_collect(Ctx& c, GrothInFlight& st, GrothSums& sums) {
+  GS_HIP(hipEventSynchronize(st.done_main));
+  GS_HIP(hipEventSynchronize(st.done_aux0));
+  GS_HIP(hipEventSynchronize(st.done_aux2));
   std::vector<G1Xyzz> g1w, g1h;
   std::vector<G2Xyzz> g2w;
   {                                                              // the host-side pair sums of the three groups, on separate cores
-    auto f2 = std::async(std::launch::async, [&] { msm_finish_g2(c, pend_g2w, g2w); });
-    auto fh = std::async(std::launch::async, [&] { msm_finish_g1(c, pend_h, g1h); });
-    msm_finish_g1(c, pend_g1w, g1w);
+    auto f2 = std::async(std::launch::async, [&] { msm_finish_g2(c, st.pend_g2w, g2w); });
+    auto fh = std::async(std::launch::async, [&] { msm_finish_g1(c, st.pend_h, g1h); });
+    msm_finish_g1(c, st.pend_g1w, g1w);
     f2.get(); fh.get();
   }
-  c.timing.poly_ms += tpoly->ms();
-  c.timing.plan_ms += tplanw->ms() + tplanh->ms();
-  c.timing.total_ms += total.ms();
+  c.timing.poly_ms += st.tpoly->ms();
+  c.timing.plan_ms += st.tplanw->ms() + st.tplanh->ms();
+  c.timing.total_ms += st.total->ms();
   sums.at = g1w[0]; sums.bacgamma1 = g1w[1]; sums.bacdelta = g1w[2]; sums.h = g1h[0]; sums.bacgamma2 = g2w[0];
   return GS_OK;
 }
 
+int groth16_sums_impl(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, const Shard& shard, GrothSums& sums) {
+  GrothInFlight st;
+  const int rc = groth16_enqueue(c, pk, w, px, shard, c.free_parity(), true, st);
+  if (rc != GS_OK) return rc;
+  return groth16_collect(c, st, sums);
+}
+
 // --- the O(1) tail on host cores (groth16.go:253-275) ----------------------------------------------------
-struct GrothTailPre {             // the products that need no MSM result (computed while the device runs)
-  std::future<G2Xyzz> sdelta2;
-  std::future<G1Xyzz> sdelta;
-  G1Xyzz rdelta, rsdelta;
-};
 static void groth16_tail_pre(GrothPkObj* pk, const uint64_t r[4], const uint64_t s[4], GrothTailPre& pre) {
   const G1Xyzz delta = xyzz_from_affine(pk->delta);
   const G2Xyzz delta2 = xyzz_from_affine(pk->delta2);
@@ -439,6 +491,51 @@ int gs_groth16_prove_resident(gs_handle hpk, gs_handle hw, gs_handle hpx, const 
     reset_timing(c);
     return groth16_prove_impl(c, pk, DevScalars{w->buf.as<uint32_t>(), w->n}, DevScalars{px->buf.as<uint32_t>(), px->n}, r, s, out_proof, inf);
   });
+}
+
+// Pipelined proving: begin enqueues a whole proof and returns; end waits for THAT proof only and runs its tail.  With two
+// proofs outstanding the device never idles between proofs (the next plan/accumulations are already queued) and the host
+// tail of proof k overlaps the device work of proof k+1.
+int gs_groth16_prove_begin(gs_handle hpk, gs_handle hw, gs_handle hpx, const uint64_t r[4], const uint64_t s[4], uint64_t* ticket) {
+  return guarded([&](Ctx& c) -> int {
+    GrothPkObj* pk = c.get<GrothPkObj>(hpk, Kind::GrothPk);
+    Scalars* w = c.get<Scalars>(hw, Kind::Scalars);
+    Scalars* px = c.get<Scalars>(hpx, Kind::Scalars);
+    if (!pk || !w || !px) return fail(GS_ERR_ARG, "gs_groth16_prove_begin: bad handle");
+    if (!r || !s || !ticket) return fail(GS_ERR_ARG, "null argument");
+    const int parity = c.free_parity();
+    if (parity < 0) return fail(GS_ERR_ARG, "gs_groth16_prove_begin: two proofs are already outstanding; call gs_groth16_prove_end first");
+    auto st = std::make_unique<GrothInFlight>();
+    memcpy(st->r, r, 32); memcpy(st->s, s, 32);
+    st->with_tail = true;
+    GrothInFlight* raw = st.get();
+    raw->pk = pk;
+    raw->fpre = std::async(std::launch::async, [raw] { groth16_tail_pre(raw->pk, raw->r, raw->s, raw->pre); });
+    const int rc = groth16_enqueue(c, pk, DevScalars{w->buf.as<uint32_t>(), w->n}, DevScalars{px->buf.as<uint32_t>(), px->n}, Shard{}, parity, false, *raw);
+    if (rc != GS_OK) return rc;
+    st->ticket = c.next_ticket++;
+    *ticket = st->ticket;
+    c.inflight[parity] = std::move(st);
+    return GS_OK;
+  }, true, true);
+}
+
+int gs_groth16_prove_end(uint64_t ticket, uint64_t out_proof[32], int inf[3]) {
+  return guarded([&](Ctx& c) -> int {
+    if (!out_proof || !inf) return fail(GS_ERR_ARG, "null argument");
+    int parity = -1;
+    for (int p = 0; p < 2; ++p) if (c.inflight[p] && c.inflight[p]->ticket == ticket) parity = p;
+    if (parity < 0) return fail(GS_ERR_ARG, "gs_groth16_prove_end: unknown ticket %llu", (unsigned long long)ticket);
+    std::unique_ptr<InFlightBase> base = std::move(c.inflight[parity]);
+    GrothInFlight& st = static_cast<GrothInFlight&>(*base);
+    reset_timing(c);
+    GrothSums sums;
+    const int rc = groth16_collect(c, st, sums);
+    if (rc != GS_OK) return rc;
+    st.fpre.get();
+    groth16_tail_post(st.pk, sums, st.pre, st.r, st.s, out_proof, inf);
+    return GS_OK;
+  }, true, true);
 }
 
 // Sharded proving: the five raw sums over this rank's term ranges, as affine points.

@@ -94,12 +94,21 @@ struct Scalars : Object {        // n x 8 u32 words, standard form, resident
   Scalars() : Object(Kind::Scalars) {}
 };
 
+// a proof whose device work has been enqueued but not collected yet (prove.hip)
+struct InFlightBase {
+  uint64_t ticket = 0;
+  virtual ~InFlightBase() = default;
+};
+
 struct Ctx {
   int device = -1;
   bool ready = false;
   hipStream_t stream = nullptr;   // the stream every engine function enqueues on (switched by StreamScope)
   hipStream_t main_stream = nullptr, aux_stream[3] = {nullptr, nullptr, nullptr};
-  void* pinned[3] = {nullptr, nullptr, nullptr};     // host staging for the per-stream result downloads
+  void* pinned[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // host staging of the result downloads (3 per proof in flight)
+  std::unique_ptr<InFlightBase> inflight[2];         // pipelined proofs (parity = which buffer set they own)
+  uint64_t next_ticket = 1;
+  int free_parity() const { return !inflight[0] ? 0 : (!inflight[1] ? 1 : -1); }
   static constexpr size_t kPinnedBytes = 256 * 1024;
   std::mutex mu;
   uint64_t next_handle = 1;
@@ -109,7 +118,7 @@ struct Ctx {
   std::mutex timing_mu;          // msm_finish of several groups may run on different host threads
   // reusable workspaces (grow-only)
   DevBuf ws_hist, ws_offsets, ws_cursor, ws_entries, ws_tiles, ws_total;
-  DevBuf ws_buckets[8], ws_chunks[8], ws_partials[8], ws_out[8];
+  DevBuf ws_buckets[16], ws_chunks[16], ws_partials[16], ws_out[16];     // 8 workspace sets per proof in flight
   DevBuf ws_misc;
   DevBuf g1_pow2, g2_pow2;       // 2^j * G tables (lazy)
   std::vector<hipEvent_t> events;
@@ -133,10 +142,12 @@ inline Ctx& ctx() {
 
 // every entry point: lock, check init, translate exceptions into status codes
 template <class F>
-int guarded(F&& f, bool need_init = true) {
+int guarded(F&& f, bool need_init = true, bool allow_inflight = false) {
   Ctx& c = ctx();
   std::lock_guard<std::mutex> lk(c.mu);
   if (need_init && !c.ready) return fail(GS_ERR_NOT_INIT, "gs_init has not been called (or failed)");
+  if (need_init && !allow_inflight && (c.inflight[0] || c.inflight[1]))
+    return fail(GS_ERR_ARG, "a pipelined proof is outstanding (gs_groth16_prove_begin): call gs_groth16_prove_end before any other entry point");
   try {
     return f(c);
   } catch (const HipError& e) {

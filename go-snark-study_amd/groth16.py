@@ -225,3 +225,22 @@ def prove_sharded(dev_pk, w_handle, px_handle, r, s, group=None):
     pts, flags = prove_partials(dev_pk, w_handle, px_handle, rank, world)
     per_rank = parallel.allgather_points(pts, flags, group)
     return finish(dev_pk, parallel.combine_partials(per_rank, flags), r, s)
+
+
+def prove_begin(dev_pk, w_handle, px_handle, r, s):
+    """Enqueue one proof (gs_groth16_prove_begin) -> ticket.  At most two may be outstanding."""
+    import ctypes
+    rs = capi.ints_to_u64([r % R, s % R])
+    t = ctypes.c_uint64(0)
+    capi.check(capi.load_library().gs_groth16_prove_begin(capi.Handle(dev_pk.handle.h), capi.Handle(w_handle.h), capi.Handle(px_handle.h),
+                                                          capi.ptr64(rs[0]), capi.ptr64(rs[1]), ctypes.cast(ctypes.byref(t), capi.u64p)))
+    return t.value
+
+
+def prove_end(ticket):
+    """Wait for that proof and return it (gs_groth16_prove_end)."""
+    import ctypes
+    out = np.zeros(32, dtype=np.uint64)
+    inf = (ctypes.c_int * 3)()
+    capi.check(capi.load_library().gs_groth16_prove_end(ctypes.c_uint64(ticket), capi.ptr64(out), inf))
+    return _proof_from_words(out, inf)

@@ -153,6 +153,14 @@ int gs_groth16_prove(gs_handle pk, const uint64_t* w, size_t nw, const uint64_t*
 int gs_groth16_prove_resident(gs_handle pk, gs_handle w, gs_handle px,
                               const uint64_t r[4], const uint64_t s[4], uint64_t out_proof[32], int inf[3]);
 
+/* Pipelined proving (inputs resident): gs_groth16_prove_begin enqueues the whole device side of one proof and returns a
+ * ticket without waiting; gs_groth16_prove_end waits for THAT proof only, then runs the host tail and writes the proof
+ * (same layout as gs_groth16_prove).  At most two proofs may be outstanding; they own disjoint workspaces, so the plan and
+ * bucket accumulations of proof k+1 run while the reduction tails, result download and host tail of proof k are still in
+ * progress.  While a ticket is outstanding every other entry point returns GS_ERR_ARG (finish the tickets first). */
+int gs_groth16_prove_begin(gs_handle pk, gs_handle w, gs_handle px, const uint64_t r[4], const uint64_t s[4], uint64_t* ticket);
+int gs_groth16_prove_end(uint64_t ticket, uint64_t out_proof[32], int inf[3]);
+
 /* One proof over several GPUs: every rank holds the key and the resident w / px, takes shard `shard_index` of
  * `shard_count` of the term ranges (contiguous, first ranges one longer when they do not divide), computes H(x) locally
  * (the polynomial stage is replicated) and returns its five raw MSM sums as affine points:

@@ -415,3 +415,43 @@ def test_device_pinocchio_setup_equals_the_key_the_reference_verifier_accepted()
     for k in ("PiA", "PiAp", "PiBp", "PiC", "PiCp", "PiH", "PiKp"):
         assert getattr(proof, k) == jac_affine_g1(GU.g1(rec["proof"][k])), k
     assert proof.PiB == jac_affine_g2(GU.g2(rec["proof"]["PiB"]))
+
+
+def test_pipelined_proving_two_in_flight_equals_blocking_calls():
+    """gs_groth16_prove_begin / _end: two proofs outstanding on disjoint workspaces; results equal the blocking entry point
+    (different witnesses and randomness per proof, collected in order); a third begin and any other entry point are refused
+    while tickets are outstanding."""
+    from gosnark_amd import synth
+    n = 1 << 12
+    inst = synth.sqchain_setup_instance(n, 0x717E)
+    pk = inst.device_pk()
+    inst_bases_dummy()
+    _, _, _, w2 = synth.sqchain_r1cs(n, 424242)
+    _, _, _, px2 = r1csqap.ComputePx(*inst.r1cs, w2, n + 1)
+    w2h, px2h = capi.scalars_upload(w2), capi.scalars_upload(px2)
+    rs = [tuple(synth.field_elems(2, 500 + i)) for i in range(5)]
+    inputs = [(inst.w, inst.px), (w2h, px2h), (inst.w, inst.px), (w2h, px2h), (inst.w, inst.px)]
+    want = [groth16.prove_resident(pk, w, px, r, s) for (w, px), (r, s) in zip(inputs, rs)]
+    got, tickets = [], []
+    for (w, px), (r, s) in zip(inputs, rs):
+        tickets.append(groth16.prove_begin(pk, w, px, r, s))
+        if len(tickets) == 2:
+            with pytest.raises(capi.GosnarkHipError):          # only two may be outstanding
+                groth16.prove_begin(pk, w, px, r, s)
+            with pytest.raises(capi.GosnarkHipError):          # and nothing else may run meanwhile
+                capi.msm(inst_bases_dummy(), np.zeros((1, 4), dtype=np.uint64))
+            got.append(groth16.prove_end(tickets.pop(0)))
+    while tickets:
+        got.append(groth16.prove_end(tickets.pop(0)))
+    assert [(p.PiA, p.PiB, p.PiC) for p in got] == [(p.PiA, p.PiB, p.PiC) for p in want]
+    with pytest.raises(capi.GosnarkHipError):
+        groth16.prove_end(123456)                                # unknown ticket
+
+
+_DUMMY_BASES = []
+
+
+def inst_bases_dummy():
+    if not _DUMMY_BASES:
+        _DUMMY_BASES.append(capi.g1_upload(capi.g1_points_to_u64([O.G1_GEN])))
+    return _DUMMY_BASES[0]
