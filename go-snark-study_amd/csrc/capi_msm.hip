@@ -84,7 +84,7 @@ int msm_resident(Ctx& c, Kind kind, gs_handle hb, size_t off, const uint32_t* sc
   MsmPlan plan;
   {
     PhaseTimer tp(c.stream);
-    build_plan(c, 0, scalars_dev, (uint32_t)n, plan);
+    build_plan(c, 0, scalars_dev, (uint32_t)n, plan, {{1, T::kWords == 16}});
     tp.stop();
     c.timing.plan_ms += tp.ms();
   }

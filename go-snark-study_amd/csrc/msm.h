@@ -17,7 +17,8 @@ struct MsmPlan {                 // digits of one scalar vector, bucket-sorted (
   int c = 0, W = 0;
   uint32_t B = 0;                // buckets per window
   uint32_t nbuckets = 0;         // W * B
-  uint32_t maxchunks = 0;        // upper bound of the number of 32-entry chunks (the exact count stays on the device)
+  uint32_t chunk = 32;           // entries per accumulate thread (32 or 64)
+  uint32_t maxchunks = 0;        // upper bound of the number of chunks (the exact count stays on the device)
   const uint32_t* offsets = nullptr;        // nbuckets + 1 (offsets[nbuckets] = number of entries)
   const uint32_t* entries = nullptr;
   const uint32_t* chunk_bucket = nullptr;   // maxchunks
@@ -43,8 +44,11 @@ struct MsmBase {                 // one job of an MSM launch: a window table and
   size_t off;
 };
 
-// scalars_dev: n x 8 u32 words (standard form, any 256-bit value).  slot: 0/1 (two plans may be alive)
-void build_plan(Ctx& c, int slot, const uint32_t* scalars_dev, uint32_t n, MsmPlan& plan);
+// A launch that will consume a plan: how many base arrays it sums at once and whether they are G2.
+struct LaunchShape { int njobs; bool g2; };
+// scalars_dev: n x 8 u32 words (standard form, any 256-bit value).  slot: 0..3 (four plans may be alive).  `users`: the
+// launches that will run on this plan (decides the chunk size: whole wave rounds for every one of them).
+void build_plan(Ctx& c, int slot, const uint32_t* scalars_dev, uint32_t n, MsmPlan& plan, const std::vector<LaunchShape>& users);
 
 // One launch sequence for up to 8 base arrays sharing a plan (their tables must have been built for plan.c).
 // msm_enqueue_* only ENQUEUES on c.stream (kernels + the async download of the <= 16 workgroup pairs per

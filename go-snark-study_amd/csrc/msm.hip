@@ -2,6 +2,7 @@
 #include "msm.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <future>
 
@@ -35,14 +36,24 @@ static void exclusive_scan(Ctx& c, PlanBuffers& pb, const uint32_t* in, uint32_t
 
 static PlanBuffers g_plan_slots[4];          // (w, h) x (two proofs in flight)
 
-void build_plan(Ctx& c, int slot, const uint32_t* scalars_dev, uint32_t n, MsmPlan& plan) {
+// Chunk size of a plan.  64-entry chunks halve the chunk partials the combine/reduce tails have to add up and the bucket
+// flushes of the accumulation; below ~2^22 entries there are too few threads for that to pay (measured at 2^20 terms:
+// proof 10.85 ms with 64 everywhere, 11.15 ms with 32 everywhere or with a per-launch "whole wave rounds" model, which
+// turned out not to be predictive; 2^16-term MSM 0.66 ms with 32, 0.80 ms with 64).
+static uint32_t choose_chunk(uint64_t entries, const std::vector<LaunchShape>& users) {
+  (void)users;
+  return entries >= (1ull << 22) ? 64u : 32u;
+}
+
+void build_plan(Ctx& c, int slot, const uint32_t* scalars_dev, uint32_t n, MsmPlan& plan, const std::vector<LaunchShape>& users) {
   PlanBuffers& pb = g_plan_slots[slot & 3];
   plan.n = n;
   plan.c = choose_window_bits(n, c.window_bits);
   plan.W = 254 / plan.c + 1;
   plan.B = 1u << (plan.c - 1);
   plan.nbuckets = plan.B;                      // one bucket set for all windows (window tables)
-  plan.maxchunks = (uint32_t)(((size_t)n * plan.W + kChunk - 1) / kChunk) + 1;
+  plan.chunk = choose_chunk((uint64_t)n * plan.W, users);
+  plan.maxchunks = (uint32_t)(((size_t)n * plan.W + plan.chunk - 1) / plan.chunk) + 1;
   const size_t ncount = (size_t)plan.nbuckets + 1;
   PlanParams pp{};
   pp.n = n; pp.c = plan.c; pp.W = plan.W; pp.B = plan.B;
@@ -55,7 +66,7 @@ void build_plan(Ctx& c, int slot, const uint32_t* scalars_dev, uint32_t n, MsmPl
   pb.hist.ensure((size_t)plan.B * plan.W * pp.S * 4);
   pb.totals.ensure(ncount * 4);
   pb.offsets.ensure(ncount * 4);
-  pb.entries.ensure(((size_t)plan.maxchunks + 1) * kChunk * 4);
+  pb.entries.ensure(((size_t)plan.maxchunks + 1) * plan.chunk * 4);
   pb.chunk_bucket.ensure((size_t)plan.maxchunks * 4);
   pb.heavy_list.ensure((size_t)kMaxHeavy * 4);
   pb.counters.ensure(16);
@@ -79,7 +90,7 @@ void build_plan(Ctx& c, int slot, const uint32_t* scalars_dev, uint32_t n, MsmPl
   if (n > 0) {
     hipLaunchKernelGGL(k_scatter, dim3(plan.W, pp.S), dim3(kSortBlock), lds, c.stream, pb.digits.as<digit_t>(), pp, pb.hist.as<uint32_t>(),
                        pb.offsets.as<uint32_t>(), pb.entries.as<uint32_t>());
-    hipLaunchKernelGGL(k_chunk_map, grid1(plan.nbuckets), dim3(256), 0, c.stream, pb.offsets.as<uint32_t>(), plan.nbuckets,
+    hipLaunchKernelGGL(k_chunk_map, grid1(plan.nbuckets), dim3(256), 0, c.stream, pb.offsets.as<uint32_t>(), plan.nbuckets, plan.chunk,
                        pb.chunk_bucket.as<uint32_t>(), pb.heavy_list.as<uint32_t>(), pb.counters.as<uint32_t>());
   }
   GS_HIP(hipGetLastError());
@@ -142,10 +153,10 @@ static void msm_enqueue(Ctx& c, const MsmPlan& plan, const std::vector<MsmBase>&
   p.tacc = std::make_shared<PhaseTimer>(c.stream);
   p.tker = std::make_shared<PhaseTimer>(c.stream);
   hipLaunchKernelGGL(k_bucket_accumulate<T>, dim3((plan.maxchunks + 255) / 256, njobs), dim3(256), 0, c.stream,
-                     jobs, plan.offsets, plan.entries, plan.chunk_bucket, plan.nbuckets);
+                     jobs, plan.offsets, plan.entries, plan.chunk_bucket, plan.nbuckets, plan.chunk);
   p.tker->stop();
   hipLaunchKernelGGL(k_heavy_combine<T>, dim3(1024, njobs), dim3(kHeavyBlock), 0, c.stream,
-                     jobs, plan.offsets, plan.heavy_list, plan.heavy_count);
+                     jobs, plan.offsets, plan.heavy_list, plan.heavy_count, plan.chunk);
   p.tacc->stop();
   // the latency-bound tail may run on another stream, in the shadow of the next group's accumulation
   hipStream_t ts = tail_stream ? tail_stream : c.stream;
@@ -157,7 +168,7 @@ static void msm_enqueue(Ctx& c, const MsmPlan& plan, const std::vector<MsmBase>&
     GS_HIP(hipEventDestroy(ev));       // released by the runtime once it has fired
   }
   p.tred = std::make_shared<PhaseTimer>(ts);
-  hipLaunchKernelGGL(k_bucket_combine<T>, dim3((plan.B + 255) / 256, njobs), dim3(256), 0, ts, jobs, plan.offsets, plan.B);
+  hipLaunchKernelGGL(k_bucket_combine<T>, dim3((plan.B + 255) / 256, njobs), dim3(256), 0, ts, jobs, plan.offsets, plan.B, plan.chunk);
   hipLaunchKernelGGL(k_block_reduce<T>, dim3(nblk, njobs), dim3(kReduceBlock), 0, ts, jobs, plan.B, L);
   GS_HIP(hipGetLastError());
   GS_HIP(hipMemcpyAsync(c.pinned[slot], outb.p, out_bytes, hipMemcpyDeviceToHost, ts));

@@ -189,25 +189,26 @@ __global__ void __launch_bounds__(kScanBlock) k_scan_add(uint32_t* __restrict__ 
 }
 
 // ---- chunk map (load balance) ------------------------------------------------------------------------------
-// The sorted entry list is cut into chunks of kChunk entries, ONE accumulate thread per chunk, whatever the
+// The sorted entry list is cut into chunks of `chunk` entries (32 or 64, chosen per plan so that the launches that use
+// it fill whole wave rounds -- see choose_chunk in msm.hip), ONE accumulate thread per chunk, whatever the
 // bucket sizes are (uniform scalars: Poisson-sized buckets; real witnesses: 0/1-heavy ones).  A bucket that is
 // cut by chunk boundaries is summed from per-chunk partials:  sum_{t = first}^{last-1} tail[t] + head[last].
-// chunk_bucket[t] = bucket holding entry t*kChunk.  Buckets cut into more than kHeavySpan + 1 pieces are listed
+// chunk_bucket[t] = bucket holding entry t*chunk.  Buckets cut into more than kHeavySpan + 1 pieces are listed
 // for a block-wide tree combine (k_heavy_combine), the others are combined by whoever reads them.
-constexpr uint32_t kChunk = 32;
+constexpr uint32_t kMinChunk = 32;            // chunk sizes are multiples of 32 entries (128-byte aligned entry loads)
 constexpr uint32_t kHeavySpan = 64;
 constexpr uint32_t kMaxHeavy = 1u << 16;
 
-__global__ void __launch_bounds__(256) k_chunk_map(const uint32_t* __restrict__ offsets, uint32_t nbuckets,
+__global__ void __launch_bounds__(256) k_chunk_map(const uint32_t* __restrict__ offsets, uint32_t nbuckets, uint32_t chunk,
                                                     uint32_t* __restrict__ chunk_bucket, uint32_t* __restrict__ heavy_list,
                                                     uint32_t* __restrict__ heavy_count) {
   const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= nbuckets) return;
   const uint32_t o0 = offsets[b], o1 = offsets[b + 1];
   if (o1 == o0) return;
-  const uint32_t t0 = (o0 + kChunk - 1) / kChunk, t1 = (o1 + kChunk - 1) / kChunk;   // chunks starting inside [o0, o1)
+  const uint32_t t0 = (o0 + chunk - 1) / chunk, t1 = (o1 + chunk - 1) / chunk;   // chunks starting inside [o0, o1)
   for (uint32_t t = t0; t < t1; ++t) chunk_bucket[t] = b;
-  if ((o1 - 1) / kChunk - o0 / kChunk > kHeavySpan) {
+  if ((o1 - 1) / chunk - o0 / chunk > kHeavySpan) {
     const uint32_t slot = atomicAdd(heavy_count, 1u);
     if (slot < kMaxHeavy) heavy_list[slot] = b;
   }
@@ -236,14 +237,14 @@ template <> struct AccTuning<Fq2Tag> { static constexpr int kMinWaves = 2; stati
 template <class T>
 __global__ void __launch_bounds__(256, AccTuning<T>::kMinWaves) k_bucket_accumulate(AccJobs jobs, const uint32_t* __restrict__ offsets,
                                                             const uint32_t* __restrict__ entries,
-                                                            const uint32_t* __restrict__ chunk_bucket, uint32_t nbuckets) {
+                                                            const uint32_t* __restrict__ chunk_bucket, uint32_t nbuckets, uint32_t chunk) {
   constexpr int pw = PointIO<T>::kXyzzWords;
   constexpr int aw = PointIO<T>::kAffineWords;
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t total = offsets[nbuckets];
-  const uint32_t beg = t * kChunk;
+  const uint32_t beg = t * chunk;
   if (beg >= total) return;
-  const uint32_t end = min(beg + kChunk, total);
+  const uint32_t end = min(beg + chunk, total);
   const AccJob job = jobs.j[blockIdx.y];
   uint32_t b = chunk_bucket[t];
   uint32_t bend = offsets[b + 1];
@@ -295,11 +296,11 @@ __global__ void __launch_bounds__(256, AccTuning<T>::kMinWaves) k_bucket_accumul
 
 // the sum of bucket b, wherever its pieces are
 template <class T>
-GS_HD Xyzz<T> load_bucket(const AccJob& job, const uint32_t* __restrict__ offsets, uint32_t b) {
+GS_HD Xyzz<T> load_bucket(const AccJob& job, const uint32_t* __restrict__ offsets, uint32_t b, uint32_t chunk) {
   constexpr int pw = PointIO<T>::kXyzzWords;
   const uint32_t o0 = offsets[b], o1 = offsets[b + 1];
   if (o1 == o0) return xyzz_inf<T>();
-  const uint32_t tf = o0 / kChunk, tl = (o1 - 1) / kChunk;
+  const uint32_t tf = o0 / chunk, tl = (o1 - 1) / chunk;
   if (tf == tl || tl - tf > kHeavySpan) return load_xyzz<T>(job.buckets + (size_t)b * pw);
   Xyzz<T> acc = load_xyzz<T>(job.heads + (size_t)tl * pw);
   for (uint32_t t = tf; t < tl; ++t) {
@@ -314,14 +315,14 @@ constexpr int kHeavyBlock = 128;
 template <class T>
 __global__ void __launch_bounds__(kHeavyBlock) k_heavy_combine(AccJobs jobs, const uint32_t* __restrict__ offsets,
                                                                 const uint32_t* __restrict__ heavy_list,
-                                                                const uint32_t* __restrict__ heavy_count) {
+                                                                const uint32_t* __restrict__ heavy_count, uint32_t chunk) {
   constexpr int pw = PointIO<T>::kXyzzWords;
   __shared__ uint32_t sh[kHeavyBlock * pw];
   const AccJob job = jobs.j[blockIdx.y];
   const uint32_t nheavy = min(*heavy_count, kMaxHeavy);
   for (uint32_t h = blockIdx.x; h < nheavy; h += gridDim.x) {
     const uint32_t b = heavy_list[h];
-    const uint32_t tf = offsets[b] / kChunk, tl = (offsets[b + 1] - 1) / kChunk;
+    const uint32_t tf = offsets[b] / chunk, tl = (offsets[b + 1] - 1) / chunk;
     Xyzz<T> acc = xyzz_inf<T>();
     for (uint32_t t = tf + threadIdx.x; t <= tl; t += kHeavyBlock) {
       const Xyzz<T> p = load_xyzz<T>((t == tl ? job.heads : job.tails) + (size_t)t * pw);
@@ -343,15 +344,15 @@ __global__ void __launch_bounds__(kHeavyBlock) k_heavy_combine(AccJobs jobs, con
 }
 
 // ---- bucket combine + reduction ---------------------------------------------------------------------------
-// merged[b] = the pieces of bucket b (it spans ~ n W / (B * kChunk) chunks).  Thanks to the window tables all W
+// merged[b] = the pieces of bucket b (it spans ~ n W / (B * chunk) chunks).  Thanks to the window tables all W
 // digit positions share one bucket set, so the MSM is simply sum_b (b + 1) * merged[b]: no per-window
 // reduction and no Horner recombination.
 template <class T>
-__global__ void __launch_bounds__(256) k_bucket_combine(AccJobs jobs, const uint32_t* __restrict__ offsets, uint32_t B) {
+__global__ void __launch_bounds__(256) k_bucket_combine(AccJobs jobs, const uint32_t* __restrict__ offsets, uint32_t B, uint32_t chunk) {
   const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   const AccJob job = jobs.j[blockIdx.y];
-  store_xyzz<T>(job.merged + (size_t)b * PointIO<T>::kXyzzWords, load_bucket<T>(job, offsets, b));
+  store_xyzz<T>(job.merged + (size_t)b * PointIO<T>::kXyzzWords, load_bucket<T>(job, offsets, b, chunk));
 }
 
 // One workgroup of 256 threads reduces 256 * L consecutive buckets to the pair

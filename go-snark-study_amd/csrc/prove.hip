@@ -144,7 +144,7 @@ int groth16_enqueue(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, const S
   {                                                              // main: plan(w), then the accumulations back to back
     StreamScope sc(c, c.main_stream);
     st.tplanw = std::make_shared<PhaseTimer>(c.stream);
-    build_plan(c, 0 + 2 * parity, w.p + wlo * 8, (uint32_t)(whi - wlo), plan_w);
+    build_plan(c, 0 + 2 * parity, w.p + wlo * 8, (uint32_t)(whi - wlo), plan_w, {{1, true}, {3, false}});
     st.tplanw->stop();
     // BACDelta's first npublic+1 entries are forced to infinity at key creation, so the reference's
     // loop from NPublic+1 (:248-250) equals a full-range MSM sharing w's plan.
@@ -160,7 +160,7 @@ int groth16_enqueue(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, const S
     if (nh) poly_quotient_dev(c, pk->z, px.p, px.n, g_hx.as<uint32_t>());      // groth16.go:266
     st.tpoly->stop();
     st.tplanh = std::make_shared<PhaseTimer>(c.stream);
-    build_plan(c, 1 + 2 * parity, g_hx.as<uint32_t>() + hlo * 8, (uint32_t)(hhi - hlo), plan_h);
+    build_plan(c, 1 + 2 * parity, g_hx.as<uint32_t>() + hlo * 8, (uint32_t)(hhi - hlo), plan_h, {{1, false}});
     st.tplanh->stop();
     GS_HIP(hipEventRecord(st.planh, c.stream));
   }
@@ -277,7 +277,7 @@ int pinocchio_prove_impl(Ctx& c, PinocchioPkObj* pk, DevScalars w, DevScalars px
   {
     StreamScope sc(c, c.main_stream);
     tplanw = std::make_shared<PhaseTimer>(c.stream);
-    build_plan(c, 0, w.p, (uint32_t)w.n, plan_w);
+    build_plan(c, 0, w.p, (uint32_t)w.n, plan_w, {{1, true}, {6, false}});
     tplanw->stop();
     // A and Ap run over i > NPublic only (snark.go:265-268): their first npublic+1 points were forced
     // to infinity at key creation; Bp, C, Cp, Kp and B run over all variables (:270-278).
@@ -291,7 +291,7 @@ int pinocchio_prove_impl(Ctx& c, PinocchioPkObj* pk, DevScalars w, DevScalars px
     if (nh) poly_quotient_dev(c, pk->z, px.p, px.n, g_hx.as<uint32_t>());      // snark.go:280
     tpoly->stop();
     tplanh = std::make_shared<PhaseTimer>(c.stream);
-    build_plan(c, 1, g_hx.as<uint32_t>(), (uint32_t)nh, plan_h);
+    build_plan(c, 1, g_hx.as<uint32_t>(), (uint32_t)nh, plan_h, {{1, false}});
     tplanh->stop();
     GS_HIP(hipEventRecord(fork.planh, c.stream));
   }
