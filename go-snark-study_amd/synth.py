@@ -89,15 +89,17 @@ def random_instance(n, seed):
     return RandomInstance(n, seed)
 
 
-def sqchain_r1cs(n, x):
+def sqchain_r1cs(n, x, extra_vars=0):
     """SURVEY 8d's synthetic circuit: variables [one, s_1 = x (public), s_2 .. s_n] (m = n + 1, NPublic = 1);
     constraint k = 1..n-1:  s_k * s_k = s_{k+1} - k * one;  constraint n:  one * one = one.
-    Returns (a_csr, b_csr, c_csr, w [m,4] uint64); nnz: A = n, B = n, C = 2n - 1 (k = 0 entries are dropped)."""
-    from . import r1csqap
-    m = n + 1
+    Returns (a_csr, b_csr, c_csr, w [m,4] uint64); nnz: A = n, B = n, C = 2n - 1 (k = 0 entries are dropped).
+    extra_vars = 1 appends an unconstrained variable: the m = n + 2 shape the reference also accepts (snark_test.go:280-290)."""
+    m = n + 1 + extra_vars
     wit = [1, x % R]
     for k in range(1, n):
         wit.append((wit[k] * wit[k] + k) % R)
+    for e in range(extra_vars):
+        wit.append((x * 31337 + e + 5) % R)
     idx = np.arange(n, dtype=np.uint32)
     one = np.zeros((n, 4), dtype=np.uint64)
     one[:, 0] = 1
@@ -155,12 +157,12 @@ class SqchainSetupInstance:
     sparse system.  Because the toxic values are known, the proof the prover must emit is known in closed form
     (expected_proof_scalars) -- an end-to-end check at sizes no reference implementation can replay."""
 
-    def __init__(self, n, seed):
+    def __init__(self, n, seed, extra_vars=0):
         from . import r1csqap
-        self.n, self.m, self.seed = n, n + 1, seed
+        self.n, self.m, self.seed = n, n + 1 + extra_vars, seed
         self.toxic = field_elems(5, seed + 20)
         x = field_elems(1, seed + 10)[0]
-        a, b, c, w = sqchain_r1cs(n, x)
+        a, b, c, w = sqchain_r1cs(n, x, extra_vars)
         self.r1cs = (a, b, c)
         self.w_host = w
         self._pk, self.vk = groth16.GenerateTrustedSetupSparse(n, self.m, 1, a, b, c, self.toxic)
@@ -230,5 +232,5 @@ class SqchainSetupInstance:
         return a, b, c
 
 
-def sqchain_setup_instance(n, seed):
-    return SqchainSetupInstance(n, seed)
+def sqchain_setup_instance(n, seed, extra_vars=0):
+    return SqchainSetupInstance(n, seed, extra_vars)

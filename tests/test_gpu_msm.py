@@ -203,3 +203,24 @@ def test_msm_skewed_witness_heavy_buckets(g2):
             assert capi.msm(bases, ks, g2=g2) == want, c
         finally:
             capi.set_window_bits(0)
+
+
+def test_reference_g1_g2_tests_through_the_c_abi():
+    """bn128/g1_test.go:14-31 and g2_test.go:12-25 through the mirror gosnark_amd.bn128 (MulScalar / Add as MSM calls):
+    g*33 + g*44 == g*77, and the affine KAT of 77*G1 the reference pins."""
+    from gosnark_amd import bn128
+    gr1 = bn128.G1.MulScalar(O.G1_GEN, 33)
+    gr2 = bn128.G1.MulScalar(O.G1_GEN, 44)
+    grsum1 = bn128.G1.Add(gr1, gr2)
+    grsum2 = bn128.G1.MulScalar(O.G1_GEN, 33 + 44)
+    assert grsum1 == grsum2
+    a = bn128.G1.Affine(grsum1)
+    assert "%064x" % a[0] == "2f978c0ab89ebaa576866706b14787f360c4d6c3869efe5a72f7c3651a72ff00"      # g1_test.go:29
+    assert "%064x" % a[1] == "12e4ba7f0edca8b4fa668fe153aebd908d322dc26ad964d4cd314795844b62b2"      # g1_test.go:30
+    h1 = bn128.G2.MulScalar(O.G2_GEN, 33)
+    h2 = bn128.G2.MulScalar(O.G2_GEN, 44)
+    assert bn128.G2.Add(h1, h2) == bn128.G2.MulScalar(O.G2_GEN, 77)
+    assert bn128.G2.Affine(bn128.G2.Add(h1, h2)) == O.G2.Affine(O.G2.MulScalar(O.G2_GEN, 77))
+    # identities the reference's Add special-cases (g1.go:33-38): P + 0 = P, 0 + 0 = 0
+    assert bn128.G1.Add(gr1, bn128.G1_ZERO) == gr1 and bn128.G1.Add(bn128.G1_ZERO, bn128.G1_ZERO) == bn128.G1_ZERO
+    assert bn128.G1.MulScalar(gr1, 0) == bn128.G1_ZERO

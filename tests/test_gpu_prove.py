@@ -455,3 +455,22 @@ def inst_bases_dummy():
     if not _DUMMY_BASES:
         _DUMMY_BASES.append(capi.g1_upload(capi.g1_points_to_u64([O.G1_GEN])))
     return _DUMMY_BASES[0]
+
+
+@pytest.mark.parametrize("logn", [3, 9])
+def test_full_pipeline_m_equals_n_plus_2(logn):
+    """The other shape the reference accepts (m = n + 2, e.g. snark_test.go:280-290: n = 4, m = 6): deg Z = n, len(hx) = n - 1,
+    len(PowersTauDelta) = n + 1.  Closed-form check as above, plus shape errors for m outside [n + 1, 2n + 1]."""
+    from gosnark_amd import synth
+    n = 1 << logn
+    inst = synth.sqchain_setup_instance(n, 0xC0DE00 + logn, extra_vars=1)
+    assert inst.m == n + 2
+    r, s = synth.field_elems(2, 6060 + logn)
+    proof = groth16.prove_resident(inst.device_pk(), inst.w, inst.px, r, s)
+    a, b, c = inst.expected_proof_scalars(r, s)
+    assert (proof.PiA[0], proof.PiA[1]) == C.g1_affine(C.g1_mul_scalar(O.G1_GEN, a))
+    assert (proof.PiB[0], proof.PiB[1]) == C.g2_affine(C.g2_mul_scalar(O.G2_GEN, b))
+    assert (proof.PiC[0], proof.PiC[1]) == C.g1_affine(C.g1_mul_scalar(O.G1_GEN, c))
+    ra, rb, rc = inst.r1cs
+    with pytest.raises(capi.GosnarkHipError):          # m = n: len(hx) would exceed len(PowersTauDelta)
+        groth16.GenerateTrustedSetupSparse(n, n, 1, ra, rb, rc, inst.toxic)
