@@ -90,13 +90,14 @@ struct GrothInFlight : InFlightBase {
   GrothPkObj* pk = nullptr;
   uint64_t r[4] = {0, 0, 0, 0}, s[4] = {0, 0, 0, 0};
   bool with_tail = false;
-  hipEvent_t planh = nullptr, done_main = nullptr, done_aux0 = nullptr, done_aux2 = nullptr;
+  hipEvent_t planw = nullptr, planh = nullptr, done_main = nullptr, done_aux0 = nullptr, done_aux2 = nullptr;
   std::unique_ptr<PhaseTimer> total;
   MsmPending pend_g1w, pend_g2w, pend_h;
   std::shared_ptr<PhaseTimer> tpoly, tplanw, tplanh;
   GrothTailPre pre;
   std::future<void> fpre;
   GrothInFlight() {
+    GS_HIP(hipEventCreateWithFlags(&planw, hipEventDisableTiming));
     GS_HIP(hipEventCreateWithFlags(&planh, hipEventDisableTiming));
     GS_HIP(hipEventCreateWithFlags(&done_main, hipEventDisableTiming));
     GS_HIP(hipEventCreateWithFlags(&done_aux0, hipEventDisableTiming));
@@ -104,7 +105,7 @@ struct GrothInFlight : InFlightBase {
   }
   ~GrothInFlight() override {
     if (fpre.valid()) fpre.wait();
-    for (hipEvent_t e : {planh, done_main, done_aux0, done_aux2}) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {planw, planh, done_main, done_aux0, done_aux2}) if (e) (void)hipEventDestroy(e);
   }
 };
 
@@ -112,7 +113,8 @@ static void groth16_tail_pre(GrothPkObj* pk, const uint64_t r[4], const uint64_t
 
 // Enqueue every device operation of one proof (no host wait).  `wait_inputs`: w / px were uploaded on the main stream
 // in this call, so the aux streams must order themselves behind that point.
-int groth16_enqueue(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, const Shard& shard, int parity, bool wait_inputs, GrothInFlight& st) {
+int groth16_enqueue(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, const Shard& shard, int parity, bool wait_inputs, bool pipelined,
+                    GrothInFlight& st) {
   if (w.n != pk->nvars) return fail(GS_ERR_SHAPE, "len(w) = %zu but the key has %zu variables", w.n, pk->nvars);
   const size_t nh = quotient_len(px.n, pk->nz);
   if (nh > pk->nptd)
@@ -141,21 +143,14 @@ int groth16_enqueue(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, const S
   }
   const int ws = 8 * parity, pin = 3 * parity;
   MsmPlan plan_w, plan_h;
-  {                                                              // main: plan(w), then the accumulations back to back
-    StreamScope sc(c, c.main_stream);
+  // The main stream carries NOTHING but the ALU-bound bucket accumulations (G2, then the three G1 arrays over w, then h),
+  // so with two proofs in flight it never idles: both plans, H(x) and every combine/reduce tail run on the aux streams.
+  {                                                              // aux 1: plan(w), then H(x), plan(h)
+    StreamScope sc(c, c.aux_stream[1]);
     st.tplanw = std::make_shared<PhaseTimer>(c.stream);
     build_plan(c, 0 + 2 * parity, w.p + wlo * 8, (uint32_t)(whi - wlo), plan_w, {{1, true}, {3, false}});
     st.tplanw->stop();
-    // BACDelta's first npublic+1 entries are forced to infinity at key creation, so the reference's
-    // loop from NPublic+1 (:248-250) equals a full-range MSM sharing w's plan.
-    // G2 first: its accumulation (2 waves/SIMD, 256 VGPRs) is the one a foreign wave hurts most, so it runs while only the
-    // cheap H(x)/plan(h) kernels are in flight; its long combine/reduce tail then hides behind the G1 accumulations.
-    msm_enqueue_g2(c, plan_w, {MsmBase{&pk->t_bacgamma2, wlo}}, ws + 4, pin + 1, st.pend_g2w, c.aux_stream[0]);
-    msm_enqueue_g1(c, plan_w, {MsmBase{&pk->t_at, wlo}, MsmBase{&pk->t_bacgamma1, wlo}, MsmBase{&pk->t_bacdelta, wlo}}, ws + 0, pin + 0,
-                   st.pend_g1w, c.aux_stream[2]);
-  }
-  {                                                              // aux 1: H(x), plan(h)
-    StreamScope sc(c, c.aux_stream[1]);
+    GS_HIP(hipEventRecord(st.planw, c.stream));
     st.tpoly = std::make_shared<PhaseTimer>(c.stream);
     if (nh) poly_quotient_dev(c, pk->z, px.p, px.n, g_hx.as<uint32_t>());      // groth16.go:266
     st.tpoly->stop();
@@ -164,10 +159,20 @@ int groth16_enqueue(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, const S
     st.tplanh->stop();
     GS_HIP(hipEventRecord(st.planh, c.stream));
   }
-  {                                                              // main again: sum h_i PTD_i once plan(h) exists
+  {                                                              // main: the accumulations back to back
     StreamScope sc(c, c.main_stream);
+    GS_HIP(hipStreamWaitEvent(c.stream, st.planw, 0));
+    // BACDelta's first npublic+1 entries are forced to infinity at key creation, so the reference's
+    // loop from NPublic+1 (:248-250) equals a full-range MSM sharing w's plan.
+    // G2 first: its accumulation (2 waves/SIMD, 256 VGPRs) is the one a foreign wave hurts most, and its long
+    // combine/reduce tail then hides behind the G1 accumulations.
+    msm_enqueue_g2(c, plan_w, {MsmBase{&pk->t_bacgamma2, wlo}}, ws + 4, pin + 1, st.pend_g2w, c.aux_stream[0]);
+    msm_enqueue_g1(c, plan_w, {MsmBase{&pk->t_at, wlo}, MsmBase{&pk->t_bacgamma1, wlo}, MsmBase{&pk->t_bacdelta, wlo}}, ws + 0, pin + 0,
+                   st.pend_g1w, c.aux_stream[2]);
     GS_HIP(hipStreamWaitEvent(c.stream, st.planh, 0));
-    msm_enqueue_g1(c, plan_h, {MsmBase{&pk->t_ptd, hlo}}, ws + 3, pin + 2, st.pend_h);        // :269-271
+    // a lone proof finishes soonest with the last tail right behind its accumulation; in a pipeline that tail must not sit
+    // in front of the next proof's accumulations
+    msm_enqueue_g1(c, plan_h, {MsmBase{&pk->t_ptd, hlo}}, ws + 3, pin + 2, st.pend_h, pipelined ? c.aux_stream[2] : nullptr);   // :269-271
   }
   st.total->stop();
   GS_HIP(hipEventRecord(st.done_main, c.main_stream));
@@ -198,7 +203,7 @@ int groth16_collect(Ctx& c, GrothInFlight& st, GrothSums& sums) {
 
 int groth16_sums_impl(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, const Shard& shard, GrothSums& sums) {
   GrothInFlight st;
-  const int rc = groth16_enqueue(c, pk, w, px, shard, c.free_parity(), true, st);
+  const int rc = groth16_enqueue(c, pk, w, px, shard, c.free_parity(), true, false, st);
   if (rc != GS_OK) return rc;
   return groth16_collect(c, st, sums);
 }
@@ -511,7 +516,7 @@ int gs_groth16_prove_begin(gs_handle hpk, gs_handle hw, gs_handle hpx, const uin
     GrothInFlight* raw = st.get();
     raw->pk = pk;
     raw->fpre = std::async(std::launch::async, [raw] { groth16_tail_pre(raw->pk, raw->r, raw->s, raw->pre); });
-    const int rc = groth16_enqueue(c, pk, DevScalars{w->buf.as<uint32_t>(), w->n}, DevScalars{px->buf.as<uint32_t>(), px->n}, Shard{}, parity, false, *raw);
+    const int rc = groth16_enqueue(c, pk, DevScalars{w->buf.as<uint32_t>(), w->n}, DevScalars{px->buf.as<uint32_t>(), px->n}, Shard{}, parity, false, true, *raw);
     if (rc != GS_OK) return rc;
     st->ticket = c.next_ticket++;
     *ticket = st->ticket;
