@@ -205,29 +205,8 @@ GS_HD Xyzz<T> xyzz_neg(const Xyzz<T>& a) {
   return r;
 }
 
-// k * p for a small non-negative integer k (bucket-reduction segment offsets)
-template <class T>
-GS_HD Xyzz<T> xyzz_mul_u32(const Xyzz<T>& p, uint32_t k) {
-  Xyzz<T> r = xyzz_inf<T>();
-  for (int bit = 31; bit >= 0; --bit) {
-    xyzz_dbl(r);
-    if ((k >> bit) & 1u) xyzz_add(r, p);
-  }
-  return r;
-}
-
-// k * p for a 256-bit scalar given as 8 little-endian u32 words (prover tail: groth16.go:253-275)
-template <class T>
-GS_HD Xyzz<T> xyzz_mul_words(const Xyzz<T>& p, const uint32_t (&k)[8]) {
-  Xyzz<T> r = xyzz_inf<T>();
-  for (int bit = 255; bit >= 0; --bit) {
-    xyzz_dbl(r);
-    if ((k[bit >> 5] >> (bit & 31)) & 1u) xyzz_add(r, p);
-  }
-  return r;
-}
-
-// the same with a fixed 4-bit window (host-side prover tail: 64 windows of 4 doublings + 1 table addition)
+// k * p for a 256-bit scalar given as 8 little-endian u32 words (prover tail, groth16.go:253-275) with a fixed 4-bit
+// window: 64 windows of 4 doublings + 1 table addition
 template <class T>
 GS_HD Xyzz<T> xyzz_mul_words_w4(const Xyzz<T>& p, const uint32_t (&k)[8]) {
   Xyzz<T> tab[16];

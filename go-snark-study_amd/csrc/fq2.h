@@ -50,10 +50,6 @@ GS_HD Fq2e<2> sqr(const Fq2e<B>& a) {
   return {mul(add(a.c0, a.c1), sub(a.c0, a.c1)), mul(dbl(a.c0), a.c1)};
 }
 
-// Fq2 element times an Fq scalar-like element (used for norm-based inversion)
-template <int Ba, int Bb>
-GS_HD Fq2e<2> mul_fq(const Fq2e<Ba>& a, const Fe<ModQ, Bb>& k) { return {mul(a.c0, k), mul(a.c1, k)}; }
-
 // 1 / (a0 + a1 u) = (a0 - a1 u) / (a0^2 + a1^2)                        [fq2.go:99-110]
 template <int B>
 GS_HD Fq2e<2> inv(const Fq2e<B>& a) {
@@ -64,6 +60,5 @@ GS_HD Fq2e<2> inv(const Fq2e<B>& a) {
 
 template <int B> GS_HD Fq2e<B> fq2_zero() { return {fe_zero<ModQ, B>(), fe_zero<ModQ, B>()}; }
 GS_HD Fq2e<1> fq2_one() { return {fe_one<ModQ>(), fe_zero<ModQ, 1>()}; }
-GS_HD Fq1e<1> fq1_one() { return fe_one<ModQ>(); }
 
 }  // namespace gs

@@ -53,13 +53,14 @@ static void run(const std::string& op, int n) {
     uint32_t k[8]; parse_hex(kh, k);
     Affine<T> a = jacobian_to_affine<T>(X, Y, Z);
     if (op == "lincomb") {
-      Xyzz<T> t = xyzz_mul_words(xyzz_from_affine(a), k);
+      Xyzz<T> t = xyzz_mul_words_w4(xyzz_from_affine(a), k);
       if (sign) t = xyzz_neg(t);
       xyzz_add(acc, t);
     } else if (op == "maddsum") {
       xyzz_madd(acc, a, sign != 0);
     } else if (op == "small") {
-      xyzz_add(acc, xyzz_mul_u32(xyzz_from_affine(a), k[0]));
+      const uint32_t small[8] = {k[0], 0, 0, 0, 0, 0, 0, 0};
+      xyzz_add(acc, xyzz_mul_words_w4(xyzz_from_affine(a), small));
     }
   }
   Affine<T> r = xyzz_to_affine(acc);
