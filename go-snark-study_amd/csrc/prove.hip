@@ -22,9 +22,11 @@ void copy_points(Ctx& c, const Bases* b, size_t words, DevBuf& dst) {
   if (b->n) GS_HIP(hipMemcpyAsync(dst.p, b->buf.p, b->n * words * 4, hipMemcpyDeviceToDevice, c.stream));
 }
 
-struct DevScalars {            // a resident scalar vector used by a prove call (not owned)
-  const uint32_t* p;
+struct DevScalars {            // a scalar vector used by a prove call (not owned)
+  const uint32_t* p;           // resident copy (device)
   size_t n;
+  const uint64_t* host = nullptr;   // if set: `p` is a staging buffer that still has to be filled from here, on the stream
+                                    // that consumes it (so the PCIe copy of px overlaps the accumulations over w)
 };
 
 // hx = floor(px / Z) on the device, returned as a workspace pointer (standard form, nz-dependent length)
@@ -151,15 +153,8 @@ int groth16_enqueue(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, const S
     build_plan(c, 0 + 2 * parity, w.p + wlo * 8, (uint32_t)(whi - wlo), plan_w, {{1, true}, {3, false}});
     st.tplanw->stop();
     GS_HIP(hipEventRecord(st.planw, c.stream));
-    st.tpoly = std::make_shared<PhaseTimer>(c.stream);
-    if (nh) poly_quotient_dev(c, pk->z, px.p, px.n, g_hx.as<uint32_t>());      // groth16.go:266
-    st.tpoly->stop();
-    st.tplanh = std::make_shared<PhaseTimer>(c.stream);
-    build_plan(c, 1 + 2 * parity, g_hx.as<uint32_t>() + hlo * 8, (uint32_t)(hhi - hlo), plan_h, {{1, false}});
-    st.tplanh->stop();
-    GS_HIP(hipEventRecord(st.planh, c.stream));
   }
-  {                                                              // main: the accumulations back to back
+  {                                                              // main: the accumulations over w, back to back
     StreamScope sc(c, c.main_stream);
     GS_HIP(hipStreamWaitEvent(c.stream, st.planw, 0));
     // BACDelta's first npublic+1 entries are forced to infinity at key creation, so the reference's
@@ -169,6 +164,25 @@ int groth16_enqueue(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, const S
     msm_enqueue_g2(c, plan_w, {MsmBase{&pk->t_bacgamma2, wlo}}, ws + 4, pin + 1, st.pend_g2w, c.aux_stream[0]);
     msm_enqueue_g1(c, plan_w, {MsmBase{&pk->t_at, wlo}, MsmBase{&pk->t_bacgamma1, wlo}, MsmBase{&pk->t_bacdelta, wlo}}, ws + 0, pin + 0,
                    st.pend_g1w, c.aux_stream[2]);
+  }
+  {                                                              // aux 1 again: (late upload of px,) H(x), plan(h)
+    StreamScope sc(c, c.aux_stream[1]);
+    if (px.host && px.n) {     // the device is already busy with ~8 ms of accumulations: this copy is off the critical path
+      PhaseTimer th(c.stream);
+      GS_HIP(hipMemcpyAsync(const_cast<uint32_t*>(px.p), px.host, px.n * 32, hipMemcpyHostToDevice, c.stream));
+      th.stop();
+      c.timing.h2d_ms += th.ms();
+    }
+    st.tpoly = std::make_shared<PhaseTimer>(c.stream);
+    if (nh) poly_quotient_dev(c, pk->z, px.p, px.n, g_hx.as<uint32_t>());      // groth16.go:266
+    st.tpoly->stop();
+    st.tplanh = std::make_shared<PhaseTimer>(c.stream);
+    build_plan(c, 1 + 2 * parity, g_hx.as<uint32_t>() + hlo * 8, (uint32_t)(hhi - hlo), plan_h, {{1, false}});
+    st.tplanh->stop();
+    GS_HIP(hipEventRecord(st.planh, c.stream));
+  }
+  {                                                              // main again: the accumulation over h
+    StreamScope sc(c, c.main_stream);
     GS_HIP(hipStreamWaitEvent(c.stream, st.planh, 0));
     // a lone proof finishes soonest with the last tail right behind its accumulation; in a pipeline that tail must not sit
     // in front of the next proof's accumulations
@@ -480,7 +494,8 @@ int gs_groth16_prove(gs_handle hpk, const uint64_t* w, size_t nw, const uint64_t
     if (!w || !px || !r || !s || !out_proof || !inf) return fail(GS_ERR_ARG, "null argument");
     reset_timing(c);
     DevScalars dw{upload_tmp(c, g_up_w, w, nw), nw};
-    DevScalars dp{upload_tmp(c, g_up_px, px, npx), npx};
+    g_up_px.ensure(std::max<size_t>(npx, 1) * 32);
+    DevScalars dp{g_up_px.as<uint32_t>(), npx, px};               // copied inside, behind the work that only needs w
     return groth16_prove_impl(c, pk, dw, dp, r, s, out_proof, inf);
   });
 }
