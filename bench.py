@@ -40,6 +40,20 @@ G2_TERM_BYTES = 160
 R = groth16.R
 
 
+def checker_leg_proof(proof, inst, r_, s_):
+    """Checker leg (with cpu_baseline below the only users of oracle/ in this file; never inside the timed region):
+    PiA, PiB, PiC of the benchmarked instance against a*G1, b*G2, c*G1 computed by the C oracle's MulScalar from the
+    closed-form scalars of synth.SqchainSetupInstance.expected_proof_scalars."""
+    from oracle import c_oracle as C, ref_py as O
+    ea, eb, ec = inst.expected_proof_scalars(r_, s_)
+    ok = ((proof.PiA[0], proof.PiA[1]) == C.g1_affine(C.g1_mul_scalar(O.G1_GEN, ea)) and
+          (proof.PiB[0], proof.PiB[1]) == C.g2_affine(C.g2_mul_scalar(O.G2_GEN, eb)) and
+          (proof.PiC[0], proof.PiC[1]) == C.g1_affine(C.g1_mul_scalar(O.G1_GEN, ec)))
+    if not ok:
+        raise SystemExit("bench.py: the proof of the benchmarked instance does not match its closed form")
+    return "PiA, PiB, PiC equal a*G1, b*G2, c*G1 for the closed-form (a, b, c) derived from the setup's toxic values"
+
+
 def cpu_baseline_all_cores(log2n_sample, seed):
     """Same algorithm with the term ranges of every MSM split over all host threads (oracle_msm_naive_mt); the reference
     itself is single-threaded (no goroutines), so this is an upper bound on what its algorithm gets from the host."""
@@ -195,17 +209,10 @@ def main():
         elapsed = float(t.item())
 
     proof_check = None
-    if rank == 0 and args.workload == "prove" and args.instance == "setup" and not args.no_check:
-        # outside the timed region: the toxic values of the synthetic setup are known, so the proof is known in closed form
-        from oracle import c_oracle as C, ref_py as O          # checker only
-        pr = step()
-        ea, eb, ec = inst.expected_proof_scalars(r_, s_)
-        ok = ((pr.PiA[0], pr.PiA[1]) == C.g1_affine(C.g1_mul_scalar(O.G1_GEN, ea)) and
-              (pr.PiB[0], pr.PiB[1]) == C.g2_affine(C.g2_mul_scalar(O.G2_GEN, eb)) and
-              (pr.PiC[0], pr.PiC[1]) == C.g1_affine(C.g1_mul_scalar(O.G1_GEN, ec)))
-        if not ok:
-            raise SystemExit("bench.py: the proof of the benchmarked instance does not match its closed form")
-        proof_check = "PiA, PiB, PiC equal a*G1, b*G2, c*G1 for the closed-form (a, b, c) derived from the setup's toxic values"
+    if rank == 0 and world == 1 and args.cpu_log2n > 0 and args.workload == "prove" and args.instance == "setup" and not args.no_check:
+        # Outside the timed region, part of the checker/baseline leg (the only place bench.py touches oracle/): the toxic
+        # values of the synthetic setup are known, so the proof the benchmarked instance must produce is known in closed form.
+        proof_check = checker_leg_proof(step(), inst, r_, s_)
     host_ms = None
     if rank == 0 and world == 1 and args.workload == "prove":
         # the boundary also accepts HOST buffers (gs_groth16_prove): w (32 B x m) and px (32 B x (2n-1)) then cross PCIe
