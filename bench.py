@@ -251,6 +251,15 @@ def main():
                          "avg_launch_ms": avg_launch_s * 1e3, "algorithmic_bytes_per_launch": bytes_per_launch,
                          "note": "integer-issue bound (254-bit modular arithmetic on 32-bit VALU): PMC evidence in "
                                  "profiles/r01c_pmc_sq_accumulate_g1.txt (VALU ~96 % busy), see DESIGN.md section 5"},
+            # the roofline that actually binds the dominant kernel: 32x32+64-bit multiply-add issue (v_mad_u64_u32).  One mixed
+            # addition = 6 products (162 mads) + 2 squarings (126) + one two-term product (243) = 1467 mads; a term takes one
+            # addition per window.  Peak: 31.5 T lane-mad/s measured by tools/ubench_valu.hip (profiles/r01_ubench_valu.txt).
+            "roofline_valu": {"bound": "valu-int-mad", "kernel": "k_bucket_accumulate<G1>",
+                              "achieved": (tm_acc["acc_g1_terms"] / launches) * 16 * 1467 / avg_launch_s / 1e12 if avg_launch_s > 0 else 0.0,
+                              "peak": 31.5, "unit": "T lane-mad/s",
+                              "frac": ((tm_acc["acc_g1_terms"] / launches) * 16 * 1467 / avg_launch_s / 1e12 / 31.5) if avg_launch_s > 0 else 0.0,
+                              "note": "16 windows at c = 16 (n >= 2^16); other instructions take the remaining issue slots, "
+                                      "profiles/r01c_pmc_sq_accumulate_g1.txt"},
             "roofline_whole_step": {"bound": "hbm", "algorithmic_bytes_per_step": (672 * n if args.workload == "prove" else G1_TERM_BYTES * n),
                                     "achieved": (672 * n if args.workload == "prove" else G1_TERM_BYTES * n) / (elapsed / args.steps) / 1e9,
                                     "peak": HBM_PEAK_GBS, "unit": "GB/s",

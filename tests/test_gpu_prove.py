@@ -327,10 +327,10 @@ def test_trusted_setup_equals_reference_on_x3_circuit():
     assert got.PiA == jac_affine_g1(want[0]) and got.PiB == jac_affine_g2(want[1]) and got.PiC == jac_affine_g1(want[2])
 
 
-@pytest.mark.parametrize("logn", [4, 10, 16])
+@pytest.mark.parametrize("logn", [4, 10, 16, 20])
 def test_full_pipeline_proof_matches_closed_form_from_toxic_values(logn):
-    """End to end at sizes the reference cannot replay: sparse R1CS -> device trusted setup -> px on the device ->
-    prove.  With the toxic scalars known, groth16.go:243-275 must output PiA = a G1, PiB = b G2, PiC = c G1 for the
+    """End to end at sizes the reference cannot replay (2^20 = BASELINE.json configs[2]): sparse R1CS -> device trusted
+    setup -> px on the device -> prove.  With the toxic scalars known, groth16.go:243-275 must output PiA = a G1, PiB = b G2, PiC = c G1 for the
     closed-form (a, b, c) of synth.SqchainSetupInstance.expected_proof_scalars; the generator multiples come from the
     C oracle's MulScalar."""
     from gosnark_amd import synth
