@@ -105,9 +105,11 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log2n", type=int, default=20)
-    ap.add_argument("--workload", default="prove", choices=["prove", "prove_sharded", "msm_g1", "msm_sharded"],
+    ap.add_argument("--workload", default="prove", choices=["prove", "prove_from_r1cs", "prove_sharded", "msm_g1", "msm_sharded"],
                     help="prove: one independent proof per GPU (weak scaling, the default the driver runs); prove_sharded: ONE proof "
-                         "whose MSM term ranges are split over the ranks (strong scaling, all-gather of 5 partial points)")
+                         "whose MSM term ranges are split over the ranks (strong scaling, all-gather of 5 partial points); "
+                         "prove_from_r1cs: every step also rebuilds px from the resident sparse R1CS and witness (gs_r1cs_px) -- the "
+                         "stage upstream of GenerateProofs, reported for information")
     ap.add_argument("--instance", default="setup", choices=["setup", "sqchain", "random"],
                     help="setup: sqchain R1CS + structured trusted setup on the device + px from the sparse system (a complete, "
                          "checkable instance, SURVEY 8d); sqchain: same R1CS with key points k_i*G; random: uniform w / px")
@@ -136,7 +138,8 @@ def main():
     n = 1 << args.log2n
     seed = 0x5EED0002 + (0 if args.workload == "prove_sharded" else rank)
     sharded = args.workload == "prove_sharded"
-    if sharded:
+    from_r1cs = args.workload == "prove_from_r1cs"
+    if sharded or from_r1cs:
         args.workload = "prove"
     if args.workload == "prove":
         inst = (synth.sqchain_setup_instance(n, seed) if args.instance == "setup" else
@@ -144,12 +147,21 @@ def main():
         pk = inst.device_pk()
         r_, s_ = synth.field_elems(2, seed ^ 0xABCDEF, R)
 
+        dev_r1cs = None
+        if from_r1cs:
+            from gosnark_amd import r1csqap
+            dev_r1cs = r1csqap.DeviceR1CS(*inst.r1cs, inst.m)
+
         def step():
             if sharded:
                 return groth16.prove_sharded(pk, inst.w, inst.px, r_, s_)
+            if from_r1cs:
+                dev_r1cs.ComputePxResident(inst.w, inst.px)            # overwrites the resident px in place
             return groth16.prove_resident(pk, inst.w, inst.px, r_, s_)
         units_per_step = n
-        workload = ("groth16_prove_2^%d_constraints_sharded_over_all_gpus" if sharded else "groth16_prove_2^%d_constraints_per_gpu") % args.log2n
+        workload = ("groth16_prove_2^%d_constraints_sharded_over_all_gpus" if sharded else
+                    "groth16_px_from_sparse_r1cs_then_prove_2^%d_constraints_per_gpu" if from_r1cs else
+                    "groth16_prove_2^%d_constraints_per_gpu") % args.log2n
     else:
         from gosnark_amd import parallel
         nterms = n
@@ -170,7 +182,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    pipelined = args.workload == "prove" and not sharded and args.pipeline == 2
+    pipelined = args.workload == "prove" and not sharded and not from_r1cs and args.pipeline == 2
 
     def run_steps(count, on_done=None):
         if not pipelined:

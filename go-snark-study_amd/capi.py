@@ -61,6 +61,8 @@ _SIGS = {
     "gs_zpoly": [ctypes.c_size_t, u64p],
     "gs_r1cs_to_px": [ctypes.c_size_t, ctypes.c_size_t, u32p, u32p, u64p, u32p, u32p, u64p, u32p, u32p, u64p,
                       u64p, u64p, u64p, u64p, u64p],
+    "gs_r1cs_upload": [ctypes.c_size_t, ctypes.c_size_t, u32p, u32p, u64p, u32p, u32p, u64p, u32p, u32p, u64p, ctypes.POINTER(Handle)],
+    "gs_r1cs_px": [Handle, Handle, ctypes.POINTER(Handle)],
     "gs_groth16_pk_create": [Handle, Handle, Handle, Handle, Handle, u64p, u64p, u64p, u64p, u64p,
                              u64p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, ctypes.POINTER(Handle)],
     "gs_groth16_prove": [Handle, u64p, ctypes.c_size_t, u64p, ctypes.c_size_t, u64p, u64p, u64p, intp],

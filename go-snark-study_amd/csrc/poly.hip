@@ -315,7 +315,8 @@ void interpolate_dev(Ctx& c, const uint32_t* values_std, size_t n, size_t nvec, 
   if (n == 0 || nvec == 0) return;
   NodeTree& t = ensure_tree(c, n, true);
   const size_t total = t.total, all = total * nvec;
-  DevBuf cur(all * 32), wide(2 * all * 32), nxt(all * 32);
+  static DevBuf cur, wide, nxt;               // grow-only workspaces (no allocation on the per-proof path)
+  cur.ensure(all * 32); wide.ensure(2 * all * 32); nxt.ensure(all * 32);
   hipLaunchKernelGGL(k_interp_leaves, grid1(all), dim3(256), 0, c.stream, values_std, t.weights.as<uint32_t>(), (uint32_t)n, (uint32_t)total,
                      (uint32_t)nvec, cur.as<uint32_t>());
   for (int j = 0; j < t.L; ++j) {

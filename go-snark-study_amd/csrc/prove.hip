@@ -690,54 +690,130 @@ int gs_zpoly(size_t deg, uint64_t* out) {
 // Sparse R1CS + witness -> ax, bx, cx, px = ax * bx - cx: the scalable replacement of the dense
 // R1CSToQAP + CombinePolynomials pair (r1csqap.go:161-210).  CombinePolynomials' ax = sum_i w_i alpha_i(x) is the
 // interpolant of the values (A w)_j at the nodes j = 1..n, so the m x n coefficient matrices are never formed.
+static const char* validate_csr(size_t n, size_t m, const uint32_t* rowptr, const uint32_t* col, const uint64_t* val) {
+  if (!rowptr) return "null row_ptr";
+  if (rowptr[0] != 0) return "row_ptr[0] must be 0";
+  for (size_t r = 0; r < n; ++r) if (rowptr[r + 1] < rowptr[r]) return "row_ptr not monotone";
+  const size_t nnz = rowptr[n];
+  if (nnz && (!col || !val)) return "null column/value array";
+  for (size_t e = 0; e < nnz; ++e) if (col[e] >= m) return "column index out of range";
+  return nullptr;
+}
+
+static int r1cs_upload_impl(Ctx& c, size_t n, size_t m, const uint32_t* const rp[3], const uint32_t* const cl[3], const uint64_t* const vl[3],
+                            R1csObj& o) {
+  if (n == 0 || m == 0) return fail(GS_ERR_ARG, "empty R1CS");
+  if (n >= (1ull << 26) || m >= (1ull << 31)) return fail(GS_ERR_ARG, "R1CS too large");
+  for (int k = 0; k < 3; ++k)
+    if (const char* e = validate_csr(n, m, rp[k], cl[k], vl[k])) return fail(GS_ERR_ARG, "R1CS matrix %c: %s", "ABC"[k], e);
+  o.n = n; o.m = m;
+  for (int k = 0; k < 3; ++k) {
+    const size_t nnz = rp[k][n];
+    o.nnz[k] = nnz;
+    o.rowptr[k].alloc((n + 1) * 4);
+    o.col[k].alloc(std::max<size_t>(nnz, 1) * 4);
+    o.val[k].alloc(std::max<size_t>(nnz, 1) * 32);
+    GS_HIP(hipMemcpyAsync(o.rowptr[k].p, rp[k], (n + 1) * 4, hipMemcpyHostToDevice, c.stream));
+    if (nnz) {
+      GS_HIP(hipMemcpyAsync(o.col[k].p, cl[k], nnz * 4, hipMemcpyHostToDevice, c.stream));
+      GS_HIP(hipMemcpyAsync(o.val[k].p, vl[k], nnz * 32, hipMemcpyHostToDevice, c.stream));
+    }
+  }
+  GS_HIP(hipStreamSynchronize(c.stream));
+  return GS_OK;
+}
+
+// w (standard form, m elements, device) -> o.coef = [ax | bx | cx] (n each) and px_out (2n - 1), canonical standard form
+static void r1cs_px_dev(Ctx& c, R1csObj& o, const uint32_t* w_dev, uint32_t* px_out) {
+  const size_t n = o.n, m = o.m, npx = 2 * n - 1;
+  o.w_mont.ensure(m * 32); o.vals.ensure(3 * n * 32); o.coef.ensure(3 * n * 32); o.prod.ensure(npx * 32);
+  GS_HIP(hipMemcpyAsync(o.w_mont.p, w_dev, m * 32, hipMemcpyDeviceToDevice, c.stream));
+  poly_canon_dev(c, o.w_mont.as<uint32_t>(), m, 1);                                         // w -> Montgomery
+  for (int k = 0; k < 3; ++k)
+    spmv_dev(c, o.rowptr[k].as<uint32_t>(), o.col[k].as<uint32_t>(), o.val[k].as<uint32_t>(), o.w_mont.as<uint32_t>(), n, m,
+             o.vals.as<uint32_t>() + k * n * 8);
+  interpolate_dev(c, o.vals.as<uint32_t>(), n, 3, o.coef.as<uint32_t>());
+  uint32_t* A = o.coef.as<uint32_t>();
+  uint32_t* B = A + n * 8;
+  uint32_t* C = B + n * 8;
+  poly_mul_dev(c, A, n, Form::Std, B, n, Form::Std, o.prod.as<uint32_t>());
+  poly_addsub_dev(c, o.prod.as<uint32_t>(), npx, C, n, true, px_out);
+  poly_canon_dev(c, px_out, npx, 0);
+  poly_canon_dev(c, A, 3 * n, 0);
+}
+
 int gs_r1cs_to_px(size_t n, size_t m,
                   const uint32_t* a_rowptr, const uint32_t* a_col, const uint64_t* a_val,
                   const uint32_t* b_rowptr, const uint32_t* b_col, const uint64_t* b_val,
                   const uint32_t* c_rowptr, const uint32_t* c_col, const uint64_t* c_val,
                   const uint64_t* w, uint64_t* ax, uint64_t* bx, uint64_t* cx, uint64_t* px) {
   return guarded([&](Ctx& c) -> int {
-    if (n == 0 || m == 0) return fail(GS_ERR_ARG, "gs_r1cs_to_px: empty system");
-    if (!a_rowptr || !b_rowptr || !c_rowptr || !w || !px) return fail(GS_ERR_ARG, "gs_r1cs_to_px: null argument");
-    if (n >= (1ull << 26) || m >= (1ull << 31)) return fail(GS_ERR_ARG, "gs_r1cs_to_px: system too large");
+    if (!w || !px) return fail(GS_ERR_ARG, "gs_r1cs_to_px: null argument");
     const uint32_t* rp[3] = {a_rowptr, b_rowptr, c_rowptr};
     const uint32_t* cl[3] = {a_col, b_col, c_col};
     const uint64_t* vl[3] = {a_val, b_val, c_val};
-    for (int k = 0; k < 3; ++k) {                      // validate the CSR structure on the host
-      if (rp[k][0] != 0) return fail(GS_ERR_ARG, "gs_r1cs_to_px: row_ptr[0] must be 0");
-      for (size_t r = 0; r < n; ++r) if (rp[k][r + 1] < rp[k][r]) return fail(GS_ERR_ARG, "gs_r1cs_to_px: row_ptr not monotone");
-      const size_t nnz = rp[k][n];
-      if (nnz && (!cl[k] || !vl[k])) return fail(GS_ERR_ARG, "gs_r1cs_to_px: null column/value array");
-      for (size_t e = 0; e < nnz; ++e) if (cl[k][e] >= m) return fail(GS_ERR_ARG, "gs_r1cs_to_px: column index %u >= m = %zu", cl[k][e], m);
-    }
-    DevBuf wm(m * 32), vals(3 * n * 32), coef(3 * n * 32);
-    GS_HIP(hipMemcpyAsync(wm.p, w, m * 32, hipMemcpyHostToDevice, c.stream));
-    poly_canon_dev(c, wm.as<uint32_t>(), m, 1);                                 // w -> Montgomery
-    for (int k = 0; k < 3; ++k) {
-      const size_t nnz = rp[k][n];
-      DevBuf drp((n + 1) * 4), dcl(std::max<size_t>(nnz, 1) * 4), dvl(std::max<size_t>(nnz, 1) * 32);
-      GS_HIP(hipMemcpyAsync(drp.p, rp[k], (n + 1) * 4, hipMemcpyHostToDevice, c.stream));
-      if (nnz) {
-        GS_HIP(hipMemcpyAsync(dcl.p, cl[k], nnz * 4, hipMemcpyHostToDevice, c.stream));
-        GS_HIP(hipMemcpyAsync(dvl.p, vl[k], nnz * 32, hipMemcpyHostToDevice, c.stream));
-      }
-      spmv_dev(c, drp.as<uint32_t>(), dcl.as<uint32_t>(), dvl.as<uint32_t>(), wm.as<uint32_t>(), n, m, vals.as<uint32_t>() + k * n * 8);
-      GS_HIP(hipStreamSynchronize(c.stream));
-    }
-    interpolate_dev(c, vals.as<uint32_t>(), n, 3, coef.as<uint32_t>());
-    uint32_t* A = coef.as<uint32_t>();
-    uint32_t* B = A + n * 8;
-    uint32_t* C = B + n * 8;
+    R1csObj o;
+    const int rc = r1cs_upload_impl(c, n, m, rp, cl, vl, o);
+    if (rc != GS_OK) return rc;
     const size_t npx = 2 * n - 1;
-    DevBuf prod(npx * 32), pxd(npx * 32);
-    poly_mul_dev(c, A, n, Form::Std, B, n, Form::Std, prod.as<uint32_t>());
-    poly_addsub_dev(c, prod.as<uint32_t>(), npx, C, n, true, pxd.as<uint32_t>());
-    poly_canon_dev(c, pxd.as<uint32_t>(), npx, 0);
-    poly_canon_dev(c, A, 3 * n, 0);
+    const uint32_t* dw = upload_tmp(c, g_up_w, w, m);
+    g_up_o.ensure(npx * 32);
+    r1cs_px_dev(c, o, dw, g_up_o.as<uint32_t>());
+    const uint32_t* A = o.coef.as<uint32_t>();
     if (ax) GS_HIP(hipMemcpyAsync(ax, A, n * 32, hipMemcpyDeviceToHost, c.stream));
-    if (bx) GS_HIP(hipMemcpyAsync(bx, B, n * 32, hipMemcpyDeviceToHost, c.stream));
-    if (cx) GS_HIP(hipMemcpyAsync(cx, C, n * 32, hipMemcpyDeviceToHost, c.stream));
-    GS_HIP(hipMemcpyAsync(px, pxd.p, npx * 32, hipMemcpyDeviceToHost, c.stream));
+    if (bx) GS_HIP(hipMemcpyAsync(bx, A + n * 8, n * 32, hipMemcpyDeviceToHost, c.stream));
+    if (cx) GS_HIP(hipMemcpyAsync(cx, A + 2 * n * 8, n * 32, hipMemcpyDeviceToHost, c.stream));
+    GS_HIP(hipMemcpyAsync(px, g_up_o.p, npx * 32, hipMemcpyDeviceToHost, c.stream));
     GS_HIP(hipStreamSynchronize(c.stream));
+    return GS_OK;
+  });
+}
+
+// The per-circuit / per-proof split of the same computation: the R1CS is uploaded and validated once ...
+int gs_r1cs_upload(size_t n, size_t m,
+                   const uint32_t* a_rowptr, const uint32_t* a_col, const uint64_t* a_val,
+                   const uint32_t* b_rowptr, const uint32_t* b_col, const uint64_t* b_val,
+                   const uint32_t* c_rowptr, const uint32_t* c_col, const uint64_t* c_val, gs_handle* out) {
+  return guarded([&](Ctx& c) -> int {
+    if (!out) return fail(GS_ERR_ARG, "gs_r1cs_upload: null output");
+    const uint32_t* rp[3] = {a_rowptr, b_rowptr, c_rowptr};
+    const uint32_t* cl[3] = {a_col, b_col, c_col};
+    const uint64_t* vl[3] = {a_val, b_val, c_val};
+    auto o = std::make_unique<R1csObj>();
+    const int rc = r1cs_upload_impl(c, n, m, rp, cl, vl, *o);
+    if (rc != GS_OK) return rc;
+    *out = c.put(std::move(o));
+    return GS_OK;
+  });
+}
+
+// ... and every proof only turns its resident witness into the resident px (nothing crosses PCIe).  *px_inout: 0 to create the
+// 2n - 1 coefficient vector, or a handle from an earlier call to overwrite.
+int gs_r1cs_px(gs_handle hr1cs, gs_handle hw, gs_handle* px_inout) {
+  return guarded([&](Ctx& c) -> int {
+    R1csObj* o = c.get<R1csObj>(hr1cs, Kind::R1cs);
+    Scalars* w = c.get<Scalars>(hw, Kind::Scalars);
+    if (!o || !w || !px_inout) return fail(GS_ERR_ARG, "gs_r1cs_px: bad handle");
+    if (w->n != o->m) return fail(GS_ERR_SHAPE, "len(w) = %zu but the system has %zu variables", w->n, o->m);
+    const size_t npx = 2 * o->n - 1;
+    Scalars* px = nullptr;
+    if (*px_inout) {
+      px = c.get<Scalars>(*px_inout, Kind::Scalars);
+      if (!px || px->n != npx) return fail(GS_ERR_ARG, "gs_r1cs_px: the px handle does not hold 2n - 1 = %zu coefficients", npx);
+    } else {
+      auto fresh = std::make_unique<Scalars>();
+      fresh->n = npx;
+      fresh->buf.alloc(npx * 32);
+      px = fresh.get();
+      *px_inout = c.put(std::move(fresh));
+    }
+    PhaseTimer t(c.stream);
+    r1cs_px_dev(c, *o, w->buf.as<uint32_t>(), px->buf.as<uint32_t>());
+    t.stop();
+    GS_HIP(hipStreamSynchronize(c.stream));
+    reset_timing(c);
+    c.timing.poly_ms = t.ms();
+    c.timing.total_ms = c.timing.poly_ms;
     return GS_OK;
   });
 }

@@ -74,7 +74,7 @@ struct DevBuf {
 };
 
 // ---- handle table ---------------------------------------------------------------------------------
-enum class Kind : uint32_t { G1Bases = 1, G2Bases, Scalars, GrothPk, PinocchioPk };
+enum class Kind : uint32_t { G1Bases = 1, G2Bases, Scalars, GrothPk, PinocchioPk, R1cs };
 
 struct Object {
   Kind kind;
@@ -87,6 +87,12 @@ struct Bases : Object {          // packed affine Montgomery points, resident (+
   size_t n = 0;
   std::shared_ptr<void> table;   // gs::BaseTable (msm.h), created on first MSM use
   explicit Bases(Kind k) : Object(k) {}
+};
+struct R1csObj : Object {        // sparse R1CS resident on the device: A, B, C in CSR (values standard form) + per-proof workspaces
+  size_t n = 0, m = 0, nnz[3] = {0, 0, 0};
+  DevBuf rowptr[3], col[3], val[3];
+  DevBuf w_mont, vals, coef, prod;       // grow-once workspaces of gs_r1cs_px
+  R1csObj() : Object(Kind::R1cs) {}
 };
 struct Scalars : Object {        // n x 8 u32 words, standard form, resident
   DevBuf buf;

@@ -121,3 +121,35 @@ def ComputePx(a_csr, b_csr, c_csr, w_u64, nvars):
 def ZPoly(deg):
     """Z(x) = prod_{i=1}^{deg} (x - i)  (r1csqap.go:177-186 / groth16.go:122-131)."""
     return capi.u64_to_ints(capi.zpoly(deg))
+
+
+def _csr_args(csrs):
+    args = []
+    for rp, cl, vl in csrs:
+        rp = np.ascontiguousarray(rp, dtype=np.uint32)
+        cl = np.ascontiguousarray(cl, dtype=np.uint32)
+        vl = np.ascontiguousarray(vl, dtype=np.uint64).reshape(-1, 4)
+        if cl.size == 0:
+            cl, vl = np.zeros(1, dtype=np.uint32), np.zeros((1, 4), dtype=np.uint64)
+        args += [rp, cl, vl]
+    return args
+
+
+class DeviceR1CS:
+    """A sparse R1CS resident on the device (gs_r1cs_upload): upload once per circuit, then ComputePxResident per proof."""
+
+    def __init__(self, a_csr, b_csr, c_csr, nvars):
+        capi.init()
+        self.n, self.nvars = a_csr[0].shape[0] - 1, nvars
+        a = _csr_args((a_csr, b_csr, c_csr))
+        h = capi.Handle(0)
+        capi.check(capi.load_library().gs_r1cs_upload(self.n, nvars, capi.ptr32(a[0]), capi.ptr32(a[1]), capi.ptr64(a[2]), capi.ptr32(a[3]),
+                                                      capi.ptr32(a[4]), capi.ptr64(a[5]), capi.ptr32(a[6]), capi.ptr32(a[7]), capi.ptr64(a[8]),
+                                                      ctypes.byref(h)))
+        self.handle = capi.DeviceHandle(h.value)
+
+    def ComputePxResident(self, w_handle, px_handle=None):
+        """resident w (capi.scalars_upload) -> resident px (a capi.DeviceHandle; pass the previous one to overwrite it)."""
+        h = capi.Handle(px_handle.h if px_handle is not None else 0)
+        capi.check(capi.load_library().gs_r1cs_px(capi.Handle(self.handle.h), capi.Handle(w_handle.h), ctypes.byref(h)))
+        return px_handle if px_handle is not None else capi.DeviceHandle(h.value)

@@ -133,6 +133,16 @@ int gs_r1cs_to_px(size_t n, size_t m,
                   const uint32_t* c_rowptr, const uint32_t* c_col, const uint64_t* c_val,
                   const uint64_t* w, uint64_t* ax, uint64_t* bx, uint64_t* cx, uint64_t* px);
 
+/* The same split per circuit / per proof: gs_r1cs_upload validates and keeps A, B, C resident (free with gs_free);
+ * gs_r1cs_px turns a resident witness (gs_scalars_upload, m elements) into the resident px (2n - 1 coefficients: pass
+ * *px_inout = 0 to create the vector, or the handle of an earlier call to overwrite it) -- nothing crosses PCIe, and the
+ * result feeds gs_groth16_prove_resident / gs_groth16_prove_begin directly.  gs_last_timing().poly_ms = device time. */
+int gs_r1cs_upload(size_t n, size_t m,
+                   const uint32_t* a_rowptr, const uint32_t* a_col, const uint64_t* a_val,
+                   const uint32_t* b_rowptr, const uint32_t* b_col, const uint64_t* b_val,
+                   const uint32_t* c_rowptr, const uint32_t* c_col, const uint64_t* c_val, gs_handle* out);
+int gs_r1cs_px(gs_handle r1cs, gs_handle w, gs_handle* px_inout);
+
 /* ---- Groth16 prover (groth16/groth16.go) --------------------------------------------------- */
 /* Device-resident proving key: groth16.Pk (groth16.go:15-32).  At, BACGamma (G1), BACDelta:
  * m points; G2 BACGamma: m points; PowersTauDelta: len(Z) points; single points as Jacobian

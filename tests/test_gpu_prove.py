@@ -474,3 +474,26 @@ def test_full_pipeline_m_equals_n_plus_2(logn):
     ra, rb, rc = inst.r1cs
     with pytest.raises(capi.GosnarkHipError):          # m = n: len(hx) would exceed len(PowersTauDelta)
         groth16.GenerateTrustedSetupSparse(n, n, 1, ra, rb, rc, inst.toxic)
+
+
+def test_resident_r1cs_px_equals_host_buffer_path_and_feeds_the_prover():
+    """gs_r1cs_upload + gs_r1cs_px (everything resident) == gs_r1cs_to_px (host buffers), the px handle can be overwritten for
+    the next witness, and it feeds the prover directly: R1CS + witness -> proof without touching the host."""
+    from gosnark_amd import synth
+    n = 1 << 10
+    inst = synth.sqchain_setup_instance(n, 0xD00D)
+    a, b, c = inst.r1cs
+    dev = r1csqap.DeviceR1CS(a, b, c, n + 1)
+    px1 = dev.ComputePxResident(inst.w)
+    assert np.array_equal(capi.scalars_download(px1), inst.px_host)
+    _, _, _, w2 = synth.sqchain_r1cs(n, 777)
+    _, _, _, want2 = r1csqap.ComputePx(a, b, c, w2, n + 1)
+    w2h = capi.scalars_upload(w2)
+    px2 = dev.ComputePxResident(w2h, px1)                       # overwrite in place
+    assert px2 is px1 and np.array_equal(capi.scalars_download(px1), want2)
+    r, s = synth.field_elems(2, 31)
+    got = groth16.prove_resident(inst.device_pk(), w2h, px1, r, s)
+    want = groth16.prove_resident(inst.device_pk(), w2h, capi.scalars_upload(want2), r, s)
+    assert (got.PiA, got.PiB, got.PiC) == (want.PiA, want.PiB, want.PiC)
+    with pytest.raises(capi.GosnarkHipError):                   # witness length must match the system
+        dev.ComputePxResident(capi.scalars_upload(w2[:-1]))
