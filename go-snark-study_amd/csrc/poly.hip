@@ -315,26 +315,28 @@ void interpolate_dev(Ctx& c, const uint32_t* values_std, size_t n, size_t nvec, 
   if (n == 0 || nvec == 0) return;
   NodeTree& t = ensure_tree(c, n, true);
   const size_t total = t.total, all = total * nvec;
-  static DevBuf cur, wide, nxt;               // grow-only workspaces (no allocation on the per-proof path)
-  cur.ensure(all * 32); wide.ensure(2 * all * 32); nxt.ensure(all * 32);
+  static DevBuf cur_a, cur_b, wide, nxt;      // grow-only workspaces (no allocation on the per-proof path)
+  cur_a.ensure(all * 32); cur_b.ensure(all * 32); wide.ensure(2 * all * 32); nxt.ensure(all * 32);
+  uint32_t* cur = cur_a.as<uint32_t>();
+  uint32_t* other = cur_b.as<uint32_t>();
   hipLaunchKernelGGL(k_interp_leaves, grid1(all), dim3(256), 0, c.stream, values_std, t.weights.as<uint32_t>(), (uint32_t)n, (uint32_t)total,
-                     (uint32_t)nvec, cur.as<uint32_t>());
+                     (uint32_t)nvec, cur, wide.as<uint32_t>());
   for (int j = 0; j < t.L; ++j) {
     const uint32_t d = 1u << j;
-    hipLaunchKernelGGL(k_expand_blocks, grid1(2 * all), dim3(256), 0, c.stream, cur.as<uint32_t>(), wide.as<uint32_t>(), d, (uint32_t)(2 * all));
+    // `wide` already holds this level's blocks zero-padded to 2d (written by the previous combine / the leaves kernel)
     ntt_forward_n(c, wide.as<uint32_t>(), 2 * all, j + 1);
     hipLaunchKernelGGL(k_pw_cross, grid1(all), dim3(256), 0, c.stream, wide.as<uint32_t>(), t.mspec[j].as<uint32_t>(), nxt.as<uint32_t>(), 2 * d,
                        (uint32_t)(total / (2 * d)), (uint32_t)all);
     ntt_inverse_unscaled_n(c, nxt.as<uint32_t>(), all, j + 1);
-    // P_L (x^d + m_R) + P_R (x^d + m_L) = [P_L m_R + P_R m_L] + x^d (P_L + P_R)
-    hipLaunchKernelGGL(k_monic_combine, grid1(all), dim3(256), 0, c.stream, nxt.as<uint32_t>(), cur.as<uint32_t>(), inv_n_const(j + 1, 0),
-                       wide.as<uint32_t>(), d, (uint32_t)all);
-    GS_HIP(hipMemcpyAsync(cur.p, wide.p, all * 32, hipMemcpyDeviceToDevice, c.stream));
+    // P_L (x^d + m_R) + P_R (x^d + m_L) = [P_L m_R + P_R m_L] + x^d (P_L + P_R): compact into `other`, padded into `wide`
+    hipLaunchKernelGGL(k_interp_combine, grid1(all), dim3(256), 0, c.stream, nxt.as<uint32_t>(), cur, inv_n_const(j + 1, 0), other,
+                       (j + 1 < t.L) ? wide.as<uint32_t>() : nullptr, d, (uint32_t)all);
+    std::swap(cur, other);
   }
   GS_HIP(hipGetLastError());
   // cur[k] = x^pad * p_k(x): coefficients pad .. pad + n - 1
   for (size_t k = 0; k < nvec; ++k)
-    GS_HIP(hipMemcpyAsync(coeffs_std + k * n * 8, cur.as<uint32_t>() + (k * total + t.pad) * 8, n * 32, hipMemcpyDeviceToDevice, c.stream));
+    GS_HIP(hipMemcpyAsync(coeffs_std + k * n * 8, cur + (k * total + t.pad) * 8, n * 32, hipMemcpyDeviceToDevice, c.stream));
   GS_HIP(hipStreamSynchronize(c.stream));
 }
 

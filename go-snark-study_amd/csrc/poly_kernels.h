@@ -233,6 +233,27 @@ __global__ void __launch_bounds__(256) k_monic_combine(const uint32_t* __restric
   store_fr(out + (size_t)i * 8, v);
 }
 
+// The same combination for the interpolation tree, writing the result twice: compact (the next level's P_L / P_R source) and
+// already zero-padded to blocks of 4d (the next level's NTT input) -- no separate copy and expansion passes.
+__global__ void __launch_bounds__(256) k_interp_combine(const uint32_t* __restrict__ prod, const uint32_t* __restrict__ src, FrConst scale,
+                                                         uint32_t* __restrict__ out, uint32_t* __restrict__ out_wide, uint32_t d, uint32_t total) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const uint32_t p = i / (2 * d), t = i - p * 2 * d;
+  Fr2 v = mul(load_fr(prod + (size_t)i * 8), from_const(scale));
+  if (t >= d) {
+    const uint32_t* a = src + ((size_t)(2 * p) * d + (t - d)) * 8;
+    v = reduce2(add(v, add(load_fr(a), load_fr(a + (size_t)d * 8))));
+  }
+  store_fr(out + (size_t)i * 8, v);
+  if (out_wide) {
+    uint32_t* w = out_wide + ((size_t)p * 4 * d + t) * 8;
+    store_fr(w, v);
+    uint4* z = reinterpret_cast<uint4*>(w + (size_t)2 * d * 8);
+    z[0] = make_uint4(0, 0, 0, 0); z[1] = z[0];
+  }
+}
+
 // interpolation tree step: out[p*d2 + t] = PL * mR + PR * mL on the spectra of adjacent blocks (one reduction for the
 // two-term dot product); the m spectra repeat every `mblocks` pairs (several value vectors share one node tree).
 __global__ void __launch_bounds__(256) k_pw_cross(const uint32_t* __restrict__ pspec, const uint32_t* __restrict__ mspec, uint32_t* __restrict__ out,
@@ -245,13 +266,17 @@ __global__ void __launch_bounds__(256) k_pw_cross(const uint32_t* __restrict__ p
   store_fr(out + (size_t)i * 8, mul_add(load_fr(pl), load_fr(ml + (size_t)d2 * 8), load_fr(pl + (size_t)d2 * 8), load_fr(ml)));
 }
 // leaves of the interpolation tree: out[k*total + j] = values[k*n + j] * weights[j] for j < n, 0 for the padding nodes
+// (also written zero-padded to blocks of 2 into out_wide, the first level's NTT input)
 __global__ void __launch_bounds__(256) k_interp_leaves(const uint32_t* __restrict__ values, const uint32_t* __restrict__ weights, uint32_t n,
-                                                        uint32_t total, uint32_t nvec, uint32_t* __restrict__ out) {
+                                                        uint32_t total, uint32_t nvec, uint32_t* __restrict__ out, uint32_t* __restrict__ out_wide) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total * nvec) return;
   const uint32_t k = i / total, j = i - k * total;
-  if (j >= n) { store_fr(out + (size_t)i * 8, fe_zero<ModR, 2>()); return; }
-  store_fr(out + (size_t)i * 8, mul(load_fr(values + ((size_t)k * n + j) * 8), load_fr(weights + (size_t)j * 8)));
+  Fr2 v = fe_zero<ModR, 2>();
+  if (j < n) v = mul(load_fr(values + ((size_t)k * n + j) * 8), load_fr(weights + (size_t)j * 8));
+  store_fr(out + (size_t)i * 8, v);
+  store_fr(out_wide + (size_t)(2 * i) * 8, v);
+  store_fr(out_wide + (size_t)(2 * i + 1) * 8, fe_zero<ModR, 2>());
 }
 // sparse matrix (CSR, values in standard form) times a Montgomery-form vector: out[row] = sum_k val[k] * x[col[k]] (standard)
 __global__ void __launch_bounds__(256) k_spmv(const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ col, const uint32_t* __restrict__ val,
