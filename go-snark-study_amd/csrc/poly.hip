@@ -47,8 +47,8 @@ static void ensure_twiddles(Ctx& c, int logn) {
   Fe<ModR, 2> w, wi;
   for (int i = 0; i < NL; ++i) { w.l[i] = ModR::omega28_mont(i); wi.l[i] = ModR::omega28_inv_mont(i); }
   for (int i = 0; i < ModR::kTwoAdicity - logn; ++i) { w = sqr(w); wi = sqr(wi); }
-  g_tw.fwd.alloc((size_t)half * 32);
-  g_tw.inv.alloc((size_t)half * 32);
+  g_tw.fwd.alloc((size_t)half * kTwWords * 4);
+  g_tw.inv.alloc((size_t)half * kTwWords * 4);
   hipLaunchKernelGGL(k_twiddle_gen, grid1(half), dim3(256), 0, c.stream, g_tw.fwd.as<uint32_t>(), half, to_const(w));
   hipLaunchKernelGGL(k_twiddle_gen, grid1(half), dim3(256), 0, c.stream, g_tw.inv.as<uint32_t>(), half, to_const(wi));
   GS_HIP(hipGetLastError());

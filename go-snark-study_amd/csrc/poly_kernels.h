@@ -51,7 +51,16 @@ GS_HD Fr2 from_const(const FrConst& c) {
   return r;
 }
 
-// tw[i] = omega^i (Montgomery), i < count, omega given as a constant
+// tw[i] = omega^i (Montgomery), i < count, omega given as a constant.  Stored pre-split: 9 canonical 29-bit limbs padded to
+// 12 words (48 B), so a butterfly loads its twiddle with three 16-byte loads and no unpacking.
+constexpr int kTwWords = 12;
+GS_HD Fe<ModR, 1> load_twiddle(const uint32_t* p) {
+  const uint4* q = reinterpret_cast<const uint4*>(p);
+  const uint4 a = q[0], b = q[1], c = q[2];
+  Fe<ModR, 1> r;
+  r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w; r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w; r.l[8] = c.x;
+  return r;
+}
 __global__ void __launch_bounds__(256) k_twiddle_gen(uint32_t* __restrict__ tw, uint32_t count, FrConst omega) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= count) return;
@@ -60,7 +69,11 @@ __global__ void __launch_bounds__(256) k_twiddle_gen(uint32_t* __restrict__ tw, 
     if (e & 1u) acc = mul(acc, base);
     base = sqr(base);
   }
-  store_fr_canon(tw + (size_t)i * 8, canon(acc));
+  const Fe<ModR, 1> cv = canon(acc);
+  uint4* q = reinterpret_cast<uint4*>(tw + (size_t)i * kTwWords);
+  q[0] = make_uint4(cv.l[0], cv.l[1], cv.l[2], cv.l[3]);
+  q[1] = make_uint4(cv.l[4], cv.l[5], cv.l[6], cv.l[7]);
+  q[2] = make_uint4(cv.l[8], 0, 0, 0);
 }
 
 // ---- fused NTT pass: k consecutive radix-2 stages on a 1024-element tile held in LDS ---------------------------------
@@ -71,6 +84,57 @@ __global__ void __launch_bounds__(256) k_twiddle_gen(uint32_t* __restrict__ tw, 
 constexpr int kNttTileLog = 10;
 constexpr int kNttTile = 1 << kNttTileLog;
 constexpr int kNttMaxStages = 7;
+
+constexpr int kNttEndBound = 32;
+template <int B>
+GS_HD void ntt_dif_step(const uint32_t (&la)[NL], const uint32_t (&lb)[NL], const Fe<ModR, 1>& w, bool reduce_sum, uint32_t (&o0)[NL], uint32_t (&o1)[NL]) {
+  Fe<ModR, B> a, b;
+#pragma unroll
+  for (int l = 0; l < NL; ++l) { a.l[l] = la[l]; b.l[l] = lb[l]; }
+  const Fr2 d = mul(sub(a, b), w);                            // (2B + 1) * 1 <= 160
+  if (reduce_sum) {
+    const Fr2 t = reduce2(add(a, b));
+#pragma unroll
+    for (int l = 0; l < NL; ++l) o0[l] = t.l[l];
+  } else {
+    const Fe<ModR, 2 * B> t = add(a, b);
+#pragma unroll
+    for (int l = 0; l < NL; ++l) o0[l] = t.l[l];
+  }
+#pragma unroll
+  for (int l = 0; l < NL; ++l) o1[l] = d.l[l];
+}
+// step 0,1,2,3 of every group of four: input bounds 2, 4, 8, 16; the fourth one reduces its sum back to 2
+GS_HD void ntt_dif_butterfly(int step, const uint32_t (&la)[NL], const uint32_t (&lb)[NL], const Fe<ModR, 1>& w, uint32_t (&o0)[NL], uint32_t (&o1)[NL]) {
+  switch (step & 3) {
+    case 0: ntt_dif_step<2>(la, lb, w, false, o0, o1); break;
+    case 1: ntt_dif_step<4>(la, lb, w, false, o0, o1); break;
+    case 2: ntt_dif_step<8>(la, lb, w, false, o0, o1); break;
+    default: ntt_dif_step<16>(la, lb, w, true, o0, o1); break;
+  }
+}
+template <int B>
+GS_HD void ntt_dit_step(const uint32_t (&la)[NL], const uint32_t (&lb)[NL], const Fe<ModR, 1>& w, uint32_t (&o0)[NL], uint32_t (&o1)[NL]) {
+  Fe<ModR, B> a, b;
+#pragma unroll
+  for (int l = 0; l < NL; ++l) { a.l[l] = la[l]; b.l[l] = lb[l]; }
+  const Fr2 t = mul(b, w);
+  const Fe<ModR, B + 2> p = add(a, t);
+  const Fe<ModR, B + 3> m = sub(a, t);
+#pragma unroll
+  for (int l = 0; l < NL; ++l) { o0[l] = p.l[l]; o1[l] = m.l[l]; }
+}
+GS_HD void ntt_dit_butterfly(int step, const uint32_t (&la)[NL], const uint32_t (&lb)[NL], const Fe<ModR, 1>& w, uint32_t (&o0)[NL], uint32_t (&o1)[NL]) {
+  switch (step) {                                             // bound after each stage: 2 -> 5 -> 8 -> 11 -> 14 -> 17 -> 20 -> 23
+    case 0: ntt_dit_step<2>(la, lb, w, o0, o1); break;
+    case 1: ntt_dit_step<5>(la, lb, w, o0, o1); break;
+    case 2: ntt_dit_step<8>(la, lb, w, o0, o1); break;
+    case 3: ntt_dit_step<11>(la, lb, w, o0, o1); break;
+    case 4: ntt_dit_step<14>(la, lb, w, o0, o1); break;
+    case 5: ntt_dit_step<17>(la, lb, w, o0, o1); break;
+    default: ntt_dit_step<20>(la, lb, w, o0, o1); break;
+  }
+}
 
 template <bool kInverse>
 __global__ void __launch_bounds__(256) k_ntt_pass(uint32_t* __restrict__ x, const uint32_t* __restrict__ tw, int tw_logn, int s_lo, int k, int clog) {
@@ -95,6 +159,9 @@ __global__ void __launch_bounds__(256) k_ntt_pass(uint32_t* __restrict__ x, cons
     for (int l = 0; l < NL; ++l) sh[l * kNttTile + le] = v.l[l];
   }
   __syncthreads();
+  // Lazy reduction: LDS holds raw limbs whose VALUE bound is tracked per stage at compile time.  DIT: (a, b) -> (a + bw, a - bw)
+  // with bw < 2r grows the bound by 3 per stage (2, 5, ..., 23 after 7 stages): no reduction inside a pass.  DIF: a + b doubles
+  // it (2, 4, 8, 16, 32), (a - b) w resets to 2: one reduction every fourth stage.  The final store reduces below 2r.
   for (int step = 0; step < k; ++step) {
     const int b = kInverse ? step : k - 1 - step;          // DIF runs the stages downwards, DIT upwards
     const int s = s_lo + b;
@@ -104,19 +171,15 @@ __global__ void __launch_bounds__(256) k_ntt_pass(uint32_t* __restrict__ x, cons
       const uint32_t e0 = (q0 << clog) + cc, e1 = e0 + ((1u << b) << clog);
       const size_t gi = base + (size_t)q0 * qstride + (size_t)cc * cstride;
       const uint32_t j = (uint32_t)gi & ((1u << s) - 1u);
-      const Fr6 w = load_fr(tw + ((size_t)j << (tw_logn - 1 - s)) * 8);
-      Fr2 a, bb;
+      const Fe<ModR, 1> w = load_twiddle(tw + ((size_t)j << (tw_logn - 1 - s)) * kTwWords);
+      uint32_t la[NL], lb[NL];
 #pragma unroll
-      for (int l = 0; l < NL; ++l) { a.l[l] = sh[l * kNttTile + e0]; bb.l[l] = sh[l * kNttTile + e1]; }
-      Fr2 o0, o1;
-      if constexpr (kInverse) {
-        const Fr2 t = mul(bb, w);
-        o0 = reduce2(add(a, t)); o1 = reduce2(sub(a, t));
-      } else {
-        o0 = reduce2(add(a, bb)); o1 = mul(sub(a, bb), w);
-      }
+      for (int l = 0; l < NL; ++l) { la[l] = sh[l * kNttTile + e0]; lb[l] = sh[l * kNttTile + e1]; }
+      uint32_t o0[NL], o1[NL];
+      if constexpr (kInverse) ntt_dit_butterfly(step, la, lb, w, o0, o1);
+      else ntt_dif_butterfly(step, la, lb, w, o0, o1);
 #pragma unroll
-      for (int l = 0; l < NL; ++l) { sh[l * kNttTile + e0] = o0.l[l]; sh[l * kNttTile + e1] = o1.l[l]; }
+      for (int l = 0; l < NL; ++l) { sh[l * kNttTile + e0] = o0[l]; sh[l * kNttTile + e1] = o1[l]; }
     }
     __syncthreads();
   }
@@ -124,10 +187,10 @@ __global__ void __launch_bounds__(256) k_ntt_pass(uint32_t* __restrict__ x, cons
     uint32_t q, cc;
     if (s_lo == 0) { q = e & (R - 1); cc = e >> k; } else { cc = e & (C - 1); q = e >> clog; }
     const uint32_t le = (q << clog) + cc;
-    Fr2 v;
+    Fe<ModR, kNttEndBound> v;                                 // >= the bound any stage sequence of <= 7 stages can leave
 #pragma unroll
     for (int l = 0; l < NL; ++l) v.l[l] = sh[l * kNttTile + le];
-    store_fr(x + (base + (size_t)q * qstride + (size_t)cc * cstride) * 8, v);
+    store_fr(x + (base + (size_t)q * qstride + (size_t)cc * cstride) * 8, reduce2(v));
   }
 }
 
