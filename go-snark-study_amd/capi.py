@@ -30,7 +30,8 @@ class Timing(ctypes.Structure):
 
 
 def lib_path():
-    return os.path.join(_HERE, "libgosnark_hip.so")
+    # GS_LIB: development aid for A/B runs of two builds inside one GPU session
+    return os.environ.get("GS_LIB") or os.path.join(_HERE, "libgosnark_hip.so")
 
 
 # name -> (argtypes); every function returns int status unless listed in _NONSTATUS

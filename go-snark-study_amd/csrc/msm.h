@@ -17,7 +17,7 @@ struct MsmPlan {                 // digits of one scalar vector, bucket-sorted (
   int c = 0, W = 0;
   uint32_t B = 0;                // buckets per window
   uint32_t nbuckets = 0;         // W * B
-  uint32_t chunk = 32;           // entries per accumulate thread (32 or 64)
+  uint32_t chunk = 32;           // entries per accumulate thread (16 or 32; always a multiple of 4)
   uint32_t maxchunks = 0;        // upper bound of the number of chunks (the exact count stays on the device)
   const uint32_t* offsets = nullptr;        // nbuckets + 1 (offsets[nbuckets] = number of entries)
   const uint32_t* entries = nullptr;

@@ -36,13 +36,21 @@ static void exclusive_scan(Ctx& c, PlanBuffers& pb, const uint32_t* in, uint32_t
 
 static PlanBuffers g_plan_slots[4];          // (w, h) x (two proofs in flight)
 
-// Chunk size of a plan.  64-entry chunks halve the chunk partials the combine/reduce tails have to add up and the bucket
-// flushes of the accumulation; below ~2^22 entries there are too few threads for that to pay (measured at 2^20 terms:
-// proof 10.85 ms with 64 everywhere, 11.15 ms with 32 everywhere or with a per-launch "whole wave rounds" model, which
-// turned out not to be predictive; 2^16-term MSM 0.66 ms with 32, 0.80 ms with 64).
-static uint32_t choose_chunk(uint64_t entries, const std::vector<LaunchShape>& users) {
+// Chunk size of a plan = additions one accumulate thread performs back to back.  Small chunks mean more threads and shorter
+// serial chains (a 2^16-term MSM with 32-entry chunks is only 512 waves of 32 dependent additions), large chunks mean fewer
+// bucket flushes and fewer chunk partials for the tails.  Measured (pipelined prove / single G1 MSM, ms):
+//   2^16 terms: chunk 8 1.16 / 0.60, 16 1.17 / 0.59, 32 1.39 / 0.65, 64 1.92
+//   2^18 terms: chunk 8 2.86, 16 2.85, 32 2.96, 64 3.48
+//   2^20 terms: chunk 16 9.97 / 2.20, 32 9.94 / 2.01, 64 10.26 / 1.99, 128 11.0
+//   2^22 terms: chunk 32 48.7, 64 40.7 -- a bucket should not be cut into more than ~32 chunks (its partials are added up
+//   serially by one combine thread, and past kHeavySpan by the block-wide tree)
+static uint32_t choose_chunk(uint64_t entries, uint32_t nbuckets, const std::vector<LaunchShape>& users) {
   (void)users;
-  return entries >= (1ull << 22) ? 64u : 32u;
+  static const int forced = getenv("GS_CHUNK") ? atoi(getenv("GS_CHUNK")) : 0;          // experiments only (multiple of 4)
+  if (forced >= 4 && forced % 4 == 0) return (uint32_t)forced;
+  uint32_t chunk = entries >= (1ull << 23) ? 32u : 16u;
+  while (chunk < 1024u && entries / std::max<uint32_t>(nbuckets, 1u) > 32ull * chunk) chunk *= 2;
+  return chunk;
 }
 
 void build_plan(Ctx& c, int slot, const uint32_t* scalars_dev, uint32_t n, MsmPlan& plan, const std::vector<LaunchShape>& users) {
@@ -52,7 +60,7 @@ void build_plan(Ctx& c, int slot, const uint32_t* scalars_dev, uint32_t n, MsmPl
   plan.W = 254 / plan.c + 1;
   plan.B = 1u << (plan.c - 1);
   plan.nbuckets = plan.B;                      // one bucket set for all windows (window tables)
-  plan.chunk = choose_chunk((uint64_t)n * plan.W, users);
+  plan.chunk = choose_chunk((uint64_t)n * plan.W, plan.nbuckets, users);
   plan.maxchunks = (uint32_t)(((size_t)n * plan.W + plan.chunk - 1) / plan.chunk) + 1;
   const size_t ncount = (size_t)plan.nbuckets + 1;
   PlanParams pp{};

@@ -189,13 +189,12 @@ __global__ void __launch_bounds__(kScanBlock) k_scan_add(uint32_t* __restrict__ 
 }
 
 // ---- chunk map (load balance) ------------------------------------------------------------------------------
-// The sorted entry list is cut into chunks of `chunk` entries (32 or 64, chosen per plan so that the launches that use
-// it fill whole wave rounds -- see choose_chunk in msm.hip), ONE accumulate thread per chunk, whatever the
+// The sorted entry list is cut into chunks of `chunk` entries (16 or 32, a multiple of 4 chosen per plan -- see choose_chunk
+// in msm.hip), ONE accumulate thread per chunk, whatever the
 // bucket sizes are (uniform scalars: Poisson-sized buckets; real witnesses: 0/1-heavy ones).  A bucket that is
 // cut by chunk boundaries is summed from per-chunk partials:  sum_{t = first}^{last-1} tail[t] + head[last].
 // chunk_bucket[t] = bucket holding entry t*chunk.  Buckets cut into more than kHeavySpan + 1 pieces are listed
 // for a block-wide tree combine (k_heavy_combine), the others are combined by whoever reads them.
-constexpr uint32_t kMinChunk = 32;            // chunk sizes are multiples of 32 entries (128-byte aligned entry loads)
 constexpr uint32_t kHeavySpan = 64;
 constexpr uint32_t kMaxHeavy = 1u << 16;
 
@@ -250,7 +249,7 @@ __global__ void __launch_bounds__(256, AccTuning<T>::kMinWaves) k_bucket_accumul
   uint32_t bend = offsets[b + 1];
   bool started_before = offsets[b] < beg;
   Xyzz<T> acc = xyzz_inf<T>();
-  const uint4* e4 = reinterpret_cast<const uint4*>(entries + beg);      // beg is a multiple of 32 entries = 128 B
+  const uint4* e4 = reinterpret_cast<const uint4*>(entries + beg);      // beg is a multiple of 4 entries = 16 B
   // Software pipeline: the table point of entry e+1 is requested before the 8M+2S of entry e, so the random
   // 64/128-byte gather (HBM miss ~900 cycles) is covered by ~4000 cycles of arithmetic of the same wave.
   // G1 keeps the whole next point in registers; G2 (register-bound) only touches its cache line.
