@@ -230,8 +230,17 @@ struct AccJobs { AccJob j[kMaxJobs]; };
 // waves per SIMD the register allocator must allow: G1 needs ~150 VGPRs (3 waves), G2 must fit 256 (2 waves;
 // left alone it takes 264 and drops to ONE wave per SIMD, which halves the v_mad_u64_u32 issue rate)
 template <class T> struct AccTuning;
-template <> struct AccTuning<FqTag> { static constexpr int kMinWaves = 3; static constexpr bool kRegisterPrefetch = true; };
-template <> struct AccTuning<Fq2Tag> { static constexpr int kMinWaves = 2; static constexpr bool kRegisterPrefetch = false; };
+#ifndef GS_G1_WAVES
+#define GS_G1_WAVES 3
+#endif
+#ifndef GS_G1_PREFETCH
+#define GS_G1_PREFETCH 1
+#endif
+#ifndef GS_G2_TOUCH
+#define GS_G2_TOUCH 0            // measured: a one-word touch of the next point's line does not pay for G2 (3.96 vs 4.07 ms)
+#endif
+template <> struct AccTuning<FqTag> { static constexpr int kMinWaves = GS_G1_WAVES; static constexpr bool kRegisterPrefetch = GS_G1_PREFETCH != 0; static constexpr bool kTouch = true; };
+template <> struct AccTuning<Fq2Tag> { static constexpr int kMinWaves = 2; static constexpr bool kRegisterPrefetch = false; static constexpr bool kTouch = GS_G2_TOUCH != 0; };
 
 template <class T>
 __global__ void __launch_bounds__(256, AccTuning<T>::kMinWaves) k_bucket_accumulate(AccJobs jobs, const uint32_t* __restrict__ offsets,
@@ -252,7 +261,8 @@ __global__ void __launch_bounds__(256, AccTuning<T>::kMinWaves) k_bucket_accumul
   const uint4* e4 = reinterpret_cast<const uint4*>(entries + beg);      // beg is a multiple of 4 entries = 16 B
   // Software pipeline: the table point of entry e+1 is requested before the 8M+2S of entry e, so the random
   // 64/128-byte gather (HBM miss ~900 cycles) is covered by ~4000 cycles of arithmetic of the same wave.
-  // G1 keeps the whole next point in registers; G2 (register-bound) only touches its cache line.
+  // G1 keeps the whole next point in registers (5.9 vs 6.3 ms without); G2 is register-bound (256 VGPRs at 2 waves/SIMD) and
+  // loads its point where it needs it.
   constexpr bool kPre = AccTuning<T>::kRegisterPrefetch;
   uint4 q = e4[0];
   uint32_t v = q.x;
@@ -281,12 +291,12 @@ __global__ void __launch_bounds__(256, AccTuning<T>::kMinWaves) k_bucket_accumul
       while (nbend <= e + 1) { ++nb; nbend = offsets[nb + 1]; }
       np = job.table + ((size_t)((v >> kWindowShift) & 31u) * job.row_stride + (v & kIndexMask)) * aw;
       if constexpr (kPre) nextp = load_raw_affine<T>(np);
-      else touch = *np;
+      else if constexpr (AccTuning<T>::kTouch) touch = *np;
     }
     if constexpr (!kPre) curp = load_raw_affine<T>(cp);
     const Affine<T> p = unpack_affine<T>(curp);
     xyzz_madd(acc, p, (cur & kSignBit) != 0);
-    if constexpr (!kPre) asm volatile("" ::"v"(touch));                  // keep the touch load alive until here
+    if constexpr (!kPre && AccTuning<T>::kTouch) asm volatile("" ::"v"(touch));   // keep the touch load alive until here
   }
   uint32_t* dst = (bend > end) ? job.tails + (size_t)t * pw
                                : (started_before ? job.heads + (size_t)t * pw : job.buckets + (size_t)b * pw);
