@@ -170,6 +170,7 @@ def main():
         if args.workload == "msm_g1":
             def step():
                 return capi.msm_resident(bases, sc, nterms)
+            msm_pipelined = args.pipeline == 2
         else:
             def step():
                 return parallel.msm_g1_sharded(bases, sc, nterms)
@@ -183,8 +184,22 @@ def main():
         torch.cuda.synchronize()
 
     pipelined = args.workload == "prove" and not sharded and not from_r1cs and args.pipeline == 2
+    msm_pipe = args.workload == "msm_g1" and args.pipeline == 2
 
     def run_steps(count, on_done=None):
+        if msm_pipe:
+            tickets = []
+            for _ in range(count):
+                tickets.append(capi.msm_begin(bases, sc, nterms))
+                if len(tickets) == 2:
+                    capi.msm_end(tickets.pop(0))
+                    if on_done:
+                        on_done()
+            while tickets:
+                capi.msm_end(tickets.pop(0))
+                if on_done:
+                    on_done()
+            return
         if not pipelined:
             for _ in range(count):
                 step()
@@ -254,7 +269,7 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None,
             "dtype": "u32 (9x29-bit Montgomery limbs of the 254-bit BN128 fields)", "data": "synthetic",
-            "config": {"workload": workload, "proofs_in_flight": 2 if pipelined else 1, "constraints": n, "variables": n + 1, "npublic": 1,
+            "config": {"workload": workload, "proofs_in_flight": 2 if (pipelined or msm_pipe) else 1, "constraints": n, "variables": n + 1, "npublic": 1,
                        "parallelism": ("one proof, MSM term ranges sharded over the ranks, all-gather of 5 partial points" if sharded else
                                        "independent proofs, one per GPU") if args.workload == "prove" else args.workload,
                        "instance": inst.describe() if args.workload == "prove" else "uniform random scalars, bases k_i*G"},

@@ -51,6 +51,9 @@ _SIGS = {
     "gs_msm_g2": [Handle, u64p, ctypes.c_size_t, ctypes.c_size_t, u64p, intp],
     "gs_msm_g1_resident": [Handle, ctypes.c_size_t, Handle, ctypes.c_size_t, ctypes.c_size_t, u64p, intp],
     "gs_msm_g2_resident": [Handle, ctypes.c_size_t, Handle, ctypes.c_size_t, ctypes.c_size_t, u64p, intp],
+    "gs_msm_g1_begin": [Handle, ctypes.c_size_t, Handle, ctypes.c_size_t, ctypes.c_size_t, u64p],
+    "gs_msm_g2_begin": [Handle, ctypes.c_size_t, Handle, ctypes.c_size_t, ctypes.c_size_t, u64p],
+    "gs_msm_end": [ctypes.c_uint64, u64p, intp],
     "gs_g1_sum_affine": [u64p, intp, ctypes.c_size_t, u64p, intp],
     "gs_g2_sum_affine": [u64p, intp, ctypes.c_size_t, u64p, intp],
     "gs_poly_mul": [u64p, ctypes.c_size_t, u64p, ctypes.c_size_t, u64p],
@@ -321,3 +324,19 @@ def zpoly(deg):
     out = np.zeros((deg + 1, 4), dtype=np.uint64)
     check(load_library().gs_zpoly(deg, ptr64(out)))
     return out
+
+
+def msm_begin(bases, scalars, n, off=0, soff=0, g2=False):
+    """Enqueue one resident MSM (gs_msm_g1_begin / gs_msm_g2_begin) -> ticket; at most two operations outstanding."""
+    t = ctypes.c_uint64(0)
+    fn = load_library().gs_msm_g2_begin if g2 else load_library().gs_msm_g1_begin
+    check(fn(Handle(bases.h), off, Handle(scalars.h), soff, n, ctypes.cast(ctypes.byref(t), u64p)))
+    return (t.value, g2)
+
+
+def msm_end(ticket):
+    t, g2 = ticket
+    out = np.zeros(16 if g2 else 8, dtype=np.uint64)
+    inf = ctypes.c_int(0)
+    check(load_library().gs_msm_end(ctypes.c_uint64(t), ptr64(out), ctypes.byref(inf)))
+    return _affine_result(out, inf, g2)

@@ -106,6 +106,76 @@ int msm_resident(Ctx& c, Kind kind, gs_handle hb, size_t off, const uint32_t* sc
   return GS_OK;
 }
 
+// ---- pipelined MSM: begin enqueues (plan on aux stream 1, accumulation on the main stream, tail on aux stream 2), end collects --
+struct MsmInFlight : InFlightBase {
+  bool g2 = false;
+  MsmPending pend;
+  std::shared_ptr<PhaseTimer> tplan;
+  hipEvent_t planned = nullptr, done = nullptr;
+  MsmInFlight() {
+    GS_HIP(hipEventCreateWithFlags(&planned, hipEventDisableTiming));
+    GS_HIP(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+  }
+  ~MsmInFlight() override { for (hipEvent_t e : {planned, done}) if (e) (void)hipEventDestroy(e); }
+};
+
+template <class T>
+int msm_begin(Ctx& c, Kind kind, gs_handle hb, size_t off, gs_handle hs, size_t soff, size_t n, uint64_t* ticket) {
+  Bases* b = c.get<Bases>(hb, kind);
+  Scalars* sc = c.get<Scalars>(hs, Kind::Scalars);
+  if (!b || !sc || !ticket) return fail(GS_ERR_ARG, "gs_msm_begin: bad handle");
+  if (n == 0 || n > (size_t)kIndexMask) return fail(GS_ERR_ARG, "gs_msm_begin: 1 .. 2^26 - 1 terms per call");
+  if (off > b->n || n > b->n - off || soff > sc->n || n > sc->n - soff) return fail(GS_ERR_ARG, "gs_msm_begin: range exceeds the resident arrays");
+  const int parity = c.free_parity();
+  if (parity < 0) return fail(GS_ERR_ARG, "gs_msm_begin: two operations are already outstanding");
+  if (!b->table) b->table = std::make_shared<BaseTable>();
+  BaseTable* tab = static_cast<BaseTable*>(b->table.get());
+  const int cbits = choose_window_bits((uint32_t)n, c.window_bits);
+  if constexpr (T::kWords == 8) ensure_table_g1(c, *tab, b->buf.as<uint32_t>(), b->n, cbits);
+  else ensure_table_g2(c, *tab, b->buf.as<uint32_t>(), b->n, cbits);
+  auto st = std::make_unique<MsmInFlight>();
+  st->g2 = T::kWords == 16;
+  MsmPlan plan;
+  {
+    StreamScope ss(c, c.aux_stream[1]);
+    st->tplan = std::make_shared<PhaseTimer>(c.stream);
+    build_plan(c, 2 * parity, sc->buf.as<uint32_t>() + soff * 8, (uint32_t)n, plan, {{1, st->g2}});
+    st->tplan->stop();
+    GS_HIP(hipEventRecord(st->planned, c.stream));
+  }
+  {
+    StreamScope ss(c, c.main_stream);
+    GS_HIP(hipStreamWaitEvent(c.stream, st->planned, 0));
+    std::vector<MsmBase> bases{MsmBase{tab, off}};
+    if constexpr (T::kWords == 8) msm_enqueue_g1(c, plan, bases, 8 * parity, 3 * parity, st->pend, c.aux_stream[2]);
+    else msm_enqueue_g2(c, plan, bases, 8 * parity + 4, 3 * parity, st->pend, c.aux_stream[2]);
+  }
+  GS_HIP(hipEventRecord(st->done, c.aux_stream[2]));
+  st->ticket = c.next_ticket++;
+  *ticket = st->ticket;
+  c.inflight[parity] = std::move(st);
+  return GS_OK;
+}
+
+int msm_end(Ctx& c, uint64_t ticket, uint64_t* out_affine, int* is_inf) {
+  if (!out_affine || !is_inf) return fail(GS_ERR_ARG, "null output");
+  int parity = -1;
+  for (int p = 0; p < 2; ++p) if (c.inflight[p] && c.inflight[p]->ticket == ticket) parity = p;
+  if (parity < 0) return fail(GS_ERR_ARG, "gs_msm_end: unknown ticket %llu", (unsigned long long)ticket);
+  MsmInFlight* st = dynamic_cast<MsmInFlight*>(c.inflight[parity].get());
+  if (!st) return fail(GS_ERR_ARG, "gs_msm_end: ticket %llu belongs to a proof (use gs_groth16_prove_end)", (unsigned long long)ticket);
+  std::unique_ptr<InFlightBase> base = std::move(c.inflight[parity]);
+  GS_HIP(hipEventSynchronize(st->done));
+  reset_timing(c);
+  c.timing.plan_ms = st->tplan->ms();
+  bool inf;
+  if (!st->g2) { std::vector<G1Xyzz> r; msm_finish_g1(c, st->pend, r); inf = g1_to_affine_std(r[0], out_affine); }
+  else { std::vector<G2Xyzz> r; msm_finish_g2(c, st->pend, r); inf = g2_to_affine_std(r[0], out_affine); }
+  *is_inf = inf ? 1 : 0;
+  c.timing.total_ms = c.timing.plan_ms + c.timing.accumulate_ms + c.timing.reduce_ms;
+  return GS_OK;
+}
+
 template <class T>
 int msm_host_scalars(Ctx& c, Kind kind, gs_handle hb, const uint64_t* scalars, size_t off, size_t n,
                      uint64_t* out_affine, int* is_inf) {
@@ -280,6 +350,16 @@ int gs_msm_g2_resident(gs_handle bases, size_t off, gs_handle scalars, size_t so
     reset_timing(c);
     return msm_resident<Fq2Tag>(c, Kind::G2Bases, bases, off, s->buf.as<uint32_t>() + soff * 8, n, out_affine, is_inf);
   });
+}
+
+int gs_msm_g1_begin(gs_handle bases, size_t off, gs_handle scalars, size_t soff, size_t n, uint64_t* ticket) {
+  return guarded([&](Ctx& c) { return msm_begin<FqTag>(c, Kind::G1Bases, bases, off, scalars, soff, n, ticket); }, true, true);
+}
+int gs_msm_g2_begin(gs_handle bases, size_t off, gs_handle scalars, size_t soff, size_t n, uint64_t* ticket) {
+  return guarded([&](Ctx& c) { return msm_begin<Fq2Tag>(c, Kind::G2Bases, bases, off, scalars, soff, n, ticket); }, true, true);
+}
+int gs_msm_end(uint64_t ticket, uint64_t* out_affine, int* is_inf) {
+  return guarded([&](Ctx& c) { return msm_end(c, ticket, out_affine, is_inf); }, true, true);
 }
 
 int gs_g1_sum_affine(const uint64_t* pts, const int* inf, size_t n, uint64_t out[8], int* is_inf) {

@@ -546,6 +546,8 @@ int gs_groth16_prove_end(uint64_t ticket, uint64_t out_proof[32], int inf[3]) {
     int parity = -1;
     for (int p = 0; p < 2; ++p) if (c.inflight[p] && c.inflight[p]->ticket == ticket) parity = p;
     if (parity < 0) return fail(GS_ERR_ARG, "gs_groth16_prove_end: unknown ticket %llu", (unsigned long long)ticket);
+    if (!dynamic_cast<GrothInFlight*>(c.inflight[parity].get()))
+      return fail(GS_ERR_ARG, "gs_groth16_prove_end: ticket %llu belongs to an MSM (use gs_msm_end)", (unsigned long long)ticket);
     std::unique_ptr<InFlightBase> base = std::move(c.inflight[parity]);
     GrothInFlight& st = static_cast<GrothInFlight&>(*base);
     reset_timing(c);

@@ -101,6 +101,12 @@ int gs_msm_g1_resident(gs_handle bases, size_t off, gs_handle scalars, size_t so
                        uint64_t out_affine[8], int* is_inf);
 int gs_msm_g2_resident(gs_handle bases, size_t off, gs_handle scalars, size_t soff, size_t n,
                        uint64_t out_affine[16], int* is_inf);
+/* Pipelined form (everything resident): begin enqueues one MSM and returns a ticket, gs_msm_end waits for that MSM only and
+ * writes the affine result (8 words for a G1 ticket, 16 for G2).  Two operations may be outstanding (MSM or proof tickets);
+ * the sort of MSM k+1 runs under the accumulation of MSM k and its accumulation starts the moment that one ends. */
+int gs_msm_g1_begin(gs_handle bases, size_t off, gs_handle scalars, size_t soff, size_t n, uint64_t* ticket);
+int gs_msm_g2_begin(gs_handle bases, size_t off, gs_handle scalars, size_t soff, size_t n, uint64_t* ticket);
+int gs_msm_end(uint64_t ticket, uint64_t* out_affine, int* is_inf);
 /* Sum of n points given as affine [x,y] pairs with infinity flags (multi-GPU combine of the
  * per-rank partial sums): out = sum_i pts[i]. */
 int gs_g1_sum_affine(const uint64_t* pts /* n x 8 */, const int* inf, size_t n, uint64_t out_affine[8], int* is_inf);

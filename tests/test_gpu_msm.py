@@ -224,3 +224,23 @@ def test_reference_g1_g2_tests_through_the_c_abi():
     # identities the reference's Add special-cases (g1.go:33-38): P + 0 = P, 0 + 0 = 0
     assert bn128.G1.Add(gr1, bn128.G1_ZERO) == gr1 and bn128.G1.Add(bn128.G1_ZERO, bn128.G1_ZERO) == bn128.G1_ZERO
     assert bn128.G1.MulScalar(gr1, 0) == bn128.G1_ZERO
+
+
+def test_pipelined_msm_tickets_equal_blocking_calls():
+    """gs_msm_g1_begin / gs_msm_g2_begin / gs_msm_end with two operations outstanding (mixed G1 / G2, different ranges)."""
+    n = 1 << 12
+    b1 = capi.g1_fixed_base(U.rand_scalars_u64(n, 901))
+    b2 = capi.g2_fixed_base(U.rand_scalars_u64(n, 902))
+    s = capi.scalars_upload(U.rand_scalars_u64(n, 903))
+    jobs = [(b1, False, 0, 0, n), (b2, True, 0, 0, n), (b1, False, 100, 7, 1000), (b2, True, 5, 5, 333), (b1, False, 0, 0, 1)]
+    want = [capi.msm_resident(b, s, cnt, off=off, soff=soff, g2=g2) for b, g2, off, soff, cnt in jobs]
+    got, tickets = [], []
+    for b, g2, off, soff, cnt in jobs:
+        tickets.append(capi.msm_begin(b, s, cnt, off=off, soff=soff, g2=g2))
+        if len(tickets) == 2:
+            got.append(capi.msm_end(tickets.pop(0)))
+    while tickets:
+        got.append(capi.msm_end(tickets.pop(0)))
+    assert got == want
+    with pytest.raises(capi.GosnarkHipError):
+        capi.msm_end((987654, False))
