@@ -237,7 +237,7 @@ int gs_init(const int* devices, int ndev) {
       // The aux streams carry the latency-/bandwidth-bound shadow work of a proof (NTT passes, plan kernels, bucket
       // combine / reduction tails) next to the ALU-bound accumulations on the main stream.  They get the HIGHEST queue
       // priority: their kernels are short but hard to place (k_hist wants 128 KiB of LDS and 16 wave slots of one CU),
-      // and a starved plan(h) would stall the last accumulation (seen in profiles/r01c_prove_step_timeline.txt).
+      // and a starved plan(h) would stall the last accumulation (seen in an earlier timeline).
       {
         int least = 0, greatest = 0;
         GS_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
