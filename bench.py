@@ -113,9 +113,10 @@ def main():
     ap.add_argument("--instance", default="setup", choices=["setup", "sqchain", "random"],
                     help="setup: sqchain R1CS + structured trusted setup on the device + px from the sparse system (a complete, "
                          "checkable instance, SURVEY 8d); sqchain: same R1CS with key points k_i*G; random: uniform w / px")
-    ap.add_argument("--pipeline", type=int, default=2, choices=[1, 2],
-                    help="proofs in flight per GPU (prove workload): 2 = gs_groth16_prove_begin/_end, the next proof's plan and "
-                         "accumulations are queued behind the current one's; 1 = one blocking call per step")
+    ap.add_argument("--pipeline", type=int, default=3, choices=[1, 2, 3],
+                    help="operations in flight per GPU (prove / msm_g1 workloads): >= 2 = gs_groth16_prove_begin/_end (gs_msm_g1_begin/"
+                         "gs_msm_end), the next operation's plan and accumulations are queued behind the current one's; 1 = one "
+                         "blocking call per step")
     ap.add_argument("--no-check", action="store_true", help="skip the closed-form proof check of the `setup` instance")
     ap.add_argument("--cpu-log2n", type=int, default=13, help="constraints of the CPU-baseline sample (0 = skip)")
     args = ap.parse_args()
@@ -170,7 +171,6 @@ def main():
         if args.workload == "msm_g1":
             def step():
                 return capi.msm_resident(bases, sc, nterms)
-            msm_pipelined = args.pipeline == 2
         else:
             def step():
                 return parallel.msm_g1_sharded(bases, sc, nterms)
@@ -183,15 +183,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    pipelined = args.workload == "prove" and not sharded and not from_r1cs and args.pipeline == 2
-    msm_pipe = args.workload == "msm_g1" and args.pipeline == 2
+    pipelined = args.workload == "prove" and not sharded and not from_r1cs and args.pipeline >= 2
+    msm_pipe = args.workload == "msm_g1" and args.pipeline >= 2
 
     def run_steps(count, on_done=None):
         if msm_pipe:
             tickets = []
             for _ in range(count):
                 tickets.append(capi.msm_begin(bases, sc, nterms))
-                if len(tickets) == 2:
+                if len(tickets) == args.pipeline:
                     capi.msm_end(tickets.pop(0))
                     if on_done:
                         on_done()
@@ -209,7 +209,7 @@ def main():
         tickets = []
         for _ in range(count):
             tickets.append(groth16.prove_begin(pk, inst.w, inst.px, r_, s_))
-            if len(tickets) == 2:
+            if len(tickets) == args.pipeline:
                 groth16.prove_end(tickets.pop(0))
                 if on_done:
                     on_done()
@@ -269,7 +269,7 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None,
             "dtype": "u32 (9x29-bit Montgomery limbs of the 254-bit BN128 fields)", "data": "synthetic",
-            "config": {"workload": workload, "proofs_in_flight": 2 if (pipelined or msm_pipe) else 1, "constraints": n, "variables": n + 1, "npublic": 1,
+            "config": {"workload": workload, "proofs_in_flight": args.pipeline if (pipelined or msm_pipe) else 1, "constraints": n, "variables": n + 1, "npublic": 1,
                        "parallelism": ("one proof, MSM term ranges sharded over the ranks, all-gather of 5 partial points" if sharded else
                                        "independent proofs, one per GPU") if args.workload == "prove" else args.workload,
                        "instance": inst.describe() if args.workload == "prove" else "uniform random scalars, bases k_i*G"},

@@ -127,7 +127,7 @@ int msm_begin(Ctx& c, Kind kind, gs_handle hb, size_t off, gs_handle hs, size_t 
   if (n == 0 || n > (size_t)kIndexMask) return fail(GS_ERR_ARG, "gs_msm_begin: 1 .. 2^26 - 1 terms per call");
   if (off > b->n || n > b->n - off || soff > sc->n || n > sc->n - soff) return fail(GS_ERR_ARG, "gs_msm_begin: range exceeds the resident arrays");
   const int parity = c.free_parity();
-  if (parity < 0) return fail(GS_ERR_ARG, "gs_msm_begin: two operations are already outstanding");
+  if (parity < 0) return fail(GS_ERR_ARG, "gs_msm_begin: three operations are already outstanding");
   if (!b->table) b->table = std::make_shared<BaseTable>();
   BaseTable* tab = static_cast<BaseTable*>(b->table.get());
   const int cbits = choose_window_bits((uint32_t)n, c.window_bits);
@@ -160,7 +160,7 @@ int msm_begin(Ctx& c, Kind kind, gs_handle hb, size_t off, gs_handle hs, size_t 
 int msm_end(Ctx& c, uint64_t ticket, uint64_t* out_affine, int* is_inf) {
   if (!out_affine || !is_inf) return fail(GS_ERR_ARG, "null output");
   int parity = -1;
-  for (int p = 0; p < 2; ++p) if (c.inflight[p] && c.inflight[p]->ticket == ticket) parity = p;
+  for (int p = 0; p < Ctx::kMaxInFlight; ++p) if (c.inflight[p] && c.inflight[p]->ticket == ticket) parity = p;
   if (parity < 0) return fail(GS_ERR_ARG, "gs_msm_end: unknown ticket %llu", (unsigned long long)ticket);
   MsmInFlight* st = dynamic_cast<MsmInFlight*>(c.inflight[parity].get());
   if (!st) return fail(GS_ERR_ARG, "gs_msm_end: ticket %llu belongs to a proof (use gs_groth16_prove_end)", (unsigned long long)ticket);

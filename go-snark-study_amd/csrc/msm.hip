@@ -34,7 +34,7 @@ static void exclusive_scan(Ctx& c, PlanBuffers& pb, const uint32_t* in, uint32_t
   hipLaunchKernelGGL(k_scan_add, dim3(ntiles), dim3(kScanBlock), 0, c.stream, out, pb.tiles.as<uint32_t>(), n);
 }
 
-static PlanBuffers g_plan_slots[4];          // (w, h) x (two proofs in flight)
+static PlanBuffers g_plan_slots[2 * Ctx::kMaxInFlight];          // (w, h) x operations in flight
 
 // Chunk size of a plan = additions one accumulate thread performs back to back.  Small chunks mean more threads and shorter
 // serial chains (a 2^16-term MSM with 32-entry chunks is only 512 waves of 32 dependent additions), large chunks mean fewer
@@ -54,7 +54,7 @@ static uint32_t choose_chunk(uint64_t entries, uint32_t nbuckets, const std::vec
 }
 
 void build_plan(Ctx& c, int slot, const uint32_t* scalars_dev, uint32_t n, MsmPlan& plan, const std::vector<LaunchShape>& users) {
-  PlanBuffers& pb = g_plan_slots[slot & 3];
+  PlanBuffers& pb = g_plan_slots[slot % (2 * Ctx::kMaxInFlight)];
   plan.n = n;
   plan.c = choose_window_bits(n, c.window_bits);
   plan.W = 254 / plan.c + 1;
@@ -142,15 +142,15 @@ static void msm_enqueue(Ctx& c, const MsmPlan& plan, const std::vector<MsmBase>&
   const size_t out_bytes = (size_t)njobs * nblk * 2 * pw * 4;
   if (out_bytes > Ctx::kPinnedBytes) throw HipError{hipErrorInvalidValue, "MSM result staging too small", __LINE__};
   AccJobs jobs{};
-  DevBuf& outb = c.ws_out[ws_base % 16];
+  DevBuf& outb = c.ws_out[ws_base % (8 * Ctx::kMaxInFlight)];
   outb.ensure(out_bytes);
   for (int j = 0; j < njobs; ++j) {
     const BaseTable* t = bases[j].table;
     if (!t || t->c != plan.c || bases[j].off + plan.n > t->n)
       throw HipError{hipErrorInvalidValue, "MSM base table does not match the plan", __LINE__};
-    DevBuf& bk = c.ws_buckets[(ws_base + j) % 16];
-    DevBuf& mg = c.ws_chunks[(ws_base + j) % 16];
-    DevBuf& pt = c.ws_partials[(ws_base + j) % 16];
+    DevBuf& bk = c.ws_buckets[(ws_base + j) % (8 * Ctx::kMaxInFlight)];
+    DevBuf& mg = c.ws_chunks[(ws_base + j) % (8 * Ctx::kMaxInFlight)];
+    DevBuf& pt = c.ws_partials[(ws_base + j) % (8 * Ctx::kMaxInFlight)];
     bk.ensure((size_t)plan.nbuckets * pw * 4);
     mg.ensure((size_t)plan.B * pw * 4);
     pt.ensure((size_t)plan.maxchunks * 2 * pw * 4);

@@ -524,7 +524,7 @@ int gs_groth16_prove_begin(gs_handle hpk, gs_handle hw, gs_handle hpx, const uin
     if (!pk || !w || !px) return fail(GS_ERR_ARG, "gs_groth16_prove_begin: bad handle");
     if (!r || !s || !ticket) return fail(GS_ERR_ARG, "null argument");
     const int parity = c.free_parity();
-    if (parity < 0) return fail(GS_ERR_ARG, "gs_groth16_prove_begin: two proofs are already outstanding; call gs_groth16_prove_end first");
+    if (parity < 0) return fail(GS_ERR_ARG, "gs_groth16_prove_begin: three operations are already outstanding; call gs_groth16_prove_end first");
     auto st = std::make_unique<GrothInFlight>();
     memcpy(st->r, r, 32); memcpy(st->s, s, 32);
     st->with_tail = true;
@@ -544,7 +544,7 @@ int gs_groth16_prove_end(uint64_t ticket, uint64_t out_proof[32], int inf[3]) {
   return guarded([&](Ctx& c) -> int {
     if (!out_proof || !inf) return fail(GS_ERR_ARG, "null argument");
     int parity = -1;
-    for (int p = 0; p < 2; ++p) if (c.inflight[p] && c.inflight[p]->ticket == ticket) parity = p;
+    for (int p = 0; p < Ctx::kMaxInFlight; ++p) if (c.inflight[p] && c.inflight[p]->ticket == ticket) parity = p;
     if (parity < 0) return fail(GS_ERR_ARG, "gs_groth16_prove_end: unknown ticket %llu", (unsigned long long)ticket);
     if (!dynamic_cast<GrothInFlight*>(c.inflight[parity].get()))
       return fail(GS_ERR_ARG, "gs_groth16_prove_end: ticket %llu belongs to an MSM (use gs_msm_end)", (unsigned long long)ticket);

@@ -111,10 +111,12 @@ struct Ctx {
   bool ready = false;
   hipStream_t stream = nullptr;   // the stream every engine function enqueues on (switched by StreamScope)
   hipStream_t main_stream = nullptr, aux_stream[3] = {nullptr, nullptr, nullptr};
-  void* pinned[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // host staging of the result downloads (3 per proof in flight)
-  std::unique_ptr<InFlightBase> inflight[2];         // pipelined proofs (parity = which buffer set they own)
+  static constexpr int kMaxInFlight = 3;             // pipelined operations (tickets); each owns one set of workspaces
+  void* pinned[3 * kMaxInFlight] = {};               // host staging of the result downloads (3 per operation in flight)
+  std::unique_ptr<InFlightBase> inflight[kMaxInFlight];
   uint64_t next_ticket = 1;
-  int free_parity() const { return !inflight[0] ? 0 : (!inflight[1] ? 1 : -1); }
+  int free_parity() const { for (int p = 0; p < kMaxInFlight; ++p) if (!inflight[p]) return p; return -1; }
+  bool any_inflight() const { for (int p = 0; p < kMaxInFlight; ++p) if (inflight[p]) return true; return false; }
   static constexpr size_t kPinnedBytes = 256 * 1024;
   std::mutex mu;
   uint64_t next_handle = 1;
@@ -124,7 +126,7 @@ struct Ctx {
   std::mutex timing_mu;          // msm_finish of several groups may run on different host threads
   // reusable workspaces (grow-only)
   DevBuf ws_hist, ws_offsets, ws_cursor, ws_entries, ws_tiles, ws_total;
-  DevBuf ws_buckets[16], ws_chunks[16], ws_partials[16], ws_out[16];     // 8 workspace sets per proof in flight
+  DevBuf ws_buckets[8 * kMaxInFlight], ws_chunks[8 * kMaxInFlight], ws_partials[8 * kMaxInFlight], ws_out[8 * kMaxInFlight];   // 8 sets per ticket
   DevBuf ws_misc;
   DevBuf g1_pow2, g2_pow2;       // 2^j * G tables (lazy)
   std::vector<hipEvent_t> events;
@@ -152,7 +154,7 @@ int guarded(F&& f, bool need_init = true, bool allow_inflight = false) {
   Ctx& c = ctx();
   std::lock_guard<std::mutex> lk(c.mu);
   if (need_init && !c.ready) return fail(GS_ERR_NOT_INIT, "gs_init has not been called (or failed)");
-  if (need_init && !allow_inflight && (c.inflight[0] || c.inflight[1]))
+  if (need_init && !allow_inflight && c.any_inflight())
     return fail(GS_ERR_ARG, "a pipelined proof is outstanding (gs_groth16_prove_begin): call gs_groth16_prove_end before any other entry point");
   try {
     return f(c);

@@ -102,7 +102,7 @@ int gs_msm_g1_resident(gs_handle bases, size_t off, gs_handle scalars, size_t so
 int gs_msm_g2_resident(gs_handle bases, size_t off, gs_handle scalars, size_t soff, size_t n,
                        uint64_t out_affine[16], int* is_inf);
 /* Pipelined form (everything resident): begin enqueues one MSM and returns a ticket, gs_msm_end waits for that MSM only and
- * writes the affine result (8 words for a G1 ticket, 16 for G2).  Two operations may be outstanding (MSM or proof tickets);
+ * writes the affine result (8 words for a G1 ticket, 16 for G2).  Three operations may be outstanding (MSM or proof tickets);
  * the sort of MSM k+1 runs under the accumulation of MSM k and its accumulation starts the moment that one ends. */
 int gs_msm_g1_begin(gs_handle bases, size_t off, gs_handle scalars, size_t soff, size_t n, uint64_t* ticket);
 int gs_msm_g2_begin(gs_handle bases, size_t off, gs_handle scalars, size_t soff, size_t n, uint64_t* ticket);
@@ -171,7 +171,7 @@ int gs_groth16_prove_resident(gs_handle pk, gs_handle w, gs_handle px,
 
 /* Pipelined proving (inputs resident): gs_groth16_prove_begin enqueues the whole device side of one proof and returns a
  * ticket without waiting; gs_groth16_prove_end waits for THAT proof only, then runs the host tail and writes the proof
- * (same layout as gs_groth16_prove).  At most two proofs may be outstanding; they own disjoint workspaces, so the plan and
+ * (same layout as gs_groth16_prove).  At most three tickets (proofs or MSMs) may be outstanding; they own disjoint workspaces, so the plan and
  * bucket accumulations of proof k+1 run while the reduction tails, result download and host tail of proof k are still in
  * progress.  While a ticket is outstanding every other entry point returns GS_ERR_ARG (finish the tickets first). */
 int gs_groth16_prove_begin(gs_handle pk, gs_handle w, gs_handle px, const uint64_t r[4], const uint64_t s[4], uint64_t* ticket);

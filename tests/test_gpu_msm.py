@@ -237,7 +237,7 @@ def test_pipelined_msm_tickets_equal_blocking_calls():
     got, tickets = [], []
     for b, g2, off, soff, cnt in jobs:
         tickets.append(capi.msm_begin(b, s, cnt, off=off, soff=soff, g2=g2))
-        if len(tickets) == 2:
+        if len(tickets) == 3:
             got.append(capi.msm_end(tickets.pop(0)))
     while tickets:
         got.append(capi.msm_end(tickets.pop(0)))

@@ -417,9 +417,9 @@ def test_device_pinocchio_setup_equals_the_key_the_reference_verifier_accepted()
     assert proof.PiB == jac_affine_g2(GU.g2(rec["proof"]["PiB"]))
 
 
-def test_pipelined_proving_two_in_flight_equals_blocking_calls():
-    """gs_groth16_prove_begin / _end: two proofs outstanding on disjoint workspaces; results equal the blocking entry point
-    (different witnesses and randomness per proof, collected in order); a third begin and any other entry point are refused
+def test_pipelined_proving_three_in_flight_equals_blocking_calls():
+    """gs_groth16_prove_begin / _end: up to three proofs outstanding on disjoint workspaces; results equal the blocking entry point
+    (different witnesses and randomness per proof, collected in order); a fourth begin and any other entry point are refused
     while tickets are outstanding."""
     from gosnark_amd import synth
     n = 1 << 12
@@ -435,8 +435,8 @@ def test_pipelined_proving_two_in_flight_equals_blocking_calls():
     got, tickets = [], []
     for (w, px), (r, s) in zip(inputs, rs):
         tickets.append(groth16.prove_begin(pk, w, px, r, s))
-        if len(tickets) == 2:
-            with pytest.raises(capi.GosnarkHipError):          # only two may be outstanding
+        if len(tickets) == 3:
+            with pytest.raises(capi.GosnarkHipError):          # only three may be outstanding
                 groth16.prove_begin(pk, w, px, r, s)
             with pytest.raises(capi.GosnarkHipError):          # and nothing else may run meanwhile
                 capi.msm(inst_bases_dummy(), np.zeros((1, 4), dtype=np.uint64))
