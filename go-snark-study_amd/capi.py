@@ -133,6 +133,8 @@ def init(device=None):
     global _INIT_DEVICE
     lib = load_library()
     if device is None:
+        if _INIT_DEVICE is not None:          # already driving a GPU: keep it (one process per GPU)
+            return
         device = int(os.environ.get("LOCAL_RANK", "0"))
     if _INIT_DEVICE == device:
         return
