@@ -168,6 +168,7 @@ int msm_end(Ctx& c, uint64_t ticket, uint64_t* out_affine, int* is_inf) {
   GS_HIP(hipEventSynchronize(st->done));
   reset_timing(c);
   c.timing.plan_ms = st->tplan->ms();
+  msm_book_timing(c, st->pend);
   bool inf;
   if (!st->g2) { std::vector<G1Xyzz> r; msm_finish_g1(c, st->pend, r); inf = g1_to_affine_std(r[0], out_affine); }
   else { std::vector<G2Xyzz> r; msm_finish_g2(c, st->pend, r); inf = g2_to_affine_std(r[0], out_affine); }

@@ -64,7 +64,8 @@ struct MsmPending {
 // tail_stream: where the window merge / reduction / download go (nullptr = c.stream)
 void msm_enqueue_g1(Ctx& c, const MsmPlan& plan, const std::vector<MsmBase>& bases, int ws_base, int slot, MsmPending& p, hipStream_t tail_stream = nullptr);
 void msm_enqueue_g2(Ctx& c, const MsmPlan& plan, const std::vector<MsmBase>& bases, int ws_base, int slot, MsmPending& p, hipStream_t tail_stream = nullptr);
-void msm_finish_g1(Ctx& c, const MsmPending& p, std::vector<G1Xyzz>& out);
+void msm_book_timing(Ctx& c, const MsmPending& p);        // HIP event queries: call on the thread that drives the device
+void msm_finish_g1(Ctx& c, const MsmPending& p, std::vector<G1Xyzz>& out);   // pure host arithmetic (worker threads allowed)
 void msm_finish_g2(Ctx& c, const MsmPending& p, std::vector<G2Xyzz>& out);
 // enqueue + synchronise + finish on c.stream
 void msm_run_g1(Ctx& c, const MsmPlan& plan, const std::vector<MsmBase>& bases, std::vector<G1Xyzz>& out);

@@ -202,6 +202,7 @@ int groth16_collect(Ctx& c, GrothInFlight& st, GrothSums& sums) {
   GS_HIP(hipEventSynchronize(st.done_aux2));
   std::vector<G1Xyzz> g1w, g1h;
   std::vector<G2Xyzz> g2w;
+  msm_book_timing(c, st.pend_g1w); msm_book_timing(c, st.pend_g2w); msm_book_timing(c, st.pend_h);
   {                                                              // the host-side pair sums of the three groups, on separate cores
     auto f2 = std::async(std::launch::async, [&] { msm_finish_g2(c, st.pend_g2w, g2w); });
     auto fh = std::async(std::launch::async, [&] { msm_finish_g1(c, st.pend_h, g1h); });
@@ -323,6 +324,7 @@ int pinocchio_prove_impl(Ctx& c, PinocchioPkObj* pk, DevScalars w, DevScalars px
   total.stop();
   std::vector<G1Xyzz> g1w, g1h;
   std::vector<G2Xyzz> g2w;
+  msm_book_timing(c, pend_g1w); msm_book_timing(c, pend_g2w); msm_book_timing(c, pend_h);
   {                                                              // the host-side pair sums of the three groups, on separate cores
     auto f2 = std::async(std::launch::async, [&] { msm_finish_g2(c, pend_g2w, g2w); });
     auto fh = std::async(std::launch::async, [&] { msm_finish_g1(c, pend_h, g1h); });

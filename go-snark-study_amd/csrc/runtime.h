@@ -154,6 +154,8 @@ int guarded(F&& f, bool need_init = true, bool allow_inflight = false) {
   Ctx& c = ctx();
   std::lock_guard<std::mutex> lk(c.mu);
   if (need_init && !c.ready) return fail(GS_ERR_NOT_INIT, "gs_init has not been called (or failed)");
+  // the HIP current device is per host thread: callers (goroutines, worker threads) may arrive on any thread
+  if (c.ready) (void)hipSetDevice(c.device);
   if (need_init && !allow_inflight && c.any_inflight())
     return fail(GS_ERR_ARG, "a pipelined proof is outstanding (gs_groth16_prove_begin): call gs_groth16_prove_end before any other entry point");
   try {
