@@ -74,6 +74,17 @@ Affine<T> download_point(Ctx& c, const uint32_t* packed_dev) {
 
 }  // namespace
 
+template <class T>
+static void host_affine_to_jacobian_std(const Affine<T>& a, uint64_t* out) {
+  constexpr int cw = PointIO<T>::kCoordWords;
+  uint32_t* o = reinterpret_cast<uint32_t*>(out);
+  memset(o, 0, 3 * cw * 4);
+  if (is_inf(a)) return;                  // infinity = all-zero triple (reference convention, g1.go:28-30)
+  PointIO<T>::store_std(o, a.x);
+  PointIO<T>::store_std(o + cw, a.y);
+  o[2 * cw] = 1;                          // Z = 1 (G2: (1, 0))
+}
+
 extern "C" {
 
 int gs_groth16_setup(size_t n, size_t m, size_t npublic,
@@ -254,13 +265,28 @@ int gs_groth16_pk_export(gs_handle hpk, int which, uint64_t* jacobian, size_t co
     const DevBuf* src = nullptr;
     size_t have = pk->nvars;
     bool g2 = false;
+    if (which == 5) {           // the single elements, Jacobian: G1 alpha, beta, delta (3 x 12) then G2 beta, delta (2 x 24)
+      if (count != 5 || !jacobian) return fail(GS_ERR_ARG, "gs_groth16_pk_export: which = 5 exports exactly 5 points (84 u64)");
+      host_affine_to_jacobian_std<FqTag>(pk->alpha, jacobian);
+      host_affine_to_jacobian_std<FqTag>(pk->beta, jacobian + 12);
+      host_affine_to_jacobian_std<FqTag>(pk->delta, jacobian + 24);
+      host_affine_to_jacobian_std<Fq2Tag>(pk->beta2, jacobian + 36);
+      host_affine_to_jacobian_std<Fq2Tag>(pk->delta2, jacobian + 60);
+      return GS_OK;
+    }
+    if (which == 6) {           // pk.Z: nz coefficients, 4 x u64 each
+      if (count != pk->nz || !jacobian) return fail(GS_ERR_ARG, "gs_groth16_pk_export: Z has %zu coefficients, asked for %zu", pk->nz, count);
+      GS_HIP(hipMemcpyAsync(jacobian, pk->z.b_std.p, count * 32, hipMemcpyDeviceToHost, c.stream));
+      GS_HIP(hipStreamSynchronize(c.stream));
+      return GS_OK;
+    }
     switch (which) {
       case 0: src = &pk->at; break;
       case 1: src = &pk->bacgamma1; break;
       case 2: src = &pk->bacgamma2; g2 = true; break;
       case 3: src = &pk->bacdelta; break;
       case 4: src = &pk->ptd; have = pk->nptd; break;
-      default: return fail(GS_ERR_ARG, "gs_groth16_pk_export: which must be 0..4");
+      default: return fail(GS_ERR_ARG, "gs_groth16_pk_export: which must be 0..6");
     }
     if (count != have || (count && !jacobian)) return fail(GS_ERR_ARG, "gs_groth16_pk_export: array has %zu points, asked for %zu", have, count);
     if (!count) return GS_OK;
@@ -279,7 +305,13 @@ int gs_pinocchio_pk_export(gs_handle hpk, int which, uint64_t* jacobian, size_t 
     PinocchioPkObj* pk = c.get<PinocchioPkObj>(hpk, Kind::PinocchioPk);
     if (!pk) return fail(GS_ERR_ARG, "gs_pinocchio_pk_export: bad proving-key handle");
     const DevBuf* arr[8] = {&pk->a, &pk->ap, &pk->b2, &pk->bp, &pk->c, &pk->cp, &pk->kp, &pk->g1t};
-    if (which < 0 || which > 7) return fail(GS_ERR_ARG, "gs_pinocchio_pk_export: which must be 0..7");
+    if (which == 8) {           // pk.Z: nz coefficients, 4 x u64 each
+      if (count != pk->nz || !jacobian) return fail(GS_ERR_ARG, "gs_pinocchio_pk_export: Z has %zu coefficients, asked for %zu", pk->nz, count);
+      GS_HIP(hipMemcpyAsync(jacobian, pk->z.b_std.p, count * 32, hipMemcpyDeviceToHost, c.stream));
+      GS_HIP(hipStreamSynchronize(c.stream));
+      return GS_OK;
+    }
+    if (which < 0 || which > 7) return fail(GS_ERR_ARG, "gs_pinocchio_pk_export: which must be 0..8");
     const bool g2 = which == 2;
     const size_t have = which == 7 ? pk->ng1t : pk->nvars;
     if (count != have || (count && !jacobian)) return fail(GS_ERR_ARG, "gs_pinocchio_pk_export: array has %zu points, asked for %zu", have, count);

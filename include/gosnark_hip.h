@@ -210,10 +210,13 @@ int gs_pinocchio_setup(size_t n, size_t m, size_t npublic,
                        const uint32_t* c_rowptr, const uint32_t* c_col, const uint64_t* c_val,
                        const uint64_t toxic[32], gs_handle* pk_out, uint64_t* vk_out);
 /* Read one array of a resident Pinocchio key back (which = 0 A, 1 Ap, 2 B (G2, 24 words per point), 3 Bp, 4 C, 5 Cp,
- * 6 Kp, 7 G1T).  Note A and Ap hold infinity for i <= NPublic (what the prover sums, snark.go:265). */
+ * 6 Kp, 7 G1T; 8 = pk.Z, count coefficients of 4 x u64).  Note A and Ap hold infinity for i <= NPublic (what the
+ * prover sums, snark.go:265). */
 int gs_pinocchio_pk_export(gs_handle pk, int which, uint64_t* jacobian, size_t count);
 /* Read one array of a resident Groth16 key back as affine Jacobian triples: which = 0 G1.At, 1 G1.BACGamma,
- * 2 G2.BACGamma (24 words per point), 3 BACDelta, 4 PowersTauDelta.  count must equal the array length. */
+ * 2 G2.BACGamma (24 words per point), 3 BACDelta, 4 PowersTauDelta; 5 = the single elements (count = 5: G1 Alpha, Beta,
+ * Delta as 3 x 12 words, then G2 Beta, Delta as 2 x 24 words); 6 = pk.Z (count coefficients of 4 x u64).  count must
+ * equal the array length.  With 0..6 a resident key can be written out in full (utils.GrothSetupToString). */
 int gs_groth16_pk_export(gs_handle pk, int which, uint64_t* jacobian, size_t count);
 
 /* ---- Pinocchio prover (snark.go) ------------------------------------------------------------ */

@@ -497,3 +497,40 @@ def test_resident_r1cs_px_equals_host_buffer_path_and_feeds_the_prover():
     assert (got.PiA, got.PiB, got.PiC) == (want.PiA, want.PiB, want.PiC)
     with pytest.raises(capi.GosnarkHipError):                   # witness length must match the system
         dev.ComputePxResident(capi.scalars_upload(w2[:-1]))
+
+
+def test_resident_key_round_trips_through_the_wire_formats(tmp_path):
+    """a key built on the device is written as the binary limb container (gs_groth16_pk_export 0..6), mapped
+    back and uploaded without becoming Python integers, and proves the reference's recorded proof; the same file, read as
+    host integers and printed with the reference's *String layout, is the golden key in affine form."""
+    from gosnark_amd import utils
+    rec = GU.load("groth_x3")
+    toxic = tuple(int.from_bytes(bytes((i * k + 7) & 0xff for i in range(30)), "big") % O.R for k in (3, 5, 7, 11, 13))
+    a, b, c = _x3_csr()
+    dpk, vk = groth16.GenerateTrustedSetupSparse(7, 8, 1, a, b, c, toxic)
+    path = str(tmp_path / "x3.gskey")
+    utils.GrothSetupToBinary(path, groth16.Circuit(8, 1), dpk, vk)
+    circ, dpk2 = utils.UploadGrothPkBinary(path)
+    assert (circ.NVars, circ.NPublic) == (8, 1)
+    r, s = GU.rs_from_stream(rec["rand"])
+    proof = groth16.GenerateProofsWithRS(circ, dpk2, rec["w"], rec["px"], r, s)
+    assert utils.GrothProofToString(proof) == {"PiA": [str(x) for x in jac_affine_g1(GU.g1(rec["proof"]["PiA"]))],
+                                               "PiB": [[str(x) for x in cc] for cc in jac_affine_g2(GU.g2(rec["proof"]["PiB"]))],
+                                               "PiC": [str(x) for x in jac_affine_g1(GU.g1(rec["proof"]["PiC"]))]}
+    _, hpk = utils.GrothPkFromBinary(path)
+    opk = GU.groth_pk(rec["setup"])
+    assert hpk.Z == [z % O.R for z in opk.Z]
+    assert (hpk.G1_Alpha, hpk.G1_Beta, hpk.G1_Delta) == tuple(jac_affine_g1(p) for p in (opk.G1_Alpha, opk.G1_Beta, opk.G1_Delta))
+    assert (hpk.G2_Beta, hpk.G2_Delta) == (jac_affine_g2(opk.G2_Beta), jac_affine_g2(opk.G2_Delta))
+    assert hpk.G1_At == [jac_affine_g1(p) for p in opk.G1_At] and hpk.G2_BACGamma == [jac_affine_g2(p) for p in opk.G2_BACGamma]
+    svk = utils.GrothVkToString(utils.GrothVkFromBinary(path))
+    want_vk = utils.GrothVkToString(utils.GrothVkFromString(rec["setup"]["Vk"]))
+    aff = lambda d: json_affine(d)   # noqa: E731
+    assert aff(svk) == aff(want_vk)
+
+
+def json_affine(vk_strings):
+    from gosnark_amd import utils
+    vk = utils.GrothVkFromString(vk_strings)
+    return ([jac_affine_g1(p) for p in vk.IC], jac_affine_g1(vk.G1_Alpha), jac_affine_g2(vk.G2_Beta), jac_affine_g2(vk.G2_Gamma),
+            jac_affine_g2(vk.G2_Delta))
