@@ -243,6 +243,20 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    proof_verified = None
+    if args.workload == "prove" and args.instance == "setup" and not args.no_check:
+        # Product verifier (groth16.VerifyProof -> gs_groth16_verify, host side), outside the timed region, on EVERY rank:
+        # the proof of this rank's instance against the vk its device setup produced, for the right public input and a wrong one.
+        x_pub = capi.u64_to_ints(inst.w_host[1:2])[0]
+        p_last = step()
+        good = groth16.VerifyProof(inst.vk, p_last, [x_pub]) and not groth16.VerifyProof(inst.vk, p_last, [(x_pub + 1) % R])
+        if world > 1:
+            t = torch.tensor([1.0 if good else 0.0], dtype=torch.float64, device="cpu" if share else "cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            good = bool(t.item() == 1.0)
+        if not good:
+            raise SystemExit("bench.py: groth16.VerifyProof rejected the proof of the benchmarked instance (or accepted a wrong public input)")
+        proof_verified = "groth16.VerifyProof accepted each rank's proof against its device-built vk and rejected a wrong public input (%d/%d ranks)" % (world, world)
     proof_check = None
     if rank == 0 and world == 1 and args.cpu_log2n > 0 and args.workload == "prove" and args.instance == "setup" and not args.no_check:
         # Outside the timed region, part of the checker/baseline leg (the only place bench.py touches oracle/): the toxic
@@ -311,6 +325,8 @@ def main():
             pass
         if host_ms is not None:
             out["host_buffers_ms_per_step"] = host_ms
+        if proof_verified:
+            out["proof_verified"] = proof_verified
         if proof_check:
             out["proof_check"] = proof_check
         if world == 1 and args.cpu_log2n > 0:

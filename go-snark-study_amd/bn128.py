@@ -40,3 +40,27 @@ class _Group:
 
 G1 = _Group(False)
 G2 = _Group(True)
+
+
+def Pairing(p1, p2):
+    """bn128.Pairing(p1, p2) (bn128.go:179-186): the reduced optimal ate pairing as the reference's nested
+    [2][3][2] integers (gs_pairing, host side)."""
+    import numpy as np
+    out = np.zeros(48, dtype=np.uint64)
+    a, b = capi.g1_points_to_u64([p1]), capi.g2_points_to_u64([p2])
+    capi.check(capi.load_library().gs_pairing(capi.ptr64(a), capi.ptr64(b), capi.ptr64(out)))
+    v = capi.u64_to_ints(out)
+    return tuple(tuple((v[6 * i + 2 * j], v[6 * i + 2 * j + 1]) for j in range(3)) for i in range(2))
+
+
+def PairingCheck(g1_points, g2_points):
+    """prod_i e(g1_i, g2_i) == 1 with one shared final exponentiation (gs_pairing_check)."""
+    import ctypes
+    import numpy as np
+    if len(g1_points) != len(g2_points):
+        raise ValueError("PairingCheck: %d G1 points, %d G2 points" % (len(g1_points), len(g2_points)))
+    a = capi.g1_points_to_u64(g1_points) if g1_points else np.zeros((1, 12), dtype=np.uint64)
+    b = capi.g2_points_to_u64(g2_points) if g2_points else np.zeros((1, 24), dtype=np.uint64)
+    ok = ctypes.c_int(0)
+    capi.check(capi.load_library().gs_pairing_check(capi.ptr64(a), capi.ptr64(b), len(g1_points), ctypes.byref(ok)))
+    return bool(ok.value)

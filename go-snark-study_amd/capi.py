@@ -86,6 +86,10 @@ _SIGS = {
     "gs_pinocchio_prove": [Handle, u64p, ctypes.c_size_t, u64p, ctypes.c_size_t, u64p, intp],
     "gs_last_timing": [ctypes.POINTER(Timing)],
     "gs_set_window_bits": [ctypes.c_int],
+    "gs_pairing": [u64p, u64p, u64p],
+    "gs_pairing_check": [u64p, u64p, ctypes.c_size_t, intp],
+    "gs_groth16_verify": [u64p, u64p, u64p, u64p, u64p, ctypes.c_size_t, u64p, ctypes.c_size_t, u64p, u64p, u64p, intp],
+    "gs_pinocchio_verify": [u64p, u64p, u64p, u64p, u64p, u64p, u64p, u64p, ctypes.c_size_t, u64p, ctypes.c_size_t, u64p, intp, intp],
 }
 EXPORTS = sorted(list(_SIGS) + ["gs_shutdown", "gs_last_error", "gs_version"])
 

@@ -244,3 +244,22 @@ def prove_end(ticket):
     inf = (ctypes.c_int * 3)()
     capi.check(capi.load_library().gs_groth16_prove_end(ctypes.c_uint64(ticket), capi.ptr64(out), inf))
     return _proof_from_words(out, inf)
+
+
+def VerifyProof(vk, proof, publicSignals, debug=False):
+    """groth16.VerifyProof(vk, proof, publicSignals, debug) (groth16.go:281-305) -> bool.  Host side
+    (gs_groth16_verify: one 4-pair multi-pairing with a shared final exponentiation); needs no device."""
+    import ctypes
+    if len(vk.IC) < len(publicSignals) + 1:
+        raise IndexError("index out of range: %d public signals, vk.IC has %d points" % (len(publicSignals), len(vk.IC)))
+    ic = capi.g1_points_to_u64(vk.IC)
+    pub = capi.ints_to_u64([int(x) % R for x in publicSignals]) if publicSignals else np.zeros((1, 4), dtype=np.uint64)
+    g1 = capi.g1_points_to_u64([vk.G1_Alpha, proof.PiA, proof.PiC])
+    g2 = capi.g2_points_to_u64([vk.G2_Beta, vk.G2_Gamma, vk.G2_Delta, proof.PiB])
+    ok = ctypes.c_int(0)
+    capi.check(capi.load_library().gs_groth16_verify(capi.ptr64(g1[0]), capi.ptr64(g2[0]), capi.ptr64(g2[1]), capi.ptr64(g2[2]),
+                                                     capi.ptr64(ic), len(vk.IC), capi.ptr64(pub), len(publicSignals),
+                                                     capi.ptr64(g1[1]), capi.ptr64(g2[3]), capi.ptr64(g1[2]), ctypes.byref(ok)))
+    if debug:
+        print("✓ groth16 verification passed" if ok.value else "❌ groth16 verification not passed")
+    return bool(ok.value)

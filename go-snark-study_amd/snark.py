@@ -118,3 +118,36 @@ def ExportPkArray(dev_pk, name):
     if which == 2:
         return [((v[6 * i], v[6 * i + 1]), (v[6 * i + 2], v[6 * i + 3]), (v[6 * i + 4], v[6 * i + 5])) for i in range(count)]
     return [(v[3 * i], v[3 * i + 1], v[3 * i + 2]) for i in range(count)]
+
+
+_CHECKS = ("e(piA, Va) == e(piA', g2), valid knowledge commitment for A",
+           "e(Vb, piB) == e(piB', g2), valid knowledge commitment for B",
+           "e(piC, Vc) == e(piC', g2), valid knowledge commitment for C",
+           "e(Vkx+piA, piB) == e(piH, Vkz) * e(piC, g2), QAP disibility checked",
+           "e(Vkx+piA+piC, g2KbetaKgamma) * e(g1KbetaKgamma, piB) == e(piK, g2Kgamma)")
+
+
+def VerifyProof(vk, proof, publicSignals, debug=False):
+    """snark.VerifyProof(vk, proof, publicSignals, debug) (snark.go:292-368) -> bool: the five pairing equations in the
+    reference's order (gs_pinocchio_verify, host side, no device needed)."""
+    if len(vk.IC) < len(publicSignals) + 1:
+        raise IndexError("index out of range: %d public signals, vk.IC has %d points" % (len(publicSignals), len(vk.IC)))
+    ic = capi.g1_points_to_u64(vk.IC)
+    pub = capi.ints_to_u64([int(x) % R for x in publicSignals]) if publicSignals else np.zeros((1, 4), dtype=np.uint64)
+    g1 = capi.g1_points_to_u64([vk.Vkb, vk.G1Kbg])
+    g2 = capi.g2_points_to_u64([vk.Vka, vk.Vkc, vk.G2Kbg, vk.G2Kg, vk.Vkz])
+    words = np.concatenate([capi.g1_points_to_u64([proof.PiA, proof.PiAp]).reshape(-1), capi.g2_points_to_u64([proof.PiB]).reshape(-1),
+                            capi.g1_points_to_u64([proof.PiBp, proof.PiC, proof.PiCp, proof.PiH, proof.PiKp]).reshape(-1)])
+    words = np.ascontiguousarray(words, dtype=np.uint64)
+    ok, bad = ctypes.c_int(0), ctypes.c_int(0)
+    capi.check(capi.load_library().gs_pinocchio_verify(capi.ptr64(g2[0]), capi.ptr64(g1[0]), capi.ptr64(g2[1]), capi.ptr64(g1[1]),
+                                                       capi.ptr64(g2[2]), capi.ptr64(g2[3]), capi.ptr64(g2[4]), capi.ptr64(ic), len(vk.IC),
+                                                       capi.ptr64(pub), len(publicSignals), capi.ptr64(words), ctypes.byref(ok),
+                                                       ctypes.byref(bad)))
+    if debug:
+        for i, text in enumerate(_CHECKS):
+            if bad.value and i + 1 == bad.value:
+                print("❌ " + text)
+                break
+            print("✓ " + text)
+    return bool(ok.value)

@@ -22,7 +22,8 @@
  *    and cannot be reproduced by a bucket method.  Infinity is [0, 0, 0].
  *  - Every function returns 0 on success or a negative gs_status; gs_last_error() gives the
  *    message (thread-local).  Nothing falls back to a CPU path: without a usable gfx950
- *    device every compute call fails with GS_ERR_NO_DEVICE.
+ *    device every prover/setup/polynomial/MSM call fails with GS_ERR_NO_DEVICE.  (The verifier
+ *    entry points at the end are host code by design -- O(1) pairings -- and say so.)
  *  - The library copies caller buffers during the call and never retains host pointers
  *    (cgo pointer rule).  Device memory lives behind opaque handles freed by gs_free().
  *  - One context per process and device (one process per GPU); calls are serialised on an
@@ -248,6 +249,37 @@ int gs_last_timing(gs_timing* out);
 
 /* Tunables (0 = automatic): Pippenger window bits. */
 int gs_set_window_bits(int c);
+
+/* ---- verifier (host side) ---------------------------------------------------------------- */
+/* The step after the prover.  These four entry points run on the calling host thread: a proof check is
+ * O(1) work (a handful of pairings, a few thousand Fq products, latency bound), so there is nothing to offload.  They
+ * need no gs_init, never touch the device and are not a fallback for anything above; they do not take the library
+ * mutex, so a verifier thread runs beside in-flight proofs.
+ *
+ * bn128.Pairing(p1, p2) (bn128/bn128.go:179-186): the reduced optimal ate pairing MillerLoop^((q^12 - 1)/r) as the
+ * reference's [2][3][2]*big.Int, 12 x 4 words in that nesting order, standard form.  Bit-identical to the reference's
+ * value (same tower Fq2[u]/(u^2+1), Fq6 = Fq2[v]/(v^3-(9+u)), Fq12 = Fq6[w]/(w^2-v); lines differ only by a factor
+ * the final exponentiation removes).  Either point at infinity gives 1.  GS_ERR_ARG if a point is off its curve. */
+int gs_pairing(const uint64_t g1[12], const uint64_t g2[24], uint64_t out_fq12[48]);
+/* *ok = [ prod_i e(g1_i, g2_i) == 1 ]: one multi-Miller loop (shared squarings, one batched inversion per step) and
+ * ONE final exponentiation for all k pairs.  Points off the curve, or G2 points that are not of order r, give *ok = 0
+ * (the reference would compute a meaningless Fq12 value and compare it). */
+int gs_pairing_check(const uint64_t* g1 /* k x 12 */, const uint64_t* g2 /* k x 24 */, size_t k, int* ok);
+/* groth16.VerifyProof(vk, proof, publicSignals, debug) (groth16/groth16.go:281-305):
+ *   icPubl = IC[0] + sum_i publicSignals[i] * IC[i+1];   e(PiA, PiB) == e(Alpha, Beta) e(icPubl, Gamma) e(PiC, Delta)
+ * as one 4-pair product check.  *ok = 1 accept / 0 reject.  GS_ERR_SHAPE when nic < npublic + 1 (the reference panics
+ * on vk.IC[i+1] out of range). */
+int gs_groth16_verify(const uint64_t vk_g1_alpha[12], const uint64_t vk_g2_beta[24], const uint64_t vk_g2_gamma[24],
+                      const uint64_t vk_g2_delta[24], const uint64_t* vk_ic /* nic x 12 */, size_t nic,
+                      const uint64_t* public_signals /* npublic x 4 */, size_t npublic,
+                      const uint64_t pi_a[12], const uint64_t pi_b[24], const uint64_t pi_c[12], int* ok);
+/* snark.VerifyProof (snark.go:292-368): the five Pinocchio checks in the reference's order, each a product check;
+ * proof = PiA, PiAp (12 words each), PiB (24), PiBp, PiC, PiCp, PiH, PiKp (12 each) = 108 words (snark.go:59-69).
+ * *failed_check (optional) = 0, or 1..5 for the first equation that does not hold (the reference's debug prints). */
+int gs_pinocchio_verify(const uint64_t vka[24], const uint64_t vkb[12], const uint64_t vkc[24], const uint64_t g1kbg[12],
+                        const uint64_t g2kbg[24], const uint64_t g2kg[24], const uint64_t vkz[24],
+                        const uint64_t* vk_ic /* nic x 12 */, size_t nic, const uint64_t* public_signals, size_t npublic,
+                        const uint64_t* proof /* 108 words */, int* ok, int* failed_check);
 
 #if defined(__GNUC__)
 #pragma GCC visibility pop

@@ -344,6 +344,11 @@ def test_full_pipeline_proof_matches_closed_form_from_toxic_values(n):
     assert (proof.PiA[0], proof.PiA[1]) == wa
     assert (proof.PiB[0], proof.PiB[1]) == wb
     assert (proof.PiC[0], proof.PiC[1]) == wc
+    # and the verifier (groth16.go:281-305) accepts it against the device-built vk for the right public input only
+    x = capi.u64_to_ints(inst.w_host[1:2])[0]
+    assert groth16.VerifyProof(inst.vk, proof, [x]) is True
+    assert groth16.VerifyProof(inst.vk, proof, [(x + 1) % O.R]) is False
+    assert groth16.VerifyProof(inst.vk, groth16.Proof(proof.PiC, proof.PiB, proof.PiA), [x]) is False
 
 
 @pytest.mark.parametrize("shards", [1, 2, 3, 8])
@@ -534,3 +539,15 @@ def json_affine(vk_strings):
     vk = utils.GrothVkFromString(vk_strings)
     return ([jac_affine_g1(p) for p in vk.IC], jac_affine_g1(vk.G1_Alpha), jac_affine_g2(vk.G2_Beta), jac_affine_g2(vk.G2_Gamma),
             jac_affine_g2(vk.G2_Delta))
+
+
+def test_device_pinocchio_setup_prove_verify_round_trip():
+    """Pinocchio end to end on the device-built key: gs_pinocchio_setup -> gs_pinocchio_prove -> snark.VerifyProof accepts
+    for the circuit's public output 35 and rejects 34 (the reference's wasm did the same with this recipe's key)."""
+    rec = GU.load("pinocchio_x3_setup")
+    toxic = tuple(int.from_bytes(bytes((i * k + 9) & 0xff for i in range(30)), "big") % O.R for k in (3, 5, 7, 11, 13, 17, 19, 23))
+    a, b, c = _x3_csr()
+    dpk, vk = snark.GenerateTrustedSetupSparse(7, 8, 1, a, b, c, toxic)
+    proof = snark.GenerateProofs(snark.Circuit(8, 1), dpk, rec["w"], rec["px"])
+    assert snark.VerifyProof(vk, proof, [35]) is True
+    assert snark.VerifyProof(vk, proof, [34]) is False
