@@ -294,3 +294,69 @@ func PolyDiv(a, b []*big.Int, order *big.Int) (quo, rem []*big.Int, err error) {
 	}
 	return
 }
+
+// Groth16VkParts carries the reference's groth16.Vk fields (groth16/groth16.go:33-43).
+type Groth16VkParts struct {
+	IC      [][3]*big.Int
+	G1Alpha [3]*big.Int
+	G2Beta  [3][2]*big.Int
+	G2Gamma [3][2]*big.Int
+	G2Delta [3][2]*big.Int
+}
+
+// Groth16Verify is groth16.VerifyProof (groth16.go:281-305): one 4-pair product check with a shared final
+// exponentiation.  Host side (gs_groth16_verify needs no Init and no device).  The reference indexes vk.IC[i+1] for
+// every public signal and panics past the end; here that is an error.
+func Groth16Verify(vk Groth16VkParts, piA [3]*big.Int, piB [3][2]*big.Int, piC [3]*big.Int, publicSignals []*big.Int, order *big.Int) (bool, error) {
+	ic, err := G1Points(vk.IC)
+	if err != nil {
+		return false, err
+	}
+	g1, err := G1Points([][3]*big.Int{vk.G1Alpha, piA, piC})
+	if err != nil {
+		return false, err
+	}
+	g2, err := G2Points([][3][2]*big.Int{vk.G2Beta, vk.G2Gamma, vk.G2Delta, piB})
+	if err != nil {
+		return false, err
+	}
+	pub, err := Scalars(publicSignals, order)
+	if err != nil {
+		return false, err
+	}
+	if len(pub) == 0 {
+		pub = make([]uint64, 4)
+	}
+	var ok C.int
+	err = status(C.gs_groth16_verify(ptr(g1[0:]), ptr(g2[0:]), ptr(g2[24:]), ptr(g2[48:]), ptr(ic), C.size_t(len(vk.IC)),
+		ptr(pub), C.size_t(len(publicSignals)), ptr(g1[12:]), ptr(g2[72:]), ptr(g1[24:]), &ok))
+	runtime.KeepAlive(ic)
+	runtime.KeepAlive(g1)
+	runtime.KeepAlive(g2)
+	runtime.KeepAlive(pub)
+	return ok == 1, err
+}
+
+// PairingCheck reports whether prod_i e(g1[i], g2[i]) == 1 (the seam under both verifiers, bn128/bn128.go:179-186):
+// e(A, B) == e(C, D) is PairingCheck([A, -C], [B, D]).
+func PairingCheck(g1 [][3]*big.Int, g2 [][3][2]*big.Int) (bool, error) {
+	if len(g1) != len(g2) {
+		return false, errors.New("gosnark-hip: PairingCheck needs as many G1 as G2 points")
+	}
+	if len(g1) == 0 {
+		return true, nil
+	}
+	a, err := G1Points(g1)
+	if err != nil {
+		return false, err
+	}
+	b, err := G2Points(g2)
+	if err != nil {
+		return false, err
+	}
+	var ok C.int
+	err = status(C.gs_pairing_check(ptr(a), ptr(b), C.size_t(len(g1)), &ok))
+	runtime.KeepAlive(a)
+	runtime.KeepAlive(b)
+	return ok == 1, err
+}

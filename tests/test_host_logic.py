@@ -1,5 +1,7 @@
 """CPU-only checks of the host-side logic around the C ABI (no GPU, no compute calls): limb packing, CSR builders,
 the sqchain synthetic circuit of SURVEY.md 8d and the reference-shaped containers."""
+import os
+
 import numpy as np
 
 import gosnark_amd  # noqa: F401
@@ -67,3 +69,21 @@ def test_reference_shaped_containers():
     assert snark.Proof.FIELDS == ("PiA", "PiAp", "PiB", "PiBp", "PiC", "PiCp", "PiH", "PiKp")     # snark.go:59-69
     r = groth16.FqRRand()
     assert 0 <= r < O.R and r < (1 << 240)                       # 30 random bytes (fields/fq.go:116-132)
+
+
+def test_pairing_header_constants_match_their_definitions():
+    """csrc/pairing.h: the word constants equal tools/gen_constants.pairing_constants(), which also asserts that the
+    final exponentiation's addition chain is exactly (q^4 - q^2 + 1)/r (so the value equals Fq12.Exp(f, FinalExp))."""
+    import importlib.util
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("gen_constants", os.path.join(root, "tools", "gen_constants.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    want = gen.pairing_constants()
+    text = open(os.path.join(root, "go-snark-study_amd", "csrc", "pairing.h")).read()
+    for name, words in want.items():
+        m = re.search(r"static const uint64_t %s(?:\[\d+\])? = \{?([^;]*?)\}?;" % name, text)
+        assert m, name
+        got = [int(x, 16) for x in re.findall(r"0x([0-9a-fA-F]+)ULL", m.group(1))]
+        assert got == words, name
