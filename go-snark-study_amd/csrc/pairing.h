@@ -363,10 +363,32 @@ inline Fp12 f12_frob(const Fp12& f, int k) {
   auto m = [&](const Fp2& c, int i) { return f2_mul(cj ? f2_conj(c) : c, g[i]); };
   return Fp12{Fp6{m(f.a0.c0, 0), m(f.a0.c1, 2), m(f.a0.c2, 4)}, Fp6{m(f.a1.c0, 1), m(f.a1.c1, 3), m(f.a1.c2, 5)}};
 }
-inline Fp12 f12_pow_x(const Fp12& a) {               // a^x, x = 63 bits
+// Squaring of a UNITARY element (f^(q^6+1) = 1, true after the easy part of the final exponentiation) by the
+// Granger-Scott formulas: write f = A + B w + C w^2 over Fq4 = Fq2[s]/(s^2 - xi), s = w^3, with
+// A = (c0, c3), B = (c1, c4), C = (c2, c5) in the w-power coefficients; then
+//   f^2 = (3 A^2 - 2 conj(A)) + (3 s C^2 + 2 conj(B)) w + (3 B^2 - 2 conj(C)) w^2        (9 Fq2 squarings)
+inline void f4_sqr(const Fp2& x0, const Fp2& x1, Fp2& r0, Fp2& r1) {
+  Fp2 t0 = f2_sqr(x0), t1 = f2_sqr(x1);
+  r1 = f2_sub(f2_sub(f2_sqr(f2_add(x0, x1)), t0), t1);
+  r0 = f2_add(t0, f2_mul_xi(t1));
+}
+inline Fp12 f12_cyclotomic_sqr(const Fp12& f) {
+  const Fp2 &c0 = f.a0.c0, &c1 = f.a1.c0, &c2 = f.a0.c1, &c3 = f.a1.c1, &c4 = f.a0.c2, &c5 = f.a1.c2;
+  Fp2 t0, t1, u0, u1, v0, v1;
+  f4_sqr(c0, c3, t0, t1);      // A^2
+  f4_sqr(c2, c5, u0, u1);      // C^2
+  f4_sqr(c1, c4, v0, v1);      // B^2
+  auto three_minus_two = [](const Fp2& t, const Fp2& c) { Fp2 d = f2_sub(t, c); return f2_add(f2_dbl(d), t); };   // 3t - 2c
+  auto three_plus_two = [](const Fp2& t, const Fp2& c) { Fp2 d = f2_add(t, c); return f2_add(f2_dbl(d), t); };    // 3t + 2c
+  Fp2 n0 = three_minus_two(t0, c0), n3 = three_plus_two(t1, c3);
+  Fp2 n1 = three_plus_two(f2_mul_xi(u1), c1), n4 = three_minus_two(u0, c4);
+  Fp2 n2 = three_minus_two(v0, c2), n5 = three_plus_two(v1, c5);
+  return Fp12{Fp6{n0, n2, n4}, Fp6{n1, n3, n5}};
+}
+inline Fp12 f12_pow_x(const Fp12& a) {               // a^x for unitary a, x = 63 bits
   Fp12 r = a;
   for (int i = 61; i >= 0; --i) {                    // bit 62 is the top set bit of kX
-    r = f12_sqr(r);
+    r = f12_cyclotomic_sqr(r);
     if ((kX >> i) & 1) r = f12_mul(r, a);
   }
   return r;
@@ -386,18 +408,18 @@ inline Fp12 final_exponentiation(const Fp12& f) {
   Fp12 y5 = f12_conj(fx2);
   Fp12 y6 = f12_conj(f12_mul(fx3, f12_frob(fx3, 1)));
   // y0 y1^2 y2^6 y3^12 y4^18 y5^30 y6^36 by a vector addition chain
-  Fp12 t0 = f12_sqr(y6);
+  Fp12 t0 = f12_cyclotomic_sqr(y6);
   t0 = f12_mul(t0, y4);
   t0 = f12_mul(t0, y5);
   Fp12 t1 = f12_mul(y3, y5);
   t1 = f12_mul(t1, t0);
   t0 = f12_mul(t0, y2);
-  t1 = f12_sqr(t1);
+  t1 = f12_cyclotomic_sqr(t1);
   t1 = f12_mul(t1, t0);
-  t1 = f12_sqr(t1);
+  t1 = f12_cyclotomic_sqr(t1);
   t0 = f12_mul(t1, y1);
   t1 = f12_mul(t1, y0);
-  t0 = f12_sqr(t0);
+  t0 = f12_cyclotomic_sqr(t0);
   return f12_mul(t0, t1);
 }
 

@@ -244,3 +244,46 @@ def test_pipelined_msm_tickets_equal_blocking_calls():
     assert got == want
     with pytest.raises(capi.GosnarkHipError):
         capi.msm_end((987654, False))
+
+
+def test_concurrent_callers_from_several_threads_get_their_own_results():
+    """SURVEY 8b threading: the shim must be callable from several goroutines.  ctypes drops the GIL during a call, so
+    these threads really overlap on the library (its mutex serialises device work; gs_last_error is thread-local; the
+    verifier entry points take no lock at all).  Every thread must get exactly what a lone caller gets."""
+    import json
+    import os
+    import threading
+    from gosnark_amd import groth16, utils
+    n = 5000
+    bases = capi.g1_fixed_base(U.rand_scalars_u64(n, 900))
+    bases2 = capi.g2_fixed_base(U.rand_scalars_u64(257, 901))
+    scal = [U.rand_scalars_u64(n, 910 + t) for t in range(6)]
+    want1 = [capi.msm(bases, s) for s in scal]
+    want2 = [capi.msm(bases2, s[:257], g2=True) for s in scal]
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "wasm_groth_x3.json")) as f:
+        rec = json.load(f)
+    _, vk = utils.GrothSetupFromString(json.loads(rec["setup"]))
+    proof = utils.GrothProofFromString(json.loads(rec["proof"]))
+    errors, lib = [], capi.load_library()
+
+    def worker(t):
+        try:
+            for it in range(4):
+                k = (t + it) % 6
+                assert capi.msm(bases, scal[k]) == want1[k]
+                assert capi.msm(bases2, scal[k][:257], g2=True) == want2[k]
+                assert groth16.VerifyProof(vk, proof, [35]) and not groth16.VerifyProof(vk, proof, [34])
+                # a failing call on this thread leaves ITS message, not another thread's
+                h = capi.Handle(0)
+                assert lib.gs_msm_g1(capi.Handle(987654 + t), capi.ptr64(scal[k]), 0, 1, capi.ptr64(np.zeros(8, dtype=np.uint64)),
+                                     capi.ctypes.byref(capi.ctypes.c_int(0))) < 0
+                assert b"handle" in lib.gs_last_error()
+                del h
+        except Exception as e:   # noqa: BLE001
+            errors.append((t, repr(e)))
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(6)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
