@@ -105,7 +105,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log2n", type=int, default=20)
-    ap.add_argument("--workload", default="prove", choices=["prove", "prove_from_r1cs", "prove_sharded", "msm_g1", "msm_sharded"],
+    ap.add_argument("--workload", default="prove", choices=["prove", "prove_from_r1cs", "prove_sharded", "prove_pinocchio", "msm_g1", "msm_sharded"],
                     help="prove: one independent proof per GPU (weak scaling, the default the driver runs); prove_sharded: ONE proof "
                          "whose MSM term ranges are split over the ranks (strong scaling, all-gather of 5 partial points); "
                          "prove_from_r1cs: every step also rebuilds px from the resident sparse R1CS and witness (gs_r1cs_px) -- the "
@@ -171,6 +171,16 @@ def main():
         workload = ("groth16_prove_2^%d_constraints_sharded_over_all_gpus" if sharded else
                     "groth16_px_from_sparse_r1cs_then_prove_2^%d_constraints_per_gpu" if from_r1cs else
                     "groth16_prove_2^%d_constraints_per_gpu") % args.log2n
+    elif args.workload == "prove_pinocchio":
+        # snark.GenerateProofs (snark.go:254-289): 6 G1 MSMs over w sharing one plan + 1 G2 MSM + px / Z + 1 G1 MSM over h
+        from gosnark_amd import snark
+        inst = synth.sqchain_pinocchio_instance(n, seed)
+        pk = inst.device_pk()
+
+        def step():
+            return snark.prove_resident(pk, inst.w, inst.px)
+        units_per_step = n
+        workload = "pinocchio_prove_2^%d_constraints_per_gpu" % args.log2n
     else:
         from gosnark_amd import parallel
         nterms = n
@@ -257,6 +267,17 @@ def main():
         if not good:
             raise SystemExit("bench.py: groth16.VerifyProof rejected the proof of the benchmarked instance (or accepted a wrong public input)")
         proof_verified = "groth16.VerifyProof accepted each rank's proof against its device-built vk and rejected a wrong public input (%d/%d ranks)" % (world, world)
+    if args.workload == "prove_pinocchio" and not args.no_check:
+        from gosnark_amd import snark as _snark
+        p_last = step()
+        good = _snark.VerifyProof(inst.vk, p_last, inst.public) and not _snark.VerifyProof(inst.vk, p_last, [(inst.public[0] + 1) % R])
+        if world > 1:
+            t = torch.tensor([1.0 if good else 0.0], dtype=torch.float64, device="cpu" if share else "cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            good = bool(t.item() == 1.0)
+        if not good:
+            raise SystemExit("bench.py: snark.VerifyProof rejected the proof of the benchmarked instance (or accepted a wrong public input)")
+        proof_verified = "snark.VerifyProof (five pairing equations) accepted each rank's proof against its device-built vk and rejected a wrong public input (%d/%d ranks)" % (world, world)
     proof_check = None
     if rank == 0 and world == 1 and args.cpu_log2n > 0 and args.workload == "prove" and args.instance == "setup" and not args.no_check:
         # Outside the timed region, part of the checker/baseline leg (the only place bench.py touches oracle/): the toxic
@@ -283,18 +304,23 @@ def main():
         avg_launch_s = tm_acc["acc_g1_ms"] / launches * 1e-3
         bytes_per_launch = G1_TERM_BYTES * tm_acc["acc_g1_terms"] / launches
         achieved = bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+        is_pin = args.workload == "prove_pinocchio"
+        is_prove = args.workload == "prove" or is_pin
+        # SURVEY 8d bytes per constraint: Groth16 544 n (4 G1 + 1 G2 MSM) + 128 n (H stage); Pinocchio 7 G1 + 1 G2 + H = 960 n
+        step_bytes = (960 * n if is_pin else 672 * n) if is_prove else G1_TERM_BYTES * n
         out = {
-            "metric": "Groth16 constraints/sec (prove) at 2^%d R1CS" % args.log2n if args.workload == "prove" else "G1-MSM terms/sec",
+            "metric": ("Pinocchio constraints/sec (prove) at 2^%d R1CS" % args.log2n if is_pin else
+                       "Groth16 constraints/sec (prove) at 2^%d R1CS" % args.log2n if is_prove else "G1-MSM terms/sec"),
             "value": value,
-            "unit": "constraints/s" if args.workload == "prove" else "terms/s",
+            "unit": "constraints/s" if is_prove else "terms/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None,
             "dtype": "u32 (9x29-bit Montgomery limbs of the 254-bit BN128 fields)", "data": "synthetic",
             "config": {"workload": workload, "proofs_in_flight": args.pipeline if (pipelined or msm_pipe) else 1, "constraints": n, "variables": n + 1, "npublic": 1,
                        "parallelism": ("one proof, MSM term ranges sharded over the ranks, all-gather of 5 partial points" if sharded else
-                                       "independent proofs, one per GPU") if args.workload == "prove" else args.workload,
-                       "instance": inst.describe() if args.workload == "prove" else "uniform random scalars, bases k_i*G"},
+                                       "independent proofs, one per GPU") if is_prove else args.workload,
+                       "instance": inst.describe() if is_prove else "uniform random scalars, bases k_i*G"},
             "roofline": {"bound": "hbm", "kernel": "k_bucket_accumulate<G1>", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "avg_launch_ms": avg_launch_s * 1e3, "algorithmic_bytes_per_launch": bytes_per_launch,
@@ -309,10 +335,10 @@ def main():
                               "frac": ((tm_acc["acc_g1_terms"] / launches) * 16 * 1467 / avg_launch_s / 1e12 / 31.5) if avg_launch_s > 0 else 0.0,
                               "note": "16 windows at c = 16 (n >= 2^16); other instructions take the remaining issue slots, "
                                       "profiles/r01c_pmc_sq_accumulate_g1.txt"},
-            "roofline_whole_step": {"bound": "hbm", "algorithmic_bytes_per_step": (672 * n if args.workload == "prove" else G1_TERM_BYTES * n),
-                                    "achieved": (672 * n if args.workload == "prove" else G1_TERM_BYTES * n) / (elapsed / args.steps) / 1e9,
+            "roofline_whole_step": {"bound": "hbm", "algorithmic_bytes_per_step": step_bytes,
+                                    "achieved": step_bytes / (elapsed / args.steps) / 1e9,
                                     "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                    "note": "SURVEY 8d: 672 B per constraint per proof (544 n MSM + 128 n H stage), wall time per step"},
+                                    "note": "SURVEY 8d: Groth16 672 B per constraint per proof (544 n MSM + 128 n H stage), Pinocchio 960 B; wall time per step"},
             "device_ms_per_step": {k: tm_acc[k] / args.steps for k in ("total_ms", "poly_ms", "plan_ms", "accumulate_ms", "reduce_ms", "acc_g1_ms", "acc_g2_ms")},
         }
         try:

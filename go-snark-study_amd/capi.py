@@ -84,6 +84,7 @@ _SIGS = {
     "gs_pinocchio_pk_create": [Handle, Handle, Handle, Handle, Handle, Handle, Handle, Handle, u64p,
                                ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, ctypes.POINTER(Handle)],
     "gs_pinocchio_prove": [Handle, u64p, ctypes.c_size_t, u64p, ctypes.c_size_t, u64p, intp],
+    "gs_pinocchio_prove_resident": [Handle, Handle, Handle, u64p, intp],
     "gs_last_timing": [ctypes.POINTER(Timing)],
     "gs_set_window_bits": [ctypes.c_int],
     "gs_pairing": [u64p, u64p, u64p],

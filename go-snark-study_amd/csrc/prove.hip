@@ -665,6 +665,18 @@ int gs_pinocchio_prove(gs_handle hpk, const uint64_t* w, size_t nw, const uint64
   });
 }
 
+int gs_pinocchio_prove_resident(gs_handle hpk, gs_handle hw, gs_handle hpx, uint64_t out_proof[72], int inf[8]) {
+  return guarded([&](Ctx& c) -> int {
+    PinocchioPkObj* pk = c.get<PinocchioPkObj>(hpk, Kind::PinocchioPk);
+    Scalars* w = c.get<Scalars>(hw, Kind::Scalars);
+    Scalars* px = c.get<Scalars>(hpx, Kind::Scalars);
+    if (!pk || !w || !px) return fail(GS_ERR_ARG, "gs_pinocchio_prove_resident: bad handle");
+    if (!out_proof || !inf) return fail(GS_ERR_ARG, "null argument");
+    reset_timing(c);
+    return pinocchio_prove_impl(c, pk, DevScalars{w->buf.as<uint32_t>(), w->n}, DevScalars{px->buf.as<uint32_t>(), px->n}, out_proof, inf);
+  });
+}
+
 // PolynomialField.LagrangeInterpolation (r1csqap.go:150-158): n values at the nodes 1..n -> n coefficients.
 int gs_lagrange_interpolation(const uint64_t* values, size_t n, uint64_t* coeffs) {
   return guarded([&](Ctx& c) -> int {

@@ -52,6 +52,10 @@ def GenerateProofs(circuit, pk, w, px):
     inf = (ctypes.c_int * 8)()
     capi.check(capi.load_library().gs_pinocchio_prove(capi.Handle(dev.h), capi.ptr64(wa), len(w), capi.ptr64(pa), len(px),
                                                       capi.ptr64(out), inf))
+    return _proof_from_words(out, inf)
+
+
+def _proof_from_words(out, inf):
     v = capi.u64_to_ints(out)
     res, pos = {}, 0
     for i, k in enumerate(Proof.FIELDS):
@@ -62,6 +66,15 @@ def GenerateProofs(circuit, pk, w, px):
             res[k] = (0, 0, 0) if inf[i] else (v[pos], v[pos + 1], 1)
             pos += 2
     return Proof(**res)
+
+
+def prove_resident(dev_pk, w_handle, px_handle):
+    """snark.GenerateProofs with the key, w and px already resident in HBM (gs_pinocchio_prove_resident)."""
+    out = np.zeros(72, dtype=np.uint64)
+    inf = (ctypes.c_int * 8)()
+    capi.check(capi.load_library().gs_pinocchio_prove_resident(capi.Handle(dev_pk.h), capi.Handle(w_handle.h), capi.Handle(px_handle.h),
+                                                               capi.ptr64(out), inf))
+    return _proof_from_words(out, inf)
 
 
 class Vk:

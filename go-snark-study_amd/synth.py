@@ -234,3 +234,35 @@ class SqchainSetupInstance:
 
 def sqchain_setup_instance(n, seed, extra_vars=0):
     return SqchainSetupInstance(n, seed, extra_vars)
+
+
+class SqchainPinocchioInstance:
+    """The same sqchain(n) system under the Pinocchio protocol (snark.go): device trusted setup from 8 seeded toxic values
+    (gs_pinocchio_setup = snark.go:98-251), resident witness and px.  The verifier (snark.VerifyProof, five pairing
+    equations) is the end-to-end check at sizes the reference cannot replay."""
+
+    def __init__(self, n, seed, extra_vars=0):
+        from . import r1csqap, snark
+        self.n, self.m, self.seed = n, n + 1 + extra_vars, seed
+        self.toxic = field_elems(8, seed + 30)
+        x = field_elems(1, seed + 10)[0]
+        a, b, c, w = sqchain_r1cs(n, x, extra_vars)
+        self.r1cs = (a, b, c)
+        self.w_host = w
+        self._pk, self.vk = snark.GenerateTrustedSetupSparse(n, self.m, 1, a, b, c, self.toxic)
+        _, _, _, self.px_host = r1csqap.ComputePx(a, b, c, w, self.m)
+        self.w = capi.scalars_upload(self.w_host)
+        self.px = capi.scalars_upload(self.px_host)
+        self.public = capi.u64_to_ints(self.w_host[1:2])
+
+    def device_pk(self):
+        return self._pk
+
+    def describe(self):
+        return ("sqchain(n) R1CS, satisfying witness, Pinocchio trusted setup on the device from seeded toxic values "
+                "(gs_pinocchio_setup), px from the sparse system; seed 0x%X" % self.seed)
+
+
+def sqchain_pinocchio_instance(n, seed, extra_vars=0):
+    return SqchainPinocchioInstance(n, seed, extra_vars)
+

@@ -229,6 +229,8 @@ int gs_pinocchio_pk_create(gs_handle a, gs_handle ap, gs_handle b_g2, gs_handle 
  * PiCp | PiH | PiKp = 7*8 + 16 = 72 words; inf[8] in that order. */
 int gs_pinocchio_prove(gs_handle pk, const uint64_t* w, size_t nw, const uint64_t* px, size_t npx,
                        uint64_t out_proof[72], int inf[8]);
+/* Same with w and px already resident (gs_scalars_upload); what bench.py --workload prove_pinocchio times. */
+int gs_pinocchio_prove_resident(gs_handle pk, gs_handle w, gs_handle px, uint64_t out_proof[72], int inf[8]);
 
 /* ---- timing of the last prove / msm call (device time, HIP events on the library stream) --- */
 typedef struct {

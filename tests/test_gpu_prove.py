@@ -551,3 +551,24 @@ def test_device_pinocchio_setup_prove_verify_round_trip():
     proof = snark.GenerateProofs(snark.Circuit(8, 1), dpk, rec["w"], rec["px"])
     assert snark.VerifyProof(vk, proof, [35]) is True
     assert snark.VerifyProof(vk, proof, [34]) is False
+
+
+@pytest.mark.parametrize("n", [16, 1000, 1 << 16])
+def test_pinocchio_full_pipeline_proofs_verify_at_sizes_the_reference_cannot_replay(n):
+    """snark.GenerateProofs at scale: sparse R1CS -> gs_pinocchio_setup -> px on the device -> the eight proof
+    elements -> snark.VerifyProof (five pairing equations against the device-built vk) accepts for the instance's public
+    input and fails the divisibility equation for any other; a corrupted element fails its own knowledge-commitment check."""
+    from gosnark_amd import synth
+    inst = synth.sqchain_pinocchio_instance(n, 0xFACE00 + n % 251)
+    proof = snark.prove_resident(inst.device_pk(), inst.w, inst.px)
+    assert snark.VerifyProof(inst.vk, proof, inst.public) is True
+    assert snark.VerifyProof(inst.vk, proof, [(inst.public[0] + 1) % O.R]) is False
+    fields = {k: getattr(proof, k) for k in snark.Proof.FIELDS}
+    fields["PiH"] = O.G1.Double(fields["PiH"])
+    assert snark.VerifyProof(inst.vk, snark.Proof(**fields), inst.public) is False
+    # host-buffer entry point gives the same eight elements
+    w = capi.u64_to_ints(inst.w_host)
+    px = capi.u64_to_ints(inst.px_host)
+    if n <= 1000:
+        again = snark.GenerateProofs(snark.Circuit(inst.m, 1), inst.device_pk(), w, px)
+        assert all(getattr(again, k) == getattr(proof, k) for k in snark.Proof.FIELDS)
