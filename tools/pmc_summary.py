@@ -13,5 +13,6 @@ for r in rows:
     acc[k][0] += 1
     acc[k][1] += float(r["Counter_Value"])
 print("kernel, dispatches, avg %s per dispatch (counter units: KB)" % want)
-for k, (n, v) in sorted(acc.items(), key=lambda kv: -kv[1][1])[:14]:
+top = int(sys.argv[3]) if len(sys.argv) > 3 else 14
+for k, (n, v) in sorted(acc.items(), key=lambda kv: -kv[1][1])[:top]:
     print("%-60s %5d %14.1f" % (k[:60], n, v / n))
