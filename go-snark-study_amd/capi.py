@@ -148,6 +148,13 @@ def init(device=None):
     _INIT_DEVICE = device
 
 
+def shutdown():
+    """gs_shutdown: every handle dies, streams / pinned buffers / workspaces are returned; init() may be called again."""
+    global _INIT_DEVICE
+    load_library().gs_shutdown()
+    _INIT_DEVICE = None
+
+
 def version():
     return load_library().gs_version().decode()
 

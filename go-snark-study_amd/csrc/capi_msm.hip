@@ -264,9 +264,29 @@ void gs_shutdown(void) {
   Ctx& c = ctx();
   std::lock_guard<std::mutex> lk(c.mu);
   if (!c.ready) return;
-  (void)hipStreamSynchronize(c.stream);
+  (void)hipSetDevice(c.device);
+  (void)hipDeviceSynchronize();
   for (auto& f : c.inflight) f.reset();
   c.objs.clear();
+  // give back what gs_init created and the grow-only workspaces; caches keyed by size (plans, twiddles, trees) stay valid
+  // for a later gs_init on the same device
+  for (auto& a : c.aux_stream) {
+    if (a && a != c.main_stream) (void)hipStreamDestroy(a);
+    a = nullptr;
+  }
+  if (c.main_stream) (void)hipStreamDestroy(c.main_stream);
+  c.main_stream = nullptr;
+  c.stream = nullptr;
+  for (auto& pp : c.pinned) {
+    if (pp) (void)hipHostFree(pp);
+    pp = nullptr;
+  }
+  c.ws_hist.release(); c.ws_offsets.release(); c.ws_cursor.release(); c.ws_entries.release(); c.ws_tiles.release(); c.ws_total.release();
+  for (auto& b : c.ws_buckets) b.release();
+  for (auto& b : c.ws_chunks) b.release();
+  for (auto& b : c.ws_partials) b.release();
+  for (auto& b : c.ws_out) b.release();
+  c.ws_misc.release();
   c.ready = false;
 }
 
