@@ -154,6 +154,12 @@ def main():
         inst = (synth.sqchain_setup_instance(n, seed) if args.instance == "setup" else
                 synth.sqchain_instance(n, seed) if args.instance == "sqchain" else synth.random_instance(n, seed))
         pk = inst.device_pk()
+        if sharded and world > 1:
+            # each GPU keeps only its 1/world slice of every proving-key array (and builds window tables for that
+            # slice only); the full key this rank built for the setup is released
+            full = pk
+            pk = groth16.ShardPk(full, rank, world)
+            full.handle.free()
         r_, s_ = synth.field_elems(2, seed ^ 0xABCDEF, R)
 
         dev_r1cs = None

@@ -73,6 +73,9 @@ _SIGS = {
     "gs_groth16_prove_resident": [Handle, Handle, Handle, u64p, u64p, u64p, intp],
     "gs_groth16_prove_begin": [Handle, Handle, Handle, u64p, u64p, u64p],
     "gs_groth16_prove_end": [ctypes.c_uint64, u64p, intp],
+    "gs_groth16_pk_create_shard": [Handle, Handle, Handle, Handle, Handle, u64p, u64p, u64p, u64p, u64p, u64p, ctypes.c_size_t,
+                                   ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, ctypes.POINTER(Handle)],
+    "gs_groth16_pk_shard": [Handle, ctypes.c_size_t, ctypes.c_size_t, ctypes.POINTER(Handle)],
     "gs_groth16_prove_partials": [Handle, Handle, Handle, ctypes.c_size_t, ctypes.c_size_t, u64p, intp],
     "gs_groth16_finish": [Handle, u64p, intp, u64p, u64p, u64p, intp],
     "gs_groth16_setup": [ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, u32p, u32p, u64p, u32p, u32p, u64p, u32p, u32p, u64p,

@@ -5,6 +5,8 @@
 
 #include "msm.h"
 #include "point_io.h"
+#include "poly.h"
+#include "prove.h"
 #include "runtime.h"
 
 using namespace gs;
@@ -304,6 +306,7 @@ int gs_len(gs_handle h, size_t* out) {
     switch (it->second->kind) {
       case Kind::G1Bases: case Kind::G2Bases: *out = static_cast<Bases*>(it->second.get())->n; return GS_OK;
       case Kind::Scalars: *out = static_cast<Scalars*>(it->second.get())->n; return GS_OK;
+      case Kind::GrothPk: *out = static_cast<GrothPkObj*>(it->second.get())->n_w; return GS_OK;       // entries of At held (a slice holds fewer than NVars)
       default: return fail(GS_ERR_ARG, "gs_len: handle has no length");
     }
   });

@@ -7,7 +7,11 @@
 namespace gs {
 
 struct GrothPkObj : Object {      // groth16.Pk (groth16/groth16.go:15-32), resident
-  size_t nvars = 0, npublic = 0, nz = 0, nptd = 0;
+  size_t nvars = 0, npublic = 0, nz = 0, nptd = 0;   // global counts (nptd = len(PowersTauDelta))
+  // Key slices (multi-GPU, SURVEY 8e "each GPU holds 1/8 of every pk array"): a key created by gs_groth16_pk_create_shard /
+  // gs_groth16_pk_shard holds only the term ranges of shard `shard_index` of `shard_count`: At / BACGamma / BACDelta entries
+  // [w_lo, w_lo + n_w) and PowersTauDelta entries [h_lo, h_lo + n_h).  A full key has shard_count = 1, n_w = nvars, n_h = nptd.
+  size_t shard_index = 0, shard_count = 1, w_lo = 0, n_w = 0, h_lo = 0, n_h = 0;
   DevBuf at, bacgamma1, bacdelta, ptd;     // packed affine G1 (owned copies)
   DevBuf bacgamma2;                        // packed affine G2
   BaseTable t_at, t_bacgamma1, t_bacdelta, t_ptd, t_bacgamma2;   // their window tables (built on the first prove)

@@ -121,17 +121,25 @@ int groth16_enqueue(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, const S
   const size_t nh = quotient_len(px.n, pk->nz);
   if (nh > pk->nptd)
     return fail(GS_ERR_SHAPE, "len(hx) = len(px) - len(Z) + 1 = %zu exceeds len(PowersTauDelta) = %zu (groth16.go:269-271)", nh, pk->nptd);
+  const bool sliced = pk->shard_count > 1;
+  if (sliced && (shard.index != pk->shard_index || shard.count != pk->shard_count))
+    return fail(GS_ERR_ARG, "this key holds shard %zu of %zu of the term ranges only: call gs_groth16_prove_partials with that shard "
+                "(asked for %zu of %zu)", pk->shard_index, pk->shard_count, shard.index, shard.count);
   size_t wlo, whi, hlo, hhi;
   shard_range(w.n, shard, wlo, whi);
-  shard_range(nh, shard, hlo, hhi);
+  if (sliced) {                     // a slice's PowersTauDelta range was fixed at key creation (split of len(PTD), clipped to len(hx))
+    hlo = std::min(pk->h_lo, nh);
+    hhi = std::min(pk->h_lo + pk->n_h, nh);
+  } else shard_range(nh, shard, hlo, hhi);
+  const size_t wbase = wlo - pk->w_lo, hbase = hlo - std::min(pk->h_lo, hlo);      // offsets into the arrays this key holds
   {
     const int cw = choose_window_bits((uint32_t)std::max<size_t>(whi - wlo, 1), c.window_bits);
     const int ch = choose_window_bits((uint32_t)std::max<size_t>(hhi - hlo, 1), c.window_bits);
-    ensure_table_g1(c, pk->t_at, pk->at.as<uint32_t>(), pk->nvars, cw);
-    ensure_table_g1(c, pk->t_bacgamma1, pk->bacgamma1.as<uint32_t>(), pk->nvars, cw);
-    ensure_table_g1(c, pk->t_bacdelta, pk->bacdelta.as<uint32_t>(), pk->nvars, cw);
-    ensure_table_g2(c, pk->t_bacgamma2, pk->bacgamma2.as<uint32_t>(), pk->nvars, cw);
-    ensure_table_g1(c, pk->t_ptd, pk->ptd.as<uint32_t>(), pk->nptd, ch);
+    ensure_table_g1(c, pk->t_at, pk->at.as<uint32_t>(), pk->n_w, cw);
+    ensure_table_g1(c, pk->t_bacgamma1, pk->bacgamma1.as<uint32_t>(), pk->n_w, cw);
+    ensure_table_g1(c, pk->t_bacdelta, pk->bacdelta.as<uint32_t>(), pk->n_w, cw);
+    ensure_table_g2(c, pk->t_bacgamma2, pk->bacgamma2.as<uint32_t>(), pk->n_w, cw);
+    ensure_table_g1(c, pk->t_ptd, pk->ptd.as<uint32_t>(), pk->n_h, ch);
     g_hx.ensure(std::max<size_t>(nh, 1) * 32);
   }
   st.pk = pk;
@@ -161,8 +169,8 @@ int groth16_enqueue(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, const S
     // loop from NPublic+1 (:248-250) equals a full-range MSM sharing w's plan.
     // G2 first: its accumulation (2 waves/SIMD, 256 VGPRs) is the one a foreign wave hurts most, and its long
     // combine/reduce tail then hides behind the G1 accumulations.
-    msm_enqueue_g2(c, plan_w, {MsmBase{&pk->t_bacgamma2, wlo}}, ws + 4, pin + 1, st.pend_g2w, c.aux_stream[0]);
-    msm_enqueue_g1(c, plan_w, {MsmBase{&pk->t_at, wlo}, MsmBase{&pk->t_bacgamma1, wlo}, MsmBase{&pk->t_bacdelta, wlo}}, ws + 0, pin + 0,
+    msm_enqueue_g2(c, plan_w, {MsmBase{&pk->t_bacgamma2, wbase}}, ws + 4, pin + 1, st.pend_g2w, c.aux_stream[0]);
+    msm_enqueue_g1(c, plan_w, {MsmBase{&pk->t_at, wbase}, MsmBase{&pk->t_bacgamma1, wbase}, MsmBase{&pk->t_bacdelta, wbase}}, ws + 0, pin + 0,
                    st.pend_g1w, c.aux_stream[2]);
   }
   {                                                              // aux 1 again: (late upload of px,) H(x), plan(h)
@@ -186,7 +194,7 @@ int groth16_enqueue(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, const S
     GS_HIP(hipStreamWaitEvent(c.stream, st.planh, 0));
     // a lone proof finishes soonest with the last tail right behind its accumulation; in a pipeline that tail must not sit
     // in front of the next proof's accumulations
-    msm_enqueue_g1(c, plan_h, {MsmBase{&pk->t_ptd, hlo}}, ws + 3, pin + 2, st.pend_h, pipelined ? c.aux_stream[2] : nullptr);   // :269-271
+    msm_enqueue_g1(c, plan_h, {MsmBase{&pk->t_ptd, hbase}}, ws + 3, pin + 2, st.pend_h, pipelined ? c.aux_stream[2] : nullptr);   // :269-271
   }
   st.total->stop();
   GS_HIP(hipEventRecord(st.done_main, c.main_stream));
@@ -449,39 +457,104 @@ int gs_poly_eval(const uint64_t* v, size_t n, const uint64_t x[4], uint64_t out[
 }
 
 // ---- Groth16 ----------------------------------------------------------------------------------------------
+// Shared builder of full keys and key slices: copies [lo, lo + n) of each source array (device, packed affine).
+struct PkSrc { const DevBuf* buf; size_t lo; };
+static void copy_slice(Ctx& c, const PkSrc& s, size_t n, size_t words, DevBuf& dst) {
+  dst.alloc(std::max<size_t>(n, 1) * words * 4);
+  if (n) GS_HIP(hipMemcpyAsync(dst.p, static_cast<const char*>(s.buf->p) + s.lo * words * 4, n * words * 4, hipMemcpyDeviceToDevice, c.stream));
+}
+static void groth_pk_fill(Ctx& c, GrothPkObj& pk, PkSrc at, PkSrc b1, PkSrc b2, PkSrc cd, PkSrc pt) {
+  copy_slice(c, at, pk.n_w, kG1Aff, pk.at);
+  copy_slice(c, b1, pk.n_w, kG1Aff, pk.bacgamma1);
+  copy_slice(c, cd, pk.n_w, kG1Aff, pk.bacdelta);
+  copy_slice(c, pt, pk.n_h, kG1Aff, pk.ptd);
+  copy_slice(c, b2, pk.n_w, kG2Aff, pk.bacgamma2);
+  // groth16.go:177-180 / :248: the C sum runs over i > NPublic; global entries [0, NPublic] of BACDelta become infinity
+  const size_t zero_hi = std::min(pk.npublic + 1, pk.w_lo + pk.n_w);
+  if (zero_hi > pk.w_lo) force_infinity(c, pk.bacdelta, zero_hi - pk.w_lo, kG1Aff);
+}
+static void set_shard(GrothPkObj& pk, size_t index, size_t count) {
+  Shard sh; sh.index = index; sh.count = count;
+  size_t lo, hi;
+  pk.shard_index = index; pk.shard_count = count;
+  shard_range(pk.nvars, sh, lo, hi);
+  pk.w_lo = lo; pk.n_w = hi - lo;
+  shard_range(pk.nptd, sh, lo, hi);
+  pk.h_lo = lo; pk.n_h = hi - lo;
+}
+
+static int groth_pk_create_impl(Ctx& c, gs_handle g1_at, gs_handle g1_bacgamma, gs_handle g2_bacgamma, gs_handle bacdelta, gs_handle ptd,
+                                const uint64_t g1_alpha[12], const uint64_t g1_beta[12], const uint64_t g1_delta[12],
+                                const uint64_t g2_beta[24], const uint64_t g2_delta[24], const uint64_t* z, size_t nz,
+                                size_t nvars, size_t npublic, size_t nptd_total, size_t shard_index, size_t shard_count, gs_handle* out) {
+  Bases* at = c.get<Bases>(g1_at, Kind::G1Bases);
+  Bases* b1 = c.get<Bases>(g1_bacgamma, Kind::G1Bases);
+  Bases* b2 = c.get<Bases>(g2_bacgamma, Kind::G2Bases);
+  Bases* cd = c.get<Bases>(bacdelta, Kind::G1Bases);
+  Bases* pt = c.get<Bases>(ptd, Kind::G1Bases);
+  if (!at || !b1 || !b2 || !cd || !pt) return fail(GS_ERR_ARG, "gs_groth16_pk_create: bad base handle");
+  if (!g1_alpha || !g1_beta || !g1_delta || !g2_beta || !g2_delta || !z || !out || nz == 0) return fail(GS_ERR_ARG, "null argument");
+  if (shard_count == 0 || shard_index >= shard_count) return fail(GS_ERR_ARG, "gs_groth16_pk_create_shard: bad shard %zu of %zu", shard_index, shard_count);
+  if (npublic + 1 > nvars) return fail(GS_ERR_SHAPE, "NPublic + 1 > NVars");
+  bool lead_zero = true;
+  for (int i = 0; i < 4; ++i) lead_zero = lead_zero && z[4 * (nz - 1) + i] == 0;
+  if (lead_zero) return fail(GS_ERR_ARG, "leading coefficient of Z is zero");
+  auto pk = std::make_unique<GrothPkObj>();
+  pk->nvars = nvars; pk->npublic = npublic; pk->nz = nz; pk->nptd = shard_count == 1 ? pt->n : nptd_total;
+  set_shard(*pk, shard_index, shard_count);
+  if (at->n != pk->n_w || b1->n != pk->n_w || b2->n != pk->n_w || cd->n != pk->n_w)
+    return fail(GS_ERR_SHAPE, "At/BACGamma/BACDelta must have %zu points (NVars = %zu, shard %zu of %zu), got %zu/%zu/%zu/%zu", pk->n_w, nvars,
+                shard_index, shard_count, at->n, b1->n, b2->n, cd->n);
+  if (pt->n != pk->n_h)
+    return fail(GS_ERR_SHAPE, "PowersTauDelta must have %zu points (total %zu, shard %zu of %zu), got %zu", pk->n_h, pk->nptd, shard_index, shard_count, pt->n);
+  groth_pk_fill(c, *pk, PkSrc{&at->buf, 0}, PkSrc{&b1->buf, 0}, PkSrc{&b2->buf, 0}, PkSrc{&cd->buf, 0}, PkSrc{&pt->buf, 0});
+  pk->alpha = g1_affine_from_jacobian_std(g1_alpha);
+  pk->beta = g1_affine_from_jacobian_std(g1_beta);
+  pk->delta = g1_affine_from_jacobian_std(g1_delta);
+  pk->beta2 = g2_affine_from_jacobian_std(g2_beta);
+  pk->delta2 = g2_affine_from_jacobian_std(g2_delta);
+  const uint32_t* dz = upload_tmp(c, g_up_a, z, nz);
+  divisor_init(c, pk->z, dz, nz);
+  GS_HIP(hipStreamSynchronize(c.stream));
+  *out = c.put(std::move(pk));
+  return GS_OK;
+}
+
 int gs_groth16_pk_create(gs_handle g1_at, gs_handle g1_bacgamma, gs_handle g2_bacgamma, gs_handle bacdelta, gs_handle ptd,
                          const uint64_t g1_alpha[12], const uint64_t g1_beta[12], const uint64_t g1_delta[12],
                          const uint64_t g2_beta[24], const uint64_t g2_delta[24], const uint64_t* z, size_t nz,
                          size_t nvars, size_t npublic, gs_handle* out) {
   return guarded([&](Ctx& c) -> int {
-    Bases* at = c.get<Bases>(g1_at, Kind::G1Bases);
-    Bases* b1 = c.get<Bases>(g1_bacgamma, Kind::G1Bases);
-    Bases* b2 = c.get<Bases>(g2_bacgamma, Kind::G2Bases);
-    Bases* cd = c.get<Bases>(bacdelta, Kind::G1Bases);
-    Bases* pt = c.get<Bases>(ptd, Kind::G1Bases);
-    if (!at || !b1 || !b2 || !cd || !pt) return fail(GS_ERR_ARG, "gs_groth16_pk_create: bad base handle");
-    if (!g1_alpha || !g1_beta || !g1_delta || !g2_beta || !g2_delta || !z || !out || nz == 0) return fail(GS_ERR_ARG, "null argument");
-    if (at->n != nvars || b1->n != nvars || b2->n != nvars || cd->n != nvars)
-      return fail(GS_ERR_SHAPE, "At/BACGamma/BACDelta must have NVars = %zu points (got %zu/%zu/%zu/%zu)", nvars, at->n, b1->n, b2->n, cd->n);
-    if (npublic + 1 > nvars) return fail(GS_ERR_SHAPE, "NPublic + 1 > NVars");
-    bool lead_zero = true;
-    for (int i = 0; i < 4; ++i) lead_zero = lead_zero && z[4 * (nz - 1) + i] == 0;
-    if (lead_zero) return fail(GS_ERR_ARG, "leading coefficient of Z is zero");
+    return groth_pk_create_impl(c, g1_at, g1_bacgamma, g2_bacgamma, bacdelta, ptd, g1_alpha, g1_beta, g1_delta, g2_beta, g2_delta, z, nz,
+                                nvars, npublic, 0, 0, 1, out);
+  });
+}
+
+int gs_groth16_pk_create_shard(gs_handle g1_at, gs_handle g1_bacgamma, gs_handle g2_bacgamma, gs_handle bacdelta, gs_handle ptd,
+                               const uint64_t g1_alpha[12], const uint64_t g1_beta[12], const uint64_t g1_delta[12],
+                               const uint64_t g2_beta[24], const uint64_t g2_delta[24], const uint64_t* z, size_t nz,
+                               size_t nvars, size_t npublic, size_t nptd_total, size_t shard_index, size_t shard_count, gs_handle* out) {
+  return guarded([&](Ctx& c) -> int {
+    return groth_pk_create_impl(c, g1_at, g1_bacgamma, g2_bacgamma, bacdelta, ptd, g1_alpha, g1_beta, g1_delta, g2_beta, g2_delta, z, nz,
+                                nvars, npublic, nptd_total, shard_index, shard_count, out);
+  });
+}
+
+// A slice of a resident full key (device-to-device copies): what each rank keeps when the full key was built or loaded
+// locally; the caller then frees the full key.
+int gs_groth16_pk_shard(gs_handle hfull, size_t shard_index, size_t shard_count, gs_handle* out) {
+  return guarded([&](Ctx& c) -> int {
+    GrothPkObj* full = c.get<GrothPkObj>(hfull, Kind::GrothPk);
+    if (!full || !out) return fail(GS_ERR_ARG, "gs_groth16_pk_shard: bad proving-key handle or null output");
+    if (full->shard_count != 1) return fail(GS_ERR_ARG, "gs_groth16_pk_shard: the source key is itself a slice");
+    if (shard_count == 0 || shard_index >= shard_count) return fail(GS_ERR_ARG, "gs_groth16_pk_shard: bad shard %zu of %zu", shard_index, shard_count);
     auto pk = std::make_unique<GrothPkObj>();
-    pk->nvars = nvars; pk->npublic = npublic; pk->nz = nz; pk->nptd = pt->n;
-    copy_points(c, at, kG1Aff, pk->at);
-    copy_points(c, b1, kG1Aff, pk->bacgamma1);
-    copy_points(c, cd, kG1Aff, pk->bacdelta);
-    copy_points(c, pt, kG1Aff, pk->ptd);
-    copy_points(c, b2, kG2Aff, pk->bacgamma2);
-    force_infinity(c, pk->bacdelta, npublic + 1, kG1Aff);          // groth16.go:177-180 / :248
-    pk->alpha = g1_affine_from_jacobian_std(g1_alpha);
-    pk->beta = g1_affine_from_jacobian_std(g1_beta);
-    pk->delta = g1_affine_from_jacobian_std(g1_delta);
-    pk->beta2 = g2_affine_from_jacobian_std(g2_beta);
-    pk->delta2 = g2_affine_from_jacobian_std(g2_delta);
-    const uint32_t* dz = upload_tmp(c, g_up_a, z, nz);
-    divisor_init(c, pk->z, dz, nz);
+    pk->nvars = full->nvars; pk->npublic = full->npublic; pk->nz = full->nz; pk->nptd = full->nptd;
+    set_shard(*pk, shard_index, shard_count);
+    groth_pk_fill(c, *pk, PkSrc{&full->at, pk->w_lo}, PkSrc{&full->bacgamma1, pk->w_lo}, PkSrc{&full->bacgamma2, pk->w_lo},
+                  PkSrc{&full->bacdelta, pk->w_lo}, PkSrc{&full->ptd, pk->h_lo});
+    pk->alpha = full->alpha; pk->beta = full->beta; pk->delta = full->delta; pk->beta2 = full->beta2; pk->delta2 = full->delta2;
+    divisor_init(c, pk->z, full->z.b_std.as<uint32_t>(), full->nz);
     GS_HIP(hipStreamSynchronize(c.stream));
     *out = c.put(std::move(pk));
     return GS_OK;

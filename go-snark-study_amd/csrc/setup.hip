@@ -129,7 +129,7 @@ int gs_groth16_setup(size_t n, size_t m, size_t npublic,
     scaled_powers_dev(c, T, zt_inv_delta, m - 1, pw.as<uint32_t>());            // tau^i Z(tau) / delta    :139-149
     // --- encryption: k * G batches --------------------------------------------------------------------------
     auto pk = std::make_unique<GrothPkObj>();
-    pk->nvars = m; pk->npublic = npublic; pk->nz = m - 1; pk->nptd = m - 1;
+    pk->nvars = m; pk->npublic = npublic; pk->nz = m - 1; pk->nptd = m - 1; pk->n_w = m; pk->n_h = m - 1;
     pk->at.alloc(m * 64); pk->bacgamma1.alloc(m * 64); pk->bacdelta.alloc(m * 64); pk->ptd.alloc(std::max<size_t>(m - 1, 1) * 64);
     pk->bacgamma2.alloc(m * 128);
     fixed_base_g1(c, at.as<uint32_t>(), (uint32_t)m, pk->at.as<uint32_t>());                    // Pk.G1.At        :164-165
@@ -263,7 +263,7 @@ int gs_groth16_pk_export(gs_handle hpk, int which, uint64_t* jacobian, size_t co
     GrothPkObj* pk = c.get<GrothPkObj>(hpk, Kind::GrothPk);
     if (!pk) return fail(GS_ERR_ARG, "gs_groth16_pk_export: bad proving-key handle");
     const DevBuf* src = nullptr;
-    size_t have = pk->nvars;
+    size_t have = pk->n_w;            // a key slice exports the entries it holds
     bool g2 = false;
     if (which == 5) {           // the single elements, Jacobian: G1 alpha, beta, delta (3 x 12) then G2 beta, delta (2 x 24)
       if (count != 5 || !jacobian) return fail(GS_ERR_ARG, "gs_groth16_pk_export: which = 5 exports exactly 5 points (84 u64)");
@@ -285,7 +285,7 @@ int gs_groth16_pk_export(gs_handle hpk, int which, uint64_t* jacobian, size_t co
       case 1: src = &pk->bacgamma1; break;
       case 2: src = &pk->bacgamma2; g2 = true; break;
       case 3: src = &pk->bacdelta; break;
-      case 4: src = &pk->ptd; have = pk->nptd; break;
+      case 4: src = &pk->ptd; have = pk->n_h; break;
       default: return fail(GS_ERR_ARG, "gs_groth16_pk_export: which must be 0..6");
     }
     if (count != have || (count && !jacobian)) return fail(GS_ERR_ARG, "gs_groth16_pk_export: array has %zu points, asked for %zu", have, count);

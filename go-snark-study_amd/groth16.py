@@ -130,6 +130,52 @@ def UploadPk(pk, circuit):
     return pk._dev
 
 
+def _shard_range(n, count, index):
+    q, rem = divmod(n, count)
+    lo = index * q + min(index, rem)
+    return lo, lo + q + (1 if index < rem else 0)
+
+
+def ShardPk(dev_pk, shard_index, shard_count):
+    """The slice of a resident full key that rank `shard_index` of `shard_count` needs for prove_partials / prove_sharded
+    (gs_groth16_pk_shard).  Free the full key afterwards (dev_pk.handle.free()) to keep only 1/shard_count of it in HBM."""
+    import ctypes
+    h = capi.Handle(0)
+    capi.check(capi.load_library().gs_groth16_pk_shard(capi.Handle(dev_pk.handle.h), shard_index, shard_count, ctypes.byref(h)))
+    return DevicePk(capi.DeviceHandle(h.value), dev_pk.nvars, dev_pk.npublic, None)
+
+
+def UploadPkShard(pk, circuit, shard_index, shard_count):
+    """Upload ONLY this rank's slice of a host key (gs_groth16_pk_create_shard): arrays cut with the split prove_partials uses."""
+    import ctypes
+    capi.init()
+    wlo, whi = _shard_range(circuit.NVars, shard_count, shard_index)
+    hlo, hhi = _shard_range(len(pk.PowersTauDelta), shard_count, shard_index)
+    empty1, empty2 = np.zeros((0, 12), dtype=np.uint64), np.zeros((0, 24), dtype=np.uint64)
+    up1 = lambda pts: capi.g1_upload(capi.g1_points_to_u64(pts) if pts else empty1)     # noqa: E731
+    at, b1, cd = up1(pk.G1_At[wlo:whi]), up1(pk.G1_BACGamma[wlo:whi]), up1(pk.BACDelta[wlo:whi])
+    pt = up1(pk.PowersTauDelta[hlo:hhi])
+    sl2 = pk.G2_BACGamma[wlo:whi]
+    b2 = capi.g2_upload(capi.g2_points_to_u64(sl2) if sl2 else empty2)
+    return device_pk_shard_from_handles(at, b1, b2, cd, pt, pk.G1_Alpha, pk.G1_Beta, pk.G1_Delta, pk.G2_Beta, pk.G2_Delta,
+                                        capi.ints_to_u64([z % R for z in pk.Z]), circuit.NVars, circuit.NPublic, len(pk.PowersTauDelta),
+                                        shard_index, shard_count)
+
+
+def device_pk_shard_from_handles(at, bacgamma1, bacgamma2, bacdelta, ptd, alpha, beta, delta, beta2, delta2, z_u64, nvars, npublic,
+                                 nptd_total, shard_index, shard_count):
+    import ctypes
+    h = capi.Handle(0)
+    a = capi.g1_points_to_u64([alpha, beta, delta])
+    b = capi.g2_points_to_u64([beta2, delta2])
+    z = np.ascontiguousarray(z_u64, dtype=np.uint64).reshape(-1, 4)
+    capi.check(capi.load_library().gs_groth16_pk_create_shard(
+        capi.Handle(at.h), capi.Handle(bacgamma1.h), capi.Handle(bacgamma2.h), capi.Handle(bacdelta.h), capi.Handle(ptd.h),
+        capi.ptr64(a[0]), capi.ptr64(a[1]), capi.ptr64(a[2]), capi.ptr64(b[0]), capi.ptr64(b[1]),
+        capi.ptr64(z), z.shape[0], nvars, npublic, nptd_total, shard_index, shard_count, ctypes.byref(h)))
+    return DevicePk(capi.DeviceHandle(h.value), nvars, npublic, None)
+
+
 def _proof_from_words(out, inf):
     v = capi.u64_to_ints(out)
     PiA = (0, 0, 0) if inf[0] else (v[0], v[1], 1)

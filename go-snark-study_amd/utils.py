@@ -357,15 +357,28 @@ def GrothPkFromBinary(path):
     return groth16.Circuit(nvars, npublic), pk
 
 
-def UploadGrothPkBinary(path):
-    """file -> memmap -> HBM: the arrays never become Python integers.  -> (Circuit, DevicePk)."""
+def UploadGrothPkBinary(path, shard=None):
+    """file -> memmap -> HBM: the arrays never become Python integers.  -> (Circuit, DevicePk).
+    shard = (index, count): map and upload ONLY that rank's slices of the five arrays (a key slice for
+    groth16.prove_partials / prove_sharded, gs_groth16_pk_create_shard) -- 1/count of the file is read."""
     protocol, nvars, npublic, sec = ReadBinary(path)
     if protocol != PROTO_GROTH16:
         raise ValueError("error parsing key file: not a Groth16 key")
-    up1 = lambda k: capi.g1_upload(np.ascontiguousarray(sec[k], dtype=np.uint64))     # noqa: E731
-    at, b1, cd, pt = up1("G1.At"), up1("G1.BACGamma"), up1("BACDelta"), up1("PowersTauDelta")
-    b2 = capi.g2_upload(np.ascontiguousarray(sec["G2.BACGamma"], dtype=np.uint64))
+    nptd = sec["PowersTauDelta"].shape[0]
+    if shard is None:
+        wlo, whi, hlo, hhi = 0, nvars, 0, nptd
+    else:
+        wlo, whi = groth16._shard_range(nvars, shard[1], shard[0])
+        hlo, hhi = groth16._shard_range(nptd, shard[1], shard[0])
+    up1 = lambda k, lo, hi: capi.g1_upload(np.ascontiguousarray(sec[k][lo:hi], dtype=np.uint64))     # noqa: E731
+    at, b1, cd = up1("G1.At", wlo, whi), up1("G1.BACGamma", wlo, whi), up1("BACDelta", wlo, whi)
+    pt = up1("PowersTauDelta", hlo, hhi)
+    b2 = capi.g2_upload(np.ascontiguousarray(sec["G2.BACGamma"][wlo:whi], dtype=np.uint64))
     abd, bd = _g1_tuples(sec["G1.ABD"]), _g2_tuples(sec["G2.BD"])
-    dev = groth16.device_pk_from_handles(at, b1, b2, cd, pt, abd[0], abd[1], abd[2], bd[0], bd[1],
-                                         np.ascontiguousarray(sec["Z"], dtype=np.uint64), nvars, npublic)
+    z = np.ascontiguousarray(sec["Z"], dtype=np.uint64)
+    if shard is None:
+        dev = groth16.device_pk_from_handles(at, b1, b2, cd, pt, abd[0], abd[1], abd[2], bd[0], bd[1], z, nvars, npublic)
+    else:
+        dev = groth16.device_pk_shard_from_handles(at, b1, b2, cd, pt, abd[0], abd[1], abd[2], bd[0], bd[1], z, nvars, npublic, nptd,
+                                                   shard[0], shard[1])
     return groth16.Circuit(nvars, npublic), dev

@@ -69,7 +69,7 @@ int gs_free(gs_handle h);
 int gs_g1_upload(const uint64_t* jacobian /* n x 12 */, size_t n, gs_handle* out);
 /* Same for G2 arrays, e.g. pk.G2.BACGamma (groth16.go:29), snark Pk.B (snark.go:19). */
 int gs_g2_upload(const uint64_t* jacobian /* n x 24 */, size_t n, gs_handle* out);
-/* Number of points behind a base handle (or coefficients behind a scalar handle). */
+/* Number of points behind a base handle, coefficients behind a scalar handle, or At entries a Groth16 key (slice) holds. */
 int gs_len(gs_handle h, size_t* out);
 /* Read points back as affine Jacobian triples [x, y, 1] / [0,0,0] (testing / serialisation). */
 int gs_g1_download(gs_handle bases, uint64_t* jacobian /* n x 12 */, size_t n);
@@ -178,7 +178,7 @@ int gs_groth16_prove_resident(gs_handle pk, gs_handle w, gs_handle px,
 int gs_groth16_prove_begin(gs_handle pk, gs_handle w, gs_handle px, const uint64_t r[4], const uint64_t s[4], uint64_t* ticket);
 int gs_groth16_prove_end(uint64_t ticket, uint64_t out_proof[32], int inf[3]);
 
-/* One proof over several GPUs: every rank holds the key and the resident w / px, takes shard `shard_index` of
+/* One proof over several GPUs: every rank holds the key (or just its slice of it, below) and the resident w / px, takes shard `shard_index` of
  * `shard_count` of the term ranges (contiguous, first ranges one longer when they do not divide), computes H(x) locally
  * (the polynomial stage is replicated) and returns its five raw MSM sums as affine points:
  * out_sums = At (8 words) | G1.BACGamma (8) | G2.BACGamma (16) | BACDelta (8) | PowersTauDelta.h (8); inf[5] in that order.
@@ -186,6 +186,20 @@ int gs_groth16_prove_end(uint64_t ticket, uint64_t out_proof[32], int inf[3]);
  * and call gs_groth16_finish, which applies the O(1) tail of groth16.go:253-275. */
 int gs_groth16_prove_partials(gs_handle pk, gs_handle w, gs_handle px, size_t shard_index, size_t shard_count,
                               uint64_t out_sums[48], int inf[5]);
+/* Key slices: a rank that only ever runs gs_groth16_prove_partials for shard `shard_index` of `shard_count` needs only that
+ * shard's entries of the proving key ("each GPU holds 1/8 of every pk array").  gs_groth16_pk_create_shard takes
+ * base handles that hold exactly the slices -- At / G1.BACGamma / G2.BACGamma / BACDelta entries of the contiguous split of
+ * [0, nvars), PowersTauDelta entries of the split of [0, nptd_total) (first ranges one longer when they do not divide; the
+ * same split gs_groth16_prove_partials uses) -- plus the single elements and Z, which every rank keeps.
+ * gs_groth16_pk_shard cuts such a slice out of a resident full key (then gs_free the full key).  A slice key is accepted
+ * by gs_groth16_prove_partials (with its own shard), gs_groth16_finish and gs_groth16_pk_export; every other entry point
+ * refuses it.  Window tables are built for the slice only: 1/shard_count of the key memory per GPU. */
+int gs_groth16_pk_create_shard(gs_handle g1_at, gs_handle g1_bacgamma, gs_handle g2_bacgamma, gs_handle bacdelta, gs_handle ptd,
+                               const uint64_t g1_alpha[12], const uint64_t g1_beta[12], const uint64_t g1_delta[12],
+                               const uint64_t g2_beta[24], const uint64_t g2_delta[24], const uint64_t* z, size_t nz,
+                               size_t nvars, size_t npublic, size_t nptd_total, size_t shard_index, size_t shard_count,
+                               gs_handle* out);
+int gs_groth16_pk_shard(gs_handle full_pk, size_t shard_index, size_t shard_count, gs_handle* out);
 int gs_groth16_finish(gs_handle pk, const uint64_t sums[48], const int inf_in[5], const uint64_t r[4], const uint64_t s[4],
                       uint64_t out_proof[32], int inf[3]);
 

@@ -572,3 +572,44 @@ def test_pinocchio_full_pipeline_proofs_verify_at_sizes_the_reference_cannot_rep
     if n <= 1000:
         again = snark.GenerateProofs(snark.Circuit(inst.m, 1), inst.device_pk(), w, px)
         assert all(getattr(again, k) == getattr(proof, k) for k in snark.Proof.FIELDS)
+
+
+@pytest.mark.parametrize("shards", [2, 3, 8])
+def test_sharded_prove_with_key_slices(shards, tmp_path):
+    """SURVEY 8e "each GPU holds 1/8 of every pk array": every logical rank holds ONLY its slice of the key -- cut from a
+    resident key (gs_groth16_pk_shard), uploaded from host slices (gs_groth16_pk_create_shard) or mapped from the binary
+    container -- and the proof assembled from the partial sums equals the single-device proof.  n + 1 = 4098 variables do
+    not divide by 3 or 8 (ragged ranges)."""
+    from gosnark_amd import synth, utils
+    n = (1 << 12) + 1
+    inst = synth.sqchain_setup_instance(n, 0x51CE)
+    pk = inst.device_pk()
+    r, s = synth.field_elems(2, 199)
+    want = groth16.prove_resident(pk, inst.w, inst.px, r, s)
+
+    def assemble(keys):
+        parts = [groth16.prove_partials(keys[k], inst.w, inst.px, k, shards)[0] for k in range(shards)]
+        combined = [capi.sum_affine([parts[k][i] for k in range(shards)], g2=g2) for i, g2 in enumerate(groth16.SUM_IS_G2)]
+        got = groth16.finish(keys[shards - 1], combined, r, s)
+        return (got.PiA, got.PiB, got.PiC)
+    slices = [groth16.ShardPk(pk, k, shards) for k in range(shards)]
+    assert assemble(slices) == (want.PiA, want.PiB, want.PiC)
+    # a slice holds 1/shards of the arrays, and refuses everything but its own shard
+    lens = [len(sl.handle) for sl in slices]
+    assert sum(lens) == n + 1 and max(lens) - min(lens) <= 1
+    with pytest.raises(capi.GosnarkHipError, match="holds shard"):
+        groth16.prove_resident(slices[0], inst.w, inst.px, r, s)
+    with pytest.raises(capi.GosnarkHipError, match="holds shard"):
+        groth16.prove_partials(slices[0], inst.w, inst.px, 1, shards)
+    with pytest.raises(capi.GosnarkHipError, match="itself a slice"):
+        groth16.ShardPk(slices[0], 0, 2)
+    # the same through the binary container: each rank maps only its slices of the file
+    path = str(tmp_path / "key.gskey")
+    utils.GrothSetupToBinary(path, groth16.Circuit(n + 1, 1), pk, inst.vk)
+    mapped = [utils.UploadGrothPkBinary(path, shard=(k, shards))[1] for k in range(shards)]
+    assert assemble(mapped) == (want.PiA, want.PiB, want.PiC)
+    if shards == 2:      # and from host integers (groth16.UploadPkShard)
+        circ, hpk = utils.GrothPkFromBinary(path)
+        host = [groth16.UploadPkShard(hpk, circ, k, shards) for k in range(shards)]
+        assert assemble(host) == (want.PiA, want.PiB, want.PiC)
+        assert groth16.VerifyProof(inst.vk, groth16.Proof(*assemble(host)), capi.u64_to_ints(inst.w_host[1:2])) is True
