@@ -87,3 +87,18 @@ def test_pairing_header_constants_match_their_definitions():
         assert m, name
         got = [int(x, 16) for x in re.findall(r"0x([0-9a-fA-F]+)ULL", m.group(1))]
         assert got == words, name
+
+
+def test_shard_split_is_the_same_everywhere():
+    """The contiguous split (first n % N ranges one longer) is written three times: parallel.shard_range (exchange layer),
+    groth16._shard_range (key slices, binary key files) and shard_range in csrc/prove.hip (gs_groth16_prove_partials, checked on
+    the GPU by the slice tests).  They must agree or a key slice would not match its rank's term range."""
+    from gosnark_amd import groth16, parallel
+    for n in (0, 1, 7, 8, 9, 4098, (1 << 20) + 1):
+        for world in (1, 2, 3, 8):
+            ranges = [parallel.shard_range(n, world, r) for r in range(world)]
+            assert ranges == [groth16._shard_range(n, world, r) for r in range(world)]
+            assert ranges[0][0] == 0 and ranges[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+            sizes = [hi - lo for lo, hi in ranges]
+            assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
