@@ -171,7 +171,8 @@ def main():
             if sharded:
                 return groth16.prove_sharded(pk, inst.w, inst.px, r_, s_)
             if from_r1cs:
-                dev_r1cs.ComputePxResident(inst.w, inst.px)            # overwrites the resident px in place
+                # one call: px from the resident sparse system (overwriting the resident px) behind the accumulations over w
+                return groth16.prove_from_r1cs(pk, dev_r1cs, inst.w, r_, s_, inst.px)[0]
             return groth16.prove_resident(pk, inst.w, inst.px, r_, s_)
         units_per_step = n
         workload = ("groth16_prove_2^%d_constraints_sharded_over_all_gpus" if sharded else

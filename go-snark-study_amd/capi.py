@@ -71,6 +71,7 @@ _SIGS = {
                              u64p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, ctypes.POINTER(Handle)],
     "gs_groth16_prove": [Handle, u64p, ctypes.c_size_t, u64p, ctypes.c_size_t, u64p, u64p, u64p, intp],
     "gs_groth16_prove_resident": [Handle, Handle, Handle, u64p, u64p, u64p, intp],
+    "gs_groth16_prove_r1cs": [Handle, Handle, Handle, ctypes.POINTER(Handle), u64p, u64p, u64p, intp],
     "gs_groth16_prove_begin": [Handle, Handle, Handle, u64p, u64p, u64p],
     "gs_groth16_prove_end": [ctypes.c_uint64, u64p, intp],
     "gs_groth16_pk_create_shard": [Handle, Handle, Handle, Handle, Handle, u64p, u64p, u64p, u64p, u64p, u64p, ctypes.c_size_t,

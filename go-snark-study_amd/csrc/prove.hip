@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <functional>
 #include <future>
 #include <vector>
 
@@ -27,6 +28,8 @@ struct DevScalars {            // a scalar vector used by a prove call (not owne
   size_t n;
   const uint64_t* host = nullptr;   // if set: `p` is a staging buffer that still has to be filled from here, on the stream
                                     // that consumes it (so the PCIe copy of px overlaps the accumulations over w)
+  std::function<void(Ctx&)> produce;   // if set: `p` is an output buffer this call still has to compute, on the stream that
+                                       // consumes it (px from the resident R1CS, behind the accumulations over w)
 };
 
 // hx = floor(px / Z) on the device, returned as a workspace pointer (standard form, nz-dependent length)
@@ -182,6 +185,7 @@ int groth16_enqueue(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, const S
       c.timing.h2d_ms += th.ms();
     }
     st.tpoly = std::make_shared<PhaseTimer>(c.stream);
+    if (px.produce) px.produce(c);                                             // r1csqap.go:161-210 on the sparse system
     if (nh) poly_quotient_dev(c, pk->z, px.p, px.n, g_hx.as<uint32_t>());      // groth16.go:266
     st.tpoly->stop();
     st.tplanh = std::make_shared<PhaseTimer>(c.stream);
@@ -904,6 +908,39 @@ int gs_r1cs_px(gs_handle hr1cs, gs_handle hw, gs_handle* px_inout) {
     c.timing.poly_ms = t.ms();
     c.timing.total_ms = c.timing.poly_ms;
     return GS_OK;
+  });
+}
+
+// R1CS + witness -> proof in one call: the px stage (three interpolations and a product, r1csqap.go:161-210) runs on the aux
+// stream BEHIND which H(x) waits anyway, while the main stream is already accumulating the four sums over w, which do not
+// need px.  *px_inout as in gs_r1cs_px (px stays available to the caller, as CombinePolynomials returns it).
+int gs_groth16_prove_r1cs(gs_handle hpk, gs_handle hr1cs, gs_handle hw, gs_handle* px_inout, const uint64_t r[4], const uint64_t s[4],
+                          uint64_t out_proof[32], int inf[3]) {
+  return guarded([&](Ctx& c) -> int {
+    GrothPkObj* pk = c.get<GrothPkObj>(hpk, Kind::GrothPk);
+    R1csObj* o = c.get<R1csObj>(hr1cs, Kind::R1cs);
+    Scalars* w = c.get<Scalars>(hw, Kind::Scalars);
+    if (!pk || !o || !w || !px_inout) return fail(GS_ERR_ARG, "gs_groth16_prove_r1cs: bad handle");
+    if (!r || !s || !out_proof || !inf) return fail(GS_ERR_ARG, "null argument");
+    if (w->n != o->m) return fail(GS_ERR_SHAPE, "len(w) = %zu but the system has %zu variables", w->n, o->m);
+    const size_t npx = 2 * o->n - 1;
+    Scalars* px = nullptr;
+    if (*px_inout) {
+      px = c.get<Scalars>(*px_inout, Kind::Scalars);
+      if (!px || px->n != npx) return fail(GS_ERR_ARG, "gs_groth16_prove_r1cs: the px handle does not hold 2n - 1 = %zu coefficients", npx);
+    } else {
+      auto fresh = std::make_unique<Scalars>();
+      fresh->n = npx;
+      fresh->buf.alloc(npx * 32);
+      px = fresh.get();
+      *px_inout = c.put(std::move(fresh));
+    }
+    reset_timing(c);
+    DevScalars dp{px->buf.as<uint32_t>(), npx};
+    const uint32_t* wdev = w->buf.as<uint32_t>();
+    uint32_t* pxdev = px->buf.as<uint32_t>();
+    dp.produce = [o, wdev, pxdev](Ctx& cc) { r1cs_px_dev(cc, *o, wdev, pxdev); };
+    return groth16_prove_impl(c, pk, DevScalars{wdev, w->n}, dp, r, s, out_proof, inf);
   });
 }
 

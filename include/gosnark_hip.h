@@ -170,6 +170,13 @@ int gs_groth16_prove(gs_handle pk, const uint64_t* w, size_t nw, const uint64_t*
 int gs_groth16_prove_resident(gs_handle pk, gs_handle w, gs_handle px,
                               const uint64_t r[4], const uint64_t s[4], uint64_t out_proof[32], int inf[3]);
 
+/* Sparse R1CS + witness -> proof in ONE call (CombinePolynomials r1csqap.go:191-210 on the resident sparse system, then
+ * GenerateProofs groth16.go:225-278): px is computed on the stream H(x) waits on, while the main stream already accumulates the
+ * four sums over w, which do not need px.  *px_inout as in gs_r1cs_px (0 = create; px stays available to the caller).
+ * Same proof as gs_r1cs_px followed by gs_groth16_prove_resident. */
+int gs_groth16_prove_r1cs(gs_handle pk, gs_handle r1cs, gs_handle w, gs_handle* px_inout, const uint64_t r[4], const uint64_t s[4],
+                          uint64_t out_proof[32], int inf[3]);
+
 /* Pipelined proving (inputs resident): gs_groth16_prove_begin enqueues the whole device side of one proof and returns a
  * ticket without waiting; gs_groth16_prove_end waits for THAT proof only, then runs the host tail and writes the proof
  * (same layout as gs_groth16_prove).  At most three tickets (proofs or MSMs) may be outstanding; they own disjoint workspaces, so the plan and

@@ -613,3 +613,21 @@ def test_sharded_prove_with_key_slices(shards, tmp_path):
         host = [groth16.UploadPkShard(hpk, circ, k, shards) for k in range(shards)]
         assert assemble(host) == (want.PiA, want.PiB, want.PiC)
         assert groth16.VerifyProof(inst.vk, groth16.Proof(*assemble(host)), capi.u64_to_ints(inst.w_host[1:2])) is True
+
+
+@pytest.mark.parametrize("n", [7, 1000, 1 << 14])
+def test_one_call_r1cs_to_proof_equals_the_two_step_path(n):
+    """gs_groth16_prove_r1cs == gs_r1cs_px then gs_groth16_prove_resident: same px, same proof, verifier accepts."""
+    from gosnark_amd import synth
+    inst = synth.sqchain_setup_instance(n, 0xC0DE + n % 97)
+    dev = r1csqap.DeviceR1CS(*inst.r1cs, inst.m)
+    r, s = synth.field_elems(2, 777 + n % 97)
+    px2 = dev.ComputePxResident(inst.w)
+    want = groth16.prove_resident(inst.device_pk(), inst.w, px2, r, s)
+    got, px1 = groth16.prove_from_r1cs(inst.device_pk(), dev, inst.w, r, s)
+    assert (got.PiA, got.PiB, got.PiC) == (want.PiA, want.PiB, want.PiC)
+    assert np.array_equal(capi.scalars_download(px1), capi.scalars_download(px2))
+    assert np.array_equal(capi.scalars_download(px1), np.asarray(inst.px_host, dtype=np.uint64).reshape(-1, 4))
+    again, px1b = groth16.prove_from_r1cs(inst.device_pk(), dev, inst.w, r, s, px1)       # overwrite in place
+    assert px1b is px1 and (again.PiA, again.PiB, again.PiC) == (want.PiA, want.PiB, want.PiC)
+    assert groth16.VerifyProof(inst.vk, got, capi.u64_to_ints(inst.w_host[1:2])) is True
