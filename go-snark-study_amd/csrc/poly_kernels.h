@@ -341,18 +341,58 @@ __global__ void __launch_bounds__(256) k_interp_leaves(const uint32_t* __restric
   store_fr(out_wide + (size_t)(2 * i) * 8, v);
   store_fr(out_wide + (size_t)(2 * i + 1) * 8, fe_zero<ModR, 2>());
 }
+constexpr uint32_t kSpmvLongRow = 512;
 // sparse matrix (CSR, values in standard form) times a Montgomery-form vector: out[row] = sum_k val[k] * x[col[k]] (standard)
 __global__ void __launch_bounds__(256) k_spmv(const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ col, const uint32_t* __restrict__ val,
                                                const uint32_t* __restrict__ x_mont, uint32_t nrows, uint32_t ncols, uint32_t* __restrict__ out) {
   const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= nrows) return;
+  const uint32_t lo = rowptr[r], hi = rowptr[r + 1];
+  if (hi - lo > kSpmvLongRow) return;                  // k_spmv_long owns this row (one thread must not walk 10^6 entries)
   Fr2 acc = fe_zero<ModR, 2>();
-  for (uint32_t k = rowptr[r]; k < rowptr[r + 1]; ++k) {
+  for (uint32_t k = lo; k < hi; ++k) {
     const uint32_t cidx = col[k];
     if (cidx >= ncols) continue;                       // validated on the host; never trust an index on the device
     acc = reduce2(add(acc, mul(load_fr(val + (size_t)k * 8), load_fr(x_mont + (size_t)cidx * 8))));
   }
   store_fr(out + (size_t)r * 8, acc);
+}
+// Rows longer than kSpmvLongRow: one workgroup per such row (the "one" variable of an R1CS sits in ~n constraints, and the
+// trusted setup multiplies by the transposed system, where it is a row).  Blocks stride over all rows and skip the short ones.
+__global__ void __launch_bounds__(256) k_spmv_long(const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ col, const uint32_t* __restrict__ val,
+                                                    const uint32_t* __restrict__ x_mont, uint32_t nrows, uint32_t ncols, uint32_t* __restrict__ out) {
+  __shared__ uint32_t sh[NL * 256];
+  for (uint32_t r = blockIdx.x; r < nrows; r += gridDim.x) {
+    const uint32_t lo = rowptr[r], hi = rowptr[r + 1];
+    if (hi - lo <= kSpmvLongRow) continue;             // uniform across the block
+    Fr2 acc = fe_zero<ModR, 2>();
+    for (uint32_t k = lo + threadIdx.x; k < hi; k += 256) {
+      const uint32_t cidx = col[k];
+      if (cidx >= ncols) continue;
+      acc = reduce2(add(acc, mul(load_fr(val + (size_t)k * 8), load_fr(x_mont + (size_t)cidx * 8))));
+    }
+#pragma unroll
+    for (int l = 0; l < NL; ++l) sh[l * 256 + threadIdx.x] = acc.l[l];
+    __syncthreads();
+    for (uint32_t stride = 128; stride > 0; stride >>= 1) {
+      if (threadIdx.x < stride) {
+        Fr2 a, b;
+#pragma unroll
+        for (int l = 0; l < NL; ++l) { a.l[l] = sh[l * 256 + threadIdx.x]; b.l[l] = sh[l * 256 + threadIdx.x + stride]; }
+        const Fr2 t = reduce2(add(a, b));
+#pragma unroll
+        for (int l = 0; l < NL; ++l) sh[l * 256 + threadIdx.x] = t.l[l];
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      Fr2 t;
+#pragma unroll
+      for (int l = 0; l < NL; ++l) t.l[l] = sh[l * 256];
+      store_fr(out + (size_t)r * 8, t);
+    }
+    __syncthreads();
+  }
 }
 
 // ---- trusted setup helpers (groth16.go:94-222 on a sparse R1CS) ---------------------------------------------------
