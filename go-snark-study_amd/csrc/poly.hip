@@ -404,9 +404,13 @@ void fr_falling_product_words(const uint64_t x[4], size_t count, uint64_t out[4]
 void spmv_dev(Ctx& c, const uint32_t* rowptr, const uint32_t* col, const uint32_t* val_std, const uint32_t* x_mont, size_t nrows, size_t ncols,
               uint32_t* out_std) {
   if (nrows) {
-    hipLaunchKernelGGL(k_spmv, grid1(nrows), dim3(256), 0, c.stream, rowptr, col, val_std, x_mont, (uint32_t)nrows, (uint32_t)ncols, out_std);
-    const uint32_t blocks = (uint32_t)std::min<size_t>(nrows, 2048);
-    hipLaunchKernelGGL(k_spmv_long, dim3(blocks), dim3(256), 0, c.stream, rowptr, col, val_std, x_mont, (uint32_t)nrows, (uint32_t)ncols, out_std);
+    static DevBuf long_rows;                 // [count | row indices]: filled by k_spmv, consumed by k_spmv_long (stream order)
+    long_rows.ensure((1 + kSpmvLongCap) * 4);
+    GS_HIP(hipMemsetAsync(long_rows.p, 0, 4, c.stream));
+    hipLaunchKernelGGL(k_spmv, grid1(nrows), dim3(256), 0, c.stream, rowptr, col, val_std, x_mont, (uint32_t)nrows, (uint32_t)ncols, out_std,
+                       long_rows.as<uint32_t>());
+    hipLaunchKernelGGL(k_spmv_long, dim3(64), dim3(256), 0, c.stream, rowptr, col, val_std, x_mont, (uint32_t)ncols, out_std,
+                       long_rows.as<uint32_t>());
   }
   GS_HIP(hipGetLastError());
 }

@@ -341,14 +341,18 @@ __global__ void __launch_bounds__(256) k_interp_leaves(const uint32_t* __restric
   store_fr(out_wide + (size_t)(2 * i) * 8, v);
   store_fr(out_wide + (size_t)(2 * i + 1) * 8, fe_zero<ModR, 2>());
 }
-constexpr uint32_t kSpmvLongRow = 512;
+constexpr uint32_t kSpmvLongRow = 512, kSpmvLongCap = 4096;
 // sparse matrix (CSR, values in standard form) times a Montgomery-form vector: out[row] = sum_k val[k] * x[col[k]] (standard)
 __global__ void __launch_bounds__(256) k_spmv(const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ col, const uint32_t* __restrict__ val,
-                                               const uint32_t* __restrict__ x_mont, uint32_t nrows, uint32_t ncols, uint32_t* __restrict__ out) {
+                                               const uint32_t* __restrict__ x_mont, uint32_t nrows, uint32_t ncols, uint32_t* __restrict__ out,
+                                               uint32_t* __restrict__ long_rows /* [0] = count, then up to kSpmvLongCap row indices */) {
   const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= nrows) return;
   const uint32_t lo = rowptr[r], hi = rowptr[r + 1];
-  if (hi - lo > kSpmvLongRow) return;                  // k_spmv_long owns this row (one thread must not walk 10^6 entries)
+  if (hi - lo > kSpmvLongRow) {                        // one thread must not walk 10^6 entries: hand the row to k_spmv_long
+    const uint32_t slot = atomicAdd(long_rows, 1u);
+    if (slot < kSpmvLongCap) { long_rows[1 + slot] = r; return; }
+  }                                                    // (list full: fall through and do it here, slowly but correctly)
   Fr2 acc = fe_zero<ModR, 2>();
   for (uint32_t k = lo; k < hi; ++k) {
     const uint32_t cidx = col[k];
@@ -357,14 +361,16 @@ __global__ void __launch_bounds__(256) k_spmv(const uint32_t* __restrict__ rowpt
   }
   store_fr(out + (size_t)r * 8, acc);
 }
-// Rows longer than kSpmvLongRow: one workgroup per such row (the "one" variable of an R1CS sits in ~n constraints, and the
-// trusted setup multiplies by the transposed system, where it is a row).  Blocks stride over all rows and skip the short ones.
+// Rows longer than kSpmvLongRow, listed by k_spmv: one workgroup per row (the "one" variable of an R1CS sits in ~n
+// constraints, and the trusted setup multiplies by the transposed system, where it is a row).
 __global__ void __launch_bounds__(256) k_spmv_long(const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ col, const uint32_t* __restrict__ val,
-                                                    const uint32_t* __restrict__ x_mont, uint32_t nrows, uint32_t ncols, uint32_t* __restrict__ out) {
+                                                    const uint32_t* __restrict__ x_mont, uint32_t ncols, uint32_t* __restrict__ out,
+                                                    const uint32_t* __restrict__ long_rows) {
   __shared__ uint32_t sh[NL * 256];
-  for (uint32_t r = blockIdx.x; r < nrows; r += gridDim.x) {
+  const uint32_t count = min(long_rows[0], kSpmvLongCap);
+  for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
+    const uint32_t r = long_rows[1 + i];
     const uint32_t lo = rowptr[r], hi = rowptr[r + 1];
-    if (hi - lo <= kSpmvLongRow) continue;             // uniform across the block
     Fr2 acc = fe_zero<ModR, 2>();
     for (uint32_t k = lo + threadIdx.x; k < hi; k += 256) {
       const uint32_t cidx = col[k];
