@@ -24,6 +24,20 @@
 #include "bn128_constants.h"
 
 #define GS_HD __host__ __device__ __forceinline__
+// Column accumulation order.  Each `acc += (u64)x * y` is meant to be ONE v_mad_u64_u32 whose addend is the running sum (the
+// carry of the previous column included).  Left alone, the compiler re-associates the sum -- products into a fresh
+// accumulator for instruction-level parallelism, then a separate 64-bit add of the carry per column (17 v_lshl_add_u64 per
+// product).  A wave cannot issue dependent or independent multiply-adds faster than one per ~11 cycles anyway
+// (tools/ubench_valu.hip) and three waves share a SIMD, so that parallelism buys nothing and the adds cost issue slots.
+// GS_PIN makes the running sum opaque after every step so the chain stays a chain.
+#ifndef GS_CHAIN
+#define GS_CHAIN 0
+#endif
+#if GS_CHAIN && defined(__HIP_DEVICE_COMPILE__)
+#define GS_PIN(acc) asm("" : "+v"(acc))
+#else
+#define GS_PIN(acc) ((void)0)
+#endif
 
 namespace gs {
 
@@ -131,9 +145,9 @@ GS_HD void mont_low_column(uint64_t& acc, uint32_t (&m)[NL], int k) {
   // add the m_i * p_{k-i} terms already known, derive m_k, clear the column, shift.
 #pragma unroll
   for (int i = 0; i < NL; ++i)
-    if (i < k) acc += (uint64_t)m[i] * M::p(k - i);
+    if (i < k) { acc += (uint64_t)m[i] * M::p(k - i); GS_PIN(acc); }
   m[k] = ((uint32_t)acc * M::kPinv29) & LMASK;
-  acc += (uint64_t)m[k] * M::p(0);
+  acc += (uint64_t)m[k] * M::p(0); GS_PIN(acc);
   acc >>= LB;
 }
 
@@ -141,7 +155,7 @@ template <class M>
 GS_HD void mont_high_column(uint64_t& acc, const uint32_t (&m)[NL], int k, uint32_t& out) {
 #pragma unroll
   for (int i = 0; i < NL; ++i)
-    if (i >= k - (NL - 1)) acc += (uint64_t)m[i] * M::p(k - i);
+    if (i >= k - (NL - 1)) { acc += (uint64_t)m[i] * M::p(k - i); GS_PIN(acc); }
   out = (uint32_t)acc & LMASK;
   acc >>= LB;
 }
@@ -156,14 +170,14 @@ GS_HD Fe<M, 2> mul(const Fe<M, Ba>& a, const Fe<M, Bb>& b) {
   for (int k = 0; k < NL; ++k) {
 #pragma unroll
     for (int i = 0; i < NL; ++i)
-      if (i <= k) acc += (uint64_t)a.l[i] * b.l[k - i];
+      if (i <= k) { acc += (uint64_t)a.l[i] * b.l[k - i]; GS_PIN(acc); }
     mont_low_column<M>(acc, m, k);
   }
 #pragma unroll
   for (int k = NL; k < 2 * NL - 1; ++k) {
 #pragma unroll
     for (int i = 0; i < NL; ++i)
-      if (i >= k - (NL - 1)) acc += (uint64_t)a.l[i] * b.l[k - i];
+      if (i >= k - (NL - 1)) { acc += (uint64_t)a.l[i] * b.l[k - i]; GS_PIN(acc); }
     mont_high_column<M>(acc, m, k, r.l[k - NL]);
   }
   r.l[NL - 1] = (uint32_t)acc;
@@ -183,9 +197,9 @@ GS_HD Fe<M, 2> sqr(const Fe<M, Ba>& a) {
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
       const int j = k - i;
-      if (j >= 0 && j < NL && i < j) acc += (uint64_t)a2[i] * a.l[j];
+      if (j >= 0 && j < NL && i < j) { acc += (uint64_t)a2[i] * a.l[j]; GS_PIN(acc); }
     }
-    if ((k & 1) == 0) acc += (uint64_t)a.l[k / 2] * a.l[k / 2];
+    if ((k & 1) == 0) { acc += (uint64_t)a.l[k / 2] * a.l[k / 2]; GS_PIN(acc); }
     if (k < NL) mont_low_column<M>(acc, m, k);
     else mont_high_column<M>(acc, m, k, r.l[k - NL]);
   }
@@ -206,8 +220,8 @@ GS_HD Fe<M, 2> mul_add(const Fe<M, Ba>& a, const Fe<M, Bb>& b, const Fe<M, Bc>& 
     for (int i = 0; i < NL; ++i) {
       const int j = k - i;
       if (j >= 0 && j < NL) {
-        acc += (uint64_t)a.l[i] * b.l[j];
-        acc += (uint64_t)c.l[i] * d.l[j];
+        acc += (uint64_t)a.l[i] * b.l[j]; GS_PIN(acc);
+        acc += (uint64_t)c.l[i] * d.l[j]; GS_PIN(acc);
       }
     }
     if (k < NL) mont_low_column<M>(acc, m, k);
@@ -231,10 +245,10 @@ GS_HD Fe<M, 2> dot4(const Fe<M, Ba>& a, const Fe<M, Bb>& b, const Fe<M, Bc>& c, 
     for (int i = 0; i < NL; ++i) {
       const int j = k - i;
       if (j >= 0 && j < NL) {
-        acc += (uint64_t)a.l[i] * b.l[j];
-        acc += (uint64_t)c.l[i] * d.l[j];
-        acc += (uint64_t)e.l[i] * f.l[j];
-        acc += (uint64_t)g.l[i] * h.l[j];
+        acc += (uint64_t)a.l[i] * b.l[j]; GS_PIN(acc);
+        acc += (uint64_t)c.l[i] * d.l[j]; GS_PIN(acc);
+        acc += (uint64_t)e.l[i] * f.l[j]; GS_PIN(acc);
+        acc += (uint64_t)g.l[i] * h.l[j]; GS_PIN(acc);
       }
     }
     if (k < NL) mont_low_column<M>(acc, m, k);
