@@ -631,3 +631,83 @@ def test_one_call_r1cs_to_proof_equals_the_two_step_path(n):
     again, px1b = groth16.prove_from_r1cs(inst.device_pk(), dev, inst.w, r, s, px1)       # overwrite in place
     assert px1b is px1 and (again.PiA, again.PiB, again.PiC) == (want.PiA, want.PiB, want.PiC)
     assert groth16.VerifyProof(inst.vk, got, capi.u64_to_ints(inst.w_host[1:2])) is True
+
+
+def _random_circuit(n, npub, seed):
+    """A random satisfied R1CS in the only shape the reference supports (NVars = n + 1): variables [one, p_1..p_npub,
+    v_1..]; constraints 1..npub: p_i * one = p_i; every later constraint multiplies two random sparse combinations of
+    earlier variables into a NEW variable.  -> dense rows (dicts), witness ints."""
+    rng = random.Random(seed)
+    w = [1] + [rng.randrange(O.R) for _ in range(npub)]
+    A, B, Cc = [], [], []
+    for i in range(1, npub + 1):
+        A.append({i: 1}); B.append({0: 1}); Cc.append({i: 1})
+    while len(A) < n:
+        def combo():
+            ks = rng.sample(range(len(w)), min(len(w), rng.randint(1, 3)))
+            return {k: rng.randrange(1, O.R) for k in ks}
+        a, b = combo(), combo()
+        va = sum(c * w[k] for k, c in a.items()) % O.R
+        vb = sum(c * w[k] for k, c in b.items()) % O.R
+        w.append(va * vb % O.R)
+        A.append(a); B.append(b); Cc.append({len(w) - 1: 1})
+    assert len(w) == n + 1
+    return A, B, Cc, w
+
+
+def _dense(rows, m):
+    return [[row.get(k, 0) for k in range(m)] for row in rows]
+
+
+def test_random_circuit_with_three_public_inputs_equals_the_oracle_and_verifies():
+    """General sparse matrices and NPublic = 3 (IC accumulation over several signals, BACDelta / A / Ap zeroed for i <= 3):
+    device setup == the oracle's GenerateTrustedSetup on the dense QAP, device proof == oracle proof, and both verifiers
+    accept exactly the right public inputs."""
+    n, npub = 12, 3
+    A, B, Cc, w = _random_circuit(n, npub, 4242)
+    m = n + 1
+    csr = [r1csqap.csr_from_rows(x) for x in (A, B, Cc)]
+    rng = random.Random(5151)
+    toxic = tuple(rng.randrange(1, O.R) for _ in range(5))
+    al, be, ga, _ = O.PF.R1CSToQAP(_dense(A, m), _dense(B, m), _dense(Cc, m))
+    opk, ovk = O.groth16_GenerateTrustedSetup(m, npub, al, be, ga, toxic)
+    dpk, vk = groth16.GenerateTrustedSetupSparse(n, m, npub, *csr, toxic)
+    for name, ref in (("G1_At", opk.G1_At), ("G1_BACGamma", opk.G1_BACGamma), ("BACDelta", opk.BACDelta), ("PowersTauDelta", opk.PowersTauDelta)):
+        assert groth16.ExportPkArray(dpk, name) == [jac_affine_g1(p) for p in ref], name
+    assert vk.IC == [jac_affine_g1(p) for p in ovk.IC] and len(vk.IC) == npub + 1
+    _, _, _, px = O.PF.CombinePolynomials(w, al, be, ga)
+    r, s = rng.randrange(O.R), rng.randrange(O.R)
+    want = O.groth16_GenerateProofs(m, npub, opk, w, px, r, s)
+    got = groth16.GenerateProofsWithRS(groth16.Circuit(m, npub), dpk, w, px, r, s)
+    assert got.PiA == jac_affine_g1(want[0]) and got.PiB == jac_affine_g2(want[1]) and got.PiC == jac_affine_g1(want[2])
+    pub = w[1:1 + npub]
+    assert groth16.VerifyProof(vk, got, pub) is True
+    assert groth16.VerifyProof(vk, got, [pub[1], pub[0], pub[2]]) is False
+    assert groth16.VerifyProof(vk, got, pub[:2]) is False
+    # Pinocchio on the same system
+    ptox = tuple(rng.randrange(1, O.R) for _ in range(8))
+    ppk, pvk = snark.GenerateTrustedSetupSparse(n, m, npub, *csr, ptox)
+    pproof = snark.GenerateProofs(snark.Circuit(m, npub), ppk, w, px)
+    assert snark.VerifyProof(pvk, pproof, pub) is True
+    assert snark.VerifyProof(pvk, pproof, [pub[0], pub[1], (pub[2] + 1) % O.R]) is False
+
+
+@pytest.mark.parametrize("n,npub", [(200, 2), (1500, 5)])
+def test_random_circuits_prove_and_verify_end_to_end(n, npub):
+    A, B, Cc, w = _random_circuit(n, npub, 77 + n)
+    m = n + 1
+    csr = [r1csqap.csr_from_rows(x) for x in (A, B, Cc)]
+    rng = random.Random(99 + n)
+    dpk, vk = groth16.GenerateTrustedSetupSparse(n, m, npub, *csr, tuple(rng.randrange(1, O.R) for _ in range(5)))
+    wa = capi.ints_to_u64(w)
+    _, _, _, px = r1csqap.ComputePx(*csr, wa, m)
+    proof = groth16.prove_resident(dpk, capi.scalars_upload(wa), capi.scalars_upload(px), rng.randrange(O.R), rng.randrange(O.R))
+    pub = w[1:1 + npub]
+    assert groth16.VerifyProof(vk, proof, pub) is True
+    bad = list(pub)
+    bad[-1] = (bad[-1] + 1) % O.R
+    assert groth16.VerifyProof(vk, proof, bad) is False
+    ppk, pvk = snark.GenerateTrustedSetupSparse(n, m, npub, *csr, tuple(rng.randrange(1, O.R) for _ in range(8)))
+    pproof = snark.prove_resident(ppk, capi.scalars_upload(wa), capi.scalars_upload(px))
+    assert snark.VerifyProof(pvk, pproof, pub) is True
+    assert snark.VerifyProof(pvk, pproof, bad) is False
