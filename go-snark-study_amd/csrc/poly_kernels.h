@@ -86,6 +86,9 @@ constexpr int kNttTile = 1 << kNttTileLog;
 constexpr int kNttMaxStages = 7;
 
 constexpr int kNttEndBound = 32;
+#ifndef GS_NTT_RADIX4
+#define GS_NTT_RADIX4 0      // measured: 17.5 ms vs 16.5 ms for the 2^20 px stage with radix-4 rounds (more registers per thread, same VALU work)
+#endif
 template <int B>
 GS_HD void ntt_dif_step(const uint32_t (&la)[NL], const uint32_t (&lb)[NL], const Fe<ModR, 1>& w, bool reduce_sum, uint32_t (&o0)[NL], uint32_t (&o1)[NL]) {
   Fe<ModR, B> a, b;
@@ -162,16 +165,57 @@ __global__ void __launch_bounds__(256) k_ntt_pass(uint32_t* __restrict__ x, cons
   // Lazy reduction: LDS holds raw limbs whose VALUE bound is tracked per stage at compile time.  DIT: (a, b) -> (a + bw, a - bw)
   // with bw < 2r grows the bound by 3 per stage (2, 5, ..., 23 after 7 stages): no reduction inside a pass.  DIF: a + b doubles
   // it (2, 4, 8, 16, 32), (a - b) w resets to 2: one reduction every fourth stage.  The final store reduces below 2r.
-  for (int step = 0; step < k; ++step) {
-    const int b = kInverse ? step : k - 1 - step;          // DIF runs the stages downwards, DIT upwards
+  // twiddle of the butterfly whose lower element sits at tile row q0 (stage bit b of this pass)
+  auto twiddle_at = [&](uint32_t q0, uint32_t cc, int b) {
+    const size_t gi = base + (size_t)q0 * qstride + (size_t)cc * cstride;
     const int s = s_lo + b;
+    const uint32_t j = (uint32_t)gi & ((1u << s) - 1u);
+    return load_twiddle(tw + ((size_t)j << (tw_logn - 1 - s)) * kTwWords);
+  };
+  int step = 0;
+#if GS_NTT_RADIX4
+  // Two stages per LDS round trip: a thread owns the four rows that differ in the two stage bits (lo, lo + 1), runs both
+  // butterfly layers in registers and writes back once: half the LDS traffic and barriers of the radix-2 loop below.
+  for (; step + 1 < k; step += 2) {
+    const int lo = kInverse ? step : k - 2 - step;           // DIT walks the bits upwards, DIF downwards
+    for (uint32_t u = threadIdx.x; u < E / 4; u += 256) {
+      const uint32_t cc = u & (C - 1), qq = u >> clog;
+      const uint32_t q00 = ((qq >> lo) << (lo + 2)) | (qq & ((1u << lo) - 1u));
+      const uint32_t q01 = q00 | (1u << lo), q10 = q00 | (2u << lo), q11 = q00 | (3u << lo);
+      const uint32_t e00 = (q00 << clog) + cc, e01 = (q01 << clog) + cc, e10 = (q10 << clog) + cc, e11 = (q11 << clog) + cc;
+      uint32_t x00[NL], x01[NL], x10[NL], x11[NL], y00[NL], y01[NL], y10[NL], y11[NL];
+#pragma unroll
+      for (int l = 0; l < NL; ++l) {
+        x00[l] = sh[l * kNttTile + e00]; x01[l] = sh[l * kNttTile + e01]; x10[l] = sh[l * kNttTile + e10]; x11[l] = sh[l * kNttTile + e11];
+      }
+      if constexpr (kInverse) {
+        // layer `step` pairs along bit lo, layer `step + 1` along bit lo + 1
+        ntt_dit_butterfly(step, x00, x01, twiddle_at(q00, cc, lo), y00, y01);
+        ntt_dit_butterfly(step, x10, x11, twiddle_at(q10, cc, lo), y10, y11);
+        ntt_dit_butterfly(step + 1, y00, y10, twiddle_at(q00, cc, lo + 1), x00, x10);
+        ntt_dit_butterfly(step + 1, y01, y11, twiddle_at(q01, cc, lo + 1), x01, x11);
+      } else {
+        // layer `step` pairs along bit lo + 1, layer `step + 1` along bit lo
+        ntt_dif_butterfly(step, x00, x10, twiddle_at(q00, cc, lo + 1), y00, y10);
+        ntt_dif_butterfly(step, x01, x11, twiddle_at(q01, cc, lo + 1), y01, y11);
+        ntt_dif_butterfly(step + 1, y00, y01, twiddle_at(q00, cc, lo), x00, x01);
+        ntt_dif_butterfly(step + 1, y10, y11, twiddle_at(q10, cc, lo), x10, x11);
+      }
+#pragma unroll
+      for (int l = 0; l < NL; ++l) {
+        sh[l * kNttTile + e00] = x00[l]; sh[l * kNttTile + e01] = x01[l]; sh[l * kNttTile + e10] = x10[l]; sh[l * kNttTile + e11] = x11[l];
+      }
+    }
+    __syncthreads();
+  }
+#endif
+  for (; step < k; ++step) {
+    const int b = kInverse ? step : k - 1 - step;          // DIF runs the stages downwards, DIT upwards
     for (uint32_t u = threadIdx.x; u < E / 2; u += 256) {
       const uint32_t cc = u & (C - 1), qq = u >> clog;
       const uint32_t q0 = ((qq >> b) << (b + 1)) | (qq & ((1u << b) - 1u));
       const uint32_t e0 = (q0 << clog) + cc, e1 = e0 + ((1u << b) << clog);
-      const size_t gi = base + (size_t)q0 * qstride + (size_t)cc * cstride;
-      const uint32_t j = (uint32_t)gi & ((1u << s) - 1u);
-      const Fe<ModR, 1> w = load_twiddle(tw + ((size_t)j << (tw_logn - 1 - s)) * kTwWords);
+      const Fe<ModR, 1> w = twiddle_at(q0, cc, b);
       uint32_t la[NL], lb[NL];
 #pragma unroll
       for (int l = 0; l < NL; ++l) { la[l] = sh[l * kNttTile + e0]; lb[l] = sh[l * kNttTile + e1]; }
