@@ -83,7 +83,7 @@ static void shard_range(size_t n, const Shard& sh, size_t& lo, size_t& hi) {
 
 void groth16_tail(GrothPkObj* pk, const GrothSums& sums, const uint64_t r[4], const uint64_t s[4], uint64_t out_proof[32], int inf[3]);
 
-// One proof in flight.  Two may be outstanding (parity 0 / 1 own disjoint plan buffers, bucket workspaces and pinned result
+// One proof in flight.  Up to Ctx::kMaxInFlight may be outstanding (slots 0 / 1 / 2 own disjoint plan buffers, bucket workspaces and pinned result
 // slots), so the plan and accumulations of proof k+1 are enqueued behind proof k's last accumulation and run while proof
 // k's combine/reduce tails, its result download and its host-side tail are still in progress.
 struct GrothTailPre {             // the tail products that need no MSM result (computed while the device runs)

@@ -287,7 +287,7 @@ def prove_sharded(dev_pk, w_handle, px_handle, r, s, group=None):
 
 
 def prove_begin(dev_pk, w_handle, px_handle, r, s):
-    """Enqueue one proof (gs_groth16_prove_begin) -> ticket.  At most two may be outstanding."""
+    """Enqueue one proof (gs_groth16_prove_begin) -> ticket.  At most three may be outstanding."""
     import ctypes
     rs = capi.ints_to_u64([r % R, s % R])
     t = ctypes.c_uint64(0)
