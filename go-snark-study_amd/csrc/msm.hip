@@ -117,7 +117,23 @@ static void ensure_table(Ctx& c, BaseTable& t, const uint32_t* row0, size_t n, i
   DevBuf fresh(std::max<size_t>(n, 1) * W * aw * 4);
   const uint32_t* src = row0 ? row0 : t.rows.as<uint32_t>();
   if (!src || (!row0 && t.n != n)) throw HipError{hipErrorInvalidValue, "window table rebuild without its points", __LINE__};
-  if (n) hipLaunchKernelGGL(k_build_table<T>, grid1(n), dim3(256), 0, c.stream, src, (uint32_t)n, cbits, W, fresh.as<uint32_t>());
+  if (n) {
+    static const bool per_row = getenv("GS_TABLE_PER_ROW") != nullptr;      // the one-inversion-per-row builder, for comparison
+    if (per_row || W <= 2) {
+      hipLaunchKernelGGL(k_build_table<T>, grid1(n), dim3(256), 0, c.stream, src, (uint32_t)n, cbits, W, fresh.as<uint32_t>());
+    } else {
+      // slabs of 2^18 points: (W - 1) rows of [XYZZ | running product] raw limbs per point (<= 1.4 GiB for G2), reused per slab
+      constexpr size_t sw = PointIO<T>::kXyzzWords + PointIO<T>::kXyzzWords / 4;
+      const size_t slab = std::min<size_t>(n, (size_t)1 << 18);
+      static DevBuf scratch;
+      scratch.ensure(slab * (size_t)(W - 1) * sw * 4);
+      for (size_t first = 0; first < n; first += slab) {
+        const size_t count = std::min(slab, n - first);
+        hipLaunchKernelGGL(k_build_table_batched<T>, grid1(count), dim3(256), 0, c.stream, src, (uint32_t)n, (uint32_t)first, (uint32_t)count, cbits, W,
+                           fresh.as<uint32_t>(), scratch.as<uint32_t>());
+      }
+    }
+  }
   GS_HIP(hipGetLastError());
   GS_HIP(hipStreamSynchronize(c.stream));       // the old rows (possibly the source) are released below
   t.rows = std::move(fresh);
