@@ -280,7 +280,9 @@ template <class T>
 static void fixed_base(Ctx& c, DevBuf& table, const uint32_t* scalars, uint32_t n, uint32_t* out) {
   if (table.p == nullptr) {
     table.alloc((size_t)256 * PointIO<T>::kAffineWords * 4);
-    hipLaunchKernelGGL(k_build_pow2_table<T>, dim3(1), dim3(64), 0, c.stream, table.as<uint32_t>());
+    DevBuf chain((size_t)256 * PointIO<T>::kXyzzWords * 4);
+    hipLaunchKernelGGL(k_build_pow2_table<T>, dim3(1), dim3(256), 0, c.stream, table.as<uint32_t>(), chain.as<uint32_t>());
+    GS_HIP(hipStreamSynchronize(c.stream));       // `chain` is released here
   }
   if (n) hipLaunchKernelGGL(k_fixed_base_mul<T>, grid1(n), dim3(256), 0, c.stream, scalars, n, table.as<uint32_t>(), out);
   GS_HIP(hipGetLastError());

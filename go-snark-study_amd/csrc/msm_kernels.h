@@ -554,27 +554,34 @@ __global__ void __launch_bounds__(256) k_fixed_base_mul(const uint32_t* __restri
   PointIO<T>::store_affine(out + (size_t)i * PointIO<T>::kAffineWords, a);
 }
 
-// table[j] = 2^j * G, j < 256 (single thread; runs once per process)
+// table[j] = 2^j * G, j < 256 (once per process).  One workgroup of 256 threads: thread 0 walks the 255 doublings in XYZZ
+// (no inversion on the chain), then every thread normalises one row -- 256 inversions side by side instead of in sequence.
 template <class T>
-__global__ void k_build_pow2_table(uint32_t* __restrict__ table) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  Affine<T> g;
-  if constexpr (PointIO<T>::kAffineWords == 16) {
+__global__ void __launch_bounds__(256) k_build_pow2_table(uint32_t* __restrict__ table, uint32_t* __restrict__ chain /* 256 x kXyzzWords */) {
+  if (blockIdx.x != 0) return;
+  constexpr int pw = PointIO<T>::kXyzzWords;
+  if (threadIdx.x == 0) {
+    Affine<T> g;
+    if constexpr (PointIO<T>::kAffineWords == 16) {
 #pragma unroll
-    for (int i = 0; i < NL; ++i) { g.x.l[i] = Gen::g1x(i); g.y.l[i] = Gen::g1y(i); }
-  } else {
+      for (int i = 0; i < NL; ++i) { g.x.l[i] = Gen::g1x(i); g.y.l[i] = Gen::g1y(i); }
+    } else {
 #pragma unroll
-    for (int i = 0; i < NL; ++i) {
-      g.x.c0.l[i] = Gen::g2x0(i); g.x.c1.l[i] = Gen::g2x1(i);
-      g.y.c0.l[i] = Gen::g2y0(i); g.y.c1.l[i] = Gen::g2y1(i);
+      for (int i = 0; i < NL; ++i) {
+        g.x.c0.l[i] = Gen::g2x0(i); g.x.c1.l[i] = Gen::g2x1(i);
+        g.y.c0.l[i] = Gen::g2y0(i); g.y.c1.l[i] = Gen::g2y1(i);
+      }
+    }
+    Xyzz<T> acc = xyzz_from_affine(g);
+    for (int j = 0; j < 256; ++j) {
+      store_xyzz<T>(chain + (size_t)j * pw, acc);
+      xyzz_dbl(acc);
     }
   }
-  Xyzz<T> acc = xyzz_from_affine(g);
-  for (int j = 0; j < 256; ++j) {
-    Affine<T> a = xyzz_to_affine(acc);
-    PointIO<T>::store_affine(table + (size_t)j * PointIO<T>::kAffineWords, a);
-    xyzz_dbl(acc);
-  }
+  __threadfence_block();
+  __syncthreads();
+  const Xyzz<T> mine = load_xyzz<T>(chain + (size_t)threadIdx.x * pw);
+  PointIO<T>::store_affine(table + (size_t)threadIdx.x * PointIO<T>::kAffineWords, xyzz_to_affine(mine));
 }
 
 }  // namespace gs
