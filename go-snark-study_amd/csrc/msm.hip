@@ -279,10 +279,12 @@ void affine_to_jacobian_std_g2(Ctx& c, const uint32_t* aff, uint32_t n, uint32_t
 template <class T>
 static void fixed_base(Ctx& c, DevBuf& table, const uint32_t* scalars, uint32_t n, uint32_t* out) {
   if (table.p == nullptr) {
-    table.alloc((size_t)256 * PointIO<T>::kAffineWords * 4);
-    DevBuf chain((size_t)256 * PointIO<T>::kXyzzWords * 4);
-    hipLaunchKernelGGL(k_build_pow2_table<T>, dim3(1), dim3(256), 0, c.stream, table.as<uint32_t>(), chain.as<uint32_t>());
-    GS_HIP(hipStreamSynchronize(c.stream));       // `chain` is released here
+    // 2^j * G for j < 256, then the 32 x 256 window table d * 2^(8 w) * G that the batch kernel reads
+    table.alloc((size_t)32 * 256 * PointIO<T>::kAffineWords * 4);
+    DevBuf pow2((size_t)256 * PointIO<T>::kAffineWords * 4), chain((size_t)256 * PointIO<T>::kXyzzWords * 4);
+    hipLaunchKernelGGL(k_build_pow2_table<T>, dim3(1), dim3(256), 0, c.stream, pow2.as<uint32_t>(), chain.as<uint32_t>());
+    hipLaunchKernelGGL(k_build_fixed_window_table<T>, dim3(32), dim3(256), 0, c.stream, pow2.as<uint32_t>(), table.as<uint32_t>());
+    GS_HIP(hipStreamSynchronize(c.stream));       // `pow2` and `chain` are released here
   }
   if (n) hipLaunchKernelGGL(k_fixed_base_mul<T>, grid1(n), dim3(256), 0, c.stream, scalars, n, table.as<uint32_t>(), out);
   GS_HIP(hipGetLastError());

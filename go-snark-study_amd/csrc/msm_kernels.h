@@ -533,10 +533,12 @@ __global__ void __launch_bounds__(256) k_affine_to_jacobian_std(const uint32_t* 
   o[2 * cw] = 1u;
 }
 
-// fixed-base batch: out[i] = k_i * G.  `table` holds 2^j * G (affine, packed) for j = 0..255.
+// fixed-base batch: out[i] = k_i * G with 8-bit windows: win[w][d] = d * 2^(8 w) * G (affine, packed; d = 0 is infinity),
+// 32 windows x 256 entries = 512 KiB for G1 (cache resident): 32 mixed additions per scalar instead of one per scalar bit
+// (a wave of the bit-serial loop paid all 254, since some lane always has the bit set).
 template <class T>
 __global__ void __launch_bounds__(256) k_fixed_base_mul(const uint32_t* __restrict__ scalars, uint32_t n,
-                                                         const uint32_t* __restrict__ table, uint32_t* __restrict__ out) {
+                                                         const uint32_t* __restrict__ win, uint32_t* __restrict__ out) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint32_t k[8];
@@ -544,14 +546,26 @@ __global__ void __launch_bounds__(256) k_fixed_base_mul(const uint32_t* __restri
   for (int j = 0; j < 8; ++j) k[j] = scalars[(size_t)i * 8 + j];
   scalar_canon(k);
   Xyzz<T> acc = xyzz_inf<T>();
-  for (int bit = 0; bit < 254; ++bit) {
-    if ((k[bit >> 5] >> (bit & 31)) & 1u) {
-      Affine<T> p = PointIO<T>::load_affine(table + (size_t)bit * PointIO<T>::kAffineWords);
+  for (int w = 0; w < 32; ++w) {
+    const uint32_t d = (k[w >> 2] >> ((w & 3) * 8)) & 0xffu;
+    if (d) {
+      Affine<T> p = PointIO<T>::load_affine(win + ((size_t)w * 256 + d) * PointIO<T>::kAffineWords);
       xyzz_madd(acc, p, false);
     }
   }
   Affine<T> a = xyzz_to_affine(acc);
   PointIO<T>::store_affine(out + (size_t)i * PointIO<T>::kAffineWords, a);
+}
+// win[w][d] = d * 2^(8 w) * G from pow2[j] = 2^j * G (8192 threads, once per process)
+template <class T>
+__global__ void __launch_bounds__(256) k_build_fixed_window_table(const uint32_t* __restrict__ pow2, uint32_t* __restrict__ win) {
+  const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= 32u * 256u) return;
+  const uint32_t w = idx >> 8, d = idx & 255u;
+  Xyzz<T> acc = xyzz_inf<T>();
+  for (int j = 0; j < 8; ++j)
+    if ((d >> j) & 1u) xyzz_madd(acc, PointIO<T>::load_affine(pow2 + (size_t)(8 * w + j) * PointIO<T>::kAffineWords), false);
+  PointIO<T>::store_affine(win + (size_t)idx * PointIO<T>::kAffineWords, xyzz_to_affine(acc));
 }
 
 // table[j] = 2^j * G, j < 256 (once per process).  One workgroup of 256 threads: thread 0 walks the 255 doublings in XYZZ

@@ -128,7 +128,7 @@ struct Ctx {
   DevBuf ws_hist, ws_offsets, ws_cursor, ws_entries, ws_tiles, ws_total;
   DevBuf ws_buckets[8 * kMaxInFlight], ws_chunks[8 * kMaxInFlight], ws_partials[8 * kMaxInFlight], ws_out[8 * kMaxInFlight];   // 8 sets per ticket
   DevBuf ws_misc;
-  DevBuf g1_pow2, g2_pow2;       // 2^j * G tables (lazy)
+  DevBuf g1_pow2, g2_pow2;       // fixed-base window tables d * 2^(8 w) * G, 32 x 256 entries (lazy)
   std::vector<hipEvent_t> events;
 
   template <class O> O* get(gs_handle h, Kind k) {
