@@ -209,6 +209,7 @@ def main():
         torch.cuda.synchronize()
 
     pipelined = args.workload == "prove" and not sharded and not from_r1cs and args.pipeline >= 2
+    pin_pipe = args.workload == "prove_pinocchio" and args.pipeline >= 2
     msm_pipe = args.workload == "msm_g1" and args.pipeline >= 2
 
     def run_steps(count, on_done=None):
@@ -222,6 +223,20 @@ def main():
                         on_done()
             while tickets:
                 capi.msm_end(tickets.pop(0))
+                if on_done:
+                    on_done()
+            return
+        if pin_pipe:
+            from gosnark_amd import snark as _sn
+            tickets = []
+            for _ in range(count):
+                tickets.append(_sn.prove_begin(pk, inst.w, inst.px))
+                if len(tickets) == args.pipeline:
+                    _sn.prove_end(tickets.pop(0))
+                    if on_done:
+                        on_done()
+            while tickets:
+                _sn.prove_end(tickets.pop(0))
                 if on_done:
                     on_done()
             return
@@ -324,7 +339,7 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None,
             "dtype": "u32 (9x29-bit Montgomery limbs of the 254-bit BN128 fields)", "data": "synthetic",
-            "config": {"workload": workload, "proofs_in_flight": args.pipeline if (pipelined or msm_pipe) else 1, "constraints": n, "variables": n + 1, "npublic": 1,
+            "config": {"workload": workload, "proofs_in_flight": args.pipeline if (pipelined or msm_pipe or pin_pipe) else 1, "constraints": n, "variables": n + 1, "npublic": 1,
                        "parallelism": ("one proof, MSM term ranges sharded over the ranks, all-gather of 5 partial points" if sharded else
                                        "independent proofs, one per GPU") if is_prove else args.workload,
                        "instance": inst.describe() if is_prove else "uniform random scalars, bases k_i*G"},

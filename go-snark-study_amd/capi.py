@@ -89,6 +89,8 @@ _SIGS = {
                                ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, ctypes.POINTER(Handle)],
     "gs_pinocchio_prove": [Handle, u64p, ctypes.c_size_t, u64p, ctypes.c_size_t, u64p, intp],
     "gs_pinocchio_prove_resident": [Handle, Handle, Handle, u64p, intp],
+    "gs_pinocchio_prove_begin": [Handle, Handle, Handle, u64p],
+    "gs_pinocchio_prove_end": [ctypes.c_uint64, u64p, intp],
     "gs_last_timing": [ctypes.POINTER(Timing)],
     "gs_set_window_bits": [ctypes.c_int],
     "gs_pairing": [u64p, u64p, u64p],

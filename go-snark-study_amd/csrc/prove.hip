@@ -43,29 +43,6 @@ size_t quotient_len(size_t npx, size_t nz) { return npx >= nz ? npx - nz + 1 : 0
 //   aux 1 : H(x) = P(x)/Z(x) -> plan(h)
 // The ALU-bound accumulation kernels run back to back on one stream (they would only fight for the
 // instruction cache if overlapped), and everything latency- or bandwidth-bound runs in their shadow.
-struct Fork {
-  Ctx& c;
-  hipEvent_t start, planw, planh, done[3];
-  explicit Fork(Ctx& ctx_) : c(ctx_) {
-    GS_HIP(hipEventCreateWithFlags(&start, hipEventDisableTiming));
-    GS_HIP(hipEventCreateWithFlags(&planw, hipEventDisableTiming));
-    GS_HIP(hipEventCreateWithFlags(&planh, hipEventDisableTiming));
-    for (auto& e : done) GS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    GS_HIP(hipEventRecord(start, c.main_stream));
-    for (auto s : c.aux_stream) GS_HIP(hipStreamWaitEvent(s, start, 0));
-  }
-  void join() {           // main waits for the aux streams, host waits for main
-    for (int i = 0; i < 3; ++i) {
-      GS_HIP(hipEventRecord(done[i], c.aux_stream[i]));
-      GS_HIP(hipStreamWaitEvent(c.main_stream, done[i], 0));
-    }
-    GS_HIP(hipStreamSynchronize(c.main_stream));
-  }
-  ~Fork() {
-    (void)hipEventDestroy(start); (void)hipEventDestroy(planw); (void)hipEventDestroy(planh);
-    for (auto& e : done) (void)hipEventDestroy(e);
-  }
-};
 
 // The five raw MSM results of a proof, before the O(1) tail.
 struct GrothSums {
@@ -285,7 +262,23 @@ int groth16_prove_impl(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, cons
   return GS_OK;
 }
 
-int pinocchio_prove_impl(Ctx& c, PinocchioPkObj* pk, DevScalars w, DevScalars px, uint64_t out[72], int inf[8]) {
+// One Pinocchio proof in flight: same stream layout as a Groth16 proof (main = accumulations only).
+struct PinInFlight : InFlightBase {
+  hipEvent_t planw = nullptr, planh = nullptr, done_main = nullptr, done_aux0 = nullptr, done_aux2 = nullptr;
+  std::unique_ptr<PhaseTimer> total;
+  MsmPending pend_g1w, pend_g2w, pend_h;
+  std::shared_ptr<PhaseTimer> tpoly, tplanw, tplanh;
+  PinInFlight() {
+    for (hipEvent_t* e : {&planw, &planh, &done_main, &done_aux0, &done_aux2}) GS_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
+  }
+  ~PinInFlight() override {
+    for (hipEvent_t e : {planw, planh, done_main, done_aux0, done_aux2}) if (e) (void)hipEventDestroy(e);
+  }
+};
+
+// snark.GenerateProofs (snark.go:254-289): six G1 sums over w sharing one plan, one G2 sum over w, H(x) = px / Z, one G1 sum
+// over h.  Ticket `parity` owns plan slots 2p / 2p + 1, workspace sets 8p .. 8p + 7 and pinned slots 3p .. 3p + 2.
+int pinocchio_enqueue(Ctx& c, PinocchioPkObj* pk, DevScalars w, DevScalars px, int parity, bool wait_inputs, bool pipelined, PinInFlight& st) {
   if (w.n != pk->nvars) return fail(GS_ERR_SHAPE, "len(w) = %zu but the key has %zu variables", w.n, pk->nvars);
   const size_t nh = quotient_len(px.n, pk->nz);
   if (nh > pk->ng1t) return fail(GS_ERR_SHAPE, "len(hx) = %zu exceeds len(G1T) = %zu (snark.go:284-286)", nh, pk->ng1t);
@@ -301,50 +294,69 @@ int pinocchio_prove_impl(Ctx& c, PinocchioPkObj* pk, DevScalars w, DevScalars px
     ensure_table_g1(c, pk->t_g1t, pk->g1t.as<uint32_t>(), pk->ng1t, ch);
     g_hx.ensure(std::max<size_t>(nh, 1) * 32);
   }
-  PhaseTimer total(c.main_stream);
-  Fork fork(c);
+  st.total = std::make_unique<PhaseTimer>(c.main_stream);
+  if (wait_inputs) {
+    hipEvent_t start;
+    GS_HIP(hipEventCreateWithFlags(&start, hipEventDisableTiming));
+    GS_HIP(hipEventRecord(start, c.main_stream));
+    for (auto a : c.aux_stream) GS_HIP(hipStreamWaitEvent(a, start, 0));
+    GS_HIP(hipEventDestroy(start));
+  }
+  const int ws = 8 * parity, pin = 3 * parity;
   MsmPlan plan_w, plan_h;
-  MsmPending pend_g1w, pend_g2w, pend_h;
-  std::shared_ptr<PhaseTimer> tpoly, tplanw, tplanh;
-  {
+  {                                                              // aux 1: plan(w)
+    StreamScope sc(c, c.aux_stream[1]);
+    st.tplanw = std::make_shared<PhaseTimer>(c.stream);
+    build_plan(c, 2 * parity, w.p, (uint32_t)w.n, plan_w, {{1, true}, {6, false}});
+    st.tplanw->stop();
+    GS_HIP(hipEventRecord(st.planw, c.stream));
+  }
+  {                                                              // main: the accumulations over w, back to back
     StreamScope sc(c, c.main_stream);
-    tplanw = std::make_shared<PhaseTimer>(c.stream);
-    build_plan(c, 0, w.p, (uint32_t)w.n, plan_w, {{1, true}, {6, false}});
-    tplanw->stop();
+    GS_HIP(hipStreamWaitEvent(c.stream, st.planw, 0));
     // A and Ap run over i > NPublic only (snark.go:265-268): their first npublic+1 points were forced
     // to infinity at key creation; Bp, C, Cp, Kp and B run over all variables (:270-278).
+    msm_enqueue_g2(c, plan_w, {MsmBase{&pk->t_b2, 0}}, ws + 6, pin + 1, st.pend_g2w, c.aux_stream[0]);
     msm_enqueue_g1(c, plan_w, {MsmBase{&pk->t_a, 0}, MsmBase{&pk->t_ap, 0}, MsmBase{&pk->t_bp, 0}, MsmBase{&pk->t_c, 0},
-                               MsmBase{&pk->t_cp, 0}, MsmBase{&pk->t_kp, 0}}, 0, 0, pend_g1w, c.aux_stream[2]);
-    msm_enqueue_g2(c, plan_w, {MsmBase{&pk->t_b2, 0}}, 6, 1, pend_g2w, c.aux_stream[0]);
+                               MsmBase{&pk->t_cp, 0}, MsmBase{&pk->t_kp, 0}}, ws + 0, pin + 0, st.pend_g1w, c.aux_stream[2]);
   }
-  {
+  {                                                              // aux 1 again: H(x), plan(h)
     StreamScope sc(c, c.aux_stream[1]);
-    tpoly = std::make_shared<PhaseTimer>(c.stream);
+    st.tpoly = std::make_shared<PhaseTimer>(c.stream);
     if (nh) poly_quotient_dev(c, pk->z, px.p, px.n, g_hx.as<uint32_t>());      // snark.go:280
-    tpoly->stop();
-    tplanh = std::make_shared<PhaseTimer>(c.stream);
-    build_plan(c, 1, g_hx.as<uint32_t>(), (uint32_t)nh, plan_h, {{1, false}});
-    tplanh->stop();
-    GS_HIP(hipEventRecord(fork.planh, c.stream));
+    st.tpoly->stop();
+    st.tplanh = std::make_shared<PhaseTimer>(c.stream);
+    build_plan(c, 2 * parity + 1, g_hx.as<uint32_t>(), (uint32_t)nh, plan_h, {{1, false}});
+    st.tplanh->stop();
+    GS_HIP(hipEventRecord(st.planh, c.stream));
   }
-  {
+  {                                                              // main again: the accumulation over h
     StreamScope sc(c, c.main_stream);
-    GS_HIP(hipStreamWaitEvent(c.stream, fork.planh, 0));
-    msm_enqueue_g1(c, plan_h, {MsmBase{&pk->t_g1t, 0}}, 7, 2, pend_h);         // :284-286
+    GS_HIP(hipStreamWaitEvent(c.stream, st.planh, 0));
+    msm_enqueue_g1(c, plan_h, {MsmBase{&pk->t_g1t, 0}}, ws + 7, pin + 2, st.pend_h, pipelined ? c.aux_stream[2] : nullptr);   // :284-286
   }
-  fork.join();
-  total.stop();
+  st.total->stop();
+  GS_HIP(hipEventRecord(st.done_main, c.main_stream));
+  GS_HIP(hipEventRecord(st.done_aux0, c.aux_stream[0]));
+  GS_HIP(hipEventRecord(st.done_aux2, c.aux_stream[2]));
+  return GS_OK;
+}
+
+int pinocchio_collect(Ctx& c, PinInFlight& st, uint64_t out[72], int inf[8]) {
+  GS_HIP(hipEventSynchronize(st.done_main));
+  GS_HIP(hipEventSynchronize(st.done_aux0));
+  GS_HIP(hipEventSynchronize(st.done_aux2));
   std::vector<G1Xyzz> g1w, g1h;
   std::vector<G2Xyzz> g2w;
-  msm_book_timing(c, pend_g1w); msm_book_timing(c, pend_g2w); msm_book_timing(c, pend_h);
+  msm_book_timing(c, st.pend_g1w); msm_book_timing(c, st.pend_g2w); msm_book_timing(c, st.pend_h);
   {                                                              // the host-side pair sums of the three groups, on separate cores
-    auto f2 = std::async(std::launch::async, [&] { msm_finish_g2(c, pend_g2w, g2w); });
-    auto fh = std::async(std::launch::async, [&] { msm_finish_g1(c, pend_h, g1h); });
-    msm_finish_g1(c, pend_g1w, g1w);
+    auto f2 = std::async(std::launch::async, [&] { msm_finish_g2(c, st.pend_g2w, g2w); });
+    auto fh = std::async(std::launch::async, [&] { msm_finish_g1(c, st.pend_h, g1h); });
+    msm_finish_g1(c, st.pend_g1w, g1w);
     f2.get(); fh.get();
   }
-  c.timing.poly_ms += tpoly->ms();
-  c.timing.plan_ms += tplanw->ms() + tplanh->ms();
+  c.timing.poly_ms += st.tpoly->ms();
+  c.timing.plan_ms += st.tplanw->ms() + st.tplanh->ms();
   // output order: PiA | PiAp | PiB | PiBp | PiC | PiCp | PiH | PiKp
   inf[0] = g1_to_affine_std(g1w[0], out) ? 1 : 0;
   inf[1] = g1_to_affine_std(g1w[1], out + 8) ? 1 : 0;
@@ -354,8 +366,15 @@ int pinocchio_prove_impl(Ctx& c, PinocchioPkObj* pk, DevScalars w, DevScalars px
   inf[5] = g1_to_affine_std(g1w[4], out + 48) ? 1 : 0;
   inf[6] = g1_to_affine_std(g1h[0], out + 56) ? 1 : 0;
   inf[7] = g1_to_affine_std(g1w[5], out + 64) ? 1 : 0;
-  c.timing.total_ms += total.ms();
+  c.timing.total_ms += st.total->ms();
   return GS_OK;
+}
+
+int pinocchio_prove_impl(Ctx& c, PinocchioPkObj* pk, DevScalars w, DevScalars px, uint64_t out[72], int inf[8]) {
+  PinInFlight st;
+  const int rc = pinocchio_enqueue(c, pk, w, px, c.free_parity(), true, false, st);
+  if (rc != GS_OK) return rc;
+  return pinocchio_collect(c, st, out, inf);
 }
 
 // zero the first `count` packed points (-> infinity)
@@ -740,6 +759,39 @@ int gs_pinocchio_prove(gs_handle hpk, const uint64_t* w, size_t nw, const uint64
     DevScalars dp{upload_tmp(c, g_up_px, px, npx), npx};
     return pinocchio_prove_impl(c, pk, dw, dp, out_proof, inf);
   });
+}
+
+// Pipelined Pinocchio proving: same ticket discipline as gs_groth16_prove_begin / _end (they share the three slots).
+int gs_pinocchio_prove_begin(gs_handle hpk, gs_handle hw, gs_handle hpx, uint64_t* ticket) {
+  return guarded([&](Ctx& c) -> int {
+    PinocchioPkObj* pk = c.get<PinocchioPkObj>(hpk, Kind::PinocchioPk);
+    Scalars* w = c.get<Scalars>(hw, Kind::Scalars);
+    Scalars* px = c.get<Scalars>(hpx, Kind::Scalars);
+    if (!pk || !w || !px || !ticket) return fail(GS_ERR_ARG, "gs_pinocchio_prove_begin: bad handle or null ticket");
+    const int parity = c.free_parity();
+    if (parity < 0) return fail(GS_ERR_ARG, "gs_pinocchio_prove_begin: three operations are already outstanding; call gs_pinocchio_prove_end first");
+    auto st = std::make_unique<PinInFlight>();
+    const int rc = pinocchio_enqueue(c, pk, DevScalars{w->buf.as<uint32_t>(), w->n}, DevScalars{px->buf.as<uint32_t>(), px->n}, parity, false, true, *st);
+    if (rc != GS_OK) return rc;
+    st->ticket = c.next_ticket++;
+    *ticket = st->ticket;
+    c.inflight[parity] = std::move(st);
+    return GS_OK;
+  }, true, true);
+}
+
+int gs_pinocchio_prove_end(uint64_t ticket, uint64_t out_proof[72], int inf[8]) {
+  return guarded([&](Ctx& c) -> int {
+    if (!out_proof || !inf) return fail(GS_ERR_ARG, "null argument");
+    int parity = -1;
+    for (int p = 0; p < Ctx::kMaxInFlight; ++p) if (c.inflight[p] && c.inflight[p]->ticket == ticket) parity = p;
+    if (parity < 0) return fail(GS_ERR_ARG, "gs_pinocchio_prove_end: unknown ticket %llu", (unsigned long long)ticket);
+    if (!dynamic_cast<PinInFlight*>(c.inflight[parity].get()))
+      return fail(GS_ERR_ARG, "gs_pinocchio_prove_end: ticket %llu is not a Pinocchio proof", (unsigned long long)ticket);
+    std::unique_ptr<InFlightBase> base = std::move(c.inflight[parity]);
+    reset_timing(c);
+    return pinocchio_collect(c, static_cast<PinInFlight&>(*base), out_proof, inf);
+  }, true, true);
 }
 
 int gs_pinocchio_prove_resident(gs_handle hpk, gs_handle hw, gs_handle hpx, uint64_t out_proof[72], int inf[8]) {

@@ -77,6 +77,22 @@ def prove_resident(dev_pk, w_handle, px_handle):
     return _proof_from_words(out, inf)
 
 
+def prove_begin(dev_pk, w_handle, px_handle):
+    """Enqueue one Pinocchio proof (gs_pinocchio_prove_begin) -> ticket.  Up to three operations may be outstanding."""
+    t = ctypes.c_uint64(0)
+    capi.check(capi.load_library().gs_pinocchio_prove_begin(capi.Handle(dev_pk.h), capi.Handle(w_handle.h), capi.Handle(px_handle.h),
+                                                            ctypes.cast(ctypes.byref(t), capi.u64p)))
+    return t.value
+
+
+def prove_end(ticket):
+    """Collect the proof of a ticket (gs_pinocchio_prove_end)."""
+    out = np.zeros(72, dtype=np.uint64)
+    inf = (ctypes.c_int * 8)()
+    capi.check(capi.load_library().gs_pinocchio_prove_end(ticket, capi.ptr64(out), inf))
+    return _proof_from_words(out, inf)
+
+
 class Vk:
     """snark.Vk (snark.go:28-38): affine Jacobian tuples."""
     FIELDS = ("Vka", "Vkb", "Vkc", "G1Kbg", "G2Kbg", "G2Kg", "Vkz")

@@ -252,6 +252,10 @@ int gs_pinocchio_prove(gs_handle pk, const uint64_t* w, size_t nw, const uint64_
                        uint64_t out_proof[72], int inf[8]);
 /* Same with w and px already resident (gs_scalars_upload); what bench.py --workload prove_pinocchio times. */
 int gs_pinocchio_prove_resident(gs_handle pk, gs_handle w, gs_handle px, uint64_t out_proof[72], int inf[8]);
+/* Pipelined Pinocchio proving: same tickets as gs_groth16_prove_begin / _end (the three in-flight slots are shared between
+ * Groth16 proofs, Pinocchio proofs and MSMs). */
+int gs_pinocchio_prove_begin(gs_handle pk, gs_handle w, gs_handle px, uint64_t* ticket);
+int gs_pinocchio_prove_end(uint64_t ticket, uint64_t out_proof[72], int inf[8]);
 
 /* ---- timing of the last prove / msm call (device time, HIP events on the library stream) --- */
 typedef struct {

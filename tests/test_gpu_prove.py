@@ -711,3 +711,43 @@ def test_random_circuits_prove_and_verify_end_to_end(n, npub):
     pproof = snark.prove_resident(ppk, capi.scalars_upload(wa), capi.scalars_upload(px))
     assert snark.VerifyProof(pvk, pproof, pub) is True
     assert snark.VerifyProof(pvk, pproof, bad) is False
+
+
+def test_mixed_tickets_groth16_pinocchio_msm_share_the_three_slots():
+    """gs_groth16_prove_begin, gs_pinocchio_prove_begin and gs_msm_g1_begin draw from the same three in-flight slots; results
+    collected out of order equal the blocking calls; a fourth begin is refused; ends of the wrong kind are refused."""
+    from gosnark_amd import synth
+    n = 1 << 12
+    g = synth.sqchain_setup_instance(n, 0xA1)
+    p = synth.sqchain_pinocchio_instance(n, 0xA2)
+    r, s = synth.field_elems(2, 31)
+    want_g = groth16.prove_resident(g.device_pk(), g.w, g.px, r, s)
+    want_p = snark.prove_resident(p.device_pk(), p.w, p.px)
+    bases = capi.g1_fixed_base(U.rand_scalars_u64(3000, 41))
+    sc = capi.scalars_upload(U.rand_scalars_u64(3000, 42))
+    want_m = capi.msm_resident(bases, sc, 3000)
+    for _ in range(3):
+        tg = groth16.prove_begin(g.device_pk(), g.w, g.px, r, s)
+        tp = snark.prove_begin(p.device_pk(), p.w, p.px)
+        tm = capi.msm_begin(bases, sc, 3000)
+        with pytest.raises(capi.GosnarkHipError, match="outstanding"):
+            snark.prove_begin(p.device_pk(), p.w, p.px)
+        with pytest.raises(capi.GosnarkHipError, match="not a Pinocchio proof"):
+            snark.prove_end(tg)
+        with pytest.raises(capi.GosnarkHipError):
+            groth16.prove_end(tp)
+        assert capi.msm_end(tm) == want_m
+        got_p = snark.prove_end(tp)
+        got_g = groth16.prove_end(tg)
+        assert (got_g.PiA, got_g.PiB, got_g.PiC) == (want_g.PiA, want_g.PiB, want_g.PiC)
+        assert all(getattr(got_p, k) == getattr(want_p, k) for k in snark.Proof.FIELDS)
+    # a stream of Pinocchio proofs, three in flight
+    tickets, outs = [], []
+    for _ in range(7):
+        tickets.append(snark.prove_begin(p.device_pk(), p.w, p.px))
+        if len(tickets) == 3:
+            outs.append(snark.prove_end(tickets.pop(0)))
+    while tickets:
+        outs.append(snark.prove_end(tickets.pop(0)))
+    assert len(outs) == 7 and all(getattr(o, k) == getattr(want_p, k) for o in outs for k in snark.Proof.FIELDS)
+    assert snark.VerifyProof(p.vk, outs[-1], p.public) is True
