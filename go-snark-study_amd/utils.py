@@ -382,3 +382,63 @@ def UploadGrothPkBinary(path, shard=None):
         dev = groth16.device_pk_shard_from_handles(at, b1, b2, cd, pt, abd[0], abd[1], abd[2], bd[0], bd[1], z, nvars, npublic, nptd,
                                                    shard[0], shard[1])
     return groth16.Circuit(nvars, npublic), dev
+
+
+# ---- Pinocchio keys in the same container ---------------------------------------------------------
+_PIN_ARRAYS = (("A", 0, 12), ("Ap", 1, 12), ("B", 2, 24), ("Bp", 3, 12), ("C", 4, 12), ("Cp", 5, 12), ("Kp", 6, 12), ("G1T", 7, 12))
+
+
+def SetupToBinary(path, circuit, pk, vk=None):
+    """snark.Pk (host integers) or snark.DevicePk (resident; gs_pinocchio_pk_export 0..8) [+ snark.Vk] -> binary container.
+    Note: a resident key's A / Ap hold infinity for i <= NPublic (what the prover sums, snark.go:265)."""
+    sec = {}
+    if isinstance(pk, snark.DevicePk):
+        lib = capi.load_library()
+        for name, which, words in _PIN_ARRAYS:
+            count = pk.nvars - 1 if which == 7 else pk.nvars
+            a = np.zeros((count, words), dtype=np.uint64)
+            capi.check(lib.gs_pinocchio_pk_export(capi.Handle(pk.h), which, capi.ptr64(a), count))
+            sec[name] = a
+        z = np.zeros((pk.nvars - 1, 4), dtype=np.uint64)
+        capi.check(lib.gs_pinocchio_pk_export(capi.Handle(pk.h), 8, capi.ptr64(z), z.shape[0]))
+        sec["Z"] = z
+    else:
+        for name, _, words in _PIN_ARRAYS:
+            pts = getattr(pk, name)
+            sec[name] = capi.g2_points_to_u64(pts) if words == 24 else capi.g1_points_to_u64(pts)
+        sec["Z"] = capi.ints_to_u64([z % groth16.R for z in pk.Z])
+    if vk is not None:
+        sec["Vk.IC"] = capi.g1_points_to_u64(vk.IC)
+        sec["Vk.G1"] = capi.g1_points_to_u64([vk.Vkb, vk.G1Kbg])
+        sec["Vk.G2"] = capi.g2_points_to_u64([vk.Vka, vk.Vkc, vk.G2Kbg, vk.G2Kg, vk.Vkz])
+    WriteBinary(path, PROTO_PINOCCHIO, circuit.NVars, circuit.NPublic, sec)
+
+
+def SetupFromBinary(path):
+    """-> (Circuit, snark.Pk as host integers, snark.Vk or None)."""
+    protocol, nvars, npublic, sec = ReadBinary(path)
+    if protocol != PROTO_PINOCCHIO:
+        raise ValueError("error parsing key file: not a Pinocchio key")
+    pk = snark.Pk(B=_g2_tuples(sec["B"]), Z=capi.u64_to_ints(sec["Z"]), **{k: _g1_tuples(sec[k]) for k in _PIN_G1})
+    vk = None
+    if "Vk.IC" in sec:
+        g1, g2 = _g1_tuples(sec["Vk.G1"]), _g2_tuples(sec["Vk.G2"])
+        vk = snark.Vk(IC=_g1_tuples(sec["Vk.IC"]), Vkb=g1[0], G1Kbg=g1[1], Vka=g2[0], Vkc=g2[1], G2Kbg=g2[2], G2Kg=g2[3], Vkz=g2[4])
+    return snark.Circuit(nvars, npublic), pk, vk
+
+
+def UploadPkBinary(path):
+    """Pinocchio key: file -> memmap -> HBM (gs_g1_upload / gs_g2_upload on the mapped sections).  -> (Circuit, DevicePk)."""
+    import ctypes
+    protocol, nvars, npublic, sec = ReadBinary(path)
+    if protocol != PROTO_PINOCCHIO:
+        raise ValueError("error parsing key file: not a Pinocchio key")
+    g1 = {k: capi.g1_upload(np.ascontiguousarray(sec[k], dtype=np.uint64)) for k in ("A", "Ap", "Bp", "C", "Cp", "Kp", "G1T")}
+    b2 = capi.g2_upload(np.ascontiguousarray(sec["B"], dtype=np.uint64))
+    z = np.ascontiguousarray(sec["Z"], dtype=np.uint64)
+    h = capi.Handle(0)
+    H = lambda x: capi.Handle(x.h)   # noqa: E731
+    capi.check(capi.load_library().gs_pinocchio_pk_create(
+        H(g1["A"]), H(g1["Ap"]), H(b2), H(g1["Bp"]), H(g1["C"]), H(g1["Cp"]), H(g1["Kp"]), H(g1["G1T"]),
+        capi.ptr64(z), z.shape[0], nvars, npublic, ctypes.byref(h)))
+    return snark.Circuit(nvars, npublic), snark.DevicePk(capi.DeviceHandle(h.value), nvars, npublic)

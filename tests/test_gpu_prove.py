@@ -751,3 +751,19 @@ def test_mixed_tickets_groth16_pinocchio_msm_share_the_three_slots():
         outs.append(snark.prove_end(tickets.pop(0)))
     assert len(outs) == 7 and all(getattr(o, k) == getattr(want_p, k) for o in outs for k in snark.Proof.FIELDS)
     assert snark.VerifyProof(p.vk, outs[-1], p.public) is True
+
+
+def test_pinocchio_resident_key_round_trips_through_the_binary_container(tmp_path):
+    from gosnark_amd import utils
+    rec = GU.load("pinocchio_x3_setup")
+    toxic = tuple(int.from_bytes(bytes((i * k + 9) & 0xff for i in range(30)), "big") % O.R for k in (3, 5, 7, 11, 13, 17, 19, 23))
+    a, b, c = _x3_csr()
+    dpk, vk = snark.GenerateTrustedSetupSparse(7, 8, 1, a, b, c, toxic)
+    path = str(tmp_path / "pin.gskey")
+    utils.SetupToBinary(path, snark.Circuit(8, 1), dpk, vk)
+    circ, dpk2 = utils.UploadPkBinary(path)
+    want = snark.GenerateProofs(snark.Circuit(8, 1), dpk, rec["w"], rec["px"])
+    got = snark.GenerateProofs(circ, dpk2, rec["w"], rec["px"])
+    assert all(getattr(got, k) == getattr(want, k) for k in snark.Proof.FIELDS)
+    _, _, vk2 = utils.SetupFromBinary(path)
+    assert snark.VerifyProof(vk2, got, [35]) is True and snark.VerifyProof(vk2, got, [34]) is False

@@ -104,3 +104,16 @@ def test_binary_container_round_trip(tmp_path):
     open(bad, "wb").write(bytes(trunc[:len(trunc) - 64]))
     with pytest.raises(ValueError, match="out of bounds"):
         utils.ReadBinary(bad)
+
+
+def test_pinocchio_binary_container_round_trip(tmp_path):
+    from gosnark_amd import snark
+    setup, _ = rec("pinocchio_rand_m9")
+    pk, vk = utils.SetupFromString(setup)
+    p = str(tmp_path / "pin.gskey")
+    utils.SetupToBinary(p, snark.Circuit(len(pk.A), 1), pk, vk)
+    circ, pk2, vk2 = utils.SetupFromBinary(p)
+    assert (circ.NVars, circ.NPublic) == (len(pk.A), 1)
+    assert utils.SetupToString(pk2, vk2) == setup
+    with pytest.raises(ValueError, match="not a Groth16 key"):
+        utils.GrothPkFromBinary(p)
