@@ -495,6 +495,45 @@ inline G1Aff g1j_affine(const G1Jac& p) {
 }
 inline G1Aff g1_neg(const G1Aff& p) { return G1Aff{p.x, fp_neg(p.y), p.inf}; }
 
+// G2 membership: E'(Fq2) has a large cofactor (2q - r), so a point on the twist need not have order r, and a pairing
+// "check" on such a point proves nothing.  On the order-r subgroup the twisted Frobenius psi acts as multiplication by
+// q = t - 1 = 6 x^2 (mod r); psi(Q) == [6 x^2] Q singles that subgroup out (127-bit scalar instead of [r] Q).
+struct G2Jac { Fp2 x, y, z; };
+inline G2Jac g2j_dbl(const G2Jac& p) {
+  if (f2_is_zero(p.z) || f2_is_zero(p.y)) return G2Jac{f2_one(), f2_one(), f2_zero()};
+  Fp2 a = f2_sqr(p.x), b = f2_sqr(p.y), c = f2_sqr(b);
+  Fp2 d = f2_dbl(f2_sub(f2_sub(f2_sqr(f2_add(p.x, b)), a), c));
+  Fp2 e = f2_add(f2_dbl(a), a), f = f2_sqr(e);
+  Fp2 x3 = f2_sub(f, f2_dbl(d));
+  Fp2 y3 = f2_sub(f2_mul(e, f2_sub(d, x3)), f2_dbl(f2_dbl(f2_dbl(c))));
+  return G2Jac{x3, y3, f2_dbl(f2_mul(p.y, p.z))};
+}
+inline G2Jac g2j_add_affine(const G2Jac& p, const G2Aff& q) {       // q finite
+  if (f2_is_zero(p.z)) return G2Jac{q.x, q.y, f2_one()};
+  Fp2 z1z1 = f2_sqr(p.z);
+  Fp2 u2 = f2_mul(q.x, z1z1), s2 = f2_mul(q.y, f2_mul(p.z, z1z1));
+  if (f2_eq(p.x, u2)) return f2_eq(p.y, s2) ? g2j_dbl(p) : G2Jac{f2_one(), f2_one(), f2_zero()};
+  Fp2 h = f2_sub(u2, p.x), r = f2_sub(s2, p.y);
+  Fp2 hh = f2_sqr(h), hhh = f2_mul(h, hh), v = f2_mul(p.x, hh);
+  Fp2 x3 = f2_sub(f2_sub(f2_sqr(r), hhh), f2_dbl(v));
+  Fp2 y3 = f2_sub(f2_mul(r, f2_sub(v, x3)), f2_mul(p.y, hhh));
+  return G2Jac{x3, y3, f2_mul(p.z, h)};
+}
+inline bool g2_in_subgroup(const G2Aff& q) {
+  if (q.inf) return true;
+  const u128 k = (u128)6 * kX * kX;                                  // 6 x^2 < 2^128
+  G2Jac acc{f2_one(), f2_one(), f2_zero()};
+  for (int i = 127; i >= 0; --i) {
+    acc = g2j_dbl(acc);
+    if ((k >> i) & 1) acc = g2j_add_affine(acc, q);
+  }
+  if (f2_is_zero(acc.z)) return false;
+  const TowerConsts& t = twc();
+  const Fp2 px = f2_mul(f2_conj(q.x), t.g1[2]), py = f2_mul(f2_conj(q.y), t.g1[3]);   // psi(Q)
+  const Fp2 zz = f2_sqr(acc.z);
+  return f2_eq(f2_mul(px, zz), acc.x) && f2_eq(f2_mul(py, f2_mul(zz, acc.z)), acc.y);
+}
+
 // ------------------------------------------------------------------------------------------------ multi-Miller loop
 // prod_i f_{6x+2, Q_i}(P_i) * (the two Frobenius lines), pairs with an infinite member contribute 1.
 // Returns false when a degenerate step shows a Q_i is not a point of order r (vertical line inside the loop).

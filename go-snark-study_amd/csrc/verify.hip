@@ -13,11 +13,15 @@ struct ShapeError { const char* msg; };
 
 // prod e(P_i, Q_i) == 1 with one shared final exponentiation.  Off-curve inputs and G2 inputs that hit a vertical
 // line inside the loop (not of order r) make the check fail instead of producing a meaningless value.
-bool product_is_one(const std::vector<G1Aff>& ps, const std::vector<G2Aff>& qs) {
+// `untrusted_g2` lists the indices of G2 inputs that came from a prover (they get the subgroup check; key material is
+// checked once by whoever installs the key, not per proof).
+bool product_is_one(const std::vector<G1Aff>& ps, const std::vector<G2Aff>& qs, const std::vector<int>& untrusted_g2 = {}) {
   for (const G1Aff& p : ps)
     if (!g1_on_curve(p)) return false;
   for (const G2Aff& q : qs)
     if (!g2_on_curve(q)) return false;
+  for (int i : untrusted_g2)
+    if (!g2_in_subgroup(qs[(size_t)i])) return false;
   Fp12 f;
   if (!multi_miller_loop(ps, qs, f)) return false;
   return f12_eq(final_exponentiation(f), f12_one());
@@ -83,7 +87,9 @@ int gs_pairing_check(const uint64_t* g1, const uint64_t* g2, size_t k, int* ok) 
       ps[i] = g1_from_jacobian_std(g1 + 12 * i);
       qs[i] = g2_from_jacobian_std(g2 + 24 * i);
     }
-    *ok = product_is_one(ps, qs) ? 1 : 0;
+    std::vector<int> all(k);
+    for (size_t i = 0; i < k; ++i) all[i] = (int)i;
+    *ok = product_is_one(ps, qs, all) ? 1 : 0;
     return GS_OK;
   });
 }
@@ -101,7 +107,7 @@ int gs_groth16_verify(const uint64_t vk_g1_alpha[12], const uint64_t vk_g2_beta[
     std::vector<G1Aff> ps{g1_neg(g1_from_jacobian_std(pi_a)), g1_from_jacobian_std(vk_g1_alpha), ic, g1_from_jacobian_std(pi_c)};
     std::vector<G2Aff> qs{g2_from_jacobian_std(pi_b), g2_from_jacobian_std(vk_g2_beta), g2_from_jacobian_std(vk_g2_gamma),
                           g2_from_jacobian_std(vk_g2_delta)};
-    *ok = product_is_one(ps, qs) ? 1 : 0;
+    *ok = product_is_one(ps, qs, {0}) ? 1 : 0;                  // PiB is the prover's G2 element
     return GS_OK;
   });
 }
@@ -127,6 +133,7 @@ int gs_pinocchio_verify(const uint64_t vka[24], const uint64_t vkb[12], const ui
       if (!bad && !product_is_one(ps, qs)) bad = which;
     };
     check(1, {piA, g1_neg(piAp)}, {Vka, g2});                       // e(piA, Va) == e(piA', g2)            snark.go:294-304
+    if (!bad && (!g2_on_curve(piB) || !g2_in_subgroup(piB))) bad = 2;   // the prover's only G2 element, first used by equation 2
     check(2, {Vkb, g1_neg(piBp)}, {piB, g2});                       // e(Vb, piB) == e(piB', g2)            :306-316
     check(3, {piC, g1_neg(piCp)}, {Vkc, g2});                       // e(piC, Vc) == e(piC', g2)            :318-328
     if (!bad) {

@@ -289,8 +289,10 @@ int gs_set_window_bits(int c);
  * the final exponentiation removes).  Either point at infinity gives 1.  GS_ERR_ARG if a point is off its curve. */
 int gs_pairing(const uint64_t g1[12], const uint64_t g2[24], uint64_t out_fq12[48]);
 /* *ok = [ prod_i e(g1_i, g2_i) == 1 ]: one multi-Miller loop (shared squarings, one batched inversion per step) and
- * ONE final exponentiation for all k pairs.  Points off the curve, or G2 points that are not of order r, give *ok = 0
- * (the reference would compute a meaningless Fq12 value and compare it). */
+ * ONE final exponentiation for all k pairs.  Points off the curve, or G2 points outside the order-r subgroup
+ * (psi(Q) != [6x^2]Q; the twist has a large cofactor), give *ok = 0 (the reference would compute a meaningless Fq12
+ * value and compare it).  gs_groth16_verify / gs_pinocchio_verify apply the subgroup check to the prover's G2 element
+ * (PiB); the G2 elements of the verification key are key material, validated by whoever installs the key. */
 int gs_pairing_check(const uint64_t* g1 /* k x 12 */, const uint64_t* g2 /* k x 24 */, size_t k, int* ok);
 /* groth16.VerifyProof(vk, proof, publicSignals, debug) (groth16/groth16.go:281-305):
  *   icPubl = IC[0] + sum_i publicSignals[i] * IC[i+1];   e(PiA, PiB) == e(Alpha, Beta) e(icPubl, Gamma) e(PiC, Delta)

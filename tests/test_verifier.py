@@ -170,3 +170,44 @@ def test_verifier_needs_no_device_and_no_init():
     import torch
     if not torch.cuda.is_available():
         assert lib.gs_g1_upload(capi.ptr64(z), 1, capi.ctypes.byref(h)) < 0       # prover side still refuses without a device
+
+
+def test_g2_points_outside_the_order_r_subgroup_are_rejected():
+    """E'(Fq2) has cofactor 2q - r: a point on the twist need not be in G2.  Such a PiB must never verify (the reference
+    would run its Miller loop on it and compare whatever comes out)."""
+    # find a twist point by trying x = (k, 1): y^2 = x^3 + 3/(9+u); a random twist point is outside G2 with overwhelming probability
+    b_twist = O.FQ2.Mul(O.FQ2.Inverse((9, 1)), (3, 0))
+    q = O.Q
+    found = None
+    k = 1
+    while found is None:
+        x = (k, 1)
+        rhs = O.FQ2.Add(O.FQ2.Mul(O.FQ2.Square(x), x), b_twist)
+        # square root in Fq2 via the norm trick (q = 3 mod 4)
+        a0, a1 = rhs
+        norm = (a0 * a0 + a1 * a1) % q
+        s = pow(norm, (q + 1) // 4, q)
+        if s * s % q == norm:
+            for sgn in (s, q - s):
+                t = (a0 + sgn) * pow(2, q - 2, q) % q
+                y0 = pow(t, (q + 1) // 4, q)
+                if y0 * y0 % q == t and y0:
+                    y1 = a1 * pow(2 * y0, q - 2, q) % q
+                    if O.FQ2.Square((y0, y1)) == rhs:
+                        found = (x, (y0, y1), (1, 0))
+                        break
+        k += 1
+    on_twist = found
+    assert O.G2.Affine(O.G2.MulScalar(on_twist, O.R)) is not None          # [r]Q != infinity: not in G2
+    assert not bn128.PairingCheck([O.G1_GEN, O.G1.Neg(O.G1_GEN)], [on_twist, on_twist])    # even e(P,Q) e(-P,Q), trivially 1 in G2
+    in_g2 = O.G2.MulScalar(O.G2_GEN, 123456789)
+    assert bn128.PairingCheck([O.G1_GEN, O.G1.Neg(O.G1_GEN)], [in_g2, in_g2])
+    # cofactor-cleared: [2q - r] Q lands in G2 and is accepted again
+    cleared = O.G2.MulScalar(on_twist, 2 * q - O.R)
+    assert O.G2.Affine(O.G2.MulScalar(cleared, O.R)) is None
+    assert bn128.PairingCheck([O.G1_GEN, O.G1.Neg(O.G1_GEN)], [cleared, cleared])
+    _, setup, proof = rec("groth_x3")
+    _, vk = utils.GrothSetupFromString(setup)
+    pr = utils.GrothProofFromString(proof)
+    assert groth16.VerifyProof(vk, pr, [35]) is True
+    assert groth16.VerifyProof(vk, groth16.Proof(pr.PiA, on_twist, pr.PiC), [35]) is False
