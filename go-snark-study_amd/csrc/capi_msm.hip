@@ -25,9 +25,10 @@ int upload_bases(Ctx& c, Kind kind, const uint64_t* jac, size_t n, gs_handle* ou
   if (n) {
     DevBuf tmp(n * 3 * cw * 4);
     GS_HIP(hipMemcpyAsync(tmp.p, jac, n * 3 * cw * 4, hipMemcpyHostToDevice, c.stream));
-    if (kind == Kind::G1Bases) jacobian_to_affine_g1(c, tmp.as<uint32_t>(), (uint32_t)n, b->buf.as<uint32_t>());
-    else jacobian_to_affine_g2(c, tmp.as<uint32_t>(), (uint32_t)n, b->buf.as<uint32_t>());
-    GS_HIP(hipStreamSynchronize(c.stream));
+    uint32_t first_bad = 0;
+    const uint32_t bad = kind == Kind::G1Bases ? jacobian_to_affine_g1(c, tmp.as<uint32_t>(), (uint32_t)n, b->buf.as<uint32_t>(), &first_bad)
+                                               : jacobian_to_affine_g2(c, tmp.as<uint32_t>(), (uint32_t)n, b->buf.as<uint32_t>(), &first_bad);
+    if (bad) return fail(GS_ERR_ARG, "%u of the %zu points are not on the curve (first at index %u)", bad, n, first_bad);
   }
   *out = c.put(std::move(b));
   return GS_OK;

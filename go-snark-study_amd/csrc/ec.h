@@ -250,6 +250,29 @@ GS_HD Affine<T> jacobian_to_affine(const EX& X, const EX& Y, const EX& Z) {
   return r;
 }
 
+// y^2 == x^3 + b on E (b = 3) / on the twist E' (b = 3 / (9 + u)); infinity passes.  Uploads check it: a key point off its
+// curve makes every later sum meaningless, silently (the reference never checks either, bn128/g1.go has no IsOnCurve).
+template <class T> GS_HD typename T::template E<1> curve_b();
+template <> GS_HD Fe<ModQ, 1> curve_b<FqTag>() {
+  Fe<ModQ, 1> r;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) r.l[i] = Gen::b1(i);
+  return r;
+}
+template <> GS_HD Fq2e<1> curve_b<Fq2Tag>() {
+  Fq2e<1> r;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) { r.c0.l[i] = Gen::b2c0(i); r.c1.l[i] = Gen::b2c1(i); }
+  return r;
+}
+template <class T>
+GS_HD bool on_curve(const Affine<T>& a) {
+  if (is_inf(a)) return true;
+  const auto lhs = ssqr<T>(a.y);
+  const auto rhs = add(smul<T>(ssqr<T>(a.x), a.x), curve_b<T>());
+  return is_zero(sub(lhs, rhs));
+}
+
 using G1Affine = Affine<FqTag>;
 using G2Affine = Affine<Fq2Tag>;
 using G1Xyzz = Xyzz<FqTag>;

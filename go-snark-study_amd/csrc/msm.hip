@@ -259,13 +259,26 @@ void msm_run_g2(Ctx& c, const MsmPlan& plan, const std::vector<MsmBase>& bases, 
   msm_finish<Fq2Tag>(c, p, out);
 }
 
-void jacobian_to_affine_g1(Ctx& c, const uint32_t* jac, uint32_t n, uint32_t* out) {
-  if (n) hipLaunchKernelGGL(k_jacobian_to_affine<FqTag>, grid1(n), dim3(256), 0, c.stream, jac, n, out);
+// Returns the number of points that are not on their curve (and the first such index); synchronises the stream.
+template <class T>
+static uint32_t jacobian_to_affine_checked(Ctx& c, const uint32_t* jac, uint32_t n, uint32_t* out, uint32_t* first_bad) {
+  if (!n) return 0;
+  DevBuf flag(8);
+  const uint32_t init[2] = {0u, 0xffffffffu};
+  GS_HIP(hipMemcpyAsync(flag.p, init, 8, hipMemcpyHostToDevice, c.stream));
+  hipLaunchKernelGGL(k_jacobian_to_affine<T>, grid1(n), dim3(256), 0, c.stream, jac, n, out, flag.as<uint32_t>());
   GS_HIP(hipGetLastError());
+  uint32_t res[2] = {0, 0};
+  GS_HIP(hipMemcpyAsync(res, flag.p, 8, hipMemcpyDeviceToHost, c.stream));
+  GS_HIP(hipStreamSynchronize(c.stream));
+  if (first_bad) *first_bad = res[1];
+  return res[0];
 }
-void jacobian_to_affine_g2(Ctx& c, const uint32_t* jac, uint32_t n, uint32_t* out) {
-  if (n) hipLaunchKernelGGL(k_jacobian_to_affine<Fq2Tag>, grid1(n), dim3(256), 0, c.stream, jac, n, out);
-  GS_HIP(hipGetLastError());
+uint32_t jacobian_to_affine_g1(Ctx& c, const uint32_t* jac, uint32_t n, uint32_t* out, uint32_t* first_bad) {
+  return jacobian_to_affine_checked<FqTag>(c, jac, n, out, first_bad);
+}
+uint32_t jacobian_to_affine_g2(Ctx& c, const uint32_t* jac, uint32_t n, uint32_t* out, uint32_t* first_bad) {
+  return jacobian_to_affine_checked<Fq2Tag>(c, jac, n, out, first_bad);
 }
 void affine_to_jacobian_std_g1(Ctx& c, const uint32_t* aff, uint32_t n, uint32_t* out) {
   if (n) hipLaunchKernelGGL(k_affine_to_jacobian_std<FqTag>, grid1(n), dim3(256), 0, c.stream, aff, n, out);

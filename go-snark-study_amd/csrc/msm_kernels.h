@@ -507,14 +507,20 @@ __global__ void __launch_bounds__(256) k_build_table_batched(const uint32_t* __r
 
 // ---- base-array preparation ----------------------------------------------------------------------------
 // Jacobian standard-form triples -> packed canonical Montgomery affine       [g1.go:157-170]
+// off_curve[0] counts the points that are not on their curve, off_curve[1] keeps the smallest such index
 template <class T>
-__global__ void __launch_bounds__(256) k_jacobian_to_affine(const uint32_t* __restrict__ jac, uint32_t n, uint32_t* __restrict__ out) {
+__global__ void __launch_bounds__(256) k_jacobian_to_affine(const uint32_t* __restrict__ jac, uint32_t n, uint32_t* __restrict__ out,
+                                                             uint32_t* __restrict__ off_curve) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   constexpr int cw = PointIO<T>::kCoordWords;
   const uint32_t* p = jac + (size_t)i * 3 * cw;
   auto X = PointIO<T>::load_std(p), Y = PointIO<T>::load_std(p + cw), Z = PointIO<T>::load_std(p + 2 * cw);
   Affine<T> a = jacobian_to_affine<T>(X, Y, Z);
+  if (!on_curve(a)) {
+    atomicAdd(off_curve, 1u);
+    atomicMin(off_curve + 1, i);
+  }
   PointIO<T>::store_affine(out + (size_t)i * PointIO<T>::kAffineWords, a);
 }
 

@@ -65,7 +65,9 @@ int gs_free(gs_handle h);
 /* ---- resident base-point arrays (proving-key material) --------------------------------- */
 /* Upload n Jacobian points, convert to Montgomery affine on the device (x = X/Z^2, y = Y/Z^3,
  * bn128/g1.go:157-170), keep them resident.  Replaces the per-call big.Int traffic of
- * pk.G1.At / pk.G1.BACGamma / pk.BACDelta / pk.PowersTauDelta (groth16.go:15-32). */
+ * pk.G1.At / pk.G1.BACGamma / pk.BACDelta / pk.PowersTauDelta (groth16.go:15-32).
+ * Every finite point must satisfy its curve equation (y^2 = x^3 + 3; on the twist y^2 = x^3 + 3/(9+u)): otherwise
+ * GS_ERR_ARG, naming the first offender (the reference never checks and would sum garbage). */
 int gs_g1_upload(const uint64_t* jacobian /* n x 12 */, size_t n, gs_handle* out);
 /* Same for G2 arrays, e.g. pk.G2.BACGamma (groth16.go:29), snark Pk.B (snark.go:19). */
 int gs_g2_upload(const uint64_t* jacobian /* n x 24 */, size_t n, gs_handle* out);

@@ -287,3 +287,23 @@ def test_concurrent_callers_from_several_threads_get_their_own_results():
     for th in threads:
         th.join()
     assert not errors, errors
+
+
+def test_upload_rejects_points_that_are_not_on_their_curve():
+    rng = random.Random(61)
+    pts = [U.rand_g1_jac(rng, 0.1) for _ in range(50)]
+    capi.g1_upload(capi.g1_points_to_u64(pts))                             # fine
+    bad = list(pts)
+    bad[17] = (5, 7, 1)
+    bad[33] = (bad[33][0], (bad[33][1] + 1) % O.Q, bad[33][2])
+    with pytest.raises(capi.GosnarkHipError, match=r"2 of the 50 points are not on the curve \(first at index 17\)"):
+        capi.g1_upload(capi.g1_points_to_u64(bad))
+    pts2 = [U.rand_g2_jac(rng, 0.1) for _ in range(9)]
+    capi.g2_upload(capi.g2_points_to_u64(pts2))
+    bad2 = list(pts2)
+    k = next(i for i, p in enumerate(bad2) if p[2] != (0, 0))
+    bad2[k] = (bad2[k][0], ((bad2[k][1][0] + 1) % O.Q, bad2[k][1][1]), bad2[k][2])
+    with pytest.raises(capi.GosnarkHipError, match="not on the curve"):
+        capi.g2_upload(capi.g2_points_to_u64(bad2))
+    # the Jacobian representative does not matter, infinity passes
+    capi.g1_upload(capi.g1_points_to_u64([(0, 0, 0), O.G1.MulScalar(O.G1_GEN, 12345), (7, 11, 0)]))
