@@ -71,3 +71,38 @@ def test_sum_affine_is_host_side_complete_addition():
     assert capi.sum_affine([]) is None
     g2 = O.G2.Affine(O.G2.MulScalar(O.G2_GEN, 777))
     assert capi.sum_affine([g2, g2], g2=True) == O.G2.Affine(O.G2.MulScalar(O.G2_GEN, 1554))
+
+
+def test_header_is_plain_c_as_cgo_needs_it(tmp_path):
+    """cgo compiles include/gosnark_hip.h as C: it must be valid C99 on its own, and a C translation unit that calls the
+    entry points the Go binding uses must compile and link against the library."""
+    import os
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gcc = shutil.which("gcc")
+    if not gcc:
+        pytest.skip("no gcc")
+    hdr = os.path.join(root, "include", "gosnark_hip.h")
+    subprocess.check_call([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", hdr])
+    src = tmp_path / "use.c"
+    src.write_text('''#include "gosnark_hip.h"
+#include <stdio.h>
+int main(void) {
+  int dev = 0, ok = -1;
+  uint64_t one[12] = {1,0,0,0, 2,0,0,0, 1,0,0,0};
+  uint64_t q[24] = {0};
+  printf("%s\\n", gs_version());
+  if (gs_pairing_check(one, q, 1, &ok) != 0 || ok != 1) return 2;      /* e(G, infinity) = 1: host-side entry point */
+  if (gs_init(&dev, 1) == 0) gs_shutdown();                              /* no device here: must fail, loudly, not crash */
+  else printf("%s\\n", gs_last_error());
+  return 0;
+}
+''')
+    exe = tmp_path / "use"
+    libdir = os.path.join(root, "go-snark-study_amd")
+    subprocess.check_call([gcc, "-std=c99", "-Wall", "-Werror", "-I", os.path.join(root, "include"), str(src), "-o", str(exe),
+                           "-L", libdir, "-lgosnark_hip", "-Wl,-rpath," + libdir])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "gosnark-hip" in out.stdout

@@ -307,3 +307,47 @@ def test_upload_rejects_points_that_are_not_on_their_curve():
         capi.g2_upload(capi.g2_points_to_u64(bad2))
     # the Jacobian representative does not matter, infinity passes
     capi.g1_upload(capi.g1_points_to_u64([(0, 0, 0), O.G1.MulScalar(O.G1_GEN, 12345), (7, 11, 0)]))
+
+
+def test_plain_c_process_drives_the_library_without_python_or_torch(tmp_path):
+    """What a cgo caller sees: a C program (no Python, no torch in the process) initialises the device, builds bases with
+    gs_g1_fixed_base, runs gs_msm_g1 and checks sum_i s_i * (k_i G) == (sum_i s_i k_i) G through a second fixed-base call."""
+    import os
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if not gcc:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "drive.c"
+    src.write_text(r'''#include "gosnark_hip.h"
+#include <stdio.h>
+#include <string.h>
+#define N 1000
+#define CHECK(x) do { int _s = (x); if (_s != 0) { printf("FAIL %s: %d %s\n", #x, _s, gs_last_error()); return 1; } } while (0)
+int main(void) {
+  int dev = 0, inf = 0;
+  static uint64_t k[N * 4], s[N * 4], pts[N * 12], one[12], sum[8];
+  uint64_t dot[4] = {0, 0, 0, 0};
+  gs_handle bases = 0, single = 0;
+  CHECK(gs_init(&dev, 1));
+  memset(k, 0, sizeof k); memset(s, 0, sizeof s);
+  for (int i = 0; i < N; ++i) { k[4 * i] = 3 + 7 * (uint64_t)i; s[4 * i] = 1000003 + 13 * (uint64_t)i; dot[0] += k[4 * i] * s[4 * i]; }   /* < 2^64 */
+  CHECK(gs_g1_fixed_base(k, N, &bases));
+  CHECK(gs_msm_g1(bases, s, 0, N, sum, &inf));
+  CHECK(gs_g1_fixed_base(dot, 1, &single));
+  CHECK(gs_g1_download(single, one, 1));
+  if (inf || memcmp(sum, one, 64) != 0) { printf("FAIL: MSM result differs from the fixed-base multiple\n"); return 2; }
+  CHECK(gs_g1_download(bases, pts, N));
+  CHECK(gs_free(bases)); CHECK(gs_free(single));
+  gs_shutdown();
+  printf("OK %s\n", gs_version());
+  return 0;
+}
+''')
+    exe = tmp_path / "drive"
+    libdir = os.path.join(root, "go-snark-study_amd")
+    subprocess.check_call([gcc, "-std=c99", "-Wall", "-Werror", "-I", os.path.join(root, "include"), str(src), "-o", str(exe),
+                           "-L", libdir, "-lgosnark_hip", "-Wl,-rpath," + libdir])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.startswith("OK"), out.stdout + out.stderr
