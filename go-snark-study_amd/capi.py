@@ -91,14 +91,36 @@ _SIGS = {
     "gs_pinocchio_prove_resident": [Handle, Handle, Handle, u64p, intp],
     "gs_pinocchio_prove_begin": [Handle, Handle, Handle, u64p],
     "gs_pinocchio_prove_end": [ctypes.c_uint64, u64p, intp],
+    "gs_device_count": [],
+    "gs_set_device": [ctypes.c_int],
+    "gs_get_device": [],
+    "gs_handle_device": [Handle],
+    "gs_scalars_clone": [Handle, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, ctypes.POINTER(Handle)],
+    "gs_g1_clone": [Handle, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, ctypes.POINTER(Handle)],
+    "gs_g2_clone": [Handle, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, ctypes.POINTER(Handle)],
+    "gs_groth16_pk_shard_to": [Handle, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, ctypes.POINTER(Handle)],
+    "gs_comm_unique_id": [ctypes.POINTER(ctypes.c_uint8)],
+    "gs_comm_init_rank": [ctypes.POINTER(ctypes.c_uint8), ctypes.c_int, ctypes.c_int],
+    "gs_comm_init_local": [],
+    "gs_comm_info": [intp, intp, intp, u64p],
+    "gs_comm_allgather": [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p],
+    "gs_msm_g1_multi": [ctypes.POINTER(Handle), ctypes.POINTER(Handle), ctypes.c_int, u64p, intp, intp],
+    "gs_msm_g2_multi": [ctypes.POINTER(Handle), ctypes.POINTER(Handle), ctypes.c_int, u64p, intp, intp],
+    "gs_groth16_prove_multi": [ctypes.POINTER(Handle), ctypes.POINTER(Handle), ctypes.POINTER(Handle), ctypes.c_int, u64p, u64p, u64p, intp, intp],
+    "gs_groth16_prove_sharded": [Handle, Handle, Handle, u64p, u64p, u64p, intp],
+    "gs_msm_g1_sharded": [Handle, Handle, u64p, intp],
+    "gs_msm_g2_sharded": [Handle, Handle, u64p, intp],
+    "gs_groth16_prove_batch": [ctypes.POINTER(Handle), ctypes.c_int, ctypes.POINTER(Handle), ctypes.POINTER(Handle), ctypes.c_size_t,
+                               u64p, u64p, u64p, intp],
     "gs_last_timing": [ctypes.POINTER(Timing)],
+    "gs_device_timing": [ctypes.c_int, ctypes.POINTER(Timing)],
     "gs_set_window_bits": [ctypes.c_int],
     "gs_pairing": [u64p, u64p, u64p],
     "gs_pairing_check": [u64p, u64p, ctypes.c_size_t, intp],
     "gs_groth16_verify": [u64p, u64p, u64p, u64p, u64p, ctypes.c_size_t, u64p, ctypes.c_size_t, u64p, u64p, u64p, intp],
     "gs_pinocchio_verify": [u64p, u64p, u64p, u64p, u64p, u64p, u64p, u64p, ctypes.c_size_t, u64p, ctypes.c_size_t, u64p, intp, intp],
 }
-EXPORTS = sorted(list(_SIGS) + ["gs_shutdown", "gs_last_error", "gs_version"])
+EXPORTS = sorted(list(_SIGS) + ["gs_shutdown", "gs_last_error", "gs_version", "gs_comm_destroy"])
 
 
 def load_library():
@@ -130,6 +152,7 @@ def load_library():
         lib.gs_last_error.restype = ctypes.c_char_p
         lib.gs_version.restype = ctypes.c_char_p
         lib.gs_shutdown.restype = None
+        lib.gs_comm_destroy.restype = None
         _LIB = lib
         return lib
 
@@ -140,18 +163,37 @@ def check(status):
 
 
 def init(device=None):
-    """gs_init on `device` (default: LOCAL_RANK or 0).  One process drives one GPU."""
+    """gs_init on `device` (default: LOCAL_RANK or 0): one process drives one GPU.  `device` may also be a list of HIP
+    ordinals -- one logical device (context) per entry, the same ordinal may repeat (see include/gosnark_hip.h)."""
     global _INIT_DEVICE
     lib = load_library()
     if device is None:
-        if _INIT_DEVICE is not None:          # already driving a GPU: keep it (one process per GPU)
+        if _INIT_DEVICE is not None:          # already initialised: keep it
             return
         device = int(os.environ.get("LOCAL_RANK", "0"))
-    if _INIT_DEVICE == device:
+    devices = tuple(int(d) for d in device) if isinstance(device, (list, tuple)) else (int(device),)
+    if _INIT_DEVICE == devices:
         return
-    arr = (ctypes.c_int * 1)(device)
-    check(lib.gs_init(arr, 1))
-    _INIT_DEVICE = device
+    arr = (ctypes.c_int * len(devices))(*devices)
+    check(lib.gs_init(arr, len(devices)))
+    _INIT_DEVICE = devices
+
+
+def device_count():
+    return load_library().gs_device_count()
+
+
+def set_device(logical):
+    """Objects created by this host thread from now on live on logical device `logical`."""
+    check(load_library().gs_set_device(int(logical)))
+
+
+def get_device():
+    return load_library().gs_get_device()
+
+
+def handle_device(handle):
+    return load_library().gs_handle_device(Handle(handle.h))
 
 
 def shutdown():
@@ -211,10 +253,15 @@ class DeviceHandle:
         self.h = int(h)
 
     def free(self):
+        """gs_free.  Safe while tickets that read the object are outstanding (the library defers the release); if the call
+        fails all the same (foreign handle) the handle is kept so that the failure is not silent."""
         if self.h:
             lib = load_library()
-            lib.gs_free(Handle(self.h))
-            self.h = 0
+            rc = lib.gs_free(Handle(self.h))
+            if rc == 0 or lib.gs_device_count() == 0:     # after gs_shutdown every handle is already gone
+                self.h = 0
+            else:
+                check(rc)
 
     def __del__(self):
         try:
@@ -360,3 +407,83 @@ def msm_end(ticket):
     inf = ctypes.c_int(0)
     check(load_library().gs_msm_end(ctypes.c_uint64(t), ptr64(out), ctypes.byref(inf)))
     return _affine_result(out, inf, g2)
+
+
+# ---- several logical devices / communicator (multi.hip) -------------------------------------------------
+def _clone(fname, handle, off, n, target):
+    h = Handle(0)
+    check(getattr(load_library(), fname)(Handle(handle.h), off, n, int(target), ctypes.byref(h)))
+    return DeviceHandle(h.value)
+
+
+def scalars_clone(handle, target, off=0, n=None):
+    return _clone("gs_scalars_clone", handle, off, len(handle) - off if n is None else n, target)
+
+
+def g1_clone(handle, target, off=0, n=None):
+    return _clone("gs_g1_clone", handle, off, len(handle) - off if n is None else n, target)
+
+
+def g2_clone(handle, target, off=0, n=None):
+    return _clone("gs_g2_clone", handle, off, len(handle) - off if n is None else n, target)
+
+
+def comm_unique_id():
+    buf = (ctypes.c_uint8 * 128)()
+    check(load_library().gs_comm_unique_id(buf))
+    return bytes(buf)
+
+
+def comm_init_rank(uid, nranks, rank):
+    buf = (ctypes.c_uint8 * 128).from_buffer_copy(uid)
+    check(load_library().gs_comm_init_rank(buf, int(nranks), int(rank)))
+
+
+def comm_init_local():
+    check(load_library().gs_comm_init_local())
+
+
+def comm_destroy():
+    load_library().gs_comm_destroy()
+
+
+def comm_info():
+    nr, rk, loc, cnt = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0), ctypes.c_uint64(0)
+    check(load_library().gs_comm_info(ctypes.byref(nr), ctypes.byref(rk), ctypes.byref(loc), ctypes.cast(ctypes.byref(cnt), u64p)))
+    return {"nranks": nr.value, "rank": rk.value, "local": bool(loc.value), "collectives": cnt.value}
+
+
+def comm_allgather(block, nblocks_out, local_blocks=1):
+    """bytes `block` (local_blocks consecutive blocks in local mode) -> bytes of all ranks' blocks."""
+    per = len(block) // local_blocks
+    send = (ctypes.c_uint8 * len(block)).from_buffer_copy(block)
+    recv = (ctypes.c_uint8 * (per * nblocks_out))()
+    check(load_library().gs_comm_allgather(send, per, recv))
+    return bytes(recv)
+
+
+def _harr(handles):
+    return (Handle * len(handles))(*[Handle(h.h if isinstance(h, DeviceHandle) else int(h)) for h in handles])
+
+
+def msm_multi(bases, scalars, g2=False):
+    """One MSM over len(bases) logical devices (gs_msm_g1_multi / gs_msm_g2_multi) -> (affine point, used_rccl)."""
+    out = np.zeros(16 if g2 else 8, dtype=np.uint64)
+    inf, used = ctypes.c_int(0), ctypes.c_int(0)
+    fn = load_library().gs_msm_g2_multi if g2 else load_library().gs_msm_g1_multi
+    check(fn(_harr(bases), _harr(scalars), len(bases), ptr64(out), ctypes.byref(inf), ctypes.byref(used)))
+    return _affine_result(out, inf, g2), bool(used.value)
+
+
+def msm_sharded(bases, scalars, g2=False):
+    out = np.zeros(16 if g2 else 8, dtype=np.uint64)
+    inf = ctypes.c_int(0)
+    fn = load_library().gs_msm_g2_sharded if g2 else load_library().gs_msm_g1_sharded
+    check(fn(Handle(bases.h), Handle(scalars.h), ptr64(out), ctypes.byref(inf)))
+    return _affine_result(out, inf, g2)
+
+
+def device_timing(logical):
+    t = Timing()
+    check(load_library().gs_device_timing(int(logical), ctypes.byref(t)))
+    return {n: getattr(t, n) for n, _ in Timing._fields_}

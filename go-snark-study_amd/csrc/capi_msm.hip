@@ -11,6 +11,8 @@
 
 using namespace gs;
 
+namespace gs { void multi_shutdown(); }
+
 namespace {
 
 
@@ -87,7 +89,7 @@ int msm_resident(Ctx& c, Kind kind, gs_handle hb, size_t off, const uint32_t* sc
   MsmPlan plan;
   {
     PhaseTimer tp(c.stream);
-    build_plan(c, 0, scalars_dev, (uint32_t)n, plan, {{1, T::kWords == 16}});
+    build_plan(c, 2 * Ctx::kBlockingSlot, scalars_dev, (uint32_t)n, plan, {{1, T::kWords == 16}});
     tp.stop();
     c.timing.plan_ms += tp.ms();
   }
@@ -130,7 +132,7 @@ int msm_begin(Ctx& c, Kind kind, gs_handle hb, size_t off, gs_handle hs, size_t 
   if (n == 0 || n > (size_t)kIndexMask) return fail(GS_ERR_ARG, "gs_msm_begin: 1 .. 2^26 - 1 terms per call");
   if (off > b->n || n > b->n - off || soff > sc->n || n > sc->n - soff) return fail(GS_ERR_ARG, "gs_msm_begin: range exceeds the resident arrays");
   const int parity = c.free_parity();
-  if (parity < 0) return fail(GS_ERR_ARG, "gs_msm_begin: three operations are already outstanding");
+  if (parity < 0) return fail(GS_ERR_BUSY, "gs_msm_begin: three operations are already outstanding");
   if (!b->table) b->table = std::make_shared<BaseTable>();
   BaseTable* tab = static_cast<BaseTable*>(b->table.get());
   const int cbits = choose_window_bits((uint32_t)n, c.window_bits);
@@ -138,6 +140,7 @@ int msm_begin(Ctx& c, Kind kind, gs_handle hb, size_t off, gs_handle hs, size_t 
   else ensure_table_g2(c, *tab, b->buf.as<uint32_t>(), b->n, cbits);
   auto st = std::make_unique<MsmInFlight>();
   st->g2 = T::kWords == 16;
+  st->keep = {c.share<Object>(hb, kind), c.share<Object>(hs, Kind::Scalars)};
   MsmPlan plan;
   {
     StreamScope ss(c, c.aux_stream[1]);
@@ -154,7 +157,7 @@ int msm_begin(Ctx& c, Kind kind, gs_handle hb, size_t off, gs_handle hs, size_t 
     else msm_enqueue_g2(c, plan, bases, 8 * parity + 4, 3 * parity, st->pend, c.aux_stream[2]);
   }
   GS_HIP(hipEventRecord(st->done, c.aux_stream[2]));
-  st->ticket = c.next_ticket++;
+  st->ticket = c.new_ticket();
   *ticket = st->ticket;
   c.inflight[parity] = std::move(st);
   return GS_OK;
@@ -222,57 +225,39 @@ extern "C" {
 const char* gs_version(void) { return "gosnark-hip 0.1 gfx950 (9x29-bit Montgomery, XYZZ Pippenger)"; }
 const char* gs_last_error(void) { return last_error_ref().c_str(); }
 
-int gs_init(const int* devices, int ndev) {
-  return guarded([&](Ctx& c) -> int {
-    if (ndev != 1 || !devices) return fail(GS_ERR_ARG, "gs_init: exactly one device per process (got ndev=%d)", ndev);
-    int count = 0;
-    hipError_t e = hipGetDeviceCount(&count);
-    if (e != hipSuccess || count == 0)
-      return fail(GS_ERR_NO_DEVICE, "no HIP device visible (%s); libgosnark_hip has no CPU path", e == hipSuccess ? "count=0" : hipGetErrorString(e));
-    if (devices[0] < 0 || devices[0] >= count) return fail(GS_ERR_ARG, "device %d out of range (0..%d)", devices[0], count - 1);
-    hipDeviceProp_t prop;
-    GS_HIP(hipGetDeviceProperties(&prop, devices[0]));
-    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
-      return fail(GS_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 (MI355X) only", devices[0], prop.gcnArchName);
-    GS_HIP(hipSetDevice(devices[0]));
-    if (c.ready && c.device != devices[0]) return fail(GS_ERR_ARG, "already initialised on device %d", c.device);
-    if (!c.ready) {
-      GS_HIP(hipStreamCreateWithFlags(&c.main_stream, hipStreamNonBlocking));
-      // The aux streams carry the latency-/bandwidth-bound shadow work of a proof (NTT passes, plan kernels, bucket
-      // combine / reduction tails) next to the ALU-bound accumulations on the main stream.  They get the HIGHEST queue
-      // priority: their kernels are short but hard to place (k_hist wants 128 KiB of LDS and 16 wave slots of one CU),
-      // and a starved plan(h) would stall the last accumulation (seen in an earlier timeline).
-      {
-        int least = 0, greatest = 0;
-        GS_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        const bool no_overlap = getenv("GS_NO_OVERLAP") != nullptr;      // debugging aid: everything on the main stream
-        const bool no_prio = getenv("GS_NO_PRIORITY") != nullptr;
-        for (auto& a : c.aux_stream) {
-          if (no_overlap) a = c.main_stream;
-          else GS_HIP(hipStreamCreateWithPriority(&a, hipStreamNonBlocking, no_prio ? least : greatest));
-        }
-      }
-      for (auto& p : c.pinned) GS_HIP(hipHostMalloc(&p, Ctx::kPinnedBytes, hipHostMallocDefault));
-      c.stream = c.main_stream;
-      c.device = devices[0];
-      static bool registered = false;
-      if (!registered) { atexit([] { process_exiting() = true; }); registered = true; }
-      c.ready = true;
-    }
-    return GS_OK;
-  }, false);
+// One context per entry of `devices` (a "logical device": its own streams, workspaces, handle table and lock).  The same
+// HIP ordinal may be listed several times -- N logical devices time-slicing one GPU -- which is how the multi-device
+// entry points (multi.hip) are exercised on a single-GPU box.
+static void ctx_create(Ctx& c, int logical, int device) {
+  c.logical = logical;
+  c.device = device;
+  GS_HIP(hipSetDevice(device));
+  GS_HIP(hipStreamCreateWithFlags(&c.main_stream, hipStreamNonBlocking));
+  // The aux streams carry the latency-/bandwidth-bound shadow work of a proof (NTT passes, plan kernels, bucket
+  // combine / reduction tails) next to the ALU-bound accumulations on the main stream.  They get the HIGHEST queue
+  // priority: their kernels are short but hard to place (k_hist wants 128 KiB of LDS and 16 wave slots of one CU),
+  // and a starved plan(h) would stall the last accumulation (seen in an earlier timeline).
+  int least = 0, greatest = 0;
+  GS_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+  const bool no_overlap = getenv("GS_NO_OVERLAP") != nullptr;      // debugging aid: everything on the main stream
+  const bool no_prio = getenv("GS_NO_PRIORITY") != nullptr;
+  for (auto& a : c.aux_stream) {
+    if (no_overlap) a = c.main_stream;
+    else GS_HIP(hipStreamCreateWithPriority(&a, hipStreamNonBlocking, no_prio ? least : greatest));
+  }
+  for (auto& p : c.pinned) GS_HIP(hipHostMalloc(&p, Ctx::kPinnedBytes, hipHostMallocDefault));
+  c.stream = c.main_stream;
+  c.ready = true;
 }
 
-void gs_shutdown(void) {
-  Ctx& c = ctx();
+static void ctx_destroy(Ctx& c) {
   std::lock_guard<std::mutex> lk(c.mu);
   if (!c.ready) return;
   (void)hipSetDevice(c.device);
   (void)hipDeviceSynchronize();
   for (auto& f : c.inflight) f.reset();
   c.objs.clear();
-  // give back what gs_init created and the grow-only workspaces; caches keyed by size (plans, twiddles, trees) stay valid
-  // for a later gs_init on the same device
+  c.msm_state.reset(); c.poly_state.reset(); c.prove_state.reset();
   for (auto& a : c.aux_stream) {
     if (a && a != c.main_stream) (void)hipStreamDestroy(a);
     a = nullptr;
@@ -284,20 +269,94 @@ void gs_shutdown(void) {
     if (pp) (void)hipHostFree(pp);
     pp = nullptr;
   }
-  c.ws_hist.release(); c.ws_offsets.release(); c.ws_cursor.release(); c.ws_entries.release(); c.ws_tiles.release(); c.ws_total.release();
   for (auto& b : c.ws_buckets) b.release();
   for (auto& b : c.ws_chunks) b.release();
   for (auto& b : c.ws_partials) b.release();
   for (auto& b : c.ws_out) b.release();
-  c.ws_misc.release();
+  c.ws_misc.release(); c.g1_pow2.release(); c.g2_pow2.release();
   c.ready = false;
 }
+
+int gs_init(const int* devices, int ndev) {
+  Registry& r = registry();
+  std::lock_guard<std::mutex> lk(r.mu);
+  try {
+    if (!devices || ndev < 1 || ndev > kMaxLogicalDevices)
+      return fail(GS_ERR_ARG, "gs_init: need 1 .. %d devices (got ndev=%d)", kMaxLogicalDevices, ndev);
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0)
+      return fail(GS_ERR_NO_DEVICE, "no HIP device visible (%s); libgosnark_hip has no CPU path", e == hipSuccess ? "count=0" : hipGetErrorString(e));
+    for (int i = 0; i < ndev; ++i) {
+      if (devices[i] < 0 || devices[i] >= count) return fail(GS_ERR_ARG, "device %d out of range (0..%d)", devices[i], count - 1);
+      hipDeviceProp_t prop;
+      GS_HIP(hipGetDeviceProperties(&prop, devices[i]));
+      if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(GS_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 (MI355X) only", devices[i], prop.gcnArchName);
+    }
+    if (!r.ctxs.empty()) {                          // a second gs_init must name the same list (idempotent), anything else needs gs_shutdown
+      bool same = r.ctxs.size() == (size_t)ndev;
+      for (int i = 0; same && i < ndev; ++i) same = r.ctxs[i]->device == devices[i];
+      if (same) return GS_OK;
+      return fail(GS_ERR_ARG, "already initialised on %zu device(s) starting with device %d: call gs_shutdown first", r.ctxs.size(), r.ctxs[0]->device);
+    }
+    static bool registered = false;
+    if (!registered) { atexit([] { process_exiting() = true; }); registered = true; }
+    std::vector<std::unique_ptr<Ctx>> fresh;
+    for (int i = 0; i < ndev; ++i) {
+      fresh.push_back(std::make_unique<Ctx>());
+      ctx_create(*fresh.back(), i, devices[i]);
+    }
+    // distinct physical devices copy key slices / scalar vectors to each other directly over xGMI
+    for (int i = 0; i < ndev; ++i)
+      for (int j = 0; j < ndev; ++j)
+        if (devices[i] != devices[j]) {
+          int can = 0;
+          if (hipDeviceCanAccessPeer(&can, devices[i], devices[j]) == hipSuccess && can) {
+            (void)hipSetDevice(devices[i]);
+            (void)hipDeviceEnablePeerAccess(devices[j], 0);      // "already enabled" is fine
+            (void)hipGetLastError();
+          }
+        }
+    r.ctxs = std::move(fresh);
+    return GS_OK;
+  } catch (const HipError& e) {
+    return fail(GS_ERR_HIP, "HIP error %d (%s) at %s line %d", (int)e.e, hipGetErrorString(e.e), e.what, e.line);
+  } catch (const std::exception& e) {
+    return fail(GS_ERR_ARG, "%s", e.what());
+  }
+}
+
+void gs_shutdown(void) {
+  multi_shutdown();                                 // communicators first (multi.hip)
+  Registry& r = registry();
+  std::lock_guard<std::mutex> lk(r.mu);
+  for (auto& c : r.ctxs) ctx_destroy(*c);
+  r.ctxs.clear();                                   // nothing survives: a later gs_init may name other devices
+}
+
+int gs_device_count(void) {
+  Registry& r = registry();
+  std::lock_guard<std::mutex> lk(r.mu);
+  return (int)r.ctxs.size();
+}
+
+int gs_set_device(int logical) {
+  if (logical < 0 || (size_t)logical >= registry().ctxs.size())
+    return fail(GS_ERR_ARG, "gs_set_device: no logical device %d (gs_init listed %zu)", logical, registry().ctxs.size());
+  current_logical() = logical;
+  return GS_OK;
+}
+
+int gs_get_device(void) { return current_logical(); }
+
+int gs_handle_device(gs_handle h) { return handle_device(h); }
 
 int gs_free(gs_handle h) {
   return guarded([&](Ctx& c) -> int {
     if (!c.objs.erase(h)) return fail(GS_ERR_ARG, "gs_free: unknown handle %llu", (unsigned long long)h);
     return GS_OK;
-  });
+  }, true, true, h);
 }
 
 int gs_len(gs_handle h, size_t* out) {
@@ -310,20 +369,20 @@ int gs_len(gs_handle h, size_t* out) {
       case Kind::GrothPk: *out = static_cast<GrothPkObj*>(it->second.get())->n_w; return GS_OK;       // entries of At held (a slice holds fewer than NVars)
       default: return fail(GS_ERR_ARG, "gs_len: handle has no length");
     }
-  });
+  }, true, true, h);
 }
 
 int gs_g1_upload(const uint64_t* jac, size_t n, gs_handle* out) {
-  return guarded([&](Ctx& c) { return upload_bases<FqTag>(c, Kind::G1Bases, jac, n, out); });
+  return guarded([&](Ctx& c) { return upload_bases<FqTag>(c, Kind::G1Bases, jac, n, out); }, true, true);
 }
 int gs_g2_upload(const uint64_t* jac, size_t n, gs_handle* out) {
-  return guarded([&](Ctx& c) { return upload_bases<Fq2Tag>(c, Kind::G2Bases, jac, n, out); });
+  return guarded([&](Ctx& c) { return upload_bases<Fq2Tag>(c, Kind::G2Bases, jac, n, out); }, true, true);
 }
 int gs_g1_download(gs_handle h, uint64_t* jac, size_t n) {
-  return guarded([&](Ctx& c) { return download_bases<FqTag>(c, Kind::G1Bases, h, jac, n); });
+  return guarded([&](Ctx& c) { return download_bases<FqTag>(c, Kind::G1Bases, h, jac, n); }, true, true, h);
 }
 int gs_g2_download(gs_handle h, uint64_t* jac, size_t n) {
-  return guarded([&](Ctx& c) { return download_bases<Fq2Tag>(c, Kind::G2Bases, h, jac, n); });
+  return guarded([&](Ctx& c) { return download_bases<Fq2Tag>(c, Kind::G2Bases, h, jac, n); }, true, true, h);
 }
 int gs_g1_fixed_base(const uint64_t* s, size_t n, gs_handle* out) {
   return guarded([&](Ctx& c) { return fixed_base_api<FqTag>(c, Kind::G1Bases, s, n, out); });
@@ -342,7 +401,7 @@ int gs_scalars_upload(const uint64_t* s, size_t n, gs_handle* out) {
     if (n) GS_HIP(hipMemcpy(o->buf.p, s, n * 32, hipMemcpyHostToDevice));
     *out = c.put(std::move(o));
     return GS_OK;
-  });
+  }, true, true);
 }
 int gs_scalars_download(gs_handle h, uint64_t* out, size_t n) {
   return guarded([&](Ctx& c) -> int {
@@ -351,14 +410,46 @@ int gs_scalars_download(gs_handle h, uint64_t* out, size_t n) {
     GS_HIP(hipStreamSynchronize(c.stream));
     if (n) GS_HIP(hipMemcpy(out, s->buf.p, n * 32, hipMemcpyDeviceToHost));
     return GS_OK;
-  });
+  }, true, true, h);
 }
 
+// Copies onto another logical device (the source may live on any device: the handle says where).
+int gs_scalars_clone(gs_handle h, size_t off, size_t n, int target_device, gs_handle* out) {
+  return guarded_pair(h, target_device, [&](Ctx& src, Ctx& dst) -> int {
+    Scalars* s = src.get<Scalars>(h, Kind::Scalars);
+    if (!s || !out) return fail(GS_ERR_ARG, "gs_scalars_clone: bad handle or null output");
+    if (off > s->n || n > s->n - off) return fail(GS_ERR_ARG, "gs_scalars_clone: range [%zu, %zu) exceeds the %zu resident scalars", off, off + n, s->n);
+    auto o = std::make_unique<Scalars>();
+    o->n = n;
+    o->buf.alloc(std::max<size_t>(n, 1) * 32);
+    if (n) GS_HIP(hipMemcpyAsync(o->buf.p, s->buf.as<uint32_t>() + off * 8, n * 32, hipMemcpyDeviceToDevice, dst.stream));
+    GS_HIP(hipStreamSynchronize(dst.stream));
+    *out = dst.put(std::move(o));
+    return GS_OK;
+  });
+}
+static int bases_clone(Kind kind, size_t words, gs_handle h, size_t off, size_t n, int target_device, gs_handle* out) {
+  return guarded_pair(h, target_device, [&](Ctx& src, Ctx& dst) -> int {
+    Bases* b = src.get<Bases>(h, kind);
+    if (!b || !out) return fail(GS_ERR_ARG, "gs_bases_clone: bad handle or null output");
+    if (off > b->n || n > b->n - off) return fail(GS_ERR_ARG, "gs_bases_clone: range [%zu, %zu) exceeds the %zu resident points", off, off + n, b->n);
+    auto o = std::make_unique<Bases>(kind);
+    o->n = n;
+    o->buf.alloc(std::max<size_t>(n, 1) * words * 4);
+    if (n) GS_HIP(hipMemcpyAsync(o->buf.p, b->buf.as<uint32_t>() + off * words, n * words * 4, hipMemcpyDeviceToDevice, dst.stream));
+    GS_HIP(hipStreamSynchronize(dst.stream));
+    *out = dst.put(std::move(o));
+    return GS_OK;
+  });
+}
+int gs_g1_clone(gs_handle h, size_t off, size_t n, int target_device, gs_handle* out) { return bases_clone(Kind::G1Bases, 16, h, off, n, target_device, out); }
+int gs_g2_clone(gs_handle h, size_t off, size_t n, int target_device, gs_handle* out) { return bases_clone(Kind::G2Bases, 32, h, off, n, target_device, out); }
+
 int gs_msm_g1(gs_handle bases, const uint64_t* scalars, size_t off, size_t n, uint64_t out_affine[8], int* is_inf) {
-  return guarded([&](Ctx& c) { return msm_host_scalars<FqTag>(c, Kind::G1Bases, bases, scalars, off, n, out_affine, is_inf); });
+  return guarded([&](Ctx& c) { return msm_host_scalars<FqTag>(c, Kind::G1Bases, bases, scalars, off, n, out_affine, is_inf); }, true, false, bases);
 }
 int gs_msm_g2(gs_handle bases, const uint64_t* scalars, size_t off, size_t n, uint64_t out_affine[16], int* is_inf) {
-  return guarded([&](Ctx& c) { return msm_host_scalars<Fq2Tag>(c, Kind::G2Bases, bases, scalars, off, n, out_affine, is_inf); });
+  return guarded([&](Ctx& c) { return msm_host_scalars<Fq2Tag>(c, Kind::G2Bases, bases, scalars, off, n, out_affine, is_inf); }, true, false, bases);
 }
 int gs_msm_g1_resident(gs_handle bases, size_t off, gs_handle scalars, size_t soff, size_t n, uint64_t out_affine[8], int* is_inf) {
   return guarded([&](Ctx& c) -> int {
@@ -366,7 +457,7 @@ int gs_msm_g1_resident(gs_handle bases, size_t off, gs_handle scalars, size_t so
     if (!s || soff > s->n || n > s->n - soff) return fail(GS_ERR_ARG, "bad scalar handle or range");
     reset_timing(c);
     return msm_resident<FqTag>(c, Kind::G1Bases, bases, off, s->buf.as<uint32_t>() + soff * 8, n, out_affine, is_inf);
-  });
+  }, true, false, bases);
 }
 int gs_msm_g2_resident(gs_handle bases, size_t off, gs_handle scalars, size_t soff, size_t n, uint64_t out_affine[16], int* is_inf) {
   return guarded([&](Ctx& c) -> int {
@@ -374,17 +465,17 @@ int gs_msm_g2_resident(gs_handle bases, size_t off, gs_handle scalars, size_t so
     if (!s || soff > s->n || n > s->n - soff) return fail(GS_ERR_ARG, "bad scalar handle or range");
     reset_timing(c);
     return msm_resident<Fq2Tag>(c, Kind::G2Bases, bases, off, s->buf.as<uint32_t>() + soff * 8, n, out_affine, is_inf);
-  });
+  }, true, false, bases);
 }
 
 int gs_msm_g1_begin(gs_handle bases, size_t off, gs_handle scalars, size_t soff, size_t n, uint64_t* ticket) {
-  return guarded([&](Ctx& c) { return msm_begin<FqTag>(c, Kind::G1Bases, bases, off, scalars, soff, n, ticket); }, true, true);
+  return guarded([&](Ctx& c) { return msm_begin<FqTag>(c, Kind::G1Bases, bases, off, scalars, soff, n, ticket); }, true, true, bases);
 }
 int gs_msm_g2_begin(gs_handle bases, size_t off, gs_handle scalars, size_t soff, size_t n, uint64_t* ticket) {
-  return guarded([&](Ctx& c) { return msm_begin<Fq2Tag>(c, Kind::G2Bases, bases, off, scalars, soff, n, ticket); }, true, true);
+  return guarded([&](Ctx& c) { return msm_begin<Fq2Tag>(c, Kind::G2Bases, bases, off, scalars, soff, n, ticket); }, true, true, bases);
 }
 int gs_msm_end(uint64_t ticket, uint64_t* out_affine, int* is_inf) {
-  return guarded([&](Ctx& c) { return msm_end(c, ticket, out_affine, is_inf); }, true, true);
+  return guarded([&](Ctx& c) { return msm_end(c, ticket, out_affine, is_inf); }, true, true, ticket);
 }
 
 int gs_g1_sum_affine(const uint64_t* pts, const int* inf, size_t n, uint64_t out[8], int* is_inf) {
@@ -402,12 +493,24 @@ int gs_last_timing(gs_timing* out) {
   }, true, true);
 }
 
+int gs_device_timing(int logical_device, gs_timing* out) {
+  if (!out) return fail(GS_ERR_ARG, "null");
+  Ctx& c = ctx_at(logical_device);
+  if (!c.ready) return fail(GS_ERR_ARG, "gs_device_timing: no logical device %d", logical_device);
+  std::lock_guard<std::mutex> lk(c.mu);
+  *out = c.timing;
+  return GS_OK;
+}
+
+// applies to every logical device (a process-wide tunable, like the environment switches)
 int gs_set_window_bits(int cbits) {
-  return guarded([&](Ctx& c) -> int {
-    if (cbits != 0 && (cbits < 8 || cbits > 17)) return fail(GS_ERR_ARG, "window bits must be 0 (auto) or 8..17");
-    c.window_bits = cbits;
-    return GS_OK;
-  });
+  if (cbits != 0 && (cbits < 8 || cbits > kMaxWindowBits)) return fail(GS_ERR_ARG, "window bits must be 0 (auto) or 8..%d", kMaxWindowBits);
+  if (registry().ctxs.empty()) return fail(GS_ERR_NOT_INIT, "gs_init has not been called (or failed)");
+  for (auto& pc : registry().ctxs) {
+    std::lock_guard<std::mutex> lk(pc->mu);
+    pc->window_bits = cbits;
+  }
+  return GS_OK;
 }
 
 }  // extern "C"

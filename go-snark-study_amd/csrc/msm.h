@@ -26,6 +26,7 @@ struct MsmPlan {                 // digits of one scalar vector, bucket-sorted (
   const uint32_t* heavy_count = nullptr;
 };
 
+constexpr int kMaxWindowBits = 17;
 int choose_window_bits(uint32_t n, int forced);
 
 // Window table of a base array: rows[j][i] = 2^(c j) * P_i (packed affine), j < W = 254 / c + 1.

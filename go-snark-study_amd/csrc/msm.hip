@@ -34,7 +34,12 @@ static void exclusive_scan(Ctx& c, PlanBuffers& pb, const uint32_t* in, uint32_t
   hipLaunchKernelGGL(k_scan_add, dim3(ntiles), dim3(kScanBlock), 0, c.stream, out, pb.tiles.as<uint32_t>(), n);
 }
 
-static PlanBuffers g_plan_slots[2 * Ctx::kMaxInFlight];          // (w, h) x operations in flight
+struct MsmState {                                  // per context (device memory belongs to one device)
+  PlanBuffers plan_slots[2 * Ctx::kSlots];         // (w, h) x slots
+  DevBuf table_scratch;                            // slab of the batched window-table builder
+  bool lds_attr_set = false;
+};
+static MsmState& msm_state(Ctx& c) { return c.state<MsmState>(c.msm_state); }
 
 // Chunk size of a plan = additions one accumulate thread performs back to back.  Small chunks mean more threads and shorter
 // serial chains (a 2^16-term MSM with 32-entry chunks is only 512 waves of 32 dependent additions), large chunks mean fewer
@@ -54,7 +59,8 @@ static uint32_t choose_chunk(uint64_t entries, uint32_t nbuckets, const std::vec
 }
 
 void build_plan(Ctx& c, int slot, const uint32_t* scalars_dev, uint32_t n, MsmPlan& plan, const std::vector<LaunchShape>& users) {
-  PlanBuffers& pb = g_plan_slots[slot % (2 * Ctx::kMaxInFlight)];
+  MsmState& ms = msm_state(c);
+  PlanBuffers& pb = ms.plan_slots[slot % (2 * Ctx::kSlots)];
   plan.n = n;
   plan.c = choose_window_bits(n, c.window_bits);
   plan.W = 254 / plan.c + 1;
@@ -79,11 +85,10 @@ void build_plan(Ctx& c, int slot, const uint32_t* scalars_dev, uint32_t n, MsmPl
   pb.heavy_list.ensure((size_t)kMaxHeavy * 4);
   pb.counters.ensure(16);
   const size_t lds = pp.packed ? (size_t)plan.B * 2 : (size_t)plan.B * 4;
-  static bool lds_attr_set = false;
-  if (!lds_attr_set) {       // B <= 2^15 counters = 128 KiB of the CU's 160 KiB LDS
+  if (!ms.lds_attr_set) {       // B <= 2^15 counters = 128 KiB of the CU's 160 KiB LDS
     GS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hist), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     GS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-    lds_attr_set = true;
+    ms.lds_attr_set = true;
   }
   GS_HIP(hipMemsetAsync(pb.totals.as<uint32_t>() + plan.nbuckets, 0, 4, c.stream));
   GS_HIP(hipMemsetAsync(pb.counters.p, 0, 16, c.stream));
@@ -125,7 +130,7 @@ static void ensure_table(Ctx& c, BaseTable& t, const uint32_t* row0, size_t n, i
       // slabs of 2^18 points: (W - 1) rows of [XYZZ | running product] raw limbs per point (<= 1.4 GiB for G2), reused per slab
       constexpr size_t sw = PointIO<T>::kXyzzWords + PointIO<T>::kXyzzWords / 4;
       const size_t slab = std::min<size_t>(n, (size_t)1 << 18);
-      static DevBuf scratch;
+      DevBuf& scratch = msm_state(c).table_scratch;
       scratch.ensure(slab * (size_t)(W - 1) * sw * 4);
       for (size_t first = 0; first < n; first += slab) {
         const size_t count = std::min(slab, n - first);
@@ -158,15 +163,15 @@ static void msm_enqueue(Ctx& c, const MsmPlan& plan, const std::vector<MsmBase>&
   const size_t out_bytes = (size_t)njobs * nblk * 2 * pw * 4;
   if (out_bytes > Ctx::kPinnedBytes) throw HipError{hipErrorInvalidValue, "MSM result staging too small", __LINE__};
   AccJobs jobs{};
-  DevBuf& outb = c.ws_out[ws_base % (8 * Ctx::kMaxInFlight)];
+  DevBuf& outb = c.ws_out[ws_base % Ctx::kWsSets];
   outb.ensure(out_bytes);
   for (int j = 0; j < njobs; ++j) {
     const BaseTable* t = bases[j].table;
     if (!t || t->c != plan.c || bases[j].off + plan.n > t->n)
       throw HipError{hipErrorInvalidValue, "MSM base table does not match the plan", __LINE__};
-    DevBuf& bk = c.ws_buckets[(ws_base + j) % (8 * Ctx::kMaxInFlight)];
-    DevBuf& mg = c.ws_chunks[(ws_base + j) % (8 * Ctx::kMaxInFlight)];
-    DevBuf& pt = c.ws_partials[(ws_base + j) % (8 * Ctx::kMaxInFlight)];
+    DevBuf& bk = c.ws_buckets[(ws_base + j) % Ctx::kWsSets];
+    DevBuf& mg = c.ws_chunks[(ws_base + j) % Ctx::kWsSets];
+    DevBuf& pt = c.ws_partials[(ws_base + j) % Ctx::kWsSets];
     bk.ensure((size_t)plan.nbuckets * pw * 4);
     mg.ensure((size_t)plan.B * pw * 4);
     pt.ensure((size_t)plan.maxchunks * 2 * pw * 4);
@@ -246,14 +251,14 @@ void msm_finish_g1(Ctx& c, const MsmPending& p, std::vector<G1Xyzz>& out) { msm_
 void msm_finish_g2(Ctx& c, const MsmPending& p, std::vector<G2Xyzz>& out) { msm_finish<Fq2Tag>(c, p, out); }
 void msm_run_g1(Ctx& c, const MsmPlan& plan, const std::vector<MsmBase>& bases, std::vector<G1Xyzz>& out) {
   MsmPending p;
-  msm_enqueue<FqTag>(c, plan, bases, 0, 0, p, nullptr);
+  msm_enqueue<FqTag>(c, plan, bases, 8 * Ctx::kBlockingSlot, 3 * Ctx::kBlockingSlot, p, nullptr);
   GS_HIP(hipStreamSynchronize(c.stream));
   msm_book_timing(c, p);
   msm_finish<FqTag>(c, p, out);
 }
 void msm_run_g2(Ctx& c, const MsmPlan& plan, const std::vector<MsmBase>& bases, std::vector<G2Xyzz>& out) {
   MsmPending p;
-  msm_enqueue<Fq2Tag>(c, plan, bases, 4, 0, p, nullptr);
+  msm_enqueue<Fq2Tag>(c, plan, bases, 8 * Ctx::kBlockingSlot + 4, 3 * Ctx::kBlockingSlot, p, nullptr);
   GS_HIP(hipStreamSynchronize(c.stream));
   msm_book_timing(c, p);
   msm_finish<Fq2Tag>(c, p, out);

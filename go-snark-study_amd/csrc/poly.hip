@@ -36,10 +36,30 @@ struct Twiddles {
   int logn = 0;              // tables serve transforms up to 2^logn
   DevBuf fwd, inv;           // omega^i, omega^-i for i < 2^(logn-1)
 };
-static Twiddles g_tw;
+// (node trees: see the subproduct-tree section below)
+struct NodeTree {
+  size_t n = 0, total = 0, pad = 0;
+  int L = 0;
+  std::vector<DevBuf> mspec;     // level j < L: spectra of the 2d-padded blocks, Montgomery, bit-reversed within each 2d block
+  DevBuf root;                   // low 2^L coefficients of x^pad * prod_{i=1}^{n} (x - i), Montgomery
+  DevBuf weights;                // n elements, Montgomery: 1 / prod_{k != j} (j - k), nodes j = 1..n
+  uint64_t stamp = 0;
+};
 
-static void ensure_twiddles(Ctx& c, int logn) {
-  if (logn <= g_tw.logn) return;
+// Everything the engine keeps between calls, per context (device memory belongs to one device).
+struct PolyState {
+  Twiddles tw;
+  DevBuf ws_a, ws_b, ws_c, ws_d;                 // product / quotient / series workspaces
+  NodeTree trees[2];
+  uint64_t tree_clock = 0;
+  DevBuf cur_a, cur_b, wide, nxt;                // interpolation workspaces (grow-only: no allocation on the per-proof path)
+  DevBuf long_rows;                              // k_spmv -> k_spmv_long hand-off
+};
+static PolyState& poly_state(Ctx& c) { return c.state<PolyState>(c.poly_state); }
+
+static Twiddles& ensure_twiddles(Ctx& c, int logn) {
+  Twiddles& tw = poly_state(c).tw;
+  if (logn <= tw.logn) return tw;
   if (logn > ModR::kTwoAdicity) throw HipError{hipErrorInvalidValue, "NTT size exceeds the 2-adicity of Fr (2^28)", __LINE__};
   logn = std::max(logn, 16);
   const uint32_t half = 1u << (logn - 1);
@@ -47,12 +67,13 @@ static void ensure_twiddles(Ctx& c, int logn) {
   Fe<ModR, 2> w, wi;
   for (int i = 0; i < NL; ++i) { w.l[i] = ModR::omega28_mont(i); wi.l[i] = ModR::omega28_inv_mont(i); }
   for (int i = 0; i < ModR::kTwoAdicity - logn; ++i) { w = sqr(w); wi = sqr(wi); }
-  g_tw.fwd.alloc((size_t)half * kTwWords * 4);
-  g_tw.inv.alloc((size_t)half * kTwWords * 4);
-  hipLaunchKernelGGL(k_twiddle_gen, grid1(half), dim3(256), 0, c.stream, g_tw.fwd.as<uint32_t>(), half, to_const(w));
-  hipLaunchKernelGGL(k_twiddle_gen, grid1(half), dim3(256), 0, c.stream, g_tw.inv.as<uint32_t>(), half, to_const(wi));
+  tw.fwd.alloc((size_t)half * kTwWords * 4);
+  tw.inv.alloc((size_t)half * kTwWords * 4);
+  hipLaunchKernelGGL(k_twiddle_gen, grid1(half), dim3(256), 0, c.stream, tw.fwd.as<uint32_t>(), half, to_const(w));
+  hipLaunchKernelGGL(k_twiddle_gen, grid1(half), dim3(256), 0, c.stream, tw.inv.as<uint32_t>(), half, to_const(wi));
   GS_HIP(hipGetLastError());
-  g_tw.logn = logn;
+  tw.logn = logn;
+  return tw;
 }
 
 void ntt_forward(Ctx& c, uint32_t* data, int logt, int logm) { ntt_forward_n(c, data, (size_t)1 << logt, logm); }
@@ -80,18 +101,18 @@ static std::vector<NttPass> ntt_schedule(size_t total, int logm) {
 
 void ntt_forward_n(Ctx& c, uint32_t* data, size_t total, int logm) {
   if (logm == 0 || total == 0) return;
-  ensure_twiddles(c, logm);
+  Twiddles& tw = ensure_twiddles(c, logm);
   for (const NttPass& p : ntt_schedule(total, logm))
-    hipLaunchKernelGGL(k_ntt_pass<false>, dim3(p.ntiles), dim3(256), 0, c.stream, data, g_tw.fwd.as<uint32_t>(), g_tw.logn, p.s_lo, p.k, p.clog);
+    hipLaunchKernelGGL(k_ntt_pass<false>, dim3(p.ntiles), dim3(256), 0, c.stream, data, tw.fwd.as<uint32_t>(), tw.logn, p.s_lo, p.k, p.clog);
   GS_HIP(hipGetLastError());
 }
 
 void ntt_inverse_unscaled_n(Ctx& c, uint32_t* data, size_t total, int logm) {
   if (logm == 0 || total == 0) return;
-  ensure_twiddles(c, logm);
+  Twiddles& tw = ensure_twiddles(c, logm);
   const std::vector<NttPass> sched = ntt_schedule(total, logm);
   for (auto it = sched.rbegin(); it != sched.rend(); ++it)
-    hipLaunchKernelGGL(k_ntt_pass<true>, dim3(it->ntiles), dim3(256), 0, c.stream, data, g_tw.inv.as<uint32_t>(), g_tw.logn, it->s_lo, it->k, it->clog);
+    hipLaunchKernelGGL(k_ntt_pass<true>, dim3(it->ntiles), dim3(256), 0, c.stream, data, tw.inv.as<uint32_t>(), tw.logn, it->s_lo, it->k, it->clog);
   GS_HIP(hipGetLastError());
 }
 
@@ -109,7 +130,6 @@ static void copy_padded(Ctx& c, const uint32_t* src, size_t n, uint32_t* dst, si
   if (total > n) GS_HIP(hipMemsetAsync(dst + n * 8, 0, (total - n) * 32, c.stream));
 }
 
-static DevBuf g_ws_a, g_ws_b, g_ws_c, g_ws_d;
 
 void poly_mul_dev(Ctx& c, const uint32_t* a, size_t na, Form fa, const uint32_t* b, size_t nb, Form fb, uint32_t* out) {
   if (na == 0 || nb == 0) return;
@@ -118,10 +138,10 @@ void poly_mul_dev(Ctx& c, const uint32_t* a, size_t na, Form fa, const uint32_t*
   const size_t N = (size_t)1 << logn;
   // mont*mont -> mont needs 1/N ; std*mont -> std needs 1/N ; std*std -> (ab/R) needs R/N
   const int extra = (fa == Form::Std && fb == Form::Std) ? 1 : 0;
-  g_ws_a.ensure(N * 32);
-  g_ws_b.ensure(N * 32);
-  uint32_t* A = g_ws_a.as<uint32_t>();
-  uint32_t* B = g_ws_b.as<uint32_t>();
+  poly_state(c).ws_a.ensure(N * 32);
+  poly_state(c).ws_b.ensure(N * 32);
+  uint32_t* A = poly_state(c).ws_a.as<uint32_t>();
+  uint32_t* B = poly_state(c).ws_b.as<uint32_t>();
   copy_padded(c, a, na, A, N);
   copy_padded(c, b, nb, B, N);
   ntt_forward(c, A, logn, logn);
@@ -154,10 +174,10 @@ void poly_inv_series_dev(Ctx& c, const uint32_t* f, size_t nf, size_t k, uint32_
     const size_t t2 = std::min(2 * t, k);
     const size_t fl = std::min(nf, t2);
     // e = f[:t2] * g[:t] (length fl + t - 1), keep the first t2 coefficients
-    g_ws_c.ensure((std::max(fl, t2) + t) * 32);
-    g_ws_d.ensure((t2 + t) * 32);
-    uint32_t* E = g_ws_c.as<uint32_t>();
-    uint32_t* U = g_ws_d.as<uint32_t>();
+    poly_state(c).ws_c.ensure((std::max(fl, t2) + t) * 32);
+    poly_state(c).ws_d.ensure((t2 + t) * 32);
+    uint32_t* E = poly_state(c).ws_c.as<uint32_t>();
+    uint32_t* U = poly_state(c).ws_d.as<uint32_t>();
     poly_mul_dev(c, f, fl, Form::Mont, g, t, Form::Mont, E);
     const size_t el = std::min(fl + t - 1, t2);
     hipLaunchKernelGGL(k_two_minus, grid1(t2), dim3(256), 0, c.stream, E, two, U, (uint32_t)el, (uint32_t)t2);
@@ -206,17 +226,17 @@ void poly_quotient_dev(Ctx& c, Divisor& d, const uint32_t* a, size_t na, uint32_
     d.logn_spec = logn;
     d.k_spec = k;
   }
-  g_ws_a.ensure(N * 32);
-  uint32_t* A = g_ws_a.as<uint32_t>();
+  poly_state(c).ws_a.ensure(N * 32);
+  uint32_t* A = poly_state(c).ws_a.as<uint32_t>();
   // A = rev(a)[:k] = a[na-1], a[na-2], ..., a[na-k]  zero padded to N   (standard form)
   hipLaunchKernelGGL(k_copy_reversed, grid1(N), dim3(256), 0, c.stream, a, (uint32_t)(na - k), (uint32_t)k, A, (uint32_t)N);
   ntt_forward(c, A, logn, logn);
   hipLaunchKernelGGL(k_pw_mul, grid1(N), dim3(256), 0, c.stream, A, d.inv_spec.as<uint32_t>(), A, (uint32_t)N);
   ntt_inverse_unscaled(c, A, logn, logn);
   // scale by 1/N and un-reverse the first k coefficients: quo[i] = A[k-1-i] / N
-  g_ws_b.ensure(k * 32);
-  hipLaunchKernelGGL(k_copy_reversed, grid1(k), dim3(256), 0, c.stream, A, 0u, (uint32_t)k, g_ws_b.as<uint32_t>(), (uint32_t)k);
-  hipLaunchKernelGGL(k_pw_mul_const, grid1(k), dim3(256), 0, c.stream, g_ws_b.as<uint32_t>(), inv_n_const(logn, 0), quo, (uint32_t)k);
+  poly_state(c).ws_b.ensure(k * 32);
+  hipLaunchKernelGGL(k_copy_reversed, grid1(k), dim3(256), 0, c.stream, A, 0u, (uint32_t)k, poly_state(c).ws_b.as<uint32_t>(), (uint32_t)k);
+  hipLaunchKernelGGL(k_pw_mul_const, grid1(k), dim3(256), 0, c.stream, poly_state(c).ws_b.as<uint32_t>(), inv_n_const(logn, 0), quo, (uint32_t)k);
   GS_HIP(hipGetLastError());
 }
 
@@ -225,16 +245,6 @@ void poly_quotient_dev(Ctx& c, Divisor& d, const uint32_t* a, size_t na, uint32_
 // (x - i) for i = 1..n and the factor x for the padding up to 2^L.  Kept per n (two most recent): the spectra of every
 // level (NTT of the zero-padded blocks, 2^(L+1) elements per level -- 1.3 GB at n = 2^20, which is what the HBM is for),
 // the root, and the barycentric weights 1 / M'(j).
-struct NodeTree {
-  size_t n = 0, total = 0, pad = 0;
-  int L = 0;
-  std::vector<DevBuf> mspec;     // level j < L: spectra of the 2d-padded blocks, Montgomery, bit-reversed within each 2d block
-  DevBuf root;                   // low 2^L coefficients of x^pad * prod_{i=1}^{n} (x - i), Montgomery
-  DevBuf weights;                // n elements, Montgomery: 1 / prod_{k != j} (j - k), nodes j = 1..n
-  uint64_t stamp = 0;
-};
-static NodeTree g_trees[2];
-static uint64_t g_tree_clock = 0;
 
 static void build_weights(Ctx& c, NodeTree& t) {
   // 1 / M'(j) = (-1)^(n-j) / ((j-1)! (n-j)!)        [cf. NewPolZeroAt's divisor, r1csqap.go:130-136, without its int overflow]
@@ -259,9 +269,10 @@ static void build_weights(Ctx& c, NodeTree& t) {
 
 static NodeTree& ensure_tree(Ctx& c, size_t n, bool need_weights) {
   NodeTree* t = nullptr;
-  for (auto& x : g_trees) if (x.n == n && x.root.p) t = &x;
+  PolyState& ps = poly_state(c);
+  for (auto& x : ps.trees) if (x.n == n && x.root.p) t = &x;
   if (!t) {
-    t = (g_trees[0].stamp <= g_trees[1].stamp) ? &g_trees[0] : &g_trees[1];
+    t = (ps.trees[0].stamp <= ps.trees[1].stamp) ? &ps.trees[0] : &ps.trees[1];
     *t = NodeTree{};
     t->n = n;
     t->L = ceil_log2(std::max<size_t>(n, 1));
@@ -291,7 +302,7 @@ static NodeTree& ensure_tree(Ctx& c, size_t n, bool need_weights) {
     t->root = std::move(cur);
   }
   if (need_weights && !t->weights.p) build_weights(c, *t);
-  t->stamp = ++g_tree_clock;
+  t->stamp = ++ps.tree_clock;
   return *t;
 }
 
@@ -315,7 +326,8 @@ void interpolate_dev(Ctx& c, const uint32_t* values_std, size_t n, size_t nvec, 
   if (n == 0 || nvec == 0) return;
   NodeTree& t = ensure_tree(c, n, true);
   const size_t total = t.total, all = total * nvec;
-  static DevBuf cur_a, cur_b, wide, nxt;      // grow-only workspaces (no allocation on the per-proof path)
+  PolyState& ps = poly_state(c);
+  DevBuf &cur_a = ps.cur_a, &cur_b = ps.cur_b, &wide = ps.wide, &nxt = ps.nxt;
   cur_a.ensure(all * 32); cur_b.ensure(all * 32); wide.ensure(2 * all * 32); nxt.ensure(all * 32);
   uint32_t* cur = cur_a.as<uint32_t>();
   uint32_t* other = cur_b.as<uint32_t>();
@@ -404,7 +416,7 @@ void fr_falling_product_words(const uint64_t x[4], size_t count, uint64_t out[4]
 void spmv_dev(Ctx& c, const uint32_t* rowptr, const uint32_t* col, const uint32_t* val_std, const uint32_t* x_mont, size_t nrows, size_t ncols,
               uint32_t* out_std) {
   if (nrows) {
-    static DevBuf long_rows;                 // [count | row indices]: filled by k_spmv, consumed by k_spmv_long (stream order)
+    DevBuf& long_rows = poly_state(c).long_rows;   // [count | row indices]: filled by k_spmv, consumed by k_spmv_long (stream order)
     long_rows.ensure((1 + kSpmvLongCap) * 4);
     GS_HIP(hipMemsetAsync(long_rows.p, 0, 4, c.stream));
     hipLaunchKernelGGL(k_spmv, grid1(nrows), dim3(256), 0, c.stream, rowptr, col, val_std, x_mont, (uint32_t)nrows, (uint32_t)ncols, out_std,
@@ -429,10 +441,10 @@ void poly_canon_dev(Ctx& c, uint32_t* x, size_t n, int mode) {
 void poly_eval_dev(Ctx& c, const uint32_t* v, size_t n, const uint64_t x[4], uint32_t* out_dev) {
   const uint32_t nchunks = (uint32_t)((n + kEvalChunk - 1) / kEvalChunk);
   if (nchunks == 0) { GS_HIP(hipMemsetAsync(out_dev, 0, 32, c.stream)); return; }
-  g_ws_c.ensure((size_t)nchunks * 32);
+  poly_state(c).ws_c.ensure((size_t)nchunks * 32);
   hipLaunchKernelGGL(k_eval_chunks, grid1(nchunks), dim3(256), 0, c.stream, v, (uint32_t)n, to_const(fr_from_words_mont(x)),
-                     g_ws_c.as<uint32_t>(), nchunks);
-  hipLaunchKernelGGL(k_sum_block, dim3(1), dim3(256), 0, c.stream, g_ws_c.as<uint32_t>(), nchunks, out_dev);
+                     poly_state(c).ws_c.as<uint32_t>(), nchunks);
+  hipLaunchKernelGGL(k_sum_block, dim3(1), dim3(256), 0, c.stream, poly_state(c).ws_c.as<uint32_t>(), nchunks, out_dev);
   GS_HIP(hipGetLastError());
 }
 

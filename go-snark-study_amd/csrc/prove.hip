@@ -32,8 +32,12 @@ struct DevScalars {            // a scalar vector used by a prove call (not owne
                                        // consumes it (px from the resident R1CS, behind the accumulations over w)
 };
 
-// hx = floor(px / Z) on the device, returned as a workspace pointer (standard form, nz-dependent length)
-DevBuf g_hx;
+// Per-context staging of the prover entry points (device memory belongs to one device).
+struct ProveState {
+  DevBuf hx[Ctx::kSlots];                       // hx = floor(px / Z), one per slot (standard form)
+  DevBuf up_w, up_px, up_a, up_b, up_o;         // uploads of host operands / results (blocking entry points only)
+};
+ProveState& prove_state(Ctx& c) { return c.state<ProveState>(c.prove_state); }
 
 size_t quotient_len(size_t npx, size_t nz) { return npx >= nz ? npx - nz + 1 : 0; }
 
@@ -97,6 +101,7 @@ static void groth16_tail_pre(GrothPkObj* pk, const uint64_t r[4], const uint64_t
 // in this call, so the aux streams must order themselves behind that point.
 int groth16_enqueue(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, const Shard& shard, int parity, bool wait_inputs, bool pipelined,
                     GrothInFlight& st) {
+  DevBuf& hxbuf = prove_state(c).hx[parity];
   if (w.n != pk->nvars) return fail(GS_ERR_SHAPE, "len(w) = %zu but the key has %zu variables", w.n, pk->nvars);
   const size_t nh = quotient_len(px.n, pk->nz);
   if (nh > pk->nptd)
@@ -120,7 +125,7 @@ int groth16_enqueue(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, const S
     ensure_table_g1(c, pk->t_bacdelta, pk->bacdelta.as<uint32_t>(), pk->n_w, cw);
     ensure_table_g2(c, pk->t_bacgamma2, pk->bacgamma2.as<uint32_t>(), pk->n_w, cw);
     ensure_table_g1(c, pk->t_ptd, pk->ptd.as<uint32_t>(), pk->n_h, ch);
-    g_hx.ensure(std::max<size_t>(nh, 1) * 32);
+    hxbuf.ensure(std::max<size_t>(nh, 1) * 32);
   }
   st.pk = pk;
   st.total = std::make_unique<PhaseTimer>(c.main_stream);
@@ -163,10 +168,10 @@ int groth16_enqueue(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, const S
     }
     st.tpoly = std::make_shared<PhaseTimer>(c.stream);
     if (px.produce) px.produce(c);                                             // r1csqap.go:161-210 on the sparse system
-    if (nh) poly_quotient_dev(c, pk->z, px.p, px.n, g_hx.as<uint32_t>());      // groth16.go:266
+    if (nh) poly_quotient_dev(c, pk->z, px.p, px.n, hxbuf.as<uint32_t>());      // groth16.go:266
     st.tpoly->stop();
     st.tplanh = std::make_shared<PhaseTimer>(c.stream);
-    build_plan(c, 1 + 2 * parity, g_hx.as<uint32_t>() + hlo * 8, (uint32_t)(hhi - hlo), plan_h, {{1, false}});
+    build_plan(c, 1 + 2 * parity, hxbuf.as<uint32_t>() + hlo * 8, (uint32_t)(hhi - hlo), plan_h, {{1, false}});
     st.tplanh->stop();
     GS_HIP(hipEventRecord(st.planh, c.stream));
   }
@@ -207,7 +212,7 @@ int groth16_collect(Ctx& c, GrothInFlight& st, GrothSums& sums) {
 
 int groth16_sums_impl(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, const Shard& shard, GrothSums& sums) {
   GrothInFlight st;
-  const int rc = groth16_enqueue(c, pk, w, px, shard, c.free_parity(), true, false, st);
+  const int rc = groth16_enqueue(c, pk, w, px, shard, Ctx::kBlockingSlot, true, false, st);
   if (rc != GS_OK) return rc;
   return groth16_collect(c, st, sums);
 }
@@ -279,6 +284,7 @@ struct PinInFlight : InFlightBase {
 // snark.GenerateProofs (snark.go:254-289): six G1 sums over w sharing one plan, one G2 sum over w, H(x) = px / Z, one G1 sum
 // over h.  Ticket `parity` owns plan slots 2p / 2p + 1, workspace sets 8p .. 8p + 7 and pinned slots 3p .. 3p + 2.
 int pinocchio_enqueue(Ctx& c, PinocchioPkObj* pk, DevScalars w, DevScalars px, int parity, bool wait_inputs, bool pipelined, PinInFlight& st) {
+  DevBuf& hxbuf = prove_state(c).hx[parity];
   if (w.n != pk->nvars) return fail(GS_ERR_SHAPE, "len(w) = %zu but the key has %zu variables", w.n, pk->nvars);
   const size_t nh = quotient_len(px.n, pk->nz);
   if (nh > pk->ng1t) return fail(GS_ERR_SHAPE, "len(hx) = %zu exceeds len(G1T) = %zu (snark.go:284-286)", nh, pk->ng1t);
@@ -292,7 +298,7 @@ int pinocchio_enqueue(Ctx& c, PinocchioPkObj* pk, DevScalars w, DevScalars px, i
     ensure_table_g1(c, pk->t_kp, pk->kp.as<uint32_t>(), pk->nvars, cw);
     ensure_table_g2(c, pk->t_b2, pk->b2.as<uint32_t>(), pk->nvars, cw);
     ensure_table_g1(c, pk->t_g1t, pk->g1t.as<uint32_t>(), pk->ng1t, ch);
-    g_hx.ensure(std::max<size_t>(nh, 1) * 32);
+    hxbuf.ensure(std::max<size_t>(nh, 1) * 32);
   }
   st.total = std::make_unique<PhaseTimer>(c.main_stream);
   if (wait_inputs) {
@@ -323,10 +329,10 @@ int pinocchio_enqueue(Ctx& c, PinocchioPkObj* pk, DevScalars w, DevScalars px, i
   {                                                              // aux 1 again: H(x), plan(h)
     StreamScope sc(c, c.aux_stream[1]);
     st.tpoly = std::make_shared<PhaseTimer>(c.stream);
-    if (nh) poly_quotient_dev(c, pk->z, px.p, px.n, g_hx.as<uint32_t>());      // snark.go:280
+    if (nh) poly_quotient_dev(c, pk->z, px.p, px.n, hxbuf.as<uint32_t>());      // snark.go:280
     st.tpoly->stop();
     st.tplanh = std::make_shared<PhaseTimer>(c.stream);
-    build_plan(c, 2 * parity + 1, g_hx.as<uint32_t>(), (uint32_t)nh, plan_h, {{1, false}});
+    build_plan(c, 2 * parity + 1, hxbuf.as<uint32_t>(), (uint32_t)nh, plan_h, {{1, false}});
     st.tplanh->stop();
     GS_HIP(hipEventRecord(st.planh, c.stream));
   }
@@ -372,7 +378,7 @@ int pinocchio_collect(Ctx& c, PinInFlight& st, uint64_t out[72], int inf[8]) {
 
 int pinocchio_prove_impl(Ctx& c, PinocchioPkObj* pk, DevScalars w, DevScalars px, uint64_t out[72], int inf[8]) {
   PinInFlight st;
-  const int rc = pinocchio_enqueue(c, pk, w, px, c.free_parity(), true, false, st);
+  const int rc = pinocchio_enqueue(c, pk, w, px, Ctx::kBlockingSlot, true, false, st);
   if (rc != GS_OK) return rc;
   return pinocchio_collect(c, st, out, inf);
 }
@@ -383,7 +389,6 @@ void force_infinity(Ctx& c, DevBuf& pts, size_t count, size_t words) {
 }
 
 // upload host scalars into a scratch buffer
-DevBuf g_up_w, g_up_px, g_up_a, g_up_b, g_up_o;
 const uint32_t* upload_tmp(Ctx& c, DevBuf& buf, const uint64_t* host, size_t n) {
   buf.ensure(std::max<size_t>(n, 1) * 32);
   if (n) {
@@ -408,13 +413,13 @@ int gs_poly_mul(const uint64_t* a, size_t na, const uint64_t* b, size_t nb, uint
   return guarded([&](Ctx& c) -> int {
     if (!a || !b || !out || na == 0 || nb == 0) return fail(GS_ERR_ARG, "gs_poly_mul: empty or null operand");
     if (na + nb > (1ull << 27)) return fail(GS_ERR_ARG, "gs_poly_mul: product too large");
-    const uint32_t* da = upload_tmp(c, g_up_a, a, na);
-    const uint32_t* db = upload_tmp(c, g_up_b, b, nb);
+    const uint32_t* da = upload_tmp(c, prove_state(c).up_a, a, na);
+    const uint32_t* db = upload_tmp(c, prove_state(c).up_b, b, nb);
     const size_t nr = na + nb - 1;
-    g_up_o.ensure(nr * 32);
-    poly_mul_dev(c, da, na, Form::Std, db, nb, Form::Std, g_up_o.as<uint32_t>());
-    poly_canon_dev(c, g_up_o.as<uint32_t>(), nr, 0);
-    download(c, out, g_up_o.p, nr);
+    prove_state(c).up_o.ensure(nr * 32);
+    poly_mul_dev(c, da, na, Form::Std, db, nb, Form::Std, prove_state(c).up_o.as<uint32_t>());
+    poly_canon_dev(c, prove_state(c).up_o.as<uint32_t>(), nr, 0);
+    download(c, out, prove_state(c).up_o.p, nr);
     return GS_OK;
   });
 }
@@ -425,13 +430,13 @@ int gs_poly_div(const uint64_t* a, size_t na, const uint64_t* b, size_t nb, uint
     bool lead_zero = true;
     for (int i = 0; i < 4; ++i) lead_zero = lead_zero && b[4 * (nb - 1) + i] == 0;
     if (lead_zero) return fail(GS_ERR_ARG, "gs_poly_div: leading coefficient of the divisor is zero");
-    const uint32_t* da = upload_tmp(c, g_up_a, a, na);
-    const uint32_t* db = upload_tmp(c, g_up_b, b, nb);
+    const uint32_t* da = upload_tmp(c, prove_state(c).up_a, a, na);
+    const uint32_t* db = upload_tmp(c, prove_state(c).up_b, b, nb);
     Divisor d;
     divisor_init(c, d, db, nb);
     const size_t nq = na - nb + 1;
-    g_up_o.ensure((nq + na + nb) * 32);
-    uint32_t* q = g_up_o.as<uint32_t>();
+    prove_state(c).up_o.ensure((nq + na + nb) * 32);
+    uint32_t* q = prove_state(c).up_o.as<uint32_t>();
     poly_quotient_dev(c, d, da, na, q);
     if (rem && nb > 1) {
       // rem = (a - q b) mod x^(nb-1)        (r1csqap.go:70-84 returns the final `rem`)
@@ -456,12 +461,12 @@ static int addsub_api(const uint64_t* a, size_t na, const uint64_t* b, size_t nb
     if ((na && !a) || (nb && !b) || !out) return fail(GS_ERR_ARG, "null operand");
     const size_t n = std::max(na, nb);
     if (n == 0) return GS_OK;
-    const uint32_t* da = upload_tmp(c, g_up_a, a, na);
-    const uint32_t* db = upload_tmp(c, g_up_b, b, nb);
-    g_up_o.ensure(n * 32);
-    poly_addsub_dev(c, da, na, db, nb, sub, g_up_o.as<uint32_t>());
-    poly_canon_dev(c, g_up_o.as<uint32_t>(), n, 0);
-    download(c, out, g_up_o.p, n);
+    const uint32_t* da = upload_tmp(c, prove_state(c).up_a, a, na);
+    const uint32_t* db = upload_tmp(c, prove_state(c).up_b, b, nb);
+    prove_state(c).up_o.ensure(n * 32);
+    poly_addsub_dev(c, da, na, db, nb, sub, prove_state(c).up_o.as<uint32_t>());
+    poly_canon_dev(c, prove_state(c).up_o.as<uint32_t>(), n, 0);
+    download(c, out, prove_state(c).up_o.p, n);
     return GS_OK;
   });
 }
@@ -471,10 +476,10 @@ int gs_poly_sub(const uint64_t* a, size_t na, const uint64_t* b, size_t nb, uint
 int gs_poly_eval(const uint64_t* v, size_t n, const uint64_t x[4], uint64_t out[4]) {
   return guarded([&](Ctx& c) -> int {
     if ((n && !v) || !x || !out) return fail(GS_ERR_ARG, "null operand");
-    const uint32_t* dv = upload_tmp(c, g_up_a, v, n);
-    g_up_o.ensure(32);
-    poly_eval_dev(c, dv, n, x, g_up_o.as<uint32_t>());
-    download(c, out, g_up_o.p, 1);
+    const uint32_t* dv = upload_tmp(c, prove_state(c).up_a, v, n);
+    prove_state(c).up_o.ensure(32);
+    poly_eval_dev(c, dv, n, x, prove_state(c).up_o.as<uint32_t>());
+    download(c, out, prove_state(c).up_o.p, 1);
     return GS_OK;
   });
 }
@@ -536,7 +541,7 @@ static int groth_pk_create_impl(Ctx& c, gs_handle g1_at, gs_handle g1_bacgamma, 
   pk->delta = g1_affine_from_jacobian_std(g1_delta);
   pk->beta2 = g2_affine_from_jacobian_std(g2_beta);
   pk->delta2 = g2_affine_from_jacobian_std(g2_delta);
-  const uint32_t* dz = upload_tmp(c, g_up_a, z, nz);
+  const uint32_t* dz = upload_tmp(c, prove_state(c).up_a, z, nz);
   divisor_init(c, pk->z, dz, nz);
   GS_HIP(hipStreamSynchronize(c.stream));
   *out = c.put(std::move(pk));
@@ -550,7 +555,7 @@ int gs_groth16_pk_create(gs_handle g1_at, gs_handle g1_bacgamma, gs_handle g2_ba
   return guarded([&](Ctx& c) -> int {
     return groth_pk_create_impl(c, g1_at, g1_bacgamma, g2_bacgamma, bacdelta, ptd, g1_alpha, g1_beta, g1_delta, g2_beta, g2_delta, z, nz,
                                 nvars, npublic, 0, 0, 1, out);
-  });
+  }, true, false, g1_at);
 }
 
 int gs_groth16_pk_create_shard(gs_handle g1_at, gs_handle g1_bacgamma, gs_handle g2_bacgamma, gs_handle bacdelta, gs_handle ptd,
@@ -560,27 +565,37 @@ int gs_groth16_pk_create_shard(gs_handle g1_at, gs_handle g1_bacgamma, gs_handle
   return guarded([&](Ctx& c) -> int {
     return groth_pk_create_impl(c, g1_at, g1_bacgamma, g2_bacgamma, bacdelta, ptd, g1_alpha, g1_beta, g1_delta, g2_beta, g2_delta, z, nz,
                                 nvars, npublic, nptd_total, shard_index, shard_count, out);
-  });
+  }, true, false, g1_at);
 }
 
 // A slice of a resident full key (device-to-device copies): what each rank keeps when the full key was built or loaded
-// locally; the caller then frees the full key.
+// locally; the caller then frees the full key.  `c` is the context the slice is created on -- the key's own, or another
+// logical device's (gs_groth16_pk_shard_to: the copies then cross xGMI, or stay on the GPU when both share one).
+static int groth_pk_shard_impl(Ctx& c, GrothPkObj* full, size_t shard_index, size_t shard_count, gs_handle* out) {
+  if (!full || !out) return fail(GS_ERR_ARG, "gs_groth16_pk_shard: bad proving-key handle or null output");
+  if (full->shard_count != 1) return fail(GS_ERR_ARG, "gs_groth16_pk_shard: the source key is itself a slice");
+  if (shard_count == 0 || shard_index >= shard_count) return fail(GS_ERR_ARG, "gs_groth16_pk_shard: bad shard %zu of %zu", shard_index, shard_count);
+  auto pk = std::make_unique<GrothPkObj>();
+  pk->nvars = full->nvars; pk->npublic = full->npublic; pk->nz = full->nz; pk->nptd = full->nptd;
+  set_shard(*pk, shard_index, shard_count);
+  groth_pk_fill(c, *pk, PkSrc{&full->at, pk->w_lo}, PkSrc{&full->bacgamma1, pk->w_lo}, PkSrc{&full->bacgamma2, pk->w_lo},
+                PkSrc{&full->bacdelta, pk->w_lo}, PkSrc{&full->ptd, pk->h_lo});
+  pk->alpha = full->alpha; pk->beta = full->beta; pk->delta = full->delta; pk->beta2 = full->beta2; pk->delta2 = full->delta2;
+  divisor_init(c, pk->z, full->z.b_std.as<uint32_t>(), full->nz);
+  GS_HIP(hipStreamSynchronize(c.stream));
+  *out = c.put(std::move(pk));
+  return GS_OK;
+}
+
 int gs_groth16_pk_shard(gs_handle hfull, size_t shard_index, size_t shard_count, gs_handle* out) {
   return guarded([&](Ctx& c) -> int {
-    GrothPkObj* full = c.get<GrothPkObj>(hfull, Kind::GrothPk);
-    if (!full || !out) return fail(GS_ERR_ARG, "gs_groth16_pk_shard: bad proving-key handle or null output");
-    if (full->shard_count != 1) return fail(GS_ERR_ARG, "gs_groth16_pk_shard: the source key is itself a slice");
-    if (shard_count == 0 || shard_index >= shard_count) return fail(GS_ERR_ARG, "gs_groth16_pk_shard: bad shard %zu of %zu", shard_index, shard_count);
-    auto pk = std::make_unique<GrothPkObj>();
-    pk->nvars = full->nvars; pk->npublic = full->npublic; pk->nz = full->nz; pk->nptd = full->nptd;
-    set_shard(*pk, shard_index, shard_count);
-    groth_pk_fill(c, *pk, PkSrc{&full->at, pk->w_lo}, PkSrc{&full->bacgamma1, pk->w_lo}, PkSrc{&full->bacgamma2, pk->w_lo},
-                  PkSrc{&full->bacdelta, pk->w_lo}, PkSrc{&full->ptd, pk->h_lo});
-    pk->alpha = full->alpha; pk->beta = full->beta; pk->delta = full->delta; pk->beta2 = full->beta2; pk->delta2 = full->delta2;
-    divisor_init(c, pk->z, full->z.b_std.as<uint32_t>(), full->nz);
-    GS_HIP(hipStreamSynchronize(c.stream));
-    *out = c.put(std::move(pk));
-    return GS_OK;
+    return groth_pk_shard_impl(c, c.get<GrothPkObj>(hfull, Kind::GrothPk), shard_index, shard_count, out);
+  }, true, false, hfull);
+}
+
+int gs_groth16_pk_shard_to(gs_handle hfull, size_t shard_index, size_t shard_count, int target_device, gs_handle* out) {
+  return guarded_pair(hfull, target_device, [&](Ctx& src, Ctx& dst) -> int {
+    return groth_pk_shard_impl(dst, src.get<GrothPkObj>(hfull, Kind::GrothPk), shard_index, shard_count, out);
   });
 }
 
@@ -591,11 +606,11 @@ int gs_groth16_prove(gs_handle hpk, const uint64_t* w, size_t nw, const uint64_t
     if (!pk) return fail(GS_ERR_ARG, "gs_groth16_prove: bad proving-key handle");
     if (!w || !px || !r || !s || !out_proof || !inf) return fail(GS_ERR_ARG, "null argument");
     reset_timing(c);
-    DevScalars dw{upload_tmp(c, g_up_w, w, nw), nw};
-    g_up_px.ensure(std::max<size_t>(npx, 1) * 32);
-    DevScalars dp{g_up_px.as<uint32_t>(), npx, px};               // copied inside, behind the work that only needs w
+    DevScalars dw{upload_tmp(c, prove_state(c).up_w, w, nw), nw};
+    prove_state(c).up_px.ensure(std::max<size_t>(npx, 1) * 32);
+    DevScalars dp{prove_state(c).up_px.as<uint32_t>(), npx, px};               // copied inside, behind the work that only needs w
     return groth16_prove_impl(c, pk, dw, dp, r, s, out_proof, inf);
-  });
+  }, true, false, hpk);
 }
 
 int gs_groth16_prove_resident(gs_handle hpk, gs_handle hw, gs_handle hpx, const uint64_t r[4], const uint64_t s[4],
@@ -608,7 +623,7 @@ int gs_groth16_prove_resident(gs_handle hpk, gs_handle hw, gs_handle hpx, const 
     if (!r || !s || !out_proof || !inf) return fail(GS_ERR_ARG, "null argument");
     reset_timing(c);
     return groth16_prove_impl(c, pk, DevScalars{w->buf.as<uint32_t>(), w->n}, DevScalars{px->buf.as<uint32_t>(), px->n}, r, s, out_proof, inf);
-  });
+  }, true, false, hpk);
 }
 
 // Pipelined proving: begin enqueues a whole proof and returns; end waits for THAT proof only and runs its tail.  With two
@@ -622,20 +637,21 @@ int gs_groth16_prove_begin(gs_handle hpk, gs_handle hw, gs_handle hpx, const uin
     if (!pk || !w || !px) return fail(GS_ERR_ARG, "gs_groth16_prove_begin: bad handle");
     if (!r || !s || !ticket) return fail(GS_ERR_ARG, "null argument");
     const int parity = c.free_parity();
-    if (parity < 0) return fail(GS_ERR_ARG, "gs_groth16_prove_begin: three operations are already outstanding; call gs_groth16_prove_end first");
+    if (parity < 0) return fail(GS_ERR_BUSY, "gs_groth16_prove_begin: three operations are already outstanding; call gs_groth16_prove_end first");
     auto st = std::make_unique<GrothInFlight>();
     memcpy(st->r, r, 32); memcpy(st->s, s, 32);
     st->with_tail = true;
     GrothInFlight* raw = st.get();
     raw->pk = pk;
+    raw->keep = {c.share<Object>(hpk, Kind::GrothPk), c.share<Object>(hw, Kind::Scalars), c.share<Object>(hpx, Kind::Scalars)};
     raw->fpre = std::async(std::launch::async, [raw] { groth16_tail_pre(raw->pk, raw->r, raw->s, raw->pre); });
     const int rc = groth16_enqueue(c, pk, DevScalars{w->buf.as<uint32_t>(), w->n}, DevScalars{px->buf.as<uint32_t>(), px->n}, Shard{}, parity, false, true, *raw);
     if (rc != GS_OK) return rc;
-    st->ticket = c.next_ticket++;
+    st->ticket = c.new_ticket();
     *ticket = st->ticket;
     c.inflight[parity] = std::move(st);
     return GS_OK;
-  }, true, true);
+  }, true, true, hpk);
 }
 
 int gs_groth16_prove_end(uint64_t ticket, uint64_t out_proof[32], int inf[3]) {
@@ -655,7 +671,7 @@ int gs_groth16_prove_end(uint64_t ticket, uint64_t out_proof[32], int inf[3]) {
     st.fpre.get();
     groth16_tail_post(st.pk, sums, st.pre, st.r, st.s, out_proof, inf);
     return GS_OK;
-  }, true, true);
+  }, true, true, ticket);
 }
 
 // Sharded proving: the five raw sums over this rank's term ranges, as affine points.
@@ -678,7 +694,7 @@ int gs_groth16_prove_partials(gs_handle hpk, gs_handle hw, gs_handle hpx, size_t
     inf[3] = g1_to_affine_std(sums.bacdelta, out_sums + 32) ? 1 : 0;
     inf[4] = g1_to_affine_std(sums.h, out_sums + 40) ? 1 : 0;
     return GS_OK;
-  });
+  }, true, false, hpk);
 }
 
 // ... and the O(1) tail of groth16.go:253-275 on the combined sums (same layout as gs_groth16_prove_partials emits).
@@ -709,7 +725,7 @@ int gs_groth16_finish(gs_handle hpk, const uint64_t sums_in[48], const int inf_i
     sums.h = g1(sums_in + 40, inf_in[4]);
     groth16_tail(pk, sums, r, s, out_proof, inf);
     return GS_OK;
-  });
+  }, true, false, hpk);
 }
 
 // ---- Pinocchio ----------------------------------------------------------------------------------------------
@@ -741,12 +757,12 @@ int gs_pinocchio_pk_create(gs_handle a, gs_handle ap, gs_handle b_g2, gs_handle 
     copy_points(c, B, kG2Aff, pk->b2);
     force_infinity(c, pk->a, npublic + 1, kG1Aff);                 // snark.go:265
     force_infinity(c, pk->ap, npublic + 1, kG1Aff);
-    const uint32_t* dz = upload_tmp(c, g_up_a, z, nz);
+    const uint32_t* dz = upload_tmp(c, prove_state(c).up_a, z, nz);
     divisor_init(c, pk->z, dz, nz);
     GS_HIP(hipStreamSynchronize(c.stream));
     *out = c.put(std::move(pk));
     return GS_OK;
-  });
+  }, true, false, a);
 }
 
 int gs_pinocchio_prove(gs_handle hpk, const uint64_t* w, size_t nw, const uint64_t* px, size_t npx, uint64_t out_proof[72], int inf[8]) {
@@ -755,10 +771,10 @@ int gs_pinocchio_prove(gs_handle hpk, const uint64_t* w, size_t nw, const uint64
     if (!pk) return fail(GS_ERR_ARG, "gs_pinocchio_prove: bad proving-key handle");
     if (!w || !px || !out_proof || !inf) return fail(GS_ERR_ARG, "null argument");
     reset_timing(c);
-    DevScalars dw{upload_tmp(c, g_up_w, w, nw), nw};
-    DevScalars dp{upload_tmp(c, g_up_px, px, npx), npx};
+    DevScalars dw{upload_tmp(c, prove_state(c).up_w, w, nw), nw};
+    DevScalars dp{upload_tmp(c, prove_state(c).up_px, px, npx), npx};
     return pinocchio_prove_impl(c, pk, dw, dp, out_proof, inf);
-  });
+  }, true, false, hpk);
 }
 
 // Pipelined Pinocchio proving: same ticket discipline as gs_groth16_prove_begin / _end (they share the three slots).
@@ -769,15 +785,16 @@ int gs_pinocchio_prove_begin(gs_handle hpk, gs_handle hw, gs_handle hpx, uint64_
     Scalars* px = c.get<Scalars>(hpx, Kind::Scalars);
     if (!pk || !w || !px || !ticket) return fail(GS_ERR_ARG, "gs_pinocchio_prove_begin: bad handle or null ticket");
     const int parity = c.free_parity();
-    if (parity < 0) return fail(GS_ERR_ARG, "gs_pinocchio_prove_begin: three operations are already outstanding; call gs_pinocchio_prove_end first");
+    if (parity < 0) return fail(GS_ERR_BUSY, "gs_pinocchio_prove_begin: three operations are already outstanding; call gs_pinocchio_prove_end first");
     auto st = std::make_unique<PinInFlight>();
+    st->keep = {c.share<Object>(hpk, Kind::PinocchioPk), c.share<Object>(hw, Kind::Scalars), c.share<Object>(hpx, Kind::Scalars)};
     const int rc = pinocchio_enqueue(c, pk, DevScalars{w->buf.as<uint32_t>(), w->n}, DevScalars{px->buf.as<uint32_t>(), px->n}, parity, false, true, *st);
     if (rc != GS_OK) return rc;
-    st->ticket = c.next_ticket++;
+    st->ticket = c.new_ticket();
     *ticket = st->ticket;
     c.inflight[parity] = std::move(st);
     return GS_OK;
-  }, true, true);
+  }, true, true, hpk);
 }
 
 int gs_pinocchio_prove_end(uint64_t ticket, uint64_t out_proof[72], int inf[8]) {
@@ -791,7 +808,7 @@ int gs_pinocchio_prove_end(uint64_t ticket, uint64_t out_proof[72], int inf[8]) 
     std::unique_ptr<InFlightBase> base = std::move(c.inflight[parity]);
     reset_timing(c);
     return pinocchio_collect(c, static_cast<PinInFlight&>(*base), out_proof, inf);
-  }, true, true);
+  }, true, true, ticket);
 }
 
 int gs_pinocchio_prove_resident(gs_handle hpk, gs_handle hw, gs_handle hpx, uint64_t out_proof[72], int inf[8]) {
@@ -803,7 +820,7 @@ int gs_pinocchio_prove_resident(gs_handle hpk, gs_handle hw, gs_handle hpx, uint
     if (!out_proof || !inf) return fail(GS_ERR_ARG, "null argument");
     reset_timing(c);
     return pinocchio_prove_impl(c, pk, DevScalars{w->buf.as<uint32_t>(), w->n}, DevScalars{px->buf.as<uint32_t>(), px->n}, out_proof, inf);
-  });
+  }, true, false, hpk);
 }
 
 // PolynomialField.LagrangeInterpolation (r1csqap.go:150-158): n values at the nodes 1..n -> n coefficients.
@@ -812,11 +829,11 @@ int gs_lagrange_interpolation(const uint64_t* values, size_t n, uint64_t* coeffs
     if (n == 0) return GS_OK;
     if (!values || !coeffs) return fail(GS_ERR_ARG, "gs_lagrange_interpolation: null argument");
     if (n >= (1ull << 26)) return fail(GS_ERR_ARG, "gs_lagrange_interpolation: too many nodes");
-    const uint32_t* dv = upload_tmp(c, g_up_a, values, n);
-    g_up_o.ensure(n * 32);
-    interpolate_dev(c, dv, n, 1, g_up_o.as<uint32_t>());
-    poly_canon_dev(c, g_up_o.as<uint32_t>(), n, 0);
-    download(c, coeffs, g_up_o.p, n);
+    const uint32_t* dv = upload_tmp(c, prove_state(c).up_a, values, n);
+    prove_state(c).up_o.ensure(n * 32);
+    interpolate_dev(c, dv, n, 1, prove_state(c).up_o.as<uint32_t>());
+    poly_canon_dev(c, prove_state(c).up_o.as<uint32_t>(), n, 0);
+    download(c, coeffs, prove_state(c).up_o.p, n);
     return GS_OK;
   });
 }
@@ -825,9 +842,9 @@ int gs_zpoly(size_t deg, uint64_t* out) {
   return guarded([&](Ctx& c) -> int {
     if (!out) return fail(GS_ERR_ARG, "gs_zpoly: null output");
     if (deg >= (1ull << 26)) return fail(GS_ERR_ARG, "gs_zpoly: degree too large");
-    g_up_o.ensure((deg + 1) * 32);
-    zpoly_dev(c, deg, g_up_o.as<uint32_t>());
-    download(c, out, g_up_o.p, deg + 1);
+    prove_state(c).up_o.ensure((deg + 1) * 32);
+    zpoly_dev(c, deg, prove_state(c).up_o.as<uint32_t>());
+    download(c, out, prove_state(c).up_o.p, deg + 1);
     return GS_OK;
   });
 }
@@ -901,14 +918,14 @@ int gs_r1cs_to_px(size_t n, size_t m,
     const int rc = r1cs_upload_impl(c, n, m, rp, cl, vl, o);
     if (rc != GS_OK) return rc;
     const size_t npx = 2 * n - 1;
-    const uint32_t* dw = upload_tmp(c, g_up_w, w, m);
-    g_up_o.ensure(npx * 32);
-    r1cs_px_dev(c, o, dw, g_up_o.as<uint32_t>());
+    const uint32_t* dw = upload_tmp(c, prove_state(c).up_w, w, m);
+    prove_state(c).up_o.ensure(npx * 32);
+    r1cs_px_dev(c, o, dw, prove_state(c).up_o.as<uint32_t>());
     const uint32_t* A = o.coef.as<uint32_t>();
     if (ax) GS_HIP(hipMemcpyAsync(ax, A, n * 32, hipMemcpyDeviceToHost, c.stream));
     if (bx) GS_HIP(hipMemcpyAsync(bx, A + n * 8, n * 32, hipMemcpyDeviceToHost, c.stream));
     if (cx) GS_HIP(hipMemcpyAsync(cx, A + 2 * n * 8, n * 32, hipMemcpyDeviceToHost, c.stream));
-    GS_HIP(hipMemcpyAsync(px, g_up_o.p, npx * 32, hipMemcpyDeviceToHost, c.stream));
+    GS_HIP(hipMemcpyAsync(px, prove_state(c).up_o.p, npx * 32, hipMemcpyDeviceToHost, c.stream));
     GS_HIP(hipStreamSynchronize(c.stream));
     return GS_OK;
   });
@@ -952,15 +969,18 @@ int gs_r1cs_px(gs_handle hr1cs, gs_handle hw, gs_handle* px_inout) {
       px = fresh.get();
       *px_inout = c.put(std::move(fresh));
     }
+    // On the stream that carries every proof's polynomial stage: stream order keeps the engine's workspaces consistent, so
+    // the px of proof k+1 may be computed while proofs are in flight (it queues behind their H(x), not behind their MSMs).
+    StreamScope sc(c, c.aux_stream[1]);
     PhaseTimer t(c.stream);
     r1cs_px_dev(c, *o, w->buf.as<uint32_t>(), px->buf.as<uint32_t>());
     t.stop();
     GS_HIP(hipStreamSynchronize(c.stream));
-    reset_timing(c);
+    if (!c.any_inflight()) reset_timing(c);
     c.timing.poly_ms = t.ms();
     c.timing.total_ms = c.timing.poly_ms;
     return GS_OK;
-  });
+  }, true, true, hr1cs);
 }
 
 // R1CS + witness -> proof in one call: the px stage (three interpolations and a product, r1csqap.go:161-210) runs on the aux
@@ -993,7 +1013,7 @@ int gs_groth16_prove_r1cs(gs_handle hpk, gs_handle hr1cs, gs_handle hw, gs_handl
     uint32_t* pxdev = px->buf.as<uint32_t>();
     dp.produce = [o, wdev, pxdev](Ctx& cc) { r1cs_px_dev(cc, *o, wdev, pxdev); };
     return groth16_prove_impl(c, pk, DevScalars{wdev, w->n}, dp, r, s, out_proof, inf);
-  });
+  }, true, false, hpk);
 }
 
 }  // extern "C"

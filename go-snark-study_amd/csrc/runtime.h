@@ -103,30 +103,44 @@ struct Scalars : Object {        // n x 8 u32 words, standard form, resident
 // a proof whose device work has been enqueued but not collected yet (prove.hip)
 struct InFlightBase {
   uint64_t ticket = 0;
+  std::vector<std::shared_ptr<Object>> keep;   // the key and scalar vectors this operation reads: gs_free on them is deferred
   virtual ~InFlightBase() = default;
 };
 
+// Handles carry the logical device they live on in their top byte (logical device 0 handles are the small integers they
+// always were); every context owns its objects, streams, workspaces and lock.
+constexpr int kHandleDevShift = 56;
+constexpr int kMaxLogicalDevices = 64;
+inline int handle_device(gs_handle h) { return (int)(h >> kHandleDevShift); }
+
 struct Ctx {
-  int device = -1;
+  int logical = 0;                // index in gs_init's device list (several entries may name the same physical device)
+  int device = -1;                // HIP ordinal
   bool ready = false;
   hipStream_t stream = nullptr;   // the stream every engine function enqueues on (switched by StreamScope)
   hipStream_t main_stream = nullptr, aux_stream[3] = {nullptr, nullptr, nullptr};
   static constexpr int kMaxInFlight = 3;             // pipelined operations (tickets); each owns one set of workspaces
-  void* pinned[3 * kMaxInFlight] = {};               // host staging of the result downloads (3 per operation in flight)
+  static constexpr int kSlots = kMaxInFlight + 1;    // + one set for the blocking entry points (serialised by `mu`), so a blocking
+  static constexpr int kBlockingSlot = kMaxInFlight; //   call made while tickets are outstanding never touches their result staging
+  void* pinned[3 * kSlots] = {};                     // host staging of the result downloads (3 per slot)
   std::unique_ptr<InFlightBase> inflight[kMaxInFlight];
   uint64_t next_ticket = 1;
+  uint64_t new_ticket() { return ((uint64_t)logical << kHandleDevShift) | next_ticket++; }
   int free_parity() const { for (int p = 0; p < kMaxInFlight; ++p) if (!inflight[p]) return p; return -1; }
   bool any_inflight() const { for (int p = 0; p < kMaxInFlight; ++p) if (inflight[p]) return true; return false; }
   static constexpr size_t kPinnedBytes = 256 * 1024;
   std::mutex mu;
   uint64_t next_handle = 1;
-  std::unordered_map<uint64_t, std::unique_ptr<Object>> objs;
+  std::unordered_map<uint64_t, std::shared_ptr<Object>> objs;     // in-flight operations hold references: gs_free defers
   int window_bits = 0;           // 0 = auto
   gs_timing timing{};
   std::mutex timing_mu;          // msm_finish of several groups may run on different host threads
   // reusable workspaces (grow-only)
-  DevBuf ws_hist, ws_offsets, ws_cursor, ws_entries, ws_tiles, ws_total;
-  DevBuf ws_buckets[8 * kMaxInFlight], ws_chunks[8 * kMaxInFlight], ws_partials[8 * kMaxInFlight], ws_out[8 * kMaxInFlight];   // 8 sets per ticket
+  static constexpr int kWsSets = 8 * kSlots;         // 8 workspace sets per slot
+  DevBuf ws_buckets[kWsSets], ws_chunks[kWsSets], ws_partials[kWsSets], ws_out[kWsSets];
+  // per-context state of the engines (plan buffers, NTT twiddles, node trees, staging buffers): device memory belongs to
+  // one device, so nothing of this may be a process-wide static
+  std::shared_ptr<void> msm_state, poly_state, prove_state;
   DevBuf ws_misc;
   DevBuf g1_pow2, g2_pow2;       // fixed-base window tables d * 2^(8 w) * G, 32 x 256 entries (lazy)
   std::vector<hipEvent_t> events;
@@ -136,29 +150,66 @@ struct Ctx {
     if (it == objs.end() || it->second->kind != k) return nullptr;
     return static_cast<O*>(it->second.get());
   }
-  gs_handle put(std::unique_ptr<Object> o) {
-    uint64_t h = next_handle++;
+  template <class O> std::shared_ptr<O> share(gs_handle h, Kind k) {
+    auto it = objs.find(h);
+    if (it == objs.end() || it->second->kind != k) return nullptr;
+    return std::static_pointer_cast<O>(it->second);
+  }
+  gs_handle put(std::shared_ptr<Object> o) {
+    uint64_t h = ((uint64_t)logical << kHandleDevShift) | next_handle++;
     objs[h] = std::move(o);
     return h;
   }
+  // lazily created engine state bags
+  template <class S> S& state(std::shared_ptr<void>& slot) {
+    if (!slot) slot = std::make_shared<S>();
+    return *static_cast<S*>(slot.get());
+  }
+  // wait for everything enqueued on this context (outstanding tickets keep their results in their pinned slots)
+  void drain() {
+    if (main_stream) GS_HIP(hipStreamSynchronize(main_stream));
+    for (auto a : aux_stream) if (a && a != main_stream) GS_HIP(hipStreamSynchronize(a));
+  }
 };
 
-inline Ctx& ctx() {
-  static Ctx c;
-  return c;
+// ---- the contexts of this process: one per entry of gs_init's device list ------------------------------------------
+struct Registry {
+  std::mutex mu;                                  // guards `ctxs` (gs_init / gs_shutdown)
+  std::vector<std::unique_ptr<Ctx>> ctxs;
+  Ctx none;                                       // what the entry points see before gs_init (ready = false)
+};
+inline Registry& registry() {
+  static Registry r;
+  return r;
 }
+// the logical device the calling host thread creates objects on (gs_set_device; like hipSetDevice, per thread)
+inline int& current_logical() {
+  static thread_local int v = 0;
+  return v;
+}
+inline Ctx& ctx_at(int logical) {
+  Registry& r = registry();
+  if (logical < 0 || (size_t)logical >= r.ctxs.size()) return r.none;
+  return *r.ctxs[logical];
+}
+inline Ctx& ctx() { return ctx_at(current_logical()); }
 
-// every entry point: lock, check init, translate exceptions into status codes
+// Every entry point: pick the context (the one `route` lives on when a handle is given, else the calling thread's current
+// logical device), lock it, check init, translate exceptions into status codes.
+// allow_inflight = false: the call uses workspaces that outstanding tickets also use, so it first waits for their device work
+// (it QUEUES behind them; their results stay in their own pinned slots until gs_*_end collects them).
 template <class F>
-int guarded(F&& f, bool need_init = true, bool allow_inflight = false) {
-  Ctx& c = ctx();
+int guarded(F&& f, bool need_init = true, bool allow_inflight = false, gs_handle route = 0) {
+  Ctx& c = route ? ctx_at(handle_device(route)) : ctx();
   std::lock_guard<std::mutex> lk(c.mu);
-  if (need_init && !c.ready) return fail(GS_ERR_NOT_INIT, "gs_init has not been called (or failed)");
+  if (need_init && !c.ready) {
+    if (registry().ctxs.empty()) return fail(GS_ERR_NOT_INIT, "gs_init has not been called (or failed)");
+    return fail(GS_ERR_ARG, "no logical device %d (gs_init listed %zu)", route ? handle_device(route) : current_logical(), registry().ctxs.size());
+  }
   // the HIP current device is per host thread: callers (goroutines, worker threads) may arrive on any thread
   if (c.ready) (void)hipSetDevice(c.device);
-  if (need_init && !allow_inflight && c.any_inflight())
-    return fail(GS_ERR_ARG, "a pipelined proof is outstanding (gs_groth16_prove_begin): call gs_groth16_prove_end before any other entry point");
   try {
+    if (need_init && !allow_inflight && c.any_inflight()) c.drain();
     return f(c);
   } catch (const HipError& e) {
     return fail(GS_ERR_HIP, "HIP error %d (%s) at %s line %d", (int)e.e, hipGetErrorString(e.e), e.what, e.line);
@@ -169,6 +220,32 @@ int guarded(F&& f, bool need_init = true, bool allow_inflight = false) {
   }
 }
 inline void reset_timing(Ctx& c) { c.timing = gs_timing{}; }
+
+// Entry points that move an object from the context `route` lives on to logical device `target`: both contexts locked
+// (std::lock: no ordering deadlock), the source drained, the HIP current device set to the target's.
+template <class F>
+int guarded_pair(gs_handle route, int target, F&& f) {
+  if (registry().ctxs.empty()) return fail(GS_ERR_NOT_INIT, "gs_init has not been called (or failed)");
+  Ctx& src = ctx_at(handle_device(route));
+  Ctx& dst = ctx_at(target);
+  if (!src.ready) return fail(GS_ERR_ARG, "bad handle (no logical device %d)", handle_device(route));
+  if (!dst.ready) return fail(GS_ERR_ARG, "no logical device %d (gs_init listed %zu)", target, registry().ctxs.size());
+  std::unique_lock<std::mutex> l1(src.mu, std::defer_lock), l2(dst.mu, std::defer_lock);
+  if (&src == &dst) l1.lock(); else std::lock(l1, l2);
+  try {
+    (void)hipSetDevice(src.device);
+    src.drain();
+    (void)hipSetDevice(dst.device);
+    if (&src != &dst && dst.any_inflight()) dst.drain();
+    return f(src, dst);
+  } catch (const HipError& e) {
+    return fail(GS_ERR_HIP, "HIP error %d (%s) at %s line %d", (int)e.e, hipGetErrorString(e.e), e.what, e.line);
+  } catch (const std::bad_alloc&) {
+    return fail(GS_ERR_HIP, "host allocation failed");
+  } catch (const std::exception& e) {
+    return fail(GS_ERR_ARG, "%s", e.what());
+  }
+}
 
 // run a section of engine calls on another stream of the context
 struct StreamScope {

@@ -145,6 +145,16 @@ def ShardPk(dev_pk, shard_index, shard_count):
     return DevicePk(capi.DeviceHandle(h.value), dev_pk.nvars, dev_pk.npublic, None)
 
 
+def ShardPkTo(dev_pk, shard_index, shard_count, target_device):
+    """The same slice, created on logical device `target_device` (gs_groth16_pk_shard_to; the copies cross xGMI when the two
+    are different GPUs)."""
+    import ctypes
+    h = capi.Handle(0)
+    capi.check(capi.load_library().gs_groth16_pk_shard_to(capi.Handle(dev_pk.handle.h), shard_index, shard_count, int(target_device),
+                                                          ctypes.byref(h)))
+    return DevicePk(capi.DeviceHandle(h.value), dev_pk.nvars, dev_pk.npublic, None)
+
+
 def UploadPkShard(pk, circuit, shard_index, shard_count):
     """Upload ONLY this rank's slice of a host key (gs_groth16_pk_create_shard): arrays cut with the split prove_partials uses."""
     import ctypes
@@ -284,6 +294,47 @@ def prove_sharded(dev_pk, w_handle, px_handle, r, s, group=None):
     pts, flags = prove_partials(dev_pk, w_handle, px_handle, rank, world)
     per_rank = parallel.allgather_points(pts, flags, group)
     return finish(dev_pk, parallel.combine_partials(per_rank, flags), r, s)
+
+
+def prove_multi(dev_pks, w_handles, px_handles, r, s):
+    """One proof over len(dev_pks) logical devices of THIS process (gs_groth16_prove_multi): dev_pks[d] is the full key or
+    slice d on logical device d, w_handles[d] / px_handles[d] replicas there.  Returns (Proof, used_rccl)."""
+    import ctypes
+    out = np.zeros(32, dtype=np.uint64)
+    inf = (ctypes.c_int * 3)()
+    used = ctypes.c_int(0)
+    rs = capi.ints_to_u64([r % R, s % R])
+    capi.check(capi.load_library().gs_groth16_prove_multi(capi._harr([k.handle for k in dev_pks]), capi._harr(w_handles), capi._harr(px_handles),
+                                                          len(dev_pks), capi.ptr64(rs[0]), capi.ptr64(rs[1]), capi.ptr64(out), inf,
+                                                          ctypes.byref(used)))
+    return _proof_from_words(out, inf), bool(used.value)
+
+
+def prove_sharded_rccl(dev_pk, w_handle, px_handle, r, s):
+    """One process per GPU, gathered INSIDE the library over the communicator of capi.comm_init_rank
+    (gs_groth16_prove_sharded).  Every rank returns the same Proof."""
+    import ctypes
+    out = np.zeros(32, dtype=np.uint64)
+    inf = (ctypes.c_int * 3)()
+    rs = capi.ints_to_u64([r % R, s % R])
+    capi.check(capi.load_library().gs_groth16_prove_sharded(capi.Handle(dev_pk.handle.h), capi.Handle(w_handle.h), capi.Handle(px_handle.h),
+                                                            capi.ptr64(rs[0]), capi.ptr64(rs[1]), capi.ptr64(out), inf))
+    return _proof_from_words(out, inf)
+
+
+def prove_batch(pk_of_device, w_handles, px_handles, rs_pairs):
+    """A batch of independent proofs round-robined over logical devices (gs_groth16_prove_batch, BASELINE configs[4]): proof i
+    runs where w_handles[i] lives, with pk_of_device[that device] (None for unused devices).  No collective."""
+    import ctypes
+    n = len(w_handles)
+    out = np.zeros((max(n, 1), 32), dtype=np.uint64)
+    inf = (ctypes.c_int * (3 * max(n, 1)))()
+    ra = capi.ints_to_u64([r % R for r, _ in rs_pairs]) if n else np.zeros((1, 4), dtype=np.uint64)
+    sa = capi.ints_to_u64([s % R for _, s in rs_pairs]) if n else np.zeros((1, 4), dtype=np.uint64)
+    pks = capi._harr([(k.handle if k is not None else 0) for k in pk_of_device])
+    capi.check(capi.load_library().gs_groth16_prove_batch(pks, len(pk_of_device), capi._harr(w_handles), capi._harr(px_handles), n,
+                                                          capi.ptr64(ra), capi.ptr64(sa), capi.ptr64(out), inf))
+    return [_proof_from_words(out[i], inf[3 * i:3 * i + 3]) for i in range(n)]
 
 
 def prove_begin(dev_pk, w_handle, px_handle, r, s):

@@ -7,6 +7,8 @@ the only exchange is an all-gather of those partials (72 B per G1 point, 136 B p
 affine words + an infinity flag) followed by world-1 local curve additions -- RCCL has no curve-point
 reduction operator, so a literal all-reduce cannot add them.  Batches of independent
 proofs (BASELINE configs[4]) need no collective at all: see bench.py."""
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -45,7 +47,9 @@ def allgather_points(partials, g2_flags, group=None):
     partials[i].  ONE all-gather of the packed bytes; returns per_rank[rank][i]."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     packed = np.concatenate([_encode(p, g2) for p, g2 in zip(partials, g2_flags)]).view(np.uint8)
-    if world == 1:
+    # A lone rank has nothing to exchange -- unless GS_FORCE_COLLECTIVE=1 asks for the collective anyway, so that the
+    # RCCL branch below is executed (and checked) on a 1-GPU box.
+    if world == 1 and not (dist.is_initialized() and os.environ.get("GS_FORCE_COLLECTIVE") == "1"):
         gathered = [packed]
     else:
         dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")

@@ -26,8 +26,15 @@
  *    entry points at the end are host code by design -- O(1) pairings -- and say so.)
  *  - The library copies caller buffers during the call and never retains host pointers
  *    (cgo pointer rule).  Device memory lives behind opaque handles freed by gs_free().
- *  - One context per process and device (one process per GPU); calls are serialised on an
- *    internal mutex, safe to call from several goroutines/threads.
+ *  - One context per LOGICAL DEVICE: gs_init takes a list of HIP ordinals and creates one context -- streams, workspaces,
+ *    handle table, lock -- per entry (the same ordinal may appear several times).  A handle or ticket carries its logical
+ *    device in its top byte, so every entry point that takes one runs on the right device whatever thread calls it; entry
+ *    points that only CREATE objects (uploads, fixed-base batches, setups, the gs_poly_* family) use the calling thread's current
+ *    logical device (gs_set_device, default 0; a Go caller wraps the pair in runtime.LockOSThread).  Calls on one logical
+ *    device are serialised on its lock and are safe from any number of goroutines/threads; different logical devices run
+ *    concurrently.  While pipelined tickets (gs_*_begin) are outstanding, every other call still works: uploads, downloads,
+ *    gs_free (deferred until the tickets that read the object are collected) and gs_r1cs_px proceed at once, the rest
+ *    first wait for the outstanding device work -- they queue, they do not fail.
  */
 #ifndef GOSNARK_HIP_H
 #define GOSNARK_HIP_H
@@ -50,13 +57,23 @@ typedef enum {
   GS_ERR_HIP = -2,         /* a HIP call or kernel failed */
   GS_ERR_ARG = -3,         /* bad argument (null pointer, size mismatch, bad handle) */
   GS_ERR_SHAPE = -4,       /* instance violates the reference's shape contract */
-  GS_ERR_NOT_INIT = -5
+  GS_ERR_NOT_INIT = -5,
+  GS_ERR_BUSY = -6         /* gs_*_begin: all three in-flight slots of this logical device are taken -- collect one with gs_*_end and retry */
 } gs_status;
 
 /* ---- lifetime ------------------------------------------------------------------------- */
-/* Select the device this process drives (devices[0]; ndev must be 1: one process per GPU). */
+/* Create one context per entry of `devices` (HIP ordinals, 1 <= ndev <= 64): "logical device" i drives devices[i].  One
+ * process per GPU passes one entry; a single Go process that drives a whole node passes all eight ("one stream +
+ * context per (goroutine, device)"); listing one ordinal N times gives N logical devices that time-slice that GPU (how the
+ * multi-device entry points below are tested on a 1-GPU box).  Calling it again with the same list is a no-op; a different
+ * list needs gs_shutdown first.  gs_shutdown releases everything, on every device. */
 int gs_init(const int* devices, int ndev);
 void gs_shutdown(void);
+/* Number of logical devices; the calling thread's current one (objects are created there); the device a handle/ticket lives on. */
+int gs_device_count(void);
+int gs_set_device(int logical_device);
+int gs_get_device(void);
+int gs_handle_device(gs_handle h);
 const char* gs_last_error(void);
 /* ABI/version string, e.g. "gosnark-hip 0.1 gfx950". */
 const char* gs_version(void);
@@ -86,6 +103,12 @@ int gs_g2_fixed_base(const uint64_t* scalars /* n x 4 */, size_t n, gs_handle* o
 /* ---- resident scalar vectors ------------------------------------------------------------- */
 int gs_scalars_upload(const uint64_t* scalars /* n x 4 */, size_t n, gs_handle* out);
 int gs_scalars_download(gs_handle scalars, uint64_t* out /* n x 4 */, size_t n);
+
+/* Copies of [off, off + n) of a resident vector / base array onto another logical device (device-to-device; across xGMI
+ * when the two are different GPUs).  How the shards of a term range are handed to the devices that will sum them. */
+int gs_scalars_clone(gs_handle scalars, size_t off, size_t n, int target_device, gs_handle* out);
+int gs_g1_clone(gs_handle bases, size_t off, size_t n, int target_device, gs_handle* out);
+int gs_g2_clone(gs_handle bases, size_t off, size_t n, int target_device, gs_handle* out);
 
 /* ---- multi-scalar multiplication ----------------------------------------------------------
  * out = sum_{i<n} scalars[i] * bases[off + i]: replaces the loop
@@ -181,9 +204,11 @@ int gs_groth16_prove_r1cs(gs_handle pk, gs_handle r1cs, gs_handle w, gs_handle* 
 
 /* Pipelined proving (inputs resident): gs_groth16_prove_begin enqueues the whole device side of one proof and returns a
  * ticket without waiting; gs_groth16_prove_end waits for THAT proof only, then runs the host tail and writes the proof
- * (same layout as gs_groth16_prove).  At most three tickets (proofs or MSMs) may be outstanding; they own disjoint workspaces, so the plan and
+ * (same layout as gs_groth16_prove).  At most three tickets (proofs or MSMs) may be outstanding per logical device (a fourth begin returns
+ * GS_ERR_BUSY); they own disjoint workspaces, so the plan and
  * bucket accumulations of proof k+1 run while the reduction tails, result download and host tail of proof k are still in
- * progress.  While a ticket is outstanding every other entry point returns GS_ERR_ARG (finish the tickets first). */
+ * progress.  Other entry points stay usable meanwhile (see "Conventions"): the key and the vectors a ticket reads may even be
+ * gs_free'd -- they are released when the ticket has been collected. */
 int gs_groth16_prove_begin(gs_handle pk, gs_handle w, gs_handle px, const uint64_t r[4], const uint64_t s[4], uint64_t* ticket);
 int gs_groth16_prove_end(uint64_t ticket, uint64_t out_proof[32], int inf[3]);
 
@@ -209,6 +234,8 @@ int gs_groth16_pk_create_shard(gs_handle g1_at, gs_handle g1_bacgamma, gs_handle
                                size_t nvars, size_t npublic, size_t nptd_total, size_t shard_index, size_t shard_count,
                                gs_handle* out);
 int gs_groth16_pk_shard(gs_handle full_pk, size_t shard_index, size_t shard_count, gs_handle* out);
+/* The same slice, created on logical device `target_device` (the full key may live on any device). */
+int gs_groth16_pk_shard_to(gs_handle full_pk, size_t shard_index, size_t shard_count, int target_device, gs_handle* out);
 int gs_groth16_finish(gs_handle pk, const uint64_t sums[48], const int inf_in[5], const uint64_t r[4], const uint64_t s[4],
                       uint64_t out_proof[32], int inf[3]);
 
@@ -259,6 +286,50 @@ int gs_pinocchio_prove_resident(gs_handle pk, gs_handle w, gs_handle px, uint64_
 int gs_pinocchio_prove_begin(gs_handle pk, gs_handle w, gs_handle px, uint64_t* ticket);
 int gs_pinocchio_prove_end(uint64_t ticket, uint64_t out_proof[72], int inf[8]);
 
+/* ---- several GPUs (BASELINE configs[3] "MSM sharded across 8 GPUs" and configs[4] "one proof per GPU") ----------
+ * The prover's sums run over independent terms (groth16.go:243-250,269-271): each device sums one contiguous shard of the
+ * term ranges, and ONE record per device is exchanged -- the five partial sums of a proof (416 bytes: 48 words of affine
+ * points | inf[5], shard index as u32) or one partial point (72 / 136 bytes).  RCCL cannot add curve points, so the exchange is
+ * ncclAllGather of the records as ncclUint8 followed by N - 1 additions on the host core.
+ *
+ * Communicator.  gs_comm_init_local: every RCCL rank lives in this process, one per distinct physical device of gs_init's
+ * list (ncclCommInitAll); the *_multi entry points then pass their records through ncclAllGather.  gs_comm_init_rank: one
+ * process per GPU -- rank 0 obtains an id with gs_comm_unique_id, the host language distributes the 128 bytes, every process
+ * calls gs_comm_init_rank(id, nranks, rank) (its current logical device joins); the *_sharded entry points gather over it.
+ * gs_comm_allgather exposes the byte gather itself (host buffers; local mode: `send` holds one block per local rank and
+ * `recv` receives rank 0's copy of all blocks).  *collectives counts the ncclAllGather calls completed so far. */
+int gs_comm_unique_id(uint8_t out_id[128]);
+int gs_comm_init_rank(const uint8_t id[128], int nranks, int rank);
+int gs_comm_init_local(void);
+void gs_comm_destroy(void);
+int gs_comm_info(int* nranks, int* rank, int* is_local, uint64_t* collectives);
+int gs_comm_allgather(const void* send, size_t bytes_per_rank, void* recv /* nranks x bytes_per_rank */);
+
+/* One MSM over `ndev` logical devices of this process: bases[d] / scalars[d] hold shard d of the term range (the same
+ * contiguous split of both, e.g. made with gs_g1_clone / gs_scalars_clone), resident on one logical device each.  The
+ * devices run concurrently (one host thread each); *used_rccl (may be NULL) reports whether the partial points travelled
+ * through ncclAllGather (a local communicator exists and the logical devices spread evenly over its ranks) or were simply
+ * read from this process's memory.  Same result as one gs_msm_g1 over the whole range. */
+int gs_msm_g1_multi(const gs_handle* bases, const gs_handle* scalars, int ndev, uint64_t out_affine[8], int* is_inf, int* used_rccl);
+int gs_msm_g2_multi(const gs_handle* bases, const gs_handle* scalars, int ndev, uint64_t out_affine[16], int* is_inf, int* used_rccl);
+/* One Groth16 proof over `ndev` logical devices: pk[d] = the full key or slice d of ndev (gs_groth16_pk_shard_to), w[d] / px[d]
+ * = replicas of the witness and of P(x) on the same logical device (gs_scalars_clone).  Device d runs
+ * gs_groth16_prove_partials for shard d; the records are exchanged as above and the O(1) tail runs once.  Same proof as
+ * gs_groth16_prove_resident with the full key. */
+int gs_groth16_prove_multi(const gs_handle* pk, const gs_handle* w, const gs_handle* px, int ndev, const uint64_t r[4], const uint64_t s[4],
+                           uint64_t out_proof[32], int inf[3], int* used_rccl);
+/* One process per GPU: this rank's shard (rank / nranks of the communicator made by gs_comm_init_rank), gathered inside the
+ * library; every rank returns the complete result.  pk is the full key or this rank's slice; bases / scalars hold this
+ * rank's shard of the term range. */
+int gs_groth16_prove_sharded(gs_handle pk, gs_handle w, gs_handle px, const uint64_t r[4], const uint64_t s[4], uint64_t out_proof[32], int inf[3]);
+int gs_msm_g1_sharded(gs_handle bases, gs_handle scalars, uint64_t out_affine[8], int* is_inf);
+int gs_msm_g2_sharded(gs_handle bases, gs_handle scalars, uint64_t out_affine[16], int* is_inf);
+/* A batch of independent proofs (configs[4]; no collective): proof i reads w[i] / px[i], runs on the logical device those
+ * handles live on with the key pk_of_device[that device] (0 for unused devices), through the pipelined prover (three in
+ * flight per device, devices concurrently).  r, s: nproofs x 4 words; out_proofs: nproofs x 32 words; inf: nproofs x 3. */
+int gs_groth16_prove_batch(const gs_handle* pk_of_device, int ndev, const gs_handle* w, const gs_handle* px, size_t nproofs,
+                           const uint64_t* r, const uint64_t* s, uint64_t* out_proofs, int* inf);
+
 /* ---- timing of the last prove / msm call (device time, HIP events on the library stream) --- */
 typedef struct {
   float total_ms;        /* all device work of the call */
@@ -274,7 +345,8 @@ typedef struct {
   uint64_t acc_g1_terms; /* (terms x base arrays) those G1 launches consumed */
   uint64_t acc_g2_terms;
 } gs_timing;
-int gs_last_timing(gs_timing* out);
+int gs_last_timing(gs_timing* out);                         /* the calling thread's current logical device */
+int gs_device_timing(int logical_device, gs_timing* out);
 
 /* Tunables (0 = automatic): Pippenger window bits. */
 int gs_set_window_bits(int c);

@@ -1,0 +1,285 @@
+"""-m gpu: several logical devices behind the C ABI (multi.hip), the RCCL gather, deferred frees and concurrent callers.
+
+Runs after the single-device modules (it re-initialises the library with EIGHT logical devices that all name GPU 0 -- how
+BASELINE configs[3] / [4] are exercised on a 1-GPU box) and hands a single-device library back to test_gpu_zz_lifecycle."""
+import ctypes
+import os
+import threading
+
+import numpy as np
+import pytest
+
+import gosnark_amd  # noqa: F401
+from gosnark_amd import capi, groth16, parallel, synth
+import gpu_util as U
+
+pytestmark = pytest.mark.gpu
+
+NLOG = 8
+
+
+@pytest.fixture(scope="module", autouse=True)
+def eight_logical_devices():
+    capi.shutdown()
+    capi.init([0] * NLOG)
+    assert capi.device_count() == NLOG
+    yield
+    capi.comm_destroy()
+    capi.shutdown()
+    capi.init()
+
+
+@pytest.fixture(scope="module")
+def inst():
+    capi.set_device(0)
+    return synth.sqchain_setup_instance(1 << 12, 0xD1CE)
+
+
+def _spread(inst, n, full_keys=False):
+    """key slices (or full replicas) + witness / px replicas on logical devices 0..n-1"""
+    full = inst.device_pk()
+    pks = [groth16.ShardPkTo(full, 0, 1, d) if full_keys else groth16.ShardPkTo(full, d, n, d) for d in range(n)]
+    ws = [capi.scalars_clone(inst.w, d) for d in range(n)]
+    pxs = [capi.scalars_clone(inst.px, d) for d in range(n)]
+    for d in range(n):
+        assert capi.handle_device(pks[d].handle) == d and capi.handle_device(ws[d]) == d
+    return pks, ws, pxs
+
+
+def _same(p, q):
+    return (p.PiA, p.PiB, p.PiC) == (q.PiA, q.PiB, q.PiC)
+
+
+@pytest.mark.parametrize("n", [2, 3, 8])
+def test_one_proof_over_n_logical_devices_is_the_single_device_proof(inst, n):
+    """the same physical device listed N = 2, 3, 8 times.  Key slices (each logical device holds 1/N of
+    every key array) and full replicas; host-memory exchange (no communicator yet)."""
+    r, s = synth.field_elems(2, 77 + n)
+    want = groth16.prove_resident(inst.device_pk(), inst.w, inst.px, r, s)
+    assert inst.vk is not None and groth16.VerifyProof(inst.vk, want, capi.u64_to_ints(inst.w_host[1:2]))
+    capi.comm_destroy()
+    for full_keys in (False, True):
+        pks, ws, pxs = _spread(inst, n, full_keys)
+        got, used = groth16.prove_multi(pks, ws, pxs, r, s)
+        assert _same(got, want) and used is False
+
+
+def test_records_travel_through_rccl_allgather_with_a_local_communicator(inst):
+    """(b): gs_comm_init_local = ncclCommInitAll over the distinct physical devices (one here): the eight 416-byte records of a
+    proof and the partial points of an MSM pass through ncclAllGather before they are added."""
+    capi.comm_destroy()
+    capi.comm_init_local()
+    info = capi.comm_info()
+    assert info["nranks"] == 1 and info["local"] is True
+    before = info["collectives"]
+    r, s = synth.field_elems(2, 99)
+    want = groth16.prove_resident(inst.device_pk(), inst.w, inst.px, r, s)
+    pks, ws, pxs = _spread(inst, NLOG)
+    got, used = groth16.prove_multi(pks, ws, pxs, r, s)
+    assert _same(got, want) and used is True
+    assert capi.comm_info()["collectives"] == before + 1
+    # raw byte gather: 8 blocks in, the same 8 blocks out
+    blocks = bytes(range(256)) * 13
+    assert capi.comm_allgather(blocks, 1) == blocks
+    capi.comm_destroy()
+    assert capi.comm_info()["nranks"] == 0
+
+
+@pytest.mark.parametrize("g2", [False, True])
+def test_msm_sharded_over_logical_devices(g2):
+    """configs[3] in miniature: a ragged 3-way split of the term range, each shard resident on its own logical device."""
+    capi.set_device(0)
+    n = 5001 if not g2 else 1203
+    ks, sc = U.rand_scalars_u64(n, 5), U.rand_scalars_u64(n, 6)
+    bases = capi.g2_fixed_base(ks) if g2 else capi.g1_fixed_base(ks)
+    scal = capi.scalars_upload(sc)
+    want = capi.msm_resident(bases, scal, n, g2=g2)
+    clone = capi.g2_clone if g2 else capi.g1_clone
+    for ndev, with_comm in ((3, False), (8, True)):
+        capi.comm_destroy()
+        if with_comm:
+            capi.comm_init_local()
+        bs, ss = [], []
+        for d in range(ndev):
+            lo, hi = parallel.shard_range(n, ndev, d)
+            bs.append(clone(bases, d, lo, hi - lo))
+            ss.append(capi.scalars_clone(scal, d, lo, hi - lo))
+        got, used = capi.msm_multi(bs, ss, g2=g2)
+        assert got == want and used is with_comm
+    capi.comm_destroy()
+
+
+def test_one_process_per_gpu_gather_inside_the_library_world_1(inst):
+    """The deployment bench.py uses (one process per GPU): gs_comm_unique_id -> gs_comm_init_rank -> gs_groth16_prove_sharded /
+    gs_msm_g1_sharded.  World size 1 here: the 1-rank communicator is created and ncclAllGather runs."""
+    capi.comm_destroy()
+    capi.set_device(0)
+    capi.comm_init_rank(capi.comm_unique_id(), 1, 0)
+    info = capi.comm_info()
+    assert (info["nranks"], info["rank"], info["local"]) == (1, 0, False)
+    r, s = synth.field_elems(2, 123)
+    want = groth16.prove_resident(inst.device_pk(), inst.w, inst.px, r, s)
+    got = groth16.prove_sharded_rccl(inst.device_pk(), inst.w, inst.px, r, s)
+    assert _same(got, want)
+    n = 3000
+    bases = capi.g1_fixed_base(U.rand_scalars_u64(n, 7))
+    scal = capi.scalars_upload(U.rand_scalars_u64(n, 8))
+    assert capi.msm_sharded(bases, scal) == capi.msm_resident(bases, scal, n)
+    assert capi.comm_info()["collectives"] == info["collectives"] + 2
+    with pytest.raises(capi.GosnarkHipError, match="already exists"):
+        capi.comm_init_local()
+    capi.comm_destroy()
+
+
+def test_torch_distributed_nccl_branch_runs_at_world_1(inst, monkeypatch):
+    """parallel.allgather_points over torch.distributed's nccl (= RCCL) backend, forced at world size 1."""
+    import torch
+    import torch.distributed as dist
+    monkeypatch.setenv("GS_FORCE_COLLECTIVE", "1")
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+    monkeypatch.setenv("MASTER_PORT", "29641")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        r, s = synth.field_elems(2, 321)
+        want = groth16.prove_resident(inst.device_pk(), inst.w, inst.px, r, s)
+        got = groth16.prove_sharded(inst.device_pk(), inst.w, inst.px, r, s)
+        assert _same(got, want)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_batch_of_independent_proofs_round_robin_over_devices(inst):
+    """configs[4] in miniature: 11 proofs (two different witnesses, fresh randomness each) over 4 logical devices, one full key
+    per device, three in flight per device, no collective."""
+    from gosnark_amd import r1csqap
+    ndev, nproofs = 4, 11
+    capi.set_device(0)
+    _, _, _, w2 = synth.sqchain_r1cs(inst.n, 31337)
+    _, _, _, px2 = r1csqap.ComputePx(*inst.r1cs, w2, inst.m)
+    w2h, px2h = capi.scalars_upload(w2), capi.scalars_upload(px2)
+    rs = [tuple(synth.field_elems(2, 900 + i)) for i in range(nproofs)]
+    src = [(inst.w, inst.px) if i % 3 else (w2h, px2h) for i in range(nproofs)]
+    want = [groth16.prove_resident(inst.device_pk(), w, px, r, s) for (w, px), (r, s) in zip(src, rs)]
+    pks = [groth16.ShardPkTo(inst.device_pk(), 0, 1, d) for d in range(ndev)]
+    ws = [capi.scalars_clone(w, i % ndev) for i, (w, _) in enumerate(src)]
+    pxs = [capi.scalars_clone(px, i % ndev) for i, (_, px) in enumerate(src)]
+    got = groth16.prove_batch(pks, ws, pxs, rs)
+    assert len(got) == nproofs and all(_same(g, w) for g, w in zip(got, want))
+    assert groth16.VerifyProof(inst.vk, got[0], capi.u64_to_ints(w2[1:2]))
+    with pytest.raises(capi.GosnarkHipError, match="do not share one logical device"):
+        groth16.prove_batch(pks, [ws[1]], [pxs[0]], rs[:1])
+
+
+def test_handles_route_to_their_device_and_foreign_handles_are_refused(inst):
+    capi.set_device(3)
+    assert capi.get_device() == 3
+    sc = capi.scalars_upload(U.rand_scalars_u64(100, 1))
+    bases = capi.g1_fixed_base(U.rand_scalars_u64(100, 2))
+    assert capi.handle_device(sc) == 3 and capi.handle_device(bases) == 3
+    capi.set_device(0)                                               # the handle, not the thread's device, decides
+    got = capi.msm_resident(bases, sc, 100)
+    on0 = capi.scalars_clone(sc, 0)
+    b0 = capi.g1_clone(bases, 0)
+    assert capi.msm_resident(b0, on0, 100) == got
+    assert (capi.scalars_download(on0) == capi.scalars_download(sc)).all()
+    with pytest.raises(capi.GosnarkHipError):                        # scalars on device 0, bases on device 3
+        capi.msm_resident(bases, on0, 100)
+    with pytest.raises(capi.GosnarkHipError, match="no logical device"):
+        capi.set_device(NLOG)
+    with pytest.raises(capi.GosnarkHipError):
+        capi.scalars_clone(sc, NLOG)
+
+
+def test_free_while_tickets_are_outstanding_is_deferred(inst):
+    """gs_free of the key / w / px a ticket reads must not fail and must not pull the objects from under the
+    proof; other entry points keep working meanwhile (they queue behind the outstanding device work)."""
+    capi.set_device(0)
+    r, s = synth.field_elems(2, 55)
+    want = groth16.prove_resident(inst.device_pk(), inst.w, inst.px, r, s)
+    pk = groth16.ShardPkTo(inst.device_pk(), 0, 1, 0)
+    w, px = capi.scalars_clone(inst.w, 0), capi.scalars_clone(inst.px, 0)
+    tickets = [groth16.prove_begin(pk, w, px, r, s) for _ in range(3)]
+    with pytest.raises(capi.GosnarkHipError) as e:
+        groth16.prove_begin(pk, w, px, r, s)
+    assert e.value.code == -6                                         # GS_ERR_BUSY: a bounded queue, not a broken library
+    pk.handle.free(); w.free(); px.free()
+    assert pk.handle.h == 0 and w.h == 0 and px.h == 0
+    # a blocking MSM and an upload while three proofs are in flight
+    bases = capi.g1_fixed_base(U.rand_scalars_u64(500, 3))
+    sc = U.rand_scalars_u64(500, 4)
+    m1 = capi.msm(bases, sc)
+    fresh = capi.scalars_upload(sc)
+    assert capi.msm_resident(bases, fresh, 500) == m1
+    for t in tickets:
+        assert _same(groth16.prove_end(t), want)
+
+
+def test_concurrent_callers_pipelined_proofs_uploads_and_msms(inst):
+    """one thread streams pipelined proofs while two others upload witnesses, compute px from the resident
+    R1CS and run MSMs on the same logical device; every result equals the serial one."""
+    from gosnark_amd import r1csqap
+    capi.set_device(0)
+    r, s = synth.field_elems(2, 66)
+    want = groth16.prove_resident(inst.device_pk(), inst.w, inst.px, r, s)
+    n = 2000
+    bases = capi.g1_fixed_base(U.rand_scalars_u64(n, 11))
+    scs = [U.rand_scalars_u64(n, 20 + i) for i in range(6)]
+    want_msm = [capi.msm(bases, sc) for sc in scs]
+    dr1cs = r1csqap.DeviceR1CS(*inst.r1cs, inst.m)
+    want_px = capi.scalars_download(dr1cs.ComputePxResident(inst.w))
+    errors, proofs, msms, pxs = [], [], [None] * len(scs), []
+
+    def prover():
+        try:
+            capi.set_device(0)
+            tickets = []
+            for _ in range(12):
+                tickets.append(groth16.prove_begin(inst.device_pk(), inst.w, inst.px, r, s))
+                if len(tickets) == 3:
+                    proofs.append(groth16.prove_end(tickets.pop(0)))
+            while tickets:
+                proofs.append(groth16.prove_end(tickets.pop(0)))
+        except Exception as e:      # noqa: BLE001
+            errors.append(e)
+
+    def msm_worker(lo, hi):
+        try:
+            capi.set_device(0)
+            for i in range(lo, hi):
+                h = capi.scalars_upload(scs[i])
+                msms[i] = capi.msm_resident(bases, h, n)
+                h.free()
+        except Exception as e:      # noqa: BLE001
+            errors.append(e)
+
+    def px_worker():
+        try:
+            capi.set_device(0)
+            for _ in range(3):
+                w = capi.scalars_upload(inst.w_host)
+                pxs.append(capi.scalars_download(dr1cs.ComputePxResident(w)))
+        except Exception as e:      # noqa: BLE001
+            errors.append(e)
+
+    th = [threading.Thread(target=prover), threading.Thread(target=msm_worker, args=(0, 3)), threading.Thread(target=msm_worker, args=(3, 6)),
+          threading.Thread(target=px_worker)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
+    assert len(proofs) == 12 and all(_same(p, want) for p in proofs)
+    assert msms == want_msm
+    assert len(pxs) == 3 and all((p == want_px).all() for p in pxs)
+
+
+def test_plain_c_process_proves_over_three_logical_devices(tmp_path):
+    """(c): the plain-C driver (no Python, no torch in the process) lists GPU 0 three times, cuts the reference's x^3 + x + 5
+    key into slices, creates the local RCCL communicator and reproduces the single-device proof with gs_groth16_prove_multi."""
+    import c_util
+    import golden_util as GU
+    blob = c_util.write_groth_instance(tmp_path, GU.load("groth_x3"))
+    out = c_util.build_and_run("multi_device.c", [str(blob)], tmp_path)
+    assert out.strip().endswith("OK"), out
+    assert "used_rccl=1" in out and "collectives=1" in out
