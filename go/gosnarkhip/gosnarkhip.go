@@ -1,11 +1,15 @@
 // Package gosnarkhip is the cgo binding of libgosnark_hip.so (include/gosnark_hip.h): the MI355X
 // implementation of go-snark-study's prover hot path.  It only packs the reference's big.Int
 // structures into flat little-endian limb buffers and calls the C ABI; all arithmetic happens in
-// the HIP library.  NOTE: the build image has no Go toolchain, so this file is reviewed-not-compiled
-// there; the same ABI is exercised from Python (ctypes) by the test-suite.
+// the HIP library.  NOTE: the build image has no Go toolchain, so this package is reviewed-not-compiled
+// there; every exported function's exact call sequence exists as a plain-C program under tests/c/
+// (INTEGRATION.md lists the pairs) and the same ABI is exercised from Python (ctypes) by the test-suite.
 //
 // cgo rules observed: only flat []uint64 / []uint32 buffers cross the boundary, the library copies
 // during the call and keeps no Go pointer, device memory lives behind opaque handles.
+//
+// Files: gosnarkhip.go (runtime, packers, MSM, polynomials), r1cs.go (dense -> CSR), groth16.go,
+// pinocchio.go (keys, setups, provers, verifiers), multi.go (several GPUs).
 package gosnarkhip
 
 /*
@@ -24,27 +28,87 @@ import (
 	"unsafe"
 )
 
-// Handle is an opaque device object (resident base array, scalar vector or proving key).
+// Handle is an opaque device object (resident base array, scalar vector, R1CS or proving key).  Its top
+// byte names the logical device it lives on (gs_handle_device).
 type Handle uint64
 
-func status(code C.int) error {
+// Error carries the library's status code (gs_status) and message.
+type Error struct {
+	Code int
+	Msg  string
+}
+
+func (e *Error) Error() string { return fmt.Sprintf("gosnark-hip: status %d: %s", e.Code, e.Msg) }
+
+// Busy reports GS_ERR_BUSY: all three in-flight slots of the device are taken (collect a ticket and retry).
+func (e *Error) Busy() bool { return e.Code == -6 }
+
+// call runs one C entry point and, on failure, reads gs_last_error() ON THE SAME OS THREAD: the message is
+// thread-local in the library and a goroutine may migrate between two cgo calls (ADVICE r1).
+func call(f func() C.int) error {
+	runtime.LockOSThread()
+	defer runtime.UnlockOSThread()
+	code := f()
 	if code == 0 {
 		return nil
 	}
-	return fmt.Errorf("gosnark-hip: status %d: %s", int(code), C.GoString(C.gs_last_error()))
+	return &Error{int(code), C.GoString(C.gs_last_error())}
 }
 
-// Init selects the GPU this process drives (one process per GPU).
-func Init(device int) error {
-	d := C.int(device)
-	return status(C.gs_init(&d, 1))
+// onDevice runs f with the calling OS thread's current logical device set to `device`: needed by the entry
+// points that CREATE objects (uploads, setups, the polynomial family); everything that takes a handle is
+// routed by the handle itself.
+func onDevice(device int, f func() C.int) error {
+	runtime.LockOSThread()
+	defer runtime.UnlockOSThread()
+	if code := C.gs_set_device(C.int(device)); code != 0 {
+		return &Error{int(code), C.GoString(C.gs_last_error())}
+	}
+	code := f()
+	if code == 0 {
+		return nil
+	}
+	return &Error{int(code), C.GoString(C.gs_last_error())}
 }
 
-// Free releases a device object.
-func Free(h Handle) { C.gs_free(C.gs_handle(h)) }
+// Init creates one context ("logical device") per entry of devices (HIP ordinals); Init(0) drives one GPU,
+// Init(0,1,...,7) a whole node from one process, Init(0,0,0) three logical devices on GPU 0.
+func Init(devices ...int) error {
+	if len(devices) == 0 {
+		devices = []int{0}
+	}
+	d := make([]C.int, len(devices))
+	for i, v := range devices {
+		d[i] = C.int(v)
+	}
+	return call(func() C.int { return C.gs_init(&d[0], C.int(len(d))) })
+}
+
+// Shutdown releases every device object, stream and workspace on every device.
+func Shutdown() { C.gs_shutdown() }
+
+// DeviceCount is the number of logical devices Init created.
+func DeviceCount() int { return int(C.gs_device_count()) }
+
+// DeviceOf is the logical device a handle lives on.
+func DeviceOf(h Handle) int { return int(C.gs_handle_device(C.gs_handle(h))) }
+
+// Version is the library's ABI / build string.
+func Version() string { return C.GoString(C.gs_version()) }
+
+// Free releases a device object (deferred by the library while tickets that read it are outstanding).
+func Free(h Handle) error {
+	if h == 0 {
+		return nil
+	}
+	return call(func() C.int { return C.gs_free(C.gs_handle(h)) })
+}
 
 // limbs writes v (0 <= v < 2^256) as 4 little-endian 64-bit words: exactly big.Int.Bits() padded.
 func limbs(dst []uint64, v *big.Int) error {
+	if v == nil {
+		return errors.New("gosnark-hip: nil *big.Int")
+	}
 	if v.Sign() < 0 {
 		return errors.New("gosnark-hip: negative value (the reference drops the sign, fields/fq.go:138-140; rejected here)")
 	}
@@ -67,8 +131,8 @@ func Scalars(vals []*big.Int, r *big.Int) ([]uint64, error) {
 	out := make([]uint64, 4*len(vals))
 	t := new(big.Int)
 	for i, v := range vals {
-		if v.Sign() < 0 {
-			return nil, errors.New("gosnark-hip: negative scalar")
+		if v == nil || v.Sign() < 0 {
+			return nil, errors.New("gosnark-hip: nil or negative scalar")
 		}
 		t.Mod(v, r)
 		if err := limbs(out[4*i:], t); err != nil {
@@ -113,28 +177,11 @@ func ptr(b []uint64) *C.uint64_t {
 	return (*C.uint64_t)(unsafe.Pointer(&b[0]))
 }
 
-// UploadG1 makes a base-point array resident (affine-normalised on the device).
-func UploadG1(pts [][3]*big.Int) (Handle, error) {
-	buf, err := G1Points(pts)
-	if err != nil {
-		return 0, err
+func ptr32(b []uint32) *C.uint32_t {
+	if len(b) == 0 {
+		return nil
 	}
-	var h C.gs_handle
-	err = status(C.gs_g1_upload(ptr(buf), C.size_t(len(pts)), &h))
-	runtime.KeepAlive(buf)
-	return Handle(h), err
-}
-
-// UploadG2 is UploadG1 for G2 arrays.
-func UploadG2(pts [][3][2]*big.Int) (Handle, error) {
-	buf, err := G2Points(pts)
-	if err != nil {
-		return 0, err
-	}
-	var h C.gs_handle
-	err = status(C.gs_g2_upload(ptr(buf), C.size_t(len(pts)), &h))
-	runtime.KeepAlive(buf)
-	return Handle(h), err
+	return (*C.uint32_t)(unsafe.Pointer(&b[0]))
 }
 
 func word(b []uint64) *big.Int {
@@ -162,110 +209,128 @@ func G2FromAffine(b []uint64, inf bool) [3][2]*big.Int {
 	return [3][2]*big.Int{{word(b[0:]), word(b[4:])}, {word(b[8:]), word(b[12:])}, {big.NewInt(1), z()}}
 }
 
-// MSMG1 = sum_i scalars[i] * bases[off+i]: the loop of groth16.go:243-250 as one call.
+// G1FromJacobian reads the 12-word triples the export / setup entry points return ([x, y, 1] or all zero).
+func G1FromJacobian(b []uint64) [3]*big.Int { return [3]*big.Int{word(b[0:]), word(b[4:]), word(b[8:])} }
+
+// G2FromJacobian reads 24-word G2 triples.
+func G2FromJacobian(b []uint64) [3][2]*big.Int {
+	return [3][2]*big.Int{{word(b[0:]), word(b[4:])}, {word(b[8:]), word(b[12:])}, {word(b[16:]), word(b[20:])}}
+}
+
+// UploadG1 makes a base-point array resident on logical device `device` (affine-normalised there).
+func UploadG1(device int, pts [][3]*big.Int) (Handle, error) {
+	buf, err := G1Points(pts)
+	if err != nil {
+		return 0, err
+	}
+	var h C.gs_handle
+	err = onDevice(device, func() C.int { return C.gs_g1_upload(ptr(buf), C.size_t(len(pts)), &h) })
+	runtime.KeepAlive(buf)
+	return Handle(h), err
+}
+
+// UploadG2 is UploadG1 for G2 arrays.
+func UploadG2(device int, pts [][3][2]*big.Int) (Handle, error) {
+	buf, err := G2Points(pts)
+	if err != nil {
+		return 0, err
+	}
+	var h C.gs_handle
+	err = onDevice(device, func() C.int { return C.gs_g2_upload(ptr(buf), C.size_t(len(pts)), &h) })
+	runtime.KeepAlive(buf)
+	return Handle(h), err
+}
+
+// UploadScalars makes a scalar vector (witness, px) resident on logical device `device`.
+func UploadScalars(device int, vals []*big.Int, order *big.Int) (Handle, error) {
+	buf, err := Scalars(vals, order)
+	if err != nil {
+		return 0, err
+	}
+	var h C.gs_handle
+	err = onDevice(device, func() C.int { return C.gs_scalars_upload(ptr(buf), C.size_t(len(vals)), &h) })
+	runtime.KeepAlive(buf)
+	return Handle(h), err
+}
+
+// CloneScalars copies [off, off+n) of a resident vector onto another logical device (over xGMI between GPUs).
+func CloneScalars(h Handle, off, n, target int) (Handle, error) {
+	var out C.gs_handle
+	err := call(func() C.int { return C.gs_scalars_clone(C.gs_handle(h), C.size_t(off), C.size_t(n), C.int(target), &out) })
+	return Handle(out), err
+}
+
+// CloneG1 / CloneG2 do the same for base arrays (the shards of a term-sharded MSM).
+func CloneG1(h Handle, off, n, target int) (Handle, error) {
+	var out C.gs_handle
+	err := call(func() C.int { return C.gs_g1_clone(C.gs_handle(h), C.size_t(off), C.size_t(n), C.int(target), &out) })
+	return Handle(out), err
+}
+func CloneG2(h Handle, off, n, target int) (Handle, error) {
+	var out C.gs_handle
+	err := call(func() C.int { return C.gs_g2_clone(C.gs_handle(h), C.size_t(off), C.size_t(n), C.int(target), &out) })
+	return Handle(out), err
+}
+
+// MSMG1 = sum_i scalars[i] * bases[off+i]: the loop of groth16.go:243-250 (bn128/g1.go:140-155 + :32-89) as one call.
 func MSMG1(bases Handle, scalars []uint64, off int) ([3]*big.Int, error) {
 	var out [8]uint64
 	var inf C.int
-	err := status(C.gs_msm_g1(C.gs_handle(bases), ptr(scalars), C.size_t(off), C.size_t(len(scalars)/4),
-		(*C.uint64_t)(unsafe.Pointer(&out[0])), &inf))
+	err := call(func() C.int {
+		return C.gs_msm_g1(C.gs_handle(bases), ptr(scalars), C.size_t(off), C.size_t(len(scalars)/4), (*C.uint64_t)(unsafe.Pointer(&out[0])), &inf)
+	})
 	runtime.KeepAlive(scalars)
 	return G1FromAffine(out[:], inf != 0), err
 }
 
-// Groth16Key is a proving key resident in HBM (groth16.Pk, groth16/groth16.go:15-32).
-type Groth16Key struct{ h Handle }
-
-// Groth16KeyParts carries the reference's Pk fields without importing the groth16 package.
-type Groth16KeyParts struct {
-	At, BACGamma1, BACDelta, PowersTauDelta [][3]*big.Int
-	BACGamma2                               [][3][2]*big.Int
-	Alpha, Beta, Delta                      [3]*big.Int
-	Beta2, Delta2                           [3][2]*big.Int
-	Z                                       []*big.Int
-	NVars, NPublic                          int
+// MSMG2 is the G2 flavour (bn128/g2.go:142-181 + :32-89).
+func MSMG2(bases Handle, scalars []uint64, off int) ([3][2]*big.Int, error) {
+	var out [16]uint64
+	var inf C.int
+	err := call(func() C.int {
+		return C.gs_msm_g2(C.gs_handle(bases), ptr(scalars), C.size_t(off), C.size_t(len(scalars)/4), (*C.uint64_t)(unsafe.Pointer(&out[0])), &inf)
+	})
+	runtime.KeepAlive(scalars)
+	return G2FromAffine(out[:], inf != 0), err
 }
 
-// NewGroth16Key uploads the key once per circuit (SURVEY.md hard part 4: never per proof).
-func NewGroth16Key(p Groth16KeyParts, r *big.Int) (*Groth16Key, error) {
-	at, err := UploadG1(p.At)
-	if err != nil {
-		return nil, err
+func unpackScalars(b []uint64) []*big.Int {
+	out := make([]*big.Int, len(b)/4)
+	for i := range out {
+		out[i] = word(b[4*i:])
 	}
-	defer Free(at)
-	b1, err := UploadG1(p.BACGamma1)
-	if err != nil {
-		return nil, err
-	}
-	defer Free(b1)
-	b2, err := UploadG2(p.BACGamma2)
-	if err != nil {
-		return nil, err
-	}
-	defer Free(b2)
-	cd, err := UploadG1(p.BACDelta)
-	if err != nil {
-		return nil, err
-	}
-	defer Free(cd)
-	pt, err := UploadG1(p.PowersTauDelta)
-	if err != nil {
-		return nil, err
-	}
-	defer Free(pt)
-	singles1, _ := G1Points([][3]*big.Int{p.Alpha, p.Beta, p.Delta})
-	singles2, _ := G2Points([][3][2]*big.Int{p.Beta2, p.Delta2})
-	z, err := Scalars(p.Z, r)
-	if err != nil {
-		return nil, err
-	}
-	var h C.gs_handle
-	err = status(C.gs_groth16_pk_create(C.gs_handle(at), C.gs_handle(b1), C.gs_handle(b2), C.gs_handle(cd), C.gs_handle(pt),
-		ptr(singles1[0:]), ptr(singles1[12:]), ptr(singles1[24:]), ptr(singles2[0:]), ptr(singles2[24:]),
-		ptr(z), C.size_t(len(p.Z)), C.size_t(p.NVars), C.size_t(p.NPublic), &h))
-	runtime.KeepAlive(singles1)
-	runtime.KeepAlive(singles2)
-	runtime.KeepAlive(z)
-	if err != nil {
-		return nil, err
-	}
-	k := &Groth16Key{Handle(h)}
-	runtime.SetFinalizer(k, func(k *Groth16Key) { Free(k.h) })
-	return k, nil
+	return out
 }
 
-// Prove is groth16.GenerateProofs (groth16.go:225-278) with r, s = what Utils.FqR.Rand() returned.
-// Returns PiA, PiB, PiC in the affine normal form (G1.Affine / G2.Affine of the reference's result).
-func (k *Groth16Key) Prove(w, px []*big.Int, r, s, order *big.Int) (piA [3]*big.Int, piB [3][2]*big.Int, piC [3]*big.Int, err error) {
-	wb, err := Scalars(w, order)
-	if err != nil {
-		return
+// PolyMul is PolynomialField.Mul (r1csqap/r1csqap.go:57-67).
+func PolyMul(a, b []*big.Int, order *big.Int) ([]*big.Int, error) {
+	if len(a) == 0 || len(b) == 0 {
+		return nil, errors.New("gosnark-hip: PolyMul of an empty polynomial")
 	}
-	pb, err := Scalars(px, order)
+	ab, err := Scalars(a, order)
 	if err != nil {
-		return
+		return nil, err
 	}
-	rs, err := Scalars([]*big.Int{r, s}, order)
+	bb, err := Scalars(b, order)
 	if err != nil {
-		return
+		return nil, err
 	}
-	var out [32]uint64
-	var inf [3]C.int
-	err = status(C.gs_groth16_prove(C.gs_handle(k.h), ptr(wb), C.size_t(len(w)), ptr(pb), C.size_t(len(px)),
-		ptr(rs[0:]), ptr(rs[4:]), (*C.uint64_t)(unsafe.Pointer(&out[0])), &inf[0]))
-	runtime.KeepAlive(wb)
-	runtime.KeepAlive(pb)
-	runtime.KeepAlive(rs)
+	out := make([]uint64, 4*(len(a)+len(b)-1))
+	err = call(func() C.int { return C.gs_poly_mul(ptr(ab), C.size_t(len(a)), ptr(bb), C.size_t(len(b)), ptr(out)) })
+	runtime.KeepAlive(ab)
+	runtime.KeepAlive(bb)
 	if err != nil {
-		return
+		return nil, err
 	}
-	piA = G1FromAffine(out[0:8], inf[0] != 0)
-	piB = G2FromAffine(out[8:24], inf[1] != 0)
-	piC = G1FromAffine(out[24:32], inf[2] != 0)
-	return
+	return unpackScalars(out), nil
 }
 
 // PolyDiv is PolynomialField.Div (r1csqap/r1csqap.go:70-84): quotient and remainder.
 func PolyDiv(a, b []*big.Int, order *big.Int) (quo, rem []*big.Int, err error) {
+	nq, nr := len(a)-len(b)+1, len(b)-1
+	if nq < 1 || len(b) == 0 {
+		return nil, nil, errors.New("gosnark-hip: PolyDiv needs len(a) >= len(b) >= 1")
+	}
 	ab, err := Scalars(a, order)
 	if err != nil {
 		return
@@ -274,71 +339,34 @@ func PolyDiv(a, b []*big.Int, order *big.Int) (quo, rem []*big.Int, err error) {
 	if err != nil {
 		return
 	}
-	nq, nr := len(a)-len(b)+1, len(b)-1
-	if nq < 1 || len(b) == 0 {
-		return nil, nil, errors.New("gosnark-hip: PolyDiv needs len(a) >= len(b) >= 1")
-	}
 	qb := make([]uint64, 4*nq)
 	rb := make([]uint64, 4*(nr+1))
-	err = status(C.gs_poly_div(ptr(ab), C.size_t(len(a)), ptr(bb), C.size_t(len(b)), ptr(qb), ptr(rb)))
+	err = call(func() C.int { return C.gs_poly_div(ptr(ab), C.size_t(len(a)), ptr(bb), C.size_t(len(b)), ptr(qb), ptr(rb)) })
 	runtime.KeepAlive(ab)
 	runtime.KeepAlive(bb)
 	if err != nil {
 		return
 	}
-	for i := 0; i < nq; i++ {
-		quo = append(quo, word(qb[4*i:]))
-	}
-	for i := 0; i < nr; i++ {
-		rem = append(rem, word(rb[4*i:]))
-	}
-	return
+	return unpackScalars(qb), unpackScalars(rb[:4*nr]), nil
 }
 
-// Groth16VkParts carries the reference's groth16.Vk fields (groth16/groth16.go:33-43).
-type Groth16VkParts struct {
-	IC      [][3]*big.Int
-	G1Alpha [3]*big.Int
-	G2Beta  [3][2]*big.Int
-	G2Gamma [3][2]*big.Int
-	G2Delta [3][2]*big.Int
-}
-
-// Groth16Verify is groth16.VerifyProof (groth16.go:281-305): one 4-pair product check with a shared final
-// exponentiation.  Host side (gs_groth16_verify needs no Init and no device).  The reference indexes vk.IC[i+1] for
-// every public signal and panics past the end; here that is an error.
-func Groth16Verify(vk Groth16VkParts, piA [3]*big.Int, piB [3][2]*big.Int, piC [3]*big.Int, publicSignals []*big.Int, order *big.Int) (bool, error) {
-	ic, err := G1Points(vk.IC)
+// LagrangeInterpolation is PolynomialField.LagrangeInterpolation (r1csqap.go:150-158), exact for every n.
+func LagrangeInterpolation(values []*big.Int, order *big.Int) ([]*big.Int, error) {
+	vb, err := Scalars(values, order)
 	if err != nil {
-		return false, err
+		return nil, err
 	}
-	g1, err := G1Points([][3]*big.Int{vk.G1Alpha, piA, piC})
+	out := make([]uint64, 4*len(values))
+	err = call(func() C.int { return C.gs_lagrange_interpolation(ptr(vb), C.size_t(len(values)), ptr(out)) })
+	runtime.KeepAlive(vb)
 	if err != nil {
-		return false, err
+		return nil, err
 	}
-	g2, err := G2Points([][3][2]*big.Int{vk.G2Beta, vk.G2Gamma, vk.G2Delta, piB})
-	if err != nil {
-		return false, err
-	}
-	pub, err := Scalars(publicSignals, order)
-	if err != nil {
-		return false, err
-	}
-	if len(pub) == 0 {
-		pub = make([]uint64, 4)
-	}
-	var ok C.int
-	err = status(C.gs_groth16_verify(ptr(g1[0:]), ptr(g2[0:]), ptr(g2[24:]), ptr(g2[48:]), ptr(ic), C.size_t(len(vk.IC)),
-		ptr(pub), C.size_t(len(publicSignals)), ptr(g1[12:]), ptr(g2[72:]), ptr(g1[24:]), &ok))
-	runtime.KeepAlive(ic)
-	runtime.KeepAlive(g1)
-	runtime.KeepAlive(g2)
-	runtime.KeepAlive(pub)
-	return ok == 1, err
+	return unpackScalars(out), nil
 }
 
 // PairingCheck reports whether prod_i e(g1[i], g2[i]) == 1 (the seam under both verifiers, bn128/bn128.go:179-186):
-// e(A, B) == e(C, D) is PairingCheck([A, -C], [B, D]).
+// e(A, B) == e(C, D) is PairingCheck([A, -C], [B, D]).  Host code: needs no Init.
 func PairingCheck(g1 [][3]*big.Int, g2 [][3][2]*big.Int) (bool, error) {
 	if len(g1) != len(g2) {
 		return false, errors.New("gosnark-hip: PairingCheck needs as many G1 as G2 points")
@@ -355,7 +383,7 @@ func PairingCheck(g1 [][3]*big.Int, g2 [][3][2]*big.Int) (bool, error) {
 		return false, err
 	}
 	var ok C.int
-	err = status(C.gs_pairing_check(ptr(a), ptr(b), C.size_t(len(g1)), &ok))
+	err = call(func() C.int { return C.gs_pairing_check(ptr(a), ptr(b), C.size_t(len(g1)), &ok) })
 	runtime.KeepAlive(a)
 	runtime.KeepAlive(b)
 	return ok == 1, err

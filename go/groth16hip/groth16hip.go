@@ -1,0 +1,229 @@
+// Package groth16hip is the drop-in for the three Groth16 functions the reference's callers use
+// (cli/main.go:262-280, :489-508, wasm/go-snark-wasm-wrapper.go:138-204, groth16/groth16_test.go):
+//
+//	GenerateTrustedSetup(witnessLength, circuit, alphas, betas, gammas) (groth16.Setup, error)   groth16/groth16.go:94
+//	GenerateProofs(circuit, pk, w, px) (groth16.Proof, error)                                    groth16/groth16.go:225
+//	VerifyProof(vk, proof, publicSignals, debug) bool                                            groth16/groth16.go:281
+//
+// with the reference's exact signatures and types, delegating to libgosnark_hip.so through go/gosnarkhip.
+// Reviewed-not-compiled in the build image (no Go toolchain there); the C call sequence behind each function is
+// run on the GPU by tests/c/groth16_*.c (INTEGRATION.md lists the pairs).
+//
+// Device selection: everything runs on logical device Device (default 0) of gosnarkhip.Init.
+package groth16hip
+
+import (
+	"errors"
+	"fmt"
+	"math/big"
+	"sync"
+
+	"github.com/arnaucube/go-snark-study/circuitcompiler"
+	"github.com/arnaucube/go-snark-study/groth16"
+
+	"gosnarkhip"
+)
+
+// Device is the logical device the package's functions use.
+var Device = 0
+
+// MaxResidentKeys bounds the proving keys kept in HBM (a 2^20-constraint key with its window tables is ~6 GiB).
+var MaxResidentKeys = 4
+
+// A proving key is recognised by the identity of its arrays, not by the address of the Pk struct: GenerateProofs
+// receives pk BY VALUE (a fresh copy per call, groth16.go:225), but the copy shares the backing arrays.  Holding
+// the pointers in the map key also keeps those arrays alive, so an address is never reused for another key.
+type keyID struct {
+	at, ptd *[3]*big.Int
+	nAt     int
+}
+
+type entry struct {
+	key  *gosnarkhip.Groth16Key
+	used uint64
+}
+
+var (
+	mu    sync.Mutex
+	keys  = map[keyID]*entry{}
+	clock uint64
+)
+
+func idOf(pk *groth16.Pk) (keyID, error) {
+	if len(pk.G1.At) == 0 || len(pk.PowersTauDelta) == 0 {
+		return keyID{}, errors.New("groth16hip: empty proving key")
+	}
+	return keyID{&pk.G1.At[0], &pk.PowersTauDelta[0], len(pk.G1.At)}, nil
+}
+
+func remember(id keyID, k *gosnarkhip.Groth16Key) {
+	clock++
+	keys[id] = &entry{k, clock}
+	for len(keys) > MaxResidentKeys { // evict the least recently used key and give its HBM back
+		var old keyID
+		var oldest uint64 = ^uint64(0)
+		for i, e := range keys {
+			if e.used < oldest {
+				old, oldest = i, e.used
+			}
+		}
+		_ = keys[old].key.Free()
+		delete(keys, old)
+	}
+}
+
+func deviceKey(circuit circuitcompiler.Circuit, pk *groth16.Pk) (*gosnarkhip.Groth16Key, error) {
+	id, err := idOf(pk)
+	if err != nil {
+		return nil, err
+	}
+	mu.Lock()
+	defer mu.Unlock()
+	if e, ok := keys[id]; ok {
+		clock++
+		e.used = clock
+		return e.key, nil
+	}
+	k, err := gosnarkhip.NewGroth16Key(Device, gosnarkhip.Groth16KeyParts{
+		At: pk.G1.At, BACGamma1: pk.G1.BACGamma, BACDelta: pk.BACDelta, PowersTauDelta: pk.PowersTauDelta,
+		BACGamma2: pk.G2.BACGamma,
+		Alpha:     pk.G1.Alpha, Beta: pk.G1.Beta, Delta: pk.G1.Delta,
+		Beta2: pk.G2.Beta, Delta2: pk.G2.Delta,
+		Z: pk.Z, NVars: circuit.NVars, NPublic: circuit.NPublic,
+	}, groth16.Utils.FqR.Q)
+	if err != nil {
+		return nil, err
+	}
+	remember(id, k)
+	return k, nil
+}
+
+// ReleaseKey frees the resident copy of pk (if any); ReleaseAll frees every cached key.
+func ReleaseKey(pk *groth16.Pk) {
+	id, err := idOf(pk)
+	if err != nil {
+		return
+	}
+	mu.Lock()
+	defer mu.Unlock()
+	if e, ok := keys[id]; ok {
+		_ = e.key.Free()
+		delete(keys, id)
+	}
+}
+func ReleaseAll() {
+	mu.Lock()
+	defer mu.Unlock()
+	for id, e := range keys {
+		_ = e.key.Free()
+		delete(keys, id)
+	}
+}
+
+// GenerateProofs has the reference's signature and semantics (groth16/groth16.go:225-278); the proof
+// elements come back as the affine representatives [x, y, 1] of the reference's Jacobian triples.
+func GenerateProofs(circuit circuitcompiler.Circuit, pk groth16.Pk, w []*big.Int, px []*big.Int) (groth16.Proof, error) {
+	var proof groth16.Proof
+	r, err := groth16.Utils.FqR.Rand() // groth16.go:231-234
+	if err != nil {
+		return proof, err
+	}
+	s, err := groth16.Utils.FqR.Rand() // :235-238
+	if err != nil {
+		return proof, err
+	}
+	return GenerateProofsWithRS(circuit, &pk, w, px, r, s)
+}
+
+// GenerateProofsWithRS injects the randomness (needed for parity tests against a recorded proof).
+// C call sequence: tests/c/groth16_generateproofs.c.
+func GenerateProofsWithRS(circuit circuitcompiler.Circuit, pk *groth16.Pk, w, px []*big.Int, r, s *big.Int) (groth16.Proof, error) {
+	var proof groth16.Proof
+	k, err := deviceKey(circuit, pk)
+	if err != nil {
+		return proof, err // callers may fall back to groth16.GenerateProofs (the CPU reference)
+	}
+	proof.PiA, proof.PiB, proof.PiC, err = k.Prove(w, px, r, s, groth16.Utils.FqR.Q)
+	return proof, err
+}
+
+// GenerateTrustedSetup has the reference's signature (groth16/groth16.go:94-222).  The device builds the key from
+// the SPARSE R1CS: circuit.R1CS (set by circuit.GenerateR1CS, circuitcompiler/circuit.go:135-137), whose column
+// interpolants alphas / betas / gammas are by construction (r1csqap.go:161-188); if the circuit carries no R1CS the
+// column values are recovered from the polynomials.  The toxic values are drawn here exactly as the reference draws
+// them (:99-119) and returned in Setup.Toxic.  The resident key stays cached under the returned Pk, so a following
+// GenerateProofs(circuit, setup.Pk, ...) uploads nothing.  C call sequence: tests/c/groth16_setup_prove_verify.c.
+func GenerateTrustedSetup(witnessLength int, circuit circuitcompiler.Circuit, alphas, betas, gammas [][]*big.Int) (groth16.Setup, error) {
+	var setup groth16.Setup
+	var err error
+	for _, dst := range []**big.Int{&setup.Toxic.T, &setup.Toxic.Kalpha, &setup.Toxic.Kbeta, &setup.Toxic.Kgamma, &setup.Toxic.Kdelta} {
+		if *dst, err = groth16.Utils.FqR.Rand(); err != nil {
+			return groth16.Setup{}, err
+		}
+	}
+	return generateTrustedSetupWithToxic(setup, witnessLength, circuit, alphas, betas, gammas)
+}
+
+func generateTrustedSetupWithToxic(setup groth16.Setup, witnessLength int, circuit circuitcompiler.Circuit, alphas, betas, gammas [][]*big.Int) (groth16.Setup, error) {
+	order := groth16.Utils.FqR.Q
+	if len(alphas) != witnessLength || len(alphas) == 0 {
+		return groth16.Setup{}, fmt.Errorf("groth16hip: %d polynomials for a witness of length %d", len(alphas), witnessLength)
+	}
+	A, B, C := circuit.R1CS.A, circuit.R1CS.B, circuit.R1CS.C
+	if len(A) == 0 {
+		n := len(alphas[0])
+		A, B, C = gosnarkhip.R1CSFromQAP(alphas, n, order), gosnarkhip.R1CSFromQAP(betas, n, order), gosnarkhip.R1CSFromQAP(gammas, n, order)
+	}
+	ca, nvars, err := gosnarkhip.CSRFromDense(A, order)
+	if err != nil {
+		return groth16.Setup{}, err
+	}
+	cb, _, err := gosnarkhip.CSRFromDense(B, order)
+	if err != nil {
+		return groth16.Setup{}, err
+	}
+	cc, _, err := gosnarkhip.CSRFromDense(C, order)
+	if err != nil {
+		return groth16.Setup{}, err
+	}
+	k, vk, err := gosnarkhip.Groth16Setup(Device, ca, cb, cc, nvars, circuit.NPublic,
+		gosnarkhip.Groth16Toxic{T: setup.Toxic.T, Kalpha: setup.Toxic.Kalpha, Kbeta: setup.Toxic.Kbeta, Kgamma: setup.Toxic.Kgamma, Kdelta: setup.Toxic.Kdelta}, order)
+	if err != nil {
+		return groth16.Setup{}, err
+	}
+	parts, err := k.Export(len(alphas) - 1) // len(Z) = deg Z + 1 = len(alphas) - 1 (groth16.go:122-131)
+	if err != nil {
+		_ = k.Free()
+		return groth16.Setup{}, err
+	}
+	setup.Pk.G1.At, setup.Pk.G1.BACGamma, setup.Pk.G2.BACGamma = parts.At, parts.BACGamma1, parts.BACGamma2
+	setup.Pk.BACDelta, setup.Pk.PowersTauDelta, setup.Pk.Z = parts.BACDelta, parts.PowersTauDelta, parts.Z
+	setup.Pk.G1.Alpha, setup.Pk.G1.Beta, setup.Pk.G1.Delta = parts.Alpha, parts.Beta, parts.Delta
+	setup.Pk.G2.Beta, setup.Pk.G2.Delta = parts.Beta2, parts.Delta2
+	setup.Vk.IC, setup.Vk.G1.Alpha = vk.IC, vk.G1Alpha
+	setup.Vk.G2.Beta, setup.Vk.G2.Gamma, setup.Vk.G2.Delta = vk.G2Beta, vk.G2Gamma, vk.G2Delta
+	if id, err := idOf(&setup.Pk); err == nil {
+		mu.Lock()
+		remember(id, k)
+		mu.Unlock()
+	}
+	return setup, nil
+}
+
+// VerifyProof has the reference's signature (groth16/groth16.go:281-305).  Where the reference panics (more public
+// signals than vk.IC entries) or compares meaningless values (points off the curve), this returns false.
+func VerifyProof(vk groth16.Vk, proof groth16.Proof, publicSignals []*big.Int, debug bool) bool {
+	ok, err := gosnarkhip.Groth16Verify(gosnarkhip.Groth16VkParts{
+		IC: vk.IC, G1Alpha: vk.G1.Alpha, G2Beta: vk.G2.Beta, G2Gamma: vk.G2.Gamma, G2Delta: vk.G2.Delta,
+	}, proof.PiA, proof.PiB, proof.PiC, publicSignals, groth16.Utils.FqR.Q)
+	if err != nil || !ok {
+		if debug {
+			fmt.Println("❌ groth16 verification not passed")
+		}
+		return false
+	}
+	if debug {
+		fmt.Println("✓ groth16 verification passed")
+	}
+	return true
+}

@@ -1,0 +1,200 @@
+// Package snarkhip is the drop-in for the three Pinocchio functions of the reference's root package
+// (snark.go; callers cli/main.go:262-280, :337-356, wasm/go-snark-wasm-wrapper.go:21-110, snark_test.go):
+//
+//	GenerateTrustedSetup(witnessLength, circuit, alphas, betas, gammas) (snark.Setup, error)   snark.go:98
+//	GenerateProofs(circuit, pk, w, px) (snark.Proof, error)                                    snark.go:254
+//	VerifyProof(vk, proof, publicSignals, debug) bool                                          snark.go:292
+//
+// with the reference's exact signatures and types, on libgosnark_hip.so through go/gosnarkhip.  Reviewed-not-compiled
+// in the build image; the C call sequences run on the GPU as tests/c/snark_*.c.
+package snarkhip
+
+import (
+	"errors"
+	"fmt"
+	"math/big"
+	"sync"
+
+	snark "github.com/arnaucube/go-snark-study"
+	"github.com/arnaucube/go-snark-study/circuitcompiler"
+
+	"gosnarkhip"
+)
+
+// Device is the logical device the package's functions use; MaxResidentKeys bounds the keys kept in HBM.
+var (
+	Device          = 0
+	MaxResidentKeys = 4
+)
+
+// identity of a key = identity of its arrays (pk arrives by value, its arrays are shared; see groth16hip)
+type keyID struct {
+	a, g1t *[3]*big.Int
+	n      int
+}
+type entry struct {
+	key  *gosnarkhip.PinocchioKey
+	used uint64
+}
+
+var (
+	mu    sync.Mutex
+	keys  = map[keyID]*entry{}
+	clock uint64
+)
+
+func idOf(pk *snark.Pk) (keyID, error) {
+	if len(pk.A) == 0 || len(pk.G1T) == 0 {
+		return keyID{}, errors.New("snarkhip: empty proving key")
+	}
+	return keyID{&pk.A[0], &pk.G1T[0], len(pk.A)}, nil
+}
+
+func remember(id keyID, k *gosnarkhip.PinocchioKey) {
+	clock++
+	keys[id] = &entry{k, clock}
+	for len(keys) > MaxResidentKeys {
+		var old keyID
+		var oldest uint64 = ^uint64(0)
+		for i, e := range keys {
+			if e.used < oldest {
+				old, oldest = i, e.used
+			}
+		}
+		_ = keys[old].key.Free()
+		delete(keys, old)
+	}
+}
+
+func deviceKey(circuit circuitcompiler.Circuit, pk *snark.Pk) (*gosnarkhip.PinocchioKey, error) {
+	id, err := idOf(pk)
+	if err != nil {
+		return nil, err
+	}
+	mu.Lock()
+	defer mu.Unlock()
+	if e, ok := keys[id]; ok {
+		clock++
+		e.used = clock
+		return e.key, nil
+	}
+	k, err := gosnarkhip.NewPinocchioKey(Device, gosnarkhip.PinocchioKeyParts{
+		G1T: pk.G1T, A: pk.A, B: pk.B, C: pk.C, Kp: pk.Kp, Ap: pk.Ap, Bp: pk.Bp, Cp: pk.Cp, Z: pk.Z,
+		NVars: circuit.NVars, NPublic: circuit.NPublic,
+	}, snark.Utils.FqR.Q)
+	if err != nil {
+		return nil, err
+	}
+	remember(id, k)
+	return k, nil
+}
+
+// ReleaseAll frees every cached key.
+func ReleaseAll() {
+	mu.Lock()
+	defer mu.Unlock()
+	for id, e := range keys {
+		_ = e.key.Free()
+		delete(keys, id)
+	}
+}
+
+// GenerateProofs has the reference's signature and semantics (snark.go:254-289): no randomness, eight proof elements,
+// returned in the affine normal form.  C call sequence: tests/c/snark_generateproofs.c.
+func GenerateProofs(circuit circuitcompiler.Circuit, pk snark.Pk, w []*big.Int, px []*big.Int) (snark.Proof, error) {
+	var proof snark.Proof
+	k, err := deviceKey(circuit, &pk)
+	if err != nil {
+		return proof, err
+	}
+	p, err := k.Prove(w, px, snark.Utils.FqR.Q)
+	if err != nil {
+		return proof, err
+	}
+	proof.PiA, proof.PiAp, proof.PiB, proof.PiBp = p.PiA, p.PiAp, p.PiB, p.PiBp
+	proof.PiC, proof.PiCp, proof.PiH, proof.PiKp = p.PiC, p.PiCp, p.PiH, p.PiKp
+	return proof, nil
+}
+
+// GenerateTrustedSetup has the reference's signature (snark.go:98-251): toxic values drawn as the reference draws them
+// (:114-149, RhoC = RhoA * RhoB), key built on the device from circuit.R1CS (or from the polynomials' values when the
+// circuit carries none), exported into snark.Setup and kept resident.  C call sequence: tests/c/snark_setup_prove_verify.c.
+func GenerateTrustedSetup(witnessLength int, circuit circuitcompiler.Circuit, alphas, betas, gammas [][]*big.Int) (snark.Setup, error) {
+	var setup snark.Setup
+	var err error
+	fq := snark.Utils.FqR
+	for _, dst := range []**big.Int{&setup.Toxic.T, &setup.Toxic.Ka, &setup.Toxic.Kb, &setup.Toxic.Kc, &setup.Toxic.Kbeta, &setup.Toxic.Kgamma,
+		&setup.Toxic.RhoA, &setup.Toxic.RhoB} {
+		if *dst, err = fq.Rand(); err != nil {
+			return snark.Setup{}, err
+		}
+	}
+	setup.Toxic.RhoC = fq.Mul(setup.Toxic.RhoA, setup.Toxic.RhoB)
+	order := fq.Q
+	if len(alphas) != witnessLength || len(alphas) == 0 {
+		return snark.Setup{}, fmt.Errorf("snarkhip: %d polynomials for a witness of length %d", len(alphas), witnessLength)
+	}
+	A, B, C := circuit.R1CS.A, circuit.R1CS.B, circuit.R1CS.C
+	if len(A) == 0 {
+		n := len(alphas[0])
+		A, B, C = gosnarkhip.R1CSFromQAP(alphas, n, order), gosnarkhip.R1CSFromQAP(betas, n, order), gosnarkhip.R1CSFromQAP(gammas, n, order)
+	}
+	ca, nvars, err := gosnarkhip.CSRFromDense(A, order)
+	if err != nil {
+		return snark.Setup{}, err
+	}
+	cb, _, err := gosnarkhip.CSRFromDense(B, order)
+	if err != nil {
+		return snark.Setup{}, err
+	}
+	cc, _, err := gosnarkhip.CSRFromDense(C, order)
+	if err != nil {
+		return snark.Setup{}, err
+	}
+	k, vk, err := gosnarkhip.PinocchioSetup(Device, ca, cb, cc, nvars, circuit.NPublic, gosnarkhip.PinocchioToxic{
+		T: setup.Toxic.T, Ka: setup.Toxic.Ka, Kb: setup.Toxic.Kb, Kc: setup.Toxic.Kc, Kbeta: setup.Toxic.Kbeta, Kgamma: setup.Toxic.Kgamma,
+		RhoA: setup.Toxic.RhoA, RhoB: setup.Toxic.RhoB}, order)
+	if err != nil {
+		return snark.Setup{}, err
+	}
+	parts, err := k.Export(len(alphas) - 1)
+	if err != nil {
+		_ = k.Free()
+		return snark.Setup{}, err
+	}
+	setup.Pk.G1T, setup.Pk.A, setup.Pk.B, setup.Pk.C, setup.Pk.Kp = parts.G1T, parts.A, parts.B, parts.C, parts.Kp
+	setup.Pk.Ap, setup.Pk.Bp, setup.Pk.Cp, setup.Pk.Z = parts.Ap, parts.Bp, parts.Cp, parts.Z
+	setup.Vk.Vka, setup.Vk.Vkb, setup.Vk.Vkc, setup.Vk.IC = vk.Vka, vk.Vkb, vk.Vkc, vk.IC
+	setup.Vk.G1Kbg, setup.Vk.G2Kbg, setup.Vk.G2Kg, setup.Vk.Vkz = vk.G1Kbg, vk.G2Kbg, vk.G2Kg, vk.Vkz
+	if id, err := idOf(&setup.Pk); err == nil {
+		mu.Lock()
+		remember(id, k)
+		mu.Unlock()
+	}
+	return setup, nil
+}
+
+// VerifyProof has the reference's signature (snark.go:292-368); debug prints name the failing check like the
+// reference's messages do.
+func VerifyProof(vk snark.Vk, proof snark.Proof, publicSignals []*big.Int, debug bool) bool {
+	ok, failed, err := gosnarkhip.PinocchioVerify(gosnarkhip.PinocchioVkParts{
+		Vka: vk.Vka, Vkb: vk.Vkb, Vkc: vk.Vkc, IC: vk.IC, G1Kbg: vk.G1Kbg, G2Kbg: vk.G2Kbg, G2Kg: vk.G2Kg, Vkz: vk.Vkz,
+	}, gosnarkhip.PinocchioProof{PiA: proof.PiA, PiAp: proof.PiAp, PiB: proof.PiB, PiBp: proof.PiBp, PiC: proof.PiC, PiCp: proof.PiCp,
+		PiH: proof.PiH, PiKp: proof.PiKp}, publicSignals, snark.Utils.FqR.Q)
+	if err != nil || !ok {
+		if debug {
+			names := []string{"", "e(piA, Va) == e(piA', g2)", "e(Vb, piB) == e(piB', g2)", "e(piC, Vc) == e(piC', g2)",
+				"e(Vkx+piA, piB) == e(piH, Vkz) * e(piC, g2)", "e(Vkx+piA+piC, g2KbetaKgamma) * e(g1KbetaKgamma, piB) == e(piK, g2Kgamma)"}
+			if err == nil && failed >= 1 && failed <= 5 {
+				fmt.Println("❌", names[failed], "not passed")
+			} else {
+				fmt.Println("❌ verification not passed:", err)
+			}
+		}
+		return false
+	}
+	if debug {
+		fmt.Println("✓ verification passed")
+	}
+	return true
+}

@@ -1,0 +1,48 @@
+/* snarkhip.GenerateTrustedSetup -> GenerateProofs -> VerifyProof (go/snarkhip/snarkhip.go), as C:
+ *   gs_pinocchio_setup (sparse R1CS + eight toxic values; snark.go:98-251) -> gs_pinocchio_pk_export 0..8 -> gs_pinocchio_prove on
+ *   the resident key -> gs_pinocchio_verify with the vk the setup returned.
+ * argv: r1cs file, instance file (w, px, public), output file:
+ *   proof 72 | inf 8 | ok, failed | vk (144 + 12 (npublic + 1)) | A, Ap (m x 12) | B (m x 24) | Bp, C, Cp, Kp (m x 12) | G1T (nz x 12) | Z (nz x 4) */
+#include "instance.h"
+
+int main(int argc, char** argv) {
+  if (argc != 4) return 9;
+  r1cs_instance r;
+  pinocchio_instance g;
+  if (read_r1cs_instance(argv[1], &r) || read_pinocchio_instance(argv[2], &g) || r.ntoxic != 8) return 8;
+  const size_t m = r.m, nz = m - 1, nvk = 144 + 12 * (r.npublic + 1);
+  const size_t total = 82 + nvk + m * 12 * 6 + m * 24 + nz * 12 + nz * 4;
+  uint64_t* out = (uint64_t*)calloc(total, 8);
+  uint64_t* vk = out + 82;
+  uint64_t* arr[9];
+  const size_t words[9] = {m * 12, m * 12, m * 24, m * 12, m * 12, m * 12, m * 12, nz * 12, nz * 4};
+  const size_t count[9] = {m, m, m, m, m, m, m, nz, nz};
+  arr[0] = vk + nvk;
+  for (int k = 1; k < 9; ++k) arr[k] = arr[k - 1] + words[k - 1];
+  int dev = 0, inf[8], ok = 0, failed = -1;
+  uint64_t proof[108];
+  gs_handle pk;
+  CHECK(gs_init(&dev, 1));
+  CHECK(gs_set_device(0));
+  CHECK(gs_pinocchio_setup(r.n, r.m, r.npublic, r.rowptr[0], r.col[0], r.val[0], r.rowptr[1], r.col[1], r.val[1], r.rowptr[2], r.col[2], r.val[2],
+                           r.toxic, &pk, vk));
+  for (int k = 0; k < 9; ++k) CHECK(gs_pinocchio_pk_export(pk, k, arr[k], count[k]));
+  CHECK(gs_pinocchio_prove(pk, g.w, g.m, g.px, g.npx, out, inf));
+  memset(proof, 0, sizeof proof);
+  {
+    const int src[8] = {0, 8, 16, 32, 40, 48, 56, 64}, dst[8] = {0, 12, 24, 48, 60, 72, 84, 96};
+    for (int k = 0; k < 8; ++k) {
+      if (inf[k]) continue;
+      if (k == 2) { memcpy(proof + dst[k], out + src[k], 128); proof[dst[k] + 16] = 1; }
+      else { memcpy(proof + dst[k], out + src[k], 64); proof[dst[k] + 8] = 1; }
+    }
+  }
+  CHECK(gs_pinocchio_verify(vk, vk + 24, vk + 36, vk + 60, vk + 72, vk + 96, vk + 120, vk + 144, r.npublic + 1, g.pub, r.npublic, proof, &ok, &failed));
+  for (int i = 0; i < 8; ++i) out[72 + i] = (uint64_t)inf[i];
+  out[80] = (uint64_t)ok; out[81] = (uint64_t)failed;
+  if (write_words(argv[3], out, total)) return 4;
+  CHECK(gs_free(pk));
+  gs_shutdown();
+  printf("OK\n");
+  return 0;
+}

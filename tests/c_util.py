@@ -56,3 +56,33 @@ def write_groth_instance(outdir, rec, public=(35,)):
              capi.g1_points_to_u64([vk.G1_Alpha]), capi.g2_points_to_u64([vk.G2_Beta, vk.G2_Gamma, vk.G2_Delta]), capi.g1_points_to_u64(vk.IC),
              capi.ints_to_u64(list(public))]
     return _blob(os.path.join(str(outdir), "groth_instance.bin"), parts)
+
+
+def write_pinocchio_instance(outdir, rec, public=(35,)):
+    """snark.Pk / Vk / w / px of a Pinocchio golden (layout: tests/c/instance.h, read_pinocchio_instance)."""
+    from gosnark_amd import utils
+    pk, vk = utils.SetupFromString(rec["setup"])
+    m, npx = len(rec["w"]), len(rec["px"])
+    g1 = capi.g1_points_to_u64
+    parts = [np.array([m, npx, len(pk.Z), len(pk.G1T), len(vk.IC), rec["circuit"]["NPublic"]], dtype=np.uint64),
+             g1(pk.A), g1(pk.Ap), capi.g2_points_to_u64(pk.B), g1(pk.Bp), g1(pk.C), g1(pk.Cp), g1(pk.Kp), g1(pk.G1T),
+             capi.ints_to_u64([z % O.R for z in pk.Z]), capi.ints_to_u64([x % O.R for x in rec["w"]]), capi.ints_to_u64([x % O.R for x in rec["px"]]),
+             capi.g2_points_to_u64([vk.Vka]), g1([vk.Vkb]), capi.g2_points_to_u64([vk.Vkc]), g1([vk.G1Kbg]),
+             capi.g2_points_to_u64([vk.G2Kbg, vk.G2Kg, vk.Vkz]), g1(vk.IC), capi.ints_to_u64(list(public))]
+    return _blob(os.path.join(str(outdir), "pinocchio_instance.bin"), parts)
+
+
+def write_r1cs(outdir, dense_abc, npublic, toxic, name="r1cs.bin"):
+    """Three dense R1CS matrices ([constraint][variable] ints) as CSR + the toxic values (read_r1cs_instance)."""
+    from gosnark_amd import r1csqap
+    n, m = len(dense_abc[0]), len(dense_abc[0][0])
+    parts = [np.array([n, m, npublic, len(toxic)], dtype=np.uint64)]
+    for mat in dense_abc:
+        rp, cl, vl = r1csqap.csr_from_rows([{k: v for k, v in enumerate(row) if v} for row in mat])
+        parts += [np.array([len(cl)], dtype=np.uint64), rp.astype(np.uint64), cl.astype(np.uint64), vl]
+    parts.append(capi.ints_to_u64([t % O.R for t in toxic]))
+    return _blob(os.path.join(str(outdir), name), parts)
+
+
+def read_words(path):
+    return np.fromfile(path, dtype="<u8")

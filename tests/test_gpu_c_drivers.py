@@ -1,0 +1,143 @@
+"""-m gpu: every Go wrapper's exact C call sequence, run from plain C processes (no Python, no torch) against the
+reference's own goldens.  The Go layer (go/) cannot be compiled in this image; these programs are its executable
+mirror -- INTEGRATION.md lists the wrapper <-> program pairs."""
+import numpy as np
+import pytest
+
+import gosnark_amd  # noqa: F401
+from gosnark_amd import capi
+import c_util
+import golden_util as GU
+from oracle import ref_py as O
+
+pytestmark = pytest.mark.gpu
+
+
+def aff1(p):
+    a = O.G1.Affine(GU.g1(p) if not isinstance(p[0], int) else p)
+    return [0, 0] if a is None else [a[0], a[1]]
+
+
+def aff2(p):
+    a = O.G2.Affine(GU.g2(p) if not isinstance(p[0][0], int) else p)
+    return [0, 0, 0, 0] if a is None else [a[0][0], a[0][1], a[1][0], a[1][1]]
+
+
+def jac1(p):
+    a = aff1(p)
+    return a + [1] if any(a) else [0, 0, 0]
+
+
+def jac2(p):
+    a = aff2(p)
+    return a + [1, 0] if any(a) else [0] * 6
+
+
+def words(arr):
+    return capi.u64_to_ints(np.ascontiguousarray(arr))
+
+
+def groth_toxic():
+    return tuple(int.from_bytes(bytes((i * k + 7) & 0xff for i in range(30)), "big") % O.R for k in (3, 5, 7, 11, 13))
+
+
+def pinocchio_toxic():
+    return tuple(int.from_bytes(bytes((i * k + 9) & 0xff for i in range(30)), "big") % O.R for k in (3, 5, 7, 11, 13, 17, 19, 23))
+
+
+def test_groth16_generateproofs_c_sequence_reproduces_the_reference_proof(tmp_path):
+    """go/groth16hip.GenerateProofsWithRS + VerifyProof == tests/c/groth16_generateproofs.c: the x^3 + x + 5 key, witness, px and
+    (r, s) as flat limb buffers -> byte for byte the affine form of the proof the reference's compiled prover produced."""
+    rec = GU.load("groth_x3")
+    blob = c_util.write_groth_instance(tmp_path, rec)
+    out = tmp_path / "proof.bin"
+    assert c_util.build_and_run("groth16_generateproofs.c", [str(blob), str(out)], tmp_path).startswith("OK")
+    raw = c_util.read_words(out)
+    assert list(raw[32:36]) == [0, 0, 0, 1]                        # no infinities; right input accepted and wrong one rejected
+    assert words(raw[:32]) == aff1(rec["proof"]["PiA"]) + aff2(rec["proof"]["PiB"]) + aff1(rec["proof"]["PiC"])
+
+
+def test_groth16_setup_prove_verify_c_sequence(tmp_path):
+    """go/groth16hip.GenerateTrustedSetup -> GenerateProofs -> VerifyProof == tests/c/groth16_setup_prove_verify.c: the key the
+    device builds from the sparse R1CS and the golden's toxic recipe, read back with gs_groth16_pk_export, is the key the
+    reference's verifier accepted; the proof made with it is the reference prover's proof."""
+    rec = GU.load("groth_x3")
+    blob = c_util.write_groth_instance(tmp_path, rec)
+    r1cs = c_util.write_r1cs(tmp_path, (O.X3_R1CS_A, O.X3_R1CS_B, O.X3_R1CS_C), 1, groth_toxic())
+    out = tmp_path / "setup.bin"
+    assert c_util.build_and_run("groth16_setup_prove_verify.c", [str(r1cs), str(blob), str(out)], tmp_path).strip() == "OK"
+    raw = c_util.read_words(out)
+    m, nz, npub = 8, 7, 1
+    assert list(raw[32:36]) == [0, 0, 0, 1]
+    assert words(raw[:32]) == aff1(rec["proof"]["PiA"]) + aff2(rec["proof"]["PiB"]) + aff1(rec["proof"]["PiC"])
+    pos = 36
+    svk, opk = rec["setup"]["Vk"], GU.groth_pk(rec["setup"])
+    nvk = 84 + 12 * (npub + 1)
+    want_vk = jac1(svk["G1"]["Alpha"]) + jac2(svk["G2"]["Beta"]) + jac2(svk["G2"]["Gamma"]) + jac2(svk["G2"]["Delta"])
+    for p in svk["IC"]:
+        want_vk += jac1(p)
+    assert words(raw[pos:pos + nvk]) == want_vk
+    pos += nvk
+    for arr, jac, w in ((opk.G1_At, jac1, 12), (opk.G1_BACGamma, jac1, 12), (opk.G2_BACGamma, jac2, 24), (opk.BACDelta, jac1, 12),
+                        (opk.PowersTauDelta, jac1, 12)):
+        want = [x for p in arr for x in jac(p)]
+        assert words(raw[pos:pos + w * len(arr)]) == want
+        pos += w * len(arr)
+    assert len(opk.PowersTauDelta) == nz
+    want_single = jac1(opk.G1_Alpha) + jac1(opk.G1_Beta) + jac1(opk.G1_Delta) + jac2(opk.G2_Beta) + jac2(opk.G2_Delta)
+    assert words(raw[pos:pos + 84]) == want_single
+    pos += 84
+    assert words(raw[pos:pos + 4 * nz]) == [z % O.R for z in opk.Z] and m == len(opk.G1_At)
+
+
+@pytest.mark.parametrize("golden", ["pinocchio_x3_fixture", "pinocchio_rand_m9"])
+def test_snark_generateproofs_c_sequence_reproduces_the_reference_proof(tmp_path, golden):
+    """go/snarkhip.GenerateProofs + VerifyProof == tests/c/snark_generateproofs.c, on the reference's own wasm/index.js fixture
+    (Pinocchio index.js fixture -> byte-identical affine proof) and on a random instance."""
+    rec = GU.load(golden)
+    public = [x for x in rec["w"][1:1 + rec["circuit"]["NPublic"]]]
+    blob = c_util.write_pinocchio_instance(tmp_path, rec, public)
+    out = tmp_path / "proof.bin"
+    assert c_util.build_and_run("snark_generateproofs.c", [str(blob), str(out)], tmp_path).strip() == "OK"
+    raw = c_util.read_words(out)
+    pr = rec["proof"]
+    want = aff1(pr["PiA"]) + aff1(pr["PiAp"]) + aff2(pr["PiB"]) + aff1(pr["PiBp"]) + aff1(pr["PiC"]) + aff1(pr["PiCp"]) + aff1(pr["PiH"]) + aff1(pr["PiKp"])
+    assert words(raw[:72]) == want
+    assert list(raw[72:80]) == [1 if not any(aff1(pr[k])) else 0 for k in ("PiA", "PiAp")] + [0] + \
+        [1 if not any(aff1(pr[k])) else 0 for k in ("PiBp", "PiC", "PiCp", "PiH", "PiKp")]
+    if golden == "pinocchio_x3_fixture":
+        assert [v["result"] for v in rec["verify"]] == ["true", "false"]
+        assert list(raw[80:82]) == [1, 0] and raw[82] == 0 and raw[83] != 0      # accepted; wrong public input fails a named check
+
+
+def test_snark_setup_prove_verify_c_sequence(tmp_path):
+    """go/snarkhip.GenerateTrustedSetup -> GenerateProofs -> VerifyProof == tests/c/snark_setup_prove_verify.c."""
+    rec = GU.load("pinocchio_x3_setup")
+    blob = c_util.write_pinocchio_instance(tmp_path, rec)
+    r1cs = c_util.write_r1cs(tmp_path, (O.X3_R1CS_A, O.X3_R1CS_B, O.X3_R1CS_C), 1, pinocchio_toxic())
+    out = tmp_path / "setup.bin"
+    assert c_util.build_and_run("snark_setup_prove_verify.c", [str(r1cs), str(blob), str(out)], tmp_path).strip() == "OK"
+    raw = c_util.read_words(out)
+    pr, spk, svk = rec["proof"], rec["setup"]["Pk"], rec["setup"]["Vk"]
+    want = aff1(pr["PiA"]) + aff1(pr["PiAp"]) + aff2(pr["PiB"]) + aff1(pr["PiBp"]) + aff1(pr["PiC"]) + aff1(pr["PiCp"]) + aff1(pr["PiH"]) + aff1(pr["PiKp"])
+    assert words(raw[:72]) == want and list(raw[80:82]) == [1, 0]
+    pos = 82
+    want_vk = jac2(svk["Vka"]) + jac1(svk["Vkb"]) + jac2(svk["Vkc"]) + jac1(svk["G1Kbg"]) + jac2(svk["G2Kbg"]) + jac2(svk["G2Kg"]) + jac2(svk["Vkz"])
+    for p in svk["IC"]:
+        want_vk += jac1(p)
+    assert words(raw[pos:pos + len(want_vk)]) == want_vk
+    pos += len(want_vk)
+    for name, w in (("A", 12), ("Ap", 12), ("B", 24), ("Bp", 12), ("C", 12), ("Cp", 12), ("Kp", 12), ("G1T", 12)):
+        arr = spk[name]
+        want = [x for p in arr for x in (jac2(p) if w == 24 else jac1(p))]
+        if name in ("A", "Ap"):                                     # infinity for i <= NPublic: what snark.go:265 skips
+            want = [0] * 24 + want[24:]
+        assert words(raw[pos:pos + w * len(arr)]) == want, name
+        pos += w * len(arr)
+    assert words(raw[pos:pos + 4 * len(spk["Z"])]) == [int(z) % O.R for z in spk["Z"]]
+
+
+def test_prove_batch_c_sequence_two_logical_devices(tmp_path):
+    """go/gosnarkhip.ProveBatch == tests/c/batch_devices.c."""
+    blob = c_util.write_groth_instance(tmp_path, GU.load("groth_x3"))
+    assert c_util.build_and_run("batch_devices.c", [str(blob)], tmp_path).strip().endswith("OK")

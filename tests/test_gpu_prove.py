@@ -771,86 +771,3 @@ def test_pinocchio_resident_key_round_trips_through_the_binary_container(tmp_pat
     assert snark.VerifyProof(vk2, got, [35]) is True and snark.VerifyProof(vk2, got, [34]) is False
 
 
-def test_plain_c_process_proves_the_reference_instance(tmp_path):
-    """The drop-in boundary as cgo would use it, from a process without Python or torch: a C program reads the x^3 + x + 5
-    key, witness, px and (r, s) as flat limb buffers, uploads the key, calls gs_groth16_prove and gs_groth16_verify, and
-    writes the proof; it must be the proof the reference's compiled prover produced."""
-    import os
-    import shutil
-    import subprocess
-    from gosnark_amd import utils
-    gcc = shutil.which("gcc")
-    if not gcc:
-        pytest.skip("no gcc")
-    rec = GU.load("groth_x3")
-    opk = GU.groth_pk(rec["setup"])
-    _, vk = utils.GrothSetupFromString(rec["setup"])
-    r, s = GU.rs_from_stream(rec["rand"])
-    m, npx = len(rec["w"]), len(rec["px"])
-    blob = tmp_path / "instance.bin"
-    parts = [np.array([m, npx, len(opk.Z), len(opk.PowersTauDelta), len(vk.IC)], dtype=np.uint64),
-             capi.g1_points_to_u64(opk.G1_At), capi.g1_points_to_u64(opk.G1_BACGamma), capi.g2_points_to_u64(opk.G2_BACGamma),
-             capi.g1_points_to_u64(opk.BACDelta), capi.g1_points_to_u64(opk.PowersTauDelta),
-             capi.g1_points_to_u64([opk.G1_Alpha, opk.G1_Beta, opk.G1_Delta]), capi.g2_points_to_u64([opk.G2_Beta, opk.G2_Delta]),
-             capi.ints_to_u64([z % O.R for z in opk.Z]), capi.ints_to_u64([x % O.R for x in rec["w"]]),
-             capi.ints_to_u64([x % O.R for x in rec["px"]]), capi.ints_to_u64([r, s]),
-             capi.g1_points_to_u64([vk.G1_Alpha]), capi.g2_points_to_u64([vk.G2_Beta, vk.G2_Gamma, vk.G2_Delta]), capi.g1_points_to_u64(vk.IC),
-             capi.ints_to_u64([35])]
-    blob.write_bytes(b"".join(np.ascontiguousarray(p, dtype="<u8").tobytes() for p in parts))
-    src = tmp_path / "prove.c"
-    src.write_text(r'''#include "gosnark_hip.h"
-#include <stdio.h>
-#include <stdlib.h>
-#define CHECK(x) do { int _s = (x); if (_s != 0) { printf("FAIL %s: %d %s\n", #x, _s, gs_last_error()); return 1; } } while (0)
-static uint64_t* take(uint64_t** p, size_t words) { uint64_t* r = *p; *p += words; return r; }
-int main(int argc, char** argv) {
-  if (argc != 3) return 9;
-  FILE* f = fopen(argv[1], "rb");
-  if (!f) return 8;
-  fseek(f, 0, SEEK_END); long bytes = ftell(f); fseek(f, 0, SEEK_SET);
-  uint64_t* buf = malloc((size_t)bytes), *p = buf;
-  if (fread(buf, 1, (size_t)bytes, f) != (size_t)bytes) return 7;
-  fclose(f);
-  size_t m = p[0], npx = p[1], nz = p[2], nptd = p[3], nic = p[4]; p += 5;
-  uint64_t *at = take(&p, m * 12), *b1 = take(&p, m * 12), *b2 = take(&p, m * 24), *cd = take(&p, m * 12), *pt = take(&p, nptd * 12);
-  uint64_t *abd = take(&p, 36), *bd2 = take(&p, 48), *z = take(&p, nz * 4), *w = take(&p, m * 4), *px = take(&p, npx * 4), *rs = take(&p, 8);
-  uint64_t *vka = take(&p, 12), *vk2 = take(&p, 72), *ic = take(&p, nic * 12), *pub = take(&p, 4);
-  int dev = 0, inf[3], ok = 0;
-  gs_handle hat, hb1, hb2, hcd, hpt, pk;
-  uint64_t proof[32], jac[48];
-  CHECK(gs_init(&dev, 1));
-  CHECK(gs_g1_upload(at, m, &hat)); CHECK(gs_g1_upload(b1, m, &hb1)); CHECK(gs_g2_upload(b2, m, &hb2));
-  CHECK(gs_g1_upload(cd, m, &hcd)); CHECK(gs_g1_upload(pt, nptd, &hpt));
-  CHECK(gs_groth16_pk_create(hat, hb1, hb2, hcd, hpt, abd, abd + 12, abd + 24, bd2, bd2 + 24, z, nz, m, 1, &pk));
-  CHECK(gs_groth16_prove(pk, w, m, px, npx, rs, rs + 4, proof, inf));
-  /* affine [x, y] -> Jacobian [x, y, 1] for the verifier */
-  for (int i = 0; i < 48; ++i) jac[i] = 0;
-  for (int i = 0; i < 8; ++i) { jac[i] = proof[i]; jac[36 + i] = proof[24 + i]; }
-  jac[8] = 1; jac[44] = 1;
-  for (int i = 0; i < 16; ++i) jac[12 + i] = proof[8 + i];
-  jac[28] = 1;
-  CHECK(gs_groth16_verify(vka, vk2, vk2 + 24, vk2 + 48, ic, nic, pub, 1, jac, jac + 12, jac + 36, &ok));
-  f = fopen(argv[2], "wb");
-  fwrite(proof, 8, 32, f); fwrite(inf, sizeof(int), 3, f); fwrite(&ok, sizeof(int), 1, f);
-  fclose(f);
-  gs_shutdown();
-  printf("OK\n");
-  return 0;
-}
-''')
-    exe = tmp_path / "prove"
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    libdir = os.path.join(root, "go-snark-study_amd")
-    subprocess.check_call([gcc, "-std=c99", "-Wall", "-Werror", "-I", os.path.join(root, "include"), str(src), "-o", str(exe),
-                           "-L", libdir, "-lgosnark_hip", "-Wl,-rpath," + libdir])
-    outp = tmp_path / "proof.bin"
-    run = subprocess.run([str(exe), str(blob), str(outp)], capture_output=True, text=True, timeout=300)
-    assert run.returncode == 0 and run.stdout.strip().endswith("OK"), run.stdout + run.stderr
-    raw = outp.read_bytes()
-    words = capi.u64_to_ints(np.frombuffer(raw[:256], dtype="<u8"))
-    flags = np.frombuffer(raw[256:272], dtype=np.int32)
-    assert list(flags) == [0, 0, 0, 1]                                 # no infinities; gs_groth16_verify accepted
-    a, b, c = jac_affine_g1(GU.g1(rec["proof"]["PiA"])), jac_affine_g2(GU.g2(rec["proof"]["PiB"])), jac_affine_g1(GU.g1(rec["proof"]["PiC"]))
-    assert (words[0], words[1]) == (a[0], a[1])
-    assert ((words[2], words[3]), (words[4], words[5])) == (b[0], b[1])
-    assert (words[6], words[7]) == (c[0], c[1])
