@@ -1,27 +1,40 @@
 #!/usr/bin/env python
 """bench.py -- Groth16 prove throughput (constraints/s) of the HIP prover on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--log2n 20] [--workload prove|msm_g1|msm_sharded]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--reps R] [--log2n 20]
+                    [--workload prove|prove_from_r1cs|prove_sharded|prove_pinocchio|msm_g1|msm_sharded] [--logical-shards S]
 
 A "step" is one full groth16.GenerateProofs (groth16/groth16.go:225-278: H(x) = P(x)/Z(x), the
 five MSMs, the O(1) tail) over a synthetic instance with n = 2^log2n constraints, m = n + 1
 variables, NPublic = 1 (BASELINE.json configs[2]); the proving key, w and px are resident in HBM
-before the timed region.  N > 1 (launched by torch.distributed.run, one rank per GPU): every rank
-proves its own independent instance of the same size -- the batch-of-proofs partition of
-BASELINE.json configs[4]; no data-path collective -- so scaling is weak and `value` is
-N * n * K / (max-over-ranks time).  `--workload msm_sharded` instead shards ONE G1 MSM of
-N * 2^log2n terms across the ranks with an all-gather of the per-rank partial points
-(configs[3]).
+before the timed region.  The timed region (K steps between barrier + synchronize) is repeated R
+times; `ms_per_step` / `value` are the MEDIAN repetition, every repetition is listed.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): every rank proves its own independent
+instance of the same size -- the batch-of-proofs partition of BASELINE.json configs[4]; no data-path
+collective -- so scaling is weak and `value` is N * n * K / (max-over-ranks time).
+`--workload prove_sharded / msm_sharded` shards ONE proof / ONE G1 MSM across the ranks and gathers the
+partial points INSIDE the library over RCCL (gs_groth16_prove_sharded / gs_msm_g1_sharded; configs[3],
+SURVEY 8e).  With `--logical-shards S` on ONE GPU the S shards run as S logical devices of one process
+(gs_groth16_prove_multi / gs_msm_g1_multi): per-shard times are measured and an S-GPU figure is MODELLED
+from them (labelled as such) -- there is no multi-GPU hardware behind a gpurun call.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
   roofline:     the dominant kernel (G1 bucket accumulation) against the HBM roofline,
   cpu_baseline: the reference algorithm (oracle/gs_oracle.c: naive MulScalar/Add loops + schoolbook
-                Div) timed on ONE host core on a bounded sample (rank 0, N = 1 only).
+                Div) timed on ONE host core on a bounded sample (rank 0, N = 1 only),
+and, on the default single-GPU run, the second half of BASELINE's metric (G1-MSM terms/s at 2^20 and
+2^16), the blocking-call latency, witness -> proof from the resident sparse R1CS, the host-buffer
+entry point, and the reference's own compiled prover (wasm under node) on a small instance.
 """
 import argparse
 import json
 import os
+import shutil
+import statistics
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -35,8 +48,9 @@ import gosnark_amd  # noqa: F401
 from gosnark_amd import capi, groth16, synth
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+MAD_PEAK_T = 31.5              # T lane-mad/s, v_mad_u64_u32, measured: tools/ubench_valu.hip -> profiles/r01_ubench_valu.txt
 G1_TERM_BYTES = 96             # 32 B scalar + 64 B affine base per G1 MSM term
-G2_TERM_BYTES = 160
+MADS_PER_MIXED_ADD = 1467      # 6 products (162 mads) + 2 squarings (126) + one two-term product (243)
 R = groth16.R
 
 
@@ -81,7 +95,6 @@ def cpu_baseline(log2n_sample, seed):
     via oracle/gs_oracle.c, on an instance with 2^log2n_sample constraints."""
     from oracle import c_oracle as C            # checker/baseline only; never on the product path
     n = 1 << log2n_sample
-    m = n + 1
     inst = synth.random_instance(n, seed)       # device arrays -> downloaded Jacobian copies for the CPU
     g1 = {k: capi.g1_download(inst.g1[k]) for k in ("at", "bacgamma", "bacdelta", "ptd")}
     g2 = capi.g2_download(inst.g2_bacgamma)
@@ -99,17 +112,160 @@ def cpu_baseline(log2n_sample, seed):
                       "+ schoolbook Div), oracle/gs_oracle.c, 1 thread, %.1f s" % (log2n_sample, dt)}
 
 
+def cpu_baseline_reference_wasm():
+    """The reference's OWN code beside the GPU (BASELINE.md plan 2a): its compiled prover wasm/go-snark.wasm (go1.12 js/wasm build
+    of groth16.GenerateProofs) under node, on the m = 17 instance of tests/golden/wasm_groth_rand_m17.json, checked to return the
+    recorded proof.  oracle/_ref/go-snark.wasm is a copy made by `make -C oracle ref` in the build container (it travels to the
+    GPU box with the snapshot; /root/reference does not exist there).  wasm on a JS engine is several times slower than native
+    Go, hence the flag; larger instances are out of reach (Div is O(n^3): 39 s at n = 256)."""
+    wasm = os.path.join(ROOT, "oracle", "_ref", "go-snark.wasm")
+    node = shutil.which("node")
+    if not (os.path.exists(wasm) and node):
+        return {"skipped": "oracle/_ref/go-snark.wasm or node not available"}
+    with open(os.path.join(ROOT, "tests", "golden", "wasm_groth_rand_m17.json")) as f:
+        rec = json.load(f)
+    job = [{"name": "bench", "kind": "groth", "circuit": rec["circuit"], "setup": rec["setup"], "px": rec["px"], "inputs": rec["inputs"],
+            "rand": rec["rand"], "verify": []}]
+    with tempfile.TemporaryDirectory() as d:
+        with open(os.path.join(d, "jobs.json"), "w") as f:
+            json.dump(job, f)
+        run = subprocess.run([node, os.path.join(ROOT, "oracle", "ref_wasm", "run_jobs.js"), wasm, os.path.join(d, "jobs.json"),
+                              os.path.join(d, "out.json")], capture_output=True, text=True, timeout=300)
+        if run.returncode != 0:
+            return {"skipped": "node failed: " + run.stderr[-200:]}
+        with open(os.path.join(d, "out.json")) as f:
+            out = json.load(f)[0]
+    n = json.loads(rec["circuit"])["NVars"] - 1
+    if out["proof"] != rec["proof"]:
+        return {"skipped": "the wasm prover did not reproduce the recorded proof"}
+    ver = subprocess.run([node, "--version"], capture_output=True, text=True).stdout.strip()
+    return {"value": n / (out["prove_ms"] / 1e3), "unit": "constraints/s", "cores": 1, "kind": "reference",
+            "flag": "wasm under node %s (not native Go: no Go toolchain in the image)" % ver,
+            "sample": "groth16.GenerateProofs of the reference (wasm/go-snark.wasm) at n = %d constraints (m = %d), %.2f s, proof equal to "
+                      "tests/golden/wasm_groth_rand_m17.json" % (n, n + 1, out["prove_ms"] / 1e3)}
+
+
+def pipelined(begin, end, count, depth, on_done=None):
+    tickets = []
+    for _ in range(count):
+        tickets.append(begin())
+        if len(tickets) == depth:
+            end(tickets.pop(0))
+            if on_done:
+                on_done()
+    while tickets:
+        end(tickets.pop(0))
+        if on_done:
+            on_done()
+
+
+def time_calls(fn, count):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(count):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / count * 1e3
+
+
+def msm_extras(seed):
+    """BASELINE metric, second half (G1-MSM terms/s; configs[1] = 2^16 terms): pipelined (three in flight) and blocking."""
+    out = {}
+    for logn in (20, 16):
+        n = 1 << logn
+        bases = capi.g1_fixed_base(synth.scalars_u64(n, seed + logn))
+        sc = capi.scalars_upload(synth.scalars_u64(n, seed + 77 + logn))
+        capi.msm_resident(bases, sc, n)                 # window table + workspaces
+        reps = 40 if logn == 20 else 200
+        pipelined(lambda: capi.msm_begin(bases, sc, n), capi.msm_end, 6, 3)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pipelined(lambda: capi.msm_begin(bases, sc, n), capi.msm_end, reps, 3)
+        torch.cuda.synchronize()
+        pipe_ms = (time.perf_counter() - t0) / reps * 1e3
+        blk_ms = time_calls(lambda: capi.msm_resident(bases, sc, n), reps // 2)
+        out["2^%d" % logn] = {"terms_per_s_pipelined": n / pipe_ms * 1e3, "ms_pipelined": pipe_ms, "terms_per_s_blocking": n / blk_ms * 1e3,
+                              "ms_blocking": blk_ms, "window_bits": capi.last_timing()["window_bits"]}
+        bases.free()
+        sc.free()
+    return out
+
+
+def logical_shard_report(args, n, seed, sharded_prove):
+    """--logical-shards S on one GPU: S logical devices (gs_init lists GPU 0 S times).  Measures every shard alone, then all shards
+    together through gs_groth16_prove_multi / gs_msm_g1_multi with the records passing through ncclAllGather, and MODELS the
+    S-GPU time as max(shard) + gather + host tail (the shards would run concurrently on S GPUs)."""
+    S = args.logical_shards
+    capi.comm_init_local()
+    out = {"logical_shards": S}
+    if sharded_prove:
+        inst = synth.sqchain_setup_instance(n, seed)
+        full = inst.device_pk()
+        r_, s_ = synth.field_elems(2, seed ^ 0xABCDEF, R)
+        want = groth16.prove_resident(full, inst.w, inst.px, r_, s_)
+        pks = [groth16.ShardPkTo(full, d, S, d) for d in range(S)]
+        full.handle.free()                                  # every logical device keeps 1/S of every key array
+        ws = [capi.scalars_clone(inst.w, d) for d in range(S)]
+        pxs = [capi.scalars_clone(inst.px, d) for d in range(S)]
+        for d in range(S):
+            groth16.prove_partials(pks[d], ws[d], pxs[d], d, S)          # window tables of the slice
+        shard_ms = [time_calls(lambda d=d: groth16.prove_partials(pks[d], ws[d], pxs[d], d, S), 3) for d in range(S)]
+        poly_ms = capi.device_timing(0)["poly_ms"]
+
+        def step():
+            return groth16.prove_multi(pks, ws, pxs, r_, s_)[0]
+        got, used = groth16.prove_multi(pks, ws, pxs, r_, s_)
+        if (got.PiA, got.PiB, got.PiC) != (want.PiA, want.PiB, want.PiC):
+            raise SystemExit("bench.py: the sharded proof differs from the single-device proof")
+        ok = groth16.VerifyProof(inst.vk, got, capi.u64_to_ints(inst.w_host[1:2]))
+        out.update({"proof_equals_single_device": True, "proof_verified": bool(ok), "used_rccl": used,
+                    "replicated_poly_stage_ms": poly_ms})
+        unit = "constraints/s"
+    else:
+        from gosnark_amd import parallel
+        bases = capi.g1_fixed_base(synth.scalars_u64(n, seed))
+        sc = capi.scalars_upload(synth.scalars_u64(n, seed + 77))
+        want = capi.msm_resident(bases, sc, n)
+        bs, ss = [], []
+        for d in range(S):
+            lo, hi = parallel.shard_range(n, S, d)
+            bs.append(capi.g1_clone(bases, d, lo, hi - lo))
+            ss.append(capi.scalars_clone(sc, d, lo, hi - lo))
+        bases.free()
+        for d in range(S):
+            capi.msm_resident(bs[d], ss[d], len(ss[d]))
+        shard_ms = [time_calls(lambda d=d: capi.msm_resident(bs[d], ss[d], len(ss[d])), 5) for d in range(S)]
+
+        def step():
+            return capi.msm_multi(bs, ss)[0]
+        got, used = capi.msm_multi(bs, ss)
+        if got != want:
+            raise SystemExit("bench.py: the sharded MSM differs from the single-device MSM")
+        out.update({"result_equals_single_device": True, "used_rccl": used})
+        unit = "terms/s"
+    # the exchange alone: S records through ncclAllGather (1 rank here: the latency floor of the collective, not xGMI)
+    blob = bytes(416 * S)
+    gather_ms = time_calls(lambda: capi.comm_allgather(blob, 1), 50)
+    out["per_shard_ms"] = shard_ms
+    out["gather_ms_one_rank_rccl"] = gather_ms
+    out["collectives_so_far"] = capi.comm_info()["collectives"]
+    return step, out, unit
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--reps", type=int, default=5, help="repetitions of the timed K steps; the median repetition is reported")
     ap.add_argument("--log2n", type=int, default=20)
     ap.add_argument("--workload", default="prove", choices=["prove", "prove_from_r1cs", "prove_sharded", "prove_pinocchio", "msm_g1", "msm_sharded"],
                     help="prove: one independent proof per GPU (weak scaling, the default the driver runs); prove_sharded: ONE proof "
-                         "whose MSM term ranges are split over the ranks (strong scaling, all-gather of 5 partial points); "
-                         "prove_from_r1cs: every step also rebuilds px from the resident sparse R1CS and witness (gs_r1cs_px) -- the "
+                         "whose MSM term ranges are split over the ranks (strong scaling, in-library RCCL gather of 416-byte records); "
+                         "prove_from_r1cs: every step also rebuilds px from the resident sparse R1CS and witness -- the "
                          "stage upstream of GenerateProofs, reported for information")
+    ap.add_argument("--logical-shards", type=int, default=0,
+                    help="prove_sharded / msm_sharded on ONE GPU: that many logical devices in this process (configs[3] stand-in, SURVEY 8e)")
     ap.add_argument("--instance", default="setup", choices=["setup", "sqchain", "random"],
                     help="setup: sqchain R1CS + structured trusted setup on the device + px from the sparse system (a complete, "
                          "checkable instance, SURVEY 8d); sqchain: same R1CS with key points k_i*G; random: uniform w / px")
@@ -118,7 +274,9 @@ def main():
                          "gs_msm_end), the next operation's plan and accumulations are queued behind the current one's; 1 = one "
                          "blocking call per step")
     ap.add_argument("--no-check", action="store_true", help="skip the closed-form proof check of the `setup` instance")
-    ap.add_argument("--cpu-log2n", type=int, default=13, help="constraints of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra measurements of the default single-GPU run")
+    ap.add_argument("--cpu-log2n", type=int, default=13, help="constraints of the CPU-baseline sample (0 = skip every CPU baseline)")
+    ap.add_argument("--window-bits", type=int, default=0, help="force the Pippenger window width (0 = the library's choice)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -131,7 +289,7 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU path for the product code")
     # development aid for 1-GPU boxes: GS_BENCH_SHARE_GPU=1 maps every rank to device 0 and uses gloo, so the multi-process
-    # code path (barriers, max-over-ranks timing, the partial-point all-gather) can be exercised without a second GPU
+    # code path (barriers, max-over-ranks timing, the partial-point gather) can be exercised without a second GPU
     share = os.environ.get("GS_BENCH_SHARE_GPU") == "1"
     if share:
         local = 0
@@ -142,15 +300,31 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    capi.init(local)
+    logical = args.logical_shards if (args.logical_shards > 1 and world == 1 and args.workload in ("prove_sharded", "msm_sharded")) else 0
+    capi.init([local] * logical if logical else local)
+    if args.window_bits or os.environ.get("GS_BENCH_C"):
+        capi.set_window_bits(args.window_bits or int(os.environ["GS_BENCH_C"]))
 
     n = 1 << args.log2n
-    seed = 0x5EED0002 + (0 if args.workload == "prove_sharded" else rank)
+    one_job = args.workload in ("prove_sharded", "msm_sharded")           # ONE proof / MSM for the whole job: strong scaling
+    seed = 0x5EED0002 + (0 if one_job else rank)
     sharded = args.workload == "prove_sharded"
     from_r1cs = args.workload == "prove_from_r1cs"
-    if sharded or from_r1cs:
+    shard_info, unit_override = None, None
+    rccl_sharded = one_job and world > 1 and not share
+    if rccl_sharded:
+        # one process per GPU: rank 0's unique id travels over torch.distributed, the gather itself runs inside the library
+        uid = [capi.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        capi.comm_init_rank(uid[0], world, rank)
+    inst = None
+    if logical:
+        step, shard_info, unit_override = logical_shard_report(args, n, seed, sharded)
+        units_per_step = n
+        workload = ("groth16_prove_2^%d_constraints_over_%d_logical_devices_of_one_gpu" if sharded else
+                    "g1_msm_2^%d_terms_over_%d_logical_devices_of_one_gpu") % (args.log2n, logical)
+    elif sharded or from_r1cs or args.workload == "prove":
         args.workload = "prove"
-    if args.workload == "prove":
         inst = (synth.sqchain_setup_instance(n, seed) if args.instance == "setup" else
                 synth.sqchain_instance(n, seed) if args.instance == "sqchain" else synth.random_instance(n, seed))
         pk = inst.device_pk()
@@ -169,7 +343,7 @@ def main():
 
         def step():
             if sharded:
-                return groth16.prove_sharded(pk, inst.w, inst.px, r_, s_)
+                return groth16.prove_sharded_rccl(pk, inst.w, inst.px, r_, s_) if rccl_sharded else groth16.prove_sharded(pk, inst.w, inst.px, r_, s_)
             if from_r1cs:
                 # one call: px from the resident sparse system (overwriting the resident px) behind the accumulations over w
                 return groth16.prove_from_r1cs(pk, dev_r1cs, inst.w, r_, s_, inst.px)[0]
@@ -190,17 +364,20 @@ def main():
         workload = "pinocchio_prove_2^%d_constraints_per_gpu" % args.log2n
     else:
         from gosnark_amd import parallel
-        nterms = n
-        bases = capi.g1_fixed_base(synth.scalars_u64(nterms, seed))
-        sc = capi.scalars_upload(synth.scalars_u64(nterms, seed + 77))
-        if args.workload == "msm_g1":
+        nterms = n                                        # per rank: msm_sharded sums N * 2^log2n terms in total
+        bases = capi.g1_fixed_base(synth.scalars_u64(nterms, seed + 1000 * rank))
+        sc = capi.scalars_upload(synth.scalars_u64(nterms, seed + 77 + 1000 * rank))
+        if args.workload == "msm_g1" or world == 1:
             def step():
                 return capi.msm_resident(bases, sc, nterms)
+        elif rccl_sharded:
+            def step():
+                return capi.msm_sharded(bases, sc)
         else:
             def step():
                 return parallel.msm_g1_sharded(bases, sc, nterms)
         units_per_step = nterms
-        workload = ("g1_msm_2^%d_terms_per_gpu" % args.log2n) + ("_allgather_partials" if args.workload == "msm_sharded" else "")
+        workload = ("g1_msm_2^%d_terms_per_gpu" % args.log2n) + ("_gathered_partials" if args.workload == "msm_sharded" else "")
 
     def barrier():
         torch.cuda.synchronize()
@@ -208,75 +385,52 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    pipelined = args.workload == "prove" and not sharded and not from_r1cs and args.pipeline >= 2
+    plain_prove = args.workload == "prove" and not sharded and not from_r1cs and not logical
+    prove_pipe = plain_prove and args.pipeline >= 2
     pin_pipe = args.workload == "prove_pinocchio" and args.pipeline >= 2
-    msm_pipe = args.workload == "msm_g1" and args.pipeline >= 2
+    msm_pipe = args.workload == "msm_g1" and args.pipeline >= 2 and not logical
 
     def run_steps(count, on_done=None):
         if msm_pipe:
-            tickets = []
-            for _ in range(count):
-                tickets.append(capi.msm_begin(bases, sc, nterms))
-                if len(tickets) == args.pipeline:
-                    capi.msm_end(tickets.pop(0))
-                    if on_done:
-                        on_done()
-            while tickets:
-                capi.msm_end(tickets.pop(0))
-                if on_done:
-                    on_done()
-            return
+            return pipelined(lambda: capi.msm_begin(bases, sc, nterms), capi.msm_end, count, args.pipeline, on_done)
         if pin_pipe:
             from gosnark_amd import snark as _sn
-            tickets = []
-            for _ in range(count):
-                tickets.append(_sn.prove_begin(pk, inst.w, inst.px))
-                if len(tickets) == args.pipeline:
-                    _sn.prove_end(tickets.pop(0))
-                    if on_done:
-                        on_done()
-            while tickets:
-                _sn.prove_end(tickets.pop(0))
-                if on_done:
-                    on_done()
-            return
-        if not pipelined:
-            for _ in range(count):
-                step()
-                if on_done:
-                    on_done()
-            return
-        tickets = []
+            return pipelined(lambda: _sn.prove_begin(pk, inst.w, inst.px), _sn.prove_end, count, args.pipeline, on_done)
+        if prove_pipe:
+            return pipelined(lambda: groth16.prove_begin(pk, inst.w, inst.px, r_, s_), groth16.prove_end, count, args.pipeline, on_done)
         for _ in range(count):
-            tickets.append(groth16.prove_begin(pk, inst.w, inst.px, r_, s_))
-            if len(tickets) == args.pipeline:
-                groth16.prove_end(tickets.pop(0))
-                if on_done:
-                    on_done()
-        while tickets:
-            groth16.prove_end(tickets.pop(0))
+            step()
             if on_done:
                 on_done()
 
     run_steps(args.warmup)
-    tm_acc = {"acc_g1_ms": 0.0, "acc_g1_launches": 0, "acc_g1_terms": 0, "acc_g2_ms": 0.0, "acc_g2_terms": 0,
-              "total_ms": 0.0, "plan_ms": 0.0, "accumulate_ms": 0.0, "reduce_ms": 0.0, "poly_ms": 0.0}
-    barrier()
-    t0 = time.perf_counter()
+    tm_keys = ("acc_g1_ms", "acc_g1_launches", "acc_g1_terms", "acc_g1_adds", "acc_g2_ms", "acc_g2_terms", "acc_g2_adds",
+               "total_ms", "plan_ms", "accumulate_ms", "reduce_ms", "poly_ms")
+    tm_acc = {k: 0.0 for k in tm_keys}
+    window_bits = [0]
+
     def book():
-        tm = capi.last_timing()      # HIP-event timings recorded on the library's streams for the proof just collected
-        for k in tm_acc:
+        tm = capi.last_timing()      # HIP-event timings recorded on the library's streams for the operation just collected
+        for k in tm_keys:
             tm_acc[k] += tm[k]
-    run_steps(args.steps, book)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share else "cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        window_bits[0] = tm["window_bits"]
+    rep_elapsed = []
+    for _ in range(max(1, args.reps)):
+        barrier()
+        t0 = time.perf_counter()
+        run_steps(args.steps, None if logical else book)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share else "cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        rep_elapsed.append(elapsed)
+    elapsed = statistics.median(rep_elapsed)
+    total_steps = args.steps * len(rep_elapsed)
 
     proof_verified = None
-    if args.workload == "prove" and args.instance == "setup" and not args.no_check:
+    if args.workload == "prove" and not logical and args.instance == "setup" and not args.no_check:
         # Product verifier (groth16.VerifyProof -> gs_groth16_verify, host side), outside the timed region, on EVERY rank:
         # the proof of this rank's instance against the vk its device setup produced, for the right public input and a wrong one.
         x_pub = capi.u64_to_ints(inst.w_host[1:2])[0]
@@ -301,89 +455,118 @@ def main():
             raise SystemExit("bench.py: snark.VerifyProof rejected the proof of the benchmarked instance (or accepted a wrong public input)")
         proof_verified = "snark.VerifyProof (five pairing equations) accepted each rank's proof against its device-built vk and rejected a wrong public input (%d/%d ranks)" % (world, world)
     proof_check = None
-    if rank == 0 and world == 1 and args.cpu_log2n > 0 and args.workload == "prove" and args.instance == "setup" and not args.no_check:
+    if rank == 0 and world == 1 and args.cpu_log2n > 0 and plain_prove and args.instance == "setup" and not args.no_check:
         # Outside the timed region, part of the checker/baseline leg (the only place bench.py touches oracle/): the toxic
         # values of the synthetic setup are known, so the proof the benchmarked instance must produce is known in closed form.
         proof_check = checker_leg_proof(step(), inst, r_, s_)
-    host_ms = None
-    if rank == 0 and world == 1 and args.workload == "prove":
-        # the boundary also accepts HOST buffers (gs_groth16_prove): w (32 B x m) and px (32 B x (2n-1)) then cross PCIe
-        # inside the call.  Reported beside the resident-input figure, never as `value`.
-        lib = capi.load_library()
+
+    extras = {}
+    if rank == 0 and world == 1 and plain_prove and not args.no_extras:
+        # --- every figure below is measured OUTSIDE the timed region and reported beside `value`, never as `value` -----------
+        # one blocking call per proof (gs_groth16_prove_resident): the latency of a lone proof
+        extras["blocking_ms_per_proof"] = time_calls(step, 6)
+        # the boundary also accepts HOST buffers (gs_groth16_prove): w (32 B x m) and px (32 B x (2n-1)) then cross PCIe inside the call
         import ctypes
+        lib = capi.load_library()
         outp = np.zeros(32, dtype=np.uint64)
         infp = (ctypes.c_int * 3)()
         rs = capi.ints_to_u64([r_, s_])
-        th = time.perf_counter()
-        for _ in range(3):
-            capi.check(lib.gs_groth16_prove(capi.Handle(pk.handle.h), capi.ptr64(inst.w_host), inst.w_host.shape[0], capi.ptr64(inst.px_host),
-                                            inst.px_host.shape[0], capi.ptr64(rs[0]), capi.ptr64(rs[1]), capi.ptr64(outp), infp))
-        host_ms = (time.perf_counter() - th) / 3 * 1e3
+        extras["host_buffers_ms_per_step"] = time_calls(lambda: capi.check(lib.gs_groth16_prove(
+            capi.Handle(pk.handle.h), capi.ptr64(inst.w_host), inst.w_host.shape[0], capi.ptr64(inst.px_host), inst.px_host.shape[0],
+            capi.ptr64(rs[0]), capi.ptr64(rs[1]), capi.ptr64(outp), infp)), 3)
+        if args.instance == "setup":
+            # witness -> proof: px rebuilt from the resident sparse R1CS every time (gs_groth16_prove_r1cs; r1csqap.go:161-210 + groth16.go:225-278)
+            from gosnark_amd import r1csqap
+            dr = r1csqap.DeviceR1CS(*inst.r1cs, inst.m)
+            pxh = capi.scalars_clone(inst.px, capi.get_device())
+            groth16.prove_from_r1cs(pk, dr, inst.w, r_, s_, pxh)
+            extras["from_r1cs_ms_per_step"] = time_calls(lambda: groth16.prove_from_r1cs(pk, dr, inst.w, r_, s_, pxh), 4)
+            extras["from_r1cs_constraints_per_s"] = n / extras["from_r1cs_ms_per_step"] * 1e3
+            pxh.free()
+            dr.handle.free()
+        extras["msm_g1"] = msm_extras(seed + 5000)
 
     if rank == 0:
-        value = units_per_step * (1 if sharded else world) * args.steps / elapsed
+        value = units_per_step * (1 if (sharded or logical) else world) * args.steps / elapsed
         launches = max(tm_acc["acc_g1_launches"], 1)
         avg_launch_s = tm_acc["acc_g1_ms"] / launches * 1e-3
         bytes_per_launch = G1_TERM_BYTES * tm_acc["acc_g1_terms"] / launches
         achieved = bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+        mads = tm_acc["acc_g1_adds"] / launches * MADS_PER_MIXED_ADD / avg_launch_s / 1e12 if avg_launch_s > 0 else 0.0
         is_pin = args.workload == "prove_pinocchio"
-        is_prove = args.workload == "prove" or is_pin
+        is_prove = bool(args.workload == "prove" or is_pin or (logical and sharded))
         # SURVEY 8d bytes per constraint: Groth16 544 n (4 G1 + 1 G2 MSM) + 128 n (H stage); Pinocchio 7 G1 + 1 G2 + H = 960 n
         step_bytes = (960 * n if is_pin else 672 * n) if is_prove else G1_TERM_BYTES * n
+        cbits = window_bits[0]
         out = {
             "metric": ("Pinocchio constraints/sec (prove) at 2^%d R1CS" % args.log2n if is_pin else
                        "Groth16 constraints/sec (prove) at 2^%d R1CS" % args.log2n if is_prove else "G1-MSM terms/sec"),
             "value": value,
-            "unit": "constraints/s" if is_prove else "terms/s",
+            "unit": unit_override or ("constraints/s" if is_prove else "terms/s"),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None,
+            "reps": len(rep_elapsed), "ms_per_step_reps": [e / args.steps * 1e3 for e in rep_elapsed],
+            "ms_per_step_min": min(rep_elapsed) / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong" if (sharded or logical) else "weak", "vs_baseline": None,
             "dtype": "u32 (9x29-bit Montgomery limbs of the 254-bit BN128 fields)", "data": "synthetic",
-            "config": {"workload": workload, "proofs_in_flight": args.pipeline if (pipelined or msm_pipe or pin_pipe) else 1, "constraints": n, "variables": n + 1, "npublic": 1,
-                       "parallelism": ("one proof, MSM term ranges sharded over the ranks, all-gather of 5 partial points" if sharded else
-                                       "independent proofs, one per GPU") if is_prove else args.workload,
-                       "instance": inst.describe() if is_prove else "uniform random scalars, bases k_i*G"},
-            "roofline": {"bound": "hbm", "kernel": "k_bucket_accumulate<G1>", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "avg_launch_ms": avg_launch_s * 1e3, "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "note": "integer-issue bound (254-bit modular arithmetic on 32-bit VALU): PMC evidence in "
-                                 "profiles/r01c_pmc_sq_accumulate_g1.txt (VALU ~96 % busy), see DESIGN.md section 5"},
-            # the roofline that actually binds the dominant kernel: 32x32+64-bit multiply-add issue (v_mad_u64_u32).  One mixed
-            # addition = 6 products (162 mads) + 2 squarings (126) + one two-term product (243) = 1467 mads; a term takes one
-            # addition per window.  Peak: 31.5 T lane-mad/s measured by tools/ubench_valu.hip (profiles/r01_ubench_valu.txt).
-            "roofline_valu": {"bound": "valu-int-mad", "kernel": "k_bucket_accumulate<G1>",
-                              "achieved": (tm_acc["acc_g1_terms"] / launches) * 16 * 1467 / avg_launch_s / 1e12 if avg_launch_s > 0 else 0.0,
-                              "peak": 31.5, "unit": "T lane-mad/s",
-                              "frac": ((tm_acc["acc_g1_terms"] / launches) * 16 * 1467 / avg_launch_s / 1e12 / 31.5) if avg_launch_s > 0 else 0.0,
-                              "note": "16 windows at c = 16 (n >= 2^16); other instructions take the remaining issue slots, "
-                                      "profiles/r01c_pmc_sq_accumulate_g1.txt"},
-            "roofline_whole_step": {"bound": "hbm", "algorithmic_bytes_per_step": step_bytes,
-                                    "achieved": step_bytes / (elapsed / args.steps) / 1e9,
-                                    "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                    "note": "SURVEY 8d: Groth16 672 B per constraint per proof (544 n MSM + 128 n H stage), Pinocchio 960 B; wall time per step"},
-            "device_ms_per_step": {k: tm_acc[k] / args.steps for k in ("total_ms", "poly_ms", "plan_ms", "accumulate_ms", "reduce_ms", "acc_g1_ms", "acc_g2_ms")},
+            "config": {"workload": workload, "proofs_in_flight": args.pipeline if (prove_pipe or msm_pipe or pin_pipe) else 1, "constraints": n, "variables": n + 1, "npublic": 1,
+                       "window_bits": cbits,
+                       "parallelism": (("%d logical devices of one GPU in one process (gs_groth16_prove_multi / gs_msm_g1_multi), records through ncclAllGather" % logical) if logical else
+                                       "one proof, MSM term ranges sharded over the ranks, in-library RCCL gather of one 416-byte record per rank" if sharded else
+                                       "independent proofs, one per GPU" if is_prove else args.workload),
+                       "instance": inst.describe() if (is_prove and inst is not None) else "uniform random scalars, bases k_i*G"},
         }
-        try:
-            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                pmc = json.load(f).get(workload)
-            if pmc:        # measured offline with rocprofv3 --pmc (bench.py cannot attach counters to itself)
-                out["roofline"]["traffic"] = pmc["fetch_bytes_per_launch_raw"] + pmc["write_bytes_per_launch_raw"]
-                out["roofline"]["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, raw counters)"
-        except OSError:
-            pass
-        if host_ms is not None:
-            out["host_buffers_ms_per_step"] = host_ms
+        if not logical:
+            out["roofline"] = {"bound": "hbm", "kernel": "k_bucket_accumulate<G1>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                               "avg_launch_ms": avg_launch_s * 1e3, "algorithmic_bytes_per_launch": bytes_per_launch,
+                               "note": "integer-issue bound (254-bit modular arithmetic on 32-bit VALU): PMC evidence under profiles/ "
+                                       "(VALU ~96 % busy), see DESIGN.md section 5"}
+            # the roofline that actually binds the dominant kernel: 32x32+64-bit multiply-add issue (v_mad_u64_u32).  One mixed
+            # addition = 1467 mads; a term takes one addition per digit position (floor(254 / c) + 1 of them).
+            out["roofline_valu"] = {"bound": "valu-int-mad", "kernel": "k_bucket_accumulate<G1>", "achieved": mads, "peak": MAD_PEAK_T,
+                                    "unit": "T lane-mad/s", "frac": mads / MAD_PEAK_T,
+                                    "note": "mixed additions per launch (gs_timing.acc_g1_adds) x 1467 v_mad_u64_u32; window width c = %d -> %d additions "
+                                            "per term; peak from tools/ubench_valu.hip (profiles/r01_ubench_valu.txt)" % (cbits, 254 // max(cbits, 1) + 1)}
+            out["roofline_whole_step"] = {"bound": "hbm", "algorithmic_bytes_per_step": step_bytes,
+                                          "achieved": step_bytes / (elapsed / args.steps) / 1e9,
+                                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                          "note": "SURVEY 8d: Groth16 672 B per constraint per proof (544 n MSM + 128 n H stage), Pinocchio 960 B; wall time per step"}
+            out["device_ms_per_step"] = {k: tm_acc[k] / total_steps for k in ("total_ms", "poly_ms", "plan_ms", "accumulate_ms", "reduce_ms", "acc_g1_ms", "acc_g2_ms")}
+            try:
+                with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                    pmc = json.load(f).get(workload)
+                if pmc:        # measured offline with rocprofv3 --pmc (bench.py cannot attach counters to itself)
+                    out["roofline"]["traffic"] = pmc["fetch_bytes_per_launch_raw"] + pmc["write_bytes_per_launch_raw"]
+                    out["roofline"]["traffic_source"] = ("profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, raw counters; measured at commit %s, "
+                                                         "window width %s)" % (pmc.get("commit", "?"), pmc.get("window_bits", "?")))
+            except OSError:
+                pass
+        if shard_info:
+            S = shard_info["logical_shards"]
+            tail_ms = 0.35          # host pair sums + the O(1) tail (two result-dependent scalar multiplications), DESIGN.md section 6
+            modelled = max(shard_info["per_shard_ms"]) + shard_info["gather_ms_one_rank_rccl"] + (tail_ms if sharded else 0.0)
+            shard_info["MODELLED_not_measured"] = {
+                "gpus": S, "ms_per_step": modelled, "value": n / modelled * 1e3, "unit": out["unit"],
+                "model": "max over shards of the shard's time alone on one MI355X + the measured 1-rank ncclAllGather latency of the S records"
+                         + (" + %.2f ms host tail" % tail_ms if sharded else "") +
+                         "; on S GPUs the shards run concurrently.  NOT measured: no multi-GPU hardware is reachable from this run."}
+            out["sharding"] = shard_info
+        for k, v in extras.items():
+            out[k] = v
         if proof_verified:
             out["proof_verified"] = proof_verified
         if proof_check:
             out["proof_check"] = proof_check
-        if world == 1 and args.cpu_log2n > 0:
+        if world == 1 and args.cpu_log2n > 0 and not logical:
             out["cpu_baseline"] = cpu_baseline(args.cpu_log2n, seed + 1000)
             out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(args.cpu_log2n + 3, seed + 2000)
             # the container may grant fewer CPUs than os.cpu_count() reports: state what the threads actually bought
             out["cpu_baseline_all_cores"]["speedup_vs_1_core"] = out["cpu_baseline_all_cores"]["value"] / out["cpu_baseline"]["value"]
             if args.workload != "prove":
                 out["cpu_baseline"]["note"] = "baseline is the Groth16 prove sample; 1 constraint ~ 4 G1 + 1 G2 terms"
+            if plain_prove and not args.no_extras:
+                out["cpu_baseline_reference_wasm"] = cpu_baseline_reference_wasm()
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -26,7 +26,9 @@ class Timing(ctypes.Structure):
     _fields_ = ([(n, ctypes.c_float) for n in
                  ("total_ms", "plan_ms", "accumulate_ms", "reduce_ms", "poly_ms", "h2d_ms", "acc_g1_ms", "acc_g2_ms")]
                 + [("acc_g1_launches", ctypes.c_uint32), ("acc_g2_launches", ctypes.c_uint32),
-                   ("acc_g1_terms", ctypes.c_uint64), ("acc_g2_terms", ctypes.c_uint64)])
+                   ("acc_g1_terms", ctypes.c_uint64), ("acc_g2_terms", ctypes.c_uint64),
+                   ("acc_g1_adds", ctypes.c_uint64), ("acc_g2_adds", ctypes.c_uint64),
+                   ("window_bits", ctypes.c_uint32), ("reserved", ctypes.c_uint32)])
 
 
 def lib_path():

@@ -132,8 +132,10 @@ GS_HD void xyzz_madd(Xyzz<T>& acc, const Affine<T>& b, bool negate = false) {
     acc.zz = relax<2>(T::one()); acc.zzz = relax<2>(T::one());
     return;
   }
-  auto U2 = smul<T>(b.x, acc.zz);
-  auto S2 = smul<T>(y2, acc.zzz);
+  typename T::template E<2> U2, S2;
+  if constexpr (GS_PAIR != 0 && T::kWords == 8) dots2<ModQ>(dot_of(b.x, acc.zz), dot_of(y2, acc.zzz), U2, S2);
+  else if constexpr (GS_PAIR != 0) mul2(b.x, acc.zz, y2, acc.zzz, U2, S2);
+  else { U2 = smul<T>(b.x, acc.zz); S2 = smul<T>(y2, acc.zzz); }
   auto P = sub(U2, acc.x);                              // 2 + 9 + 1 = 12
   auto R = sub(S2, acc.y);                              // 2 + 5 + 1 = 8
   if (is_zero(P)) {
@@ -141,15 +143,40 @@ GS_HD void xyzz_madd(Xyzz<T>& acc, const Affine<T>& b, bool negate = false) {
     else acc = xyzz_inf<T>();
     return;
   }
-  auto PP = ssqr<T>(P);
-  auto PPP = smul<T>(P, PP);
-  auto Q = smul<T>(acc.x, PP);
-  auto RR = ssqr<T>(R);
-  auto X3 = sub(RR, add(PPP, dbl(Q)));                  // 2 + 6 + 1 = 9
-  auto Y3 = smul_sub<T>(R, sub(Q, X3), acc.y, PPP);     // R (Q - X3) - Y1 PPP, one reduction per coordinate
-  acc.zz = smul<T>(acc.zz, PP);
-  acc.zzz = smul<T>(acc.zzz, PPP);
-  acc.x = X3; acc.y = relax<5>(Y3);
+  if constexpr (GS_PAIR != 0 && T::kWords == 8) {
+    // G1: independent products share their issue slots (fp29.h, interleaved column chains): P^2 | R^2, P^3 | Q,
+    // Y3 | ZZ3 | ZZZ3.
+    typename T::template E<2> PP, RR, PPP, Q, Y3, ZZ3, ZZZ3;
+    sqr2(P, R, PP, RR);
+    dots2<ModQ>(dot_of(P, PP), dot_of(acc.x, PP), PPP, Q);
+    auto X3 = sub(RR, add(PPP, dbl(Q)));                // 2 + 6 + 1 = 9
+    const auto D = sub(Q, X3);                          // 2 + 9 + 1 = 12
+    const auto ny = neg(acc.y);                         // 6
+    dots3<ModQ>(dot_of(R, D, ny, PPP), dot_of(acc.zz, PP), dot_of(acc.zzz, PPP), Y3, ZZ3, ZZZ3);
+    acc.zz = ZZ3; acc.zzz = ZZZ3;
+    acc.x = X3; acc.y = relax<5>(Y3);
+  } else if constexpr (GS_PAIR != 0) {
+    // G2: two Fq2 products at a time = four chains (both coordinates of both): P^2 | R^2, P^3 | Q, ZZ3 | ZZZ3
+    typename T::template E<2> PP, RR, PPP, Q, ZZ3, ZZZ3;
+    const auto Pr = reduce2(P), Rr = reduce2(R);        // the Fq2 square takes (2a)(2a + 1) <= 160
+    sqr2(Pr, Rr, PP, RR);
+    mul2(Pr, PP, acc.x, PP, PPP, Q);
+    auto X3 = sub(RR, add(PPP, dbl(Q)));                // 9
+    auto Y3 = mul_sub(Rr, sub(Q, X3), acc.y, PPP);      // (2, 12, 5, 2): two four-term chains
+    mul2(acc.zz, PP, acc.zzz, PPP, ZZ3, ZZZ3);
+    acc.zz = ZZ3; acc.zzz = ZZZ3;
+    acc.x = X3; acc.y = relax<5>(Y3);
+  } else {
+    auto PP = ssqr<T>(P);
+    auto PPP = smul<T>(P, PP);
+    auto Q = smul<T>(acc.x, PP);
+    auto RR = ssqr<T>(R);
+    auto X3 = sub(RR, add(PPP, dbl(Q)));                // 2 + 6 + 1 = 9
+    auto Y3 = smul_sub<T>(R, sub(Q, X3), acc.y, PPP);   // R (Q - X3) - Y1 PPP, one reduction per coordinate
+    acc.zz = smul<T>(acc.zz, PP);
+    acc.zzz = smul<T>(acc.zzz, PPP);
+    acc.x = X3; acc.y = relax<5>(Y3);
+  }
 }
 
 // 2 * acc   [dbl-2008-s-1: 6M + 4S... a = 0]

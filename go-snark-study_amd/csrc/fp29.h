@@ -258,6 +258,229 @@ GS_HD Fe<M, 2> dot4(const Fe<M, Ba>& a, const Fe<M, Bb>& b, const Fe<M, Bc>& c, 
   return r;
 }
 
+// ---- interleaved column chains --------------------------------------------------------------------------
+// A Montgomery product is ONE dependent chain of 162 v_mad_u64_u32 through its 64-bit column accumulator.  Left alone, the
+// compiler breaks the chain for instruction-level parallelism -- products into a second accumulator, then a 64-bit add per
+// column (17 v_lshl_add_u64 per product, ~7 % of the kernel's issue cycles: tools/ubench_valu2.hip prices the add like a
+// multiply-add) -- and pinning the chain (GS_CHAIN) trades the adds for one s_nop wait state per dependent pair.  Two (or three)
+// INDEPENDENT dot products computed together avoid both: their multiply-adds alternate in program order, so no instruction
+// depends on its predecessor, nothing is re-associated and no wait state is needed.  A point addition has such pairs everywhere
+// (U2 | S2, P^2 | R^2, P^3 | Q, and the two coordinates of every Fq2 product).
+// GS_STEP pins an accumulator after one multiply-add (device code; volatile, so the alternation survives scheduling).
+#ifndef GS_PAIR
+#define GS_PAIR 1
+#endif
+#if GS_PAIR && defined(__HIP_DEVICE_COMPILE__) && !defined(GS_NOSTEP)
+#define GS_STEP(acc) asm volatile("" : "+v"(acc))
+#else
+#define GS_STEP(acc) ((void)0)
+#endif
+
+// one dot product of T limb-array pairs: the operands of sum_t a[t] * b[t]
+template <int T>
+struct Dot {
+  const uint32_t* a[T];
+  const uint32_t* b[T];
+};
+template <> struct Dot<0> {};
+template <class M, int Ba, int Bb>
+GS_HD Dot<1> dot_of(const Fe<M, Ba>& a, const Fe<M, Bb>& b) {
+  static_assert(Ba * Bb <= 160, "Montgomery product input bound exceeded");
+  return Dot<1>{{a.l}, {b.l}};
+}
+template <class M, int Ba, int Bb, int Bc, int Bd>
+GS_HD Dot<2> dot_of(const Fe<M, Ba>& a, const Fe<M, Bb>& b, const Fe<M, Bc>& c, const Fe<M, Bd>& d) {
+  static_assert(Ba * Bb + Bc * Bd <= 160, "dot-product input bound exceeded");
+  return Dot<2>{{a.l, c.l}, {b.l, d.l}};
+}
+template <class M, int Ba, int Bb, int Bc, int Bd, int Be, int Bf, int Bg, int Bh>
+GS_HD Dot<4> dot_of(const Fe<M, Ba>& a, const Fe<M, Bb>& b, const Fe<M, Bc>& c, const Fe<M, Bd>& d,
+                    const Fe<M, Be>& e, const Fe<M, Bf>& f, const Fe<M, Bg>& g, const Fe<M, Bh>& h) {
+  static_assert(Ba * Bb + Bc * Bd + Be * Bf + Bg * Bh <= 160, "dot-product input bound exceeded");
+  return Dot<4>{{a.l, c.l, e.l, g.l}, {b.l, d.l, f.l, h.l}};
+}
+
+// r_x = REDC(x), r_y = REDC(y) [, r_z = REDC(z)]: the chains advance in lock step, one multiply-add of each in turn
+// (order per column position: x_0 y_0 x_1 y_1 ... then z, so that with (TX, TY, TZ) = (2, 1, 1) no chain follows itself).
+// The low and the high columns are two separate loops on purpose: with the pins (convergent inline asm) inside an
+// `if (k < NL) ... else ...` of ONE loop the unroller gives up and the limbs end up in scratch memory.
+#define GS_DOTS_PRODUCTS(COND)                                                                             \
+  _Pragma("unroll") for (int i = 0; i < NL; ++i) {                                                         \
+    if (COND) {                                                                                            \
+      const int j = k - i;                                                                                 \
+      if constexpr (TX > 0) { ax += (uint64_t)x.a[0][i] * x.b[0][j]; GS_STEP(ax); }                        \
+      if constexpr (TY > 0) { ay += (uint64_t)y.a[0][i] * y.b[0][j]; GS_STEP(ay); }                        \
+      if constexpr (TX > 1) { ax += (uint64_t)x.a[1][i] * x.b[1][j]; GS_STEP(ax); }                        \
+      if constexpr (TY > 1) { ay += (uint64_t)y.a[1][i] * y.b[1][j]; GS_STEP(ay); }                        \
+      if constexpr (TX > 2) { ax += (uint64_t)x.a[2][i] * x.b[2][j]; GS_STEP(ax); }                        \
+      if constexpr (TY > 2) { ay += (uint64_t)y.a[2][i] * y.b[2][j]; GS_STEP(ay); }                        \
+      if constexpr (TX > 3) { ax += (uint64_t)x.a[3][i] * x.b[3][j]; GS_STEP(ax); }                        \
+      if constexpr (TY > 3) { ay += (uint64_t)y.a[3][i] * y.b[3][j]; GS_STEP(ay); }                        \
+      if constexpr (TZ > 0) { az += (uint64_t)z->a[0][i] * z->b[0][j]; GS_STEP(az); }                      \
+    }                                                                                                      \
+  }
+#define GS_DOTS_REDUCE(COND)                                                                               \
+  _Pragma("unroll") for (int i = 0; i < NL; ++i)                                                           \
+    if (COND) {                                                                                            \
+      ax += (uint64_t)mx[i] * M::p(k - i); GS_STEP(ax);                                                    \
+      ay += (uint64_t)my[i] * M::p(k - i); GS_STEP(ay);                                                    \
+      if constexpr (TZ > 0) { az += (uint64_t)mz[i] * M::p(k - i); GS_STEP(az); }                          \
+    }
+
+template <class M, int TX, int TY, int TZ>
+GS_HD void dots_interleaved(const Dot<TX>& x, const Dot<TY>& y, const Dot<TZ>* z, Fe<M, 2>& rx, Fe<M, 2>& ry, Fe<M, 2>* rz) {
+  static_assert(TZ <= 1 && TX >= 1 && TY >= 1 && TX <= 4 && TY <= 4, "third chain carries one product; at most four terms per chain");
+  uint32_t mx[NL], my[NL], mz[NL];
+  uint64_t ax = 0, ay = 0, az = 0;
+#pragma unroll
+  for (int k = 0; k < NL; ++k) {
+    GS_DOTS_PRODUCTS(i <= k)
+    GS_DOTS_REDUCE(i < k)
+    mx[k] = ((uint32_t)ax * M::kPinv29) & LMASK;
+    my[k] = ((uint32_t)ay * M::kPinv29) & LMASK;
+    if constexpr (TZ > 0) mz[k] = ((uint32_t)az * M::kPinv29) & LMASK;
+    ax += (uint64_t)mx[k] * M::p(0); GS_STEP(ax);
+    ay += (uint64_t)my[k] * M::p(0); GS_STEP(ay);
+    if constexpr (TZ > 0) { az += (uint64_t)mz[k] * M::p(0); GS_STEP(az); }
+    ax >>= LB; ay >>= LB;
+    if constexpr (TZ > 0) az >>= LB;
+  }
+#pragma unroll
+  for (int k = NL; k < 2 * NL - 1; ++k) {
+    GS_DOTS_PRODUCTS(i >= k - (NL - 1))
+    GS_DOTS_REDUCE(i >= k - (NL - 1))
+    rx.l[k - NL] = (uint32_t)ax & LMASK;
+    ry.l[k - NL] = (uint32_t)ay & LMASK;
+    if constexpr (TZ > 0) rz->l[k - NL] = (uint32_t)az & LMASK;
+    ax >>= LB; ay >>= LB;
+    if constexpr (TZ > 0) az >>= LB;
+  }
+  rx.l[NL - 1] = (uint32_t)ax;
+  ry.l[NL - 1] = (uint32_t)ay;
+  if constexpr (TZ > 0) rz->l[NL - 1] = (uint32_t)az;
+  (void)mz; (void)az;
+}
+#undef GS_DOTS_PRODUCTS
+#undef GS_DOTS_REDUCE
+template <class M, int TX, int TY>
+GS_HD void dots2(const Dot<TX>& x, const Dot<TY>& y, Fe<M, 2>& rx, Fe<M, 2>& ry) {
+  dots_interleaved<M, TX, TY, 0>(x, y, static_cast<const Dot<0>*>(nullptr), rx, ry, static_cast<Fe<M, 2>*>(nullptr));
+}
+template <class M, int TX, int TY, int TZ>
+GS_HD void dots3(const Dot<TX>& x, const Dot<TY>& y, const Dot<TZ>& z, Fe<M, 2>& rx, Fe<M, 2>& ry, Fe<M, 2>& rz) {
+  dots_interleaved<M, TX, TY, TZ>(x, y, &z, rx, ry, &rz);
+}
+
+// N chains of T terms each, strictly round-robin: chain c's multiply-adds are N - 1 instructions apart (N = 4 for two Fq2
+// products side by side: both coordinates of both).  Measured (tools/ubench_mulmod.hip, cycles per product per SIMD):
+// compiler-scheduled 1204, two chains 1166, three chains 1100.
+template <class M, int N, int T>
+GS_HD void dots_uniform(const Dot<T> (&d)[N], Fe<M, 2> (&r)[N]) {
+  uint32_t m[N][NL];
+  uint64_t acc[N];
+#pragma unroll
+  for (int c = 0; c < N; ++c) acc[c] = 0;
+#pragma unroll
+  for (int k = 0; k < NL; ++k) {
+#pragma unroll
+    for (int i = 0; i < NL; ++i)
+      if (i <= k) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+#pragma unroll
+          for (int c = 0; c < N; ++c) { acc[c] += (uint64_t)d[c].a[t][i] * d[c].b[t][k - i]; GS_STEP(acc[c]); }
+        }
+      }
+#pragma unroll
+    for (int i = 0; i < NL; ++i)
+      if (i < k) {
+#pragma unroll
+        for (int c = 0; c < N; ++c) { acc[c] += (uint64_t)m[c][i] * M::p(k - i); GS_STEP(acc[c]); }
+      }
+#pragma unroll
+    for (int c = 0; c < N; ++c) m[c][k] = ((uint32_t)acc[c] * M::kPinv29) & LMASK;
+#pragma unroll
+    for (int c = 0; c < N; ++c) { acc[c] += (uint64_t)m[c][k] * M::p(0); GS_STEP(acc[c]); }
+#pragma unroll
+    for (int c = 0; c < N; ++c) acc[c] >>= LB;
+  }
+#pragma unroll
+  for (int k = NL; k < 2 * NL - 1; ++k) {
+#pragma unroll
+    for (int i = 0; i < NL; ++i)
+      if (i >= k - (NL - 1)) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+#pragma unroll
+          for (int c = 0; c < N; ++c) { acc[c] += (uint64_t)d[c].a[t][i] * d[c].b[t][k - i]; GS_STEP(acc[c]); }
+        }
+      }
+#pragma unroll
+    for (int i = 0; i < NL; ++i)
+      if (i >= k - (NL - 1)) {
+#pragma unroll
+        for (int c = 0; c < N; ++c) { acc[c] += (uint64_t)m[c][i] * M::p(k - i); GS_STEP(acc[c]); }
+      }
+#pragma unroll
+    for (int c = 0; c < N; ++c) { r[c].l[k - NL] = (uint32_t)acc[c] & LMASK; acc[c] >>= LB; }
+  }
+#pragma unroll
+  for (int c = 0; c < N; ++c) r[c].l[NL - 1] = (uint32_t)acc[c];
+}
+
+// two squares together (the doubled-operand trick of sqr: 45 products each)
+template <class M, int Ba, int Bb>
+GS_HD void sqr2(const Fe<M, Ba>& a, const Fe<M, Bb>& b, Fe<M, 2>& ra, Fe<M, 2>& rb) {
+  static_assert(Ba * Ba <= 160 && Bb * Bb <= 160, "Montgomery square input bound exceeded");
+  uint32_t ma[NL], mb[NL], a2[NL], b2[NL];
+#pragma unroll
+  for (int i = 0; i < NL; ++i) { a2[i] = a.l[i] << 1; b2[i] = b.l[i] << 1; }
+  uint64_t xa = 0, xb = 0;
+#define GS_SQR_PRODUCTS                                                                                    \
+  _Pragma("unroll") for (int i = 0; i < NL; ++i) {                                                         \
+    const int j = k - i;                                                                                   \
+    if (j >= 0 && j < NL && i < j) {                                                                       \
+      xa += (uint64_t)a2[i] * a.l[j]; GS_STEP(xa);                                                         \
+      xb += (uint64_t)b2[i] * b.l[j]; GS_STEP(xb);                                                         \
+    }                                                                                                      \
+  }                                                                                                        \
+  if ((k & 1) == 0) {                                                                                      \
+    xa += (uint64_t)a.l[k / 2] * a.l[k / 2]; GS_STEP(xa);                                                  \
+    xb += (uint64_t)b.l[k / 2] * b.l[k / 2]; GS_STEP(xb);                                                  \
+  }
+#pragma unroll
+  for (int k = 0; k < NL; ++k) {
+    GS_SQR_PRODUCTS
+#pragma unroll
+    for (int i = 0; i < NL; ++i)
+      if (i < k) {
+        xa += (uint64_t)ma[i] * M::p(k - i); GS_STEP(xa);
+        xb += (uint64_t)mb[i] * M::p(k - i); GS_STEP(xb);
+      }
+    ma[k] = ((uint32_t)xa * M::kPinv29) & LMASK;
+    mb[k] = ((uint32_t)xb * M::kPinv29) & LMASK;
+    xa += (uint64_t)ma[k] * M::p(0); GS_STEP(xa);
+    xb += (uint64_t)mb[k] * M::p(0); GS_STEP(xb);
+    xa >>= LB; xb >>= LB;
+  }
+#pragma unroll
+  for (int k = NL; k < 2 * NL - 1; ++k) {
+    GS_SQR_PRODUCTS
+#pragma unroll
+    for (int i = 0; i < NL; ++i)
+      if (i >= k - (NL - 1)) {
+        xa += (uint64_t)ma[i] * M::p(k - i); GS_STEP(xa);
+        xb += (uint64_t)mb[i] * M::p(k - i); GS_STEP(xb);
+      }
+    ra.l[k - NL] = (uint32_t)xa & LMASK;
+    rb.l[k - NL] = (uint32_t)xb & LMASK;
+    xa >>= LB; xb >>= LB;
+  }
+#undef GS_SQR_PRODUCTS
+  ra.l[NL - 1] = (uint32_t)xa;
+  rb.l[NL - 1] = (uint32_t)xb;
+}
+
 // a*b - c*d with one reduction
 template <class M, int Ba, int Bb, int Bc, int Bd>
 GS_HD Fe<M, 2> mul_sub(const Fe<M, Ba>& a, const Fe<M, Bb>& b, const Fe<M, Bc>& c, const Fe<M, Bd>& d) {

@@ -29,9 +29,17 @@ template <int B> GS_HD bool is_zero(const Fq2e<B>& a) { return is_zero(a.c0) && 
 template <int B> GS_HD Fq2e<B> select(bool c, const Fq2e<B>& a, const Fq2e<B>& b) { return {select(c, a.c0, b.c0), select(c, a.c1, b.c1)}; }
 
 // (a0 + a1 u)(b0 + b1 u) = (a0 b0 - a1 b1) + (a0 b1 + a1 b0) u        [fq2.go:63-76]
+// The two coordinates are independent dot products: their column chains run interleaved (fp29.h, dots2).
 template <int Ba, int Bb>
 GS_HD Fq2e<2> mul(const Fq2e<Ba>& a, const Fq2e<Bb>& b) {
+#if GS_PAIR
+  const auto nb1 = neg(b.c1);
+  Fq2e<2> r;
+  dots2<ModQ>(dot_of(a.c0, b.c0, a.c1, nb1), dot_of(a.c0, b.c1, a.c1, b.c0), r.c0, r.c1);
+  return r;
+#else
   return {mul_add(a.c0, b.c0, a.c1, neg(b.c1)), mul_add(a.c0, b.c1, a.c1, b.c0)};
+#endif
 }
 
 // a*b - c*d with ONE reduction per coordinate (four-term dot products): 2 x 405 mads instead of 2 x 486
@@ -41,13 +49,49 @@ GS_HD Fq2e<2> mul_sub(const Fq2e<Ba>& a, const Fq2e<Bb>& b, const Fq2e<Bc>& c, c
   const auto nc0 = neg(c.c0);
   const auto nc1 = neg(c.c1);
   // re: a0 b0 - a1 b1 - c0 d0 + c1 d1      im: a0 b1 + a1 b0 - c0 d1 - c1 d0
+#if GS_PAIR
+  Fq2e<2> r;
+  dots2<ModQ>(dot_of(a.c0, b.c0, na1, b.c1, nc0, d.c0, c.c1, d.c1), dot_of(a.c0, b.c1, a.c1, b.c0, nc0, d.c1, nc1, d.c0), r.c0, r.c1);
+  return r;
+#else
   return {dot4(a.c0, b.c0, na1, b.c1, nc0, d.c0, c.c1, d.c1), dot4(a.c0, b.c1, a.c1, b.c0, nc0, d.c1, nc1, d.c0)};
+#endif
 }
 
 // (a0 + a1 u)^2 = (a0 + a1)(a0 - a1) + 2 a0 a1 u                       [fq2.go:118-133]
 template <int B>
 GS_HD Fq2e<2> sqr(const Fq2e<B>& a) {
+#if GS_PAIR
+  const auto s = add(a.c0, a.c1);
+  const auto d = sub(a.c0, a.c1);
+  const auto t = dbl(a.c0);
+  Fq2e<2> r;
+  dots2<ModQ>(dot_of(s, d), dot_of(t, a.c1), r.c0, r.c1);
+  return r;
+#else
   return {mul(add(a.c0, a.c1), sub(a.c0, a.c1)), mul(dbl(a.c0), a.c1)};
+#endif
+}
+
+// Two independent Fq2 products / squares side by side: four interleaved column chains (fp29.h, dots_uniform).
+template <int Ba, int Bb, int Bc, int Bd>
+GS_HD void mul2(const Fq2e<Ba>& a, const Fq2e<Bb>& b, const Fq2e<Bc>& c, const Fq2e<Bd>& d, Fq2e<2>& ab, Fq2e<2>& cd) {
+  const auto nb1 = neg(b.c1);
+  const auto nd1 = neg(d.c1);
+  const Dot<2> ch[4] = {dot_of(a.c0, b.c0, a.c1, nb1), dot_of(a.c0, b.c1, a.c1, b.c0), dot_of(c.c0, d.c0, c.c1, nd1), dot_of(c.c0, d.c1, c.c1, d.c0)};
+  Fe<ModQ, 2> r[4];
+  dots_uniform<ModQ, 4, 2>(ch, r);
+  ab.c0 = r[0]; ab.c1 = r[1]; cd.c0 = r[2]; cd.c1 = r[3];
+}
+template <int Ba, int Bb>
+GS_HD void sqr2(const Fq2e<Ba>& a, const Fq2e<Bb>& b, Fq2e<2>& aa, Fq2e<2>& bb) {
+  const auto sa = add(a.c0, a.c1), sb = add(b.c0, b.c1);
+  const auto da = sub(a.c0, a.c1), db = sub(b.c0, b.c1);
+  const auto ta = dbl(a.c0), tb = dbl(b.c0);
+  const Dot<1> ch[4] = {dot_of(sa, da), dot_of(ta, a.c1), dot_of(sb, db), dot_of(tb, b.c1)};
+  Fe<ModQ, 2> r[4];
+  dots_uniform<ModQ, 4, 1>(ch, r);
+  aa.c0 = r[0]; aa.c1 = r[1]; bb.c0 = r[2]; bb.c1 = r[3];
 }
 
 // 1 / (a0 + a1 u) = (a0 - a1 u) / (a0^2 + a1^2)                        [fq2.go:99-110]

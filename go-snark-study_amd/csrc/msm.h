@@ -10,6 +10,7 @@ namespace gs {
 struct PlanBuffers {             // grow-only device workspaces owned by a plan slot
   DevBuf digits, hist, totals, offsets, entries, tiles, total;
   DevBuf chunk_bucket, heavy_list, counters;
+  DevBuf recs, parts;              // wide windows: (term, bucket) records partitioned by (window, range); counts | bases | cursors
 };
 
 struct MsmPlan {                 // digits of one scalar vector, bucket-sorted (device resident)
@@ -26,7 +27,7 @@ struct MsmPlan {                 // digits of one scalar vector, bucket-sorted (
   const uint32_t* heavy_count = nullptr;
 };
 
-constexpr int kMaxWindowBits = 17;
+constexpr int kMaxWindowBits = 20;
 int choose_window_bits(uint32_t n, int forced);
 
 // Window table of a base array: rows[j][i] = 2^(c j) * P_i (packed affine), j < W = 254 / c + 1.
@@ -57,9 +58,10 @@ void build_plan(Ctx& c, int slot, const uint32_t* scalars_dev, uint32_t n, MsmPl
 // stream has been synchronised, msm_finish_* adds the pairs on the host core and books the timings.
 // ws_base: first of the 8 workspace sets to use (groups in flight together must not share sets).
 struct MsmPending {
-  int njobs = 0, L = 1, slot = 0;
+  int njobs = 0, L = 1, slot = 0, c = 0, W = 0;
   uint32_t nblk = 0, n = 0;
   bool g2 = false;
+  bool folded = false;             // the device folded the workgroup pairs: one XYZZ point per job in the pinned slot
   std::shared_ptr<PhaseTimer> tacc, tker, tred;
 };
 // tail_stream: where the window merge / reduction / download go (nullptr = c.stream)

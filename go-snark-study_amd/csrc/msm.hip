@@ -15,14 +15,21 @@ static_assert(sizeof(G2Xyzz) == PointIO<Fq2Tag>::kXyzzWords * 4, "G2 XYZZ must b
 
 static inline dim3 grid1(size_t n, int block = 256) { return dim3((unsigned)((n + block - 1) / block)); }
 
+// Window width.  With window tables an MSM costs n * W(c) mixed additions (W = floor(254 / c) + 1 digit positions, all feeding
+// ONE bucket set) plus two complete additions per bucket for the reduction (a complete XYZZ addition is ~1.4 mixed ones) plus
+// the chunk partials, so wide windows pay as soon as n is large against the 2^(c-1) buckets: c = 20 at n = 2^20 is 13
+// additions per term instead of 16.  GS_WINDOW_COST_BUCKET (in mixed additions per bucket) tunes the model for experiments.
 int choose_window_bits(uint32_t n, int forced) {
-  if (forced >= 8 && forced <= 17) return forced;
-  int lg = 0;
-  while ((1u << (lg + 1)) <= n) ++lg;                 // floor(log2 n), n >= 1
-  // with window tables the accumulation costs n * W(c) additions and the reduction only 2^(c-1) buckets
-  // c = 17 (2^16 buckets, u16-pair LDS counters) is supported and tested but measured no faster at 2^20 (15 instead of
-  // 16 additions per term, paid back by a slower sort and the same number of wave rounds), so 16 stays the default cap
-  return std::max(8, std::min(16, lg));
+  if (forced >= 8 && forced <= kMaxWindowBits) return forced;
+  static const double per_bucket = getenv("GS_WINDOW_COST_BUCKET") ? atof(getenv("GS_WINDOW_COST_BUCKET")) : 6.0;
+  int best = 8;
+  double best_cost = 1e300;
+  for (int c = 8; c <= kMaxWindowBits; ++c) {
+    const int W = 254 / c + 1;
+    const double cost = (double)n * W + per_bucket * (double)(1u << (c - 1));
+    if (cost < best_cost) { best_cost = cost; best = c; }
+  }
+  return best;
 }
 
 static void exclusive_scan(Ctx& c, PlanBuffers& pb, const uint32_t* in, uint32_t* out, uint32_t n) {
@@ -71,12 +78,29 @@ void build_plan(Ctx& c, int slot, const uint32_t* scalars_dev, uint32_t n, MsmPl
   const size_t ncount = (size_t)plan.nbuckets + 1;
   PlanParams pp{};
   pp.n = n; pp.c = plan.c; pp.W = plan.W; pp.B = plan.B;
-  pp.packed = plan.B > 32768u ? 1u : 0u;                  // c = 17: u16-pair counters, so a slice may hold at most 65535 scalars
-  pp.S = pp.packed ? std::max<uint32_t>(1u, (n + 65534u) / 65535u)
-                   : std::max<uint32_t>(1u, std::min<uint32_t>(16u, (n + 16383u) / 16384u));
+  pp.R = std::max<uint32_t>(1u, plan.B >> kRangeLog);      // bucket ranges of 2^15 counters (one LDS histogram each)
+  // slices: enough (window, slice, range) workgroups to cover the 256 CUs, never less than 16384 scalars per slice, and a
+  // histogram matrix hist[W * S][B] of at most 64 MiB
+  {
+    const uint32_t want = (256u + plan.W * pp.R - 1) / (plan.W * pp.R);
+    const uint32_t by_size = std::max<uint32_t>(1u, (n + 16383u) / 16384u);
+    const uint32_t by_mem = std::max<uint32_t>(1u, (uint32_t)((64ull << 20) / ((uint64_t)plan.B * plan.W * 4)));
+    pp.S = std::max<uint32_t>(1u, std::min(std::min<uint32_t>(16u, std::max<uint32_t>(want, 1u)), std::min(by_size, by_mem)));
+    if (pp.R == 1) pp.S = std::max<uint32_t>(1u, std::min<uint32_t>(16u, by_size));     // narrow windows: as before
+  }
   pp.slice = (n + pp.S - 1) / pp.S;
   pp.stride = (n + 63u) & ~63u;
-  pb.digits.ensure((size_t)std::max<uint32_t>(pp.stride, 64u) * plan.W * sizeof(digit_t));
+  // R >= 4 bucket ranges: partition by (window, range) first (msm_kernels.h); with two ranges reading the digit matrix twice is
+  // cheaper than writing and re-reading 8-byte records
+  static const uint32_t part_min_r = getenv("GS_PART_MIN_R") ? (uint32_t)atoi(getenv("GS_PART_MIN_R")) : 4u;
+  const bool wide = pp.R >= part_min_r;
+  const uint32_t nparts = (uint32_t)plan.W * pp.R;
+  if (wide && nparts > kMaxParts) throw HipError{hipErrorInvalidValue, "too many (window, range) partitions", __LINE__};
+  if (!wide) pb.digits.ensure((size_t)std::max<uint32_t>(pp.stride, 64u) * plan.W * sizeof(digit_t));
+  else {
+    pb.recs.ensure(std::max<size_t>((size_t)n * plan.W, 1) * 8);
+    pb.parts.ensure((size_t)(3 * kMaxParts + 4) * 4);
+  }
   pb.hist.ensure((size_t)plan.B * plan.W * pp.S * 4);
   pb.totals.ensure(ncount * 4);
   pb.offsets.ensure(ncount * 4);
@@ -84,25 +108,41 @@ void build_plan(Ctx& c, int slot, const uint32_t* scalars_dev, uint32_t n, MsmPl
   pb.chunk_bucket.ensure((size_t)plan.maxchunks * 4);
   pb.heavy_list.ensure((size_t)kMaxHeavy * 4);
   pb.counters.ensure(16);
-  const size_t lds = pp.packed ? (size_t)plan.B * 2 : (size_t)plan.B * 4;
+  const size_t lds = (size_t)std::min<uint32_t>(plan.B, kRangeBuckets) * 4;
+  static const int sort_block = getenv("GS_SORT_BLOCK") ? std::max(64, std::min(kSortBlock, atoi(getenv("GS_SORT_BLOCK")))) : kSortBlock;
   if (!ms.lds_attr_set) {       // B <= 2^15 counters = 128 KiB of the CU's 160 KiB LDS
     GS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hist), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     GS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    GS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hist_part), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    GS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_scatter_part), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     ms.lds_attr_set = true;
   }
   GS_HIP(hipMemsetAsync(pb.totals.as<uint32_t>() + plan.nbuckets, 0, 4, c.stream));
   GS_HIP(hipMemsetAsync(pb.counters.p, 0, 16, c.stream));
-  if (n > 0) {
+  uint32_t* part_count = pb.parts.as<uint32_t>();
+  uint32_t* part_base = part_count ? part_count + kMaxParts : nullptr;
+  uint32_t* part_cursor = part_count ? part_base + kMaxParts + 4 : nullptr;
+  if (n > 0 && wide) {
+    GS_HIP(hipMemsetAsync(part_count, 0, (size_t)nparts * 4, c.stream));
+    hipLaunchKernelGGL(k_part_count, grid1(n, kPartBlock), dim3(kPartBlock), 0, c.stream, scalars_dev, pp, part_count);
+    hipLaunchKernelGGL(k_part_scan, dim3(1), dim3(64), 0, c.stream, part_count, nparts, part_base, part_cursor);
+    hipLaunchKernelGGL(k_part_scatter, grid1(n, kPartBlock * kPartPerThread), dim3(kPartBlock), 0, c.stream, scalars_dev, pp, part_base, part_cursor,
+                       pb.recs.as<uint2>());
+    hipLaunchKernelGGL(k_hist_part, dim3(8 * pp.S * ((nparts + 7) / 8)), dim3(sort_block), lds, c.stream, pb.recs.as<uint2>(), part_base, pp, pb.hist.as<uint32_t>());
+    hipLaunchKernelGGL(k_colscan, grid1(plan.B), dim3(256), 0, c.stream, pb.hist.as<uint32_t>(), pp, pb.totals.as<uint32_t>());
+  } else if (n > 0) {
     hipLaunchKernelGGL(k_digits, grid1(n), dim3(256), 0, c.stream, scalars_dev, pp, pb.digits.as<digit_t>());
-    hipLaunchKernelGGL(k_hist, dim3(plan.W, pp.S), dim3(kSortBlock), lds, c.stream, pb.digits.as<digit_t>(), pp, pb.hist.as<uint32_t>());
+    hipLaunchKernelGGL(k_hist, dim3(plan.W, pp.S, pp.R), dim3(sort_block), lds, c.stream, pb.digits.as<digit_t>(), pp, pb.hist.as<uint32_t>());
     hipLaunchKernelGGL(k_colscan, grid1(plan.B), dim3(256), 0, c.stream, pb.hist.as<uint32_t>(), pp, pb.totals.as<uint32_t>());
   } else {
     GS_HIP(hipMemsetAsync(pb.totals.p, 0, ncount * 4, c.stream));
   }
   exclusive_scan(c, pb, pb.totals.as<uint32_t>(), pb.offsets.as<uint32_t>(), (uint32_t)ncount);
   if (n > 0) {
-    hipLaunchKernelGGL(k_scatter, dim3(plan.W, pp.S), dim3(kSortBlock), lds, c.stream, pb.digits.as<digit_t>(), pp, pb.hist.as<uint32_t>(),
-                       pb.offsets.as<uint32_t>(), pb.entries.as<uint32_t>());
+    if (wide) hipLaunchKernelGGL(k_scatter_part, dim3(8 * pp.S * ((nparts + 7) / 8)), dim3(sort_block), lds, c.stream, pb.recs.as<uint2>(), part_base, pp,
+                                 pb.hist.as<uint32_t>(), pb.offsets.as<uint32_t>(), pb.entries.as<uint32_t>());
+    else hipLaunchKernelGGL(k_scatter, dim3(plan.W, pp.S, pp.R), dim3(sort_block), lds, c.stream, pb.digits.as<digit_t>(), pp, pb.hist.as<uint32_t>(),
+                            pb.offsets.as<uint32_t>(), pb.entries.as<uint32_t>());
     hipLaunchKernelGGL(k_chunk_map, grid1(plan.nbuckets), dim3(256), 0, c.stream, pb.offsets.as<uint32_t>(), plan.nbuckets, plan.chunk,
                        pb.chunk_bucket.as<uint32_t>(), pb.heavy_list.as<uint32_t>(), pb.counters.as<uint32_t>());
   }
@@ -153,6 +193,7 @@ static void msm_enqueue(Ctx& c, const MsmPlan& plan, const std::vector<MsmBase>&
   const int njobs = (int)bases.size();
   p = MsmPending{};
   p.njobs = njobs; p.slot = slot; p.n = plan.n; p.g2 = PointIO<T>::kAffineWords == 32;
+  p.c = plan.c; p.W = plan.W;
   if (njobs == 0 || plan.n == 0) { p.njobs = plan.n == 0 ? -njobs : 0; return; }
   if (njobs > kMaxJobs) throw HipError{hipErrorInvalidValue, "too many MSM jobs", __LINE__};
   constexpr size_t pw = PointIO<T>::kXyzzWords;
@@ -160,11 +201,15 @@ static void msm_enqueue(Ctx& c, const MsmPlan& plan, const std::vector<MsmBase>&
   const int L = (int)std::max<uint32_t>(1u, std::min<uint32_t>(8u, plan.B / kReduceBlock));
   const uint32_t nblk = (plan.B + kReduceBlock * L - 1) / (kReduceBlock * L);
   p.L = L; p.nblk = nblk;
-  const size_t out_bytes = (size_t)njobs * nblk * 2 * pw * 4;
+  p.folded = nblk > 16;                                   // wide windows: the pairs are folded on the device (k_pair_reduce)
+  if (nblk > (uint32_t)kReduceBlock) throw HipError{hipErrorInvalidValue, "too many reduce workgroups for one fold", __LINE__};
+  const size_t pair_bytes = (size_t)njobs * nblk * 2 * pw * 4, final_bytes = (size_t)njobs * pw * 4;
+  const size_t out_bytes = p.folded ? final_bytes : pair_bytes;
   if (out_bytes > Ctx::kPinnedBytes) throw HipError{hipErrorInvalidValue, "MSM result staging too small", __LINE__};
   AccJobs jobs{};
   DevBuf& outb = c.ws_out[ws_base % Ctx::kWsSets];
-  outb.ensure(out_bytes);
+  outb.ensure(pair_bytes + final_bytes);
+  uint32_t* finals = outb.as<uint32_t>() + pair_bytes / 4;
   for (int j = 0; j < njobs; ++j) {
     const BaseTable* t = bases[j].table;
     if (!t || t->c != plan.c || bases[j].off + plan.n > t->n)
@@ -177,15 +222,13 @@ static void msm_enqueue(Ctx& c, const MsmPlan& plan, const std::vector<MsmBase>&
     pt.ensure((size_t)plan.maxchunks * 2 * pw * 4);
     jobs.j[j] = AccJob{t->rows.as<uint32_t>() + bases[j].off * aw, (uint32_t)t->n, bk.as<uint32_t>(), pt.as<uint32_t>(),
                        pt.as<uint32_t>() + (size_t)plan.maxchunks * pw, mg.as<uint32_t>(),
-                       outb.as<uint32_t>() + (size_t)j * nblk * 2 * pw};
+                       outb.as<uint32_t>() + (size_t)j * nblk * 2 * pw, finals + (size_t)j * pw};
   }
   p.tacc = std::make_shared<PhaseTimer>(c.stream);
   p.tker = std::make_shared<PhaseTimer>(c.stream);
   hipLaunchKernelGGL(k_bucket_accumulate<T>, dim3((plan.maxchunks + 255) / 256, njobs), dim3(256), 0, c.stream,
                      jobs, plan.offsets, plan.entries, plan.chunk_bucket, plan.nbuckets, plan.chunk);
   p.tker->stop();
-  hipLaunchKernelGGL(k_heavy_combine<T>, dim3(1024, njobs), dim3(kHeavyBlock), 0, c.stream,
-                     jobs, plan.offsets, plan.heavy_list, plan.heavy_count, plan.chunk);
   p.tacc->stop();
   // the latency-bound tail may run on another stream, in the shadow of the next group's accumulation
   hipStream_t ts = tail_stream ? tail_stream : c.stream;
@@ -197,10 +240,19 @@ static void msm_enqueue(Ctx& c, const MsmPlan& plan, const std::vector<MsmBase>&
     GS_HIP(hipEventDestroy(ev));       // released by the runtime once it has fired
   }
   p.tred = std::make_shared<PhaseTimer>(ts);
+  // (the block-wide tree for buckets cut into very many chunks belongs to the tail too: with uniform scalars it finds nothing
+  // to do, and on the accumulation stream even an empty launch waited ~0.5 ms for register space)
+  hipLaunchKernelGGL(k_heavy_combine<T>, dim3(1024, njobs), dim3(kHeavyBlock), 0, ts,
+                     jobs, plan.offsets, plan.heavy_list, plan.heavy_count, plan.chunk);
   hipLaunchKernelGGL(k_bucket_combine<T>, dim3((plan.B + 255) / 256, njobs), dim3(256), 0, ts, jobs, plan.offsets, plan.B, plan.chunk);
   hipLaunchKernelGGL(k_block_reduce<T>, dim3(nblk, njobs), dim3(kReduceBlock), 0, ts, jobs, plan.B, L);
+  if (p.folded) {
+    int log2_span = 0;
+    while ((1u << log2_span) < (uint32_t)kReduceBlock * (uint32_t)L) ++log2_span;
+    hipLaunchKernelGGL(k_pair_reduce<T>, dim3(1, njobs), dim3(kReduceBlock), 0, ts, jobs, nblk, log2_span);
+  }
   GS_HIP(hipGetLastError());
-  GS_HIP(hipMemcpyAsync(c.pinned[slot], outb.p, out_bytes, hipMemcpyDeviceToHost, ts));
+  GS_HIP(hipMemcpyAsync(c.pinned[slot], p.folded ? (const void*)finals : outb.p, out_bytes, hipMemcpyDeviceToHost, ts));
   p.tred->stop();
 }
 
@@ -224,8 +276,10 @@ void msm_book_timing(Ctx& c, const MsmPending& p) {
   if (p.njobs <= 0) return;
   std::lock_guard<std::mutex> lk(c.timing_mu);
   c.timing.accumulate_ms += p.tacc->ms();
-  if (!p.g2) { c.timing.acc_g1_ms += p.tker->ms(); c.timing.acc_g1_launches += 1; c.timing.acc_g1_terms += (uint64_t)p.n * p.njobs; }
-  else { c.timing.acc_g2_ms += p.tker->ms(); c.timing.acc_g2_launches += 1; c.timing.acc_g2_terms += (uint64_t)p.n * p.njobs; }
+  const uint64_t terms = (uint64_t)p.n * p.njobs;
+  if (!p.g2) { c.timing.acc_g1_ms += p.tker->ms(); c.timing.acc_g1_launches += 1; c.timing.acc_g1_terms += terms; c.timing.acc_g1_adds += terms * p.W; }
+  else { c.timing.acc_g2_ms += p.tker->ms(); c.timing.acc_g2_launches += 1; c.timing.acc_g2_terms += terms; c.timing.acc_g2_adds += terms * p.W; }
+  c.timing.window_bits = (uint32_t)p.c;
   c.timing.reduce_ms += p.tred->ms();
 }
 
@@ -234,6 +288,10 @@ static void msm_finish(Ctx& c, const MsmPending& p, std::vector<Xyzz<T>>& out) {
   if (p.njobs <= 0) { out.assign(-p.njobs, xyzz_inf<T>()); return; }
   out.assign(p.njobs, xyzz_inf<T>());
   const Xyzz<T>* pairs = static_cast<const Xyzz<T>*>(c.pinned[p.slot]);
+  if (p.folded) {                                          // one point per job came back
+    for (int j = 0; j < p.njobs; ++j) out[j] = pairs[j];
+    return;
+  }
   std::vector<std::future<Xyzz<T>>> fut;
   for (int j = 1; j < p.njobs; ++j)
     fut.push_back(std::async(std::launch::async, [=] { return sum_pairs<T>(pairs + (size_t)j * p.nblk * 2, p.nblk, p.L); }));

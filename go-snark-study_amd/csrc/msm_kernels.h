@@ -7,7 +7,7 @@
 // Pipeline (all on the library stream, no host round trips):
 //   plan (once per scalar vector, shared by every base array multiplied by it; no host round trip):
 //     k_digits        scalars -> signed c-bit digit matrix (u16)
-//     k_hist          per (window, slice) workgroup: bucket histogram in LDS (128 KiB of the 160 KiB; u16 pairs for c = 17)
+//     k_hist          per (window, slice, bucket range) workgroup: histogram of 2^15 buckets in LDS (128 KiB of the 160 KiB)
 //     k_colscan+scan  exclusive prefix sums -> bucket offsets, per-slice cursors
 //     k_scatter       counting sort with LDS cursors: entries[] = term index (sign in bit 31) grouped by bucket
 //     k_chunk_map     cut the sorted entry list into equal chunks of 32 entries (load balance)
@@ -33,14 +33,20 @@ namespace gs {
 
 struct PlanParams {
   uint32_t n;        // scalars
-  int c;             // window bits (<= 17)
+  int c;             // window bits (<= 20)
   int W;             // windows = floor(254 / c) + 1
   uint32_t B;        // buckets per window = 2^(c-1)   (digits are signed: [-B+1, B])
   uint32_t S;        // slices of the scalar vector (one histogram/scatter workgroup per (window, slice))
   uint32_t slice;    // scalars per slice
   uint32_t stride;   // row stride of the digit matrix (elements)
-  uint32_t packed;   // 1: LDS counters are u16 pairs (B = 2^16 buckets, c = 17); slices hold <= 65535 scalars
+  uint32_t R;        // bucket ranges of kRangeBuckets counters each (B <= 2^15: one range; c = 20: sixteen)
 };
+// One histogram / scatter workgroup keeps the counters of ONE bucket range in LDS (2^15 u32 = 128 KiB of the CU's 160 KiB) and
+// counts the digits of its (window, slice) that fall into it; wide windows (c > 16) take R = B / 2^15 such workgroups per
+// (window, slice), each re-reading the slice's digits (sequential 4-byte reads: the sort is bandwidth-cheap, the accumulation is
+// not -- fewer, wider windows trade R passes over a 50 MiB digit matrix for 3 fewer point additions per term).
+constexpr uint32_t kRangeLog = 15;
+constexpr uint32_t kRangeBuckets = 1u << kRangeLog;
 
 // signed digit of window w with the running carry (digit in [-B+1, B]; 0 <-> the term is skipped in that window)
 GS_HD int32_t next_digit(const uint32_t (&k)[8], const PlanParams& pp, int w, uint32_t& carry) {
@@ -67,34 +73,30 @@ __global__ void __launch_bounds__(256) k_digits(const uint32_t* __restrict__ sca
   }
 }
 
-// ---- plan, step 2: per-(window, slice) bucket histogram in LDS (B counters <= 128 KiB of the CU's 160 KiB) -----
-// grid = (W, S): blockIdx.x = window, so that all slices of a window run on XCD (w % 8) and the window's
+// ---- plan, step 2: per-(window, slice, range) bucket histogram in LDS -----------------------------------------
+// grid = (W, S, R): blockIdx.x = window, so that all slices of a window run on XCD (w % 8) and the window's
 // 4n-byte region of `entries` is assembled in ONE L2 by the scatter pass below.
-constexpr int kSortBlock = 1024;
-// LDS counter access: plain u32 counters (B <= 2^15), or u16 pairs packed in u32 words (B = 2^16: 128 KiB again)
-GS_HD uint32_t packed_inc(uint32_t b) { return (b & 1u) ? 0x10000u : 1u; }
-GS_HD uint32_t packed_get(uint32_t word, uint32_t b) { return (b & 1u) ? (word >> 16) : (word & 0xffffu); }
+constexpr int kSortBlock = 1024;      // upper bound; the launch picks 256 .. 1024 threads (msm.hip: sort_block)
 
 __global__ void __launch_bounds__(kSortBlock) k_hist(const digit_t* __restrict__ digits, PlanParams pp, uint32_t* __restrict__ hist) {
   extern __shared__ uint32_t sh[];
-  const uint32_t w = blockIdx.x, s = blockIdx.y;
-  const uint32_t nwords = pp.packed ? pp.B / 2 : pp.B;
-  for (uint32_t b = threadIdx.x; b < nwords; b += kSortBlock) sh[b] = 0;
+  const uint32_t w = blockIdx.x, s = blockIdx.y, r = blockIdx.z;
+  const uint32_t nb = min(pp.B, kRangeBuckets), base = r << kRangeLog;
+  for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) sh[b] = 0;
   __syncthreads();
   const uint32_t lo = s * pp.slice, hi = min(pp.n, lo + pp.slice);
   const digit_t* row = digits + (size_t)w * pp.stride;
   const int32_t zero = (int32_t)pp.B - 1;
-  for (uint32_t i = lo + threadIdx.x; i < hi; i += kSortBlock) {
+  for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
     const int32_t d = (int32_t)row[i] - zero;
     if (d != 0) {
       const uint32_t b = (uint32_t)(d < 0 ? -d : d) - 1u;
-      if (pp.packed) atomicAdd(&sh[b >> 1], packed_inc(b));
-      else atomicAdd(&sh[b], 1u);
+      if ((b >> kRangeLog) == r) atomicAdd(&sh[b - base], 1u);
     }
   }
   __syncthreads();
-  uint32_t* out = hist + ((size_t)w * pp.S + s) * pp.B;
-  for (uint32_t b = threadIdx.x; b < pp.B; b += kSortBlock) out[b] = pp.packed ? packed_get(sh[b >> 1], b) : sh[b];
+  uint32_t* out = hist + ((size_t)w * pp.S + s) * pp.B + base;
+  for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) out[b] = sh[b];
 }
 
 // hist[q][b], q = w*S + s  ->  exclusive prefix over q (in place); totals[b] = sum over q.
@@ -110,28 +112,167 @@ __global__ void __launch_bounds__(256) k_colscan(uint32_t* __restrict__ hist, Pl
   totals[b] = run;
 }
 
-// ---- plan, step 4: counting-sort scatter; cursors live in LDS ------------------------------------------------
+// ---- plan, step 4: counting-sort scatter; the cursors of the workgroup's bucket range live in LDS -------------------
 // entry = sign (bit 31) | window (bits 30..26) | term index (bits 25..0)
 __global__ void __launch_bounds__(kSortBlock) k_scatter(const digit_t* __restrict__ digits, PlanParams pp, const uint32_t* __restrict__ hist,
                                                          const uint32_t* __restrict__ offsets, uint32_t* __restrict__ entries) {
   extern __shared__ uint32_t sh[];
-  const uint32_t w = blockIdx.x, s = blockIdx.y;
-  const uint32_t* pre = hist + ((size_t)w * pp.S + s) * pp.B;
-  if (pp.packed) { for (uint32_t b = threadIdx.x; b < pp.B / 2; b += kSortBlock) sh[b] = 0; }       // local u16 counters; bases stay in L2
-  else { for (uint32_t b = threadIdx.x; b < pp.B; b += kSortBlock) sh[b] = offsets[b] + pre[b]; }    // full u32 cursors in LDS
+  const uint32_t w = blockIdx.x, s = blockIdx.y, r = blockIdx.z;
+  const uint32_t nb = min(pp.B, kRangeBuckets), base = r << kRangeLog;
+  const uint32_t* pre = hist + ((size_t)w * pp.S + s) * pp.B + base;
+  for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) sh[b] = offsets[base + b] + pre[b];
   __syncthreads();
   const uint32_t lo = s * pp.slice, hi = min(pp.n, lo + pp.slice);
   const digit_t* row = digits + (size_t)w * pp.stride;
   const int32_t zero = (int32_t)pp.B - 1;
-  for (uint32_t i = lo + threadIdx.x; i < hi; i += kSortBlock) {
+  for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
     const int32_t d = (int32_t)row[i] - zero;
     if (d != 0) {
       const uint32_t b = (uint32_t)(d < 0 ? -d : d) - 1u;
-      uint32_t pos;
-      if (pp.packed) pos = offsets[b] + pre[b] + packed_get(atomicAdd(&sh[b >> 1], packed_inc(b)), b);
-      else pos = atomicAdd(&sh[b], 1u);
-      entries[pos] = i | (w << kWindowShift) | (d < 0 ? kSignBit : 0u);
+      if ((b >> kRangeLog) == r) {
+        const uint32_t pos = atomicAdd(&sh[b - base], 1u);
+        entries[pos] = i | (w << kWindowShift) | (d < 0 ? kSignBit : 0u);
+      }
     }
+  }
+}
+
+// ---- wide windows (R > 1 bucket ranges): partition first, then the same LDS counting sort per partition --------------
+// Filtering a (window, slice) of the digit matrix once per range would read it R times (16 x 50 MiB at c = 20).  Instead
+// the (term, digit) pairs are first PARTITIONED by (window, range) -- W * R <= 512 partitions of ~n / R records each, sizes
+// counted by k_part_count, bases by k_part_scan, records written by k_part_scatter -- and the LDS histogram / scatter
+// workgroup of (window, range, slice) then reads only its own partition: every pair is read twice, whatever R is.
+// record = bucket (high word) | sign (bit 31) term index (low word); the window is implied by the partition.
+constexpr int kPartBlock = 256;
+constexpr int kPartPerThread = 4;        // scalars per thread of k_part_scatter: runs of ~kPartBlock * 4 / R records per partition
+constexpr uint32_t kMaxParts = 512;
+
+GS_HD void load_scalar_canon(const uint32_t* __restrict__ scalars, uint32_t i, uint32_t (&k)[8]) {
+  const uint4* s4 = reinterpret_cast<const uint4*>(scalars + (size_t)i * 8);
+  const uint4 lo = s4[0], hi = s4[1];
+  k[0] = lo.x; k[1] = lo.y; k[2] = lo.z; k[3] = lo.w; k[4] = hi.x; k[5] = hi.y; k[6] = hi.z; k[7] = hi.w;
+  scalar_canon(k);
+}
+
+__global__ void __launch_bounds__(kPartBlock) k_part_count(const uint32_t* __restrict__ scalars, PlanParams pp, uint32_t* __restrict__ part_count) {
+  __shared__ uint32_t cnt[kMaxParts];
+  const uint32_t nparts = (uint32_t)pp.W * pp.R;
+  for (uint32_t t = threadIdx.x; t < nparts; t += kPartBlock) cnt[t] = 0;
+  __syncthreads();
+  const uint32_t i = blockIdx.x * kPartBlock + threadIdx.x;
+  if (i < pp.n) {
+    uint32_t k[8];
+    load_scalar_canon(scalars, i, k);
+    uint32_t carry = 0;
+    for (int w = 0; w < pp.W; ++w) {
+      const int32_t d = next_digit(k, pp, w, carry);
+      if (d != 0) atomicAdd(&cnt[(uint32_t)w * pp.R + (((uint32_t)(d < 0 ? -d : d) - 1u) >> kRangeLog)], 1u);
+    }
+  }
+  __syncthreads();
+  for (uint32_t t = threadIdx.x; t < nparts; t += kPartBlock) if (cnt[t]) atomicAdd(&part_count[t], cnt[t]);
+}
+
+// part_base[0 .. nparts] = exclusive prefix of the partition sizes; cursors start at zero
+__global__ void __launch_bounds__(64) k_part_scan(uint32_t* __restrict__ part_count, uint32_t nparts, uint32_t* __restrict__ part_base,
+                                                    uint32_t* __restrict__ part_cursor) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  uint32_t run = 0;
+  for (uint32_t t = 0; t < nparts; ++t) { part_base[t] = run; run += part_count[t]; part_cursor[t] = 0; part_count[t] = 0; }
+  part_base[nparts] = run;
+}
+
+__global__ void __launch_bounds__(kPartBlock) k_part_scatter(const uint32_t* __restrict__ scalars, PlanParams pp, const uint32_t* __restrict__ part_base,
+                                                              uint32_t* __restrict__ part_cursor, uint2* __restrict__ recs) {
+  __shared__ uint32_t cnt[kMaxParts];      // this workgroup's records per partition, then its write cursor in each
+  const uint32_t nparts = (uint32_t)pp.W * pp.R;
+  for (uint32_t t = threadIdx.x; t < nparts; t += kPartBlock) cnt[t] = 0;
+  __syncthreads();
+  const uint32_t first = blockIdx.x * (kPartBlock * kPartPerThread);
+  for (int j = 0; j < kPartPerThread; ++j) {
+    const uint32_t i = first + j * kPartBlock + threadIdx.x;
+    if (i >= pp.n) break;
+    uint32_t k[8];
+    load_scalar_canon(scalars, i, k);
+    uint32_t carry = 0;
+    for (int w = 0; w < pp.W; ++w) {
+      const int32_t d = next_digit(k, pp, w, carry);
+      if (d != 0) atomicAdd(&cnt[(uint32_t)w * pp.R + (((uint32_t)(d < 0 ? -d : d) - 1u) >> kRangeLog)], 1u);
+    }
+  }
+  __syncthreads();
+  for (uint32_t t = threadIdx.x; t < nparts; t += kPartBlock) {            // reserve this workgroup's run in every partition
+    const uint32_t mine = cnt[t];
+    cnt[t] = part_base[t] + (mine ? atomicAdd(&part_cursor[t], mine) : 0u);
+  }
+  __syncthreads();
+  for (int j = 0; j < kPartPerThread; ++j) {
+    const uint32_t i = first + j * kPartBlock + threadIdx.x;
+    if (i >= pp.n) break;
+    uint32_t k[8];
+    load_scalar_canon(scalars, i, k);
+    uint32_t carry = 0;
+    for (int w = 0; w < pp.W; ++w) {
+      const int32_t d = next_digit(k, pp, w, carry);
+      if (d != 0) {
+        const uint32_t b = (uint32_t)(d < 0 ? -d : d) - 1u;
+        const uint32_t pos = atomicAdd(&cnt[(uint32_t)w * pp.R + (b >> kRangeLog)], 1u);
+        recs[pos] = make_uint2(i | (d < 0 ? kSignBit : 0u), b);
+      }
+    }
+  }
+}
+
+// Workgroup -> (partition, slice).  Workgroups go to the 8 XCDs round-robin by linear id, and every XCD has its own L2: all
+// slices of a partition are given ids with the same (id mod 8), so the partition's window of `entries` (B / R buckets worth
+// of 4-byte scattered writes) is assembled in ONE L2 instead of bouncing between eight.
+GS_HD bool part_of_block(uint32_t id, const PlanParams& pp, uint32_t& w, uint32_t& r, uint32_t& s) {
+  const uint32_t xcd = id & 7u, j = id >> 3;
+  const uint32_t p = xcd + 8u * (j / pp.S);
+  s = j % pp.S;
+  w = p / pp.R; r = p % pp.R;
+  return p < (uint32_t)pp.W * pp.R;
+}
+
+// the records of slice s of partition (w, r)
+GS_HD void part_slice(const uint32_t* __restrict__ part_base, const PlanParams& pp, uint32_t w, uint32_t r, uint32_t s, uint32_t& lo, uint32_t& hi) {
+  const uint32_t p0 = part_base[w * pp.R + r], p1 = part_base[w * pp.R + r + 1];
+  const uint32_t len = p1 - p0, per = (len + pp.S - 1) / pp.S;
+  lo = min(p1, p0 + s * per);
+  hi = min(p1, lo + per);
+}
+
+__global__ void __launch_bounds__(kSortBlock) k_hist_part(const uint2* __restrict__ recs, const uint32_t* __restrict__ part_base, PlanParams pp,
+                                                           uint32_t* __restrict__ hist) {
+  extern __shared__ uint32_t sh[];
+  uint32_t w, r, s;
+  if (!part_of_block(blockIdx.x, pp, w, r, s)) return;
+  const uint32_t base = r << kRangeLog;
+  for (uint32_t b = threadIdx.x; b < kRangeBuckets; b += blockDim.x) sh[b] = 0;
+  __syncthreads();
+  uint32_t lo, hi;
+  part_slice(part_base, pp, w, r, s, lo, hi);
+  for (uint32_t e = lo + threadIdx.x; e < hi; e += blockDim.x) atomicAdd(&sh[recs[e].y - base], 1u);
+  __syncthreads();
+  uint32_t* out = hist + ((size_t)w * pp.S + s) * pp.B + base;
+  for (uint32_t b = threadIdx.x; b < kRangeBuckets; b += blockDim.x) out[b] = sh[b];
+}
+
+__global__ void __launch_bounds__(kSortBlock) k_scatter_part(const uint2* __restrict__ recs, const uint32_t* __restrict__ part_base, PlanParams pp,
+                                                              const uint32_t* __restrict__ hist, const uint32_t* __restrict__ offsets,
+                                                              uint32_t* __restrict__ entries) {
+  extern __shared__ uint32_t sh[];
+  uint32_t w, r, s;
+  if (!part_of_block(blockIdx.x, pp, w, r, s)) return;
+  const uint32_t base = r << kRangeLog;
+  const uint32_t* pre = hist + ((size_t)w * pp.S + s) * pp.B + base;
+  for (uint32_t b = threadIdx.x; b < kRangeBuckets; b += blockDim.x) sh[b] = offsets[base + b] + pre[b];
+  __syncthreads();
+  uint32_t lo, hi;
+  part_slice(part_base, pp, w, r, s, lo, hi);
+  for (uint32_t e = lo + threadIdx.x; e < hi; e += blockDim.x) {
+    const uint2 rec = recs[e];
+    entries[atomicAdd(&sh[rec.y - base], 1u)] = rec.x | (w << kWindowShift);
   }
 }
 
@@ -223,6 +364,7 @@ struct AccJob {
   uint32_t* tails;            // maxchunks * kXyzzWords: partial of the bucket that continues into the next chunk
   uint32_t* merged;           // B * kXyzzWords: bucket sums over all windows
   uint32_t* out;              // nblocks * 2 * kXyzzWords: per reduce-workgroup (A, S) pairs
+  uint32_t* final_out;        // kXyzzWords: the job's result when the pairs are folded on the device (k_pair_reduce)
 };
 constexpr int kMaxJobs = 8;
 struct AccJobs { AccJob j[kMaxJobs]; };
@@ -415,6 +557,52 @@ __global__ void __launch_bounds__(kReduceBlock) k_block_reduce(AccJobs jobs, uin
     __syncthreads();
   }
   if (t == 0) store_xyzz<T>(job.out + (size_t)blockIdx.x * 2 * pw, acc);          // A
+}
+
+// Second level, for wide windows (more than 16 reduce workgroups per job): one workgroup per job folds the nblk <= 256
+// pairs (A_blk, S_blk) into the job's result  sum_blk A_blk + (256 L) * sum_blk blk * S_blk  -- the suffix-scan identity
+// again (sum_blk blk * S_blk = sum_{blk >= 1} R_blk with R_blk = sum_{b' >= blk} S_b'), then log2(256 L) doublings -- so the
+// host receives ONE point per job however many buckets there were.
+template <class T>
+__global__ void __launch_bounds__(kReduceBlock) k_pair_reduce(AccJobs jobs, uint32_t nblk, int log2_span) {
+  constexpr int pw = PointIO<T>::kXyzzWords;
+  __shared__ uint32_t sh[kReduceBlock * pw];
+  const AccJob job = jobs.j[blockIdx.y];
+  const uint32_t t = threadIdx.x;
+  Xyzz<T> A = xyzz_inf<T>(), R = xyzz_inf<T>();
+  if (t < nblk) {
+    A = load_xyzz<T>(job.out + (size_t)t * 2 * pw);
+    R = load_xyzz<T>(job.out + ((size_t)t * 2 + 1) * pw);
+  }
+  store_xyzz<T>(sh + t * pw, R);
+  __syncthreads();
+  for (int off = 1; off < kReduceBlock; off <<= 1) {                 // inclusive suffix scan of S
+    Xyzz<T> o = xyzz_inf<T>();
+    const bool has = t + (uint32_t)off < (uint32_t)kReduceBlock;
+    if (has) o = load_xyzz<T>(sh + (t + off) * pw);
+    __syncthreads();
+    if (has) { xyzz_add(R, o); store_xyzz<T>(sh + t * pw, R); }
+    __syncthreads();
+  }
+  if (t == 0) R = xyzz_inf<T>();                                     // the sum runs over blk >= 1
+  for (int pass = 0; pass < 2; ++pass) {                             // tree sums: first of R (weighted part), then of A
+    Xyzz<T>& v = pass == 0 ? R : A;
+    store_xyzz<T>(sh + t * pw, v);
+    __syncthreads();
+    for (int half = kReduceBlock / 2; half >= 1; half >>= 1) {
+      if ((int)t < half) {
+        const Xyzz<T> o = load_xyzz<T>(sh + (t + half) * pw);
+        xyzz_add(v, o);
+        store_xyzz<T>(sh + t * pw, v);
+      }
+      __syncthreads();
+    }
+  }
+  if (t == 0) {
+    for (int k = 0; k < log2_span; ++k) xyzz_dbl(R);
+    xyzz_add(A, R);
+    store_xyzz<T>(job.final_out, A);
+  }
 }
 
 // ---- window tables ----------------------------------------------------------------------------------------

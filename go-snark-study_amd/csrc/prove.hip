@@ -140,23 +140,15 @@ int groth16_enqueue(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, const S
   MsmPlan plan_w, plan_h;
   // The main stream carries NOTHING but the ALU-bound bucket accumulations (G2, then the three G1 arrays over w, then h),
   // so with two proofs in flight it never idles: both plans, H(x) and every combine/reduce tail run on the aux streams.
-  {                                                              // aux 1: plan(w), then H(x), plan(h)
-    StreamScope sc(c, c.aux_stream[1]);
+  // plan(w) has its own stream: with several proofs in flight the sort of proof k+1's witness must not queue behind proof k's
+  // H(x) and plan(h) (timeline profiles/r02_timeline_*: that chain was the pace-setter)
+  static const int planw_stream = getenv("GS_PLANW_STREAM") ? atoi(getenv("GS_PLANW_STREAM")) % Ctx::kAuxStreams : 3;
+  {                                                              // aux 3: plan(w)
+    StreamScope sc(c, c.aux_stream[planw_stream]);
     st.tplanw = std::make_shared<PhaseTimer>(c.stream);
     build_plan(c, 0 + 2 * parity, w.p + wlo * 8, (uint32_t)(whi - wlo), plan_w, {{1, true}, {3, false}});
     st.tplanw->stop();
     GS_HIP(hipEventRecord(st.planw, c.stream));
-  }
-  {                                                              // main: the accumulations over w, back to back
-    StreamScope sc(c, c.main_stream);
-    GS_HIP(hipStreamWaitEvent(c.stream, st.planw, 0));
-    // BACDelta's first npublic+1 entries are forced to infinity at key creation, so the reference's
-    // loop from NPublic+1 (:248-250) equals a full-range MSM sharing w's plan.
-    // G2 first: its accumulation (2 waves/SIMD, 256 VGPRs) is the one a foreign wave hurts most, and its long
-    // combine/reduce tail then hides behind the G1 accumulations.
-    msm_enqueue_g2(c, plan_w, {MsmBase{&pk->t_bacgamma2, wbase}}, ws + 4, pin + 1, st.pend_g2w, c.aux_stream[0]);
-    msm_enqueue_g1(c, plan_w, {MsmBase{&pk->t_at, wbase}, MsmBase{&pk->t_bacgamma1, wbase}, MsmBase{&pk->t_bacdelta, wbase}}, ws + 0, pin + 0,
-                   st.pend_g1w, c.aux_stream[2]);
   }
   {                                                              // aux 1 again: (late upload of px,) H(x), plan(h)
     StreamScope sc(c, c.aux_stream[1]);
@@ -174,6 +166,17 @@ int groth16_enqueue(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, const S
     build_plan(c, 1 + 2 * parity, hxbuf.as<uint32_t>() + hlo * 8, (uint32_t)(hhi - hlo), plan_h, {{1, false}});
     st.tplanh->stop();
     GS_HIP(hipEventRecord(st.planh, c.stream));
+  }
+  {                                                              // main: the accumulations over w, back to back
+    StreamScope sc(c, c.main_stream);
+    GS_HIP(hipStreamWaitEvent(c.stream, st.planw, 0));
+    // BACDelta's first npublic+1 entries are forced to infinity at key creation, so the reference's
+    // loop from NPublic+1 (:248-250) equals a full-range MSM sharing w's plan.
+    // G2 first: its accumulation (2 waves/SIMD, 256 VGPRs) is the one a foreign wave hurts most, and its long
+    // combine/reduce tail then hides behind the G1 accumulations.
+    msm_enqueue_g2(c, plan_w, {MsmBase{&pk->t_bacgamma2, wbase}}, ws + 4, pin + 1, st.pend_g2w, c.aux_stream[0]);
+    msm_enqueue_g1(c, plan_w, {MsmBase{&pk->t_at, wbase}, MsmBase{&pk->t_bacgamma1, wbase}, MsmBase{&pk->t_bacdelta, wbase}}, ws + 0, pin + 0,
+                   st.pend_g1w, c.aux_stream[2]);
   }
   {                                                              // main again: the accumulation over h
     StreamScope sc(c, c.main_stream);
@@ -310,8 +313,8 @@ int pinocchio_enqueue(Ctx& c, PinocchioPkObj* pk, DevScalars w, DevScalars px, i
   }
   const int ws = 8 * parity, pin = 3 * parity;
   MsmPlan plan_w, plan_h;
-  {                                                              // aux 1: plan(w)
-    StreamScope sc(c, c.aux_stream[1]);
+  {                                                              // aux 3: plan(w)
+    StreamScope sc(c, c.aux_stream[3]);
     st.tplanw = std::make_shared<PhaseTimer>(c.stream);
     build_plan(c, 2 * parity, w.p, (uint32_t)w.n, plan_w, {{1, true}, {6, false}});
     st.tplanw->stop();

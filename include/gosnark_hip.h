@@ -344,6 +344,10 @@ typedef struct {
   uint32_t acc_g1_launches, acc_g2_launches;
   uint64_t acc_g1_terms; /* (terms x base arrays) those G1 launches consumed */
   uint64_t acc_g2_terms;
+  uint64_t acc_g1_adds;  /* mixed point additions those G1 launches performed = terms x base arrays x digit positions (windows) */
+  uint64_t acc_g2_adds;
+  uint32_t window_bits;  /* Pippenger window width c of the last plan; every term costs floor(254 / c) + 1 additions */
+  uint32_t reserved;
 } gs_timing;
 int gs_last_timing(gs_timing* out);                         /* the calling thread's current logical device */
 int gs_device_timing(int logical_device, gs_timing* out);

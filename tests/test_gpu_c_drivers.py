@@ -125,13 +125,13 @@ def test_snark_setup_prove_verify_c_sequence(tmp_path):
     want_vk = jac2(svk["Vka"]) + jac1(svk["Vkb"]) + jac2(svk["Vkc"]) + jac1(svk["G1Kbg"]) + jac2(svk["G2Kbg"]) + jac2(svk["G2Kg"]) + jac2(svk["Vkz"])
     for p in svk["IC"]:
         want_vk += jac1(p)
-    assert words(raw[pos:pos + len(want_vk)]) == want_vk
-    pos += len(want_vk)
+    assert words(raw[pos:pos + 4 * len(want_vk)]) == want_vk
+    pos += 4 * len(want_vk)
     for name, w in (("A", 12), ("Ap", 12), ("B", 24), ("Bp", 12), ("C", 12), ("Cp", 12), ("Kp", 12), ("G1T", 12)):
         arr = spk[name]
         want = [x for p in arr for x in (jac2(p) if w == 24 else jac1(p))]
         if name in ("A", "Ap"):                                     # infinity for i <= NPublic: what snark.go:265 skips
-            want = [0] * 24 + want[24:]
+            want = [0] * 6 + want[6:]                               # two points of three coordinates
         assert words(raw[pos:pos + w * len(arr)]) == want, name
         pos += w * len(arr)
     assert words(raw[pos:pos + 4 * len(spk["Z"])]) == [int(z) % O.R for z in spk["Z"]]

@@ -78,7 +78,7 @@ def test_g1_msm_degenerate_inputs_complete_addition():
     assert capi.msm(h, capi.ints_to_u64(big)) == U.ref_msm_affine(O.G1, pts, big)
 
 
-@pytest.mark.parametrize("c", [8, 9, 11, 16, 17])
+@pytest.mark.parametrize("c", [8, 9, 11, 16, 17, 18, 20])
 def test_g1_msm_every_window_width(c):
     rng = random.Random(300 + c)
     n = 200
@@ -197,7 +197,7 @@ def test_msm_skewed_witness_heavy_buckets(g2):
     else:
         bases = capi.g1_fixed_base(U.rand_scalars_u64(n, 78))
         want = C.g1_affine(C.g1_msm_naive(capi.g1_download(bases), ks, threads=8))
-    for c in (0, 8, 13, 17):
+    for c in (0, 8, 13, 17, 19, 20):
         capi.set_window_bits(c)
         try:
             assert capi.msm(bases, ks, g2=g2) == want, c
