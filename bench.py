@@ -480,7 +480,13 @@ def main():
             dr = r1csqap.DeviceR1CS(*inst.r1cs, inst.m)
             pxh = capi.scalars_clone(inst.px, capi.get_device())
             groth16.prove_from_r1cs(pk, dr, inst.w, r_, s_, pxh)
-            extras["from_r1cs_ms_per_step"] = time_calls(lambda: groth16.prove_from_r1cs(pk, dr, inst.w, r_, s_, pxh), 4)
+            extras["from_r1cs_via_px_ms_per_step"] = time_calls(lambda: groth16.prove_from_r1cs(pk, dr, inst.w, r_, s_, pxh), 4)
+            # ... and without px: H(x) straight from the constraint values (gs_groth16_prove_witness)
+            pw = groth16.prove_from_witness(pk, dr, inst.w, r_, s_)
+            ref = step()
+            if (pw.PiA, pw.PiB, pw.PiC) != (ref.PiA, ref.PiB, ref.PiC):
+                raise SystemExit("bench.py: gs_groth16_prove_witness disagrees with the px route")
+            extras["from_r1cs_ms_per_step"] = time_calls(lambda: groth16.prove_from_witness(pk, dr, inst.w, r_, s_), 6)
             extras["from_r1cs_constraints_per_s"] = n / extras["from_r1cs_ms_per_step"] * 1e3
             pxh.free()
             dr.handle.free()

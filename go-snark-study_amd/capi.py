@@ -74,6 +74,7 @@ _SIGS = {
     "gs_groth16_prove": [Handle, u64p, ctypes.c_size_t, u64p, ctypes.c_size_t, u64p, u64p, u64p, intp],
     "gs_groth16_prove_resident": [Handle, Handle, Handle, u64p, u64p, u64p, intp],
     "gs_groth16_prove_r1cs": [Handle, Handle, Handle, ctypes.POINTER(Handle), u64p, u64p, u64p, intp],
+    "gs_groth16_prove_witness": [Handle, Handle, Handle, u64p, u64p, u64p, intp],
     "gs_groth16_prove_begin": [Handle, Handle, Handle, u64p, u64p, u64p],
     "gs_groth16_prove_end": [ctypes.c_uint64, u64p, intp],
     "gs_groth16_pk_create_shard": [Handle, Handle, Handle, Handle, Handle, u64p, u64p, u64p, u64p, u64p, u64p, ctypes.c_size_t,
@@ -117,6 +118,7 @@ _SIGS = {
     "gs_last_timing": [ctypes.POINTER(Timing)],
     "gs_device_timing": [ctypes.c_int, ctypes.POINTER(Timing)],
     "gs_set_window_bits": [ctypes.c_int],
+    "gs_verify_set_strict": [ctypes.c_int],
     "gs_pairing": [u64p, u64p, u64p],
     "gs_pairing_check": [u64p, u64p, ctypes.c_size_t, intp],
     "gs_groth16_verify": [u64p, u64p, u64p, u64p, u64p, ctypes.c_size_t, u64p, ctypes.c_size_t, u64p, u64p, u64p, intp],

@@ -47,6 +47,10 @@ void zpoly_dev(Ctx& c, size_t deg, uint32_t* out_std);
 // Lagrange interpolation on the nodes 1..n of nvec value vectors (nvec x n, standard form) -> nvec x n coefficients
 // (standard form, values < 2r); O(n log^2 n) on a cached subproduct tree.
 void interpolate_dev(Ctx& c, const uint32_t* values_std, size_t n, size_t nvec, uint32_t* coeffs_std);
+// H(x) = (A(x) B(x) - C(x)) / Z(x) straight from the constraint values [A w | B w | C w] (n each, standard form) when the
+// witness satisfies the constraints at the dz = deg Z roots of Z: node extension by one batched convolution, ONE tree
+// interpolation, one Taylor shift.  false (nothing written) when a constraint is violated -- take the px route then.
+bool hx_direct_dev(Ctx& c, const uint32_t* vals_std, size_t n, size_t dz, uint32_t* hx_out_std);
 // CSR sparse matrix (standard-form values) times a Montgomery-form vector -> standard-form vector
 void spmv_dev(Ctx& c, const uint32_t* rowptr, const uint32_t* col, const uint32_t* val_std, const uint32_t* x_mont, size_t nrows, size_t ncols,
               uint32_t* out_std);

@@ -54,6 +54,15 @@ struct PolyState {
   uint64_t tree_clock = 0;
   DevBuf cur_a, cur_b, wide, nxt;                // interpolation workspaces (grow-only: no allocation on the per-proof path)
   DevBuf long_rows;                              // k_spmv -> k_spmv_long hand-off
+  // factorial tables fact[i] = i!, invfact[i] = 1 / i! for i <= fact_top (Montgomery), grown on demand
+  size_t fact_top = 0;
+  DevBuf fact, invfact;
+  // tables of the direct H route (hx_direct_dev), per (n, deg Z)
+  struct HxTables {
+    size_t n = 0, dz = 0, N = 0;
+    DevBuf inv_spec, shift_spec, t1, t2;         // spectra of 1/(t+1) and (-n)^t/t! (size N), value scalings (n each)
+    DevBuf conv, hv, g;                          // workspaces: 3 N, n, n
+  } hx;
 };
 static PolyState& poly_state(Ctx& c) { return c.state<PolyState>(c.poly_state); }
 
@@ -246,24 +255,48 @@ void poly_quotient_dev(Ctx& c, Divisor& d, const uint32_t* a, size_t na, uint32_
 // level (NTT of the zero-padded blocks, 2^(L+1) elements per level -- 1.3 GB at n = 2^20, which is what the HBM is for),
 // the root, and the barycentric weights 1 / M'(j).
 
+// fact / invfact up to `top` (>= 1): two tiled prefix-product scans and ONE field inversion (of top!)
+static void prefix_products(Ctx& c, int mode, uint32_t top, uint32_t count, uint32_t* out, Fe<ModR, 2>* last_host) {
+  const uint32_t ntiles = (count + kPpTile - 1) / kPpTile;
+  DevBuf tiles((size_t)ntiles * 32);
+  hipLaunchKernelGGL(k_pp_tiles, dim3(ntiles), dim3(kPpBlock), 0, c.stream, mode, top, count, out, tiles.as<uint32_t>());
+  if (ntiles > 1) {
+    hipLaunchKernelGGL(k_pp_tile_scan, dim3(1), dim3(1024), 0, c.stream, tiles.as<uint32_t>(), ntiles);
+    hipLaunchKernelGGL(k_pp_apply, grid1(count), dim3(256), 0, c.stream, out, tiles.as<uint32_t>(), count);
+  }
+  GS_HIP(hipGetLastError());
+  if (last_host) {
+    uint32_t w[8];
+    GS_HIP(hipMemcpyAsync(w, out + (size_t)(count - 1) * 8, 32, hipMemcpyDeviceToHost, c.stream));
+    GS_HIP(hipStreamSynchronize(c.stream));
+    *last_host = reduce2(unpack32<ModR>(w));         // stored Montgomery value (< 2r), as is
+  }
+  GS_HIP(hipStreamSynchronize(c.stream));            // `tiles` is released here
+}
+static void ensure_factorials(Ctx& c, size_t top) {
+  PolyState& ps = poly_state(c);
+  if (top <= ps.fact_top) return;
+  top = std::max<size_t>(top, 2 * ps.fact_top);
+  if (top >= (1ull << 31)) throw HipError{hipErrorInvalidValue, "factorial table too large", __LINE__};
+  DevBuf fwd(top * 32), rev(top * 32);
+  Fe<ModR, 2> top_fact;
+  prefix_products(c, 0, (uint32_t)top, (uint32_t)top, fwd.as<uint32_t>(), &top_fact);       // fwd[i] = (i + 1)!
+  prefix_products(c, 1, (uint32_t)top, (uint32_t)top, rev.as<uint32_t>(), nullptr);         // rev[t] = top! / (top - t - 1)!
+  ps.fact.alloc((top + 1) * 32);
+  ps.invfact.alloc((top + 1) * 32);
+  hipLaunchKernelGGL(k_fact_tables, grid1(top + 1), dim3(256), 0, c.stream, fwd.as<uint32_t>(), rev.as<uint32_t>(), to_const(inv(top_fact)), (uint32_t)top,
+                     ps.fact.as<uint32_t>(), ps.invfact.as<uint32_t>());
+  GS_HIP(hipGetLastError());
+  GS_HIP(hipStreamSynchronize(c.stream));
+  ps.fact_top = top;
+}
+
 static void build_weights(Ctx& c, NodeTree& t) {
   // 1 / M'(j) = (-1)^(n-j) / ((j-1)! (n-j)!)        [cf. NewPolZeroAt's divisor, r1csqap.go:130-136, without its int overflow]
-  const size_t n = t.n;
-  std::vector<Fe<ModR, 2>> invf(n);                  // invf[k] = 1 / k!
-  Fe<ModR, 2> f = relax<2>(fe_one<ModR>());
-  for (size_t k = 1; k < n; ++k) f = mul(f, fr_small_mont(k));
-  Fe<ModR, 2> inv_top = inv(f);                      // 1 / (n-1)!
-  for (size_t k = n; k-- > 0;) { invf[k] = inv_top; if (k) inv_top = mul(inv_top, fr_small_mont(k)); }
-  std::vector<uint32_t> w(n * 8);
-  for (size_t j = 1; j <= n; ++j) {
-    Fe<ModR, 2> v = mul(invf[j - 1], invf[n - j]);
-    Fe<ModR, 1> cv = ((n - j) & 1) ? canon(neg(v)) : canon(v);
-    uint32_t words[8];
-    pack32<ModR>(cv, words);
-    memcpy(&w[(j - 1) * 8], words, 32);
-  }
-  t.weights.alloc(std::max<size_t>(n, 1) * 32);
-  GS_HIP(hipMemcpyAsync(t.weights.p, w.data(), n * 32, hipMemcpyHostToDevice, c.stream));
+  ensure_factorials(c, std::max<size_t>(t.n, 1));
+  t.weights.alloc(std::max<size_t>(t.n, 1) * 32);
+  if (t.n) hipLaunchKernelGGL(k_bary_weights, grid1(t.n), dim3(256), 0, c.stream, poly_state(c).invfact.as<uint32_t>(), (uint32_t)t.n, t.weights.as<uint32_t>());
+  GS_HIP(hipGetLastError());
   GS_HIP(hipStreamSynchronize(c.stream));
 }
 
@@ -350,6 +383,72 @@ void interpolate_dev(Ctx& c, const uint32_t* values_std, size_t n, size_t nvec, 
   for (size_t k = 0; k < nvec; ++k)
     GS_HIP(hipMemcpyAsync(coeffs_std + k * n * 8, cur + (k * total + t.pad) * 8, n * 32, hipMemcpyDeviceToDevice, c.stream));
   GS_HIP(hipStreamSynchronize(c.stream));
+}
+
+// H = (A B - C) / Z from the constraint values (vals: [A w | B w | C w], n each, standard form), for a witness that satisfies
+// the constraints at every root of Z (deg Z = dz in {n - 1, n}).  Returns false -- and writes nothing -- when it does not:
+// the caller then takes the exact route (px, then the floor quotient the reference computes, r1csqap.go:70-84).
+// hx_out: nh = 2n - 1 - dz coefficients, canonical standard form.  See poly_kernels.h for the derivation.
+bool hx_direct_dev(Ctx& c, const uint32_t* vals_std, size_t n, size_t dz, uint32_t* hx_out) {
+  if (n < 2 || (dz != n - 1 && dz != n)) return false;
+  PolyState& ps = poly_state(c);
+  PolyState::HxTables& hx = ps.hx;
+  const int logN = ceil_log2(2 * n);
+  const size_t N = (size_t)1 << logN, nh = 2 * n - 1 - dz;
+  Fe<ModR, 1> r2;
+  for (int i = 0; i < NL; ++i) r2.l[i] = ModR::r2(i);
+  const FrConst r2c = to_const(relax<2>(r2));
+  {                                                     // satisfied at the roots of Z?
+    DevBuf bad(4);
+    GS_HIP(hipMemsetAsync(bad.p, 0, 4, c.stream));
+    hipLaunchKernelGGL(k_r1cs_check, grid1(n), dim3(256), 0, c.stream, vals_std, (uint32_t)n, (uint32_t)dz, r2c, bad.as<uint32_t>());
+    uint32_t nbad = 0;
+    GS_HIP(hipMemcpyAsync(&nbad, bad.p, 4, hipMemcpyDeviceToHost, c.stream));
+    GS_HIP(hipStreamSynchronize(c.stream));
+    if (nbad) return false;
+  }
+  NodeTree& t = ensure_tree(c, n, true);
+  const FrConst inv_N = inv_n_const(logN, 0);
+  if (hx.n != n || hx.dz != dz) {                       // tables of this (n, deg Z): once
+    ensure_factorials(c, 2 * n);
+    hx = PolyState::HxTables{};
+    hx.inv_spec.alloc(N * 32); hx.shift_spec.alloc(N * 32); hx.t1.alloc(n * 32); hx.t2.alloc(n * 32);
+    hx.conv.alloc(3 * N * 32); hx.hv.alloc(n * 32); hx.g.alloc(n * 32);
+    hipLaunchKernelGGL(k_hx_tables, grid1(N), dim3(256), 0, c.stream, ps.fact.as<uint32_t>(), ps.invfact.as<uint32_t>(), (uint32_t)n, (uint32_t)dz, (uint32_t)N,
+                       inv_N, r2c, hx.inv_spec.as<uint32_t>(), hx.t1.as<uint32_t>(), hx.t2.as<uint32_t>());
+    // (-n)^t, t < n, in standard form (scale 1), then / t!
+    DevBuf pw(n * 32);
+    uint64_t negn[4], one[4] = {1, 0, 0, 0};
+    {
+      uint64_t nn[4] = {(uint64_t)n, 0, 0, 0};
+      fr_words_from_mont(reduce2(neg(fr_from_words_mont(nn))), negn);
+    }
+    scaled_powers_dev(c, negn, one, n, pw.as<uint32_t>());
+    hipLaunchKernelGGL(k_hx_shift_table, grid1(N), dim3(256), 0, c.stream, ps.invfact.as<uint32_t>(), pw.as<uint32_t>(), (uint32_t)n, (uint32_t)N,
+                       hx.shift_spec.as<uint32_t>());
+    ntt_forward(c, hx.inv_spec.as<uint32_t>(), logN, logN);
+    ntt_forward(c, hx.shift_spec.as<uint32_t>(), logN, logN);
+    GS_HIP(hipGetLastError());
+    GS_HIP(hipStreamSynchronize(c.stream));              // `pw` is released here
+    hx.n = n; hx.dz = dz; hx.N = N;
+  }
+  uint32_t* conv = hx.conv.as<uint32_t>();
+  // values of A, B, C at the nodes n+1 .. 2n: three cyclic convolutions with 1 / (t + 1), batched
+  hipLaunchKernelGGL(k_hx_weigh, grid1(3 * N), dim3(256), 0, c.stream, vals_std, t.weights.as<uint32_t>(), (uint32_t)n, (uint32_t)N, 3u, conv);
+  ntt_forward_n(c, conv, 3 * N, logN);
+  hipLaunchKernelGGL(k_pw_mul_bcast, grid1(3 * N), dim3(256), 0, c.stream, conv, hx.inv_spec.as<uint32_t>(), (uint32_t)N, 3u);
+  ntt_inverse_unscaled_n(c, conv, 3 * N, logN);
+  hipLaunchKernelGGL(k_hx_values, grid1(n), dim3(256), 0, c.stream, conv, hx.t1.as<uint32_t>(), hx.t2.as<uint32_t>(), (uint32_t)n, (uint32_t)N, hx.hv.as<uint32_t>());
+  GS_HIP(hipGetLastError());
+  // G(y) = H(y + n) from its values at y = 1..n, then H(x) = G(x - n)
+  interpolate_dev(c, hx.hv.as<uint32_t>(), n, 1, hx.g.as<uint32_t>());
+  hipLaunchKernelGGL(k_hx_shift_in, grid1(N), dim3(256), 0, c.stream, hx.g.as<uint32_t>(), ps.fact.as<uint32_t>(), (uint32_t)n, (uint32_t)N, conv);
+  ntt_forward(c, conv, logN, logN);
+  hipLaunchKernelGGL(k_pw_mul, grid1(N), dim3(256), 0, c.stream, conv, hx.shift_spec.as<uint32_t>(), conv, (uint32_t)N);
+  ntt_inverse_unscaled(c, conv, logN, logN);
+  hipLaunchKernelGGL(k_hx_shift_out, grid1(nh), dim3(256), 0, c.stream, conv, ps.invfact.as<uint32_t>(), inv_N, (uint32_t)n, (uint32_t)nh, hx_out);
+  GS_HIP(hipGetLastError());
+  return true;
 }
 
 const uint32_t* interpolation_weights_dev(Ctx& c, size_t n) { return ensure_tree(c, n, true).weights.as<uint32_t>(); }

@@ -445,6 +445,173 @@ __global__ void __launch_bounds__(256) k_spmv_long(const uint32_t* __restrict__ 
   }
 }
 
+// ---- H(x) straight from the constraint values (the fast route of gs_groth16_prove_witness) -------------------------
+// CombinePolynomials + DivisorPolynomial (r1csqap.go:191-216) interpolate A, B, C (three O(n log^2 n) tree interpolations),
+// multiply them (size 2n) and divide by Z.  For a SATISFYING witness P = A B - C is an exact multiple of Z, so H = P / Z has
+// only n coefficients and is fixed by n values: H(n + k) = (A(n + k) B(n + k) - C(n + k)) / Z(n + k), k = 1..n.  The values of
+// A at the nodes n+1 .. 2n follow from its values at 1 .. n by ONE cyclic convolution of size 2n, because the nodes are equally
+// spaced:  A(n + k) = M(n + k) * sum_j a_j w_j / (n + k - j)  with the barycentric weights w_j = 1 / M'(j).  Then one
+// interpolation (instead of three) gives G(y) = H(y + n) and a Taylor shift (one more convolution) gives H.
+// All tables below are per (n, deg Z), built once on the device from factorials.
+
+// prefix products of an arithmetic sequence, tile by tile: value(i) = mode 0: i + 1 (-> (i + 1)!),  mode 1: top - i
+constexpr int kPpBlock = 256, kPpPerThread = 8, kPpTile = kPpBlock * kPpPerThread;
+GS_HD Fr2 pp_value(int mode, uint32_t top, uint32_t i) {
+  uint32_t w[8] = {mode == 0 ? i + 1u : top - i, 0, 0, 0, 0, 0, 0, 0};
+  return to_mont(unpack32<ModR>(w));
+}
+__global__ void __launch_bounds__(kPpBlock) k_pp_tiles(int mode, uint32_t top, uint32_t n, uint32_t* __restrict__ out, uint32_t* __restrict__ tile_prod) {
+  __shared__ uint32_t sh[kPpBlock * NL];
+  const uint32_t base = blockIdx.x * kPpTile + threadIdx.x * kPpPerThread;
+  Fr2 v[kPpPerThread];
+  Fr2 run = relax<2>(fe_one<ModR>());
+#pragma unroll
+  for (int j = 0; j < kPpPerThread; ++j) {
+    if (base + j < n) run = mul(run, pp_value(mode, top, base + j));
+    v[j] = run;
+  }
+  for (int l = 0; l < NL; ++l) sh[threadIdx.x * NL + l] = run.l[l];
+  __syncthreads();
+  Fr2 incl = run;
+  for (int off = 1; off < kPpBlock; off <<= 1) {                   // Hillis-Steele inclusive scan of the thread products
+    Fr2 o = relax<2>(fe_one<ModR>());
+    const bool has = threadIdx.x >= (uint32_t)off;
+    if (has) for (int l = 0; l < NL; ++l) o.l[l] = sh[(threadIdx.x - off) * NL + l];
+    __syncthreads();
+    if (has) { incl = mul(incl, o); for (int l = 0; l < NL; ++l) sh[threadIdx.x * NL + l] = incl.l[l]; }
+    __syncthreads();
+  }
+  Fr2 excl = relax<2>(fe_one<ModR>());
+  if (threadIdx.x > 0) for (int l = 0; l < NL; ++l) excl.l[l] = sh[(threadIdx.x - 1) * NL + l];
+#pragma unroll
+  for (int j = 0; j < kPpPerThread; ++j)
+    if (base + j < n) store_fr(out + (size_t)(base + j) * 8, mul(v[j], excl));
+  if (threadIdx.x == kPpBlock - 1) store_fr(tile_prod + (size_t)blockIdx.x * 8, incl);
+}
+// exclusive prefix products of the tile products, in place (one workgroup; ntiles <= 1024 * 64)
+__global__ void __launch_bounds__(1024) k_pp_tile_scan(uint32_t* __restrict__ tile_prod, uint32_t ntiles) {
+  __shared__ uint32_t sh[1024 * NL];
+  const uint32_t per = (ntiles + 1023u) / 1024u, b0 = threadIdx.x * per;
+  Fr2 run = relax<2>(fe_one<ModR>());
+  for (uint32_t j = 0; j < per; ++j) if (b0 + j < ntiles) run = mul(run, load_fr(tile_prod + (size_t)(b0 + j) * 8));
+  for (int l = 0; l < NL; ++l) sh[threadIdx.x * NL + l] = run.l[l];
+  __syncthreads();
+  Fr2 incl = run;
+  for (int off = 1; off < 1024; off <<= 1) {
+    Fr2 o = relax<2>(fe_one<ModR>());
+    const bool has = threadIdx.x >= (uint32_t)off;
+    if (has) for (int l = 0; l < NL; ++l) o.l[l] = sh[(threadIdx.x - off) * NL + l];
+    __syncthreads();
+    if (has) { incl = mul(incl, o); for (int l = 0; l < NL; ++l) sh[threadIdx.x * NL + l] = incl.l[l]; }
+    __syncthreads();
+  }
+  Fr2 excl = relax<2>(fe_one<ModR>());
+  if (threadIdx.x > 0) for (int l = 0; l < NL; ++l) excl.l[l] = sh[(threadIdx.x - 1) * NL + l];
+  for (uint32_t j = 0; j < per; ++j)
+    if (b0 + j < ntiles) {
+      const Fr2 t = mul(excl, load_fr(tile_prod + (size_t)(b0 + j) * 8));
+      store_fr(tile_prod + (size_t)(b0 + j) * 8, excl);
+      excl = t;
+    }
+}
+__global__ void __launch_bounds__(256) k_pp_apply(uint32_t* __restrict__ out, const uint32_t* __restrict__ tile_prefix, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || i < (uint32_t)kPpTile) return;
+  store_fr(out + (size_t)i * 8, mul(load_fr(out + (size_t)i * 8), load_fr(tile_prefix + (size_t)(i / kPpTile) * 8)));
+}
+
+// fact[i] = i!, invfact[i] = 1 / i! for i <= top (Montgomery), from fwd[i] = (i + 1)! and rev[t] = top! / (top - t - 1)!:
+//   invfact[i] = inv_top * (top! / i!) = inv_top * rev[top - i - 1]   (invfact[top] = inv_top)
+__global__ void __launch_bounds__(256) k_fact_tables(const uint32_t* __restrict__ fwd, const uint32_t* __restrict__ rev, FrConst inv_top, uint32_t top,
+                                                      uint32_t* __restrict__ fact, uint32_t* __restrict__ invfact) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > top) return;
+  if (i == 0) store_fr_canon(fact, canon(relax<2>(fe_one<ModR>())));
+  else store_fr_canon(fact + (size_t)i * 8, canon(reduce2(load_fr(fwd + (size_t)(i - 1) * 8))));
+  if (i == top) store_fr_canon(invfact + (size_t)i * 8, canon(from_const(inv_top)));
+  else store_fr_canon(invfact + (size_t)i * 8, canon(mul(from_const(inv_top), load_fr(rev + (size_t)(top - i - 1) * 8))));
+}
+// barycentric weights of the nodes 1..n: w_j = (-1)^(n - j) / ((j - 1)! (n - j)!)        [r1csqap.go:130-136 without its int overflow]
+__global__ void __launch_bounds__(256) k_bary_weights(const uint32_t* __restrict__ invfact, uint32_t n, uint32_t* __restrict__ out) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x + 1;
+  if (j > n) return;
+  const Fr2 v = mul(load_fr(invfact + (size_t)(j - 1) * 8), load_fr(invfact + (size_t)(n - j) * 8));
+  if ((n - j) & 1u) store_fr_canon(out + (size_t)(j - 1) * 8, canon(neg(v)));
+  else store_fr_canon(out + (size_t)(j - 1) * 8, canon(v));
+}
+// the tables of the direct H route, all Montgomery:
+//   inv_seq[t] = 1 / (t + 1), t < 2n - 1 (padded with zeros to N)          the convolution kernel of the node extension
+//   t1[k-1] = R * M(n+k)^2 / (N^2 Z(n+k)),  t2[k-1] = M(n+k) / (N Z(n+k)) = invfact[k-1] fact[n+k-1-dz] / N      (k = 1..n)
+//   shift_q[t] = (-n)^t / t!, t < n (padded to N)                          the Taylor-shift kernel
+__global__ void __launch_bounds__(256) k_hx_tables(const uint32_t* __restrict__ fact, const uint32_t* __restrict__ invfact, uint32_t n, uint32_t dz, uint32_t N,
+                                                    FrConst inv_N, FrConst r2, uint32_t* __restrict__ inv_seq, uint32_t* __restrict__ t1, uint32_t* __restrict__ t2) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  if (i < 2 * n - 1) store_fr_canon(inv_seq + (size_t)i * 8, canon(mul(load_fr(invfact + (size_t)(i + 1) * 8), load_fr(fact + (size_t)i * 8))));
+  else store_fr_canon(inv_seq + (size_t)i * 8, canon(fe_zero<ModR, 2>()));
+  if (i < n) {
+    const uint32_t k = i + 1;
+    const Fr2 b = mul(mul(load_fr(invfact + (size_t)(k - 1) * 8), load_fr(fact + (size_t)(n + k - 1 - dz) * 8)), from_const(inv_N));     // t2
+    const Fr2 mk = mul(load_fr(fact + (size_t)(n + k - 1) * 8), load_fr(invfact + (size_t)(k - 1) * 8));                                   // M(n + k)
+    store_fr_canon(t2 + (size_t)i * 8, canon(b));
+    store_fr_canon(t1 + (size_t)i * 8, canon(mul(mul(mul(b, mk), from_const(inv_N)), from_const(r2))));
+  }
+}
+__global__ void __launch_bounds__(256) k_hx_shift_table(const uint32_t* __restrict__ invfact, const uint32_t* __restrict__ negn_pow, uint32_t n, uint32_t N,
+                                                         uint32_t* __restrict__ shift_q) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  if (i < n) store_fr_canon(shift_q + (size_t)i * 8, canon(mul(to_mont(load_fr(negn_pow + (size_t)i * 8)), load_fr(invfact + (size_t)i * 8))));
+  else store_fr_canon(shift_q + (size_t)i * 8, canon(fe_zero<ModR, 2>()));
+}
+// u[v*N + j] = vals[v*n + j] * w[j] for j < n, 0 up to N (three vectors at once); standard form in, standard out
+__global__ void __launch_bounds__(256) k_hx_weigh(const uint32_t* __restrict__ vals, const uint32_t* __restrict__ weights, uint32_t n, uint32_t N, uint32_t nvec,
+                                                   uint32_t* __restrict__ u) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * nvec) return;
+  const uint32_t v = i / N, j = i - v * N;
+  if (j < n) store_fr(u + (size_t)i * 8, mul(load_fr(vals + ((size_t)v * n + j) * 8), load_fr(weights + (size_t)j * 8)));
+  else store_fr(u + (size_t)i * 8, fe_zero<ModR, 2>());
+}
+// spectra times the cached kernel spectrum, for nvec vectors of N
+__global__ void __launch_bounds__(256) k_pw_mul_bcast(uint32_t* __restrict__ x, const uint32_t* __restrict__ spec, uint32_t N, uint32_t nvec) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * nvec) return;
+  store_fr(x + (size_t)i * 8, mul(load_fr(x + (size_t)i * 8), load_fr(spec + (size_t)(i % N) * 8)));
+}
+// hv[k-1] = convA convB t1 - convC t2 at the nodes n + k (conv_X = x[X * N + n + k - 2], the middle of the cyclic convolutions)
+__global__ void __launch_bounds__(256) k_hx_values(const uint32_t* __restrict__ conv, const uint32_t* __restrict__ t1, const uint32_t* __restrict__ t2, uint32_t n,
+                                                    uint32_t N, uint32_t* __restrict__ hv) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const size_t at = (size_t)(n - 1 + i);
+  const Fr2 ab = mul(load_fr(conv + at * 8), load_fr(conv + ((size_t)N + at) * 8));
+  const Fr2 x = mul(ab, load_fr(t1 + (size_t)i * 8));
+  const Fr2 y = mul(load_fr(conv + ((size_t)2 * N + at) * 8), load_fr(t2 + (size_t)i * 8));
+  store_fr(hv + (size_t)i * 8, reduce2(sub(x, y)));
+}
+// a_j b_j == c_j at every root j of Z (j = 1..dz)?  bad[0] counts the violations
+__global__ void __launch_bounds__(256) k_r1cs_check(const uint32_t* __restrict__ vals, uint32_t n, uint32_t dz, const FrConst r2, uint32_t* __restrict__ bad) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= dz || j >= n) return;
+  const Fr2 ab = mul(mul(load_fr(vals + (size_t)j * 8), load_fr(vals + ((size_t)n + j) * 8)), from_const(r2));      // standard a b
+  if (!is_zero(sub(ab, load_fr(vals + ((size_t)2 * n + j) * 8)))) atomicAdd(bad, 1u);
+}
+// Taylor shift, step 1: p[i'] = g[n-1-i'] (n-1-i')! for i' < n, zero padded to N
+__global__ void __launch_bounds__(256) k_hx_shift_in(const uint32_t* __restrict__ g, const uint32_t* __restrict__ fact, uint32_t n, uint32_t N, uint32_t* __restrict__ p) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  if (i < n) store_fr(p + (size_t)i * 8, mul(load_fr(g + (size_t)(n - 1 - i) * 8), load_fr(fact + (size_t)(n - 1 - i) * 8)));
+  else store_fr(p + (size_t)i * 8, fe_zero<ModR, 2>());
+}
+// step 2: h[j] = conv[n-1-j] / (j! N), canonical standard form
+__global__ void __launch_bounds__(256) k_hx_shift_out(const uint32_t* __restrict__ conv, const uint32_t* __restrict__ invfact, FrConst inv_N, uint32_t n, uint32_t nh,
+                                                       uint32_t* __restrict__ h) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= nh) return;
+  store_fr_canon(h + (size_t)j * 8, canon(mul(mul(load_fr(conv + (size_t)(n - 1 - j) * 8), load_fr(invfact + (size_t)j * 8)), from_const(inv_N))));
+}
+
 // ---- trusted setup helpers (groth16.go:94-222 on a sparse R1CS) ---------------------------------------------------
 // Lagrange basis at tau over the nodes 1..n:  L_j(tau) = M(tau) * w_j / (tau - j),  w_j = 1 / M'(j)   (Montgomery out)
 __global__ void __launch_bounds__(256) k_lagrange_at(const uint32_t* __restrict__ weights, uint32_t n, FrConst tau, FrConst mtau,

@@ -30,6 +30,8 @@ struct DevScalars {            // a scalar vector used by a prove call (not owne
                                     // that consumes it (so the PCIe copy of px overlaps the accumulations over w)
   std::function<void(Ctx&)> produce;   // if set: `p` is an output buffer this call still has to compute, on the stream that
                                        // consumes it (px from the resident R1CS, behind the accumulations over w)
+  std::function<bool(Ctx&, uint32_t*)> produce_hx;   // if set: try to compute hx = px / Z directly (poly.h: hx_direct_dev) into the given
+                                                     // buffer; false = not applicable, fall back to produce + quotient
 };
 
 // Per-context staging of the prover entry points (device memory belongs to one device).
@@ -159,8 +161,12 @@ int groth16_enqueue(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, const S
       c.timing.h2d_ms += th.ms();
     }
     st.tpoly = std::make_shared<PhaseTimer>(c.stream);
-    if (px.produce) px.produce(c);                                             // r1csqap.go:161-210 on the sparse system
-    if (nh) poly_quotient_dev(c, pk->z, px.p, px.n, hxbuf.as<uint32_t>());      // groth16.go:266
+    bool have_hx = false;
+    if (px.produce_hx && nh) have_hx = px.produce_hx(c, hxbuf.as<uint32_t>());  // H from the constraint values (satisfying witness)
+    if (!have_hx) {
+      if (px.produce) px.produce(c);                                           // r1csqap.go:161-210 on the sparse system
+      if (nh) poly_quotient_dev(c, pk->z, px.p, px.n, hxbuf.as<uint32_t>());    // groth16.go:266
+    }
     st.tpoly->stop();
     st.tplanh = std::make_shared<PhaseTimer>(c.stream);
     build_plan(c, 1 + 2 * parity, hxbuf.as<uint32_t>() + hlo * 8, (uint32_t)(hhi - hlo), plan_h, {{1, false}});
@@ -888,15 +894,23 @@ static int r1cs_upload_impl(Ctx& c, size_t n, size_t m, const uint32_t* const rp
   return GS_OK;
 }
 
-// w (standard form, m elements, device) -> o.coef = [ax | bx | cx] (n each) and px_out (2n - 1), canonical standard form
-static void r1cs_px_dev(Ctx& c, R1csObj& o, const uint32_t* w_dev, uint32_t* px_out) {
-  const size_t n = o.n, m = o.m, npx = 2 * n - 1;
-  o.w_mont.ensure(m * 32); o.vals.ensure(3 * n * 32); o.coef.ensure(3 * n * 32); o.prod.ensure(npx * 32);
+// w (standard form, m elements, device) -> o.vals = [A w | B w | C w] (n each, standard form): the values of ax, bx, cx at the
+// nodes 1..n (CombinePolynomials' sum_i w_i alpha_i(x) evaluated there, r1csqap.go:191-210)
+static void r1cs_values_dev(Ctx& c, R1csObj& o, const uint32_t* w_dev) {
+  const size_t n = o.n, m = o.m;
+  o.w_mont.ensure(m * 32); o.vals.ensure(3 * n * 32);
   GS_HIP(hipMemcpyAsync(o.w_mont.p, w_dev, m * 32, hipMemcpyDeviceToDevice, c.stream));
   poly_canon_dev(c, o.w_mont.as<uint32_t>(), m, 1);                                         // w -> Montgomery
   for (int k = 0; k < 3; ++k)
     spmv_dev(c, o.rowptr[k].as<uint32_t>(), o.col[k].as<uint32_t>(), o.val[k].as<uint32_t>(), o.w_mont.as<uint32_t>(), n, m,
              o.vals.as<uint32_t>() + k * n * 8);
+}
+
+// w -> o.coef = [ax | bx | cx] (n each) and px_out (2n - 1), canonical standard form
+static void r1cs_px_dev(Ctx& c, R1csObj& o, const uint32_t* w_dev, uint32_t* px_out) {
+  const size_t n = o.n, npx = 2 * n - 1;
+  r1cs_values_dev(c, o, w_dev);
+  o.coef.ensure(3 * n * 32); o.prod.ensure(npx * 32);
   interpolate_dev(c, o.vals.as<uint32_t>(), n, 3, o.coef.as<uint32_t>());
   uint32_t* A = o.coef.as<uint32_t>();
   uint32_t* B = A + n * 8;
@@ -1014,6 +1028,34 @@ int gs_groth16_prove_r1cs(gs_handle hpk, gs_handle hr1cs, gs_handle hw, gs_handl
     DevScalars dp{px->buf.as<uint32_t>(), npx};
     const uint32_t* wdev = w->buf.as<uint32_t>();
     uint32_t* pxdev = px->buf.as<uint32_t>();
+    dp.produce = [o, wdev, pxdev](Ctx& cc) { r1cs_px_dev(cc, *o, wdev, pxdev); };
+    return groth16_prove_impl(c, pk, DevScalars{wdev, w->n}, dp, r, s, out_proof, inf);
+  }, true, false, hpk);
+}
+
+// Witness -> proof without ever forming px: H(x) comes straight from the constraint values [A w | B w | C w] (one batched
+// convolution, ONE interpolation, one Taylor shift: poly.h, hx_direct_dev) instead of three interpolations, a size-2n product
+// and a division (CombinePolynomials + DivisorPolynomial, r1csqap.go:191-216).  Requires what a proof requires anyway -- a witness
+// that satisfies the R1CS; when a constraint is violated the call takes the exact route of gs_groth16_prove_r1cs and returns the
+// same (meaningless) proof the reference would.  Same result as gs_r1cs_px + gs_groth16_prove_resident.
+int gs_groth16_prove_witness(gs_handle hpk, gs_handle hr1cs, gs_handle hw, const uint64_t r[4], const uint64_t s[4], uint64_t out_proof[32], int inf[3]) {
+  return guarded([&](Ctx& c) -> int {
+    GrothPkObj* pk = c.get<GrothPkObj>(hpk, Kind::GrothPk);
+    R1csObj* o = c.get<R1csObj>(hr1cs, Kind::R1cs);
+    Scalars* w = c.get<Scalars>(hw, Kind::Scalars);
+    if (!pk || !o || !w) return fail(GS_ERR_ARG, "gs_groth16_prove_witness: bad handle");
+    if (!r || !s || !out_proof || !inf) return fail(GS_ERR_ARG, "null argument");
+    if (w->n != o->m) return fail(GS_ERR_SHAPE, "len(w) = %zu but the system has %zu variables", w->n, o->m);
+    const size_t npx = 2 * o->n - 1;
+    reset_timing(c);
+    o->prod.ensure(npx * 32);                                     // px, only written on the fallback route
+    const uint32_t* wdev = w->buf.as<uint32_t>();
+    DevBuf& pxbuf = prove_state(c).up_px;
+    pxbuf.ensure(npx * 32);
+    uint32_t* pxdev = pxbuf.as<uint32_t>();
+    DevScalars dp{pxdev, npx};
+    const size_t dz = pk->nz - 1;
+    dp.produce_hx = [o, wdev, dz](Ctx& cc, uint32_t* hx) { r1cs_values_dev(cc, *o, wdev); return hx_direct_dev(cc, o->vals.as<uint32_t>(), o->n, dz, hx); };
     dp.produce = [o, wdev, pxdev](Ctx& cc) { r1cs_px_dev(cc, *o, wdev, pxdev); };
     return groth16_prove_impl(c, pk, DevScalars{wdev, w->n}, dp, r, s, out_proof, inf);
   }, true, false, hpk);

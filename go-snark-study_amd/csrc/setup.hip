@@ -98,6 +98,10 @@ int gs_groth16_setup(size_t n, size_t m, size_t npublic,
     if (n >= (1ull << 26) || m >= (1ull << 26)) return fail(GS_ERR_ARG, "gs_groth16_setup: system too large");
     // the prover indexes PowersTauDelta[i] for i < len(hx) = 2n - 1 - (m - 1) + 1 (groth16.go:269-271): m in {n+1, n+2}
     if (2 * n + 1 < m || 2 * n - m + 1 > m - 1) return fail(GS_ERR_SHAPE, "gs_groth16_setup: len(hx) = 2n - m + 1 would exceed len(PowersTauDelta) = m - 1 (SURVEY fact 8)");
+    // Z(x) = prod_{k=1}^{m-2} (x - k) (groth16.go:122-131): for m > n + 2 it has roots at nodes beyond the n constraints, where
+    // A B - C does not vanish -- no witness could ever produce a verifying proof with such a key.  (m = n + 1 leaves constraint n
+    // outside Z: the reference's own gap, kept for parity and stated in DESIGN.md.)
+    if (m > n + 2) return fail(GS_ERR_SHAPE, "gs_groth16_setup: m = %zu variables for n = %zu constraints: Z would have %zu roots, more than there are constraints (need m <= n + 2)", m, n, m - 2);
     const uint64_t* T = toxic;
     const uint64_t* Kalpha = toxic + 4;
     const uint64_t* Kbeta = toxic + 8;
@@ -184,6 +188,7 @@ int gs_pinocchio_setup(size_t n, size_t m, size_t npublic,
     if (n == 0 || m < 2 || npublic + 1 > m) return fail(GS_ERR_SHAPE, "gs_pinocchio_setup: need n >= 1, m >= 2, NPublic + 1 <= m");
     if (n >= (1ull << 26) || m >= (1ull << 26)) return fail(GS_ERR_ARG, "gs_pinocchio_setup: system too large");
     if (m < n + 1 || m > 2 * n + 1) return fail(GS_ERR_SHAPE, "gs_pinocchio_setup: need n + 1 <= m <= 2n + 1 (len(hx) must fit len(G1T), snark.go:284-286)");
+    if (m > n + 2) return fail(GS_ERR_SHAPE, "gs_pinocchio_setup: m = %zu variables for n = %zu constraints: Z would have %zu roots, more than there are constraints (need m <= n + 2)", m, n, m - 2);
     const uint64_t *T = toxic, *Ka = toxic + 4, *Kb = toxic + 8, *Kc = toxic + 12, *Kbeta = toxic + 16, *Kgamma = toxic + 20, *RhoA = toxic + 24,
                    *RhoB = toxic + 28;
     HostCsc ca, cb, cc;

@@ -1,6 +1,8 @@
 // Verifier entry points: groth16.VerifyProof (groth16/groth16.go:281-305), snark.VerifyProof
 // (snark.go:292-368) and the pairing seam under them (bn128/bn128.go:179-186), on the host.  They do not touch the
 // device context and do not take its lock: a verifier thread can run beside in-flight proofs.
+#include <atomic>
+
 #include "pairing.h"
 #include "runtime.h"
 
@@ -10,6 +12,22 @@ using namespace gs::pairing;
 namespace {
 
 struct ShapeError { const char* msg; };
+
+// gs_verify_set_strict: 0 (default) = the reference's big.Int behaviour, 1 = canonical encodings only
+std::atomic<int> g_strict{0};
+const uint64_t kRorder[4] = {0x43e1f593f0000001ULL, 0x2833e84879b97091ULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL};   // bn128.go:46 (R)
+
+// every coordinate < q ?  (words: count of 4-limb field elements)
+bool coords_canonical(const uint64_t* w, size_t count) {
+  for (size_t i = 0; i < count; ++i)
+    if (limbs_geq(w + 4 * i, kP)) return false;
+  return true;
+}
+bool scalars_canonical(const uint64_t* w, size_t count) {
+  for (size_t i = 0; i < count; ++i)
+    if (limbs_geq(w + 4 * i, kRorder)) return false;
+  return true;
+}
 
 // prod e(P_i, Q_i) == 1 with one shared final exponentiation.  Off-curve inputs and G2 inputs that hit a vertical
 // line inside the loop (not of order r) make the check fail instead of producing a meaningless value.
@@ -94,6 +112,11 @@ int gs_pairing_check(const uint64_t* g1, const uint64_t* g2, size_t k, int* ok) 
   });
 }
 
+int gs_verify_set_strict(int on) {
+  g_strict.store(on ? 1 : 0);
+  return GS_OK;
+}
+
 int gs_groth16_verify(const uint64_t vk_g1_alpha[12], const uint64_t vk_g2_beta[24], const uint64_t vk_g2_gamma[24],
                       const uint64_t vk_g2_delta[24], const uint64_t* vk_ic, size_t nic, const uint64_t* public_signals,
                       size_t npublic, const uint64_t pi_a[12], const uint64_t pi_b[24], const uint64_t pi_c[12], int* ok) {
@@ -102,6 +125,15 @@ int gs_groth16_verify(const uint64_t vk_g1_alpha[12], const uint64_t vk_g2_beta[
       return fail(GS_ERR_ARG, "gs_groth16_verify: null argument");
     // the reference indexes vk.IC[i+1] for every public signal and panics past the end (groth16.go:285)
     if (nic < npublic + 1) return fail(GS_ERR_SHAPE, "gs_groth16_verify: %zu public signals need %zu IC points, vk has %zu", npublic, npublic + 1, nic);
+    if (g_strict.load()) {
+      // strict: exactly one signal per IC point (a short list would silently verify the statement "the missing inputs are 0"),
+      // and canonical encodings only (x and x + r, X and X + q name the same element: accepting both makes proofs malleable)
+      if (nic != npublic + 1) return fail(GS_ERR_SHAPE, "gs_groth16_verify (strict): vk has %zu IC points, so exactly %zu public signals are required (got %zu)", nic, nic - 1, npublic);
+      if (!scalars_canonical(public_signals, npublic) || !coords_canonical(pi_a, 3) || !coords_canonical(pi_b, 6) || !coords_canonical(pi_c, 3)) {
+        *ok = 0;
+        return GS_OK;
+      }
+    }
     G1Aff ic = g1j_affine(accumulate_ic(vk_ic, nic, public_signals, npublic));
     // e(A, B) == e(alpha, beta) e(IC, gamma) e(C, delta)   <=>   e(-A, B) e(alpha, beta) e(IC, gamma) e(C, delta) == 1
     std::vector<G1Aff> ps{g1_neg(g1_from_jacobian_std(pi_a)), g1_from_jacobian_std(vk_g1_alpha), ic, g1_from_jacobian_std(pi_c)};
@@ -119,6 +151,14 @@ int gs_pinocchio_verify(const uint64_t vka[24], const uint64_t vkb[12], const ui
     if (!vka || !vkb || !vkc || !g1kbg || !g2kbg || !g2kg || !vkz || !vk_ic || !proof || !ok || (npublic && !public_signals))
       return fail(GS_ERR_ARG, "gs_pinocchio_verify: null argument");
     if (nic < npublic + 1) return fail(GS_ERR_SHAPE, "gs_pinocchio_verify: %zu public signals need %zu IC points, vk has %zu", npublic, npublic + 1, nic);
+    if (g_strict.load()) {
+      if (nic != npublic + 1) return fail(GS_ERR_SHAPE, "gs_pinocchio_verify (strict): vk has %zu IC points, so exactly %zu public signals are required (got %zu)", nic, nic - 1, npublic);
+      if (!scalars_canonical(public_signals, npublic) || !coords_canonical(proof, 27)) {
+        *ok = 0;
+        if (failed_check) *failed_check = 0;
+        return GS_OK;
+      }
+    }
     // proof layout: PiA, PiAp (G1) | PiB (G2) | PiBp, PiC, PiCp, PiH, PiKp (G1)  -- snark.go:59-69
     const G1Aff piA = g1_from_jacobian_std(proof), piAp = g1_from_jacobian_std(proof + 12);
     const G2Aff piB = g2_from_jacobian_std(proof + 24);

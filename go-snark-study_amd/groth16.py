@@ -245,6 +245,17 @@ def prove_from_r1cs(dev_pk, dev_r1cs, w_handle, r, s, px_handle=None):
     return _proof_from_words(out, inf), (px_handle if px_handle is not None else capi.DeviceHandle(h.value))
 
 
+def prove_from_witness(dev_pk, dev_r1cs, w_handle, r, s):
+    """Sparse R1CS + resident witness -> proof, H(x) straight from the constraint values (gs_groth16_prove_witness): no px."""
+    import ctypes
+    rs = capi.ints_to_u64([r % R, s % R])
+    out = np.zeros(32, dtype=np.uint64)
+    inf = (ctypes.c_int * 3)()
+    capi.check(capi.load_library().gs_groth16_prove_witness(capi.Handle(dev_pk.handle.h), capi.Handle(dev_r1cs.handle.h), capi.Handle(w_handle.h),
+                                                            capi.ptr64(rs[0]), capi.ptr64(rs[1]), capi.ptr64(out), inf))
+    return _proof_from_words(out, inf)
+
+
 def prove_partials(dev_pk, w_handle, px_handle, shard_index, shard_count):
     """This rank's five raw MSM sums (gs_groth16_prove_partials): [At, G1.BACGamma, G2.BACGamma, BACDelta, h.PTD] as affine
     points / None, plus the g2 flags parallel.allgather_points wants."""

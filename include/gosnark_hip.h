@@ -202,6 +202,14 @@ int gs_groth16_prove_resident(gs_handle pk, gs_handle w, gs_handle px,
 int gs_groth16_prove_r1cs(gs_handle pk, gs_handle r1cs, gs_handle w, gs_handle* px_inout, const uint64_t r[4], const uint64_t s[4],
                           uint64_t out_proof[32], int inf[3]);
 
+/* Witness -> proof WITHOUT px: H(x) = (A(x) B(x) - C(x)) / Z(x) is computed straight from the constraint values A w, B w, C w
+ * (their values at the nodes n+1..2n by one batched convolution, ONE interpolation instead of three, a Taylor shift; no size-2n
+ * product, no division) -- the fast form of CombinePolynomials + DivisorPolynomial (r1csqap.go:191-216) for a witness that
+ * satisfies the R1CS, which is the only case in which a proof means anything.  If a constraint is violated the call falls back to
+ * the exact route and returns what gs_groth16_prove_r1cs returns.  Same proof as gs_r1cs_px + gs_groth16_prove_resident. */
+int gs_groth16_prove_witness(gs_handle pk, gs_handle r1cs, gs_handle w, const uint64_t r[4], const uint64_t s[4],
+                             uint64_t out_proof[32], int inf[3]);
+
 /* Pipelined proving (inputs resident): gs_groth16_prove_begin enqueues the whole device side of one proof and returns a
  * ticket without waiting; gs_groth16_prove_end waits for THAT proof only, then runs the host tail and writes the proof
  * (same layout as gs_groth16_prove).  At most three tickets (proofs or MSMs) may be outstanding per logical device (a fourth begin returns
@@ -372,6 +380,13 @@ int gs_pairing(const uint64_t g1[12], const uint64_t g2[24], uint64_t out_fq12[4
  * value and compare it).  gs_groth16_verify / gs_pinocchio_verify apply the subgroup check to the prover's G2 element
  * (PiB); the G2 elements of the verification key are key material, validated by whoever installs the key. */
 int gs_pairing_check(const uint64_t* g1 /* k x 12 */, const uint64_t* g2 /* k x 24 */, size_t k, int* ok);
+/* Input strictness of the two verifiers (process-wide).  0 (default) answers exactly like the reference's big.Int code: a
+ * coordinate X and X + q, a public signal x and x + r name the same element, and fewer public signals than the vk has IC
+ * points verify the statement with the missing inputs taken as 0 (groth16.go:283-286 loops over publicSignals only).  1 = strict:
+ * coordinates must be < q and public signals < r (otherwise *ok = 0: no proof / input aliasing), and npublic must equal
+ * nic - 1 (otherwise GS_ERR_SHAPE).  Deployments that accept proofs from untrusted parties should switch it on. */
+int gs_verify_set_strict(int on);
+
 /* groth16.VerifyProof(vk, proof, publicSignals, debug) (groth16/groth16.go:281-305):
  *   icPubl = IC[0] + sum_i publicSignals[i] * IC[i+1];   e(PiA, PiB) == e(Alpha, Beta) e(icPubl, Gamma) e(PiC, Delta)
  * as one 4-pair product check.  *ok = 1 accept / 0 reject.  GS_ERR_SHAPE when nic < npublic + 1 (the reference panics

@@ -148,3 +148,26 @@ def poly_eval(v, x):
     out = np.zeros(4, dtype=np.uint64)
     lib().oracle_poly_eval(_p(_u64(v)), ctypes.c_size_t(len(v)), _p(_u64([x])), _p(out))
     return _ints(out)[0]
+
+
+def mul_scalar_batch(base_jac, scalars_u64, g2=False, threads=1):
+    """[MulScalar(base, k_i)] as an [n, 12] / [n, 24] Jacobian limb array (the setup's encryption loops, multi-threaded)."""
+    sc = np.ascontiguousarray(scalars_u64, dtype=np.uint64)
+    n = sc.size // 4
+    b = _u64([c for xy in base_jac for c in xy]) if g2 else _u64(base_jac)
+    out = np.zeros((n, 24 if g2 else 12), dtype=np.uint64)
+    lib().oracle_mul_scalar_batch_mt(_p(b), _p(sc), ctypes.c_size_t(n), 1 if g2 else 0, int(threads), _p(out))
+    return out
+
+
+def poly_u64(coeffs):
+    """list of ints -> [n, 4] limb array"""
+    return _u64(coeffs).reshape(-1, 4)
+
+
+def poly_mul_u64(a_u64, b_u64):
+    a = np.ascontiguousarray(a_u64, dtype=np.uint64).reshape(-1, 4)
+    b = np.ascontiguousarray(b_u64, dtype=np.uint64).reshape(-1, 4)
+    out = np.zeros((a.shape[0] + b.shape[0] - 1, 4), dtype=np.uint64)
+    lib().oracle_poly_mul(_p(a), ctypes.c_size_t(a.shape[0]), _p(b), ctypes.c_size_t(b.shape[0]), _p(out))
+    return out

@@ -1,0 +1,129 @@
+#!/usr/bin/env python3
+"""ORACLE TOOLING (test infrastructure, not product code).
+
+BASELINE configs[1] as worded -- "2^16 G1 Pippenger MSM, bit-exact vs the bn128.G1 loop" -- and a 2^16-constraint Groth16
+proof: golden AFFINE outputs computed offline by the C restatement of the reference's naive loops (oracle/gs_oracle.c:
+MulScalar = MSB-first double-and-add, Add = add-2007-bl, Div = schoolbook) on all host cores, on the same seeded inputs
+the GPU tests rebuild (gosnark_amd.synth).  Takes ~10 minutes on 8 cores; run in the build container:
+
+    python3 oracle/gen_golden_large.py [msm|prove|all]
+
+Writes tests/golden/oracle_msm_g1_2p16.json and tests/golden/oracle_groth_2p16.json.
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+from oracle import c_oracle as C, ref_py as O  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+THREADS = os.cpu_count() or 1
+_R_LIMBS = [(O.R >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)]
+
+
+def scalars_u64(n, seed):
+    """Bit-identical to gosnark_amd.synth.scalars_u64 (kept separate: the oracle must not import the product package)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    out = np.zeros((n, 4), dtype=np.uint64)
+    todo = np.arange(n)
+    while todo.size:
+        cand = rng.integers(0, 2**64, size=(todo.size, 4), dtype=np.uint64)
+        cand[:, 3] &= np.uint64(0x3FFFFFFFFFFFFFFF)
+        lt = np.zeros(todo.size, dtype=bool)
+        eq = np.ones(todo.size, dtype=bool)
+        for i in (3, 2, 1, 0):
+            lt |= eq & (cand[:, i] < np.uint64(_R_LIMBS[i]))
+            eq &= cand[:, i] == np.uint64(_R_LIMBS[i])
+        out[todo[lt]] = cand[lt]
+        todo = todo[~lt]
+    return out
+
+
+def ints(a):
+    raw = np.ascontiguousarray(a, dtype="<u8").tobytes()
+    return [int.from_bytes(raw[i:i + 32], "little") for i in range(0, len(raw), 32)]
+
+
+def msm_golden(logn=16, seed=0x60D0):
+    n = 1 << logn
+    t0 = time.time()
+    bases = C.mul_scalar_batch(O.G1_GEN, scalars_u64(n, seed), threads=THREADS)           # P_i = k_i * G
+    sc = scalars_u64(n, seed + 1)
+    got = C.g1_affine(C.g1_msm_naive(bases, sc, threads=THREADS))                           # sum_i MulScalar(P_i, s_i)
+    rec = {"what": "sum_i s_i * (k_i * G1) by the naive MulScalar / Add loop (bn128/g1.go:140-155, :32-89), affine",
+           "n": n, "seed_bases": seed, "seed_scalars": seed + 1, "x": str(got[0]), "y": str(got[1]),
+           "generator": "oracle/gen_golden_large.py msm (oracle/gs_oracle.c, %d threads, %.1f s)" % (THREADS, time.time() - t0)}
+    with open(os.path.join(OUT, "oracle_msm_g1_2p%d.json" % logn), "w") as f:
+        json.dump(rec, f, indent=1)
+    print(rec)
+
+
+def zpoly(deg):
+    """prod_{i=1}^{deg} (x - i) over Fr by a product tree of schoolbook products (r1csqap.go:57-67 / groth16.go:122-131)."""
+    polys = [C.poly_u64([(-i) % O.R, 1]) for i in range(1, deg + 1)]
+    while len(polys) > 1:
+        nxt = [C.poly_mul_u64(polys[i], polys[i + 1]) if i + 1 < len(polys) else polys[i] for i in range(0, len(polys), 2)]
+        polys = nxt
+    return polys[0]
+
+
+def prove_golden(logn=16, seed=0x60D1):
+    """The instance gosnark_amd.synth.RandomInstance(n, seed) defines (key points k_i * G, uniform w and px)."""
+    n = 1 << logn
+    m = n + 1
+    t0 = time.time()
+    fb1 = lambda cnt, sd: C.mul_scalar_batch(O.G1_GEN, scalars_u64(cnt, sd), threads=THREADS)      # noqa: E731
+    at, bacgamma, bacdelta, ptd = fb1(m, seed + 1), fb1(m, seed + 2), fb1(m, seed + 3), fb1(n, seed + 4)
+    bacgamma2 = C.mul_scalar_batch(O.G2_GEN, scalars_u64(m, seed + 5), g2=True, threads=THREADS)
+    s1 = fb1(3, seed + 6)
+    s2 = C.mul_scalar_batch(O.G2_GEN, scalars_u64(2, seed + 7), g2=True, threads=1)
+    alpha, beta, delta = (tuple(ints(s1[i])) for i in range(3))
+    g2pt = lambda row: (lambda v: ((v[0], v[1]), (v[2], v[3]), (v[4], v[5])))(ints(row))              # noqa: E731
+    beta2, delta2 = g2pt(s2[0]), g2pt(s2[1])
+    w = scalars_u64(m, seed + 8)
+    w[0] = (1, 0, 0, 0)
+    px = scalars_u64(2 * n - 1, seed + 9)
+    print("key rebuilt on the CPU in %.0f s" % (time.time() - t0), flush=True)
+    z = zpoly(m - 2)
+    print("Z built, %.0f s" % (time.time() - t0), flush=True)
+    hx, _ = C.poly_div_u64(px, z)                                                          # groth16.go:266 (quotient only)
+    print("hx = px / Z done, %.0f s" % (time.time() - t0), flush=True)
+    r, s = (int(x) % O.R for x in ints(scalars_u64(2, seed + 10)))
+    G1, G2 = O.G1, O.G2
+    # groth16.go:243-275, MSMs by the naive loop on all cores
+    piA = C.g1_msm_naive(at, w, threads=THREADS)
+    piB1 = C.g1_msm_naive(bacgamma, w, threads=THREADS)
+    piB = C.g2_msm_naive(bacgamma2, w, threads=THREADS)
+    piC = C.g1_msm_naive(bacdelta[2:], w[2:], threads=THREADS)                              # i > NPublic = 1
+    hsum = C.g1_msm_naive(ptd[:hx.shape[0]], hx, threads=THREADS)
+    print("MSMs done, %.0f s" % (time.time() - t0), flush=True)
+    piA = G1.Add(G1.Add(piA, alpha), G1.MulScalar(delta, r))
+    piB = G2.Add(G2.Add(piB, beta2), G2.MulScalar(delta2, s))
+    piB1 = G1.Add(G1.Add(piB1, beta), G1.MulScalar(delta, s))
+    piC = G1.Add(piC, hsum)
+    piC = G1.Add(piC, G1.MulScalar(piA, s))
+    piC = G1.Add(piC, G1.MulScalar(piB1, r))
+    piC = G1.Add(piC, G1.Neg(G1.MulScalar(delta, r * s % O.R)))
+    a, b, c = G1.Affine(piA), G2.Affine(piB), G1.Affine(piC)
+    rec = {"what": "groth16.GenerateProofs (groth16.go:225-278) on gosnark_amd.synth.RandomInstance(n, seed), r and s from "
+                   "scalars_u64(2, seed + 10); MSMs by the naive loops, hx by schoolbook Div; affine",
+           "n": n, "seed": seed, "r": str(r), "s": str(s),
+           "PiA": [str(a[0]), str(a[1])], "PiB": [[str(b[0][0]), str(b[0][1])], [str(b[1][0]), str(b[1][1])]], "PiC": [str(c[0]), str(c[1])],
+           "generator": "oracle/gen_golden_large.py prove (oracle/gs_oracle.c + oracle/ref_py.py tail, %d threads, %.0f s)" % (THREADS, time.time() - t0)}
+    with open(os.path.join(OUT, "oracle_groth_2p%d.json" % logn), "w") as f:
+        json.dump(rec, f, indent=1)
+    print(rec)
+
+
+if __name__ == "__main__":
+    what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if what in ("msm", "all"):
+        msm_golden()
+    if what in ("prove", "all"):
+        prove_golden()

@@ -234,6 +234,31 @@ void oracle_msm_naive_mt(const uint64_t* pts, const uint64_t* scalars, size_t n,
   free(jobs); free(th);
 }
 
+/* out[i] = MulScalar(base, k_i): the encryption loops of the trusted setups (groth16.go:139-175, snark.go:152-230) over nthreads
+ * slices; used by oracle/gen_golden_large.py to rebuild on the CPU the key points the synthetic instances define as k_i * G. */
+typedef struct { const uint64_t* base; const uint64_t* sc; size_t n; int g2; uint64_t* out; } fb_job;
+static void* fb_run(void* arg) {
+  fb_job* j = (fb_job*)arg;
+  for (size_t i = 0; i < j->n; ++i) {
+    if (j->g2) oracle_g2_mul_scalar(j->base, j->sc + 4 * i, j->out + 24 * i);
+    else oracle_g1_mul_scalar(j->base, j->sc + 4 * i, j->out + 12 * i);
+  }
+  return NULL;
+}
+void oracle_mul_scalar_batch_mt(const uint64_t* base, const uint64_t* scalars, size_t n, int g2, int nthreads, uint64_t* out) {
+  if (nthreads < 1) nthreads = 1;
+  fb_job* jobs = (fb_job*)calloc((size_t)nthreads, sizeof(fb_job));
+  pthread_t* th = (pthread_t*)calloc((size_t)nthreads, sizeof(pthread_t));
+  const size_t pw = g2 ? 24 : 12;
+  for (int t = 0; t < nthreads; ++t) {
+    size_t b = n * (size_t)t / (size_t)nthreads, e = n * (size_t)(t + 1) / (size_t)nthreads;
+    jobs[t].base = base; jobs[t].sc = scalars + 4 * b; jobs[t].n = e - b; jobs[t].g2 = g2; jobs[t].out = out + pw * b;
+    pthread_create(&th[t], NULL, fb_run, &jobs[t]);
+  }
+  for (int t = 0; t < nthreads; ++t) pthread_join(th[t], NULL);
+  free(jobs); free(th);
+}
+
 /* affine normal form (g1.go:157-170 / g2.go:183-200); returns 1 for infinity */
 int oracle_g1_affine(const uint64_t jac[12], uint64_t out[8]) {
   g1_pt p; g1_load(&p, jac); memset(out, 0, 64);

@@ -351,3 +351,31 @@ int main(void) {
                            "-L", libdir, "-lgosnark_hip", "-Wl,-rpath," + libdir])
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and out.stdout.startswith("OK"), out.stdout + out.stderr
+
+
+def test_config_2_as_worded_2p16_g1_msm_equals_the_naive_loop_golden():
+    """BASELINE configs[1]: 'Synthetic 2^16 ... G1 Pippenger MSM only, bit-exact vs bn128.G1 loop'.  The expected point was computed
+    offline by oracle/gen_golden_large.py: bases P_i = MulScalar(G, k_i), then acc = Add(acc, MulScalar(P_i, s_i)) over all 2^16
+    terms with the C restatement of bn128/g1.go on all host cores (tests/golden/oracle_msm_g1_2p16.json)."""
+    import json
+    import os
+    from gosnark_amd import synth
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_msm_g1_2p16.json")) as f:
+        rec = json.load(f)
+    n = rec["n"]
+    bases = capi.g1_fixed_base(synth.scalars_u64(n, rec["seed_bases"]))
+    sc = synth.scalars_u64(n, rec["seed_scalars"])
+    want = (int(rec["x"]), int(rec["y"]))
+    assert capi.msm(bases, sc) == want
+    for c in (13, 16, 18):                                  # and at other window widths
+        capi.set_window_bits(c)
+        try:
+            assert capi.msm(bases, sc) == want, c
+        finally:
+            capi.set_window_bits(0)
+    # the bases themselves: the device's fixed-base batch against the oracle's MulScalar(G, k) on a sample
+    pts = capi.g1_download(bases)
+    ks = U.u64_rows_to_ints(synth.scalars_u64(n, rec["seed_bases"]))
+    for i in (0, 1, n // 2, n - 1):
+        a = O.G1.Affine(O.G1.MulScalar(O.G1_GEN, ks[i]))
+        assert tuple(U.u64_rows_to_ints(pts[i])) == (a[0], a[1], 1)
