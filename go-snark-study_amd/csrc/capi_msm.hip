@@ -143,7 +143,7 @@ int msm_begin(Ctx& c, Kind kind, gs_handle hb, size_t off, gs_handle hs, size_t 
   st->keep = {c.share<Object>(hb, kind), c.share<Object>(hs, Kind::Scalars)};
   MsmPlan plan;
   {
-    StreamScope ss(c, c.aux_stream[3]);
+    StreamScope ss(c, c.aux_stream[1]);
     st->tplan = std::make_shared<PhaseTimer>(c.stream);
     build_plan(c, 2 * parity, sc->buf.as<uint32_t>() + soff * 8, (uint32_t)n, plan, {{1, st->g2}});
     st->tplan->stop();

@@ -142,11 +142,8 @@ int groth16_enqueue(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, const S
   MsmPlan plan_w, plan_h;
   // The main stream carries NOTHING but the ALU-bound bucket accumulations (G2, then the three G1 arrays over w, then h),
   // so with two proofs in flight it never idles: both plans, H(x) and every combine/reduce tail run on the aux streams.
-  // plan(w) has its own stream: with several proofs in flight the sort of proof k+1's witness must not queue behind proof k's
-  // H(x) and plan(h) (timeline profiles/r02_timeline_*: that chain was the pace-setter)
-  static const int planw_stream = getenv("GS_PLANW_STREAM") ? atoi(getenv("GS_PLANW_STREAM")) % Ctx::kAuxStreams : 3;
-  {                                                              // aux 3: plan(w)
-    StreamScope sc(c, c.aux_stream[planw_stream]);
+  {                                                              // aux 1: plan(w), then H(x), plan(h)
+    StreamScope sc(c, c.aux_stream[1]);
     st.tplanw = std::make_shared<PhaseTimer>(c.stream);
     build_plan(c, 0 + 2 * parity, w.p + wlo * 8, (uint32_t)(whi - wlo), plan_w, {{1, true}, {3, false}});
     st.tplanw->stop();
@@ -319,8 +316,8 @@ int pinocchio_enqueue(Ctx& c, PinocchioPkObj* pk, DevScalars w, DevScalars px, i
   }
   const int ws = 8 * parity, pin = 3 * parity;
   MsmPlan plan_w, plan_h;
-  {                                                              // aux 3: plan(w)
-    StreamScope sc(c, c.aux_stream[3]);
+  {                                                              // aux 1: plan(w)
+    StreamScope sc(c, c.aux_stream[1]);
     st.tplanw = std::make_shared<PhaseTimer>(c.stream);
     build_plan(c, 2 * parity, w.p, (uint32_t)w.n, plan_w, {{1, true}, {6, false}});
     st.tplanw->stop();

@@ -119,8 +119,10 @@ struct Ctx {
   bool ready = false;
   hipStream_t stream = nullptr;   // the stream every engine function enqueues on (switched by StreamScope)
   hipStream_t main_stream = nullptr;
-  static constexpr int kAuxStreams = 4;             // 0 / 2: reduction tails, 1: H(x) + plan(h), 3: plan(w) of the NEXT operation
-  hipStream_t aux_stream[kAuxStreams] = {nullptr, nullptr, nullptr, nullptr};
+  // 0 / 2: reduction tails, 1: plans and H(x).  (A fourth stream for plan(w) was tried and LOST 5 %: beyond four streams two of
+  // them share a hardware queue, and the sort of the next proof then queues behind a reduction tail.)
+  static constexpr int kAuxStreams = 3;
+  hipStream_t aux_stream[kAuxStreams] = {nullptr, nullptr, nullptr};
   static constexpr int kMaxInFlight = 3;             // pipelined operations (tickets); each owns one set of workspaces
   static constexpr int kSlots = kMaxInFlight + 1;    // + one set for the blocking entry points (serialised by `mu`), so a blocking
   static constexpr int kBlockingSlot = kMaxInFlight; //   call made while tickets are outstanding never touches their result staging
