@@ -106,3 +106,74 @@ int main(void) {
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "gosnark-hip" in out.stdout
+
+
+def test_multi_device_entry_points_without_a_device():
+    """No GPU here: the per-device contexts, the communicator and the multi-device entry points must say so, not crash."""
+    import ctypes
+    lib = capi.load_library()
+    assert lib.gs_device_count() == 0
+    assert lib.gs_set_device(0) == -3 and b"no logical device" in lib.gs_last_error()
+    assert lib.gs_comm_init_local() == -5                                   # GS_ERR_NOT_INIT
+    nr, rk, loc, cnt = ctypes.c_int(9), ctypes.c_int(9), ctypes.c_int(9), ctypes.c_uint64(9)
+    assert lib.gs_comm_info(ctypes.byref(nr), ctypes.byref(rk), ctypes.byref(loc), ctypes.cast(ctypes.byref(cnt), capi.u64p)) == 0
+    assert (nr.value, rk.value, loc.value) == (0, -1, 0)
+    h = (capi.Handle * 2)(1, (1 << 56) | 1)
+    out = np.zeros(32, dtype=np.uint64)
+    inf = (ctypes.c_int * 3)()
+    used = ctypes.c_int(0)
+    rs = capi.ints_to_u64([1, 2])
+    st = lib.gs_groth16_prove_multi(h, h, h, 2, capi.ptr64(rs[0]), capi.ptr64(rs[1]), capi.ptr64(out), inf, ctypes.byref(used))
+    assert st < 0 and b"gs_init did not create" in lib.gs_last_error()
+    assert lib.gs_handle_device(capi.Handle((5 << 56) | 77)) == 5
+    assert lib.gs_verify_set_strict(1) == 0 and lib.gs_verify_set_strict(0) == 0
+
+
+def test_c_drivers_of_the_go_wrappers_compile_and_link(tmp_path):
+    """tests/c/*.c (the executable mirror of go/: every wrapper's exact call sequence) must at least build everywhere; they RUN in
+    the -m gpu suite (tests/test_gpu_c_drivers.py, tests/test_gpu_zy_multi.py)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import c_util
+    for name in sorted(os.listdir(c_util.CDIR)):
+        if name.endswith(".c"):
+            exe = c_util.compile_c(name, tmp_path)
+            assert os.path.exists(exe)
+
+
+def test_verifier_strict_mode_rejects_aliased_inputs():
+    """ADVICE r1 (low): with gs_verify_set_strict(1) a public signal x + r, a coordinate X + q or a short signal list no longer pass;
+    the default stays the reference's big.Int behaviour."""
+    import golden_util as GU
+    from gosnark_amd import groth16, utils
+    from oracle import ref_py as O
+    rec = GU.load("groth_x3")
+    _, vk = utils.GrothSetupFromString(rec["setup"])
+    pr = utils.GrothProofFromString(rec["proof"]) if hasattr(utils, "GrothProofFromString") else None
+    if pr is None:
+        pr = groth16.Proof(GU.g1(rec["proof"]["PiA"]), GU.g2(rec["proof"]["PiB"]), GU.g1(rec["proof"]["PiC"]))
+    lib = capi.load_library()
+
+    def raw_verify(pub_ints, proof):
+        import ctypes
+        ic = capi.g1_points_to_u64(vk.IC)
+        pub = capi.ints_to_u64(pub_ints) if pub_ints else np.zeros((1, 4), dtype=np.uint64)
+        g1 = capi.g1_points_to_u64([vk.G1_Alpha, proof.PiA, proof.PiC])
+        g2 = capi.g2_points_to_u64([vk.G2_Beta, vk.G2_Gamma, vk.G2_Delta, proof.PiB])
+        ok = ctypes.c_int(7)
+        st = lib.gs_groth16_verify(capi.ptr64(g1[0]), capi.ptr64(g2[0]), capi.ptr64(g2[1]), capi.ptr64(g2[2]), capi.ptr64(ic), len(vk.IC),
+                                   capi.ptr64(pub), len(pub_ints), capi.ptr64(g1[1]), capi.ptr64(g2[3]), capi.ptr64(g1[2]), ctypes.byref(ok))
+        return st, ok.value
+    a = O.G1.Affine(pr.PiA)
+    aliased = groth16.Proof((a[0] + O.Q, a[1], 1), pr.PiB, pr.PiC)                 # X + q < 2^256 names the same point
+    try:
+        assert raw_verify([35], pr) == (0, 1) and raw_verify([35 + O.R], pr) == (0, 1) and raw_verify([35], aliased) == (0, 1)
+        assert raw_verify([], pr) == (0, 0)                                        # lenient: missing inputs are zeros -> reject, no error
+        assert lib.gs_verify_set_strict(1) == 0
+        assert raw_verify([35], pr) == (0, 1)
+        assert raw_verify([35 + O.R], pr) == (0, 0) and raw_verify([35], aliased) == (0, 0)
+        st, _ = raw_verify([], pr)
+        assert st == -4 and b"strict" in lib.gs_last_error()
+    finally:
+        lib.gs_verify_set_strict(0)
