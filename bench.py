@@ -573,6 +573,8 @@ def main():
                 out["cpu_baseline"]["note"] = "baseline is the Groth16 prove sample; 1 constraint ~ 4 G1 + 1 G2 terms"
             if plain_prove and not args.no_extras:
                 out["cpu_baseline_reference_wasm"] = cpu_baseline_reference_wasm()
+        import ctypes
+        ctypes.CDLL(None).fflush(None)       # anything native libraries left in C stdio (RCCL's version banner) goes out BEFORE the line
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -198,7 +198,10 @@ static void msm_enqueue(Ctx& c, const MsmPlan& plan, const std::vector<MsmBase>&
   if (njobs > kMaxJobs) throw HipError{hipErrorInvalidValue, "too many MSM jobs", __LINE__};
   constexpr size_t pw = PointIO<T>::kXyzzWords;
   constexpr size_t aw = PointIO<T>::kAffineWords;
-  const int L = (int)std::max<uint32_t>(1u, std::min<uint32_t>(8u, plan.B / kReduceBlock));
+  // buckets per reduce thread: 8, or as many as it takes (up to 32) to stay at <= 16 workgroup pairs, which the host folds while
+  // the device moves on -- the on-device fold (k_pair_reduce) is one more ~35-deep chain of dependent additions in the tail
+  int L = (int)std::max<uint32_t>(1u, std::min<uint32_t>(8u, plan.B / kReduceBlock));
+  while (L < 32 && plan.B / ((uint32_t)kReduceBlock * (uint32_t)L) > 16u) L *= 2;
   const uint32_t nblk = (plan.B + kReduceBlock * L - 1) / (kReduceBlock * L);
   p.L = L; p.nblk = nblk;
   p.folded = nblk > 16;                                   // wide windows: the pairs are folded on the device (k_pair_reduce)
@@ -242,7 +245,7 @@ static void msm_enqueue(Ctx& c, const MsmPlan& plan, const std::vector<MsmBase>&
   p.tred = std::make_shared<PhaseTimer>(ts);
   // (the block-wide tree for buckets cut into very many chunks belongs to the tail too: with uniform scalars it finds nothing
   // to do, and on the accumulation stream even an empty launch waited ~0.5 ms for register space)
-  hipLaunchKernelGGL(k_heavy_combine<T>, dim3(1024, njobs), dim3(kHeavyBlock), 0, ts,
+  hipLaunchKernelGGL(k_heavy_combine<T>, dim3(64, njobs), dim3(kHeavyBlock), 0, ts,
                      jobs, plan.offsets, plan.heavy_list, plan.heavy_count, plan.chunk);
   hipLaunchKernelGGL(k_bucket_combine<T>, dim3((plan.B + 255) / 256, njobs), dim3(256), 0, ts, jobs, plan.offsets, plan.B, plan.chunk);
   hipLaunchKernelGGL(k_block_reduce<T>, dim3(nblk, njobs), dim3(kReduceBlock), 0, ts, jobs, plan.B, L);
