@@ -153,10 +153,11 @@ int msm_begin(Ctx& c, Kind kind, gs_handle hb, size_t off, gs_handle hs, size_t 
     StreamScope ss(c, c.main_stream);
     GS_HIP(hipStreamWaitEvent(c.stream, st->planned, 0));
     std::vector<MsmBase> bases{MsmBase{tab, off}};
-    if constexpr (T::kWords == 8) msm_enqueue_g1(c, plan, bases, 8 * parity, 3 * parity, st->pend, c.aux_stream[2]);
-    else msm_enqueue_g2(c, plan, bases, 8 * parity + 4, 3 * parity, st->pend, c.aux_stream[2]);
+    c.next_tails((uint32_t)n);                               // consecutive small MSMs reduce on alternating tail streams
+    if constexpr (T::kWords == 8) msm_enqueue_g1(c, plan, bases, 8 * parity, 3 * parity, st->pend, c.tail_stream(0));
+    else msm_enqueue_g2(c, plan, bases, 8 * parity + 4, 3 * parity, st->pend, c.tail_stream(0));
   }
-  GS_HIP(hipEventRecord(st->done, c.aux_stream[2]));
+  GS_HIP(hipEventRecord(st->done, c.tail_stream(0)));
   st->ticket = c.new_ticket();
   *ticket = st->ticket;
   c.inflight[parity] = std::move(st);

@@ -22,9 +22,12 @@ static inline dim3 grid1(size_t n, int block = 256) { return dim3((unsigned)((n 
 int choose_window_bits(uint32_t n, int forced) {
   if (forced >= 8 && forced <= kMaxWindowBits) return forced;
   static const double per_bucket = getenv("GS_WINDOW_COST_BUCKET") ? atof(getenv("GS_WINDOW_COST_BUCKET")) : 6.0;
+  // The model stops at 17 bits: wider windows need 4+ bucket ranges in the sort and a deeper reduce, and measured end to end they
+  // lose what the shorter accumulation wins (2^22-constraint proof: c = 17 37.8 ms, 18 41.3 ms, 20 41.6 ms; 2^20: 9.1 / 9.6 / 9.9).
+  static const int auto_max = getenv("GS_AUTO_MAX_C") ? atoi(getenv("GS_AUTO_MAX_C")) : 17;
   int best = 8;
   double best_cost = 1e300;
-  for (int c = 8; c <= kMaxWindowBits; ++c) {
+  for (int c = 8; c <= std::min(kMaxWindowBits, std::max(8, auto_max)); ++c) {
     const int W = 254 / c + 1;
     const double cost = (double)n * W + per_bucket * (double)(1u << (c - 1));
     if (cost < best_cost) { best_cost = cost; best = c; }

@@ -177,16 +177,17 @@ int groth16_enqueue(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, const S
     // loop from NPublic+1 (:248-250) equals a full-range MSM sharing w's plan.
     // G2 first: its accumulation (2 waves/SIMD, 256 VGPRs) is the one a foreign wave hurts most, and its long
     // combine/reduce tail then hides behind the G1 accumulations.
-    msm_enqueue_g2(c, plan_w, {MsmBase{&pk->t_bacgamma2, wbase}}, ws + 4, pin + 1, st.pend_g2w, c.aux_stream[0]);
+    if (pipelined) c.next_tails(plan_w.n);
+    msm_enqueue_g2(c, plan_w, {MsmBase{&pk->t_bacgamma2, wbase}}, ws + 4, pin + 1, st.pend_g2w, c.tail_stream(0));
     msm_enqueue_g1(c, plan_w, {MsmBase{&pk->t_at, wbase}, MsmBase{&pk->t_bacgamma1, wbase}, MsmBase{&pk->t_bacdelta, wbase}}, ws + 0, pin + 0,
-                   st.pend_g1w, c.aux_stream[2]);
+                   st.pend_g1w, c.tail_stream(1));
   }
   {                                                              // main again: the accumulation over h
     StreamScope sc(c, c.main_stream);
     GS_HIP(hipStreamWaitEvent(c.stream, st.planh, 0));
     // a lone proof finishes soonest with the last tail right behind its accumulation; in a pipeline that tail must not sit
     // in front of the next proof's accumulations
-    msm_enqueue_g1(c, plan_h, {MsmBase{&pk->t_ptd, hbase}}, ws + 3, pin + 2, st.pend_h, pipelined ? c.aux_stream[2] : nullptr);   // :269-271
+    msm_enqueue_g1(c, plan_h, {MsmBase{&pk->t_ptd, hbase}}, ws + 3, pin + 2, st.pend_h, pipelined ? c.tail_stream(1) : nullptr);   // :269-271
   }
   st.total->stop();
   GS_HIP(hipEventRecord(st.done_main, c.main_stream));
@@ -328,9 +329,10 @@ int pinocchio_enqueue(Ctx& c, PinocchioPkObj* pk, DevScalars w, DevScalars px, i
     GS_HIP(hipStreamWaitEvent(c.stream, st.planw, 0));
     // A and Ap run over i > NPublic only (snark.go:265-268): their first npublic+1 points were forced
     // to infinity at key creation; Bp, C, Cp, Kp and B run over all variables (:270-278).
-    msm_enqueue_g2(c, plan_w, {MsmBase{&pk->t_b2, 0}}, ws + 6, pin + 1, st.pend_g2w, c.aux_stream[0]);
+    if (pipelined) c.next_tails(plan_w.n);
+    msm_enqueue_g2(c, plan_w, {MsmBase{&pk->t_b2, 0}}, ws + 6, pin + 1, st.pend_g2w, c.tail_stream(0));
     msm_enqueue_g1(c, plan_w, {MsmBase{&pk->t_a, 0}, MsmBase{&pk->t_ap, 0}, MsmBase{&pk->t_bp, 0}, MsmBase{&pk->t_c, 0},
-                               MsmBase{&pk->t_cp, 0}, MsmBase{&pk->t_kp, 0}}, ws + 0, pin + 0, st.pend_g1w, c.aux_stream[2]);
+                               MsmBase{&pk->t_cp, 0}, MsmBase{&pk->t_kp, 0}}, ws + 0, pin + 0, st.pend_g1w, c.tail_stream(1));
   }
   {                                                              // aux 1 again: H(x), plan(h)
     StreamScope sc(c, c.aux_stream[1]);
@@ -345,7 +347,7 @@ int pinocchio_enqueue(Ctx& c, PinocchioPkObj* pk, DevScalars w, DevScalars px, i
   {                                                              // main again: the accumulation over h
     StreamScope sc(c, c.main_stream);
     GS_HIP(hipStreamWaitEvent(c.stream, st.planh, 0));
-    msm_enqueue_g1(c, plan_h, {MsmBase{&pk->t_g1t, 0}}, ws + 7, pin + 2, st.pend_h, pipelined ? c.aux_stream[2] : nullptr);   // :284-286
+    msm_enqueue_g1(c, plan_h, {MsmBase{&pk->t_g1t, 0}}, ws + 7, pin + 2, st.pend_h, pipelined ? c.tail_stream(1) : nullptr);   // :284-286
   }
   st.total->stop();
   GS_HIP(hipEventRecord(st.done_main, c.main_stream));

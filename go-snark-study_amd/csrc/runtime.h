@@ -5,6 +5,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -129,6 +130,16 @@ struct Ctx {
   void* pinned[3 * kSlots] = {};                     // host staging of the result downloads (3 per slot)
   std::unique_ptr<InFlightBase> inflight[kMaxInFlight];
   uint64_t next_ticket = 1;
+  // Consecutive pipelined operations swap the two tail streams: the reduction tails are chains of dependent point additions
+  // (latency, not throughput), so the tails of operation k + 1 may run beside those of operation k instead of queueing behind
+  // them -- at 2^16 the G2 tail (1.2 ms) was longer than the accumulations of a whole proof (0.9 ms) and set the pace.
+  unsigned tail_flip = 0;
+  hipStream_t tail_stream(int which) { return aux_stream[((which ^ (int)(tail_flip & 1u)) & 1) ? 2 : 0]; }
+  void next_tails(uint32_t n) {                     // called once per pipelined operation of n terms
+    static const int mode = getenv("GS_TAIL_FLIP") ? atoi(getenv("GS_TAIL_FLIP")) : 1;      // 0 never, 1 always, 2 by size
+    if (mode == 1 || (mode == 2 && n <= kTailFlipMaxTerms)) tail_flip ^= 1u;
+  }
+  static constexpr uint32_t kTailFlipMaxTerms = 1u << 18;
   uint64_t new_ticket() { return ((uint64_t)logical << kHandleDevShift) | next_ticket++; }
   int free_parity() const { for (int p = 0; p < kMaxInFlight; ++p) if (!inflight[p]) return p; return -1; }
   bool any_inflight() const { for (int p = 0; p < kMaxInFlight; ++p) if (inflight[p]) return true; return false; }
