@@ -31,6 +31,11 @@ class Timing(ctypes.Structure):
                    ("window_bits", ctypes.c_uint32), ("reserved", ctypes.c_uint32)])
 
 
+class Memory(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_uint64) for n in ("device_total_bytes", "device_free_bytes", "library_bytes", "object_bytes", "table_bytes",
+                                               "workspace_bytes", "objects", "reserved")]
+
+
 def lib_path():
     # GS_LIB: development aid for A/B runs of two builds inside one GPU session
     return os.environ.get("GS_LIB") or os.path.join(_HERE, "libgosnark_hip.so")
@@ -92,6 +97,7 @@ _SIGS = {
                                ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, ctypes.POINTER(Handle)],
     "gs_pinocchio_prove": [Handle, u64p, ctypes.c_size_t, u64p, ctypes.c_size_t, u64p, intp],
     "gs_pinocchio_prove_resident": [Handle, Handle, Handle, u64p, intp],
+    "gs_pinocchio_prove_witness": [Handle, Handle, Handle, u64p, intp],
     "gs_pinocchio_prove_begin": [Handle, Handle, Handle, u64p],
     "gs_pinocchio_prove_end": [ctypes.c_uint64, u64p, intp],
     "gs_device_count": [],
@@ -118,6 +124,10 @@ _SIGS = {
     "gs_last_timing": [ctypes.POINTER(Timing)],
     "gs_device_timing": [ctypes.c_int, ctypes.POINTER(Timing)],
     "gs_set_window_bits": [ctypes.c_int],
+    "gs_memory_query": [ctypes.POINTER(Memory)],
+    "gs_handle_bytes": [Handle, u64p, u64p],
+    "gs_release_tables": [Handle],
+    "gs_trim": [],
     "gs_verify_set_strict": [ctypes.c_int],
     "gs_pairing": [u64p, u64p, u64p],
     "gs_pairing_check": [u64p, u64p, ctypes.c_size_t, intp],
@@ -382,6 +392,35 @@ def last_timing():
     t = Timing()
     check(load_library().gs_last_timing(ctypes.byref(t)))
     return {n: getattr(t, n) for n, _ in Timing._fields_}
+
+
+def _raw(h):
+    return int(h.h) if hasattr(h, "h") else int(h)
+
+
+def memory_query():
+    """gs_memory_query: what the current logical device's GPU and this library hold (bytes)."""
+    init()
+    m = Memory()
+    check(load_library().gs_memory_query(ctypes.byref(m)))
+    return {n: int(getattr(m, n)) for n, _ in Memory._fields_ if n != "reserved"}
+
+
+def handle_bytes(h):
+    """gs_handle_bytes -> (object bytes, window-table bytes) of one handle."""
+    a, b = ctypes.c_uint64(0), ctypes.c_uint64(0)
+    check(load_library().gs_handle_bytes(Handle(_raw(h)), ctypes.cast(ctypes.byref(a), u64p), ctypes.cast(ctypes.byref(b), u64p)))
+    return int(a.value), int(b.value)
+
+
+def release_tables(h):
+    """gs_release_tables: drop the window tables of a key / base array (rebuilt on its next use)."""
+    check(load_library().gs_release_tables(Handle(_raw(h))))
+
+
+def trim():
+    """gs_trim: drop the cached workspaces of the current logical device."""
+    check(load_library().gs_trim())
 
 
 def set_window_bits(c):

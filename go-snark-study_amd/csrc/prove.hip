@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <functional>
+#include <chrono>
 #include <future>
 #include <vector>
 
@@ -78,7 +79,9 @@ struct GrothInFlight : InFlightBase {
   GrothPkObj* pk = nullptr;
   uint64_t r[4] = {0, 0, 0, 0}, s[4] = {0, 0, 0, 0};
   bool with_tail = false;
-  hipEvent_t planw = nullptr, planh = nullptr, done_main = nullptr, done_aux0 = nullptr, done_aux2 = nullptr;
+  // done_g2 / done_g1w / done_h: one per MSM group, recorded behind that group's reduction tail, so the host can add up a
+  // group's partial sums while the later groups are still on the device
+  hipEvent_t planw = nullptr, planh = nullptr, done_main = nullptr, done_g2 = nullptr, done_g1w = nullptr, done_h = nullptr;
   std::unique_ptr<PhaseTimer> total;
   MsmPending pend_g1w, pend_g2w, pend_h;
   std::shared_ptr<PhaseTimer> tpoly, tplanw, tplanh;
@@ -87,13 +90,11 @@ struct GrothInFlight : InFlightBase {
   GrothInFlight() {
     GS_HIP(hipEventCreateWithFlags(&planw, hipEventDisableTiming));
     GS_HIP(hipEventCreateWithFlags(&planh, hipEventDisableTiming));
-    GS_HIP(hipEventCreateWithFlags(&done_main, hipEventDisableTiming));
-    GS_HIP(hipEventCreateWithFlags(&done_aux0, hipEventDisableTiming));
-    GS_HIP(hipEventCreateWithFlags(&done_aux2, hipEventDisableTiming));
+    for (hipEvent_t* e : {&done_main, &done_g2, &done_g1w, &done_h}) GS_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
   }
   ~GrothInFlight() override {
     if (fpre.valid()) fpre.wait();
-    for (hipEvent_t e : {planw, planh, done_main, done_aux0, done_aux2}) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {planw, planh, done_main, done_g2, done_g1w, done_h}) if (e) (void)hipEventDestroy(e);
   }
 };
 
@@ -149,6 +150,8 @@ int groth16_enqueue(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, const S
     st.tplanw->stop();
     GS_HIP(hipEventRecord(st.planw, c.stream));
   }
+  // (Starting H(x) and plan(h) of a lone proof beside plan(w) on another stream instead of behind it was tried: the blocking proof
+  // got SLOWER, 11.5-11.7 vs 11.0-11.25 ms -- the NTT passes then overlap the G2 accumulation's first milliseconds more densely.)
   {                                                              // aux 1 again: (late upload of px,) H(x), plan(h)
     StreamScope sc(c, c.aux_stream[1]);
     if (px.host && px.n) {     // the device is already busy with ~8 ms of accumulations: this copy is off the critical path
@@ -179,8 +182,10 @@ int groth16_enqueue(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, const S
     // combine/reduce tail then hides behind the G1 accumulations.
     if (pipelined) c.next_tails(plan_w.n);
     msm_enqueue_g2(c, plan_w, {MsmBase{&pk->t_bacgamma2, wbase}}, ws + 4, pin + 1, st.pend_g2w, c.tail_stream(0));
+    GS_HIP(hipEventRecord(st.done_g2, c.tail_stream(0)));
     msm_enqueue_g1(c, plan_w, {MsmBase{&pk->t_at, wbase}, MsmBase{&pk->t_bacgamma1, wbase}, MsmBase{&pk->t_bacdelta, wbase}}, ws + 0, pin + 0,
                    st.pend_g1w, c.tail_stream(1));
+    GS_HIP(hipEventRecord(st.done_g1w, c.tail_stream(1)));
   }
   {                                                              // main again: the accumulation over h
     StreamScope sc(c, c.main_stream);
@@ -188,28 +193,41 @@ int groth16_enqueue(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, const S
     // a lone proof finishes soonest with the last tail right behind its accumulation; in a pipeline that tail must not sit
     // in front of the next proof's accumulations
     msm_enqueue_g1(c, plan_h, {MsmBase{&pk->t_ptd, hbase}}, ws + 3, pin + 2, st.pend_h, pipelined ? c.tail_stream(1) : nullptr);   // :269-271
+    GS_HIP(hipEventRecord(st.done_h, pipelined ? c.tail_stream(1) : c.main_stream));
   }
   st.total->stop();
   GS_HIP(hipEventRecord(st.done_main, c.main_stream));
-  GS_HIP(hipEventRecord(st.done_aux0, c.aux_stream[0]));
-  GS_HIP(hipEventRecord(st.done_aux2, c.aux_stream[2]));
   return GS_OK;
 }
 
 // Wait for that proof's device work (only its own events: later proofs keep running) and add up the results.
+static double host_now_ms() {
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+static bool host_trace() { static const bool on = getenv("GS_HOST_TRACE") != nullptr; return on; }
+
 int groth16_collect(Ctx& c, GrothInFlight& st, GrothSums& sums) {
-  GS_HIP(hipEventSynchronize(st.done_main));
-  GS_HIP(hipEventSynchronize(st.done_aux0));
-  GS_HIP(hipEventSynchronize(st.done_aux2));
+  const double t0 = host_trace() ? host_now_ms() : 0;
+  double t1 = 0;
   std::vector<G1Xyzz> g1w, g1h;
   std::vector<G2Xyzz> g2w;
-  msm_book_timing(c, st.pend_g1w); msm_book_timing(c, st.pend_g2w); msm_book_timing(c, st.pend_h);
-  {                                                              // the host-side pair sums of the three groups, on separate cores
+  {   // The host-side pair sums of the three groups, each as soon as its own tail is through: the groups over w finish milliseconds
+      // before the one over h, so only h's handful of additions is left when the device goes idle.
+    // (HIP calls stay on the calling thread: a fresh thread pays ~0.3 ms for its first hipSetDevice / event wait.)
+    GS_HIP(hipEventSynchronize(st.done_g2));
     auto f2 = std::async(std::launch::async, [&] { msm_finish_g2(c, st.pend_g2w, g2w); });
-    auto fh = std::async(std::launch::async, [&] { msm_finish_g1(c, st.pend_h, g1h); });
-    msm_finish_g1(c, st.pend_g1w, g1w);
-    f2.get(); fh.get();
+    struct Join { std::future<void>& f; ~Join() { if (f.valid()) f.wait(); } } j2{f2};     // a throwing wait below must not outrun the threads
+    GS_HIP(hipEventSynchronize(st.done_g1w));
+    auto f1 = std::async(std::launch::async, [&] { msm_finish_g1(c, st.pend_g1w, g1w); });
+    Join j1{f1};
+    GS_HIP(hipEventSynchronize(st.done_h));
+    t1 = host_trace() ? host_now_ms() : 0;
+    msm_finish_g1(c, st.pend_h, g1h);
+    f2.get(); f1.get();
   }
+  GS_HIP(hipEventSynchronize(st.done_main));
+  if (host_trace()) fprintf(stderr, "[gs host] collect: wait %.3f ms, fold %.3f ms\n", t1 - t0, host_now_ms() - t1);
+  msm_book_timing(c, st.pend_g1w); msm_book_timing(c, st.pend_g2w); msm_book_timing(c, st.pend_h);
   c.timing.poly_ms += st.tpoly->ms();
   c.timing.plan_ms += st.tplanw->ms() + st.tplanh->ms();
   c.timing.total_ms += st.total->ms();
@@ -264,27 +282,33 @@ void groth16_tail(GrothPkObj* pk, const GrothSums& sums, const uint64_t r[4], co
 int groth16_prove_impl(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, const uint64_t r[4], const uint64_t s[4],
                        uint64_t out_proof[32], int inf[3]) {
   // the result-independent tail products run on other host cores while this thread enqueues and waits for the device
+  const double t0 = host_trace() ? host_now_ms() : 0;
   GrothTailPre pre;
   std::future<void> fpre = std::async(std::launch::async, [&] { groth16_tail_pre(pk, r, s, pre); });
   GrothSums sums;
-  const int rc = groth16_sums_impl(c, pk, w, px, Shard{}, sums);
+  GrothInFlight st;
+  int rc = groth16_enqueue(c, pk, w, px, Shard{}, Ctx::kBlockingSlot, true, false, st);
+  const double t1 = host_trace() ? host_now_ms() : 0;
+  if (rc == GS_OK) rc = groth16_collect(c, st, sums);
+  const double t2 = host_trace() ? host_now_ms() : 0;
   fpre.get();
   if (rc != GS_OK) return rc;
   groth16_tail_post(pk, sums, pre, r, s, out_proof, inf);
+  if (host_trace()) fprintf(stderr, "[gs host] prove: enqueue %.3f ms, collect %.3f ms, tail %.3f ms (entered at %.3f)\n", t1 - t0, t2 - t1, host_now_ms() - t2, t0);
   return GS_OK;
 }
 
 // One Pinocchio proof in flight: same stream layout as a Groth16 proof (main = accumulations only).
 struct PinInFlight : InFlightBase {
-  hipEvent_t planw = nullptr, planh = nullptr, done_main = nullptr, done_aux0 = nullptr, done_aux2 = nullptr;
+  hipEvent_t planw = nullptr, planh = nullptr, done_main = nullptr, done_g2 = nullptr, done_g1w = nullptr, done_h = nullptr;   // as GrothInFlight
   std::unique_ptr<PhaseTimer> total;
   MsmPending pend_g1w, pend_g2w, pend_h;
   std::shared_ptr<PhaseTimer> tpoly, tplanw, tplanh;
   PinInFlight() {
-    for (hipEvent_t* e : {&planw, &planh, &done_main, &done_aux0, &done_aux2}) GS_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    for (hipEvent_t* e : {&planw, &planh, &done_main, &done_g2, &done_g1w, &done_h}) GS_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
   }
   ~PinInFlight() override {
-    for (hipEvent_t e : {planw, planh, done_main, done_aux0, done_aux2}) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {planw, planh, done_main, done_g2, done_g1w, done_h}) if (e) (void)hipEventDestroy(e);
   }
 };
 
@@ -331,13 +355,20 @@ int pinocchio_enqueue(Ctx& c, PinocchioPkObj* pk, DevScalars w, DevScalars px, i
     // to infinity at key creation; Bp, C, Cp, Kp and B run over all variables (:270-278).
     if (pipelined) c.next_tails(plan_w.n);
     msm_enqueue_g2(c, plan_w, {MsmBase{&pk->t_b2, 0}}, ws + 6, pin + 1, st.pend_g2w, c.tail_stream(0));
+    GS_HIP(hipEventRecord(st.done_g2, c.tail_stream(0)));
     msm_enqueue_g1(c, plan_w, {MsmBase{&pk->t_a, 0}, MsmBase{&pk->t_ap, 0}, MsmBase{&pk->t_bp, 0}, MsmBase{&pk->t_c, 0},
                                MsmBase{&pk->t_cp, 0}, MsmBase{&pk->t_kp, 0}}, ws + 0, pin + 0, st.pend_g1w, c.tail_stream(1));
+    GS_HIP(hipEventRecord(st.done_g1w, c.tail_stream(1)));
   }
   {                                                              // aux 1 again: H(x), plan(h)
     StreamScope sc(c, c.aux_stream[1]);
     st.tpoly = std::make_shared<PhaseTimer>(c.stream);
-    if (nh) poly_quotient_dev(c, pk->z, px.p, px.n, hxbuf.as<uint32_t>());      // snark.go:280
+    bool have_hx = false;
+    if (px.produce_hx && nh) have_hx = px.produce_hx(c, hxbuf.as<uint32_t>());   // H from the constraint values (satisfying witness)
+    if (!have_hx) {
+      if (px.produce) px.produce(c);                                            // r1csqap.go:191-210 on the sparse system
+      if (nh) poly_quotient_dev(c, pk->z, px.p, px.n, hxbuf.as<uint32_t>());     // snark.go:280
+    }
     st.tpoly->stop();
     st.tplanh = std::make_shared<PhaseTimer>(c.stream);
     build_plan(c, 2 * parity + 1, hxbuf.as<uint32_t>(), (uint32_t)nh, plan_h, {{1, false}});
@@ -348,27 +379,29 @@ int pinocchio_enqueue(Ctx& c, PinocchioPkObj* pk, DevScalars w, DevScalars px, i
     StreamScope sc(c, c.main_stream);
     GS_HIP(hipStreamWaitEvent(c.stream, st.planh, 0));
     msm_enqueue_g1(c, plan_h, {MsmBase{&pk->t_g1t, 0}}, ws + 7, pin + 2, st.pend_h, pipelined ? c.tail_stream(1) : nullptr);   // :284-286
+    GS_HIP(hipEventRecord(st.done_h, pipelined ? c.tail_stream(1) : c.main_stream));
   }
   st.total->stop();
   GS_HIP(hipEventRecord(st.done_main, c.main_stream));
-  GS_HIP(hipEventRecord(st.done_aux0, c.aux_stream[0]));
-  GS_HIP(hipEventRecord(st.done_aux2, c.aux_stream[2]));
   return GS_OK;
 }
 
 int pinocchio_collect(Ctx& c, PinInFlight& st, uint64_t out[72], int inf[8]) {
-  GS_HIP(hipEventSynchronize(st.done_main));
-  GS_HIP(hipEventSynchronize(st.done_aux0));
-  GS_HIP(hipEventSynchronize(st.done_aux2));
   std::vector<G1Xyzz> g1w, g1h;
   std::vector<G2Xyzz> g2w;
-  msm_book_timing(c, st.pend_g1w); msm_book_timing(c, st.pend_g2w); msm_book_timing(c, st.pend_h);
-  {                                                              // the host-side pair sums of the three groups, on separate cores
+  {                                          // the host-side pair sums, each group as soon as its own tail is through (groth16_collect)
+    GS_HIP(hipEventSynchronize(st.done_g2));
     auto f2 = std::async(std::launch::async, [&] { msm_finish_g2(c, st.pend_g2w, g2w); });
-    auto fh = std::async(std::launch::async, [&] { msm_finish_g1(c, st.pend_h, g1h); });
-    msm_finish_g1(c, st.pend_g1w, g1w);
-    f2.get(); fh.get();
+    struct Join { std::future<void>& f; ~Join() { if (f.valid()) f.wait(); } } j2{f2};
+    GS_HIP(hipEventSynchronize(st.done_g1w));
+    auto f1 = std::async(std::launch::async, [&] { msm_finish_g1(c, st.pend_g1w, g1w); });
+    Join j1{f1};
+    GS_HIP(hipEventSynchronize(st.done_h));
+    msm_finish_g1(c, st.pend_h, g1h);
+    f2.get(); f1.get();
   }
+  GS_HIP(hipEventSynchronize(st.done_main));
+  msm_book_timing(c, st.pend_g1w); msm_book_timing(c, st.pend_g2w); msm_book_timing(c, st.pend_h);
   c.timing.poly_ms += st.tpoly->ms();
   c.timing.plan_ms += st.tplanw->ms() + st.tplanh->ms();
   // output order: PiA | PiAp | PiB | PiBp | PiC | PiCp | PiH | PiKp
@@ -1057,6 +1090,32 @@ int gs_groth16_prove_witness(gs_handle hpk, gs_handle hr1cs, gs_handle hw, const
     dp.produce_hx = [o, wdev, dz](Ctx& cc, uint32_t* hx) { r1cs_values_dev(cc, *o, wdev); return hx_direct_dev(cc, o->vals.as<uint32_t>(), o->n, dz, hx); };
     dp.produce = [o, wdev, pxdev](Ctx& cc) { r1cs_px_dev(cc, *o, wdev, pxdev); };
     return groth16_prove_impl(c, pk, DevScalars{wdev, w->n}, dp, r, s, out_proof, inf);
+  }, true, false, hpk);
+}
+
+// snark.GenerateProofs straight from the witness (the Pinocchio twin of gs_groth16_prove_witness): CombinePolynomials + Div
+// (r1csqap.go:191-216, snark.go:280) collapse into H(x) from the constraint values; the exact px route when a constraint is violated.
+int gs_pinocchio_prove_witness(gs_handle hpk, gs_handle hr1cs, gs_handle hw, uint64_t out_proof[72], int inf[8]) {
+  return guarded([&](Ctx& c) -> int {
+    PinocchioPkObj* pk = c.get<PinocchioPkObj>(hpk, Kind::PinocchioPk);
+    R1csObj* o = c.get<R1csObj>(hr1cs, Kind::R1cs);
+    Scalars* w = c.get<Scalars>(hw, Kind::Scalars);
+    if (!pk || !o || !w) return fail(GS_ERR_ARG, "gs_pinocchio_prove_witness: bad handle");
+    if (!out_proof || !inf) return fail(GS_ERR_ARG, "null argument");
+    if (w->n != o->m) return fail(GS_ERR_SHAPE, "len(w) = %zu but the system has %zu variables", w->n, o->m);
+    if (pk->nz == 0) return fail(GS_ERR_SHAPE, "the key has no Z");
+    const size_t npx = 2 * o->n - 1;
+    reset_timing(c);
+    o->prod.ensure(npx * 32);
+    const uint32_t* wdev = w->buf.as<uint32_t>();
+    DevBuf& pxbuf = prove_state(c).up_px;
+    pxbuf.ensure(npx * 32);
+    uint32_t* pxdev = pxbuf.as<uint32_t>();
+    DevScalars dp{pxdev, npx};
+    const size_t dz = pk->nz - 1;
+    dp.produce_hx = [o, wdev, dz](Ctx& cc, uint32_t* hx) { r1cs_values_dev(cc, *o, wdev); return hx_direct_dev(cc, o->vals.as<uint32_t>(), o->n, dz, hx); };
+    dp.produce = [o, wdev, pxdev](Ctx& cc) { r1cs_px_dev(cc, *o, wdev, pxdev); };
+    return pinocchio_prove_impl(c, pk, DevScalars{wdev, w->n}, dp, out_proof, inf);
   }, true, false, hpk);
 }
 

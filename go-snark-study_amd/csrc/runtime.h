@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -50,6 +51,12 @@ inline bool& process_exiting() {
 }
 
 // ---- device buffers -------------------------------------------------------------------------------
+// every device byte this library holds (all contexts): gs_memory_query reports it
+inline std::atomic<uint64_t>& devbuf_bytes() {
+  static std::atomic<uint64_t> v{0};
+  return v;
+}
+
 struct DevBuf {
   void* p = nullptr;
   size_t bytes = 0;
@@ -68,9 +75,10 @@ struct DevBuf {
     if (n == 0) n = 16;
     GS_HIP(hipMalloc(&p, n));
     bytes = n;
+    devbuf_bytes() += n;
   }
   void ensure(size_t n) { if (n > bytes) alloc(n + n / 8); }      // grow-only workspace
-  void release() { if (p) { if (!process_exiting()) (void)hipFree(p); p = nullptr; bytes = 0; } }
+  void release() { if (p) { if (!process_exiting()) (void)hipFree(p); devbuf_bytes() -= bytes; p = nullptr; bytes = 0; } }
   template <class U> U* as() const { return reinterpret_cast<U*>(p); }
 };
 

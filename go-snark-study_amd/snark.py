@@ -77,6 +77,15 @@ def prove_resident(dev_pk, w_handle, px_handle):
     return _proof_from_words(out, inf)
 
 
+def prove_from_witness(dev_pk, dev_r1cs, w_handle):
+    """Sparse R1CS + resident witness -> proof, H(x) straight from the constraint values (gs_pinocchio_prove_witness): no px."""
+    out = np.zeros(72, dtype=np.uint64)
+    inf = (ctypes.c_int * 8)()
+    capi.check(capi.load_library().gs_pinocchio_prove_witness(capi.Handle(dev_pk.h), capi.Handle(dev_r1cs.handle.h), capi.Handle(w_handle.h),
+                                                              capi.ptr64(out), inf))
+    return _proof_from_words(out, inf)
+
+
 def prove_begin(dev_pk, w_handle, px_handle):
     """Enqueue one Pinocchio proof (gs_pinocchio_prove_begin) -> ticket.  Up to three operations may be outstanding."""
     t = ctypes.c_uint64(0)

@@ -105,7 +105,11 @@ func (k *PinocchioKey) Prove(w, px []*big.Int, order *big.Int) (PinocchioProof, 
 	if err != nil {
 		return proof, err
 	}
-	// out = PiA | PiAp | PiB (16 words) | PiBp | PiC | PiCp | PiH | PiKp
+	return pinocchioProofFromWords(out[:], inf[:]), nil
+}
+
+// out = PiA | PiAp | PiB (16 words) | PiBp | PiC | PiCp | PiH | PiKp
+func pinocchioProofFromWords(out []uint64, inf []C.int) (proof PinocchioProof) {
 	proof.PiA = G1FromAffine(out[0:], inf[0] != 0)
 	proof.PiAp = G1FromAffine(out[8:], inf[1] != 0)
 	proof.PiB = G2FromAffine(out[16:], inf[2] != 0)
@@ -114,7 +118,7 @@ func (k *PinocchioKey) Prove(w, px []*big.Int, order *big.Int) (PinocchioProof, 
 	proof.PiCp = G1FromAffine(out[48:], inf[5] != 0)
 	proof.PiH = G1FromAffine(out[56:], inf[6] != 0)
 	proof.PiKp = G1FromAffine(out[64:], inf[7] != 0)
-	return proof, nil
+	return proof
 }
 
 // PinocchioToxic = the eight values snark.GenerateTrustedSetup draws (snark.go:114-148; RhoC = RhoA RhoB, :149).

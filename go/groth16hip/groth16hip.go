@@ -40,6 +40,7 @@ type keyID struct {
 
 type entry struct {
 	key  *gosnarkhip.Groth16Key
+	r1cs *gosnarkhip.R1CS // the circuit's sparse system, uploaded by the first GenerateProofsFromWitness
 	used uint64
 }
 
@@ -58,7 +59,7 @@ func idOf(pk *groth16.Pk) (keyID, error) {
 
 func remember(id keyID, k *gosnarkhip.Groth16Key) {
 	clock++
-	keys[id] = &entry{k, clock}
+	keys[id] = &entry{key: k, used: clock}
 	for len(keys) > MaxResidentKeys { // evict the least recently used key and give its HBM back
 		var old keyID
 		var oldest uint64 = ^uint64(0)
@@ -67,6 +68,7 @@ func remember(id keyID, k *gosnarkhip.Groth16Key) {
 				old, oldest = i, e.used
 			}
 		}
+		_ = keys[old].r1cs.Free()
 		_ = keys[old].key.Free()
 		delete(keys, old)
 	}
@@ -107,6 +109,7 @@ func ReleaseKey(pk *groth16.Pk) {
 	mu.Lock()
 	defer mu.Unlock()
 	if e, ok := keys[id]; ok {
+		_ = e.r1cs.Free()
 		_ = e.key.Free()
 		delete(keys, id)
 	}
@@ -115,6 +118,7 @@ func ReleaseAll() {
 	mu.Lock()
 	defer mu.Unlock()
 	for id, e := range keys {
+		_ = e.r1cs.Free()
 		_ = e.key.Free()
 		delete(keys, id)
 	}
@@ -145,6 +149,79 @@ func GenerateProofsWithRS(circuit circuitcompiler.Circuit, pk *groth16.Pk, w, px
 	}
 	proof.PiA, proof.PiB, proof.PiC, err = k.Prove(w, px, r, s, groth16.Utils.FqR.Q)
 	return proof, err
+}
+
+// GenerateProofsFromWitness is GenerateProofs for callers that have not computed px: the reference's callers run
+// R1CSToQAP + CombinePolynomials on the CPU first (cli/main.go:480-501, O(m n^3) and wrong past n = 21,
+// r1csqap.go:129-147); here circuit.R1CS is uploaded once per key and H(x) comes straight from the constraint values
+// of the witness on the device.  Same proof as GenerateProofs(circuit, pk, w, px) with the exact px.
+// C call sequence: tests/c/witness_to_proof.c.
+func GenerateProofsFromWitness(circuit circuitcompiler.Circuit, pk groth16.Pk, w []*big.Int) (groth16.Proof, error) {
+	var proof groth16.Proof
+	r, err := groth16.Utils.FqR.Rand()
+	if err != nil {
+		return proof, err
+	}
+	s, err := groth16.Utils.FqR.Rand()
+	if err != nil {
+		return proof, err
+	}
+	return GenerateProofsFromWitnessWithRS(circuit, &pk, w, r, s)
+}
+
+func GenerateProofsFromWitnessWithRS(circuit circuitcompiler.Circuit, pk *groth16.Pk, w []*big.Int, r, s *big.Int) (groth16.Proof, error) {
+	var proof groth16.Proof
+	order := groth16.Utils.FqR.Q
+	k, err := deviceKey(circuit, pk)
+	if err != nil {
+		return proof, err
+	}
+	q, err := deviceR1CS(circuit, pk)
+	if err != nil {
+		return proof, err
+	}
+	wh, err := gosnarkhip.UploadScalars(Device, w, order)
+	if err != nil {
+		return proof, err
+	}
+	defer gosnarkhip.Free(wh)
+	proof.PiA, proof.PiB, proof.PiC, err = k.ProveWitness(q, wh, r, s, order)
+	return proof, err
+}
+
+// deviceR1CS returns the circuit's resident sparse system, uploading circuit.R1CS on first use (cached with the key).
+func deviceR1CS(circuit circuitcompiler.Circuit, pk *groth16.Pk) (*gosnarkhip.R1CS, error) {
+	id, err := idOf(pk)
+	if err != nil {
+		return nil, err
+	}
+	mu.Lock()
+	defer mu.Unlock()
+	e, ok := keys[id]
+	if !ok {
+		return nil, errors.New("groth16hip: key not resident")
+	}
+	if e.r1cs != nil {
+		return e.r1cs, nil
+	}
+	if len(circuit.R1CS.A) == 0 {
+		return nil, errors.New("groth16hip: the circuit carries no R1CS (call circuit.GenerateR1CS first)")
+	}
+	order := groth16.Utils.FqR.Q
+	ca, nvars, err := gosnarkhip.CSRFromDense(circuit.R1CS.A, order)
+	if err != nil {
+		return nil, err
+	}
+	cb, _, err := gosnarkhip.CSRFromDense(circuit.R1CS.B, order)
+	if err != nil {
+		return nil, err
+	}
+	cc, _, err := gosnarkhip.CSRFromDense(circuit.R1CS.C, order)
+	if err != nil {
+		return nil, err
+	}
+	e.r1cs, err = gosnarkhip.UploadR1CS(Device, ca, cb, cc, nvars)
+	return e.r1cs, err
 }
 
 // GenerateTrustedSetup has the reference's signature (groth16/groth16.go:94-222).  The device builds the key from

@@ -34,6 +34,7 @@ type keyID struct {
 }
 type entry struct {
 	key  *gosnarkhip.PinocchioKey
+	r1cs *gosnarkhip.R1CS // uploaded by the first GenerateProofsFromWitness
 	used uint64
 }
 
@@ -52,7 +53,7 @@ func idOf(pk *snark.Pk) (keyID, error) {
 
 func remember(id keyID, k *gosnarkhip.PinocchioKey) {
 	clock++
-	keys[id] = &entry{k, clock}
+	keys[id] = &entry{key: k, used: clock}
 	for len(keys) > MaxResidentKeys {
 		var old keyID
 		var oldest uint64 = ^uint64(0)
@@ -61,6 +62,7 @@ func remember(id keyID, k *gosnarkhip.PinocchioKey) {
 				old, oldest = i, e.used
 			}
 		}
+		_ = keys[old].r1cs.Free()
 		_ = keys[old].key.Free()
 		delete(keys, old)
 	}
@@ -94,6 +96,7 @@ func ReleaseAll() {
 	mu.Lock()
 	defer mu.Unlock()
 	for id, e := range keys {
+		_ = e.r1cs.Free()
 		_ = e.key.Free()
 		delete(keys, id)
 	}
@@ -114,6 +117,68 @@ func GenerateProofs(circuit circuitcompiler.Circuit, pk snark.Pk, w []*big.Int, 
 	proof.PiA, proof.PiAp, proof.PiB, proof.PiBp = p.PiA, p.PiAp, p.PiB, p.PiBp
 	proof.PiC, proof.PiCp, proof.PiH, proof.PiKp = p.PiC, p.PiCp, p.PiH, p.PiKp
 	return proof, nil
+}
+
+// GenerateProofsFromWitness is GenerateProofs for callers that have not computed px (the reference's callers run
+// R1CSToQAP + CombinePolynomials on the CPU first, cli/main.go:330-349): circuit.R1CS is uploaded once per key and
+// H(x) comes from the constraint values of the witness on the device.  C call sequence: tests/c/witness_to_proof.c.
+func GenerateProofsFromWitness(circuit circuitcompiler.Circuit, pk snark.Pk, w []*big.Int) (snark.Proof, error) {
+	var proof snark.Proof
+	order := snark.Utils.FqR.Q
+	k, err := deviceKey(circuit, &pk)
+	if err != nil {
+		return proof, err
+	}
+	q, err := deviceR1CS(circuit, &pk)
+	if err != nil {
+		return proof, err
+	}
+	wh, err := gosnarkhip.UploadScalars(Device, w, order)
+	if err != nil {
+		return proof, err
+	}
+	defer gosnarkhip.Free(wh)
+	p, err := k.ProveWitness(q, wh)
+	if err != nil {
+		return proof, err
+	}
+	proof.PiA, proof.PiAp, proof.PiB, proof.PiBp = p.PiA, p.PiAp, p.PiB, p.PiBp
+	proof.PiC, proof.PiCp, proof.PiH, proof.PiKp = p.PiC, p.PiCp, p.PiH, p.PiKp
+	return proof, nil
+}
+
+func deviceR1CS(circuit circuitcompiler.Circuit, pk *snark.Pk) (*gosnarkhip.R1CS, error) {
+	id, err := idOf(pk)
+	if err != nil {
+		return nil, err
+	}
+	mu.Lock()
+	defer mu.Unlock()
+	e, ok := keys[id]
+	if !ok {
+		return nil, errors.New("snarkhip: key not resident")
+	}
+	if e.r1cs != nil {
+		return e.r1cs, nil
+	}
+	if len(circuit.R1CS.A) == 0 {
+		return nil, errors.New("snarkhip: the circuit carries no R1CS (call circuit.GenerateR1CS first)")
+	}
+	order := snark.Utils.FqR.Q
+	ca, nvars, err := gosnarkhip.CSRFromDense(circuit.R1CS.A, order)
+	if err != nil {
+		return nil, err
+	}
+	cb, _, err := gosnarkhip.CSRFromDense(circuit.R1CS.B, order)
+	if err != nil {
+		return nil, err
+	}
+	cc, _, err := gosnarkhip.CSRFromDense(circuit.R1CS.C, order)
+	if err != nil {
+		return nil, err
+	}
+	e.r1cs, err = gosnarkhip.UploadR1CS(Device, ca, cb, cc, nvars)
+	return e.r1cs, err
 }
 
 // GenerateTrustedSetup has the reference's signature (snark.go:98-251): toxic values drawn as the reference draws them

@@ -289,6 +289,9 @@ int gs_pinocchio_prove(gs_handle pk, const uint64_t* w, size_t nw, const uint64_
                        uint64_t out_proof[72], int inf[8]);
 /* Same with w and px already resident (gs_scalars_upload); what bench.py --workload prove_pinocchio times. */
 int gs_pinocchio_prove_resident(gs_handle pk, gs_handle w, gs_handle px, uint64_t out_proof[72], int inf[8]);
+/* snark.GenerateProofs from the witness alone (the Pinocchio twin of gs_groth16_prove_witness): H(x) straight from the constraint
+ * values of the resident R1CS, no px; a witness that violates a constraint takes the exact px route (same result as the reference). */
+int gs_pinocchio_prove_witness(gs_handle pk, gs_handle r1cs, gs_handle w, uint64_t out_proof[72], int inf[8]);
 /* Pipelined Pinocchio proving: same tickets as gs_groth16_prove_begin / _end (the three in-flight slots are shared between
  * Groth16 proofs, Pinocchio proofs and MSMs). */
 int gs_pinocchio_prove_begin(gs_handle pk, gs_handle w, gs_handle px, uint64_t* ticket);
@@ -359,6 +362,27 @@ typedef struct {
 } gs_timing;
 int gs_last_timing(gs_timing* out);                         /* the calling thread's current logical device */
 int gs_device_timing(int logical_device, gs_timing* out);
+
+/* ---- device memory: accounting and eviction ---------------------------------------------------------------------------
+ * The window tables (rows 2^(c j) P_i of every base array, built on a handle's first proof / MSM) are 15x the key data at
+ * c = 17: 5.6 GiB per 2^20-constraint Groth16 key.  A host that keeps several keys resident can see what each one costs and
+ * drop the tables of the idle ones; they are rebuilt on the handle's next use (~140 ms per 2^20 Groth16 key). */
+typedef struct {
+  uint64_t device_total_bytes, device_free_bytes;   /* hipMemGetInfo of the current logical device's GPU */
+  uint64_t library_bytes;     /* every device byte this library holds, all logical devices of the process */
+  uint64_t object_bytes;      /* the current logical device's handles: base arrays, keys (with their divisor caches), scalars, R1CS */
+  uint64_t table_bytes;       /* window tables of those handles */
+  uint64_t workspace_bytes;   /* bucket sets, chunk partials, result staging, fixed-base tables (plan / polynomial caches: in library_bytes) */
+  uint64_t objects;           /* live handles on the current logical device */
+  uint64_t reserved;
+} gs_memory;
+int gs_memory_query(gs_memory* out);
+int gs_handle_bytes(gs_handle h, uint64_t* object_bytes, uint64_t* table_bytes);     /* either pointer may be NULL */
+/* Free the window tables of a key or base array (queues behind outstanding tickets); results of later calls are unchanged. */
+int gs_release_tables(gs_handle h);
+/* Free every cached workspace of the current logical device (bucket sets, plan buffers, NTT twiddles, node trees, factorial
+ * tables); rebuilt on demand.  Handles and their tables stay. */
+int gs_trim(void);
 
 /* Tunables (0 = automatic): Pippenger window bits. */
 int gs_set_window_bits(int c);

@@ -141,3 +141,26 @@ def test_prove_batch_c_sequence_two_logical_devices(tmp_path):
     """go/gosnarkhip.ProveBatch == tests/c/batch_devices.c."""
     blob = c_util.write_groth_instance(tmp_path, GU.load("groth_x3"))
     assert c_util.build_and_run("batch_devices.c", [str(blob)], tmp_path).strip().endswith("OK")
+
+
+def test_memory_eviction_c_sequence(tmp_path):
+    """go/gosnarkhip.MemoryOf / HandleBytes / ReleaseTables / Trim == tests/c/memory_eviction.c."""
+    blob = c_util.write_groth_instance(tmp_path, GU.load("groth_x3"))
+    assert c_util.build_and_run("memory_eviction.c", [str(blob)], tmp_path).strip().endswith("OK")
+
+
+def test_witness_to_proof_c_sequence_reproduces_both_reference_proofs(tmp_path):
+    """go/groth16hip.GenerateProofsFromWitness + go/snarkhip.GenerateProofsFromWitness == tests/c/witness_to_proof.c: the x^3+x+5
+    circuit's sparse R1CS resident, then witness -> proof on the device for both protocols; px equals the reference's
+    CombinePolynomials output and the proofs are the reference prover's (wasm goldens)."""
+    g, p = GU.load("groth_x3"), GU.load("pinocchio_x3_setup")
+    gblob = c_util.write_groth_instance(tmp_path, g)
+    pblob = c_util.write_pinocchio_instance(tmp_path, p)
+    r1cs = c_util.write_r1cs(tmp_path, (O.X3_R1CS_A, O.X3_R1CS_B, O.X3_R1CS_C), 1, [])
+    out = tmp_path / "proofs.bin"
+    assert c_util.build_and_run("witness_to_proof.c", [str(r1cs), str(gblob), str(pblob), str(out)], tmp_path).strip() == "OK"
+    raw = c_util.read_words(out)
+    assert words(raw[:32]) == aff1(g["proof"]["PiA"]) + aff2(g["proof"]["PiB"]) + aff1(g["proof"]["PiC"])
+    pr = p["proof"]
+    assert words(raw[32:104]) == aff1(pr["PiA"]) + aff1(pr["PiAp"]) + aff2(pr["PiB"]) + aff1(pr["PiBp"]) + aff1(pr["PiC"]) + \
+        aff1(pr["PiCp"]) + aff1(pr["PiH"]) + aff1(pr["PiKp"])

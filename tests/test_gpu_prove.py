@@ -834,3 +834,66 @@ def test_witness_to_proof_falls_back_to_the_exact_quotient_for_a_violated_constr
     got = groth16.prove_from_witness(inst.device_pk(), dev, wh, r, s)
     assert (got.PiA, got.PiB, got.PiC) == (want.PiA, want.PiB, want.PiC)
     assert not groth16.VerifyProof(inst.vk, got, capi.u64_to_ints(w_bad[1:2]))
+
+
+def test_memory_accounting_and_table_eviction_leave_results_unchanged():
+    """gs_memory_query / gs_handle_bytes see a key's window tables (W - ... rows per base array, many times the key data);
+    gs_release_tables frees them (device memory comes back) and the next proof rebuilds them; gs_trim drops every cached
+    workspace; the proof is the same before and after both, and an in-flight ticket is waited for, not broken."""
+    from gosnark_amd import synth
+    n = 1 << 12
+    inst = synth.sqchain_setup_instance(n, 0x5A00)
+    pk = inst.device_pk()
+    r, s = synth.field_elems(2, 777)
+    want = groth16.prove_resident(pk, inst.w, inst.px, r, s)
+    obj_b, tab_b = capi.handle_bytes(pk.handle.h)
+    key_points = 4 * (n + 1) * 64 + (n + 1) * 128              # 4 G1 arrays + 1 G2 array of about m entries, packed affine
+    assert obj_b >= key_points - 4 * 64 * 8 and tab_b >= 8 * obj_b // 2        # tables: >= 8 rows of every array
+    t = groth16.prove_begin(pk, inst.w, inst.px, r, s)          # a ticket in flight reads the tables: release must queue behind it
+    before = capi.memory_query()
+    assert before["table_bytes"] >= tab_b and before["library_bytes"] >= before["table_bytes"] + before["object_bytes"]
+    assert before["device_total_bytes"] > before["device_free_bytes"] > 0 and before["objects"] >= 1
+    capi.release_tables(pk.handle.h)
+    assert capi.handle_bytes(pk.handle.h) == (obj_b, 0)
+    after = capi.memory_query()
+    assert after["table_bytes"] == before["table_bytes"] - tab_b
+    assert after["library_bytes"] <= before["library_bytes"] - tab_b
+    got_t = groth16.prove_end(t)
+    assert (got_t.PiA, got_t.PiB, got_t.PiC) == (want.PiA, want.PiB, want.PiC)
+    got = groth16.prove_resident(pk, inst.w, inst.px, r, s)     # rebuilds the tables
+    assert (got.PiA, got.PiB, got.PiC) == (want.PiA, want.PiB, want.PiC)
+    assert capi.handle_bytes(pk.handle.h)[1] == tab_b
+    capi.trim()
+    trimmed = capi.memory_query()
+    assert trimmed["workspace_bytes"] == 0 and trimmed["library_bytes"] < capi.memory_query()["library_bytes"] + 1
+    got = groth16.prove_resident(pk, inst.w, inst.px, r, s)
+    assert (got.PiA, got.PiB, got.PiC) == (want.PiA, want.PiB, want.PiC)
+    bases = capi.g1_fixed_base(synth.scalars_u64(1 << 10, 5))
+    sc = capi.scalars_upload(synth.scalars_u64(1 << 10, 6))
+    p0 = capi.msm_resident(bases, sc, 1 << 10)
+    assert capi.handle_bytes(bases)[1] > 0
+    capi.release_tables(bases)
+    assert capi.handle_bytes(bases)[1] == 0 and capi.msm_resident(bases, sc, 1 << 10) == p0
+
+
+@pytest.mark.parametrize("n,extra", [(16, 0), (300, 0), (300, 1), (1 << 12, 0), (1 << 12, 1), (1 << 16, 0)])
+def test_pinocchio_witness_to_proof_without_px_equals_the_px_route(n, extra):
+    """gs_pinocchio_prove_witness (snark.GenerateProofs with H(x) straight from the constraint values) gives the eight elements of
+    gs_r1cs_px + gs_pinocchio_prove_resident, for both Z shapes (m = n + 1 / n + 2) and ragged sizes, and the five pairing
+    equations accept it; a violated constraint takes the exact quotient route (same meaningless proof as the px route)."""
+    from gosnark_amd import synth
+    inst = synth.sqchain_pinocchio_instance(n, 0x5B00 + n % 97, extra_vars=extra)
+    dev = r1csqap.DeviceR1CS(*inst.r1cs, inst.m)
+    want = snark.prove_resident(inst.device_pk(), inst.w, inst.px)
+    got = snark.prove_from_witness(inst.device_pk(), dev, inst.w)
+    assert all(getattr(got, k) == getattr(want, k) for k in snark.Proof.FIELDS)
+    if n <= (1 << 12):
+        assert snark.VerifyProof(inst.vk, got, inst.public) is True
+    if n == 300:
+        w_bad = inst.w_host.copy()
+        w_bad[9] = (777, 0, 0, 0)
+        _, _, _, px_bad = r1csqap.ComputePx(*inst.r1cs, w_bad, inst.m)
+        wh, pxh = capi.scalars_upload(w_bad), capi.scalars_upload(px_bad)
+        want_bad = snark.prove_resident(inst.device_pk(), wh, pxh)
+        got_bad = snark.prove_from_witness(inst.device_pk(), dev, wh)
+        assert all(getattr(got_bad, k) == getattr(want_bad, k) for k in snark.Proof.FIELDS)
