@@ -462,9 +462,14 @@ GS_HD Xyzz<T> load_bucket(const AccJob& job, const uint32_t* __restrict__ offset
 }
 
 // one block per heavy bucket (grid-stride over the device-side list): tails[first..last) + heads[last] -> buckets[b]
+// Registers of the reduction-tail kernels: left alone the Fq2 instances take 256 VGPRs + 59..133 AGPRs = ONE wave per SIMD, and
+// such a wave cannot share a SIMD with any accumulation wave (160 / 256 registers each of 512).  GS_TAIL_WAVES = 2 caps them at 256.
+#ifndef GS_TAIL_WAVES
+#define GS_TAIL_WAVES 1
+#endif
 constexpr int kHeavyBlock = 128;
 template <class T>
-__global__ void __launch_bounds__(kHeavyBlock) k_heavy_combine(AccJobs jobs, const uint32_t* __restrict__ offsets,
+__global__ void __launch_bounds__(kHeavyBlock, GS_TAIL_WAVES) k_heavy_combine(AccJobs jobs, const uint32_t* __restrict__ offsets,
                                                                 const uint32_t* __restrict__ heavy_list,
                                                                 const uint32_t* __restrict__ heavy_count, uint32_t chunk) {
   constexpr int pw = PointIO<T>::kXyzzWords;
@@ -499,7 +504,7 @@ __global__ void __launch_bounds__(kHeavyBlock) k_heavy_combine(AccJobs jobs, con
 // digit positions share one bucket set, so the MSM is simply sum_b (b + 1) * merged[b]: no per-window
 // reduction and no Horner recombination.
 template <class T>
-__global__ void __launch_bounds__(256) k_bucket_combine(AccJobs jobs, const uint32_t* __restrict__ offsets, uint32_t B, uint32_t chunk) {
+__global__ void __launch_bounds__(256, GS_TAIL_WAVES) k_bucket_combine(AccJobs jobs, const uint32_t* __restrict__ offsets, uint32_t B, uint32_t chunk) {
   const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   const AccJob job = jobs.j[blockIdx.y];
@@ -513,7 +518,7 @@ __global__ void __launch_bounds__(256) k_bucket_combine(AccJobs jobs, const uint
 // (at most 16) pairs: result = sum_blk A_blk + 256 L * sum_blk blk * S_blk.
 constexpr int kReduceBlock = 256;
 template <class T>
-__global__ void __launch_bounds__(kReduceBlock) k_block_reduce(AccJobs jobs, uint32_t B, int L) {
+__global__ void __launch_bounds__(kReduceBlock, GS_TAIL_WAVES) k_block_reduce(AccJobs jobs, uint32_t B, int L) {
   constexpr int pw = PointIO<T>::kXyzzWords;
   __shared__ uint32_t sh[kReduceBlock * pw];
   const AccJob job = jobs.j[blockIdx.y];
@@ -564,7 +569,7 @@ __global__ void __launch_bounds__(kReduceBlock) k_block_reduce(AccJobs jobs, uin
 // again (sum_blk blk * S_blk = sum_{blk >= 1} R_blk with R_blk = sum_{b' >= blk} S_b'), then log2(256 L) doublings -- so the
 // host receives ONE point per job however many buckets there were.
 template <class T>
-__global__ void __launch_bounds__(kReduceBlock) k_pair_reduce(AccJobs jobs, uint32_t nblk, int log2_span) {
+__global__ void __launch_bounds__(kReduceBlock, GS_TAIL_WAVES) k_pair_reduce(AccJobs jobs, uint32_t nblk, int log2_span) {
   constexpr int pw = PointIO<T>::kXyzzWords;
   __shared__ uint32_t sh[kReduceBlock * pw];
   const AccJob job = jobs.j[blockIdx.y];
