@@ -94,6 +94,30 @@ GS_HD Xyzz<T> xyzz_inf() {
   return r;
 }
 
+// acc = infinity in the G1 mixed addition: on the device the zeros come out of an opaque one-instruction asm INSIDE the rare
+// branch.  A plain `acc = xyzz_inf()` makes the compiler materialise the 36 `v_mov v, 0` (phi inputs of the merged accumulator) on
+// the common path of every addition, in front of the branch -- twice: 72 of 2292 instructions.  Measured in one run
+// (profiles/r02_ab_opaque_infinity.txt): G1 accumulations 5.11 -> 4.98 ms per proof.  The Fq2 instance and the general addition of
+// the tails keep the plain form: there the same change moved spills around and LOST (G2 3.78 -> 3.94 ms, tails 7.6 -> 8.4 ms).
+#ifndef GS_OPAQUE_INF
+#define GS_OPAQUE_INF 1
+#endif
+template <class M, int B> GS_HD void fill_limbs(Fe<M, B>& a, uint32_t z) {
+#pragma unroll
+  for (int i = 0; i < NL; ++i) a.l[i] = z;
+}
+template <int B> GS_HD void fill_limbs(Fq2e<B>& a, uint32_t z) { fill_limbs(a.c0, z); fill_limbs(a.c1, z); }
+template <class T>
+GS_HD void xyzz_set_inf(Xyzz<T>& a) {
+#if defined(__HIP_DEVICE_COMPILE__) && GS_OPAQUE_INF
+  uint32_t z;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+  fill_limbs(a.x, z); fill_limbs(a.y, z); fill_limbs(a.zz, z); fill_limbs(a.zzz, z);
+#else
+  a = xyzz_inf<T>();
+#endif
+}
+
 template <class T>
 GS_HD Xyzz<T> xyzz_from_affine(const Affine<T>& a) {
   if (is_inf(a)) return xyzz_inf<T>();
@@ -140,6 +164,7 @@ GS_HD void xyzz_madd(Xyzz<T>& acc, const Affine<T>& b, bool negate = false) {
   auto R = sub(S2, acc.y);                              // 2 + 5 + 1 = 8
   if (is_zero(P)) {
     if (is_zero(R)) acc = xyzz_dbl_affine<T>(b.x, y2);
+    else if constexpr (T::kWords == 8) xyzz_set_inf(acc);
     else acc = xyzz_inf<T>();
     return;
   }
