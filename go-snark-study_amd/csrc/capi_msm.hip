@@ -4,6 +4,7 @@
 #include <vector>
 
 #include "msm.h"
+#include "hostcopy.h"
 #include "point_io.h"
 #include "poly.h"
 #include "prove.h"
@@ -193,7 +194,7 @@ int msm_host_scalars(Ctx& c, Kind kind, gs_handle hb, const uint64_t* scalars, s
   c.ws_misc.ensure(std::max<size_t>(n, 1) * 32);
   if (n) {
     PhaseTimer th(c.stream);
-    GS_HIP(hipMemcpyAsync(c.ws_misc.p, scalars, n * 32, hipMemcpyHostToDevice, c.stream));
+    staged_h2d(c, c.ws_misc.p, scalars, n * 32, c.stream);
     th.stop();
     c.timing.h2d_ms += th.ms();
   }
@@ -269,6 +270,13 @@ static void ctx_destroy(Ctx& c) {
   for (auto& pp : c.pinned) {
     if (pp) (void)hipHostFree(pp);
     pp = nullptr;
+  }
+  if (c.copy_stream) (void)hipStreamDestroy(c.copy_stream);
+  c.copy_stream = nullptr;
+  for (int b = 0; b < Ctx::kStageBuffers; ++b) {
+    if (c.stage[b]) (void)hipHostFree(c.stage[b]);
+    if (c.stage_ev[b]) (void)hipEventDestroy(c.stage_ev[b]);
+    c.stage[b] = nullptr; c.stage_ev[b] = nullptr;
   }
   for (auto& b : c.ws_buckets) b.release();
   for (auto& b : c.ws_chunks) b.release();
@@ -399,7 +407,11 @@ int gs_scalars_upload(const uint64_t* s, size_t n, gs_handle* out) {
     auto o = std::make_unique<Scalars>();
     o->n = n;
     o->buf.alloc(std::max<size_t>(n, 1) * 32);
-    if (n) GS_HIP(hipMemcpy(o->buf.p, s, n * 32, hipMemcpyHostToDevice));
+    if (n) {                       // own stream: an upload must not queue behind the accumulations of outstanding tickets
+      if (!c.copy_stream) GS_HIP(hipStreamCreateWithFlags(&c.copy_stream, hipStreamNonBlocking));
+      staged_h2d(c, o->buf.p, s, n * 32, c.copy_stream);
+      GS_HIP(hipStreamSynchronize(c.copy_stream));
+    }
     *out = c.put(std::move(o));
     return GS_OK;
   }, true, true);

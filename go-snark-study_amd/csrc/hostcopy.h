@@ -1,0 +1,100 @@
+// Host -> device copies from PAGEABLE caller memory (the reference's signatures hand over plain Go slices).  hipMemcpyAsync from
+// pageable memory stages through the runtime on the calling thread at ~12 GB/s; here the staging is ours: a few persistent host
+// threads memcpy 4 MiB pieces into pinned buffers (each context owns two) while the previous piece's DMA is in flight.
+#pragma once
+#include <atomic>
+#include <condition_variable>
+#include <cstring>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#include "runtime.h"
+
+namespace gs {
+
+class HostCopyPool {                       // process-wide; workers sleep on a condition variable between jobs
+ public:
+  static HostCopyPool& get() {
+    static HostCopyPool* p = new HostCopyPool();       // leaked on purpose: worker threads must not be joined from a static destructor
+    return *p;
+  }
+  // dst[0..n) = src[0..n), split over the workers and the calling thread; returns when every byte has been copied
+  void copy(void* dst, const void* src, size_t n) {
+    if (n < (256u << 10) || workers_.empty()) { memcpy(dst, src, n); return; }
+    std::lock_guard<std::mutex> one_job(job_mu_);
+    const size_t parts = workers_.size() + 1;
+    const size_t piece = ((n + parts - 1) / parts + 4095) & ~size_t(4095);
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      dst_ = static_cast<char*>(dst); src_ = static_cast<const char*>(src); n_ = n; piece_ = piece;
+      next_.store(0); left_ = (n + piece - 1) / piece; ++generation_;
+    }
+    cv_.notify_all();
+    run_pieces();
+    std::unique_lock<std::mutex> lk(mu_);
+    done_cv_.wait(lk, [&] { return left_ == 0; });
+  }
+
+ private:
+  HostCopyPool() {
+    unsigned hw = std::thread::hardware_concurrency();
+    const char* env = getenv("GS_COPY_THREADS");
+    int want = env ? atoi(env) : 4;
+    if (hw && (unsigned)want > hw) want = (int)hw;
+    for (int i = 1; i < want; ++i) workers_.emplace_back([this] { loop(); });
+    for (auto& t : workers_) t.detach();
+  }
+  void run_pieces() {
+    for (;;) {
+      const size_t i = next_.fetch_add(1);
+      const size_t off = i * piece_;
+      if (off >= n_) return;
+      memcpy(dst_ + off, src_ + off, std::min(piece_, n_ - off));
+      std::lock_guard<std::mutex> lk(mu_);
+      if (--left_ == 0) done_cv_.notify_all();
+    }
+  }
+  void loop() {
+    uint64_t seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return generation_ != seen; });
+        seen = generation_;
+      }
+      run_pieces();
+    }
+  }
+  std::vector<std::thread> workers_;
+  std::mutex job_mu_, mu_;
+  std::condition_variable cv_, done_cv_;
+  char* dst_ = nullptr;
+  const char* src_ = nullptr;
+  size_t n_ = 0, piece_ = 1, left_ = 0;
+  std::atomic<size_t> next_{0};
+  uint64_t generation_ = 0;
+};
+
+// Enqueue dst_dev[0..bytes) = src_host[0..bytes) on `stream`; returns when the LAST piece has been staged (its DMA may still be in
+// flight: it is ordered on the stream like any other operation).  The caller holds the context lock.
+inline void staged_h2d(Ctx& c, void* dst_dev, const void* src_host, size_t bytes, hipStream_t stream) {
+  if (bytes < (1u << 20)) { GS_HIP(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, stream)); return; }
+  for (int b = 0; b < Ctx::kStageBuffers; ++b) {
+    if (!c.stage[b]) GS_HIP(hipHostMalloc(&c.stage[b], Ctx::kStageBytes, hipHostMallocDefault));
+    if (!c.stage_ev[b]) GS_HIP(hipEventCreateWithFlags(&c.stage_ev[b], hipEventDisableTiming));
+  }
+  HostCopyPool& pool = HostCopyPool::get();
+  size_t off = 0;
+  for (int i = 0; off < bytes; ++i) {
+    const int b = i % Ctx::kStageBuffers;
+    const size_t len = std::min(Ctx::kStageBytes, bytes - off);
+    GS_HIP(hipEventSynchronize(c.stage_ev[b]));                     // the DMA that last read this buffer (no-op on a fresh event)
+    pool.copy(c.stage[b], static_cast<const char*>(src_host) + off, len);
+    GS_HIP(hipMemcpyAsync(static_cast<char*>(dst_dev) + off, c.stage[b], len, hipMemcpyHostToDevice, stream));
+    GS_HIP(hipEventRecord(c.stage_ev[b], stream));
+    off += len;
+  }
+}
+
+}  // namespace gs

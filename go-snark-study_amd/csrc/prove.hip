@@ -10,6 +10,7 @@
 #include <future>
 #include <vector>
 
+#include "hostcopy.h"
 #include "point_io.h"
 
 using namespace gs;
@@ -150,13 +151,29 @@ int groth16_enqueue(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, const S
     st.tplanw->stop();
     GS_HIP(hipEventRecord(st.planw, c.stream));
   }
+  // Host order: the accumulations over w are enqueued BEFORE the block that may copy px from pageable host memory -- that copy
+  // stages through the runtime inside the call (~5 ms for 64 MiB), and the device must already have its 7 ms of work by then.
+  {                                                              // main: the accumulations over w, back to back
+    StreamScope sc(c, c.main_stream);
+    GS_HIP(hipStreamWaitEvent(c.stream, st.planw, 0));
+    // BACDelta's first npublic+1 entries are forced to infinity at key creation, so the reference's
+    // loop from NPublic+1 (:248-250) equals a full-range MSM sharing w's plan.
+    // G2 first: its accumulation (2 waves/SIMD, 256 VGPRs) is the one a foreign wave hurts most, and its long
+    // combine/reduce tail then hides behind the G1 accumulations.
+    if (pipelined) c.next_tails(plan_w.n);
+    msm_enqueue_g2(c, plan_w, {MsmBase{&pk->t_bacgamma2, wbase}}, ws + 4, pin + 1, st.pend_g2w, c.tail_stream(0));
+    GS_HIP(hipEventRecord(st.done_g2, c.tail_stream(0)));
+    msm_enqueue_g1(c, plan_w, {MsmBase{&pk->t_at, wbase}, MsmBase{&pk->t_bacgamma1, wbase}, MsmBase{&pk->t_bacdelta, wbase}}, ws + 0, pin + 0,
+                   st.pend_g1w, c.tail_stream(1));
+    GS_HIP(hipEventRecord(st.done_g1w, c.tail_stream(1)));
+  }
   // (Starting H(x) and plan(h) of a lone proof beside plan(w) on another stream instead of behind it was tried: the blocking proof
   // got SLOWER, 11.5-11.7 vs 11.0-11.25 ms -- the NTT passes then overlap the G2 accumulation's first milliseconds more densely.)
   {                                                              // aux 1 again: (late upload of px,) H(x), plan(h)
     StreamScope sc(c, c.aux_stream[1]);
     if (px.host && px.n) {     // the device is already busy with ~8 ms of accumulations: this copy is off the critical path
       PhaseTimer th(c.stream);
-      GS_HIP(hipMemcpyAsync(const_cast<uint32_t*>(px.p), px.host, px.n * 32, hipMemcpyHostToDevice, c.stream));
+      staged_h2d(c, const_cast<uint32_t*>(px.p), px.host, px.n * 32, c.stream);
       th.stop();
       c.timing.h2d_ms += th.ms();
     }
@@ -172,20 +189,6 @@ int groth16_enqueue(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, const S
     build_plan(c, 1 + 2 * parity, hxbuf.as<uint32_t>() + hlo * 8, (uint32_t)(hhi - hlo), plan_h, {{1, false}});
     st.tplanh->stop();
     GS_HIP(hipEventRecord(st.planh, c.stream));
-  }
-  {                                                              // main: the accumulations over w, back to back
-    StreamScope sc(c, c.main_stream);
-    GS_HIP(hipStreamWaitEvent(c.stream, st.planw, 0));
-    // BACDelta's first npublic+1 entries are forced to infinity at key creation, so the reference's
-    // loop from NPublic+1 (:248-250) equals a full-range MSM sharing w's plan.
-    // G2 first: its accumulation (2 waves/SIMD, 256 VGPRs) is the one a foreign wave hurts most, and its long
-    // combine/reduce tail then hides behind the G1 accumulations.
-    if (pipelined) c.next_tails(plan_w.n);
-    msm_enqueue_g2(c, plan_w, {MsmBase{&pk->t_bacgamma2, wbase}}, ws + 4, pin + 1, st.pend_g2w, c.tail_stream(0));
-    GS_HIP(hipEventRecord(st.done_g2, c.tail_stream(0)));
-    msm_enqueue_g1(c, plan_w, {MsmBase{&pk->t_at, wbase}, MsmBase{&pk->t_bacgamma1, wbase}, MsmBase{&pk->t_bacdelta, wbase}}, ws + 0, pin + 0,
-                   st.pend_g1w, c.tail_stream(1));
-    GS_HIP(hipEventRecord(st.done_g1w, c.tail_stream(1)));
   }
   {                                                              // main again: the accumulation over h
     StreamScope sc(c, c.main_stream);
@@ -434,7 +437,7 @@ const uint32_t* upload_tmp(Ctx& c, DevBuf& buf, const uint64_t* host, size_t n) 
   buf.ensure(std::max<size_t>(n, 1) * 32);
   if (n) {
     PhaseTimer th(c.stream);
-    GS_HIP(hipMemcpyAsync(buf.p, host, n * 32, hipMemcpyHostToDevice, c.stream));
+    staged_h2d(c, buf.p, host, n * 32, c.stream);
     th.stop();
     c.timing.h2d_ms += th.ms();
   }

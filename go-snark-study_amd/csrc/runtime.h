@@ -136,6 +136,11 @@ struct Ctx {
   static constexpr int kSlots = kMaxInFlight + 1;    // + one set for the blocking entry points (serialised by `mu`), so a blocking
   static constexpr int kBlockingSlot = kMaxInFlight; //   call made while tickets are outstanding never touches their result staging
   void* pinned[3 * kSlots] = {};                     // host staging of the result downloads (3 per slot)
+  static constexpr int kStageBuffers = 2;            // pinned staging of uploads from pageable caller memory (hostcopy.h), lazy
+  static constexpr size_t kStageBytes = 4u << 20;
+  void* stage[kStageBuffers] = {};
+  hipEvent_t stage_ev[kStageBuffers] = {};
+  hipStream_t copy_stream = nullptr;                 // gs_scalars_upload (lazy)
   std::unique_ptr<InFlightBase> inflight[kMaxInFlight];
   uint64_t next_ticket = 1;
   // Consecutive pipelined operations swap the two tail streams: the reduction tails are chains of dependent point additions
