@@ -365,6 +365,12 @@ int pinocchio_enqueue(Ctx& c, PinocchioPkObj* pk, DevScalars w, DevScalars px, i
   }
   {                                                              // aux 1 again: H(x), plan(h)
     StreamScope sc(c, c.aux_stream[1]);
+    if (px.host && px.n) {     // the accumulations over w are already enqueued: this copy is off the critical path
+      PhaseTimer th(c.stream);
+      staged_h2d(c, const_cast<uint32_t*>(px.p), px.host, px.n * 32, c.stream);
+      th.stop();
+      c.timing.h2d_ms += th.ms();
+    }
     st.tpoly = std::make_shared<PhaseTimer>(c.stream);
     bool have_hx = false;
     if (px.produce_hx && nh) have_hx = px.produce_hx(c, hxbuf.as<uint32_t>());   // H from the constraint values (satisfying witness)
@@ -816,7 +822,8 @@ int gs_pinocchio_prove(gs_handle hpk, const uint64_t* w, size_t nw, const uint64
     if (!w || !px || !out_proof || !inf) return fail(GS_ERR_ARG, "null argument");
     reset_timing(c);
     DevScalars dw{upload_tmp(c, prove_state(c).up_w, w, nw), nw};
-    DevScalars dp{upload_tmp(c, prove_state(c).up_px, px, npx), npx};
+    prove_state(c).up_px.ensure(std::max<size_t>(npx, 1) * 32);
+    DevScalars dp{prove_state(c).up_px.as<uint32_t>(), npx, px};               // copied inside, behind the work that only needs w
     return pinocchio_prove_impl(c, pk, dw, dp, out_proof, inf);
   }, true, false, hpk);
 }
