@@ -24,14 +24,18 @@ class HostCopyPool {                       // process-wide; workers sleep on a c
     if (n < (256u << 10) || workers_.empty()) { memcpy(dst, src, n); return; }
     std::lock_guard<std::mutex> one_job(job_mu_);
     const size_t parts = workers_.size() + 1;
-    const size_t piece = ((n + parts - 1) / parts + 4095) & ~size_t(4095);
+    Job j;
+    j.dst = static_cast<char*>(dst); j.src = static_cast<const char*>(src); j.n = n;
+    j.piece = ((n + parts - 1) / parts + 4095) & ~size_t(4095);
     {
       std::lock_guard<std::mutex> lk(mu_);
-      dst_ = static_cast<char*>(dst); src_ = static_cast<const char*>(src); n_ = n; piece_ = piece;
-      next_.store(0); left_ = (n + piece - 1) / piece; ++generation_;
+      j.gen = ++generation_;
+      job_ = j;
+      left_ = (n + j.piece - 1) / j.piece;
+      next_.store(j.gen << 32);                       // the piece counter carries its job: a late worker of job g - 1 cannot take a piece of g
     }
     cv_.notify_all();
-    run_pieces();
+    run_pieces(j);
     std::unique_lock<std::mutex> lk(mu_);
     done_cv_.wait(lk, [&] { return left_ == 0; });
   }
@@ -45,12 +49,16 @@ class HostCopyPool {                       // process-wide; workers sleep on a c
     for (int i = 1; i < want; ++i) workers_.emplace_back([this] { loop(); });
     for (auto& t : workers_) t.detach();
   }
-  void run_pieces() {
+  struct Job { char* dst = nullptr; const char* src = nullptr; size_t n = 0, piece = 1; uint64_t gen = 0; };
+  void run_pieces(const Job& j) {
     for (;;) {
-      const size_t i = next_.fetch_add(1);
-      const size_t off = i * piece_;
-      if (off >= n_) return;
-      memcpy(dst_ + off, src_ + off, std::min(piece_, n_ - off));
+      uint64_t ticket = next_.load();
+      do {
+        if ((ticket >> 32) != j.gen) return;           // another job owns the counter by now: do not touch it
+      } while (!next_.compare_exchange_weak(ticket, ticket + 1));
+      const size_t off = (size_t)(ticket & 0xffffffffu) * j.piece;
+      if (off >= j.n) return;
+      memcpy(j.dst + off, j.src + off, std::min(j.piece, j.n - off));
       std::lock_guard<std::mutex> lk(mu_);
       if (--left_ == 0) done_cv_.notify_all();
     }
@@ -58,21 +66,22 @@ class HostCopyPool {                       // process-wide; workers sleep on a c
   void loop() {
     uint64_t seen = 0;
     for (;;) {
+      Job j;
       {
         std::unique_lock<std::mutex> lk(mu_);
         cv_.wait(lk, [&] { return generation_ != seen; });
         seen = generation_;
+        j = job_;
       }
-      run_pieces();
+      run_pieces(j);
     }
   }
   std::vector<std::thread> workers_;
   std::mutex job_mu_, mu_;
   std::condition_variable cv_, done_cv_;
-  char* dst_ = nullptr;
-  const char* src_ = nullptr;
-  size_t n_ = 0, piece_ = 1, left_ = 0;
-  std::atomic<size_t> next_{0};
+  Job job_;
+  size_t left_ = 0;
+  std::atomic<uint64_t> next_{0};
   uint64_t generation_ = 0;
 };
 

@@ -85,3 +85,13 @@ def test_is_zero_exact(exe, f):
         lines.append("%s iszero %x %x %x 0" % (f, a, b, c))
         want.append(("1" if a == b else "0") + ("1" if (a + b - c) % p == 0 else "0"))
     assert hostbuild.run_lines(exe, lines) == want
+
+
+def test_host_copy_pool_copies_every_byte():
+    """go-snark-study_amd/csrc/hostcopy.h: the persistent host threads that fill the pinned staging buffers of uploads from
+    pageable memory -- 6000 back-to-back jobs around the threshold and up to 8 MiB, odd offsets; a late worker of job g - 1 must
+    neither take nor skip a piece of job g."""
+    import subprocess
+    exe = hostbuild.build("hostcopy_test")
+    out = subprocess.run([exe, "6000"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.startswith("OK"), out.stdout + out.stderr
