@@ -99,6 +99,13 @@ GS_HD Xyzz<T> xyzz_inf() {
 // the common path of every addition, in front of the branch -- twice: 72 of 2292 instructions.  Measured in one run
 // (profiles/r02_ab_opaque_infinity.txt): G1 accumulations 5.11 -> 4.98 ms per proof.  The Fq2 instance and the general addition of
 // the tails keep the plain form: there the same change moved spills around and LOST (G2 3.78 -> 3.94 ms, tails 7.6 -> 8.4 ms).
+// Which steps of the G2 mixed addition run two Fq2 products at once (four interleaved column chains) instead of one after the
+// other (two chains): bit 0 U2|S2, bit 1 P^2|R^2, bit 2 P^3|Q, bit 3 ZZ3|ZZZ3.  Four chains fill more issue slots but hold more
+// registers in a kernel that sits at 256 VGPRs and spills: all four steps (15) leave 112 B per lane in scratch, 9 leaves 36 B and
+// measured 1-1.5 % faster (profiles/r02_ab_g2_chain_mask.txt); P^3|Q is the step that costs the registers.
+#ifndef GS_G2_MASK
+#define GS_G2_MASK 9
+#endif
 #ifndef GS_OPAQUE_INF
 #define GS_OPAQUE_INF 1
 #endif
@@ -158,7 +165,8 @@ GS_HD void xyzz_madd(Xyzz<T>& acc, const Affine<T>& b, bool negate = false) {
   }
   typename T::template E<2> U2, S2;
   if constexpr (GS_PAIR != 0 && T::kWords == 8) dots2<ModQ>(dot_of(b.x, acc.zz), dot_of(y2, acc.zzz), U2, S2);
-  else if constexpr (GS_PAIR != 0) mul2(b.x, acc.zz, y2, acc.zzz, U2, S2);
+  else if constexpr (GS_PAIR != 0 && (GS_G2_MASK & 1) != 0) mul2(b.x, acc.zz, y2, acc.zzz, U2, S2);
+  else if constexpr (GS_PAIR != 0) { U2 = mul(b.x, acc.zz); S2 = mul(y2, acc.zzz); }
   else { U2 = smul<T>(b.x, acc.zz); S2 = smul<T>(y2, acc.zzz); }
   auto P = sub(U2, acc.x);                              // 2 + 9 + 1 = 12
   auto R = sub(S2, acc.y);                              // 2 + 5 + 1 = 8
@@ -184,11 +192,14 @@ GS_HD void xyzz_madd(Xyzz<T>& acc, const Affine<T>& b, bool negate = false) {
     // G2: two Fq2 products at a time = four chains (both coordinates of both): P^2 | R^2, P^3 | Q, ZZ3 | ZZZ3
     typename T::template E<2> PP, RR, PPP, Q, ZZ3, ZZZ3;
     const auto Pr = reduce2(P), Rr = reduce2(R);        // the Fq2 square takes (2a)(2a + 1) <= 160
-    sqr2(Pr, Rr, PP, RR);
-    mul2(Pr, PP, acc.x, PP, PPP, Q);
+    if constexpr ((GS_G2_MASK & 2) != 0) sqr2(Pr, Rr, PP, RR);
+    else { PP = sqr(Pr); RR = sqr(Rr); }
+    if constexpr ((GS_G2_MASK & 4) != 0) mul2(Pr, PP, acc.x, PP, PPP, Q);
+    else { PPP = mul(Pr, PP); Q = mul(acc.x, PP); }
     auto X3 = sub(RR, add(PPP, dbl(Q)));                // 9
     auto Y3 = mul_sub(Rr, sub(Q, X3), acc.y, PPP);      // (2, 12, 5, 2): two four-term chains
-    mul2(acc.zz, PP, acc.zzz, PPP, ZZ3, ZZZ3);
+    if constexpr ((GS_G2_MASK & 8) != 0) mul2(acc.zz, PP, acc.zzz, PPP, ZZ3, ZZZ3);
+    else { ZZ3 = mul(acc.zz, PP); ZZZ3 = mul(acc.zzz, PPP); }
     acc.zz = ZZ3; acc.zzz = ZZZ3;
     acc.x = X3; acc.y = relax<5>(Y3);
   } else {
