@@ -95,10 +95,16 @@ GS_HD Xyzz<T> xyzz_inf() {
 }
 
 // acc = infinity in the G1 mixed addition: on the device the zeros come out of an opaque one-instruction asm INSIDE the rare
-// branch.  A plain `acc = xyzz_inf()` makes the compiler materialise the 36 `v_mov v, 0` (phi inputs of the merged accumulator) on
-// the common path of every addition, in front of the branch -- twice: 72 of 2292 instructions.  Measured in one run
-// (profiles/r02_ab_opaque_infinity.txt): G1 accumulations 5.11 -> 4.98 ms per proof.  The Fq2 instance and the general addition of
-// the tails keep the plain form: there the same change moved spills around and LOST (G2 3.78 -> 3.94 ms, tails 7.6 -> 8.4 ms).
+// branch.  With a plain `acc = xyzz_inf()` the compiler materialises the 36 zero phi inputs of the merged accumulator as `v_mov v, 0`
+// in front of the branches of the cancellation test (72 static instructions); they turned out to sit behind the cheap first-level
+// filter, so the DYNAMIC count is unchanged (SQ_INSTS_VALU: 2292 per addition before and after) -- but the register allocation of
+// the common path improves: G1 accumulations 5.11 -> 4.98 ms per proof in one run (profiles/r02_ab_opaque_infinity.txt).  The Fq2
+// instance and the general addition of the tails keep the plain form: there the same change moved spills around and LOST
+// (G2 3.78 -> 3.94 ms, tails 7.6 -> 8.4 ms).
+#ifndef GS_OPAQUE_INF
+#define GS_OPAQUE_INF 1
+#endif
+
 // Which steps of the G2 mixed addition run two Fq2 products at once (four interleaved column chains) instead of one after the
 // other (two chains): bit 0 U2|S2, bit 1 P^2|R^2, bit 2 P^3|Q, bit 3 ZZ3|ZZZ3.  Four chains fill more issue slots but hold more
 // registers in a kernel that sits at 256 VGPRs and spills: all four steps (15) leave 112 B per lane in scratch, 9 leaves 36 B and
@@ -106,9 +112,7 @@ GS_HD Xyzz<T> xyzz_inf() {
 #ifndef GS_G2_MASK
 #define GS_G2_MASK 9
 #endif
-#ifndef GS_OPAQUE_INF
-#define GS_OPAQUE_INF 1
-#endif
+
 template <class M, int B> GS_HD void fill_limbs(Fe<M, B>& a, uint32_t z) {
 #pragma unroll
   for (int i = 0; i < NL; ++i) a.l[i] = z;

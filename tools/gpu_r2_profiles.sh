@@ -45,3 +45,6 @@ for L in 16 18 22; do ( timeout 900 python bench.py --log2n $L --reps 3 --cpu-lo
 ( timeout 900 python bench.py --workload msm_sharded --logical-shards 8 --log2n 22 --steps 5 --warmup 1 --reps 3 --cpu-log2n 0 2>>$OUT/sharded_stderr.txt | line ) > $OUT/bench_line_msm_sharded_8_logical_2p22.json
 ( timeout 900 python bench.py --workload prove_sharded --logical-shards 8 --log2n 20 --steps 5 --warmup 1 --reps 3 --cpu-log2n 0 2>>$OUT/sharded_stderr.txt | line ) > $OUT/bench_line_prove_sharded_8_logical_2p20.json
 ls -la $OUT | head -40
+# --- the multi-process code path of bench.py on a 1-GPU box (two ranks share GPU 0, gloo): barriers, max-over-ranks, one line
+( GS_BENCH_SHARE_GPU=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --log2n 16 --steps 20 --warmup 3 --reps 2 --cpu-log2n 0 2>$OUT/two_ranks_stderr.txt | line ) > $OUT/bench_line_two_ranks_sharing_one_gpu_2p16.json
+ls $OUT | wc -l
