@@ -546,7 +546,11 @@ def main():
             try:
                 with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
                     pmc = json.load(f).get(workload)
-                if pmc:        # measured offline with rocprofv3 --pmc (bench.py cannot attach counters to itself)
+                if pmc and pmc.get("window_bits") not in (None, cbits):
+                    # the counters were taken with another window width = another number of table rows per term: stale, do not quote
+                    out["roofline"]["traffic_source"] = ("profiles/pmc_traffic.json was measured at window width %s, this run used %d: not quoted"
+                                                         % (pmc.get("window_bits"), cbits))
+                elif pmc:      # measured offline with rocprofv3 --pmc (bench.py cannot attach counters to itself)
                     out["roofline"]["traffic"] = pmc["fetch_bytes_per_launch_raw"] + pmc["write_bytes_per_launch_raw"]
                     out["roofline"]["traffic_source"] = ("profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, raw counters; measured at commit %s, "
                                                          "window width %s)" % (pmc.get("commit", "?"), pmc.get("window_bits", "?")))
