@@ -379,3 +379,20 @@ def test_config_2_as_worded_2p16_g1_msm_equals_the_naive_loop_golden():
     for i in (0, 1, n // 2, n - 1):
         a = O.G1.Affine(O.G1.MulScalar(O.G1_GEN, ks[i]))
         assert tuple(U.u64_rows_to_ints(pts[i])) == (a[0], a[1], 1)
+
+
+@pytest.mark.parametrize("n", [32767, 131072, 131073, 3 * 131072 + 5])
+def test_uploads_from_pageable_memory_across_the_staging_pieces(n):
+    """Host buffers reach the device through 4 MiB pinned staging pieces filled by several host threads (csrc/hostcopy.h): sizes just
+    below the 1 MiB threshold, exactly one piece, one piece + one element, several pieces + a ragged tail; from a deliberately
+    misaligned (odd-offset) source.  The resident copy reads back identical, and the host-scalar MSM equals the resident one."""
+    from gosnark_amd import synth
+    raw = np.zeros(4 * n + 1, dtype=np.uint64)
+    sc = raw[1:].reshape(n, 4)                       # 8 bytes off any 16-byte alignment
+    sc[:] = synth.scalars_u64(n, 0xC0FFEE + n)
+    h = capi.scalars_upload(sc)
+    assert np.array_equal(capi.scalars_download(h), sc)
+    bases = capi.g1_fixed_base(synth.scalars_u64(n, 17 + n))
+    assert capi.msm(bases, sc) == capi.msm_resident(bases, h, n)
+    h.free()
+    bases.free()
