@@ -897,3 +897,32 @@ def test_pinocchio_witness_to_proof_without_px_equals_the_px_route(n, extra):
         want_bad = snark.prove_resident(inst.device_pk(), wh, pxh)
         got_bad = snark.prove_from_witness(inst.device_pk(), dev, wh)
         assert all(getattr(got_bad, k) == getattr(want_bad, k) for k in snark.Proof.FIELDS)
+
+
+def test_host_buffer_provers_at_2p16_equal_the_resident_ones():
+    """gs_groth16_prove / gs_pinocchio_prove with w and px in pageable host memory at a size where both cross the boundary in
+    several staged pieces (w 2 MiB, px 4 MiB; csrc/hostcopy.h) and px is copied BEHIND the already enqueued accumulations over w:
+    same proof as the resident entry points; twice in a row (the staging buffers are reused)."""
+    import ctypes
+    from gosnark_amd import synth
+    n = 1 << 16
+    inst = synth.sqchain_setup_instance(n, 0x6C00)
+    lib = capi.load_library()
+    r, s = synth.field_elems(2, 31)
+    want = groth16.prove_resident(inst.device_pk(), inst.w, inst.px, r, s)
+    rs = capi.ints_to_u64([r, s])
+    for _ in range(2):
+        out = np.zeros(32, dtype=np.uint64)
+        inf = (ctypes.c_int * 3)()
+        capi.check(lib.gs_groth16_prove(capi.Handle(inst.device_pk().handle.h), capi.ptr64(inst.w_host), inst.w_host.shape[0],
+                                        capi.ptr64(inst.px_host), inst.px_host.shape[0], capi.ptr64(rs[0]), capi.ptr64(rs[1]), capi.ptr64(out), inf))
+        got = groth16._proof_from_words(out, inf)
+        assert (got.PiA, got.PiB, got.PiC) == (want.PiA, want.PiB, want.PiC)
+    pin = synth.sqchain_pinocchio_instance(n, 0x6C01)
+    pwant = snark.prove_resident(pin.device_pk(), pin.w, pin.px)
+    out = np.zeros(72, dtype=np.uint64)
+    inf8 = (ctypes.c_int * 8)()
+    capi.check(lib.gs_pinocchio_prove(capi.Handle(pin.device_pk().h), capi.ptr64(pin.w_host), pin.w_host.shape[0],
+                                      capi.ptr64(pin.px_host), pin.px_host.shape[0], capi.ptr64(out), inf8))
+    pgot = snark._proof_from_words(out, inf8)
+    assert all(getattr(pgot, k) == getattr(pwant, k) for k in snark.Proof.FIELDS)
