@@ -201,13 +201,17 @@ static void msm_enqueue(Ctx& c, const MsmPlan& plan, const std::vector<MsmBase>&
   if (njobs > kMaxJobs) throw HipError{hipErrorInvalidValue, "too many MSM jobs", __LINE__};
   constexpr size_t pw = PointIO<T>::kXyzzWords;
   constexpr size_t aw = PointIO<T>::kAffineWords;
-  // buckets per reduce thread: 8, or as many as it takes (up to 32) to stay at <= 16 workgroup pairs, which the host folds while
-  // the device moves on -- the on-device fold (k_pair_reduce) is one more ~35-deep chain of dependent additions in the tail
-  int L = (int)std::max<uint32_t>(1u, std::min<uint32_t>(8u, plan.B / kReduceBlock));
-  while (L < 32 && plan.B / ((uint32_t)kReduceBlock * (uint32_t)L) > 16u) L *= 2;
+  // buckets per reduce thread: 4, or as many as it takes (up to 32) to stay at <= 32 workgroup pairs, which the host folds while
+  // the device moves on (3 host additions per pair) -- the on-device fold (k_pair_reduce) is one more ~35-deep chain of dependent
+  // additions in the tail.  The thread's chain is 2 L additions deep (+ 16 for the scan and the tree): L = 8 at 65536 buckets.
+  // Measured (profiles/r02_ab_reduce_depth.txt): tails of a 2^20 proof alone 2.44 -> 1.9 ms against (16 pairs, L = 16).
+  static const uint32_t fold_max = getenv("GS_FOLD_MAX") ? (uint32_t)std::max(1, atoi(getenv("GS_FOLD_MAX"))) : 32u;
+  static const uint32_t l_min = getenv("GS_REDUCE_L") ? (uint32_t)std::max(1, atoi(getenv("GS_REDUCE_L"))) : 4u;
+  int L = (int)std::max<uint32_t>(1u, std::min<uint32_t>(l_min, plan.B / kReduceBlock));
+  while (L < 32 && plan.B / ((uint32_t)kReduceBlock * (uint32_t)L) > fold_max) L *= 2;
   const uint32_t nblk = (plan.B + kReduceBlock * L - 1) / (kReduceBlock * L);
   p.L = L; p.nblk = nblk;
-  p.folded = nblk > 16;                                   // wide windows: the pairs are folded on the device (k_pair_reduce)
+  p.folded = nblk > fold_max;                             // wide windows: the pairs are folded on the device (k_pair_reduce)
   if (nblk > (uint32_t)kReduceBlock) throw HipError{hipErrorInvalidValue, "too many reduce workgroups for one fold", __LINE__};
   const size_t pair_bytes = (size_t)njobs * nblk * 2 * pw * 4, final_bytes = (size_t)njobs * pw * 4;
   const size_t out_bytes = p.folded ? final_bytes : pair_bytes;
