@@ -177,3 +177,22 @@ def test_verifier_strict_mode_rejects_aliased_inputs():
         assert st == -4 and b"strict" in lib.gs_last_error()
     finally:
         lib.gs_verify_set_strict(0)
+
+
+def test_memory_and_witness_entry_points_without_a_device():
+    """The memory accounting / eviction calls and the witness -> proof provers exist and say GS_ERR_NOT_INIT without a GPU (nothing
+    falls back to host code)."""
+    import ctypes
+    lib = capi.load_library()
+    m = capi.Memory()
+    assert lib.gs_memory_query(ctypes.byref(m)) == -5 and b"gs_init" in lib.gs_last_error()
+    a = ctypes.c_uint64(7)
+    assert lib.gs_handle_bytes(capi.Handle(1), ctypes.cast(ctypes.byref(a), capi.u64p), None) == -5 and a.value == 7
+    assert lib.gs_release_tables(capi.Handle(1)) == -5
+    assert lib.gs_trim() == -5
+    out = np.zeros(72, dtype=np.uint64)
+    inf = (ctypes.c_int * 8)()
+    rs = capi.ints_to_u64([1, 2])
+    assert lib.gs_pinocchio_prove_witness(capi.Handle(1), capi.Handle(2), capi.Handle(3), capi.ptr64(out), inf) == -5
+    assert lib.gs_groth16_prove_witness(capi.Handle(1), capi.Handle(2), capi.Handle(3), capi.ptr64(rs[0]), capi.ptr64(rs[1]), capi.ptr64(out), inf) == -5
+    assert not out.any()
