@@ -205,7 +205,10 @@ static void msm_enqueue(Ctx& c, const MsmPlan& plan, const std::vector<MsmBase>&
   // the device moves on (3 host additions per pair) -- the on-device fold (k_pair_reduce) is one more ~35-deep chain of dependent
   // additions in the tail.  The thread's chain is 2 L additions deep (+ 16 for the scan and the tree): L = 8 at 65536 buckets.
   // Measured (profiles/r02_ab_reduce_depth.txt): tails of a 2^20 proof alone 2.44 -> 1.9 ms against (16 pairs, L = 16).
-  static const uint32_t fold_max = getenv("GS_FOLD_MAX") ? (uint32_t)std::max(1, atoi(getenv("GS_FOLD_MAX"))) : 32u;
+  // (32 pairs only from 2^19 terms on: a 2^17 / 2^18 proof takes 1.6 / 2.7 ms, and three host additions per pair for five jobs then
+  // make the host the pace-setter in some repetitions -- median 2.0 vs 1.6 ms at 2^17 with the same best case.)
+  static const uint32_t fold_env = getenv("GS_FOLD_MAX") ? (uint32_t)std::max(1, atoi(getenv("GS_FOLD_MAX"))) : 0u;
+  const uint32_t fold_max = fold_env ? fold_env : (plan.n >= (1u << 19) ? 32u : 16u);
   static const uint32_t l_min = getenv("GS_REDUCE_L") ? (uint32_t)std::max(1, atoi(getenv("GS_REDUCE_L"))) : 4u;
   int L = (int)std::max<uint32_t>(1u, std::min<uint32_t>(l_min, plan.B / kReduceBlock));
   while (L < 32 && plan.B / ((uint32_t)kReduceBlock * (uint32_t)L) > fold_max) L *= 2;
