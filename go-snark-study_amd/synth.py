@@ -263,6 +263,43 @@ class SqchainPinocchioInstance:
                 "(gs_pinocchio_setup), px from the sparse system; seed 0x%X" % self.seed)
 
 
+class RandomPinocchioInstance:
+    """A Pinocchio instance of the reference's shape (m = n + 1, NPublic = 1, len(Z) = len(hx) = n = len(G1T)) whose key points are
+    k_i * G for seeded uniform k_i and whose w / px are seeded uniform field elements: what snark.GenerateProofs (snark.go:254-289)
+    computes on it is pinned by a golden from the naive loops (oracle/gen_golden_large.py pinocchio)."""
+    G1_ARRAYS = ("A", "Ap", "Bp", "C", "Cp", "Kp")
+
+    def __init__(self, n, seed):
+        import ctypes
+        from . import snark
+        self.n, self.m, self.seed = n, n + 1, seed
+        m = self.m
+        g1 = {k: capi.g1_fixed_base(scalars_u64(m, seed + 1 + i)) for i, k in enumerate(self.G1_ARRAYS)}
+        g1t = capi.g1_fixed_base(scalars_u64(n, seed + 7))
+        b2 = capi.g2_fixed_base(scalars_u64(m, seed + 8))
+        self.w_host = scalars_u64(m, seed + 9)
+        self.w_host[0] = (1, 0, 0, 0)
+        self.px_host = scalars_u64(2 * n - 1, seed + 10)
+        z = capi.zpoly(m - 2)
+        h = capi.Handle(0)
+        H = lambda x: capi.Handle(x.h)   # noqa: E731
+        capi.check(capi.load_library().gs_pinocchio_pk_create(
+            H(g1["A"]), H(g1["Ap"]), H(b2), H(g1["Bp"]), H(g1["C"]), H(g1["Cp"]), H(g1["Kp"]), H(g1t),
+            capi.ptr64(z), z.shape[0], m, 1, ctypes.byref(h)))
+        for x in list(g1.values()) + [g1t, b2]:
+            x.free()
+        self._pk = snark.DevicePk(capi.DeviceHandle(h.value), m, 1)
+        self.w = capi.scalars_upload(self.w_host)
+        self.px = capi.scalars_upload(self.px_host)
+
+    def device_pk(self):
+        return self._pk
+
+
+def random_pinocchio_instance(n, seed):
+    return RandomPinocchioInstance(n, seed)
+
+
 def sqchain_pinocchio_instance(n, seed, extra_vars=0):
     return SqchainPinocchioInstance(n, seed, extra_vars)
 

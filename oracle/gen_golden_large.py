@@ -6,9 +6,9 @@ proof: golden AFFINE outputs computed offline by the C restatement of the refere
 MulScalar = MSB-first double-and-add, Add = add-2007-bl, Div = schoolbook) on all host cores, on the same seeded inputs
 the GPU tests rebuild (gosnark_amd.synth).  Takes ~10 minutes on 8 cores; run in the build container:
 
-    python3 oracle/gen_golden_large.py [msm|prove|all]
+    python3 oracle/gen_golden_large.py [msm|prove|pinocchio|all]
 
-Writes tests/golden/oracle_msm_g1_2p16.json and tests/golden/oracle_groth_2p16.json.
+Writes tests/golden/oracle_msm_g1_2p16.json, tests/golden/oracle_groth_2p16.json and tests/golden/oracle_pinocchio_2p16.json.
 """
 import json
 import os
@@ -121,8 +121,44 @@ def prove_golden(logn=16, seed=0x60D1):
     print(rec)
 
 
+def pinocchio_golden(logn=16, seed=0x60D2):
+    """snark.GenerateProofs (snark.go:254-289) on the instance gosnark_amd.synth.RandomPinocchioInstance(n, seed) defines."""
+    n = 1 << logn
+    m = n + 1
+    t0 = time.time()
+    fb1 = lambda cnt, sd: C.mul_scalar_batch(O.G1_GEN, scalars_u64(cnt, sd), threads=THREADS)      # noqa: E731
+    names = ("A", "Ap", "Bp", "C", "Cp", "Kp")
+    arr = {k: fb1(m, seed + 1 + i) for i, k in enumerate(names)}
+    g1t = fb1(n, seed + 7)
+    b2 = C.mul_scalar_batch(O.G2_GEN, scalars_u64(m, seed + 8), g2=True, threads=THREADS)
+    w = scalars_u64(m, seed + 9)
+    w[0] = (1, 0, 0, 0)
+    px = scalars_u64(2 * n - 1, seed + 10)
+    print("key rebuilt on the CPU in %.0f s" % (time.time() - t0), flush=True)
+    hx, _ = C.poly_div_u64(px, zpoly(m - 2))                                                # snark.go:280
+    print("hx = px / Z done, %.0f s" % (time.time() - t0), flush=True)
+    out = {}
+    for k in ("A", "Ap"):                                                                   # i > NPublic = 1 only (:265-268)
+        out["Pi" + k] = O.G1.Affine(C.g1_msm_naive(arr[k][2:], w[2:], threads=THREADS))
+    for k in ("Bp", "C", "Cp", "Kp"):                                                       # all variables (:270-278)
+        out["Pi" + k] = O.G1.Affine(C.g1_msm_naive(arr[k], w, threads=THREADS))
+    out["PiB"] = O.G2.Affine(C.g2_msm_naive(b2, w, threads=THREADS))
+    out["PiH"] = O.G1.Affine(C.g1_msm_naive(g1t[:hx.shape[0]], hx, threads=THREADS))        # :284-286
+    print("MSMs done, %.0f s" % (time.time() - t0), flush=True)
+    rec = {"what": "snark.GenerateProofs (snark.go:254-289) on gosnark_amd.synth.RandomPinocchioInstance(n, seed); MSMs by the naive "
+                   "loops, hx by schoolbook Div; affine", "n": n, "seed": seed,
+           "generator": "oracle/gen_golden_large.py pinocchio (oracle/gs_oracle.c, %d threads, %.0f s)" % (THREADS, time.time() - t0)}
+    for k, v in out.items():
+        rec[k] = [[str(v[0][0]), str(v[0][1])], [str(v[1][0]), str(v[1][1])]] if k == "PiB" else [str(v[0]), str(v[1])]
+    with open(os.path.join(OUT, "oracle_pinocchio_2p%d.json" % logn), "w") as f:
+        json.dump(rec, f, indent=1)
+    print({k: v for k, v in rec.items() if not k.startswith("Pi")})
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if what in ("pinocchio", "all"):
+        pinocchio_golden()
     if what in ("msm", "all"):
         msm_golden()
     if what in ("prove", "all"):

@@ -926,3 +926,32 @@ def test_host_buffer_provers_at_2p16_equal_the_resident_ones():
                                       capi.ptr64(pin.px_host), pin.px_host.shape[0], capi.ptr64(out), inf8))
     pgot = snark._proof_from_words(out, inf8)
     assert all(getattr(pgot, k) == getattr(pwant, k) for k in snark.Proof.FIELDS)
+
+
+def test_2p16_pinocchio_proof_on_random_keys_equals_the_naive_loop_golden():
+    """SURVEY 8 a2 at config size, pinned from outside the library: the eight elements of snark.GenerateProofs (snark.go:254-289) on
+    synth.RandomPinocchioInstance(2^16, seed) were computed offline by the C restatement of the reference's naive loops on all host
+    cores (oracle/gen_golden_large.py pinocchio -> tests/golden/oracle_pinocchio_2p16.json); resident, pipelined and at another
+    window width the device gives the same affine points.  A and Ap sum over i > NPublic only (snark.go:265-268)."""
+    import json
+    import os
+    from gosnark_amd import synth
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_pinocchio_2p16.json")) as f:
+        rec = json.load(f)
+    inst = synth.random_pinocchio_instance(rec["n"], rec["seed"])
+
+    def want(k):
+        v = rec[k]
+        return ((int(v[0][0]), int(v[0][1])), (int(v[1][0]), int(v[1][1])), (1, 0)) if k == "PiB" else (int(v[0]), int(v[1]), 1)
+    got = snark.prove_resident(inst.device_pk(), inst.w, inst.px)
+    for k in snark.Proof.FIELDS:
+        assert getattr(got, k) == want(k), k
+    t = snark.prove_begin(inst.device_pk(), inst.w, inst.px)
+    got = snark.prove_end(t)
+    assert all(getattr(got, k) == want(k) for k in snark.Proof.FIELDS)
+    capi.set_window_bits(13)
+    try:
+        got = snark.prove_resident(inst.device_pk(), inst.w, inst.px)
+    finally:
+        capi.set_window_bits(0)
+    assert all(getattr(got, k) == want(k) for k in snark.Proof.FIELDS)
