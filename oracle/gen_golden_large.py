@@ -6,9 +6,9 @@ proof: golden AFFINE outputs computed offline by the C restatement of the refere
 MulScalar = MSB-first double-and-add, Add = add-2007-bl, Div = schoolbook) on all host cores, on the same seeded inputs
 the GPU tests rebuild (gosnark_amd.synth).  Takes ~10 minutes on 8 cores; run in the build container:
 
-    python3 oracle/gen_golden_large.py [msm|prove|pinocchio|all]
+    python3 oracle/gen_golden_large.py [msm|msm20|partials20|prove|pinocchio|all]
 
-Writes tests/golden/oracle_msm_g1_2p16.json, tests/golden/oracle_groth_2p16.json and tests/golden/oracle_pinocchio_2p16.json.
+Writes tests/golden/oracle_msm_g1_2p16.json, oracle_msm_g1_2p20.json, oracle_groth_partials_2p20.json, tests/golden/oracle_groth_2p16.json and tests/golden/oracle_pinocchio_2p16.json.
 """
 import json
 import os
@@ -121,6 +121,39 @@ def prove_golden(logn=16, seed=0x60D1):
     print(rec)
 
 
+def partials_golden(logn=20, seed=0x60D4):
+    """The four sums over w of groth16.GenerateProofs (groth16.go:243-250) at the headline size, on the key and witness
+    gosnark_amd.synth.RandomInstance(n, seed) defines: what gs_groth16_prove_partials returns before the O(1) tail.  (The fifth sum
+    needs hx = px / Z, and schoolbook Div at 2^20 is a day of CPU: it is pinned at 2^16 by prove_golden.)"""
+    n = 1 << logn
+    m = n + 1
+    t0 = time.time()
+    fb1 = lambda cnt, sd: C.mul_scalar_batch(O.G1_GEN, scalars_u64(cnt, sd), threads=THREADS)      # noqa: E731
+    w = scalars_u64(m, seed + 8)
+    w[0] = (1, 0, 0, 0)
+    rec = {"what": "sum_i w_i * P_i for P = G1.At, G1.BACGamma, G2.BACGamma (all i) and BACDelta (i > NPublic = 1) of "
+                   "gosnark_amd.synth.RandomInstance(n, seed), by the naive MulScalar / Add loops (groth16.go:243-250); affine",
+           "n": n, "seed": seed}
+    at = fb1(m, seed + 1)
+    a = O.G1.Affine(C.g1_msm_naive(at, w, threads=THREADS)); del at
+    rec["At"] = [str(a[0]), str(a[1])]
+    print("At done, %.0f s" % (time.time() - t0), flush=True)
+    bg = fb1(m, seed + 2)
+    a = O.G1.Affine(C.g1_msm_naive(bg, w, threads=THREADS)); del bg
+    rec["BACGamma1"] = [str(a[0]), str(a[1])]
+    bd = fb1(m, seed + 3)
+    a = O.G1.Affine(C.g1_msm_naive(bd[2:], w[2:], threads=THREADS)); del bd
+    rec["BACDelta"] = [str(a[0]), str(a[1])]
+    print("G1 sums done, %.0f s" % (time.time() - t0), flush=True)
+    b2 = C.mul_scalar_batch(O.G2_GEN, scalars_u64(m, seed + 5), g2=True, threads=THREADS)
+    b = O.G2.Affine(C.g2_msm_naive(b2, w, threads=THREADS))
+    rec["BACGamma2"] = [[str(b[0][0]), str(b[0][1])], [str(b[1][0]), str(b[1][1])]]
+    rec["generator"] = "oracle/gen_golden_large.py partials20 (oracle/gs_oracle.c, %d threads, %.0f s)" % (THREADS, time.time() - t0)
+    with open(os.path.join(OUT, "oracle_groth_partials_2p%d.json" % logn), "w") as f:
+        json.dump(rec, f, indent=1)
+    print(rec["generator"])
+
+
 def pinocchio_golden(logn=16, seed=0x60D2):
     """snark.GenerateProofs (snark.go:254-289) on the instance gosnark_amd.synth.RandomPinocchioInstance(n, seed) defines."""
     n = 1 << logn
@@ -161,5 +194,9 @@ if __name__ == "__main__":
         pinocchio_golden()
     if what in ("msm", "all"):
         msm_golden()
+    if what in ("partials20", "all"):
+        partials_golden()
+    if what in ("msm20", "all"):
+        msm_golden(logn=20, seed=0x60D3)          # the headline size: ~2 minutes on 8 cores
     if what in ("prove", "all"):
         prove_golden()

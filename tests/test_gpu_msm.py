@@ -353,6 +353,32 @@ int main(void) {
     assert out.returncode == 0 and out.stdout.startswith("OK"), out.stdout + out.stderr
 
 
+def test_2p20_g1_msm_equals_the_naive_loop_golden():
+    """The headline size against the literal reference loop: sum_i MulScalar(MulScalar(G, k_i), s_i) over 2^20 seeded terms, computed
+    offline by the C restatement of bn128/g1.go on all host cores (oracle/gen_golden_large.py msm20 ->
+    tests/golden/oracle_msm_g1_2p20.json).  Host scalars, resident scalars, three MSMs in flight, and the widest window."""
+    import json
+    import os
+    from gosnark_amd import synth
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_msm_g1_2p20.json")) as f:
+        rec = json.load(f)
+    n = rec["n"]
+    bases = capi.g1_fixed_base(synth.scalars_u64(n, rec["seed_bases"]))
+    sc = synth.scalars_u64(n, rec["seed_scalars"])
+    want = (int(rec["x"]), int(rec["y"]))
+    assert capi.msm(bases, sc) == want
+    h = capi.scalars_upload(sc)
+    tickets = [capi.msm_begin(bases, h, n) for _ in range(3)]
+    assert [capi.msm_end(t) for t in tickets] == [want] * 3
+    capi.set_window_bits(20)
+    try:
+        assert capi.msm_resident(bases, h, n) == want
+    finally:
+        capi.set_window_bits(0)
+    h.free()
+    bases.free()
+
+
 def test_config_2_as_worded_2p16_g1_msm_equals_the_naive_loop_golden():
     """BASELINE configs[1]: 'Synthetic 2^16 ... G1 Pippenger MSM only, bit-exact vs bn128.G1 loop'.  The expected point was computed
     offline by oracle/gen_golden_large.py: bases P_i = MulScalar(G, k_i), then acc = Add(acc, MulScalar(P_i, s_i)) over all 2^16

@@ -955,3 +955,23 @@ def test_2p16_pinocchio_proof_on_random_keys_equals_the_naive_loop_golden():
     finally:
         capi.set_window_bits(0)
     assert all(getattr(got, k) == want(k) for k in snark.Proof.FIELDS)
+
+
+def test_2p20_four_of_the_five_sums_of_a_proof_equal_the_naive_loop_golden():
+    """The headline size (BASELINE configs[2]) against the literal reference loops: the sums over w of groth16.go:243-250 -- G1.At,
+    G1.BACGamma, G2.BACGamma over all variables, BACDelta over i > NPublic -- on synth.RandomInstance(2^20, seed), computed offline by
+    oracle/gs_oracle.c on all host cores (oracle/gen_golden_large.py partials20 -> tests/golden/oracle_groth_partials_2p20.json),
+    equal what gs_groth16_prove_partials returns in front of the O(1) tail.  (The fifth sum needs px / Z, a day of schoolbook Div
+    at this size; it is pinned at 2^16 and, at 2^20, through the closed form and the verifier.)"""
+    import json
+    import os
+    from gosnark_amd import synth
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_groth_partials_2p20.json")) as f:
+        rec = json.load(f)
+    inst = synth.random_instance(rec["n"], rec["seed"])
+    pts, _ = groth16.prove_partials(inst.device_pk(), inst.w, inst.px, 0, 1)
+    g1 = lambda k: (int(rec[k][0]), int(rec[k][1]))                                                     # noqa: E731
+    assert pts[0] == g1("At")
+    assert pts[1] == g1("BACGamma1")
+    assert pts[2] == ((int(rec["BACGamma2"][0][0]), int(rec["BACGamma2"][0][1])), (int(rec["BACGamma2"][1][0]), int(rec["BACGamma2"][1][1])))
+    assert pts[3] == g1("BACDelta")
