@@ -437,7 +437,7 @@ def zpoly(deg):
 
 
 def msm_begin(bases, scalars, n, off=0, soff=0, g2=False):
-    """Enqueue one resident MSM (gs_msm_g1_begin / gs_msm_g2_begin) -> ticket; at most two operations outstanding."""
+    """Enqueue one resident MSM (gs_msm_g1_begin / gs_msm_g2_begin) -> ticket; at most three operations outstanding per logical device."""
     t = ctypes.c_uint64(0)
     fn = load_library().gs_msm_g2_begin if g2 else load_library().gs_msm_g1_begin
     check(fn(Handle(bases.h), off, Handle(scalars.h), soff, n, ctypes.cast(ctypes.byref(t), u64p)))
