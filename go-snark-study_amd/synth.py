@@ -89,6 +89,32 @@ def random_instance(n, seed):
     return RandomInstance(n, seed)
 
 
+class QuotientInstance(RandomInstance):
+    """RandomInstance's key and witness with a px whose quotient is KNOWN: px = hx * Z + rem for seeded uniform hx (n coefficients)
+    and rem (n - 2 coefficients, degree below Z's), built here with the library's own gs_poly_mul / gs_poly_add.  The golden generator
+    (oracle/gen_golden_large.py prove20) builds the same px by an unrelated exact product (oracle/crt_ntt.py) and records its SHA-256,
+    so a test can pin the device product at 2^20 and then the whole proof, whose fifth sum is sum_i hx_i PTD_i for that known hx."""
+
+    def __init__(self, n, seed):
+        import hashlib
+        super().__init__(n, seed)
+        lib = capi.load_library()
+        self.hx_host = scalars_u64(n, seed + 11)
+        rem = scalars_u64(n - 2, seed + 12)
+        prod = np.zeros((2 * n - 1, 4), dtype=np.uint64)
+        capi.check(lib.gs_poly_mul(capi.ptr64(self.hx_host), n, capi.ptr64(self.z_host), self.z_host.shape[0], capi.ptr64(prod)))
+        px = np.zeros((2 * n - 1, 4), dtype=np.uint64)
+        capi.check(lib.gs_poly_add(capi.ptr64(prod), 2 * n - 1, capi.ptr64(rem), n - 2, capi.ptr64(px)))
+        self.px_host = px
+        self.px_sha256 = hashlib.sha256(np.ascontiguousarray(px, dtype="<u8").tobytes()).hexdigest()
+        self.px.free()
+        self.px = capi.scalars_upload(px)
+
+
+def quotient_instance(n, seed):
+    return QuotientInstance(n, seed)
+
+
 def sqchain_r1cs(n, x, extra_vars=0):
     """SURVEY 8d's synthetic circuit: variables [one, s_1 = x (public), s_2 .. s_n] (m = n + 1, NPublic = 1);
     constraint k = 1..n-1:  s_k * s_k = s_{k+1} - k * one;  constraint n:  one * one = one.

@@ -6,9 +6,9 @@ proof: golden AFFINE outputs computed offline by the C restatement of the refere
 MulScalar = MSB-first double-and-add, Add = add-2007-bl, Div = schoolbook) on all host cores, on the same seeded inputs
 the GPU tests rebuild (gosnark_amd.synth).  Takes ~10 minutes on 8 cores; run in the build container:
 
-    python3 oracle/gen_golden_large.py [msm|msm20|partials20|prove|pinocchio|all]
+    python3 oracle/gen_golden_large.py [msm|msm20|partials20|prove20|prove|pinocchio|all]
 
-Writes tests/golden/oracle_msm_g1_2p16.json, oracle_msm_g1_2p20.json, oracle_groth_partials_2p20.json, tests/golden/oracle_groth_2p16.json and tests/golden/oracle_pinocchio_2p16.json.
+Writes tests/golden/oracle_msm_g1_2p16.json, oracle_msm_g1_2p20.json, oracle_groth_partials_2p20.json, oracle_groth_quotient_2p12.json / _2p20.json, tests/golden/oracle_groth_2p16.json and tests/golden/oracle_pinocchio_2p16.json.
 """
 import json
 import os
@@ -154,6 +154,76 @@ def partials_golden(logn=20, seed=0x60D4):
     print(rec["generator"])
 
 
+def zpoly_fast(deg):
+    """prod_{i=1}^{deg} (x - i): schoolbook products (oracle/gs_oracle.c) while the factors are short, the exact multi-prime product
+    of oracle/crt_ntt.py above that."""
+    from oracle import crt_ntt
+    polys = [C.poly_u64([(-i) % O.R, 1]) for i in range(1, deg + 1)]
+    while len(polys) > 1:
+        big = polys[0].shape[0] > 512
+        mul = crt_ntt.poly_mul_mod_r if big else C.poly_mul_u64
+        polys = [mul(polys[i], polys[i + 1]) if i + 1 < len(polys) else polys[i] for i in range(0, len(polys), 2)]
+    return polys[0]
+
+
+def prove20_golden(logn=20, seed=0x60D5):
+    """A COMPLETE Groth16 proof at the headline size from outside the library, on gosnark_amd.synth.QuotientInstance(n, seed): the key
+    and witness of RandomInstance, and px = hx * Z + rem for seeded hx and rem, so that floor(px / Z) = hx is known without the
+    schoolbook Div (a day of CPU at this size).  px itself is built by oracle/crt_ntt.py and its SHA-256 recorded."""
+    import hashlib
+    from oracle import crt_ntt
+    n = 1 << logn
+    m = n + 1
+    t0 = time.time()
+    z = zpoly_fast(m - 2)
+    print("Z built, %.0f s" % (time.time() - t0), flush=True)
+    hx = scalars_u64(n, seed + 11)
+    rem = scalars_u64(n - 2, seed + 12)
+    prod = crt_ntt.poly_mul_mod_r(hx, z)
+    pi, ri = ints(prod), ints(rem)
+    px = C.poly_u64([(pi[i] + (ri[i] if i < len(ri) else 0)) % O.R for i in range(len(pi))])
+    sha = hashlib.sha256(np.ascontiguousarray(px, dtype="<u8").tobytes()).hexdigest()
+    print("px = hx Z + rem built, %.0f s" % (time.time() - t0), flush=True)
+    fb1 = lambda cnt, sd: C.mul_scalar_batch(O.G1_GEN, scalars_u64(cnt, sd), threads=THREADS)      # noqa: E731
+    w = scalars_u64(m, seed + 8)
+    w[0] = (1, 0, 0, 0)
+    G1, G2 = O.G1, O.G2
+    at = fb1(m, seed + 1)
+    piA = C.g1_msm_naive(at, w, threads=THREADS); del at
+    bg = fb1(m, seed + 2)
+    piB1 = C.g1_msm_naive(bg, w, threads=THREADS); del bg
+    bd = fb1(m, seed + 3)
+    piC = C.g1_msm_naive(bd[2:], w[2:], threads=THREADS); del bd                             # i > NPublic = 1
+    ptd = fb1(n, seed + 4)
+    hsum = C.g1_msm_naive(ptd[:n], hx, threads=THREADS); del ptd
+    print("G1 sums done, %.0f s" % (time.time() - t0), flush=True)
+    b2 = C.mul_scalar_batch(O.G2_GEN, scalars_u64(m, seed + 5), g2=True, threads=THREADS)
+    piB = C.g2_msm_naive(b2, w, threads=THREADS); del b2
+    s1 = fb1(3, seed + 6)
+    s2 = C.mul_scalar_batch(O.G2_GEN, scalars_u64(2, seed + 7), g2=True, threads=1)
+    alpha, beta, delta = (tuple(ints(s1[i])) for i in range(3))
+    g2pt = lambda row: (lambda v: ((v[0], v[1]), (v[2], v[3]), (v[4], v[5])))(ints(row))              # noqa: E731
+    beta2, delta2 = g2pt(s2[0]), g2pt(s2[1])
+    r, s = (int(x) % O.R for x in ints(scalars_u64(2, seed + 10)))
+    piA = G1.Add(G1.Add(piA, alpha), G1.MulScalar(delta, r))
+    piB = G2.Add(G2.Add(piB, beta2), G2.MulScalar(delta2, s))
+    piB1 = G1.Add(G1.Add(piB1, beta), G1.MulScalar(delta, s))
+    piC = G1.Add(piC, hsum)
+    piC = G1.Add(piC, G1.MulScalar(piA, s))
+    piC = G1.Add(piC, G1.MulScalar(piB1, r))
+    piC = G1.Add(piC, G1.Neg(G1.MulScalar(delta, r * s % O.R)))
+    a, b, c = G1.Affine(piA), G2.Affine(piB), G1.Affine(piC)
+    rec = {"what": "groth16.GenerateProofs (groth16.go:225-278) on gosnark_amd.synth.QuotientInstance(n, seed): px = hx Z + rem built by "
+                   "oracle/crt_ntt.py (SHA-256 below), so hx = floor(px / Z) is known; the five MSMs by the naive loops; affine",
+           "n": n, "seed": seed, "r": str(r), "s": str(s), "px_sha256": sha,
+           "PiA": [str(a[0]), str(a[1])], "PiB": [[str(b[0][0]), str(b[0][1])], [str(b[1][0]), str(b[1][1])]], "PiC": [str(c[0]), str(c[1])],
+           "generator": "oracle/gen_golden_large.py prove20 (oracle/gs_oracle.c + oracle/crt_ntt.py + oracle/ref_py.py tail, %d threads, %.0f s)"
+                        % (THREADS, time.time() - t0)}
+    with open(os.path.join(OUT, "oracle_groth_quotient_2p%d.json" % logn), "w") as f:
+        json.dump(rec, f, indent=1)
+    print({k: v for k, v in rec.items() if k in ("n", "seed", "px_sha256", "generator")})
+
+
 def pinocchio_golden(logn=16, seed=0x60D2):
     """snark.GenerateProofs (snark.go:254-289) on the instance gosnark_amd.synth.RandomPinocchioInstance(n, seed) defines."""
     n = 1 << logn
@@ -194,6 +264,8 @@ if __name__ == "__main__":
         pinocchio_golden()
     if what in ("msm", "all"):
         msm_golden()
+    if what in ("prove20", "all"):
+        prove20_golden(int(sys.argv[2]) if len(sys.argv) > 2 else 20)
     if what in ("partials20", "all"):
         partials_golden()
     if what in ("msm20", "all"):

@@ -975,3 +975,37 @@ def test_2p20_four_of_the_five_sums_of_a_proof_equal_the_naive_loop_golden():
     assert pts[1] == g1("BACGamma1")
     assert pts[2] == ((int(rec["BACGamma2"][0][0]), int(rec["BACGamma2"][0][1])), (int(rec["BACGamma2"][1][0]), int(rec["BACGamma2"][1][1])))
     assert pts[3] == g1("BACDelta")
+
+
+@pytest.mark.parametrize("logn", [12, 20])
+def test_complete_proof_on_a_known_quotient_equals_the_golden_from_outside_the_library(logn):
+    """BASELINE configs[2] at its exact size, every element of the proof pinned from outside the library: on
+    synth.QuotientInstance(n, seed) px = hx Z + rem, so floor(px / Z) = hx is known and the reference's day-long schoolbook Div is not
+    needed.  oracle/gen_golden_large.py prove20 built px by an unrelated exact product (eighteen 31-bit NTT primes + Garner,
+    oracle/crt_ntt.py -- checked against the schoolbook Mul in tests/test_oracle_crt_ntt.py), the five MSMs by the naive MulScalar /
+    Add loops and the tail by oracle/ref_py.py.  Here: the px the LIBRARY builds (gs_zpoly, gs_poly_mul, gs_poly_add) has the
+    recorded SHA-256, and the proof -- blocking, pipelined, and from host buffers -- is the golden one."""
+    import json
+    import os
+    from gosnark_amd import synth
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_groth_quotient_2p%d.json" % logn)) as f:
+        rec = json.load(f)
+    assert rec["n"] == 1 << logn and "px_sha256" in rec
+    inst = synth.quotient_instance(rec["n"], rec["seed"])
+    assert inst.px_sha256 == rec["px_sha256"]
+    r, s = synth.field_elems(2, rec["seed"] + 10)
+    assert (r, s) == (int(rec["r"]), int(rec["s"]))
+    want = ((int(rec["PiA"][0]), int(rec["PiA"][1]), 1),
+            ((int(rec["PiB"][0][0]), int(rec["PiB"][0][1])), (int(rec["PiB"][1][0]), int(rec["PiB"][1][1])), (1, 0)),
+            (int(rec["PiC"][0]), int(rec["PiC"][1]), 1))
+    got = groth16.prove_resident(inst.device_pk(), inst.w, inst.px, r, s)
+    assert (got.PiA, got.PiB, got.PiC) == want
+    tickets = [groth16.prove_begin(inst.device_pk(), inst.w, inst.px, r, s) for _ in range(3)]
+    for t in tickets:
+        got = groth16.prove_end(t)
+        assert (got.PiA, got.PiB, got.PiC) == want
+    # the quotient itself
+    hx = np.zeros((rec["n"], 4), dtype=np.uint64)
+    capi.check(capi.load_library().gs_poly_div(capi.ptr64(inst.px_host), inst.px_host.shape[0], capi.ptr64(inst.z_host), inst.z_host.shape[0],
+                                               capi.ptr64(hx), None))
+    assert np.array_equal(hx, inst.hx_host)
