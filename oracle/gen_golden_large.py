@@ -6,9 +6,9 @@ proof: golden AFFINE outputs computed offline by the C restatement of the refere
 MulScalar = MSB-first double-and-add, Add = add-2007-bl, Div = schoolbook) on all host cores, on the same seeded inputs
 the GPU tests rebuild (gosnark_amd.synth).  Takes ~10 minutes on 8 cores; run in the build container:
 
-    python3 oracle/gen_golden_large.py [msm|msm20|partials20|prove20|prove|pinocchio|all]
+    python3 oracle/gen_golden_large.py [msm|msm20|msm22|partials20|prove20|prove|pinocchio|all]
 
-Writes tests/golden/oracle_msm_g1_2p16.json, oracle_msm_g1_2p20.json, oracle_groth_partials_2p20.json, oracle_groth_quotient_2p12.json / _2p20.json, tests/golden/oracle_groth_2p16.json and tests/golden/oracle_pinocchio_2p16.json.
+Writes tests/golden/oracle_msm_g1_2p16.json, oracle_msm_g1_2p20.json, oracle_msm_g1_2p22.json, oracle_groth_partials_2p20.json, oracle_groth_quotient_2p12.json / _2p20.json, tests/golden/oracle_groth_2p16.json and tests/golden/oracle_pinocchio_2p16.json.
 """
 import json
 import os
@@ -268,6 +268,8 @@ if __name__ == "__main__":
         prove20_golden(int(sys.argv[2]) if len(sys.argv) > 2 else 20)
     if what in ("partials20", "all"):
         partials_golden()
+    if what in ("msm22", "all"):
+        msm_golden(logn=22, seed=0x60D6)          # BASELINE configs[3]: the 2^22-term MSM that is sharded over 8 GPUs; ~6 minutes on 8 cores
     if what in ("msm20", "all"):
         msm_golden(logn=20, seed=0x60D3)          # the headline size: ~2 minutes on 8 cores
     if what in ("prove", "all"):

@@ -283,3 +283,29 @@ def test_plain_c_process_proves_over_three_logical_devices(tmp_path):
     out = c_util.build_and_run("multi_device.c", [str(blob)], tmp_path)
     assert out.strip().endswith("OK"), out
     assert "used_rccl=1" in out and "collectives=1" in out
+
+
+def test_config_4_2p22_msm_over_8_logical_devices_equals_the_naive_loop_golden():
+    """BASELINE configs[3]: 'Synthetic 2^22-term MSM sharded over 8 GPUs' -- here over 8 logical devices of the one GPU, with the
+    record exchange through the in-library ncclAllGather: shard d holds terms [d 2^19, (d + 1) 2^19).  The expected point was
+    computed offline by the C restatement of the reference's MulScalar / Add loop over all 2^22 terms on all host cores
+    (oracle/gen_golden_large.py msm22 -> tests/golden/oracle_msm_g1_2p22.json); the single-device MSM gives it too."""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_msm_g1_2p22.json")) as f:
+        rec = json.load(f)
+    n, S = rec["n"], 8
+    want = (int(rec["x"]), int(rec["y"]))
+    capi.set_device(0)
+    bases = capi.g1_fixed_base(synth.scalars_u64(n, rec["seed_bases"]))
+    sc = capi.scalars_upload(synth.scalars_u64(n, rec["seed_scalars"]))
+    assert capi.msm_resident(bases, sc, n) == want
+    capi.comm_init_local()
+    per = n // S
+    bs = [capi.g1_clone(bases, d, d * per, per) for d in range(S)]
+    ss = [capi.scalars_clone(sc, d, d * per, per) for d in range(S)]
+    got, used_rccl = capi.msm_multi(bs, ss)
+    assert got == want and used_rccl
+    for h in bs + ss + [bases, sc]:
+        h.free()
+    capi.comm_destroy()
