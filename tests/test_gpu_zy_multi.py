@@ -309,3 +309,36 @@ def test_config_4_2p22_msm_over_8_logical_devices_equals_the_naive_loop_golden()
     for h in bs + ss + [bases, sc]:
         h.free()
     capi.comm_destroy()
+
+
+def test_config_5_2p18_proofs_round_robin_over_8_logical_devices_against_the_golden():
+    """BASELINE configs[4] in its own size class: independent 2^18-constraint proofs round-robin over 8 devices (here 8 logical devices of
+    the one GPU), one full key per device, three in flight per device, no collective.  The instance is synth.QuotientInstance(2^18,
+    seed), whose proof for the golden's (r, s) was computed outside the library (oracle/gen_golden_large.py prove20 18 ->
+    tests/golden/oracle_groth_quotient_2p18.json: naive-loop MSMs, px by oracle/crt_ntt.py): every device produces exactly it; the
+    proofs with other randomness equal the single-device blocking ones."""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_groth_quotient_2p18.json")) as f:
+        rec = json.load(f)
+    capi.set_device(0)
+    q = synth.quotient_instance(rec["n"], rec["seed"])
+    assert q.px_sha256 == rec["px_sha256"]
+    want = ((int(rec["PiA"][0]), int(rec["PiA"][1]), 1),
+            ((int(rec["PiB"][0][0]), int(rec["PiB"][0][1])), (int(rec["PiB"][1][0]), int(rec["PiB"][1][1])), (1, 0)),
+            (int(rec["PiC"][0]), int(rec["PiC"][1]), 1))
+    ndev, nproofs = 8, 16
+    golden_rs = (int(rec["r"]), int(rec["s"]))
+    rs = [golden_rs if i < ndev else tuple(synth.field_elems(2, 700 + i)) for i in range(nproofs)]       # the first round: one golden proof per device
+    pks = [groth16.ShardPkTo(q.device_pk(), 0, 1, d) for d in range(ndev)]
+    ws = [capi.scalars_clone(q.w, i % ndev) for i in range(nproofs)]
+    pxs = [capi.scalars_clone(q.px, i % ndev) for i in range(nproofs)]
+    got = groth16.prove_batch(pks, ws, pxs, rs)
+    for i in range(ndev):
+        assert (got[i].PiA, got[i].PiB, got[i].PiC) == want, i
+    for i in range(ndev, nproofs):
+        assert _same(got[i], groth16.prove_resident(q.device_pk(), q.w, q.px, *rs[i]))
+    for h in ws + pxs:
+        h.free()
+    for k in pks:
+        k.handle.free()
