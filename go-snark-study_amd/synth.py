@@ -326,6 +326,31 @@ def random_pinocchio_instance(n, seed):
     return RandomPinocchioInstance(n, seed)
 
 
+class QuotientPinocchioInstance(RandomPinocchioInstance):
+    """RandomPinocchioInstance with px = hx * Z + rem for seeded hx / rem (see QuotientInstance): the quotient snark.go:280 takes is
+    known, so a complete golden proof can be computed outside the library at sizes where the schoolbook Div cannot."""
+
+    def __init__(self, n, seed):
+        import hashlib
+        super().__init__(n, seed)
+        lib = capi.load_library()
+        self.hx_host = scalars_u64(n, seed + 11)
+        rem = scalars_u64(n - 2, seed + 12)
+        z = capi.zpoly(self.m - 2)
+        prod = np.zeros((2 * n - 1, 4), dtype=np.uint64)
+        capi.check(lib.gs_poly_mul(capi.ptr64(self.hx_host), n, capi.ptr64(z), z.shape[0], capi.ptr64(prod)))
+        px = np.zeros((2 * n - 1, 4), dtype=np.uint64)
+        capi.check(lib.gs_poly_add(capi.ptr64(prod), 2 * n - 1, capi.ptr64(rem), n - 2, capi.ptr64(px)))
+        self.px_host = px
+        self.px_sha256 = hashlib.sha256(np.ascontiguousarray(px, dtype="<u8").tobytes()).hexdigest()
+        self.px.free()
+        self.px = capi.scalars_upload(px)
+
+
+def quotient_pinocchio_instance(n, seed):
+    return QuotientPinocchioInstance(n, seed)
+
+
 def sqchain_pinocchio_instance(n, seed, extra_vars=0):
     return SqchainPinocchioInstance(n, seed, extra_vars)
 

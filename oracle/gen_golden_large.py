@@ -6,9 +6,9 @@ proof: golden AFFINE outputs computed offline by the C restatement of the refere
 MulScalar = MSB-first double-and-add, Add = add-2007-bl, Div = schoolbook) on all host cores, on the same seeded inputs
 the GPU tests rebuild (gosnark_amd.synth).  Takes ~10 minutes on 8 cores; run in the build container:
 
-    python3 oracle/gen_golden_large.py [msm|msm20|msm22|partials20|prove20|prove|pinocchio|all]
+    python3 oracle/gen_golden_large.py [msm|msm20|msm22|partials20|prove20|pinocchio20|prove|pinocchio|all]
 
-Writes tests/golden/oracle_msm_g1_2p16.json, oracle_msm_g1_2p20.json, oracle_msm_g1_2p22.json, oracle_groth_partials_2p20.json, oracle_groth_quotient_2p12.json / _2p20.json, tests/golden/oracle_groth_2p16.json and tests/golden/oracle_pinocchio_2p16.json.
+Writes tests/golden/oracle_msm_g1_2p16.json, oracle_msm_g1_2p20.json, oracle_msm_g1_2p22.json, oracle_groth_partials_2p20.json, oracle_groth_quotient_2p12.json / _2p18.json / _2p20.json, oracle_pinocchio_quotient_2p12.json / _2p20.json, tests/golden/oracle_groth_2p16.json and tests/golden/oracle_pinocchio_2p16.json.
 """
 import json
 import os
@@ -224,6 +224,47 @@ def prove20_golden(logn=20, seed=0x60D5):
     print({k: v for k, v in rec.items() if k in ("n", "seed", "px_sha256", "generator")})
 
 
+def pinocchio20_golden(logn=20, seed=0x60D7):
+    """A COMPLETE snark.GenerateProofs output at the headline size from outside the library, on
+    gosnark_amd.synth.QuotientPinocchioInstance(n, seed): px = hx Z + rem (oracle/crt_ntt.py), the eight sums by the naive loops."""
+    import hashlib
+    from oracle import crt_ntt
+    n = 1 << logn
+    m = n + 1
+    t0 = time.time()
+    z = zpoly_fast(m - 2)
+    hx = scalars_u64(n, seed + 11)
+    rem = scalars_u64(n - 2, seed + 12)
+    pi, ri = ints(crt_ntt.poly_mul_mod_r(hx, z)), ints(rem)
+    px = C.poly_u64([(pi[i] + (ri[i] if i < len(ri) else 0)) % O.R for i in range(len(pi))])
+    sha = hashlib.sha256(np.ascontiguousarray(px, dtype="<u8").tobytes()).hexdigest()
+    del pi, ri, px, z
+    print("px = hx Z + rem built, %.0f s" % (time.time() - t0), flush=True)
+    fb1 = lambda cnt, sd: C.mul_scalar_batch(O.G1_GEN, scalars_u64(cnt, sd), threads=THREADS)      # noqa: E731
+    w = scalars_u64(m, seed + 9)
+    w[0] = (1, 0, 0, 0)
+    out = {}
+    for i, k in enumerate(("A", "Ap", "Bp", "C", "Cp", "Kp")):
+        arr = fb1(m, seed + 1 + i)
+        lo = 2 if k in ("A", "Ap") else 0                                                   # i > NPublic = 1 only (snark.go:265-268)
+        out["Pi" + k] = O.G1.Affine(C.g1_msm_naive(arr[lo:], w[lo:], threads=THREADS))
+        del arr
+        print("Pi%s done, %.0f s" % (k, time.time() - t0), flush=True)
+    g1t = fb1(n, seed + 7)
+    out["PiH"] = O.G1.Affine(C.g1_msm_naive(g1t, hx, threads=THREADS)); del g1t              # :284-286, len(hx) = n
+    b2 = C.mul_scalar_batch(O.G2_GEN, scalars_u64(m, seed + 8), g2=True, threads=THREADS)
+    out["PiB"] = O.G2.Affine(C.g2_msm_naive(b2, w, threads=THREADS)); del b2
+    rec = {"what": "snark.GenerateProofs (snark.go:254-289) on gosnark_amd.synth.QuotientPinocchioInstance(n, seed): px = hx Z + rem built "
+                   "by oracle/crt_ntt.py (SHA-256 below), so hx = floor(px / Z) is known; the eight sums by the naive loops; affine",
+           "n": n, "seed": seed, "px_sha256": sha,
+           "generator": "oracle/gen_golden_large.py pinocchio20 (oracle/gs_oracle.c + oracle/crt_ntt.py, %d threads, %.0f s)" % (THREADS, time.time() - t0)}
+    for k, v in out.items():
+        rec[k] = [[str(v[0][0]), str(v[0][1])], [str(v[1][0]), str(v[1][1])]] if k == "PiB" else [str(v[0]), str(v[1])]
+    with open(os.path.join(OUT, "oracle_pinocchio_quotient_2p%d.json" % logn), "w") as f:
+        json.dump(rec, f, indent=1)
+    print({k: v for k, v in rec.items() if not k.startswith("Pi")})
+
+
 def pinocchio_golden(logn=16, seed=0x60D2):
     """snark.GenerateProofs (snark.go:254-289) on the instance gosnark_amd.synth.RandomPinocchioInstance(n, seed) defines."""
     n = 1 << logn
@@ -264,6 +305,8 @@ if __name__ == "__main__":
         pinocchio_golden()
     if what in ("msm", "all"):
         msm_golden()
+    if what in ("pinocchio20", "all"):
+        pinocchio20_golden(int(sys.argv[2]) if len(sys.argv) > 2 else 20)
     if what in ("prove20", "all"):
         prove20_golden(int(sys.argv[2]) if len(sys.argv) > 2 else 20)
     if what in ("partials20", "all"):

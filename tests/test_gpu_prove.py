@@ -1009,3 +1009,28 @@ def test_complete_proof_on_a_known_quotient_equals_the_golden_from_outside_the_l
     capi.check(capi.load_library().gs_poly_div(capi.ptr64(inst.px_host), inst.px_host.shape[0], capi.ptr64(inst.z_host), inst.z_host.shape[0],
                                                capi.ptr64(hx), None))
     assert np.array_equal(hx, inst.hx_host)
+
+
+@pytest.mark.parametrize("logn", [12, 20])
+def test_complete_pinocchio_proof_on_a_known_quotient_equals_the_golden_from_outside_the_library(logn):
+    """snark.GenerateProofs at the headline size, all eight elements pinned from outside the library: on
+    synth.QuotientPinocchioInstance(n, seed) px = hx Z + rem (built there by the library, by oracle/crt_ntt.py in the generator: same
+    SHA-256), the eight sums by the naive loops (oracle/gen_golden_large.py pinocchio20).  Blocking and pipelined."""
+    import json
+    import os
+    from gosnark_amd import synth
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_pinocchio_quotient_2p%d.json" % logn)) as f:
+        rec = json.load(f)
+    inst = synth.quotient_pinocchio_instance(rec["n"], rec["seed"])
+    assert inst.px_sha256 == rec["px_sha256"]
+
+    def want(k):
+        v = rec[k]
+        return ((int(v[0][0]), int(v[0][1])), (int(v[1][0]), int(v[1][1])), (1, 0)) if k == "PiB" else (int(v[0]), int(v[1]), 1)
+    got = snark.prove_resident(inst.device_pk(), inst.w, inst.px)
+    for k in snark.Proof.FIELDS:
+        assert getattr(got, k) == want(k), k
+    tickets = [snark.prove_begin(inst.device_pk(), inst.w, inst.px) for _ in range(3)]
+    for t in tickets:
+        got = snark.prove_end(t)
+        assert all(getattr(got, k) == want(k) for k in snark.Proof.FIELDS)
