@@ -29,3 +29,26 @@ def test_crt_ntt_extreme_coefficients():
     for p in crt_ntt.PRIMES:
         prod *= p
     assert prod > (1 << 20) * O.R * O.R
+
+
+def test_golden_generator_draws_the_same_scalars_as_the_product_side_instances():
+    """oracle/gen_golden_large.py keeps its own copy of the seeded scalar generator (the oracle must not import the product package);
+    the goldens only mean something if it is bit-identical to gosnark_amd.synth.scalars_u64, which the GPU tests use to rebuild the
+    instances."""
+    import importlib.util
+    import os
+    import sys
+    import gosnark_amd  # noqa: F401
+    from gosnark_amd import synth
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "gen_golden_large.py")
+    spec = importlib.util.spec_from_file_location("gen_golden_large", path)
+    gen = importlib.util.module_from_spec(spec)
+    argv, sys.argv = sys.argv, ["gen_golden_large.py", "none"]
+    try:
+        spec.loader.exec_module(gen)
+    finally:
+        sys.argv = argv
+    for n, seed in ((1, 0), (7, 0x60D0), (1000, 0x60D5 + 11), (4097, 24789)):
+        a, b = gen.scalars_u64(n, seed), synth.scalars_u64(n, seed)
+        assert a.dtype == b.dtype and np.array_equal(a, b)
+        assert all(v < O.R for v in C._ints(a))

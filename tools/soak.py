@@ -1,6 +1,7 @@
 """Soak: many proofs through every prove entry point; device memory and results must stay put (dev tool)."""
 import sys, time
-sys.path.insert(0, "/root/repo")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import gosnark_amd
 from gosnark_amd import capi, synth, groth16, snark
