@@ -501,6 +501,30 @@ def main():
                 raise SystemExit("bench.py: gs_groth16_prove_witness disagrees with the px route")
             extras["from_r1cs_ms_per_step"] = time_calls(lambda: groth16.prove_from_witness(pk, dr, inst.w, r_, s_), 6)
             extras["from_r1cs_constraints_per_s"] = n / extras["from_r1cs_ms_per_step"] * 1e3
+            extras["from_r1cs_route"] = ("evaluation-basis PowersTauDelta (h-MSM over H's values, %d points)" % capi.pk_eval_count(pk.handle)
+                                         if capi.pk_eval_count(pk.handle) else "coefficient route (interpolation + Taylor shift)")
+            # ... three witness -> proof operations in flight (gs_groth16_prove_witness_begin / gs_groth16_prove_end)
+            pipelined(lambda: groth16.prove_witness_begin(pk, dr, inst.w, r_, s_), groth16.prove_end, 6, 3)
+            samples = []
+            for _ in range(3):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                pipelined(lambda: groth16.prove_witness_begin(pk, dr, inst.w, r_, s_), groth16.prove_end, 10, 3)
+                torch.cuda.synchronize()
+                samples.append((time.perf_counter() - t0) / 10 * 1e3)
+            extras["from_r1cs_pipelined_ms_per_step"] = statistics.median(samples)
+            extras["from_r1cs_pipelined_ms_reps"] = samples
+            extras["from_r1cs_pipelined_constraints_per_s"] = n / extras["from_r1cs_pipelined_ms_per_step"] * 1e3
+            if capi.pk_eval_count(pk.handle):
+                # the same key through H's coefficients (round 2's route, what a key without the evaluation-basis array takes)
+                capi.set_eval_basis(False)
+                try:
+                    pc = groth16.prove_from_witness(pk, dr, inst.w, r_, s_)
+                    if (pc.PiA, pc.PiB, pc.PiC) != (ref.PiA, ref.PiB, ref.PiC):
+                        raise SystemExit("bench.py: the coefficient witness route disagrees with the px route")
+                    extras["from_r1cs_coefficient_route_ms_per_step"] = time_calls(lambda: groth16.prove_from_witness(pk, dr, inst.w, r_, s_), 4)
+                finally:
+                    capi.set_eval_basis(True)
             pxh.free()
             dr.handle.free()
         extras["msm_g1"] = msm_extras(seed + 5000)

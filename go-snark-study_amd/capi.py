@@ -28,7 +28,7 @@ class Timing(ctypes.Structure):
                 + [("acc_g1_launches", ctypes.c_uint32), ("acc_g2_launches", ctypes.c_uint32),
                    ("acc_g1_terms", ctypes.c_uint64), ("acc_g2_terms", ctypes.c_uint64),
                    ("acc_g1_adds", ctypes.c_uint64), ("acc_g2_adds", ctypes.c_uint64),
-                   ("window_bits", ctypes.c_uint32), ("reserved", ctypes.c_uint32)])
+                   ("window_bits", ctypes.c_uint32), ("fallbacks", ctypes.c_uint32)])
 
 
 class Memory(ctypes.Structure):
@@ -80,6 +80,11 @@ _SIGS = {
     "gs_groth16_prove_resident": [Handle, Handle, Handle, u64p, u64p, u64p, intp],
     "gs_groth16_prove_r1cs": [Handle, Handle, Handle, ctypes.POINTER(Handle), u64p, u64p, u64p, intp],
     "gs_groth16_prove_witness": [Handle, Handle, Handle, u64p, u64p, u64p, intp],
+    "gs_groth16_prove_witness_begin": [Handle, Handle, Handle, u64p, u64p, u64p],
+    "gs_groth16_pk_set_eval": [Handle, Handle],
+    "gs_pk_eval_count": [Handle, ctypes.POINTER(ctypes.c_size_t)],
+    "gs_pinocchio_pk_set_eval": [Handle, Handle],
+    "gs_pinocchio_prove_witness_begin": [Handle, Handle, Handle, u64p],
     "gs_groth16_prove_begin": [Handle, Handle, Handle, u64p, u64p, u64p],
     "gs_groth16_prove_end": [ctypes.c_uint64, u64p, intp],
     "gs_groth16_pk_create_shard": [Handle, Handle, Handle, Handle, Handle, u64p, u64p, u64p, u64p, u64p, u64p, ctypes.c_size_t,
@@ -124,6 +129,7 @@ _SIGS = {
     "gs_last_timing": [ctypes.POINTER(Timing)],
     "gs_device_timing": [ctypes.c_int, ctypes.POINTER(Timing)],
     "gs_set_window_bits": [ctypes.c_int],
+    "gs_set_eval_basis": [ctypes.c_int],
     "gs_memory_query": [ctypes.POINTER(Memory)],
     "gs_handle_bytes": [Handle, u64p, u64p],
     "gs_release_tables": [Handle],
@@ -296,6 +302,13 @@ def _upload(fname, arr, n):
     return DeviceHandle(h.value)
 
 
+def pk_eval_count(pk_handle):
+    """gs_pk_eval_count: evaluation-basis points a resident Groth16 / Pinocchio key holds (0 = none)."""
+    n = ctypes.c_size_t(0)
+    check(load_library().gs_pk_eval_count(Handle(_raw(pk_handle)), ctypes.byref(n)))
+    return int(n.value)
+
+
 def g1_upload(points_u64):
     a = np.ascontiguousarray(points_u64, dtype=np.uint64).reshape(-1, 12)
     return _upload("gs_g1_upload", a, a.shape[0])
@@ -421,6 +434,11 @@ def release_tables(h):
 def trim():
     """gs_trim: drop the cached workspaces of the current logical device."""
     check(load_library().gs_trim())
+
+
+def set_eval_basis(on):
+    init()
+    check(load_library().gs_set_eval_basis(1 if on else 0))
 
 
 def set_window_bits(c):

@@ -22,12 +22,12 @@ void for_each_table(Object* o, F f) {
     }
     case Kind::GrothPk: {
       auto* k = static_cast<GrothPkObj*>(o);
-      for (BaseTable* t : {&k->t_at, &k->t_bacgamma1, &k->t_bacdelta, &k->t_ptd, &k->t_bacgamma2}) f(*t);
+      for (BaseTable* t : {&k->t_at, &k->t_bacgamma1, &k->t_bacdelta, &k->t_ptd, &k->t_bacgamma2, &k->t_ptd_eval}) f(*t);
       break;
     }
     case Kind::PinocchioPk: {
       auto* k = static_cast<PinocchioPkObj*>(o);
-      for (BaseTable* t : {&k->t_a, &k->t_ap, &k->t_bp, &k->t_c, &k->t_cp, &k->t_kp, &k->t_g1t, &k->t_b2}) f(*t);
+      for (BaseTable* t : {&k->t_a, &k->t_ap, &k->t_bp, &k->t_c, &k->t_cp, &k->t_kp, &k->t_g1t, &k->t_b2, &k->t_g1t_eval}) f(*t);
       break;
     }
     default: break;
@@ -40,11 +40,11 @@ uint64_t object_bytes(Object* o) {
     case Kind::Scalars: return static_cast<Scalars*>(o)->buf.bytes;
     case Kind::GrothPk: {
       auto* k = static_cast<GrothPkObj*>(o);
-      return k->at.bytes + k->bacgamma1.bytes + k->bacdelta.bytes + k->ptd.bytes + k->bacgamma2.bytes + divisor_bytes(k->z);
+      return k->at.bytes + k->bacgamma1.bytes + k->bacdelta.bytes + k->ptd.bytes + k->bacgamma2.bytes + k->ptd_eval.bytes + divisor_bytes(k->z);
     }
     case Kind::PinocchioPk: {
       auto* k = static_cast<PinocchioPkObj*>(o);
-      return k->a.bytes + k->ap.bytes + k->bp.bytes + k->c.bytes + k->cp.bytes + k->kp.bytes + k->g1t.bytes + k->b2.bytes + divisor_bytes(k->z);
+      return k->a.bytes + k->ap.bytes + k->bp.bytes + k->c.bytes + k->cp.bytes + k->kp.bytes + k->g1t.bytes + k->b2.bytes + k->g1t_eval.bytes + divisor_bytes(k->z);
     }
     case Kind::R1cs: {
       auto* r = static_cast<R1csObj*>(o);

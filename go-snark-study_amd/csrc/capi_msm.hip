@@ -526,4 +526,15 @@ int gs_set_window_bits(int cbits) {
   return GS_OK;
 }
 
+// Witness route of keys that carry an evaluation-basis array: 1 (default) = h-MSM over H's values, 0 = the coefficient route
+// (interpolation + Taylor shift) every other key takes.  Same proofs; a switch for measurements and tests.  Every logical device.
+int gs_set_eval_basis(int enabled) {
+  if (registry().ctxs.empty()) return fail(GS_ERR_NOT_INIT, "gs_init has not been called (or failed)");
+  for (auto& pc : registry().ctxs) {
+    std::lock_guard<std::mutex> lk(pc->mu);
+    pc->eval_basis = enabled != 0;
+  }
+  return GS_OK;
+}
+
 }  // extern "C"

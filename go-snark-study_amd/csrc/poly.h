@@ -51,6 +51,13 @@ void interpolate_dev(Ctx& c, const uint32_t* values_std, size_t n, size_t nvec, 
 // witness satisfies the constraints at the dz = deg Z roots of Z: node extension by one batched convolution, ONE tree
 // interpolation, one Taylor shift.  false (nothing written) when a constraint is violated -- take the px route then.
 bool hx_direct_dev(Ctx& c, const uint32_t* vals_std, size_t n, size_t dz, uint32_t* hx_out_std);
+// The two halves of the above, for keys that carry an evaluation-basis copy of PowersTauDelta / G1T (prove.h): the prover then
+// needs only H's VALUES at the nodes n+1..2n.  hx_values_dev: hv[k-1] = H(n+k), k = 1..n, canonical standard form (false: shape
+// not served); r1cs_check_dev: *bad_dev = number of roots of Z at which a b != c (enqueue only -- the caller reads the word when
+// it collects the proof, and takes the exact route if it is not zero); hx_from_values_dev: values -> coefficients.
+bool hx_values_dev(Ctx& c, const uint32_t* vals_std, size_t n, size_t dz, uint32_t* hv_out_std);
+void r1cs_check_dev(Ctx& c, const uint32_t* vals_std, size_t n, size_t dz, uint32_t* bad_dev);
+void hx_from_values_dev(Ctx& c, const uint32_t* hv_std, size_t n, size_t dz, uint32_t* hx_out_std);
 // CSR sparse matrix (standard-form values) times a Montgomery-form vector -> standard-form vector
 void spmv_dev(Ctx& c, const uint32_t* rowptr, const uint32_t* col, const uint32_t* val_std, const uint32_t* x_mont, size_t nrows, size_t ncols,
               uint32_t* out_std);
@@ -65,6 +72,7 @@ Fe<ModR, 2> fr_from_words_mont(const uint64_t w[4]);
 void fr_words_from_mont(const Fe<ModR, 2>& a, uint64_t out[4]);
 void fr_mul_words(const uint64_t a[4], const uint64_t b[4], uint64_t out[4]);
 void fr_inv_words(const uint64_t a[4], uint64_t out[4]);
+void fr_sub_words(const uint64_t a[4], const uint64_t b[4], uint64_t out[4]);
 bool fr_is_zero_words(const uint64_t a[4]);
 void fr_falling_product_words(const uint64_t x[4], size_t count, uint64_t out[4]);     // prod_{k=1}^{count} (x - k)
 
@@ -78,5 +86,7 @@ void pinocchio_scalars_dev(Ctx& c, const uint32_t* at, const uint32_t* bt, const
                            const uint64_t rhoc[4], const uint64_t ka[4], const uint64_t kb[4], const uint64_t kc[4], const uint64_t kbeta[4],
                            uint32_t* const out[7]);
 void scaled_powers_dev(Ctx& c, const uint64_t base[4], const uint64_t scale_std[4], size_t count, uint32_t* out_std);
+// out[i] = a_mont[i] * scale (scale in standard words), canonical standard form
+void scale_mont_by_std_dev(Ctx& c, const uint32_t* a_mont, const uint64_t scale_std[4], size_t n, uint32_t* out_std);
 
 }  // namespace gs

@@ -61,7 +61,7 @@ struct PolyState {
   struct HxTables {
     size_t n = 0, dz = 0, N = 0;
     DevBuf inv_spec, shift_spec, t1, t2;         // spectra of 1/(t+1) and (-n)^t/t! (size N), value scalings (n each)
-    DevBuf conv, hv, g;                          // workspaces: 3 N, n, n
+    DevBuf conv, hv, g, bad;                     // workspaces: 3 N, n, n; the violated-constraint counter (one word)
   } hx;
 };
 static PolyState& poly_state(Ctx& c) { return c.state<PolyState>(c.poly_state); }
@@ -382,72 +382,109 @@ void interpolate_dev(Ctx& c, const uint32_t* values_std, size_t n, size_t nvec, 
   // cur[k] = x^pad * p_k(x): coefficients pad .. pad + n - 1
   for (size_t k = 0; k < nvec; ++k)
     GS_HIP(hipMemcpyAsync(coeffs_std + k * n * 8, cur + (k * total + t.pad) * 8, n * 32, hipMemcpyDeviceToDevice, c.stream));
-  GS_HIP(hipStreamSynchronize(c.stream));
+  // (no host wait: every workspace above is persistent, and callers that read the result on the host synchronise themselves)
 }
 
-// H = (A B - C) / Z from the constraint values (vals: [A w | B w | C w], n each, standard form), for a witness that satisfies
-// the constraints at every root of Z (deg Z = dz in {n - 1, n}).  Returns false -- and writes nothing -- when it does not:
-// the caller then takes the exact route (px, then the floor quotient the reference computes, r1csqap.go:70-84).
-// hx_out: nh = 2n - 1 - dz coefficients, canonical standard form.  See poly_kernels.h for the derivation.
-bool hx_direct_dev(Ctx& c, const uint32_t* vals_std, size_t n, size_t dz, uint32_t* hx_out) {
-  if (n < 2 || (dz != n - 1 && dz != n)) return false;
+// ---- H = (A B - C) / Z from the constraint values -----------------------------------------------------------------------
+// vals: [A w | B w | C w], n each, standard form.  For a witness that satisfies the constraints at every root of Z
+// (deg Z = dz in {n - 1, n}) P = A B - C is an exact multiple of Z and H is fixed by its values at the n nodes n+1..2n.
+// See poly_kernels.h for the derivation.
+static bool hx_shape_ok(size_t n, size_t dz) { return n >= 2 && (dz == n - 1 || dz == n); }
+
+// tables of one (n, deg Z): once (synchronises the stream when it builds)
+static PolyState::HxTables& hx_tables(Ctx& c, size_t n, size_t dz) {
   PolyState& ps = poly_state(c);
   PolyState::HxTables& hx = ps.hx;
+  if (hx.n == n && hx.dz == dz) return hx;
   const int logN = ceil_log2(2 * n);
-  const size_t N = (size_t)1 << logN, nh = 2 * n - 1 - dz;
+  const size_t N = (size_t)1 << logN;
   Fe<ModR, 1> r2;
   for (int i = 0; i < NL; ++i) r2.l[i] = ModR::r2(i);
   const FrConst r2c = to_const(relax<2>(r2));
-  {                                                     // satisfied at the roots of Z?
-    DevBuf bad(4);
-    GS_HIP(hipMemsetAsync(bad.p, 0, 4, c.stream));
-    hipLaunchKernelGGL(k_r1cs_check, grid1(n), dim3(256), 0, c.stream, vals_std, (uint32_t)n, (uint32_t)dz, r2c, bad.as<uint32_t>());
-    uint32_t nbad = 0;
-    GS_HIP(hipMemcpyAsync(&nbad, bad.p, 4, hipMemcpyDeviceToHost, c.stream));
-    GS_HIP(hipStreamSynchronize(c.stream));
-    if (nbad) return false;
-  }
-  NodeTree& t = ensure_tree(c, n, true);
   const FrConst inv_N = inv_n_const(logN, 0);
-  if (hx.n != n || hx.dz != dz) {                       // tables of this (n, deg Z): once
-    ensure_factorials(c, 2 * n);
-    hx = PolyState::HxTables{};
-    hx.inv_spec.alloc(N * 32); hx.shift_spec.alloc(N * 32); hx.t1.alloc(n * 32); hx.t2.alloc(n * 32);
-    hx.conv.alloc(3 * N * 32); hx.hv.alloc(n * 32); hx.g.alloc(n * 32);
-    hipLaunchKernelGGL(k_hx_tables, grid1(N), dim3(256), 0, c.stream, ps.fact.as<uint32_t>(), ps.invfact.as<uint32_t>(), (uint32_t)n, (uint32_t)dz, (uint32_t)N,
-                       inv_N, r2c, hx.inv_spec.as<uint32_t>(), hx.t1.as<uint32_t>(), hx.t2.as<uint32_t>());
-    // (-n)^t, t < n, in standard form (scale 1), then / t!
-    DevBuf pw(n * 32);
-    uint64_t negn[4], one[4] = {1, 0, 0, 0};
-    {
-      uint64_t nn[4] = {(uint64_t)n, 0, 0, 0};
-      fr_words_from_mont(reduce2(neg(fr_from_words_mont(nn))), negn);
-    }
-    scaled_powers_dev(c, negn, one, n, pw.as<uint32_t>());
-    hipLaunchKernelGGL(k_hx_shift_table, grid1(N), dim3(256), 0, c.stream, ps.invfact.as<uint32_t>(), pw.as<uint32_t>(), (uint32_t)n, (uint32_t)N,
-                       hx.shift_spec.as<uint32_t>());
-    ntt_forward(c, hx.inv_spec.as<uint32_t>(), logN, logN);
-    ntt_forward(c, hx.shift_spec.as<uint32_t>(), logN, logN);
-    GS_HIP(hipGetLastError());
-    GS_HIP(hipStreamSynchronize(c.stream));              // `pw` is released here
-    hx.n = n; hx.dz = dz; hx.N = N;
+  ensure_tree(c, n, true);
+  ensure_factorials(c, 2 * n);
+  hx = PolyState::HxTables{};
+  hx.inv_spec.alloc(N * 32); hx.shift_spec.alloc(N * 32); hx.t1.alloc(n * 32); hx.t2.alloc(n * 32);
+  hx.conv.alloc(3 * N * 32); hx.hv.alloc(n * 32); hx.g.alloc(n * 32); hx.bad.alloc(16);
+  hipLaunchKernelGGL(k_hx_tables, grid1(N), dim3(256), 0, c.stream, ps.fact.as<uint32_t>(), ps.invfact.as<uint32_t>(), (uint32_t)n, (uint32_t)dz, (uint32_t)N,
+                     inv_N, r2c, hx.inv_spec.as<uint32_t>(), hx.t1.as<uint32_t>(), hx.t2.as<uint32_t>());
+  // (-n)^t, t < n, in standard form (scale 1), then / t!
+  DevBuf pw(n * 32);
+  uint64_t negn[4], one[4] = {1, 0, 0, 0};
+  {
+    uint64_t nn[4] = {(uint64_t)n, 0, 0, 0};
+    fr_words_from_mont(reduce2(neg(fr_from_words_mont(nn))), negn);
   }
+  scaled_powers_dev(c, negn, one, n, pw.as<uint32_t>());
+  hipLaunchKernelGGL(k_hx_shift_table, grid1(N), dim3(256), 0, c.stream, ps.invfact.as<uint32_t>(), pw.as<uint32_t>(), (uint32_t)n, (uint32_t)N,
+                     hx.shift_spec.as<uint32_t>());
+  ntt_forward(c, hx.inv_spec.as<uint32_t>(), logN, logN);
+  ntt_forward(c, hx.shift_spec.as<uint32_t>(), logN, logN);
+  GS_HIP(hipGetLastError());
+  GS_HIP(hipStreamSynchronize(c.stream));              // `pw` is released here
+  hx.n = n; hx.dz = dz; hx.N = N;
+  return hx;
+}
+
+// *bad_dev (one device word) = number of roots j of Z at which a_j b_j != c_j.  Enqueue only.
+void r1cs_check_dev(Ctx& c, const uint32_t* vals_std, size_t n, size_t dz, uint32_t* bad_dev) {
+  Fe<ModR, 1> r2;
+  for (int i = 0; i < NL; ++i) r2.l[i] = ModR::r2(i);
+  GS_HIP(hipMemsetAsync(bad_dev, 0, 4, c.stream));
+  if (n) hipLaunchKernelGGL(k_r1cs_check, grid1(n), dim3(256), 0, c.stream, vals_std, (uint32_t)n, (uint32_t)dz, to_const(relax<2>(r2)), bad_dev);
+  GS_HIP(hipGetLastError());
+}
+
+// hv[k - 1] = H(n + k), k = 1..n (canonical standard form): the values of A, B, C at the nodes n+1..2n by three cyclic
+// convolutions with 1 / (t + 1) (batched), then (a b - c) / Z point-wise.  No host wait once the tables of (n, dz) exist.
+bool hx_values_dev(Ctx& c, const uint32_t* vals_std, size_t n, size_t dz, uint32_t* hv_out) {
+  if (!hx_shape_ok(n, dz)) return false;
+  PolyState::HxTables& hx = hx_tables(c, n, dz);
+  NodeTree& t = ensure_tree(c, n, true);
+  const int logN = ceil_log2(2 * n);
+  const size_t N = hx.N;
   uint32_t* conv = hx.conv.as<uint32_t>();
-  // values of A, B, C at the nodes n+1 .. 2n: three cyclic convolutions with 1 / (t + 1), batched
   hipLaunchKernelGGL(k_hx_weigh, grid1(3 * N), dim3(256), 0, c.stream, vals_std, t.weights.as<uint32_t>(), (uint32_t)n, (uint32_t)N, 3u, conv);
   ntt_forward_n(c, conv, 3 * N, logN);
   hipLaunchKernelGGL(k_pw_mul_bcast, grid1(3 * N), dim3(256), 0, c.stream, conv, hx.inv_spec.as<uint32_t>(), (uint32_t)N, 3u);
   ntt_inverse_unscaled_n(c, conv, 3 * N, logN);
-  hipLaunchKernelGGL(k_hx_values, grid1(n), dim3(256), 0, c.stream, conv, hx.t1.as<uint32_t>(), hx.t2.as<uint32_t>(), (uint32_t)n, (uint32_t)N, hx.hv.as<uint32_t>());
+  hipLaunchKernelGGL(k_hx_values, grid1(n), dim3(256), 0, c.stream, conv, hx.t1.as<uint32_t>(), hx.t2.as<uint32_t>(), (uint32_t)n, (uint32_t)N, hv_out);
   GS_HIP(hipGetLastError());
-  // G(y) = H(y + n) from its values at y = 1..n, then H(x) = G(x - n)
-  interpolate_dev(c, hx.hv.as<uint32_t>(), n, 1, hx.g.as<uint32_t>());
+  return true;
+}
+
+// H's nh = 2n - 1 - dz coefficients (canonical standard form) from those values: G(y) = H(y + n) by ONE tree interpolation at
+// y = 1..n, then the Taylor shift H(x) = G(x - n) (one more convolution).
+void hx_from_values_dev(Ctx& c, const uint32_t* hv_std, size_t n, size_t dz, uint32_t* hx_out) {
+  PolyState& ps = poly_state(c);
+  PolyState::HxTables& hx = hx_tables(c, n, dz);
+  const int logN = ceil_log2(2 * n);
+  const size_t N = hx.N, nh = 2 * n - 1 - dz;
+  const FrConst inv_N = inv_n_const(logN, 0);
+  uint32_t* conv = hx.conv.as<uint32_t>();
+  interpolate_dev(c, hv_std, n, 1, hx.g.as<uint32_t>());
   hipLaunchKernelGGL(k_hx_shift_in, grid1(N), dim3(256), 0, c.stream, hx.g.as<uint32_t>(), ps.fact.as<uint32_t>(), (uint32_t)n, (uint32_t)N, conv);
   ntt_forward(c, conv, logN, logN);
   hipLaunchKernelGGL(k_pw_mul, grid1(N), dim3(256), 0, c.stream, conv, hx.shift_spec.as<uint32_t>(), conv, (uint32_t)N);
   ntt_inverse_unscaled(c, conv, logN, logN);
   hipLaunchKernelGGL(k_hx_shift_out, grid1(nh), dim3(256), 0, c.stream, conv, ps.invfact.as<uint32_t>(), inv_N, (uint32_t)n, (uint32_t)nh, hx_out);
   GS_HIP(hipGetLastError());
+}
+
+// Both steps, for keys that only have the monomial PowersTauDelta / G1T.  Returns false -- and writes nothing -- when a constraint
+// is violated at a root of Z: the caller then takes the exact route (px, then the floor quotient the reference computes,
+// r1csqap.go:70-84).  hx_out: nh = 2n - 1 - dz coefficients, canonical standard form.
+bool hx_direct_dev(Ctx& c, const uint32_t* vals_std, size_t n, size_t dz, uint32_t* hx_out) {
+  if (!hx_shape_ok(n, dz)) return false;
+  PolyState::HxTables& hx = hx_tables(c, n, dz);
+  uint32_t nbad = 0;                                    // the flag word lives with the tables: no allocation on the per-proof path
+  r1cs_check_dev(c, vals_std, n, dz, hx.bad.as<uint32_t>());
+  GS_HIP(hipMemcpyAsync(&nbad, hx.bad.p, 4, hipMemcpyDeviceToHost, c.stream));
+  GS_HIP(hipStreamSynchronize(c.stream));
+  if (nbad) return false;
+  hx_values_dev(c, vals_std, n, dz, hx.hv.as<uint32_t>());
+  hx_from_values_dev(c, hx.hv.as<uint32_t>(), n, dz, hx_out);
   return true;
 }
 
@@ -478,6 +515,18 @@ void pinocchio_scalars_dev(Ctx& c, const uint32_t* at, const uint32_t* bt, const
   GS_HIP(hipGetLastError());
 }
 
+// out[i] = a[i] * scale: a Montgomery, scale given in STANDARD words (used raw) -> canonical standard form
+void scale_mont_by_std_dev(Ctx& c, const uint32_t* a_mont, const uint64_t scale_std[4], size_t n, uint32_t* out_std) {
+  FrConst sc;
+  uint32_t u[8];
+  for (int i = 0; i < 4; ++i) { u[2 * i] = (uint32_t)scale_std[i]; u[2 * i + 1] = (uint32_t)(scale_std[i] >> 32); }
+  const Fe<ModR, 6> raw = unpack32<ModR>(u);
+  for (int i = 0; i < NL; ++i) sc.l[i] = raw.l[i];
+  if (n) hipLaunchKernelGGL(k_pw_mul_const, grid1(n), dim3(256), 0, c.stream, a_mont, sc, out_std, (uint32_t)n);
+  GS_HIP(hipGetLastError());
+  poly_canon_dev(c, out_std, n, 0);
+}
+
 void scaled_powers_dev(Ctx& c, const uint64_t base[4], const uint64_t scale_std[4], size_t count, uint32_t* out_std) {
   // scale is passed in STANDARD limbs (not converted): acc starts as the raw value, Montgomery products by base keep it standard
   FrConst sc;
@@ -497,6 +546,7 @@ void fr_words_from_mont(const Fe<ModR, 2>& a, uint64_t out[4]) {
 }
 void fr_mul_words(const uint64_t a[4], const uint64_t b[4], uint64_t out[4]) { fr_words_from_mont(mul(fr_from_words_mont(a), fr_from_words_mont(b)), out); }
 void fr_inv_words(const uint64_t a[4], uint64_t out[4]) { fr_words_from_mont(inv(fr_from_words_mont(a)), out); }
+void fr_sub_words(const uint64_t a[4], const uint64_t b[4], uint64_t out[4]) { fr_words_from_mont(reduce2(sub(fr_from_words_mont(a), fr_from_words_mont(b))), out); }
 bool fr_is_zero_words(const uint64_t a[4]) { return is_zero(fr_from_words_mont(a)); }
 // prod_{k=1}^{count} (x - k)
 void fr_falling_product_words(const uint64_t x[4], size_t count, uint64_t out[4]) {

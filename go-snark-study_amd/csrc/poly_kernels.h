@@ -588,7 +588,7 @@ __global__ void __launch_bounds__(256) k_hx_values(const uint32_t* __restrict__ 
   const Fr2 ab = mul(load_fr(conv + at * 8), load_fr(conv + ((size_t)N + at) * 8));
   const Fr2 x = mul(ab, load_fr(t1 + (size_t)i * 8));
   const Fr2 y = mul(load_fr(conv + ((size_t)2 * N + at) * 8), load_fr(t2 + (size_t)i * 8));
-  store_fr(hv + (size_t)i * 8, reduce2(sub(x, y)));
+  store_fr_canon(hv + (size_t)i * 8, canon(reduce2(sub(x, y))));      // canonical: these values are MSM scalars on the evaluation-basis route
 }
 // a_j b_j == c_j at every root j of Z (j = 1..dz)?  bad[0] counts the violations
 __global__ void __launch_bounds__(256) k_r1cs_check(const uint32_t* __restrict__ vals, uint32_t n, uint32_t dz, const FrConst r2, uint32_t* __restrict__ bad) {

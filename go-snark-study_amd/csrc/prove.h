@@ -18,6 +18,13 @@ struct GrothPkObj : Object {      // groth16.Pk (groth16/groth16.go:15-32), resi
   G1Affine alpha, beta, delta;             // host, Montgomery
   G2Affine beta2, delta2;
   Divisor z;                               // pk.Z with cached 1/rev(Z) series + spectrum
+  // Evaluation-basis copy of PowersTauDelta (optional; gs_groth16_setup builds it, gs_groth16_pk_set_eval attaches one):
+  //   ptd_eval[j-1] = l_j(tau) * Z(tau) / delta * G,  l_j = Lagrange basis over the nodes n+1 .. 2n  (j = 1..n_eval = #constraints)
+  // so that  sum_j H(n+j) ptd_eval[j-1] = H(tau) Z(tau) / delta * G = sum_i h_i PowersTauDelta[i]  (groth16.go:139-149, 269-271):
+  // the witness route runs the h-MSM over H's VALUES and never interpolates H.  A slice holds entries [e_lo, e_lo + n_e).
+  size_t n_eval = 0, e_lo = 0, n_e = 0;
+  DevBuf ptd_eval;
+  BaseTable t_ptd_eval;
   GrothPkObj() : Object(Kind::GrothPk) {}
 };
 
@@ -27,6 +34,11 @@ struct PinocchioPkObj : Object {  // snark.Pk (snark.go:16-26), resident
   DevBuf b2;                               // packed affine G2
   BaseTable t_a, t_ap, t_bp, t_c, t_cp, t_kp, t_g1t, t_b2;
   Divisor z;
+  // evaluation-basis copy of G1T (optional, as GrothPkObj::ptd_eval): g1t_eval[j-1] = l_j(tau) * G over the nodes n+1 .. 2n, so that
+  // sum_j H(n+j) g1t_eval[j-1] = H(tau) G = sum_i h_i G1T[i]  (snark.go:239-247, 284-286)
+  size_t n_eval = 0;
+  DevBuf g1t_eval;
+  BaseTable t_g1t_eval;
   PinocchioPkObj() : Object(Kind::PinocchioPk) {}
 };
 

@@ -34,16 +34,31 @@ struct DevScalars {            // a scalar vector used by a prove call (not owne
                                        // consumes it (px from the resident R1CS, behind the accumulations over w)
   std::function<bool(Ctx&, uint32_t*)> produce_hx;   // if set: try to compute hx = px / Z directly (poly.h: hx_direct_dev) into the given
                                                      // buffer; false = not applicable, fall back to produce + quotient
+  // Evaluation-basis route (keys with ptd_eval / g1t_eval): if set, the h-MSM runs over H's VALUES at the nodes n+1..2n, which this
+  // writes (n_eval of them) into the first buffer; the second is a device word that receives the number of violated constraints.
+  // No host wait: the word is read when the proof is collected, and a non-zero count sends the caller down the exact route.
+  std::function<void(Ctx&, uint32_t*, uint32_t*)> produce_hv;
 };
 
 // Per-context staging of the prover entry points (device memory belongs to one device).
 struct ProveState {
-  DevBuf hx[Ctx::kSlots];                       // hx = floor(px / Z), one per slot (standard form)
+  DevBuf hx[Ctx::kSlots];                       // hx = floor(px / Z) -- or H's values on the evaluation-basis route --, one per slot (standard form)
   DevBuf up_w, up_px, up_a, up_b, up_o;         // uploads of host operands / results (blocking entry points only)
+  DevBuf bad_dev;                               // violated-constraint counters of the evaluation-basis route, one word per slot ...
+  uint32_t* bad_host = nullptr;                 // ... and their pinned host copies (written by an async copy behind the check kernel)
+  ProveState() {
+    bad_dev.alloc(Ctx::kSlots * 4);
+    GS_HIP(hipHostMalloc(reinterpret_cast<void**>(&bad_host), Ctx::kSlots * 4, hipHostMallocDefault));
+    memset(bad_host, 0, Ctx::kSlots * 4);
+  }
+  ~ProveState() { if (bad_host && !process_exiting()) (void)hipHostFree(bad_host); }
 };
 ProveState& prove_state(Ctx& c) { return c.state<ProveState>(c.prove_state); }
 
 size_t quotient_len(size_t npx, size_t nz) { return npx >= nz ? npx - nz + 1 : 0; }
+// internal status of *_collect: the witness violates a constraint, so the optimistic evaluation-basis result is void --
+// run the exact route (px, floor quotient) instead.  Never crosses the C ABI.
+constexpr int kRetryExact = 1;
 
 // Stream layout of one proof (all device work is enqueued before the host waits once):
 //   main  : plan(w) -> accumulate G2 over w -> accumulate G1 x3 over w -> [wait plan(h)] accumulate G1 over h -> its tail
@@ -88,6 +103,8 @@ struct GrothInFlight : InFlightBase {
   std::shared_ptr<PhaseTimer> tpoly, tplanw, tplanh;
   GrothTailPre pre;
   std::future<void> fpre;
+  const uint32_t* bad_host = nullptr;      // evaluation-basis route: the violated-constraint count (valid once done_h has fired)
+  std::function<int(Ctx&, GrothSums&)> exact_route;   // ... and what to run instead when it is not zero (witness tickets)
   GrothInFlight() {
     GS_HIP(hipEventCreateWithFlags(&planw, hipEventDisableTiming));
     GS_HIP(hipEventCreateWithFlags(&planh, hipEventDisableTiming));
@@ -107,8 +124,9 @@ int groth16_enqueue(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, const S
                     GrothInFlight& st) {
   DevBuf& hxbuf = prove_state(c).hx[parity];
   if (w.n != pk->nvars) return fail(GS_ERR_SHAPE, "len(w) = %zu but the key has %zu variables", w.n, pk->nvars);
-  const size_t nh = quotient_len(px.n, pk->nz);
-  if (nh > pk->nptd)
+  const bool eval = (bool)px.produce_hv;        // h-MSM over H's values against the evaluation-basis table (the caller checked the key has one)
+  const size_t nh = eval ? pk->n_eval : quotient_len(px.n, pk->nz);
+  if (!eval && nh > pk->nptd)
     return fail(GS_ERR_SHAPE, "len(hx) = len(px) - len(Z) + 1 = %zu exceeds len(PowersTauDelta) = %zu (groth16.go:269-271)", nh, pk->nptd);
   const bool sliced = pk->shard_count > 1;
   if (sliced && (shard.index != pk->shard_index || shard.count != pk->shard_count))
@@ -116,11 +134,13 @@ int groth16_enqueue(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, const S
                 "(asked for %zu of %zu)", pk->shard_index, pk->shard_count, shard.index, shard.count);
   size_t wlo, whi, hlo, hhi;
   shard_range(w.n, shard, wlo, whi);
-  if (sliced) {                     // a slice's PowersTauDelta range was fixed at key creation (split of len(PTD), clipped to len(hx))
+  if (sliced && eval) { hlo = pk->e_lo; hhi = pk->e_lo + pk->n_e; }
+  else if (sliced) {                // a slice's PowersTauDelta range was fixed at key creation (split of len(PTD), clipped to len(hx))
     hlo = std::min(pk->h_lo, nh);
     hhi = std::min(pk->h_lo + pk->n_h, nh);
   } else shard_range(nh, shard, hlo, hhi);
-  const size_t wbase = wlo - pk->w_lo, hbase = hlo - std::min(pk->h_lo, hlo);      // offsets into the arrays this key holds
+  const size_t held_lo = eval ? pk->e_lo : pk->h_lo;
+  const size_t wbase = wlo - pk->w_lo, hbase = hlo - std::min(held_lo, hlo);      // offsets into the arrays this key holds
   {
     const int cw = choose_window_bits((uint32_t)std::max<size_t>(whi - wlo, 1), c.window_bits);
     const int ch = choose_window_bits((uint32_t)std::max<size_t>(hhi - hlo, 1), c.window_bits);
@@ -128,7 +148,8 @@ int groth16_enqueue(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, const S
     ensure_table_g1(c, pk->t_bacgamma1, pk->bacgamma1.as<uint32_t>(), pk->n_w, cw);
     ensure_table_g1(c, pk->t_bacdelta, pk->bacdelta.as<uint32_t>(), pk->n_w, cw);
     ensure_table_g2(c, pk->t_bacgamma2, pk->bacgamma2.as<uint32_t>(), pk->n_w, cw);
-    ensure_table_g1(c, pk->t_ptd, pk->ptd.as<uint32_t>(), pk->n_h, ch);
+    if (eval) ensure_table_g1(c, pk->t_ptd_eval, pk->ptd_eval.as<uint32_t>(), pk->n_e, ch);
+    else ensure_table_g1(c, pk->t_ptd, pk->ptd.as<uint32_t>(), pk->n_h, ch);
     hxbuf.ensure(std::max<size_t>(nh, 1) * 32);
   }
   st.pk = pk;
@@ -179,7 +200,14 @@ int groth16_enqueue(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, const S
     }
     st.tpoly = std::make_shared<PhaseTimer>(c.stream);
     bool have_hx = false;
-    if (px.produce_hx && nh) have_hx = px.produce_hx(c, hxbuf.as<uint32_t>());  // H from the constraint values (satisfying witness)
+    if (eval) {                                                                // H's values, for the evaluation-basis table
+      ProveState& ps = prove_state(c);
+      px.produce_hv(c, hxbuf.as<uint32_t>(), ps.bad_dev.as<uint32_t>() + parity);
+      GS_HIP(hipMemcpyAsync(ps.bad_host + parity, ps.bad_dev.as<uint32_t>() + parity, 4, hipMemcpyDeviceToHost, c.stream));
+      st.bad_host = ps.bad_host + parity;
+      have_hx = true;
+    }
+    if (!have_hx && px.produce_hx && nh) have_hx = px.produce_hx(c, hxbuf.as<uint32_t>());  // H from the constraint values (satisfying witness)
     if (!have_hx) {
       if (px.produce) px.produce(c);                                           // r1csqap.go:161-210 on the sparse system
       if (nh) poly_quotient_dev(c, pk->z, px.p, px.n, hxbuf.as<uint32_t>());    // groth16.go:266
@@ -195,7 +223,7 @@ int groth16_enqueue(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, const S
     GS_HIP(hipStreamWaitEvent(c.stream, st.planh, 0));
     // a lone proof finishes soonest with the last tail right behind its accumulation; in a pipeline that tail must not sit
     // in front of the next proof's accumulations
-    msm_enqueue_g1(c, plan_h, {MsmBase{&pk->t_ptd, hbase}}, ws + 3, pin + 2, st.pend_h, pipelined ? c.tail_stream(1) : nullptr);   // :269-271
+    msm_enqueue_g1(c, plan_h, {MsmBase{eval ? &pk->t_ptd_eval : &pk->t_ptd, hbase}}, ws + 3, pin + 2, st.pend_h, pipelined ? c.tail_stream(1) : nullptr);   // :269-271
     GS_HIP(hipEventRecord(st.done_h, pipelined ? c.tail_stream(1) : c.main_stream));
   }
   st.total->stop();
@@ -235,14 +263,21 @@ int groth16_collect(Ctx& c, GrothInFlight& st, GrothSums& sums) {
   c.timing.plan_ms += st.tplanw->ms() + st.tplanh->ms();
   c.timing.total_ms += st.total->ms();
   sums.at = g1w[0]; sums.bacgamma1 = g1w[1]; sums.bacdelta = g1w[2]; sums.h = g1h[0]; sums.bacgamma2 = g2w[0];
+  // evaluation-basis route: H's values only determine H when A B - C vanishes at every root of Z
+  if (st.bad_host && *st.bad_host != 0) return kRetryExact;
   return GS_OK;
 }
 
 int groth16_sums_impl(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, const Shard& shard, GrothSums& sums) {
-  GrothInFlight st;
-  const int rc = groth16_enqueue(c, pk, w, px, shard, Ctx::kBlockingSlot, true, false, st);
-  if (rc != GS_OK) return rc;
-  return groth16_collect(c, st, sums);
+  for (;;) {
+    GrothInFlight st;
+    int rc = groth16_enqueue(c, pk, w, px, shard, Ctx::kBlockingSlot, true, false, st);
+    if (rc != GS_OK) return rc;
+    rc = groth16_collect(c, st, sums);
+    if (rc != kRetryExact) return rc;
+    px.produce_hv = nullptr;                   // violated constraint: once more through px and the floor quotient
+    c.timing.fallbacks += 1;
+  }
 }
 
 // --- the O(1) tail on host cores (groth16.go:253-275) ----------------------------------------------------
@@ -289,10 +324,19 @@ int groth16_prove_impl(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, cons
   GrothTailPre pre;
   std::future<void> fpre = std::async(std::launch::async, [&] { groth16_tail_pre(pk, r, s, pre); });
   GrothSums sums;
-  GrothInFlight st;
-  int rc = groth16_enqueue(c, pk, w, px, Shard{}, Ctx::kBlockingSlot, true, false, st);
-  const double t1 = host_trace() ? host_now_ms() : 0;
-  if (rc == GS_OK) rc = groth16_collect(c, st, sums);
+  int rc;
+  double t1 = 0;
+  {
+    GrothInFlight st;
+    rc = groth16_enqueue(c, pk, w, px, Shard{}, Ctx::kBlockingSlot, true, false, st);
+    t1 = host_trace() ? host_now_ms() : 0;
+    if (rc == GS_OK) rc = groth16_collect(c, st, sums);
+  }
+  if (rc == kRetryExact) {                     // violated constraint on the evaluation-basis route: the exact route, blocking
+    px.produce_hv = nullptr;
+    c.timing.fallbacks += 1;
+    rc = groth16_sums_impl(c, pk, w, px, Shard{}, sums);
+  }
   const double t2 = host_trace() ? host_now_ms() : 0;
   fpre.get();
   if (rc != GS_OK) return rc;
@@ -307,6 +351,8 @@ struct PinInFlight : InFlightBase {
   std::unique_ptr<PhaseTimer> total;
   MsmPending pend_g1w, pend_g2w, pend_h;
   std::shared_ptr<PhaseTimer> tpoly, tplanw, tplanh;
+  const uint32_t* bad_host = nullptr;                       // as GrothInFlight
+  std::function<int(Ctx&, uint64_t*, int*)> exact_route;
   PinInFlight() {
     for (hipEvent_t* e : {&planw, &planh, &done_main, &done_g2, &done_g1w, &done_h}) GS_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
   }
@@ -320,8 +366,9 @@ struct PinInFlight : InFlightBase {
 int pinocchio_enqueue(Ctx& c, PinocchioPkObj* pk, DevScalars w, DevScalars px, int parity, bool wait_inputs, bool pipelined, PinInFlight& st) {
   DevBuf& hxbuf = prove_state(c).hx[parity];
   if (w.n != pk->nvars) return fail(GS_ERR_SHAPE, "len(w) = %zu but the key has %zu variables", w.n, pk->nvars);
-  const size_t nh = quotient_len(px.n, pk->nz);
-  if (nh > pk->ng1t) return fail(GS_ERR_SHAPE, "len(hx) = %zu exceeds len(G1T) = %zu (snark.go:284-286)", nh, pk->ng1t);
+  const bool eval = (bool)px.produce_hv;        // h-MSM over H's values against g1t_eval (the caller checked the key has one)
+  const size_t nh = eval ? pk->n_eval : quotient_len(px.n, pk->nz);
+  if (!eval && nh > pk->ng1t) return fail(GS_ERR_SHAPE, "len(hx) = %zu exceeds len(G1T) = %zu (snark.go:284-286)", nh, pk->ng1t);
   {
     const int cw = choose_window_bits((uint32_t)w.n, c.window_bits), ch = choose_window_bits((uint32_t)std::max<size_t>(nh, 1), c.window_bits);
     ensure_table_g1(c, pk->t_a, pk->a.as<uint32_t>(), pk->nvars, cw);
@@ -331,7 +378,8 @@ int pinocchio_enqueue(Ctx& c, PinocchioPkObj* pk, DevScalars w, DevScalars px, i
     ensure_table_g1(c, pk->t_cp, pk->cp.as<uint32_t>(), pk->nvars, cw);
     ensure_table_g1(c, pk->t_kp, pk->kp.as<uint32_t>(), pk->nvars, cw);
     ensure_table_g2(c, pk->t_b2, pk->b2.as<uint32_t>(), pk->nvars, cw);
-    ensure_table_g1(c, pk->t_g1t, pk->g1t.as<uint32_t>(), pk->ng1t, ch);
+    if (eval) ensure_table_g1(c, pk->t_g1t_eval, pk->g1t_eval.as<uint32_t>(), pk->n_eval, ch);
+    else ensure_table_g1(c, pk->t_g1t, pk->g1t.as<uint32_t>(), pk->ng1t, ch);
     hxbuf.ensure(std::max<size_t>(nh, 1) * 32);
   }
   st.total = std::make_unique<PhaseTimer>(c.main_stream);
@@ -373,7 +421,14 @@ int pinocchio_enqueue(Ctx& c, PinocchioPkObj* pk, DevScalars w, DevScalars px, i
     }
     st.tpoly = std::make_shared<PhaseTimer>(c.stream);
     bool have_hx = false;
-    if (px.produce_hx && nh) have_hx = px.produce_hx(c, hxbuf.as<uint32_t>());   // H from the constraint values (satisfying witness)
+    if (eval) {                                                                 // H's values, for the evaluation-basis table
+      ProveState& ps = prove_state(c);
+      px.produce_hv(c, hxbuf.as<uint32_t>(), ps.bad_dev.as<uint32_t>() + parity);
+      GS_HIP(hipMemcpyAsync(ps.bad_host + parity, ps.bad_dev.as<uint32_t>() + parity, 4, hipMemcpyDeviceToHost, c.stream));
+      st.bad_host = ps.bad_host + parity;
+      have_hx = true;
+    }
+    if (!have_hx && px.produce_hx && nh) have_hx = px.produce_hx(c, hxbuf.as<uint32_t>());   // H from the constraint values (satisfying witness)
     if (!have_hx) {
       if (px.produce) px.produce(c);                                            // r1csqap.go:191-210 on the sparse system
       if (nh) poly_quotient_dev(c, pk->z, px.p, px.n, hxbuf.as<uint32_t>());     // snark.go:280
@@ -387,7 +442,7 @@ int pinocchio_enqueue(Ctx& c, PinocchioPkObj* pk, DevScalars w, DevScalars px, i
   {                                                              // main again: the accumulation over h
     StreamScope sc(c, c.main_stream);
     GS_HIP(hipStreamWaitEvent(c.stream, st.planh, 0));
-    msm_enqueue_g1(c, plan_h, {MsmBase{&pk->t_g1t, 0}}, ws + 7, pin + 2, st.pend_h, pipelined ? c.tail_stream(1) : nullptr);   // :284-286
+    msm_enqueue_g1(c, plan_h, {MsmBase{eval ? &pk->t_g1t_eval : &pk->t_g1t, 0}}, ws + 7, pin + 2, st.pend_h, pipelined ? c.tail_stream(1) : nullptr);   // :284-286
     GS_HIP(hipEventRecord(st.done_h, pipelined ? c.tail_stream(1) : c.main_stream));
   }
   st.total->stop();
@@ -413,6 +468,8 @@ int pinocchio_collect(Ctx& c, PinInFlight& st, uint64_t out[72], int inf[8]) {
   msm_book_timing(c, st.pend_g1w); msm_book_timing(c, st.pend_g2w); msm_book_timing(c, st.pend_h);
   c.timing.poly_ms += st.tpoly->ms();
   c.timing.plan_ms += st.tplanw->ms() + st.tplanh->ms();
+  c.timing.total_ms += st.total->ms();
+  if (st.bad_host && *st.bad_host != 0) return kRetryExact;   // evaluation-basis route on a witness that violates a constraint
   // output order: PiA | PiAp | PiB | PiBp | PiC | PiCp | PiH | PiKp
   inf[0] = g1_to_affine_std(g1w[0], out) ? 1 : 0;
   inf[1] = g1_to_affine_std(g1w[1], out + 8) ? 1 : 0;
@@ -422,15 +479,19 @@ int pinocchio_collect(Ctx& c, PinInFlight& st, uint64_t out[72], int inf[8]) {
   inf[5] = g1_to_affine_std(g1w[4], out + 48) ? 1 : 0;
   inf[6] = g1_to_affine_std(g1h[0], out + 56) ? 1 : 0;
   inf[7] = g1_to_affine_std(g1w[5], out + 64) ? 1 : 0;
-  c.timing.total_ms += st.total->ms();
   return GS_OK;
 }
 
 int pinocchio_prove_impl(Ctx& c, PinocchioPkObj* pk, DevScalars w, DevScalars px, uint64_t out[72], int inf[8]) {
-  PinInFlight st;
-  const int rc = pinocchio_enqueue(c, pk, w, px, Ctx::kBlockingSlot, true, false, st);
-  if (rc != GS_OK) return rc;
-  return pinocchio_collect(c, st, out, inf);
+  for (;;) {
+    PinInFlight st;
+    int rc = pinocchio_enqueue(c, pk, w, px, Ctx::kBlockingSlot, true, false, st);
+    if (rc != GS_OK) return rc;
+    rc = pinocchio_collect(c, st, out, inf);
+    if (rc != kRetryExact) return rc;
+    px.produce_hv = nullptr;                   // violated constraint: once more through px and the floor quotient
+    c.timing.fallbacks += 1;
+  }
 }
 
 // zero the first `count` packed points (-> infinity)
@@ -716,7 +777,8 @@ int gs_groth16_prove_end(uint64_t ticket, uint64_t out_proof[32], int inf[3]) {
     GrothInFlight& st = static_cast<GrothInFlight&>(*base);
     reset_timing(c);
     GrothSums sums;
-    const int rc = groth16_collect(c, st, sums);
+    int rc = groth16_collect(c, st, sums);
+    if (rc == kRetryExact && st.exact_route) { c.timing.fallbacks += 1; rc = st.exact_route(c, sums); }
     if (rc != GS_OK) return rc;
     st.fpre.get();
     groth16_tail_post(st.pk, sums, st.pre, st.r, st.s, out_proof, inf);
@@ -857,8 +919,11 @@ int gs_pinocchio_prove_end(uint64_t ticket, uint64_t out_proof[72], int inf[8]) 
     if (!dynamic_cast<PinInFlight*>(c.inflight[parity].get()))
       return fail(GS_ERR_ARG, "gs_pinocchio_prove_end: ticket %llu is not a Pinocchio proof", (unsigned long long)ticket);
     std::unique_ptr<InFlightBase> base = std::move(c.inflight[parity]);
+    PinInFlight& st = static_cast<PinInFlight&>(*base);
     reset_timing(c);
-    return pinocchio_collect(c, static_cast<PinInFlight&>(*base), out_proof, inf);
+    int rc = pinocchio_collect(c, st, out_proof, inf);
+    if (rc == kRetryExact && st.exact_route) { c.timing.fallbacks += 1; rc = st.exact_route(c, out_proof, inf); }
+    return rc;
   }, true, true, ticket);
 }
 
@@ -1075,11 +1140,38 @@ int gs_groth16_prove_r1cs(gs_handle hpk, gs_handle hr1cs, gs_handle hw, gs_handl
   }, true, false, hpk);
 }
 
-// Witness -> proof without ever forming px: H(x) comes straight from the constraint values [A w | B w | C w] (one batched
-// convolution, ONE interpolation, one Taylor shift: poly.h, hx_direct_dev) instead of three interpolations, a size-2n product
-// and a division (CombinePolynomials + DivisorPolynomial, r1csqap.go:191-216).  Requires what a proof requires anyway -- a witness
-// that satisfies the R1CS; when a constraint is violated the call takes the exact route of gs_groth16_prove_r1cs and returns the
-// same (meaningless) proof the reference would.  Same result as gs_r1cs_px + gs_groth16_prove_resident.
+// Witness -> proof without ever forming px (the fast form of CombinePolynomials + DivisorPolynomial, r1csqap.go:191-216, for a
+// witness that satisfies the R1CS -- the only case in which a proof means anything):
+//   * key with an evaluation-basis copy of PowersTauDelta (gs_groth16_setup builds one): the values of H at the nodes n+1..2n come
+//     out of ONE batched convolution of the constraint values [A w | B w | C w], and the h-MSM runs over those values.  No
+//     interpolation, no Taylor shift, no host wait: the violated-constraint count is read when the proof is collected.
+//   * key without one: H's coefficients from the same values by one interpolation and a Taylor shift (poly.h, hx_direct_dev).
+// When a constraint is violated the call takes the exact route of gs_groth16_prove_r1cs and returns the same (meaningless) proof
+// the reference would.  Same result as gs_r1cs_px + gs_groth16_prove_resident either way.
+static bool hx_shape(size_t n, size_t nz) { return n >= 2 && nz >= 1 && (nz - 1 == n - 1 || nz - 1 == n); }
+
+// the three ways to the h-scalars of a witness proof, in the order the prover tries them
+static DevScalars witness_scalars(R1csObj* o, const uint32_t* wdev, size_t nz, bool eval, std::function<uint32_t*(Ctx&)> px_buffer) {
+  const size_t npx = 2 * o->n - 1, dz = nz - 1;
+  DevScalars dp{nullptr, npx};
+  if (eval)
+    dp.produce_hv = [o, wdev, dz](Ctx& cc, uint32_t* hv, uint32_t* bad) {
+      r1cs_values_dev(cc, *o, wdev);
+      r1cs_check_dev(cc, o->vals.as<uint32_t>(), o->n, dz, bad);
+      hx_values_dev(cc, o->vals.as<uint32_t>(), o->n, dz, hv);
+    };
+  dp.produce_hx = [o, wdev, dz](Ctx& cc, uint32_t* hx) { r1cs_values_dev(cc, *o, wdev); return hx_direct_dev(cc, o->vals.as<uint32_t>(), o->n, dz, hx); };
+  dp.produce = [o, wdev, px_buffer](Ctx& cc) { r1cs_px_dev(cc, *o, wdev, px_buffer(cc)); };
+  return dp;
+}
+// px of the exact route lives in the blocking entry points' staging buffer (allocated only if that route is ever taken)
+static uint32_t* exact_px_buffer(Ctx& c, R1csObj* o) {
+  const size_t npx = 2 * o->n - 1;
+  o->prod.ensure(npx * 32);
+  prove_state(c).up_px.ensure(npx * 32);
+  return prove_state(c).up_px.as<uint32_t>();
+}
+
 int gs_groth16_prove_witness(gs_handle hpk, gs_handle hr1cs, gs_handle hw, const uint64_t r[4], const uint64_t s[4], uint64_t out_proof[32], int inf[3]) {
   return guarded([&](Ctx& c) -> int {
     GrothPkObj* pk = c.get<GrothPkObj>(hpk, Kind::GrothPk);
@@ -1088,23 +1180,63 @@ int gs_groth16_prove_witness(gs_handle hpk, gs_handle hr1cs, gs_handle hw, const
     if (!pk || !o || !w) return fail(GS_ERR_ARG, "gs_groth16_prove_witness: bad handle");
     if (!r || !s || !out_proof || !inf) return fail(GS_ERR_ARG, "null argument");
     if (w->n != o->m) return fail(GS_ERR_SHAPE, "len(w) = %zu but the system has %zu variables", w->n, o->m);
-    const size_t npx = 2 * o->n - 1;
     reset_timing(c);
-    o->prod.ensure(npx * 32);                                     // px, only written on the fallback route
     const uint32_t* wdev = w->buf.as<uint32_t>();
-    DevBuf& pxbuf = prove_state(c).up_px;
-    pxbuf.ensure(npx * 32);
-    uint32_t* pxdev = pxbuf.as<uint32_t>();
-    DevScalars dp{pxdev, npx};
-    const size_t dz = pk->nz - 1;
-    dp.produce_hx = [o, wdev, dz](Ctx& cc, uint32_t* hx) { r1cs_values_dev(cc, *o, wdev); return hx_direct_dev(cc, o->vals.as<uint32_t>(), o->n, dz, hx); };
-    dp.produce = [o, wdev, pxdev](Ctx& cc) { r1cs_px_dev(cc, *o, wdev, pxdev); };
+    const bool eval = c.eval_basis && pk->shard_count == 1 && pk->n_eval == o->n && hx_shape(o->n, pk->nz);
+    uint32_t* pxdev = exact_px_buffer(c, o);
+    DevScalars dp = witness_scalars(o, wdev, pk->nz, eval, [pxdev](Ctx&) { return pxdev; });
+    dp.p = pxdev;
     return groth16_prove_impl(c, pk, DevScalars{wdev, w->n}, dp, r, s, out_proof, inf);
   }, true, false, hpk);
 }
 
+// The same, pipelined: a ticket for gs_groth16_prove_end (which also runs the exact route, blocking, should the witness turn out
+// to violate a constraint).  With an evaluation-basis key nothing in here waits for the device.
+int gs_groth16_prove_witness_begin(gs_handle hpk, gs_handle hr1cs, gs_handle hw, const uint64_t r[4], const uint64_t s[4], uint64_t* ticket) {
+  return guarded([&](Ctx& c) -> int {
+    GrothPkObj* pk = c.get<GrothPkObj>(hpk, Kind::GrothPk);
+    R1csObj* o = c.get<R1csObj>(hr1cs, Kind::R1cs);
+    Scalars* w = c.get<Scalars>(hw, Kind::Scalars);
+    if (!pk || !o || !w) return fail(GS_ERR_ARG, "gs_groth16_prove_witness_begin: bad handle");
+    if (!r || !s || !ticket) return fail(GS_ERR_ARG, "null argument");
+    if (w->n != o->m) return fail(GS_ERR_SHAPE, "len(w) = %zu but the system has %zu variables", w->n, o->m);
+    if (pk->shard_count != 1) return fail(GS_ERR_ARG, "gs_groth16_prove_witness_begin: the key is a slice");
+    const int parity = c.free_parity();
+    if (parity < 0) return fail(GS_ERR_BUSY, "gs_groth16_prove_witness_begin: three operations are already outstanding; call gs_groth16_prove_end first");
+    const bool eval = c.eval_basis && pk->n_eval == o->n && hx_shape(o->n, pk->nz);
+    auto st = std::make_unique<GrothInFlight>();
+    memcpy(st->r, r, 32); memcpy(st->s, s, 32);
+    st->with_tail = true;
+    GrothInFlight* raw = st.get();
+    raw->pk = pk;
+    raw->keep = {c.share<Object>(hpk, Kind::GrothPk), c.share<Object>(hr1cs, Kind::R1cs), c.share<Object>(hw, Kind::Scalars)};
+    raw->fpre = std::async(std::launch::async, [raw] { groth16_tail_pre(raw->pk, raw->r, raw->s, raw->pre); });
+    const uint32_t* wdev = w->buf.as<uint32_t>();
+    const size_t nw = w->n, nz = pk->nz;
+    DevScalars dp = witness_scalars(o, wdev, nz, eval, [o](Ctx& cc) { return exact_px_buffer(cc, o); });
+    if (!eval) {                               // the monomial route may have to write px at once (its check is a host wait inside enqueue)
+      dp.p = exact_px_buffer(c, o);
+    } else {
+      dp.produce_hx = nullptr; dp.produce = nullptr;
+      raw->exact_route = [pk, o, wdev, nw, nz](Ctx& cc, GrothSums& sums) {
+        uint32_t* pxdev = exact_px_buffer(cc, o);
+        DevScalars ex = witness_scalars(o, wdev, nz, false, [pxdev](Ctx&) { return pxdev; });
+        ex.p = pxdev;
+        return groth16_sums_impl(cc, pk, DevScalars{wdev, nw}, ex, Shard{}, sums);
+      };
+    }
+    const int rc = groth16_enqueue(c, pk, DevScalars{wdev, nw}, dp, Shard{}, parity, false, true, *raw);
+    if (rc != GS_OK) return rc;
+    st->ticket = c.new_ticket();
+    *ticket = st->ticket;
+    c.inflight[parity] = std::move(st);
+    return GS_OK;
+  }, true, true, hpk);
+}
+
 // snark.GenerateProofs straight from the witness (the Pinocchio twin of gs_groth16_prove_witness): CombinePolynomials + Div
-// (r1csqap.go:191-216, snark.go:280) collapse into H(x) from the constraint values; the exact px route when a constraint is violated.
+// (r1csqap.go:191-216, snark.go:280) collapse into H's values (evaluation-basis key) or H(x) from the constraint values; the exact
+// px route when a constraint is violated.
 int gs_pinocchio_prove_witness(gs_handle hpk, gs_handle hr1cs, gs_handle hw, uint64_t out_proof[72], int inf[8]) {
   return guarded([&](Ctx& c) -> int {
     PinocchioPkObj* pk = c.get<PinocchioPkObj>(hpk, Kind::PinocchioPk);
@@ -1114,19 +1246,50 @@ int gs_pinocchio_prove_witness(gs_handle hpk, gs_handle hr1cs, gs_handle hw, uin
     if (!out_proof || !inf) return fail(GS_ERR_ARG, "null argument");
     if (w->n != o->m) return fail(GS_ERR_SHAPE, "len(w) = %zu but the system has %zu variables", w->n, o->m);
     if (pk->nz == 0) return fail(GS_ERR_SHAPE, "the key has no Z");
-    const size_t npx = 2 * o->n - 1;
     reset_timing(c);
-    o->prod.ensure(npx * 32);
     const uint32_t* wdev = w->buf.as<uint32_t>();
-    DevBuf& pxbuf = prove_state(c).up_px;
-    pxbuf.ensure(npx * 32);
-    uint32_t* pxdev = pxbuf.as<uint32_t>();
-    DevScalars dp{pxdev, npx};
-    const size_t dz = pk->nz - 1;
-    dp.produce_hx = [o, wdev, dz](Ctx& cc, uint32_t* hx) { r1cs_values_dev(cc, *o, wdev); return hx_direct_dev(cc, o->vals.as<uint32_t>(), o->n, dz, hx); };
-    dp.produce = [o, wdev, pxdev](Ctx& cc) { r1cs_px_dev(cc, *o, wdev, pxdev); };
+    const bool eval = c.eval_basis && pk->n_eval == o->n && hx_shape(o->n, pk->nz);
+    uint32_t* pxdev = exact_px_buffer(c, o);
+    DevScalars dp = witness_scalars(o, wdev, pk->nz, eval, [pxdev](Ctx&) { return pxdev; });
+    dp.p = pxdev;
     return pinocchio_prove_impl(c, pk, DevScalars{wdev, w->n}, dp, out_proof, inf);
   }, true, false, hpk);
+}
+
+int gs_pinocchio_prove_witness_begin(gs_handle hpk, gs_handle hr1cs, gs_handle hw, uint64_t* ticket) {
+  return guarded([&](Ctx& c) -> int {
+    PinocchioPkObj* pk = c.get<PinocchioPkObj>(hpk, Kind::PinocchioPk);
+    R1csObj* o = c.get<R1csObj>(hr1cs, Kind::R1cs);
+    Scalars* w = c.get<Scalars>(hw, Kind::Scalars);
+    if (!pk || !o || !w || !ticket) return fail(GS_ERR_ARG, "gs_pinocchio_prove_witness_begin: bad handle or null ticket");
+    if (w->n != o->m) return fail(GS_ERR_SHAPE, "len(w) = %zu but the system has %zu variables", w->n, o->m);
+    if (pk->nz == 0) return fail(GS_ERR_SHAPE, "the key has no Z");
+    const int parity = c.free_parity();
+    if (parity < 0) return fail(GS_ERR_BUSY, "gs_pinocchio_prove_witness_begin: three operations are already outstanding; call gs_pinocchio_prove_end first");
+    const bool eval = c.eval_basis && pk->n_eval == o->n && hx_shape(o->n, pk->nz);
+    auto st = std::make_unique<PinInFlight>();
+    st->keep = {c.share<Object>(hpk, Kind::PinocchioPk), c.share<Object>(hr1cs, Kind::R1cs), c.share<Object>(hw, Kind::Scalars)};
+    const uint32_t* wdev = w->buf.as<uint32_t>();
+    const size_t nw = w->n, nz = pk->nz;
+    DevScalars dp = witness_scalars(o, wdev, nz, eval, [o](Ctx& cc) { return exact_px_buffer(cc, o); });
+    if (!eval) {
+      dp.p = exact_px_buffer(c, o);
+    } else {
+      dp.produce_hx = nullptr; dp.produce = nullptr;
+      st->exact_route = [pk, o, wdev, nw, nz](Ctx& cc, uint64_t* out, int* inf) {
+        uint32_t* pxdev = exact_px_buffer(cc, o);
+        DevScalars ex = witness_scalars(o, wdev, nz, false, [pxdev](Ctx&) { return pxdev; });
+        ex.p = pxdev;
+        return pinocchio_prove_impl(cc, pk, DevScalars{wdev, nw}, ex, out, inf);
+      };
+    }
+    const int rc = pinocchio_enqueue(c, pk, DevScalars{wdev, nw}, dp, parity, false, true, *st);
+    if (rc != GS_OK) return rc;
+    st->ticket = c.new_ticket();
+    *ticket = st->ticket;
+    c.inflight[parity] = std::move(st);
+    return GS_OK;
+  }, true, true, hpk);
 }
 
 }  // extern "C"

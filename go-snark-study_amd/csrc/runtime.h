@@ -161,6 +161,7 @@ struct Ctx {
   uint64_t next_handle = 1;
   std::unordered_map<uint64_t, std::shared_ptr<Object>> objs;     // in-flight operations hold references: gs_free defers
   int window_bits = 0;           // 0 = auto
+  bool eval_basis = true;        // gs_set_eval_basis: witness route over H's values when the key has an evaluation-basis array
   gs_timing timing{};
   std::mutex timing_mu;          // msm_finish of several groups may run on different host threads
   // reusable workspaces (grow-only)

@@ -64,6 +64,19 @@ void force_infinity_points(Ctx& c, DevBuf& pts, size_t count, size_t words) {
   if (count) GS_HIP(hipMemsetAsync(pts.p, 0, count * words * 4, c.stream));
 }
 
+// scalars of an evaluation-basis array: out[j-1] = scale * l_j(tau), l_j = Lagrange basis over the nodes n+1 .. 2n, j = 1..n
+// (canonical standard form).  l_j(tau) = L_j(tau - n) with L over 1..n, so the node tree's weights serve.  false when tau is
+// one of those nodes (the basis then degenerates; the key simply gets no evaluation-basis copy).
+bool eval_basis_scalars(Ctx& c, size_t n, const uint64_t tau[4], const uint64_t scale_std[4], DevBuf& lag, DevBuf& out) {
+  uint64_t nn[4] = {(uint64_t)n, 0, 0, 0}, tn[4], mtn[4];
+  fr_sub_words(tau, nn, tn);
+  fr_falling_product_words(tn, n, mtn);                       // prod_{k=1}^{n} (tau - n - k)
+  if (fr_is_zero_words(mtn)) return false;
+  lagrange_at_dev(c, n, tn, mtn, lag.as<uint32_t>());         // Montgomery
+  scale_mont_by_std_dev(c, lag.as<uint32_t>(), scale_std, n, out.as<uint32_t>());
+  return true;
+}
+
 template <class T>
 Affine<T> download_point(Ctx& c, const uint32_t* packed_dev) {
   uint32_t w[PointIO<T>::kAffineWords];
@@ -141,6 +154,14 @@ int gs_groth16_setup(size_t n, size_t m, size_t npublic,
     fixed_base_g2(c, bt.as<uint32_t>(), (uint32_t)m, pk->bacgamma2.as<uint32_t>());             // Pk.G2.BACGamma  :169,173
     fixed_base_g1(c, cd.as<uint32_t>(), (uint32_t)m, pk->bacdelta.as<uint32_t>());              // Pk.BACDelta     :177-200 (i <= NPublic: infinity)
     fixed_base_g1(c, pw.as<uint32_t>(), (uint32_t)(m - 1), pk->ptd.as<uint32_t>());             // PowersTauDelta  :139-149
+    // The same group element through H's VALUES (prove.h): ptd_eval[j-1] = l_j(tau) Z(tau) / delta * G with l_j the Lagrange basis
+    // over the nodes n+1 .. 2n, i.e. L_j(tau - n) over 1 .. n -- one more fixed-base batch while tau is still known.
+    DevBuf lag2(n * 32), qe(n * 32);
+    if (eval_basis_scalars(c, n, T, zt_inv_delta, lag2, qe)) {
+      pk->ptd_eval.alloc(n * 64);
+      fixed_base_g1(c, qe.as<uint32_t>(), (uint32_t)n, pk->ptd_eval.as<uint32_t>());
+      pk->n_eval = n; pk->e_lo = 0; pk->n_e = n;
+    }
     // single points: alpha, beta, delta in G1; beta, gamma, delta in G2                          :151-160
     DevBuf s1(3 * 32), s2(3 * 32), p1(3 * 64), p2(3 * 128);
     uint64_t h1[12], h2[12];
@@ -224,6 +245,13 @@ int gs_pinocchio_setup(size_t n, size_t m, size_t npublic,
     fixed_base_g2(c, outs[1], (uint32_t)m, pk->b2.as<uint32_t>());                   // Pk.B                 :192-194
     pk->g1t.alloc((m - 1) * 64);
     fixed_base_g1(c, pw.as<uint32_t>(), (uint32_t)(m - 1), pk->g1t.as<uint32_t>());
+    // evaluation-basis copy of G1T (prove.h): g1t_eval[j-1] = l_j(tau) * G over the nodes n+1 .. 2n
+    DevBuf lag2(n * 32), qe(n * 32);
+    if (eval_basis_scalars(c, n, T, one, lag2, qe)) {
+      pk->g1t_eval.alloc(n * 64);
+      fixed_base_g1(c, qe.as<uint32_t>(), (uint32_t)n, pk->g1t_eval.as<uint32_t>());
+      pk->n_eval = n;
+    }
     DevBuf zc((m - 1) * 32);
     zpoly_dev(c, m - 2, zc.as<uint32_t>());
     divisor_init(c, pk->z, zc.as<uint32_t>(), m - 1);
@@ -291,7 +319,8 @@ int gs_groth16_pk_export(gs_handle hpk, int which, uint64_t* jacobian, size_t co
       case 2: src = &pk->bacgamma2; g2 = true; break;
       case 3: src = &pk->bacdelta; break;
       case 4: src = &pk->ptd; have = pk->n_h; break;
-      default: return fail(GS_ERR_ARG, "gs_groth16_pk_export: which must be 0..6");
+      case 7: src = &pk->ptd_eval; have = pk->n_e; break;       // evaluation-basis copy of PowersTauDelta (0 points when the key has none)
+      default: return fail(GS_ERR_ARG, "gs_groth16_pk_export: which must be 0..7");
     }
     if (count != have || (count && !jacobian)) return fail(GS_ERR_ARG, "gs_groth16_pk_export: array has %zu points, asked for %zu", have, count);
     if (!count) return GS_OK;
@@ -309,16 +338,16 @@ int gs_pinocchio_pk_export(gs_handle hpk, int which, uint64_t* jacobian, size_t 
   return guarded([&](Ctx& c) -> int {
     PinocchioPkObj* pk = c.get<PinocchioPkObj>(hpk, Kind::PinocchioPk);
     if (!pk) return fail(GS_ERR_ARG, "gs_pinocchio_pk_export: bad proving-key handle");
-    const DevBuf* arr[8] = {&pk->a, &pk->ap, &pk->b2, &pk->bp, &pk->c, &pk->cp, &pk->kp, &pk->g1t};
+    const DevBuf* arr[10] = {&pk->a, &pk->ap, &pk->b2, &pk->bp, &pk->c, &pk->cp, &pk->kp, &pk->g1t, nullptr, &pk->g1t_eval};
     if (which == 8) {           // pk.Z: nz coefficients, 4 x u64 each
       if (count != pk->nz || !jacobian) return fail(GS_ERR_ARG, "gs_pinocchio_pk_export: Z has %zu coefficients, asked for %zu", pk->nz, count);
       GS_HIP(hipMemcpyAsync(jacobian, pk->z.b_std.p, count * 32, hipMemcpyDeviceToHost, c.stream));
       GS_HIP(hipStreamSynchronize(c.stream));
       return GS_OK;
     }
-    if (which < 0 || which > 7) return fail(GS_ERR_ARG, "gs_pinocchio_pk_export: which must be 0..8");
+    if (which < 0 || which > 9) return fail(GS_ERR_ARG, "gs_pinocchio_pk_export: which must be 0..9");
     const bool g2 = which == 2;
-    const size_t have = which == 7 ? pk->ng1t : pk->nvars;
+    const size_t have = which == 7 ? pk->ng1t : which == 9 ? pk->n_eval : pk->nvars;     // 9: evaluation-basis copy of G1T (0 points when there is none)
     if (count != have || (count && !jacobian)) return fail(GS_ERR_ARG, "gs_pinocchio_pk_export: array has %zu points, asked for %zu", have, count);
     if (!count) return GS_OK;
     const size_t words = g2 ? 48 : 24;
@@ -329,6 +358,54 @@ int gs_pinocchio_pk_export(gs_handle hpk, int which, uint64_t* jacobian, size_t 
     GS_HIP(hipStreamSynchronize(c.stream));
     return GS_OK;
   });
+}
+
+// Attach an evaluation-basis array to a key that was not built here (a key file that carries one: utils.py's binary container,
+// sections "PowersTauDeltaEval" / "G1TEval"): `bases` holds n_constraints G1 points,
+//   Groth16:   l_j(tau) Z(tau) / delta * G,     Pinocchio:   l_j(tau) * G        (l_j: Lagrange basis over the nodes n+1 .. 2n).
+// The library cannot check the points against tau (nobody knows tau any more); a wrong array gives proofs that do not verify,
+// exactly as a wrong PowersTauDelta does.  n_constraints must be len(Z) - 1 or len(Z).
+int gs_groth16_pk_set_eval(gs_handle hpk, gs_handle hbases) {
+  return guarded([&](Ctx& c) -> int {
+    GrothPkObj* pk = c.get<GrothPkObj>(hpk, Kind::GrothPk);
+    Bases* b = c.get<Bases>(hbases, Kind::G1Bases);
+    if (!pk || !b) return fail(GS_ERR_ARG, "gs_groth16_pk_set_eval: bad handle");
+    if (pk->shard_count != 1) return fail(GS_ERR_ARG, "gs_groth16_pk_set_eval: the key is a slice");
+    const size_t n = b->n;
+    if (n < 2 || pk->nz == 0 || (pk->nz - 1 != n - 1 && pk->nz - 1 != n))
+      return fail(GS_ERR_SHAPE, "gs_groth16_pk_set_eval: %zu points, but deg Z = %zu needs n = deg Z or deg Z + 1 constraints", n, pk->nz ? pk->nz - 1 : 0);
+    pk->t_ptd_eval = BaseTable{};
+    pk->ptd_eval.alloc(n * 64);
+    GS_HIP(hipMemcpyAsync(pk->ptd_eval.p, b->buf.p, n * 64, hipMemcpyDeviceToDevice, c.stream));
+    GS_HIP(hipStreamSynchronize(c.stream));
+    pk->n_eval = n; pk->e_lo = 0; pk->n_e = n;
+    return GS_OK;
+  }, true, false, hpk);
+}
+// number of evaluation-basis points a resident Groth16 or Pinocchio key holds (0 = none; a slice: its own share)
+int gs_pk_eval_count(gs_handle hpk, size_t* count) {
+  return guarded([&](Ctx& c) -> int {
+    if (!count) return fail(GS_ERR_ARG, "gs_pk_eval_count: null output");
+    if (GrothPkObj* g = c.get<GrothPkObj>(hpk, Kind::GrothPk)) { *count = g->n_e; return GS_OK; }
+    if (PinocchioPkObj* p = c.get<PinocchioPkObj>(hpk, Kind::PinocchioPk)) { *count = p->n_eval; return GS_OK; }
+    return fail(GS_ERR_ARG, "gs_pk_eval_count: not a proving-key handle");
+  }, true, true, hpk);
+}
+int gs_pinocchio_pk_set_eval(gs_handle hpk, gs_handle hbases) {
+  return guarded([&](Ctx& c) -> int {
+    PinocchioPkObj* pk = c.get<PinocchioPkObj>(hpk, Kind::PinocchioPk);
+    Bases* b = c.get<Bases>(hbases, Kind::G1Bases);
+    if (!pk || !b) return fail(GS_ERR_ARG, "gs_pinocchio_pk_set_eval: bad handle");
+    const size_t n = b->n;
+    if (n < 2 || pk->nz == 0 || (pk->nz - 1 != n - 1 && pk->nz - 1 != n))
+      return fail(GS_ERR_SHAPE, "gs_pinocchio_pk_set_eval: %zu points, but deg Z = %zu needs n = deg Z or deg Z + 1 constraints", n, pk->nz ? pk->nz - 1 : 0);
+    pk->t_g1t_eval = BaseTable{};
+    pk->g1t_eval.alloc(n * 64);
+    GS_HIP(hipMemcpyAsync(pk->g1t_eval.p, b->buf.p, n * 64, hipMemcpyDeviceToDevice, c.stream));
+    GS_HIP(hipStreamSynchronize(c.stream));
+    pk->n_eval = n;
+    return GS_OK;
+  }, true, false, hpk);
 }
 
 }  // extern "C"

@@ -100,13 +100,17 @@ def GenerateTrustedSetupSparse(n, nvars, npublic, a_csr, b_csr, c_csr, toxic):
     return DevicePk(capi.DeviceHandle(h.value), nvars, npublic, None), vkey
 
 
-PK_ARRAYS = {"G1_At": 0, "G1_BACGamma": 1, "G2_BACGamma": 2, "BACDelta": 3, "PowersTauDelta": 4}
+# "PowersTauDeltaEval": the evaluation-basis copy of PowersTauDelta (include/gosnark_hip.h, gs_groth16_pk_set_eval) -- not a field
+# of the reference's Pk; keys built by gs_groth16_setup carry it, the binary key container stores it as an extra section.
+PK_ARRAYS = {"G1_At": 0, "G1_BACGamma": 1, "G2_BACGamma": 2, "BACDelta": 3, "PowersTauDelta": 4, "PowersTauDeltaEval": 7}
 
 
 def ExportPkArray(dev_pk, name):
     """One array of a resident key as affine Jacobian int tuples (testing / serialisation)."""
     which = PK_ARRAYS[name]
-    count = dev_pk.nvars if which != 4 else dev_pk.nvars - 1
+    count = capi.pk_eval_count(dev_pk.handle) if which == 7 else dev_pk.nvars if which != 4 else dev_pk.nvars - 1
+    if count == 0:
+        return []
     words = 24 if which == 2 else 12
     out = np.zeros((count, words), dtype=np.uint64)
     capi.check(capi.load_library().gs_groth16_pk_export(capi.Handle(dev_pk.handle.h), which, capi.ptr64(out), count))
@@ -254,6 +258,25 @@ def prove_from_witness(dev_pk, dev_r1cs, w_handle, r, s):
     capi.check(capi.load_library().gs_groth16_prove_witness(capi.Handle(dev_pk.handle.h), capi.Handle(dev_r1cs.handle.h), capi.Handle(w_handle.h),
                                                             capi.ptr64(rs[0]), capi.ptr64(rs[1]), capi.ptr64(out), inf))
     return _proof_from_words(out, inf)
+
+
+def prove_witness_begin(dev_pk, dev_r1cs, w_handle, r, s):
+    """Enqueue one witness -> proof (gs_groth16_prove_witness_begin) -> ticket for prove_end.  With an evaluation-basis key the
+    call never waits for the device."""
+    import ctypes
+    rs = capi.ints_to_u64([r % R, s % R])
+    t = ctypes.c_uint64(0)
+    capi.check(capi.load_library().gs_groth16_prove_witness_begin(capi.Handle(dev_pk.handle.h), capi.Handle(dev_r1cs.handle.h), capi.Handle(w_handle.h),
+                                                                  capi.ptr64(rs[0]), capi.ptr64(rs[1]), ctypes.cast(ctypes.byref(t), capi.u64p)))
+    return t.value
+
+
+def SetEvalBasis(dev_pk, points):
+    """Attach an evaluation-basis copy of PowersTauDelta (n Jacobian int triples, e.g. read from a key file) to a resident key:
+    gs_groth16_pk_set_eval.  The witness route then runs its h-MSM over H's values (no interpolation)."""
+    arr = capi.ints_to_u64([c for p in points for c in p]).reshape(-1, 12)
+    b = capi.g1_upload(arr)
+    capi.check(capi.load_library().gs_groth16_pk_set_eval(capi.Handle(dev_pk.handle.h), capi.Handle(b.h)))
 
 
 def prove_partials(dev_pk, w_handle, px_handle, shard_index, shard_count):

@@ -86,6 +86,21 @@ def prove_from_witness(dev_pk, dev_r1cs, w_handle):
     return _proof_from_words(out, inf)
 
 
+def prove_witness_begin(dev_pk, dev_r1cs, w_handle):
+    """Enqueue one witness -> proof (gs_pinocchio_prove_witness_begin) -> ticket for prove_end."""
+    t = ctypes.c_uint64(0)
+    capi.check(capi.load_library().gs_pinocchio_prove_witness_begin(capi.Handle(dev_pk.h), capi.Handle(dev_r1cs.handle.h), capi.Handle(w_handle.h),
+                                                                    ctypes.cast(ctypes.byref(t), capi.u64p)))
+    return t.value
+
+
+def SetEvalBasis(dev_pk, points):
+    """Attach an evaluation-basis copy of G1T (n Jacobian int triples) to a resident key: gs_pinocchio_pk_set_eval."""
+    arr = capi.ints_to_u64([c for p in points for c in p]).reshape(-1, 12)
+    b = capi.g1_upload(arr)
+    capi.check(capi.load_library().gs_pinocchio_pk_set_eval(capi.Handle(dev_pk.h), capi.Handle(b.h)))
+
+
 def prove_begin(dev_pk, w_handle, px_handle):
     """Enqueue one Pinocchio proof (gs_pinocchio_prove_begin) -> ticket.  Up to three operations may be outstanding."""
     t = ctypes.c_uint64(0)
@@ -112,7 +127,7 @@ class Vk:
             setattr(self, k, kw[k])
 
 
-PK_ARRAYS = {"A": 0, "Ap": 1, "B": 2, "Bp": 3, "C": 4, "Cp": 5, "Kp": 6, "G1T": 7}
+PK_ARRAYS = {"A": 0, "Ap": 1, "B": 2, "Bp": 3, "C": 4, "Cp": 5, "Kp": 6, "G1T": 7, "G1TEval": 9}   # G1TEval: evaluation-basis copy of G1T
 
 
 class DevicePk:
@@ -148,7 +163,9 @@ def GenerateTrustedSetupSparse(n, nvars, npublic, a_csr, b_csr, c_csr, toxic):
 
 def ExportPkArray(dev_pk, name):
     which = PK_ARRAYS[name]
-    count = dev_pk.nvars - 1 if which == 7 else dev_pk.nvars
+    count = capi.pk_eval_count(dev_pk.handle) if which == 9 else dev_pk.nvars - 1 if which == 7 else dev_pk.nvars
+    if count == 0:
+        return []
     words = 24 if which == 2 else 12
     out = np.zeros((count, words), dtype=np.uint64)
     capi.check(capi.load_library().gs_pinocchio_pk_export(capi.Handle(dev_pk.h), which, capi.ptr64(out), count))

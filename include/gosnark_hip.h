@@ -209,6 +209,18 @@ int gs_groth16_prove_r1cs(gs_handle pk, gs_handle r1cs, gs_handle w, gs_handle* 
  * the exact route and returns what gs_groth16_prove_r1cs returns.  Same proof as gs_r1cs_px + gs_groth16_prove_resident. */
 int gs_groth16_prove_witness(gs_handle pk, gs_handle r1cs, gs_handle w, const uint64_t r[4], const uint64_t s[4],
                              uint64_t out_proof[32], int inf[3]);
+/* Keys with an EVALUATION-BASIS copy of PowersTauDelta take a shorter way still.  The prover only needs the group element
+ * sum_i h_i PowersTauDelta[i] = H(tau) Z(tau)/delta G (groth16.go:139-149, 269-271); with E[j-1] = l_j(tau) Z(tau)/delta G, l_j the
+ * Lagrange basis over the nodes n+1..2n (n = #constraints), the same element is sum_j H(n+j) E[j-1] -- an MSM over the VALUES of H,
+ * which fall out of the one batched convolution: no interpolation, no Taylor shift, no host wait (the violated-constraint count
+ * is read when the proof is collected; a non-zero count repeats the proof on the exact route).  gs_groth16_setup builds E while it
+ * knows tau (64 B per constraint + its window table; gs_handle_bytes reports both); gs_groth16_pk_set_eval attaches one to a key
+ * loaded from a file (`bases`: n G1 points from gs_g1_upload; nobody can check them against tau -- a wrong array yields proofs that
+ * do not verify, as a wrong PowersTauDelta does); gs_groth16_pk_export which = 7 reads it back.  Bit-identical proofs either way.
+ * gs_groth16_prove_witness_begin is the pipelined form (collect with gs_groth16_prove_end; same three slots per device). */
+int gs_groth16_pk_set_eval(gs_handle pk, gs_handle bases);
+int gs_pk_eval_count(gs_handle pk, size_t* count);     /* Groth16 or Pinocchio key: evaluation-basis points it holds (0 = none) */
+int gs_groth16_prove_witness_begin(gs_handle pk, gs_handle r1cs, gs_handle w, const uint64_t r[4], const uint64_t s[4], uint64_t* ticket);
 
 /* Pipelined proving (inputs resident): gs_groth16_prove_begin enqueues the whole device side of one proof and returns a
  * ticket without waiting; gs_groth16_prove_end waits for THAT proof only, then runs the host tail and writes the proof
@@ -269,13 +281,13 @@ int gs_pinocchio_setup(size_t n, size_t m, size_t npublic,
                        const uint32_t* c_rowptr, const uint32_t* c_col, const uint64_t* c_val,
                        const uint64_t toxic[32], gs_handle* pk_out, uint64_t* vk_out);
 /* Read one array of a resident Pinocchio key back (which = 0 A, 1 Ap, 2 B (G2, 24 words per point), 3 Bp, 4 C, 5 Cp,
- * 6 Kp, 7 G1T; 8 = pk.Z, count coefficients of 4 x u64).  Note A and Ap hold infinity for i <= NPublic (what the
+ * 6 Kp, 7 G1T; 8 = pk.Z, count coefficients of 4 x u64; 9 = the evaluation-basis copy of G1T, n points or none).  Note A and Ap hold infinity for i <= NPublic (what the
  * prover sums, snark.go:265). */
 int gs_pinocchio_pk_export(gs_handle pk, int which, uint64_t* jacobian, size_t count);
 /* Read one array of a resident Groth16 key back as affine Jacobian triples: which = 0 G1.At, 1 G1.BACGamma,
  * 2 G2.BACGamma (24 words per point), 3 BACDelta, 4 PowersTauDelta; 5 = the single elements (count = 5: G1 Alpha, Beta,
- * Delta as 3 x 12 words, then G2 Beta, Delta as 2 x 24 words); 6 = pk.Z (count coefficients of 4 x u64).  count must
- * equal the array length.  With 0..6 a resident key can be written out in full (utils.GrothSetupToString). */
+ * Delta as 3 x 12 words, then G2 Beta, Delta as 2 x 24 words); 6 = pk.Z (count coefficients of 4 x u64); 7 = the
+ * evaluation-basis copy of PowersTauDelta (n points, or 0 when the key has none).  count must equal the array length.  With 0..6 a resident key can be written out in full (utils.GrothSetupToString). */
 int gs_groth16_pk_export(gs_handle pk, int which, uint64_t* jacobian, size_t count);
 
 /* ---- Pinocchio prover (snark.go) ------------------------------------------------------------ */
@@ -292,6 +304,11 @@ int gs_pinocchio_prove_resident(gs_handle pk, gs_handle w, gs_handle px, uint64_
 /* snark.GenerateProofs from the witness alone (the Pinocchio twin of gs_groth16_prove_witness): H(x) straight from the constraint
  * values of the resident R1CS, no px; a witness that violates a constraint takes the exact px route (same result as the reference). */
 int gs_pinocchio_prove_witness(gs_handle pk, gs_handle r1cs, gs_handle w, uint64_t out_proof[72], int inf[8]);
+/* ... with the evaluation-basis copy of G1T (E[j-1] = l_j(tau) G over the nodes n+1..2n, so that sum_j H(n+j) E[j-1] = H(tau) G =
+ * sum_i h_i G1T[i], snark.go:239-247, 284-286) when the key has one: gs_pinocchio_setup builds it, gs_pinocchio_pk_set_eval attaches
+ * one, gs_pinocchio_pk_export which = 9 reads it back.  gs_pinocchio_prove_witness_begin: pipelined, collect with gs_pinocchio_prove_end. */
+int gs_pinocchio_pk_set_eval(gs_handle pk, gs_handle bases);
+int gs_pinocchio_prove_witness_begin(gs_handle pk, gs_handle r1cs, gs_handle w, uint64_t* ticket);
 /* Pipelined Pinocchio proving: same tickets as gs_groth16_prove_begin / _end (the three in-flight slots are shared between
  * Groth16 proofs, Pinocchio proofs and MSMs). */
 int gs_pinocchio_prove_begin(gs_handle pk, gs_handle w, gs_handle px, uint64_t* ticket);
@@ -358,7 +375,7 @@ typedef struct {
   uint64_t acc_g1_adds;  /* mixed point additions those G1 launches performed = terms x base arrays x digit positions (windows) */
   uint64_t acc_g2_adds;
   uint32_t window_bits;  /* Pippenger window width c of the last plan; every term costs floor(254 / c) + 1 additions */
-  uint32_t reserved;
+  uint32_t fallbacks;    /* witness-route calls that had to repeat on the exact px route because the witness violates a constraint */
 } gs_timing;
 int gs_last_timing(gs_timing* out);                         /* the calling thread's current logical device */
 int gs_device_timing(int logical_device, gs_timing* out);
@@ -386,6 +403,9 @@ int gs_trim(void);
 
 /* Tunables (0 = automatic): Pippenger window bits. */
 int gs_set_window_bits(int c);
+/* Witness route of keys that carry an evaluation-basis array (gs_groth16_pk_set_eval): 1 (default) = h-MSM over H's values,
+ * 0 = the coefficient route every other key takes.  Identical proofs; for measurements and tests. */
+int gs_set_eval_basis(int enabled);
 
 /* ---- verifier (host side) ---------------------------------------------------------------- */
 /* The step after the prover.  These four entry points run on the calling host thread: a proof check is

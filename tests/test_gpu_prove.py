@@ -810,12 +810,98 @@ def test_witness_to_proof_without_px_equals_the_px_route(n, extra):
     dev = r1csqap.DeviceR1CS(*inst.r1cs, inst.m)
     r, s = synth.field_elems(2, 9000 + n)
     want = groth16.prove_resident(inst.device_pk(), inst.w, inst.px, r, s)
-    got = groth16.prove_from_witness(inst.device_pk(), dev, inst.w, r, s)
-    assert (got.PiA, got.PiB, got.PiC) == (want.PiA, want.PiB, want.PiC)
+    # the key comes from gs_groth16_setup, so it carries the evaluation-basis copy of PowersTauDelta: with the switch on the h-MSM
+    # runs over H's values (no interpolation), with it off over H's coefficients (interpolation + Taylor shift) -- same proof
+    assert capi.pk_eval_count(inst.device_pk().handle) == n
+    for on in (True, False):
+        capi.set_eval_basis(on)
+        try:
+            got = groth16.prove_from_witness(inst.device_pk(), dev, inst.w, r, s)
+            piped = groth16.prove_end(groth16.prove_witness_begin(inst.device_pk(), dev, inst.w, r, s))
+        finally:
+            capi.set_eval_basis(True)
+        assert (got.PiA, got.PiB, got.PiC) == (want.PiA, want.PiB, want.PiC), on
+        assert (piped.PiA, piped.PiB, piped.PiC) == (want.PiA, want.PiB, want.PiC), on
+        assert capi.last_timing()["fallbacks"] == 0
     assert groth16.VerifyProof(inst.vk, got, capi.u64_to_ints(inst.w_host[1:2]))
     if n >= 64:
         a, b, c = inst.expected_proof_scalars(r, s)
         assert (got.PiC[0], got.PiC[1]) == C.g1_affine(C.g1_mul_scalar(O.G1_GEN, c))
+
+
+@pytest.mark.parametrize("logn", [18, 20])
+def test_witness_route_at_config_sizes_equals_px_route_and_closed_form(logn):
+    """the witness -> proof routes at 2^18 (BASELINE configs[4]) and 2^20 (configs[2], the headline size), inside
+    pytest: evaluation-basis route (blocking and three pipelined tickets), coefficient route, px route and the closed form of
+    the setup's toxic values all give the same proof; the verifier accepts it."""
+    from gosnark_amd import synth
+    n = 1 << logn
+    inst = synth.sqchain_setup_instance(n, 0x4D77 + logn)
+    dev = r1csqap.DeviceR1CS(*inst.r1cs, inst.m)
+    r, s = synth.field_elems(2, 9100 + logn)
+    pk = inst.device_pk()
+    want = groth16.prove_resident(pk, inst.w, inst.px, r, s)
+    a, b, c = inst.expected_proof_scalars(r, s)
+    assert (want.PiA[0], want.PiA[1]) == C.g1_affine(C.g1_mul_scalar(O.G1_GEN, a))
+    assert (want.PiC[0], want.PiC[1]) == C.g1_affine(C.g1_mul_scalar(O.G1_GEN, c))
+    got = groth16.prove_from_witness(pk, dev, inst.w, r, s)
+    assert (got.PiA, got.PiB, got.PiC) == (want.PiA, want.PiB, want.PiC)
+    tickets = [groth16.prove_witness_begin(pk, dev, inst.w, r, s) for _ in range(3)]
+    for t in tickets:
+        p = groth16.prove_end(t)
+        assert (p.PiA, p.PiB, p.PiC) == (want.PiA, want.PiB, want.PiC)
+    capi.set_eval_basis(False)
+    try:
+        coef = groth16.prove_from_witness(pk, dev, inst.w, r, s)
+    finally:
+        capi.set_eval_basis(True)
+    assert (coef.PiA, coef.PiB, coef.PiC) == (want.PiA, want.PiB, want.PiC)
+    assert groth16.VerifyProof(inst.vk, got, capi.u64_to_ints(inst.w_host[1:2])) is True
+    # the table of the evaluation-basis array is visible to the memory accounting (64 B per constraint + its window rows)
+    obj_b, tab_b = capi.handle_bytes(pk.handle.h)
+    assert obj_b >= 5 * n * 64 + n * 128 and tab_b >= 6 * 8 * n * 64
+
+
+def test_eval_basis_round_trips_through_export_and_attach():
+    """gs_groth16_pk_export which = 7 reads the evaluation-basis array back; a key rebuilt from its exported arrays
+    (gs_groth16_pk_create: no evaluation basis, coefficient route) gives the same witness proof, and again after
+    gs_groth16_pk_set_eval attached the exported array (evaluation-basis route).  The array is what the header says:
+    sum_j H(n+j) E[j-1] == sum_i h_i PowersTauDelta[i] checked through the two MSMs on an independent H."""
+    from gosnark_amd import synth
+    n = 500
+    inst = synth.sqchain_setup_instance(n, 0x4F10)
+    pk = inst.device_pk()
+    dev = r1csqap.DeviceR1CS(*inst.r1cs, inst.m)
+    r, s = synth.field_elems(2, 515)
+    want = groth16.prove_from_witness(pk, dev, inst.w, r, s)
+    arrays = {k: groth16.ExportPkArray(pk, k) for k in groth16.PK_ARRAYS}
+    assert len(arrays["PowersTauDeltaEval"]) == n
+    singles = np.zeros(84, dtype=np.uint64)
+    capi.check(capi.load_library().gs_groth16_pk_export(capi.Handle(pk.handle.h), 5, capi.ptr64(singles), 5))
+    v = capi.u64_to_ints(singles)
+    z = np.zeros((inst.m - 1, 4), dtype=np.uint64)
+    capi.check(capi.load_library().gs_groth16_pk_export(capi.Handle(pk.handle.h), 6, capi.ptr64(z), inst.m - 1))
+    hpk = groth16.Pk(BACDelta=arrays["BACDelta"], Z=capi.u64_to_ints(z), G1_Alpha=(v[0], v[1], v[2]), G1_Beta=(v[3], v[4], v[5]),
+                     G1_Delta=(v[6], v[7], v[8]), G1_At=arrays["G1_At"], G1_BACGamma=arrays["G1_BACGamma"],
+                     G2_Beta=((v[9], v[10]), (v[11], v[12]), (v[13], v[14])), G2_Delta=((v[15], v[16]), (v[17], v[18]), (v[19], v[20])),
+                     G2_BACGamma=arrays["G2_BACGamma"], PowersTauDelta=arrays["PowersTauDelta"])
+    foreign = groth16.UploadPk(hpk, groth16.Circuit(inst.m, 1))
+    assert capi.pk_eval_count(foreign.handle) == 0
+    got = groth16.prove_from_witness(foreign, dev, inst.w, r, s)            # coefficient route
+    assert (got.PiA, got.PiB, got.PiC) == (want.PiA, want.PiB, want.PiC)
+    groth16.SetEvalBasis(foreign, arrays["PowersTauDeltaEval"])
+    assert capi.pk_eval_count(foreign.handle) == n
+    got = groth16.prove_from_witness(foreign, dev, inst.w, r, s)            # evaluation-basis route on the attached array
+    assert (got.PiA, got.PiB, got.PiC) == (want.PiA, want.PiB, want.PiC)
+    # the defining identity on an H that has nothing to do with the instance: random coefficients h (degree n - 1), values by Horner
+    rng = random.Random(99)
+    h = [rng.randrange(O.R) for _ in range(n)]
+    vals = [sum(c * pow(n + j, i, O.R) for i, c in enumerate(h)) % O.R for j in range(1, n + 1)]
+    mono = capi.msm(capi.g1_upload(capi.ints_to_u64([c for p in arrays["PowersTauDelta"] for c in p]).reshape(-1, 12)), capi.ints_to_u64(h))
+    ev = capi.msm(capi.g1_upload(capi.ints_to_u64([c for p in arrays["PowersTauDeltaEval"] for c in p]).reshape(-1, 12)), capi.ints_to_u64(vals))
+    assert mono == ev
+    with pytest.raises(capi.GosnarkHipError):
+        groth16.SetEvalBasis(foreign, arrays["PowersTauDeltaEval"][:n - 2])     # neither deg Z nor deg Z + 1 points
 
 
 def test_witness_to_proof_falls_back_to_the_exact_quotient_for_a_violated_constraint():
@@ -831,8 +917,19 @@ def test_witness_to_proof_falls_back_to_the_exact_quotient_for_a_violated_constr
     dev = r1csqap.DeviceR1CS(*inst.r1cs, inst.m)
     r, s = synth.field_elems(2, 4242)
     want = groth16.prove_resident(inst.device_pk(), wh, pxh, r, s)
-    got = groth16.prove_from_witness(inst.device_pk(), dev, wh, r, s)
-    assert (got.PiA, got.PiB, got.PiC) == (want.PiA, want.PiB, want.PiC)
+    good = groth16.prove_resident(inst.device_pk(), inst.w, inst.px, r, s)
+    for on in (True, False):       # evaluation-basis route: the violation is only seen when the proof is collected, then repeated exactly
+        capi.set_eval_basis(on)
+        try:
+            got = groth16.prove_from_witness(inst.device_pk(), dev, wh, r, s)
+            assert capi.last_timing()["fallbacks"] == (1 if on else 0)
+            # pipelined: a bad ticket between two good ones falls back inside gs_groth16_prove_end and disturbs neither neighbour
+            t = [groth16.prove_witness_begin(inst.device_pk(), dev, x, r, s) for x in (inst.w, wh, inst.w)]
+            res = [groth16.prove_end(x) for x in t]
+        finally:
+            capi.set_eval_basis(True)
+        assert (got.PiA, got.PiB, got.PiC) == (want.PiA, want.PiB, want.PiC), on
+        assert [(p.PiA, p.PiB, p.PiC) for p in res] == [(q.PiA, q.PiB, q.PiC) for q in (good, want, good)], on
     assert not groth16.VerifyProof(inst.vk, got, capi.u64_to_ints(w_bad[1:2]))
 
 
@@ -885,8 +982,19 @@ def test_pinocchio_witness_to_proof_without_px_equals_the_px_route(n, extra):
     inst = synth.sqchain_pinocchio_instance(n, 0x5B00 + n % 97, extra_vars=extra)
     dev = r1csqap.DeviceR1CS(*inst.r1cs, inst.m)
     want = snark.prove_resident(inst.device_pk(), inst.w, inst.px)
-    got = snark.prove_from_witness(inst.device_pk(), dev, inst.w)
-    assert all(getattr(got, k) == getattr(want, k) for k in snark.Proof.FIELDS)
+    assert capi.pk_eval_count(inst.device_pk().handle) == n       # gs_pinocchio_setup built the evaluation-basis copy of G1T
+    for on in (True, False):                                      # H's values against it / H's coefficients against G1T
+        capi.set_eval_basis(on)
+        try:
+            got = snark.prove_from_witness(inst.device_pk(), dev, inst.w)
+            piped = snark.prove_end(snark.prove_witness_begin(inst.device_pk(), dev, inst.w))
+        finally:
+            capi.set_eval_basis(True)
+        assert all(getattr(got, k) == getattr(want, k) for k in snark.Proof.FIELDS), on
+        assert all(getattr(piped, k) == getattr(want, k) for k in snark.Proof.FIELDS), on
+    if n == 300 and extra == 0:                                   # export (which = 9) / attach on a key without one
+        ev = snark.ExportPkArray(inst.device_pk(), "G1TEval")
+        assert len(ev) == n
     if n <= (1 << 12):
         assert snark.VerifyProof(inst.vk, got, inst.public) is True
     if n == 300:
@@ -897,6 +1005,9 @@ def test_pinocchio_witness_to_proof_without_px_equals_the_px_route(n, extra):
         want_bad = snark.prove_resident(inst.device_pk(), wh, pxh)
         got_bad = snark.prove_from_witness(inst.device_pk(), dev, wh)
         assert all(getattr(got_bad, k) == getattr(want_bad, k) for k in snark.Proof.FIELDS)
+        assert capi.last_timing()["fallbacks"] == 1
+        piped_bad = snark.prove_end(snark.prove_witness_begin(inst.device_pk(), dev, wh))
+        assert all(getattr(piped_bad, k) == getattr(want_bad, k) for k in snark.Proof.FIELDS)
 
 
 def test_host_buffer_provers_at_2p16_equal_the_resident_ones():
