@@ -264,11 +264,13 @@ def main():
     ap.add_argument("--settle-ms", type=float, default=400.0, help="untimed steps before the W warm-up steps until this many ms have passed (0 = none)")
     ap.add_argument("--reps", type=int, default=5, help="repetitions of the timed K steps; the median repetition is reported")
     ap.add_argument("--log2n", type=int, default=20)
-    ap.add_argument("--workload", default="prove", choices=["prove", "prove_from_r1cs", "prove_sharded", "prove_pinocchio", "msm_g1", "msm_sharded"],
+    ap.add_argument("--workload", default="prove", choices=["prove", "prove_from_r1cs", "prove_witness", "prove_sharded", "prove_pinocchio", "msm_g1", "msm_sharded"],
                     help="prove: one independent proof per GPU (weak scaling, the default the driver runs); prove_sharded: ONE proof "
                          "whose MSM term ranges are split over the ranks (strong scaling, in-library RCCL gather of 416-byte records); "
                          "prove_from_r1cs: every step also rebuilds px from the resident sparse R1CS and witness -- the "
-                         "stage upstream of GenerateProofs, reported for information")
+                         "stage upstream of GenerateProofs, reported for information; prove_witness: witness -> proof without px "
+                         "(gs_groth16_prove_witness[_begin]: BASELINE configs[2] as worded, 'full prove + QAP kernels'), the h-MSM over H's values "
+                         "when the key carries the evaluation-basis PowersTauDelta")
     ap.add_argument("--logical-shards", type=int, default=0,
                     help="prove_sharded / msm_sharded on ONE GPU: that many logical devices in this process (configs[3] stand-in, SURVEY 8e)")
     ap.add_argument("--instance", default="setup", choices=["setup", "sqchain", "random"],
@@ -315,6 +317,7 @@ def main():
     seed = 0x5EED0002 + (0 if one_job else rank)
     sharded = args.workload == "prove_sharded"
     from_r1cs = args.workload == "prove_from_r1cs"
+    from_witness = args.workload == "prove_witness"
     shard_info, unit_override = None, None
     rccl_sharded = one_job and world > 1 and not share
     if rccl_sharded:
@@ -328,7 +331,7 @@ def main():
         units_per_step = n
         workload = ("groth16_prove_2^%d_constraints_over_%d_logical_devices_of_one_gpu" if sharded else
                     "g1_msm_2^%d_terms_over_%d_logical_devices_of_one_gpu") % (args.log2n, logical)
-    elif sharded or from_r1cs or args.workload == "prove":
+    elif sharded or from_r1cs or from_witness or args.workload == "prove":
         args.workload = "prove"
         inst = (synth.sqchain_setup_instance(n, seed) if args.instance == "setup" else
                 synth.sqchain_instance(n, seed) if args.instance == "sqchain" else synth.random_instance(n, seed))
@@ -342,7 +345,7 @@ def main():
         r_, s_ = synth.field_elems(2, seed ^ 0xABCDEF, R)
 
         dev_r1cs = None
-        if from_r1cs:
+        if from_r1cs or from_witness:
             from gosnark_amd import r1csqap
             dev_r1cs = r1csqap.DeviceR1CS(*inst.r1cs, inst.m)
 
@@ -352,10 +355,13 @@ def main():
             if from_r1cs:
                 # one call: px from the resident sparse system (overwriting the resident px) behind the accumulations over w
                 return groth16.prove_from_r1cs(pk, dev_r1cs, inst.w, r_, s_, inst.px)[0]
+            if from_witness:
+                return groth16.prove_from_witness(pk, dev_r1cs, inst.w, r_, s_)
             return groth16.prove_resident(pk, inst.w, inst.px, r_, s_)
         units_per_step = n
         workload = ("groth16_prove_2^%d_constraints_sharded_over_all_gpus" if sharded else
                     "groth16_px_from_sparse_r1cs_then_prove_2^%d_constraints_per_gpu" if from_r1cs else
+                    "groth16_witness_to_proof_2^%d_constraints_per_gpu" if from_witness else
                     "groth16_prove_2^%d_constraints_per_gpu") % args.log2n
     elif args.workload == "prove_pinocchio":
         # snark.GenerateProofs (snark.go:254-289): 6 G1 MSMs over w sharing one plan + 1 G2 MSM + px / Z + 1 G1 MSM over h
@@ -390,8 +396,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    plain_prove = args.workload == "prove" and not sharded and not from_r1cs and not logical
+    plain_prove = args.workload == "prove" and not sharded and not from_r1cs and not from_witness and not logical
     prove_pipe = plain_prove and args.pipeline >= 2
+    witness_pipe = from_witness and args.pipeline >= 2
     pin_pipe = args.workload == "prove_pinocchio" and args.pipeline >= 2
     msm_pipe = args.workload == "msm_g1" and args.pipeline >= 2 and not logical
 
@@ -403,6 +410,8 @@ def main():
             return pipelined(lambda: _sn.prove_begin(pk, inst.w, inst.px), _sn.prove_end, count, args.pipeline, on_done)
         if prove_pipe:
             return pipelined(lambda: groth16.prove_begin(pk, inst.w, inst.px, r_, s_), groth16.prove_end, count, args.pipeline, on_done)
+        if witness_pipe:
+            return pipelined(lambda: groth16.prove_witness_begin(pk, dev_r1cs, inst.w, r_, s_), groth16.prove_end, count, args.pipeline, on_done)
         for _ in range(count):
             step()
             if on_done:
@@ -552,7 +561,7 @@ def main():
             "ms_per_step_min": min(rep_elapsed) / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong" if (sharded or logical) else "weak", "vs_baseline": None,
             "dtype": "u32 (9x29-bit Montgomery limbs of the 254-bit BN128 fields)", "data": "synthetic",
-            "config": {"workload": workload, "settle_ms_before_warmup": args.settle_ms, "proofs_in_flight": args.pipeline if (prove_pipe or msm_pipe or pin_pipe) else 1, "constraints": n, "variables": n + 1, "npublic": 1,
+            "config": {"workload": workload, "settle_ms_before_warmup": args.settle_ms, "proofs_in_flight": args.pipeline if (prove_pipe or msm_pipe or pin_pipe or witness_pipe) else 1, "constraints": n, "variables": n + 1, "npublic": 1,
                        "window_bits": cbits,
                        "parallelism": (("%d logical devices of one GPU in one process (gs_groth16_prove_multi / gs_msm_g1_multi), records through ncclAllGather" % logical) if logical else
                                        "one proof, MSM term ranges sharded over the ranks, in-library RCCL gather of one 416-byte record per rank" if sharded else

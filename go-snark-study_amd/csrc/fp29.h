@@ -138,6 +138,96 @@ GS_HD Fe<M, B + 1> neg(const Fe<M, B>& a) {
   return r;
 }
 
+// ---- lazy limbs: add / sub / neg results that skip the carry pass ------------------------------------------------
+// A carry pass (carry_save) is 24 instructions, a subtraction with it 42 -- and most sums and differences of a point addition
+// are used exactly once, as ONE operand of a Montgomery product.  The 64-bit column accumulator has room for that: a column
+// is 9 T products of nearly-normal limbs (T terms, each < 2^58 (1 + 2^-25)) + 9 reduction products (< 2^58) + the carry of the
+// previous column (< 2^36), and 2^64 / (9 * 2^58) = 7.1.  Lz<M, B, W> is a field element of VALUE < B p whose limbs are only
+// bounded by W * 2^29 + 16 (W = 2: an un-carried add / dbl / neg, 3: an un-carried sub): a product term with operand limb
+// weights (wa, wb) counts wa * wb instead of 1, and every dot product statically checks  9 * sum_t maxa_t * maxb_t + 9 * 2^58 +
+// 2^36 < 2^64  with the exact limb maxima (dot_of below).  Nothing but dot_of (and select / normalize) accepts an Lz.
+template <class M, int B, int W>
+struct Lz {
+  static_assert(B >= 1 && B <= M::kMaxBiasK && W >= 1 && W <= 3, "lazy element out of range");
+  uint32_t l[NL];
+};
+constexpr uint64_t kNearlyNormalMax = (1ull << LB) + 16;          // limbs 0..7 of a nearly-normal Fe stay below this
+constexpr uint64_t limb_max(int w) { return (uint64_t)w * (1ull << LB) + 16; }
+
+template <class X> struct Operand;                                 // value bound + limb weight of a product operand
+template <class M, int B> struct Operand<Fe<M, B>> { using Mod = M; static constexpr int bound = B, weight = 1; };
+template <class M, int B, int W> struct Operand<Lz<M, B, W>> { using Mod = M; static constexpr int bound = B, weight = W; };
+
+template <class M, int B> GS_HD Lz<M, B, 1> as_lazy(const Fe<M, B>& a) {
+  Lz<M, B, 1> r;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) r.l[i] = a.l[i];
+  return r;
+}
+template <int WN, class M, int B, int W> GS_HD Lz<M, B, WN> widen(const Lz<M, B, W>& a) {
+  static_assert(WN >= W, "widen can only loosen a limb bound");
+  Lz<M, B, WN> r;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) r.l[i] = a.l[i];
+  return r;
+}
+template <class M, int B, int W> GS_HD Lz<M, B, W> select(bool c, const Lz<M, B, W>& a, const Lz<M, B, W>& b) {
+  Lz<M, B, W> r;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) r.l[i] = c ? a.l[i] : b.l[i];
+  return r;
+}
+// the carry pass after all: nearly normal again
+template <class M, int B, int W> GS_HD Fe<M, B> normalize(const Lz<M, B, W>& a) {
+  Fe<M, B> r;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) r.l[i] = a.l[i];
+  carry_save(r);
+  return r;
+}
+// a + b, limbs < 2^30 + 32
+template <class M, int Ba, int Bb>
+GS_HD Lz<M, Ba + Bb, 2> add_lazy(const Fe<M, Ba>& a, const Fe<M, Bb>& b) {
+  Lz<M, Ba + Bb, 2> r;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) r.l[i] = a.l[i] + b.l[i];
+  return r;
+}
+template <class M, int B>
+GS_HD Lz<M, 2 * B, 2> dbl_lazy(const Fe<M, B>& a) {
+  Lz<M, 2 * B, 2> r;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) r.l[i] = a.l[i] << 1;
+  return r;
+}
+// K p - a with the TIGHT bias (tools/gen_constants.py: low limbs of the bias in [2^29 + 15, 2^30)): limbs < 2^30, K = tbias_k(B + 1)
+template <class M, int B>
+GS_HD Lz<M, M::tbias_k(B + 1), 2> neg_lazy(const Fe<M, B>& a) {
+  Lz<M, M::tbias_k(B + 1), 2> r;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) r.l[i] = M::tbias(B + 1, i) - a.l[i];
+  return r;
+}
+// a - b + K p, limbs < 3 * 2^29 + 16
+template <class M, int Ba, int Bb>
+GS_HD Lz<M, Ba + M::tbias_k(Bb + 1), 3> sub_lazy(const Fe<M, Ba>& a, const Fe<M, Bb>& b) {
+  Lz<M, Ba + M::tbias_k(Bb + 1), 3> r;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) r.l[i] = a.l[i] + (M::tbias(Bb + 1, i) - b.l[i]);
+  return r;
+}
+// a - b - 2 c + (Bb + 2 Bc + 1) p with ONE carry pass (the X3 of every addition formula: RR - PPP - 2 Q).  Wide bias: low limbs
+// >= 2^31 - 4 >= b_i + 2 c_i, and a_i + bias_i - b_i - 2 c_i < 2^32.
+template <class M, int Ba, int Bb, int Bc>
+GS_HD Fe<M, Ba + Bb + 2 * Bc + 1> sub_b_2c(const Fe<M, Ba>& a, const Fe<M, Bb>& b, const Fe<M, Bc>& c) {
+  constexpr int K = Bb + 2 * Bc + 1;
+  Fe<M, Ba + K> r;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) r.l[i] = a.l[i] + (M::wbias(K, i) - ((c.l[i] << 1) + b.l[i]));
+  carry_save(r);
+  return r;
+}
+
 // ---- Montgomery product (product scanning, reduction interleaved) ---------------------------
 // acc is the 64-bit column accumulator: each `acc += (u64)x * y` is one v_mad_u64_u32.
 template <class M>
@@ -283,20 +373,31 @@ struct Dot {
   const uint32_t* b[T];
 };
 template <> struct Dot<0> {};
-template <class M, int Ba, int Bb>
-GS_HD Dot<1> dot_of(const Fe<M, Ba>& a, const Fe<M, Bb>& b) {
-  static_assert(Ba * Bb <= 160, "Montgomery product input bound exceeded");
+// Operands may be nearly-normal Fe or lazy Lz (above); both checks are static: the value bound of Montgomery's reduction
+// (sum of Ba * Bb <= 160) and the 64-bit column accumulator (exact limb maxima).
+constexpr bool column_fits(uint64_t sum_of_limb_products /* sum_t maxa_t * maxb_t */) {
+  const unsigned __int128 col = (unsigned __int128)9 * sum_of_limb_products + (unsigned __int128)9 * (1ull << LB) * (1ull << LB) + ((unsigned __int128)1 << 36);
+  return col < ((unsigned __int128)1 << 64);
+}
+template <class A, class Bv> constexpr uint64_t term_limbs() { return limb_max(Operand<A>::weight) * limb_max(Operand<Bv>::weight); }
+template <class A, class Bv>
+GS_HD Dot<1> dot_of(const A& a, const Bv& b) {
+  static_assert(Operand<A>::bound * Operand<Bv>::bound <= 160, "Montgomery product input bound exceeded");
+  static_assert(column_fits(term_limbs<A, Bv>()), "column accumulator would overflow: normalize an operand");
   return Dot<1>{{a.l}, {b.l}};
 }
-template <class M, int Ba, int Bb, int Bc, int Bd>
-GS_HD Dot<2> dot_of(const Fe<M, Ba>& a, const Fe<M, Bb>& b, const Fe<M, Bc>& c, const Fe<M, Bd>& d) {
-  static_assert(Ba * Bb + Bc * Bd <= 160, "dot-product input bound exceeded");
+template <class A, class Bv, class Cv, class Dv>
+GS_HD Dot<2> dot_of(const A& a, const Bv& b, const Cv& c, const Dv& d) {
+  static_assert(Operand<A>::bound * Operand<Bv>::bound + Operand<Cv>::bound * Operand<Dv>::bound <= 160, "dot-product input bound exceeded");
+  static_assert(column_fits(term_limbs<A, Bv>() + term_limbs<Cv, Dv>()), "column accumulator would overflow: normalize an operand");
   return Dot<2>{{a.l, c.l}, {b.l, d.l}};
 }
-template <class M, int Ba, int Bb, int Bc, int Bd, int Be, int Bf, int Bg, int Bh>
-GS_HD Dot<4> dot_of(const Fe<M, Ba>& a, const Fe<M, Bb>& b, const Fe<M, Bc>& c, const Fe<M, Bd>& d,
-                    const Fe<M, Be>& e, const Fe<M, Bf>& f, const Fe<M, Bg>& g, const Fe<M, Bh>& h) {
-  static_assert(Ba * Bb + Bc * Bd + Be * Bf + Bg * Bh <= 160, "dot-product input bound exceeded");
+template <class A, class Bv, class Cv, class Dv, class Ev, class Fv, class Gv, class Hv>
+GS_HD Dot<4> dot_of(const A& a, const Bv& b, const Cv& c, const Dv& d, const Ev& e, const Fv& f, const Gv& g, const Hv& h) {
+  static_assert(Operand<A>::bound * Operand<Bv>::bound + Operand<Cv>::bound * Operand<Dv>::bound + Operand<Ev>::bound * Operand<Fv>::bound +
+                Operand<Gv>::bound * Operand<Hv>::bound <= 160, "dot-product input bound exceeded");
+  static_assert(column_fits(term_limbs<A, Bv>() + term_limbs<Cv, Dv>() + term_limbs<Ev, Fv>() + term_limbs<Gv, Hv>()),
+                "column accumulator would overflow: normalize an operand");
   return Dot<4>{{a.l, c.l, e.l, g.l}, {b.l, d.l, f.l, h.l}};
 }
 
@@ -369,6 +470,33 @@ GS_HD void dots2(const Dot<TX>& x, const Dot<TY>& y, Fe<M, 2>& rx, Fe<M, 2>& ry)
 template <class M, int TX, int TY, int TZ>
 GS_HD void dots3(const Dot<TX>& x, const Dot<TY>& y, const Dot<TZ>& z, Fe<M, 2>& rx, Fe<M, 2>& ry, Fe<M, 2>& rz) {
   dots_interleaved<M, TX, TY, TZ>(x, y, &z, rx, ry, &rz);
+}
+
+// one product with lazy operands (single chain)
+template <class A, class Bv>
+GS_HD Fe<typename Operand<A>::Mod, 2> mul_lazy(const A& a, const Bv& b) {
+  using M = typename Operand<A>::Mod;
+  static_assert(Operand<A>::bound * Operand<Bv>::bound <= 160, "Montgomery product input bound exceeded");
+  static_assert(column_fits(term_limbs<A, Bv>()), "column accumulator would overflow: normalize an operand");
+  uint32_t m[NL];
+  Fe<M, 2> r;
+  uint64_t acc = 0;
+#pragma unroll
+  for (int k = 0; k < NL; ++k) {
+#pragma unroll
+    for (int i = 0; i < NL; ++i)
+      if (i <= k) { acc += (uint64_t)a.l[i] * b.l[k - i]; GS_PIN(acc); }
+    mont_low_column<M>(acc, m, k);
+  }
+#pragma unroll
+  for (int k = NL; k < 2 * NL - 1; ++k) {
+#pragma unroll
+    for (int i = 0; i < NL; ++i)
+      if (i >= k - (NL - 1)) { acc += (uint64_t)a.l[i] * b.l[k - i]; GS_PIN(acc); }
+    mont_high_column<M>(acc, m, k, r.l[k - NL]);
+  }
+  r.l[NL - 1] = (uint32_t)acc;
+  return r;
 }
 
 // N chains of T terms each, strictly round-robin: chain c's multiply-adds are N - 1 instructions apart (N = 4 for two Fq2

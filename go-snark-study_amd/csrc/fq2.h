@@ -24,6 +24,10 @@ template <int Ba, int Bb> GS_HD Fq2e<Ba + Bb + 1> sub(const Fq2e<Ba>& a, const F
 template <int B> GS_HD Fq2e<2 * B> dbl(const Fq2e<B>& a) { return {dbl(a.c0), dbl(a.c1)}; }
 template <int B> GS_HD Fq2e<B + 1> neg(const Fq2e<B>& a) { return {neg(a.c0), neg(a.c1)}; }
 template <int B> GS_HD Fq2e<2> reduce2(const Fq2e<B>& a) { return {reduce2(a.c0), reduce2(a.c1)}; }
+// a - b - 2 c with one carry pass per coordinate (fp29.h)
+template <int Ba, int Bb, int Bc> GS_HD Fq2e<Ba + Bb + 2 * Bc + 1> sub_b_2c(const Fq2e<Ba>& a, const Fq2e<Bb>& b, const Fq2e<Bc>& c) {
+  return {sub_b_2c(a.c0, b.c0, c.c0), sub_b_2c(a.c1, b.c1, c.c1)};
+}
 template <int B> GS_HD Fq2e<1> canon(const Fq2e<B>& a) { return {canon(a.c0), canon(a.c1)}; }
 template <int B> GS_HD bool is_zero(const Fq2e<B>& a) { return is_zero(a.c0) && is_zero(a.c1); }
 template <int B> GS_HD Fq2e<B> select(bool c, const Fq2e<B>& a, const Fq2e<B>& b) { return {select(c, a.c0, b.c0), select(c, a.c1, b.c1)}; }
@@ -33,7 +37,7 @@ template <int B> GS_HD Fq2e<B> select(bool c, const Fq2e<B>& a, const Fq2e<B>& b
 template <int Ba, int Bb>
 GS_HD Fq2e<2> mul(const Fq2e<Ba>& a, const Fq2e<Bb>& b) {
 #if GS_PAIR
-  const auto nb1 = neg(b.c1);
+  const auto nb1 = neg_lazy(b.c1);                     // used once, as one factor of one term: no carry pass (fp29.h, Lz)
   Fq2e<2> r;
   dots2<ModQ>(dot_of(a.c0, b.c0, a.c1, nb1), dot_of(a.c0, b.c1, a.c1, b.c0), r.c0, r.c1);
   return r;
@@ -45,9 +49,15 @@ GS_HD Fq2e<2> mul(const Fq2e<Ba>& a, const Fq2e<Bb>& b) {
 // a*b - c*d with ONE reduction per coordinate (four-term dot products): 2 x 405 mads instead of 2 x 486
 template <int Ba, int Bb, int Bc, int Bd>
 GS_HD Fq2e<2> mul_sub(const Fq2e<Ba>& a, const Fq2e<Bb>& b, const Fq2e<Bc>& c, const Fq2e<Bd>& d) {
+#if GS_PAIR
+  const auto na1 = neg_lazy(a.c1);
+  const auto nc0 = neg_lazy(c.c0);
+  const auto nc1 = neg_lazy(c.c1);
+#else
   const auto na1 = neg(a.c1);
   const auto nc0 = neg(c.c0);
   const auto nc1 = neg(c.c1);
+#endif
   // re: a0 b0 - a1 b1 - c0 d0 + c1 d1      im: a0 b1 + a1 b0 - c0 d1 - c1 d0
 #if GS_PAIR
   Fq2e<2> r;
@@ -62,9 +72,9 @@ GS_HD Fq2e<2> mul_sub(const Fq2e<Ba>& a, const Fq2e<Bb>& b, const Fq2e<Bc>& c, c
 template <int B>
 GS_HD Fq2e<2> sqr(const Fq2e<B>& a) {
 #if GS_PAIR
-  const auto s = add(a.c0, a.c1);
-  const auto d = sub(a.c0, a.c1);
-  const auto t = dbl(a.c0);
+  const auto s = add_lazy(a.c0, a.c1);                 // limb weights 2 x 3 + the reduction = 7 of the column's 7.1 (fp29.h)
+  const auto d = sub_lazy(a.c0, a.c1);
+  const auto t = dbl_lazy(a.c0);
   Fq2e<2> r;
   dots2<ModQ>(dot_of(s, d), dot_of(t, a.c1), r.c0, r.c1);
   return r;
@@ -76,8 +86,8 @@ GS_HD Fq2e<2> sqr(const Fq2e<B>& a) {
 // Two independent Fq2 products / squares side by side: four interleaved column chains (fp29.h, dots_uniform).
 template <int Ba, int Bb, int Bc, int Bd>
 GS_HD void mul2(const Fq2e<Ba>& a, const Fq2e<Bb>& b, const Fq2e<Bc>& c, const Fq2e<Bd>& d, Fq2e<2>& ab, Fq2e<2>& cd) {
-  const auto nb1 = neg(b.c1);
-  const auto nd1 = neg(d.c1);
+  const auto nb1 = neg_lazy(b.c1);
+  const auto nd1 = neg_lazy(d.c1);
   const Dot<2> ch[4] = {dot_of(a.c0, b.c0, a.c1, nb1), dot_of(a.c0, b.c1, a.c1, b.c0), dot_of(c.c0, d.c0, c.c1, nd1), dot_of(c.c0, d.c1, c.c1, d.c0)};
   Fe<ModQ, 2> r[4];
   dots_uniform<ModQ, 4, 2>(ch, r);
@@ -85,9 +95,9 @@ GS_HD void mul2(const Fq2e<Ba>& a, const Fq2e<Bb>& b, const Fq2e<Bc>& c, const F
 }
 template <int Ba, int Bb>
 GS_HD void sqr2(const Fq2e<Ba>& a, const Fq2e<Bb>& b, Fq2e<2>& aa, Fq2e<2>& bb) {
-  const auto sa = add(a.c0, a.c1), sb = add(b.c0, b.c1);
-  const auto da = sub(a.c0, a.c1), db = sub(b.c0, b.c1);
-  const auto ta = dbl(a.c0), tb = dbl(b.c0);
+  const auto sa = add_lazy(a.c0, a.c1), sb = add_lazy(b.c0, b.c1);
+  const auto da = sub_lazy(a.c0, a.c1), db = sub_lazy(b.c0, b.c1);
+  const auto ta = dbl_lazy(a.c0), tb = dbl_lazy(b.c0);
   const Dot<1> ch[4] = {dot_of(sa, da), dot_of(ta, a.c1), dot_of(sb, db), dot_of(tb, b.c1)};
   Fe<ModQ, 2> r[4];
   dots_uniform<ModQ, 4, 1>(ch, r);

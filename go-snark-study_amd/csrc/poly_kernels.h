@@ -85,58 +85,114 @@ constexpr int kNttTileLog = 10;
 constexpr int kNttTile = 1 << kNttTileLog;
 constexpr int kNttMaxStages = 7;
 
-constexpr int kNttEndBound = 32;
-#ifndef GS_NTT_RADIX4
-#define GS_NTT_RADIX4 0      // measured: 17.5 ms vs 16.5 ms for the 2^20 px stage with radix-4 rounds (more registers per thread, same VALU work)
-#endif
-template <int B>
-GS_HD void ntt_dif_step(const uint32_t (&la)[NL], const uint32_t (&lb)[NL], const Fe<ModR, 1>& w, bool reduce_sum, uint32_t (&o0)[NL], uint32_t (&o1)[NL]) {
-  Fe<ModR, B> a, b;
+constexpr int kNttEndBound = 34;     // >= the bound any stage sequence of <= 7 stages can leave (DIF: 32, or 2 * 16 + 1 after a twiddle-free last stage)
+// (Radix-4 rounds -- two stages per LDS round trip -- were measured in round 2: 17.5 vs 16.5 ms for the 2^20 px stage: more registers
+// per thread for the same VALU work; multiplication by the fourth root of unity is a full product in a prime field.)
+// A thread owns TWO butterflies of a stage (a 1024-element tile has 512, the workgroup 256 threads): their twiddle products are two
+// independent Montgomery dot products whose column chains run interleaved (fp29.h, dots2) -- no chain follows itself, so the compiler
+// neither re-associates the sums (17 v_lshl_add_u64 per product) nor pads them with wait states.  Differences that only feed the
+// twiddle product skip their carry pass (fp29.h, Lz).
+struct Bfly { uint32_t a[NL], b[NL]; };          // in: the two inputs; out: the two outputs (same slots)
+
+// DIF: (a, b) -> (a + b, (a - b) w).  B = value bound of the inputs; the sum is reduced below 2r when `reduce_sum`.
+template <int B, int N>
+GS_HD void ntt_dif_step(Bfly (&x)[N], const Fe<ModR, 1> (&w)[N], bool reduce_sum, bool trivial) {
+  static_assert(N == 1 || N == 2, "one or two butterflies per thread");
+  Fe<ModR, B> a[N], b[N];
 #pragma unroll
-  for (int l = 0; l < NL; ++l) { a.l[l] = la[l]; b.l[l] = lb[l]; }
-  const Fr2 d = mul(sub(a, b), w);                            // (2B + 1) * 1 <= 160
-  if (reduce_sum) {
-    const Fr2 t = reduce2(add(a, b));
+  for (int t = 0; t < N; ++t)
 #pragma unroll
-    for (int l = 0; l < NL; ++l) o0[l] = t.l[l];
+    for (int l = 0; l < NL; ++l) { a[t].l[l] = x[t].a[l]; b[t].l[l] = x[t].b[l]; }
+  if (trivial) {                                   // stage 0 of a transform: every twiddle is 1
+#pragma unroll
+    for (int t = 0; t < N; ++t) {
+      const auto d = sub(a[t], b[t]);              // value bound 2 B + 1 <= kNttEndBound: only ever the last stage of a pass
+#pragma unroll
+      for (int l = 0; l < NL; ++l) x[t].b[l] = d.l[l];
+    }
   } else {
-    const Fe<ModR, 2 * B> t = add(a, b);
+    Fr2 d[N];
+    if constexpr (N == 2) dots2<ModR>(dot_of(sub_lazy(a[0], b[0]), w[0]), dot_of(sub_lazy(a[1], b[1]), w[1]), d[0], d[1]);
+    else d[0] = mul_lazy(sub_lazy(a[0], b[0]), w[0]);
 #pragma unroll
-    for (int l = 0; l < NL; ++l) o0[l] = t.l[l];
+    for (int t = 0; t < N; ++t)
+#pragma unroll
+      for (int l = 0; l < NL; ++l) x[t].b[l] = d[t].l[l];
   }
 #pragma unroll
-  for (int l = 0; l < NL; ++l) o1[l] = d.l[l];
-}
-// step 0,1,2,3 of every group of four: input bounds 2, 4, 8, 16; the fourth one reduces its sum back to 2
-GS_HD void ntt_dif_butterfly(int step, const uint32_t (&la)[NL], const uint32_t (&lb)[NL], const Fe<ModR, 1>& w, uint32_t (&o0)[NL], uint32_t (&o1)[NL]) {
-  switch (step & 3) {
-    case 0: ntt_dif_step<2>(la, lb, w, false, o0, o1); break;
-    case 1: ntt_dif_step<4>(la, lb, w, false, o0, o1); break;
-    case 2: ntt_dif_step<8>(la, lb, w, false, o0, o1); break;
-    default: ntt_dif_step<16>(la, lb, w, true, o0, o1); break;
+  for (int t = 0; t < N; ++t) {
+    if (reduce_sum) {
+      const Fr2 s = reduce2(add(a[t], b[t]));
+#pragma unroll
+      for (int l = 0; l < NL; ++l) x[t].a[l] = s.l[l];
+    } else {
+      const Fe<ModR, 2 * B> s = add(a[t], b[t]);
+#pragma unroll
+      for (int l = 0; l < NL; ++l) x[t].a[l] = s.l[l];
+    }
   }
 }
-template <int B>
-GS_HD void ntt_dit_step(const uint32_t (&la)[NL], const uint32_t (&lb)[NL], const Fe<ModR, 1>& w, uint32_t (&o0)[NL], uint32_t (&o1)[NL]) {
-  Fe<ModR, B> a, b;
-#pragma unroll
-  for (int l = 0; l < NL; ++l) { a.l[l] = la[l]; b.l[l] = lb[l]; }
-  const Fr2 t = mul(b, w);
-  const Fe<ModR, B + 2> p = add(a, t);
-  const Fe<ModR, B + 3> m = sub(a, t);
-#pragma unroll
-  for (int l = 0; l < NL; ++l) { o0[l] = p.l[l]; o1[l] = m.l[l]; }
+// step 0,1,2,3 of every group of four: input bounds 2, 4, 8, 16; the fourth one reduces its sum back to 2.  ONE code body for all
+// four (instantiated at the largest bound: the bound only selects the bias constant and feeds the static checks) -- four copies of a
+// ~1300-instruction butterfly per kernel, with co-resident workgroups in different stages, do not fit the instruction cache well.
+template <int N>
+GS_HD void ntt_dif_butterfly(int step, Bfly (&x)[N], const Fe<ModR, 1> (&w)[N], bool trivial) {
+  ntt_dif_step<16, N>(x, w, (step & 3) == 3, trivial);
 }
-GS_HD void ntt_dit_butterfly(int step, const uint32_t (&la)[NL], const uint32_t (&lb)[NL], const Fe<ModR, 1>& w, uint32_t (&o0)[NL], uint32_t (&o1)[NL]) {
-  switch (step) {                                             // bound after each stage: 2 -> 5 -> 8 -> 11 -> 14 -> 17 -> 20 -> 23
-    case 0: ntt_dit_step<2>(la, lb, w, o0, o1); break;
-    case 1: ntt_dit_step<5>(la, lb, w, o0, o1); break;
-    case 2: ntt_dit_step<8>(la, lb, w, o0, o1); break;
-    case 3: ntt_dit_step<11>(la, lb, w, o0, o1); break;
-    case 4: ntt_dit_step<14>(la, lb, w, o0, o1); break;
-    case 5: ntt_dit_step<17>(la, lb, w, o0, o1); break;
-    default: ntt_dit_step<20>(la, lb, w, o0, o1); break;
+// DIT: (a, b) -> (a + b w, a - b w).  The subtrahend is always the fresh product t = b w (nearly normal), so an EVEN step may leave
+// both outputs un-carried (limbs < 3 * 2^29: fine as the next step's addend and, weight 3, as its twiddle-product operand) and the
+// ODD step after it carries: one carry pass per element every second stage.  Value bound after each stage: 2 -> 5 -> 8 -> ... -> 23.
+template <int B, int N>
+GS_HD void ntt_dit_step(Bfly (&x)[N], const Fe<ModR, 1> (&w)[N], bool lazy_in, bool lazy_out, bool trivial) {
+  static_assert(N == 1 || N == 2, "one or two butterflies per thread");
+  Fr2 t[N];
+  if (trivial) {                                   // stage 0: twiddle 1, and the first stage of a pass: inputs nearly normal, bound 2
+#pragma unroll
+    for (int k = 0; k < N; ++k)
+#pragma unroll
+      for (int l = 0; l < NL; ++l) t[k].l[l] = x[k].b[l];
+  } else if (lazy_in) {
+    Lz<ModR, B, 3> b[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k)
+#pragma unroll
+      for (int l = 0; l < NL; ++l) b[k].l[l] = x[k].b[l];
+    if constexpr (N == 2) dots2<ModR>(dot_of(b[0], w[0]), dot_of(b[1], w[1]), t[0], t[1]);
+    else t[0] = mul_lazy(b[0], w[0]);
+  } else {
+    Fe<ModR, B> b[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k)
+#pragma unroll
+      for (int l = 0; l < NL; ++l) b[k].l[l] = x[k].b[l];
+    if constexpr (N == 2) dots2<ModR>(dot_of(b[0], w[0]), dot_of(b[1], w[1]), t[0], t[1]);
+    else t[0] = mul_lazy(b[0], w[0]);
   }
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    // raw limb arithmetic: a (limbs < 3 * 2^29 + 16) + t resp. a + (bias - t) stay below 2^32; t < 2r, so the bias is 3r (tbias(3))
+    uint32_t p[NL], m[NL];
+#pragma unroll
+    for (int l = 0; l < NL; ++l) { p[l] = x[k].a[l] + t[k].l[l]; m[l] = x[k].a[l] + (ModR::tbias(3, l) - t[k].l[l]); }
+    static_assert(ModR::tbias_k(3) == 3, "the DIT bound table (B + 2, B + 3) assumes the 3r bias");
+    if (!lazy_out) {
+      Fe<ModR, B + 3> pp, mm;
+#pragma unroll
+      for (int l = 0; l < NL; ++l) { pp.l[l] = p[l]; mm.l[l] = m[l]; }
+      carry_save(pp); carry_save(mm);
+#pragma unroll
+      for (int l = 0; l < NL; ++l) { p[l] = pp.l[l]; m[l] = mm.l[l]; }
+    }
+#pragma unroll
+    for (int l = 0; l < NL; ++l) { x[k].a[l] = p[l]; x[k].b[l] = m[l]; }
+  }
+}
+template <int N>
+GS_HD void ntt_dit_butterfly(int step, int nsteps, Bfly (&x)[N], const Fe<ModR, 1> (&w)[N], bool trivial) {
+  // even steps leave their outputs un-carried when an odd step follows inside this pass; odd steps take lazy inputs and carry.
+  // Value bound after each stage: 2 -> 5 -> 8 -> 11 -> 14 -> 17 -> 20 -> 23; one code body, instantiated at the largest (see the DIF).
+  const bool lazy_out = (step & 1) == 0 && step + 1 < nsteps;
+  ntt_dit_step<20, N>(x, w, true, lazy_out, trivial);
 }
 
 template <bool kInverse>
@@ -173,57 +229,46 @@ __global__ void __launch_bounds__(256) k_ntt_pass(uint32_t* __restrict__ x, cons
     return load_twiddle(tw + ((size_t)j << (tw_logn - 1 - s)) * kTwWords);
   };
   int step = 0;
-#if GS_NTT_RADIX4
-  // Two stages per LDS round trip: a thread owns the four rows that differ in the two stage bits (lo, lo + 1), runs both
-  // butterfly layers in registers and writes back once: half the LDS traffic and barriers of the radix-2 loop below.
-  for (; step + 1 < k; step += 2) {
-    const int lo = kInverse ? step : k - 2 - step;           // DIT walks the bits upwards, DIF downwards
-    for (uint32_t u = threadIdx.x; u < E / 4; u += 256) {
-      const uint32_t cc = u & (C - 1), qq = u >> clog;
-      const uint32_t q00 = ((qq >> lo) << (lo + 2)) | (qq & ((1u << lo) - 1u));
-      const uint32_t q01 = q00 | (1u << lo), q10 = q00 | (2u << lo), q11 = q00 | (3u << lo);
-      const uint32_t e00 = (q00 << clog) + cc, e01 = (q01 << clog) + cc, e10 = (q10 << clog) + cc, e11 = (q11 << clog) + cc;
-      uint32_t x00[NL], x01[NL], x10[NL], x11[NL], y00[NL], y01[NL], y10[NL], y11[NL];
-#pragma unroll
-      for (int l = 0; l < NL; ++l) {
-        x00[l] = sh[l * kNttTile + e00]; x01[l] = sh[l * kNttTile + e01]; x10[l] = sh[l * kNttTile + e10]; x11[l] = sh[l * kNttTile + e11];
-      }
-      if constexpr (kInverse) {
-        // layer `step` pairs along bit lo, layer `step + 1` along bit lo + 1
-        ntt_dit_butterfly(step, x00, x01, twiddle_at(q00, cc, lo), y00, y01);
-        ntt_dit_butterfly(step, x10, x11, twiddle_at(q10, cc, lo), y10, y11);
-        ntt_dit_butterfly(step + 1, y00, y10, twiddle_at(q00, cc, lo + 1), x00, x10);
-        ntt_dit_butterfly(step + 1, y01, y11, twiddle_at(q01, cc, lo + 1), x01, x11);
-      } else {
-        // layer `step` pairs along bit lo + 1, layer `step + 1` along bit lo
-        ntt_dif_butterfly(step, x00, x10, twiddle_at(q00, cc, lo + 1), y00, y10);
-        ntt_dif_butterfly(step, x01, x11, twiddle_at(q01, cc, lo + 1), y01, y11);
-        ntt_dif_butterfly(step + 1, y00, y01, twiddle_at(q00, cc, lo), x00, x01);
-        ntt_dif_butterfly(step + 1, y10, y11, twiddle_at(q10, cc, lo), x10, x11);
-      }
-#pragma unroll
-      for (int l = 0; l < NL; ++l) {
-        sh[l * kNttTile + e00] = x00[l]; sh[l * kNttTile + e01] = x01[l]; sh[l * kNttTile + e10] = x10[l]; sh[l * kNttTile + e11] = x11[l];
-      }
-    }
-    __syncthreads();
-  }
-#endif
   for (; step < k; ++step) {
     const int b = kInverse ? step : k - 1 - step;          // DIF runs the stages downwards, DIT upwards
-    for (uint32_t u = threadIdx.x; u < E / 2; u += 256) {
-      const uint32_t cc = u & (C - 1), qq = u >> clog;
-      const uint32_t q0 = ((qq >> b) << (b + 1)) | (qq & ((1u << b) - 1u));
-      const uint32_t e0 = (q0 << clog) + cc, e1 = e0 + ((1u << b) << clog);
-      const Fe<ModR, 1> w = twiddle_at(q0, cc, b);
-      uint32_t la[NL], lb[NL];
+    const bool trivial = (s_lo + b) == 0;                  // stage 0 of the transform: every twiddle is 1
+    auto slots = [&](uint32_t u, uint32_t& e0, uint32_t& e1, uint32_t& q0, uint32_t& cc) {
+      cc = u & (C - 1);
+      const uint32_t qq = u >> clog;
+      q0 = ((qq >> b) << (b + 1)) | (qq & ((1u << b) - 1u));
+      e0 = (q0 << clog) + cc; e1 = e0 + ((1u << b) << clog);
+    };
+    uint32_t u = threadIdx.x;
+    for (; u + 256 < E / 2; u += 512) {                    // two butterflies of this thread at once (the full-tile case: one round)
+      uint32_t e0[2], e1[2], q0[2], cc[2];
+      slots(u, e0[0], e1[0], q0[0], cc[0]);
+      slots(u + 256, e0[1], e1[1], q0[1], cc[1]);
+      Fe<ModR, 1> w[2];
+      if (!trivial) { w[0] = twiddle_at(q0[0], cc[0], b); w[1] = twiddle_at(q0[1], cc[1], b); }
+      Bfly x[2];
 #pragma unroll
-      for (int l = 0; l < NL; ++l) { la[l] = sh[l * kNttTile + e0]; lb[l] = sh[l * kNttTile + e1]; }
-      uint32_t o0[NL], o1[NL];
-      if constexpr (kInverse) ntt_dit_butterfly(step, la, lb, w, o0, o1);
-      else ntt_dif_butterfly(step, la, lb, w, o0, o1);
+      for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int l = 0; l < NL; ++l) { sh[l * kNttTile + e0] = o0[l]; sh[l * kNttTile + e1] = o1[l]; }
+        for (int l = 0; l < NL; ++l) { x[t].a[l] = sh[l * kNttTile + e0[t]]; x[t].b[l] = sh[l * kNttTile + e1[t]]; }
+      if constexpr (kInverse) ntt_dit_butterfly<2>(step, k, x, w, trivial);
+      else ntt_dif_butterfly<2>(step, x, w, trivial);
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int l = 0; l < NL; ++l) { sh[l * kNttTile + e0[t]] = x[t].a[l]; sh[l * kNttTile + e1[t]] = x[t].b[l]; }
+    }
+    for (; u < E / 2; u += 256) {                          // small tiles: one at a time
+      uint32_t e0, e1, q0, cc;
+      slots(u, e0, e1, q0, cc);
+      Fe<ModR, 1> w[1];
+      if (!trivial) w[0] = twiddle_at(q0, cc, b);
+      Bfly x[1];
+#pragma unroll
+      for (int l = 0; l < NL; ++l) { x[0].a[l] = sh[l * kNttTile + e0]; x[0].b[l] = sh[l * kNttTile + e1]; }
+      if constexpr (kInverse) ntt_dit_butterfly<1>(step, k, x, w, trivial);
+      else ntt_dif_butterfly<1>(step, x, w, trivial);
+#pragma unroll
+      for (int l = 0; l < NL; ++l) { sh[l * kNttTile + e0] = x[0].a[l]; sh[l * kNttTile + e1] = x[0].b[l]; }
     }
     __syncthreads();
   }

@@ -41,6 +41,28 @@ def bias_limbs(kp):
     return d
 
 
+def tight_bias_limbs(kp):
+    """K*p with every low limb in [2^29 + 15, 2^30): limb-wise (a + bias - b) never underflows for nearly-normal b (limbs < 2^29 + 16)
+    and stays below 3 * 2^29 + 16 -- the bias of the LAZY subtraction (fp29.h, sub_lazy / neg_lazy), whose result skips the carry
+    pass and goes straight into a product.  Needs every low limb of K*p >= 16 (None otherwise: the caller takes the next K)."""
+    l = limbs(kp)
+    if any(v < 16 for v in l[:N - 1]) or l[N - 1] < 1:
+        return None
+    d = [l[0] + (1 << 29)] + [l[i] + (1 << 29) - 1 for i in range(1, N - 1)] + [l[N - 1] - 1]
+    assert sum(v << (W * i) for i, v in enumerate(d)) == kp
+    assert all((1 << 29) + 15 <= v < (1 << 30) for v in d[:N - 1])
+    return d
+
+
+def wide_bias_limbs(kp):
+    """K*p with every low limb >= 2^31 - 4: a + bias - b - 2c never underflows for nearly-normal b, c (fp29.h, sub_b_2c)."""
+    l = limbs(kp)
+    d = [l[0] + (1 << 31)] + [l[i] + (1 << 31) - 4 for i in range(1, N - 1)] + [l[N - 1] - 4]
+    assert sum(v << (W * i) for i, v in enumerate(d)) == kp
+    assert all(0 <= v < (1 << 31) + (1 << 29) for v in d) and d[-1] >= 0
+    return d
+
+
 def field(name, p, extra=""):
     pinv = (-pow(p, -1, 1 << W)) % (1 << W)
     s = "struct %s {\n" % name
@@ -57,6 +79,24 @@ def field(name, p, extra=""):
     s += "  static __host__ __device__ __forceinline__ constexpr uint32_t bias(int k, int i) {\n    switch (k * 16 + i) {\n"
     for k in range(1, maxk + 1):
         d = bias_limbs(k * p)
+        s += "      " + " ".join("case %d: return 0x%08xu;" % (k * 16 + i, v) for i, v in enumerate(d)) + "\n"
+    s += "      default: return 0u;\n    }\n  }\n"
+    # tight bias (lazy subtraction): entry k holds K' p for the smallest K' >= k whose low limbs are all >= 16
+    tk = []
+    s += "  static __host__ __device__ __forceinline__ constexpr uint32_t tbias(int k, int i) {\n    switch (k * 16 + i) {\n"
+    for k in range(1, maxk + 1):
+        kk = k
+        while tight_bias_limbs(kk * p) is None:
+            kk += 1
+        tk.append(kk)
+        d = tight_bias_limbs(kk * p)
+        s += "      " + " ".join("case %d: return 0x%08xu;" % (k * 16 + i, v) for i, v in enumerate(d)) + "\n"
+    s += "      default: return 0u;\n    }\n  }\n"
+    s += "  static __host__ __device__ __forceinline__ constexpr int tbias_k(int k) {      // the multiple of p entry k of tbias holds\n    switch (k) { "
+    s += " ".join("case %d: return %d;" % (k, kk) for k, kk in zip(range(1, maxk + 1), tk)) + " default: return 0; }\n  }\n"
+    s += "  static __host__ __device__ __forceinline__ constexpr uint32_t wbias(int k, int i) {\n    switch (k * 16 + i) {\n"
+    for k in range(1, maxk + 1):
+        d = wide_bias_limbs(k * p)
         s += "      " + " ".join("case %d: return 0x%08xu;" % (k * 16 + i, v) for i, v in enumerate(d)) + "\n"
     s += "      default: return 0u;\n    }\n  }\n"
     s += extra

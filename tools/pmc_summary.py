@@ -6,8 +6,12 @@ import sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 want = sys.argv[2]
 acc = collections.defaultdict(lambda: [0, 0.0])
+import os
+min_grid = int(os.environ.get("PMC_MIN_GRID", "0"))      # only dispatches with at least this many work-items (e.g. the 2^21-point NTT passes)
 for r in rows:
     if r.get("Counter_Name") != want:
+        continue
+    if min_grid and int(r.get("Grid_Size", "0") or 0) < min_grid:
         continue
     k = r["Kernel_Name"].split("(")[0]
     acc[k][0] += 1
