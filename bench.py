@@ -224,6 +224,29 @@ def logical_shard_report(args, n, seed, sharded_prove):
         ok = groth16.VerifyProof(inst.vk, got, capi.u64_to_ints(inst.w_host[1:2]))
         out.update({"proof_equals_single_device": True, "proof_verified": bool(ok), "used_rccl": used,
                     "replicated_poly_stage_ms": poly_ms})
+        if sum(capi.pk_eval_count(k.handle) for k in pks) == n:
+            # The values route (gs_groth16_witness_values on ONE owner per proof, slices of H's values scattered, every shard sums only
+            # its term ranges): no replicated polynomial stage.  Measured here: the owner's stage, every shard alone, the proof itself.
+            from gosnark_amd import r1csqap
+            capi.set_device(0)
+            dr = r1csqap.DeviceR1CS(*inst.r1cs, inst.m)
+            hv, bad = groth16.witness_values(pks[0], dr, ws[0])
+            assert bad == 0
+            values_ms = time_calls(lambda: groth16.witness_values(pks[0], dr, ws[0], hv), 4)
+            slices = groth16.scatter_values(hv, S)
+
+            def scatter_once():
+                for h in groth16.scatter_values(hv, S):
+                    h.free()
+            scatter_ms = time_calls(scatter_once, 3)
+            for d in range(S):
+                groth16.prove_partials_values(pks[d], ws[d], slices[d], d, S)       # evaluation-basis tables of the slice
+            v_ms = [time_calls(lambda d=d: groth16.prove_partials_values(pks[d], ws[d], slices[d], d, S), 3) for d in range(S)]
+            gotv, usedv = groth16.prove_multi_values(pks, ws, slices, r_, s_)
+            if (gotv.PiA, gotv.PiB, gotv.PiC) != (want.PiA, want.PiB, want.PiC):
+                raise SystemExit("bench.py: the values-route sharded proof differs from the single-device proof")
+            out["values_route"] = {"owner_polynomial_stage_ms": values_ms, "per_shard_ms": v_ms, "proof_equals_single_device": True,
+                                   "scatter_payload_bytes_per_peer": 32 * (n // S), "scatter_on_one_gpu_ms": scatter_ms, "used_rccl": usedv}
         unit = "constraints/s"
     else:
         from gosnark_amd import parallel
@@ -271,6 +294,10 @@ def main():
                          "stage upstream of GenerateProofs, reported for information; prove_witness: witness -> proof without px "
                          "(gs_groth16_prove_witness[_begin]: BASELINE configs[2] as worded, 'full prove + QAP kernels'), the h-MSM over H's values "
                          "when the key carries the evaluation-basis PowersTauDelta")
+    ap.add_argument("--sharded-route", default="px", choices=["px", "values"],
+                    help="prove_sharded with one process per GPU: px = every rank computes H(x) itself (replicated polynomial stage); values = "
+                         "the ranks take turns as owner of a proof's polynomial stage (gs_groth16_witness_values), the owner scatters H's values "
+                         "(gs_scalars_scatter) and every rank sums only its term ranges (gs_groth16_prove_sharded_values)")
     ap.add_argument("--logical-shards", type=int, default=0,
                     help="prove_sharded / msm_sharded on ONE GPU: that many logical devices in this process (configs[3] stand-in, SURVEY 8e)")
     ap.add_argument("--instance", default="setup", choices=["setup", "sqchain", "random"],
@@ -349,7 +376,22 @@ def main():
             from gosnark_amd import r1csqap
             dev_r1cs = r1csqap.DeviceR1CS(*inst.r1cs, inst.m)
 
+        values_route = sharded and rccl_sharded and args.sharded_route == "values"
+        if values_route:
+            from gosnark_amd import r1csqap
+            dev_r1cs = r1csqap.DeviceR1CS(*inst.r1cs, inst.m)
+        vstate = {"i": 0, "hv": None, "mine": None}
+
         def step():
+            if values_route:
+                owner = vstate["i"] % world
+                vstate["i"] += 1
+                if rank == owner:
+                    vstate["hv"], bad = groth16.witness_values(pk, dev_r1cs, inst.w, vstate["hv"])
+                    if bad:
+                        raise SystemExit("bench.py: the benchmark witness violates a constraint")
+                vstate["mine"] = capi.scalars_scatter(vstate["hv"] if rank == owner else None, n, owner, vstate["mine"])
+                return groth16.prove_sharded_values_rccl(pk, inst.w, vstate["mine"], r_, s_)
             if sharded:
                 return groth16.prove_sharded_rccl(pk, inst.w, inst.px, r_, s_) if rccl_sharded else groth16.prove_sharded(pk, inst.w, inst.px, r_, s_)
             if from_r1cs:
@@ -359,7 +401,8 @@ def main():
                 return groth16.prove_from_witness(pk, dev_r1cs, inst.w, r_, s_)
             return groth16.prove_resident(pk, inst.w, inst.px, r_, s_)
         units_per_step = n
-        workload = ("groth16_prove_2^%d_constraints_sharded_over_all_gpus" if sharded else
+        workload = ("groth16_prove_2^%d_constraints_sharded_over_all_gpus_owner_values_route" if values_route else
+                    "groth16_prove_2^%d_constraints_sharded_over_all_gpus" if sharded else
                     "groth16_px_from_sparse_r1cs_then_prove_2^%d_constraints_per_gpu" if from_r1cs else
                     "groth16_witness_to_proof_2^%d_constraints_per_gpu" if from_witness else
                     "groth16_prove_2^%d_constraints_per_gpu") % args.log2n
@@ -607,6 +650,16 @@ def main():
                 "model": "max over shards of the shard's time alone on one MI355X + the measured 1-rank ncclAllGather latency of the S records"
                          + (" + %.2f ms host tail" % tail_ms if sharded else "") +
                          "; on S GPUs the shards run concurrently.  NOT measured: no multi-GPU hardware is reachable from this run."}
+            if "values_route" in shard_info:
+                vr = shard_info["values_route"]
+                per_proof = max(vr["per_shard_ms"]) + vr["owner_polynomial_stage_ms"] / S + shard_info["gather_ms_one_rank_rccl"] + tail_ms
+                vr["MODELLED_not_measured"] = {
+                    "gpus": S, "ms_per_proof_streaming": per_proof, "value": n / per_proof * 1e3, "unit": out["unit"],
+                    "ms_latency_of_a_lone_proof": max(vr["per_shard_ms"]) + vr["owner_polynomial_stage_ms"] + shard_info["gather_ms_one_rank_rccl"] + tail_ms,
+                    "model": "a stream of proofs on S GPUs, the ranks take turns as owner: per proof every rank spends its shard's sums (max over shards, measured "
+                             "alone on one MI355X) + 1/S of one owner stage (measured) + the measured 1-rank ncclAllGather + %.2f ms host tail; the scatter (%d bytes "
+                             "per peer, one ncclSend per xGMI link in one group) runs on the communicator's stream beside the sums and is not priced.  NOT measured: "
+                             "no multi-GPU hardware is reachable from this run." % (tail_ms, vr["scatter_payload_bytes_per_peer"])}
             out["sharding"] = shard_info
         for k, v in extras.items():
             out[k] = v

@@ -87,6 +87,7 @@ _SIGS = {
     "gs_pinocchio_prove_witness_begin": [Handle, Handle, Handle, u64p],
     "gs_groth16_prove_begin": [Handle, Handle, Handle, u64p, u64p, u64p],
     "gs_groth16_prove_end": [ctypes.c_uint64, u64p, intp],
+    "gs_ticket_cancel": [ctypes.c_uint64],
     "gs_groth16_pk_create_shard": [Handle, Handle, Handle, Handle, Handle, u64p, u64p, u64p, u64p, u64p, u64p, ctypes.c_size_t,
                                    ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, ctypes.POINTER(Handle)],
     "gs_groth16_pk_shard": [Handle, ctypes.c_size_t, ctypes.c_size_t, ctypes.POINTER(Handle)],
@@ -122,6 +123,11 @@ _SIGS = {
     "gs_msm_g2_multi": [ctypes.POINTER(Handle), ctypes.POINTER(Handle), ctypes.c_int, u64p, intp, intp],
     "gs_groth16_prove_multi": [ctypes.POINTER(Handle), ctypes.POINTER(Handle), ctypes.POINTER(Handle), ctypes.c_int, u64p, u64p, u64p, intp, intp],
     "gs_groth16_prove_sharded": [Handle, Handle, Handle, u64p, u64p, u64p, intp],
+    "gs_groth16_witness_values": [Handle, Handle, Handle, ctypes.POINTER(Handle), ctypes.POINTER(ctypes.c_uint32)],
+    "gs_groth16_prove_partials_values": [Handle, Handle, Handle, ctypes.c_size_t, ctypes.c_size_t, u64p, intp],
+    "gs_groth16_prove_multi_values": [ctypes.POINTER(Handle), ctypes.POINTER(Handle), ctypes.POINTER(Handle), ctypes.c_int, u64p, u64p, u64p, intp, intp],
+    "gs_groth16_prove_sharded_values": [Handle, Handle, Handle, u64p, u64p, u64p, intp],
+    "gs_scalars_scatter": [Handle, ctypes.c_size_t, ctypes.c_int, ctypes.POINTER(Handle)],
     "gs_msm_g1_sharded": [Handle, Handle, u64p, intp],
     "gs_msm_g2_sharded": [Handle, Handle, u64p, intp],
     "gs_groth16_prove_batch": [ctypes.POINTER(Handle), ctypes.c_int, ctypes.POINTER(Handle), ctypes.POINTER(Handle), ctypes.c_size_t,
@@ -462,6 +468,11 @@ def msm_begin(bases, scalars, n, off=0, soff=0, g2=False):
     return (t.value, g2)
 
 
+def ticket_cancel(ticket):
+    """gs_ticket_cancel: abandon a pipelined operation (proof ticket, or the integer of an MSM ticket) without its result."""
+    check(load_library().gs_ticket_cancel(ctypes.c_uint64(ticket[0] if isinstance(ticket, tuple) else ticket)))
+
+
 def msm_end(ticket):
     t, g2 = ticket
     out = np.zeros(16 if g2 else 8, dtype=np.uint64)
@@ -487,6 +498,14 @@ def g1_clone(handle, target, off=0, n=None):
 
 def g2_clone(handle, target, off=0, n=None):
     return _clone("gs_g2_clone", handle, off, len(handle) - off if n is None else n, target)
+
+
+def scalars_scatter(full_handle, total, root, slice_handle=None):
+    """gs_scalars_scatter (one process per GPU, communicator of comm_init_rank): the root's `total` scalars -> every rank's slice of
+    the contiguous split.  full_handle is ignored on the other ranks (pass None)."""
+    h = Handle(slice_handle.h if slice_handle is not None else 0)
+    check(load_library().gs_scalars_scatter(Handle(full_handle.h if full_handle is not None else 0), int(total), int(root), ctypes.byref(h)))
+    return slice_handle if slice_handle is not None else DeviceHandle(h.value)
 
 
 def comm_unique_id():

@@ -311,9 +311,9 @@ int gs_init(const int* devices, int ndev) {
     }
     static bool registered = false;
     if (!registered) { atexit([] { process_exiting() = true; }); registered = true; }
-    std::vector<std::unique_ptr<Ctx>> fresh;
+    std::vector<std::shared_ptr<Ctx>> fresh;
     for (int i = 0; i < ndev; ++i) {
-      fresh.push_back(std::make_unique<Ctx>());
+      fresh.push_back(std::make_shared<Ctx>());
       ctx_create(*fresh.back(), i, devices[i]);
     }
     // distinct physical devices copy key slices / scalar vectors to each other directly over xGMI
@@ -344,15 +344,11 @@ void gs_shutdown(void) {
   r.ctxs.clear();                                   // nothing survives: a later gs_init may name other devices
 }
 
-int gs_device_count(void) {
-  Registry& r = registry();
-  std::lock_guard<std::mutex> lk(r.mu);
-  return (int)r.ctxs.size();
-}
+int gs_device_count(void) { return (int)logical_device_count(); }
 
 int gs_set_device(int logical) {
-  if (logical < 0 || (size_t)logical >= registry().ctxs.size())
-    return fail(GS_ERR_ARG, "gs_set_device: no logical device %d (gs_init listed %zu)", logical, registry().ctxs.size());
+  const size_t n = logical_device_count();
+  if (logical < 0 || (size_t)logical >= n) return fail(GS_ERR_ARG, "gs_set_device: no logical device %d (gs_init listed %zu)", logical, n);
   current_logical() = logical;
   return GS_OK;
 }
@@ -435,7 +431,7 @@ int gs_scalars_clone(gs_handle h, size_t off, size_t n, int target_device, gs_ha
     auto o = std::make_unique<Scalars>();
     o->n = n;
     o->buf.alloc(std::max<size_t>(n, 1) * 32);
-    if (n) GS_HIP(hipMemcpyAsync(o->buf.p, s->buf.as<uint32_t>() + off * 8, n * 32, hipMemcpyDeviceToDevice, dst.stream));
+    copy_between(dst, o->buf.p, src, s->buf.as<uint32_t>() + off * 8, n * 32);
     GS_HIP(hipStreamSynchronize(dst.stream));
     *out = dst.put(std::move(o));
     return GS_OK;
@@ -449,7 +445,7 @@ static int bases_clone(Kind kind, size_t words, gs_handle h, size_t off, size_t 
     auto o = std::make_unique<Bases>(kind);
     o->n = n;
     o->buf.alloc(std::max<size_t>(n, 1) * words * 4);
-    if (n) GS_HIP(hipMemcpyAsync(o->buf.p, b->buf.as<uint32_t>() + off * words, n * words * 4, hipMemcpyDeviceToDevice, dst.stream));
+    copy_between(dst, o->buf.p, src, b->buf.as<uint32_t>() + off * words, n * words * 4);
     GS_HIP(hipStreamSynchronize(dst.stream));
     *out = dst.put(std::move(o));
     return GS_OK;
@@ -508,18 +504,36 @@ int gs_last_timing(gs_timing* out) {
 
 int gs_device_timing(int logical_device, gs_timing* out) {
   if (!out) return fail(GS_ERR_ARG, "null");
-  Ctx& c = ctx_at(logical_device);
-  if (!c.ready) return fail(GS_ERR_ARG, "gs_device_timing: no logical device %d", logical_device);
+  std::shared_ptr<Ctx> pc = ctx_ref(logical_device);
+  if (!pc) return fail(GS_ERR_ARG, "gs_device_timing: no logical device %d", logical_device);
+  Ctx& c = *pc;
   std::lock_guard<std::mutex> lk(c.mu);
+  if (!c.ready) return fail(GS_ERR_NOT_INIT, "the library was shut down");
   *out = c.timing;
   return GS_OK;
+}
+
+// Give up a pipelined operation: waits for the device work it enqueued (its workspaces must be quiet before another operation
+// takes the slot), then releases the slot and the references to the key and vectors it read.  Nothing is returned.
+int gs_ticket_cancel(uint64_t ticket) {
+  return guarded([&](Ctx& c) -> int {
+    for (int p = 0; p < Ctx::kMaxInFlight; ++p)
+      if (c.inflight[p] && c.inflight[p]->ticket == ticket) {
+        c.drain();
+        c.inflight[p].reset();
+        return GS_OK;
+      }
+    return fail(GS_ERR_ARG, "gs_ticket_cancel: unknown ticket %llu", (unsigned long long)ticket);
+  }, true, true, ticket);
 }
 
 // applies to every logical device (a process-wide tunable, like the environment switches)
 int gs_set_window_bits(int cbits) {
   if (cbits != 0 && (cbits < 8 || cbits > kMaxWindowBits)) return fail(GS_ERR_ARG, "window bits must be 0 (auto) or 8..%d", kMaxWindowBits);
-  if (registry().ctxs.empty()) return fail(GS_ERR_NOT_INIT, "gs_init has not been called (or failed)");
-  for (auto& pc : registry().ctxs) {
+  Registry& r = registry();
+  std::lock_guard<std::mutex> rl(r.mu);
+  if (r.ctxs.empty()) return fail(GS_ERR_NOT_INIT, "gs_init has not been called (or failed)");
+  for (auto& pc : r.ctxs) {
     std::lock_guard<std::mutex> lk(pc->mu);
     pc->window_bits = cbits;
   }
@@ -529,8 +543,10 @@ int gs_set_window_bits(int cbits) {
 // Witness route of keys that carry an evaluation-basis array: 1 (default) = h-MSM over H's values, 0 = the coefficient route
 // (interpolation + Taylor shift) every other key takes.  Same proofs; a switch for measurements and tests.  Every logical device.
 int gs_set_eval_basis(int enabled) {
-  if (registry().ctxs.empty()) return fail(GS_ERR_NOT_INIT, "gs_init has not been called (or failed)");
-  for (auto& pc : registry().ctxs) {
+  Registry& r = registry();
+  std::lock_guard<std::mutex> rl(r.mu);
+  if (r.ctxs.empty()) return fail(GS_ERR_NOT_INIT, "gs_init has not been called (or failed)");
+  for (auto& pc : r.ctxs) {
     std::lock_guard<std::mutex> lk(pc->mu);
     pc->eval_basis = enabled != 0;
   }

@@ -189,11 +189,11 @@ int check_devices(const gs_handle* a, const gs_handle* b, const gs_handle* c, in
   phys_of.assign(ndev, -1);
   for (int d = 0; d < ndev; ++d) {
     const int ld = handle_device(a[d]);
-    Ctx& cx = ctx_at(ld);
-    if (!cx.ready) return fail(GS_ERR_ARG, "%s: shard %d: handle names logical device %d, which gs_init did not create", fn, d, ld);
+    std::shared_ptr<Ctx> cx = ctx_ref(ld);
+    if (!cx) return fail(GS_ERR_ARG, "%s: shard %d: handle names logical device %d, which gs_init did not create", fn, d, ld);
     if ((b && handle_device(b[d]) != ld) || (c && handle_device(c[d]) != ld))
       return fail(GS_ERR_ARG, "%s: shard %d: its handles live on different logical devices", fn, d);
-    phys_of[d] = cx.device;
+    phys_of[d] = cx->device;             // (`device` is written once, before the context is published)
   }
   return GS_OK;
 }
@@ -222,8 +222,9 @@ int gs_comm_unique_id(uint8_t out[128]) {
 
 int gs_comm_init_rank(const uint8_t id_bytes[128], int nranks, int rank) {
   if (!id_bytes || nranks < 1 || rank < 0 || rank >= nranks) return fail(GS_ERR_ARG, "gs_comm_init_rank: bad id / rank %d of %d", rank, nranks);
-  Ctx& c = ctx();
-  if (!c.ready) return fail(GS_ERR_NOT_INIT, "gs_comm_init_rank: gs_init first (the calling thread's current logical device joins)");
+  std::shared_ptr<Ctx> pc = ctx_ref(current_logical());
+  if (!pc) return fail(GS_ERR_NOT_INIT, "gs_comm_init_rank: gs_init first (the calling thread's current logical device joins)");
+  Ctx& c = *pc;
   Comm& cm = comm();
   std::lock_guard<std::mutex> lk(cm.mu);
   if (cm.active()) return fail(GS_ERR_ARG, "a communicator already exists: gs_comm_destroy first");
@@ -240,13 +241,16 @@ int gs_comm_init_rank(const uint8_t id_bytes[128], int nranks, int rank) {
 }
 
 int gs_comm_init_local(void) {
-  Registry& r = registry();
-  if (r.ctxs.empty()) return fail(GS_ERR_NOT_INIT, "gs_comm_init_local: gs_init first");
+  std::vector<int> phys;
+  {
+    Registry& r = registry();
+    std::lock_guard<std::mutex> rl(r.mu);
+    if (r.ctxs.empty()) return fail(GS_ERR_NOT_INIT, "gs_comm_init_local: gs_init first");
+    for (auto& c : r.ctxs) if (std::find(phys.begin(), phys.end(), c->device) == phys.end()) phys.push_back(c->device);
+  }
   Comm& cm = comm();
   std::lock_guard<std::mutex> lk(cm.mu);
   if (cm.active()) return fail(GS_ERR_ARG, "a communicator already exists: gs_comm_destroy first");
-  std::vector<int> phys;
-  for (auto& c : r.ctxs) if (std::find(phys.begin(), phys.end(), c->device) == phys.end()) phys.push_back(c->device);
   cm.local = true; cm.nranks = (int)phys.size(); cm.rank = 0; cm.phys = phys;
   cm.comms.assign(phys.size(), nullptr); cm.streams.assign(phys.size(), nullptr);
   cm.send.assign(phys.size(), nullptr); cm.recv.assign(phys.size(), nullptr);
@@ -372,6 +376,110 @@ int gs_groth16_prove_sharded(gs_handle pk, gs_handle w, gs_handle px, const uint
   return gs_groth16_finish(pk, sums, sinf, r, s, out_proof, inf);
 }
 
+// ---- the same two, with the polynomial stage on ONE rank per proof (prove.hip: gs_groth16_witness_values) ------------------------
+// hv[d]: device d's slice of H's values (the range of its key slice's evaluation-basis array), scattered by the proof's owner.
+int gs_groth16_prove_multi_values(const gs_handle* pk, const gs_handle* w, const gs_handle* hv, int ndev, const uint64_t r[4], const uint64_t s[4],
+                                  uint64_t out_proof[32], int inf[3], int* used_rccl) {
+  std::vector<int> phys_of;
+  if (int rc = check_devices(pk, w, hv, ndev, "gs_groth16_prove_multi_values", phys_of)) return rc;
+  if (!w || !hv || !r || !s || !out_proof || !inf) return fail(GS_ERR_ARG, "gs_groth16_prove_multi_values: null argument");
+  std::vector<ProofRecord> mine(ndev), all;
+  if (int rc = on_devices(ndev, [&](int d) {
+        int f[5] = {0, 0, 0, 0, 0};
+        const int rc = gs_groth16_prove_partials_values(pk[d], w[d], hv[d], (size_t)d, (size_t)ndev, mine[d].sums, f);
+        for (int k = 0; k < 5; ++k) mine[d].inf[k] = (uint32_t)f[k];
+        mine[d].shard = (uint32_t)d; mine[d].pad[0] = mine[d].pad[1] = 0;
+        return rc;
+      }, "gs_groth16_prove_multi_values")) return rc;
+  if (int rc = exchange(mine, phys_of, all, used_rccl)) return rc;
+  uint64_t sums[48];
+  int sinf[5];
+  if (int rc = sum_proof_records(all, sums, sinf)) return rc;
+  return gs_groth16_finish(pk[0], sums, sinf, r, s, out_proof, inf);
+}
+
+int gs_groth16_prove_sharded_values(gs_handle pk, gs_handle w, gs_handle hv_slice, const uint64_t r[4], const uint64_t s[4], uint64_t out_proof[32], int inf[3]) {
+  if (!r || !s || !out_proof || !inf) return fail(GS_ERR_ARG, "gs_groth16_prove_sharded_values: null argument");
+  int nranks = 0, rank = -1, local = 0;
+  gs_comm_info(&nranks, &rank, &local, nullptr);
+  if (nranks < 1 || local) return fail(GS_ERR_ARG, "gs_groth16_prove_sharded_values: needs the communicator of gs_comm_init_rank (one process per GPU)");
+  ProofRecord mine{};
+  int f[5] = {0, 0, 0, 0, 0};
+  if (int rc = gs_groth16_prove_partials_values(pk, w, hv_slice, (size_t)rank, (size_t)nranks, mine.sums, f)) return rc;
+  for (int k = 0; k < 5; ++k) mine.inf[k] = (uint32_t)f[k];
+  mine.shard = (uint32_t)rank;
+  std::vector<ProofRecord> all(nranks);
+  if (int rc = gs_comm_allgather(&mine, sizeof mine, all.data())) return rc;
+  for (int i = 0; i < nranks; ++i)
+    if (all[i].shard != (uint32_t)i) return fail(GS_ERR_HIP, "gathered record %d carries shard index %u", i, all[i].shard);
+  uint64_t sums[48];
+  int sinf[5];
+  if (int rc = sum_proof_records(all, sums, sinf)) return rc;
+  return gs_groth16_finish(pk, sums, sinf, r, s, out_proof, inf);
+}
+
+// The owner's scatter between processes: rank `root` holds `total` scalars (handle `full`, ignored on the other ranks); every rank
+// -- the root included -- ends up with its slice of the contiguous split of [0, total) (first ranks one longer: the split every
+// sharded entry point uses) in *slice_inout (0 = create).  ncclSend / ncclRecv in one group on the communicator's stream: the
+// root's 32 (n / N) bytes per peer leave over its xGMI links in parallel (n = 2^22 over 8 ranks = 16 MiB per peer).
+int gs_scalars_scatter(gs_handle full, size_t total, int root, gs_handle* slice_inout) {
+  if (!slice_inout) return fail(GS_ERR_ARG, "gs_scalars_scatter: null output");
+  Comm& cm = comm();
+  std::lock_guard<std::mutex> lk(cm.mu);
+  if (!cm.active() || cm.local) return fail(GS_ERR_ARG, "gs_scalars_scatter: needs the communicator of gs_comm_init_rank (one process per GPU)");
+  if (root < 0 || root >= cm.nranks) return fail(GS_ERR_ARG, "gs_scalars_scatter: root %d of %d ranks", root, cm.nranks);
+  auto range = [&](int k, size_t& lo, size_t& hi) {
+    const size_t q = total / (size_t)cm.nranks, rem = total % (size_t)cm.nranks;
+    lo = (size_t)k * q + std::min<size_t>((size_t)k, rem);
+    hi = lo + q + ((size_t)k < rem ? 1 : 0);
+  };
+  size_t mylo, myhi;
+  range(cm.rank, mylo, myhi);
+  const size_t mine = myhi - mylo;
+  uint32_t* dst = nullptr;
+  const uint32_t* src = nullptr;
+  // resolve the handles on their context (objects are kept alive by the caller for the duration of the call)
+  int rc = guarded([&](Ctx& c) -> int {
+    Scalars* out = nullptr;
+    if (*slice_inout) {
+      out = c.get<Scalars>(*slice_inout, Kind::Scalars);
+      if (!out || out->n != mine) return fail(GS_ERR_ARG, "gs_scalars_scatter: the output handle does not hold this rank's %zu values", mine);
+    } else {
+      auto fresh = std::make_unique<Scalars>();
+      fresh->n = mine;
+      fresh->buf.alloc(std::max<size_t>(mine, 1) * 32);
+      out = fresh.get();
+      *slice_inout = c.put(std::move(fresh));
+    }
+    dst = out->buf.as<uint32_t>();
+    if (cm.rank == root) {
+      Scalars* f = c.get<Scalars>(full, Kind::Scalars);
+      if (!f || f->n != total) return fail(GS_ERR_ARG, "gs_scalars_scatter: the root's vector must hold the %zu values", total);
+      src = f->buf.as<uint32_t>();
+    }
+    c.drain();                                          // whatever produced the root's vector / still reads the old slice
+    return GS_OK;
+  }, true, true, *slice_inout ? *slice_inout : (cm.rank == root ? full : 0));
+  if (rc != GS_OK) return rc;
+  GS_HIPRC(hipSetDevice(cm.phys[0]));
+  GS_NCCL(ncclGroupStart());
+  if (cm.rank == root) {
+    for (int k = 0; k < cm.nranks; ++k) {
+      size_t lo, hi;
+      range(k, lo, hi);
+      if (k == root || hi == lo) continue;
+      GS_NCCL(ncclSend(src + lo * 8, (hi - lo) * 32, ncclUint8, k, cm.comms[0], cm.streams[0]));
+    }
+  } else if (mine) {
+    GS_NCCL(ncclRecv(dst, mine * 32, ncclUint8, root, cm.comms[0], cm.streams[0]));
+  }
+  GS_NCCL(ncclGroupEnd());
+  if (cm.rank == root && mine) GS_HIPRC(hipMemcpyAsync(dst, src + mylo * 8, mine * 32, hipMemcpyDeviceToDevice, cm.streams[0]));
+  GS_HIPRC(hipStreamSynchronize(cm.streams[0]));
+  cm.collectives += 1;
+  return GS_OK;
+}
+
 static int msm_sharded(bool g2, gs_handle bases, gs_handle scalars, uint64_t* out_affine, int* is_inf) {
   if (!out_affine || !is_inf) return fail(GS_ERR_ARG, "gs_msm_sharded: null output");
   int nranks = 0, rank = -1, local = 0;
@@ -421,19 +529,31 @@ int gs_groth16_prove_batch(const gs_handle* pk_of_device, int ndev, const gs_han
   }
   return on_devices(ndev, [&](int d) -> int {
     const std::vector<size_t>& q = work[d];
-    std::vector<uint64_t> tickets(q.size());
+    std::vector<uint64_t> tickets(q.size(), 0);
     const size_t depth = Ctx::kMaxInFlight;
-    for (size_t k = 0; k < q.size() + depth; ++k) {
-      if (k >= depth) {
-        const size_t i = q[k - depth];
-        if (int rc = gs_groth16_prove_end(tickets[k - depth], out_proofs + i * 32, inf + i * 3)) return rc;
+    size_t begun = 0, collected = 0;
+    int rc = GS_OK;
+    for (size_t k = 0; k < q.size() + depth && rc == GS_OK; ++k) {
+      if (k >= depth && collected < begun) {
+        const size_t i = q[collected];
+        rc = gs_groth16_prove_end(tickets[collected], out_proofs + i * 32, inf + i * 3);
+        ++collected;                                  // collected or not, that ticket is gone (prove_end consumed the slot)
+        if (rc != GS_OK) break;
       }
       if (k < q.size()) {
         const size_t i = q[k];
-        if (int rc = gs_groth16_prove_begin(pk_of_device[d], w[i], px[i], r + i * 4, s + i * 4, &tickets[k])) return rc;
+        rc = gs_groth16_prove_begin(pk_of_device[d], w[i], px[i], r + i * 4, s + i * 4, &tickets[k]);
+        if (rc == GS_OK) ++begun;
       }
     }
-    return GS_OK;
+    if (rc != GS_OK) {
+      // Leave no ticket behind: an uncollected ticket keeps its slot, its key and its vectors, and every later
+      // gs_*_begin on this device would answer GS_ERR_BUSY until gs_shutdown.  The error that is reported is the first one.
+      const std::string first = gs_last_error();
+      for (size_t t = collected; t < begun; ++t) (void)gs_ticket_cancel(tickets[t]);
+      last_error_ref() = first;
+    }
+    return rc;
   }, "gs_groth16_prove_batch");
 }
 

@@ -38,6 +38,9 @@ struct DevScalars {            // a scalar vector used by a prove call (not owne
   // writes (n_eval of them) into the first buffer; the second is a device word that receives the number of violated constraints.
   // No host wait: the word is read when the proof is collected, and a non-zero count sends the caller down the exact route.
   std::function<void(Ctx&, uint32_t*, uint32_t*)> produce_hv;
+  // ... or the values of this key slice's range [e_lo, e_lo + n_e) are already there (computed by another rank and scattered:
+  // gs_groth16_prove_partials_values); n = n_e then
+  const uint32_t* hv_slice = nullptr;
 };
 
 // Per-context staging of the prover entry points (device memory belongs to one device).
@@ -124,7 +127,7 @@ int groth16_enqueue(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, const S
                     GrothInFlight& st) {
   DevBuf& hxbuf = prove_state(c).hx[parity];
   if (w.n != pk->nvars) return fail(GS_ERR_SHAPE, "len(w) = %zu but the key has %zu variables", w.n, pk->nvars);
-  const bool eval = (bool)px.produce_hv;        // h-MSM over H's values against the evaluation-basis table (the caller checked the key has one)
+  const bool eval = (bool)px.produce_hv || px.hv_slice;   // h-MSM over H's values against the evaluation-basis table (the caller checked the key has one)
   const size_t nh = eval ? pk->n_eval : quotient_len(px.n, pk->nz);
   if (!eval && nh > pk->nptd)
     return fail(GS_ERR_SHAPE, "len(hx) = len(px) - len(Z) + 1 = %zu exceeds len(PowersTauDelta) = %zu (groth16.go:269-271)", nh, pk->nptd);
@@ -200,7 +203,8 @@ int groth16_enqueue(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, const S
     }
     st.tpoly = std::make_shared<PhaseTimer>(c.stream);
     bool have_hx = false;
-    if (eval) {                                                                // H's values, for the evaluation-basis table
+    if (px.hv_slice) have_hx = true;                                           // H's values came from another rank
+    else if (eval) {                                                           // H's values, for the evaluation-basis table
       ProveState& ps = prove_state(c);
       px.produce_hv(c, hxbuf.as<uint32_t>(), ps.bad_dev.as<uint32_t>() + parity);
       GS_HIP(hipMemcpyAsync(ps.bad_host + parity, ps.bad_dev.as<uint32_t>() + parity, 4, hipMemcpyDeviceToHost, c.stream));
@@ -214,7 +218,7 @@ int groth16_enqueue(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, const S
     }
     st.tpoly->stop();
     st.tplanh = std::make_shared<PhaseTimer>(c.stream);
-    build_plan(c, 1 + 2 * parity, hxbuf.as<uint32_t>() + hlo * 8, (uint32_t)(hhi - hlo), plan_h, {{1, false}});
+    build_plan(c, 1 + 2 * parity, px.hv_slice ? px.hv_slice : hxbuf.as<uint32_t>() + hlo * 8, (uint32_t)(hhi - hlo), plan_h, {{1, false}});
     st.tplanh->stop();
     GS_HIP(hipEventRecord(st.planh, c.stream));
   }
@@ -598,16 +602,17 @@ int gs_poly_eval(const uint64_t* v, size_t n, const uint64_t x[4], uint64_t out[
 // ---- Groth16 ----------------------------------------------------------------------------------------------
 // Shared builder of full keys and key slices: copies [lo, lo + n) of each source array (device, packed affine).
 struct PkSrc { const DevBuf* buf; size_t lo; };
-static void copy_slice(Ctx& c, const PkSrc& s, size_t n, size_t words, DevBuf& dst) {
+// `from`: the context the source arrays live on (another GPU for gs_groth16_pk_shard_to)
+static void copy_slice(Ctx& c, Ctx& from, const PkSrc& s, size_t n, size_t words, DevBuf& dst) {
   dst.alloc(std::max<size_t>(n, 1) * words * 4);
-  if (n) GS_HIP(hipMemcpyAsync(dst.p, static_cast<const char*>(s.buf->p) + s.lo * words * 4, n * words * 4, hipMemcpyDeviceToDevice, c.stream));
+  copy_between(c, dst.p, from, static_cast<const char*>(s.buf->p) + s.lo * words * 4, n * words * 4);
 }
-static void groth_pk_fill(Ctx& c, GrothPkObj& pk, PkSrc at, PkSrc b1, PkSrc b2, PkSrc cd, PkSrc pt) {
-  copy_slice(c, at, pk.n_w, kG1Aff, pk.at);
-  copy_slice(c, b1, pk.n_w, kG1Aff, pk.bacgamma1);
-  copy_slice(c, cd, pk.n_w, kG1Aff, pk.bacdelta);
-  copy_slice(c, pt, pk.n_h, kG1Aff, pk.ptd);
-  copy_slice(c, b2, pk.n_w, kG2Aff, pk.bacgamma2);
+static void groth_pk_fill(Ctx& c, Ctx& from, GrothPkObj& pk, PkSrc at, PkSrc b1, PkSrc b2, PkSrc cd, PkSrc pt) {
+  copy_slice(c, from, at, pk.n_w, kG1Aff, pk.at);
+  copy_slice(c, from, b1, pk.n_w, kG1Aff, pk.bacgamma1);
+  copy_slice(c, from, cd, pk.n_w, kG1Aff, pk.bacdelta);
+  copy_slice(c, from, pt, pk.n_h, kG1Aff, pk.ptd);
+  copy_slice(c, from, b2, pk.n_w, kG2Aff, pk.bacgamma2);
   // groth16.go:177-180 / :248: the C sum runs over i > NPublic; global entries [0, NPublic] of BACDelta become infinity
   const size_t zero_hi = std::min(pk.npublic + 1, pk.w_lo + pk.n_w);
   if (zero_hi > pk.w_lo) force_infinity(c, pk.bacdelta, zero_hi - pk.w_lo, kG1Aff);
@@ -646,7 +651,7 @@ static int groth_pk_create_impl(Ctx& c, gs_handle g1_at, gs_handle g1_bacgamma, 
                 shard_index, shard_count, at->n, b1->n, b2->n, cd->n);
   if (pt->n != pk->n_h)
     return fail(GS_ERR_SHAPE, "PowersTauDelta must have %zu points (total %zu, shard %zu of %zu), got %zu", pk->n_h, pk->nptd, shard_index, shard_count, pt->n);
-  groth_pk_fill(c, *pk, PkSrc{&at->buf, 0}, PkSrc{&b1->buf, 0}, PkSrc{&b2->buf, 0}, PkSrc{&cd->buf, 0}, PkSrc{&pt->buf, 0});
+  groth_pk_fill(c, c, *pk, PkSrc{&at->buf, 0}, PkSrc{&b1->buf, 0}, PkSrc{&b2->buf, 0}, PkSrc{&cd->buf, 0}, PkSrc{&pt->buf, 0});
   pk->alpha = g1_affine_from_jacobian_std(g1_alpha);
   pk->beta = g1_affine_from_jacobian_std(g1_beta);
   pk->delta = g1_affine_from_jacobian_std(g1_delta);
@@ -682,17 +687,29 @@ int gs_groth16_pk_create_shard(gs_handle g1_at, gs_handle g1_bacgamma, gs_handle
 // A slice of a resident full key (device-to-device copies): what each rank keeps when the full key was built or loaded
 // locally; the caller then frees the full key.  `c` is the context the slice is created on -- the key's own, or another
 // logical device's (gs_groth16_pk_shard_to: the copies then cross xGMI, or stay on the GPU when both share one).
-static int groth_pk_shard_impl(Ctx& c, GrothPkObj* full, size_t shard_index, size_t shard_count, gs_handle* out) {
+static int groth_pk_shard_impl(Ctx& c, Ctx& from, GrothPkObj* full, size_t shard_index, size_t shard_count, gs_handle* out) {
   if (!full || !out) return fail(GS_ERR_ARG, "gs_groth16_pk_shard: bad proving-key handle or null output");
   if (full->shard_count != 1) return fail(GS_ERR_ARG, "gs_groth16_pk_shard: the source key is itself a slice");
   if (shard_count == 0 || shard_index >= shard_count) return fail(GS_ERR_ARG, "gs_groth16_pk_shard: bad shard %zu of %zu", shard_index, shard_count);
   auto pk = std::make_unique<GrothPkObj>();
   pk->nvars = full->nvars; pk->npublic = full->npublic; pk->nz = full->nz; pk->nptd = full->nptd;
   set_shard(*pk, shard_index, shard_count);
-  groth_pk_fill(c, *pk, PkSrc{&full->at, pk->w_lo}, PkSrc{&full->bacgamma1, pk->w_lo}, PkSrc{&full->bacgamma2, pk->w_lo},
+  groth_pk_fill(c, from, *pk, PkSrc{&full->at, pk->w_lo}, PkSrc{&full->bacgamma1, pk->w_lo}, PkSrc{&full->bacgamma2, pk->w_lo},
                 PkSrc{&full->bacdelta, pk->w_lo}, PkSrc{&full->ptd, pk->h_lo});
+  if (full->n_eval) {                                   // the evaluation-basis array is cut like the other term ranges (its own split of [0, n))
+    Shard sh; sh.index = shard_index; sh.count = shard_count;
+    size_t lo, hi;
+    shard_range(full->n_eval, sh, lo, hi);
+    pk->n_eval = full->n_eval; pk->e_lo = lo; pk->n_e = hi - lo;
+    copy_slice(c, from, PkSrc{&full->ptd_eval, lo}, pk->n_e, kG1Aff, pk->ptd_eval);
+  }
   pk->alpha = full->alpha; pk->beta = full->beta; pk->delta = full->delta; pk->beta2 = full->beta2; pk->delta2 = full->delta2;
-  divisor_init(c, pk->z, full->z.b_std.as<uint32_t>(), full->nz);
+  {                                                     // Z travels with every slice
+    DevBuf zc(std::max<size_t>(full->nz, 1) * 32);
+    copy_between(c, zc.p, from, full->z.b_std.p, full->nz * 32);
+    divisor_init(c, pk->z, zc.as<uint32_t>(), full->nz);
+    GS_HIP(hipStreamSynchronize(c.stream));             // `zc` is released here
+  }
   GS_HIP(hipStreamSynchronize(c.stream));
   *out = c.put(std::move(pk));
   return GS_OK;
@@ -700,13 +717,13 @@ static int groth_pk_shard_impl(Ctx& c, GrothPkObj* full, size_t shard_index, siz
 
 int gs_groth16_pk_shard(gs_handle hfull, size_t shard_index, size_t shard_count, gs_handle* out) {
   return guarded([&](Ctx& c) -> int {
-    return groth_pk_shard_impl(c, c.get<GrothPkObj>(hfull, Kind::GrothPk), shard_index, shard_count, out);
+    return groth_pk_shard_impl(c, c, c.get<GrothPkObj>(hfull, Kind::GrothPk), shard_index, shard_count, out);
   }, true, false, hfull);
 }
 
 int gs_groth16_pk_shard_to(gs_handle hfull, size_t shard_index, size_t shard_count, int target_device, gs_handle* out) {
   return guarded_pair(hfull, target_device, [&](Ctx& src, Ctx& dst) -> int {
-    return groth_pk_shard_impl(dst, src.get<GrothPkObj>(hfull, Kind::GrothPk), shard_index, shard_count, out);
+    return groth_pk_shard_impl(dst, src, src.get<GrothPkObj>(hfull, Kind::GrothPk), shard_index, shard_count, out);
   });
 }
 
@@ -799,6 +816,83 @@ int gs_groth16_prove_partials(gs_handle hpk, gs_handle hw, gs_handle hpx, size_t
     GrothSums sums;
     Shard sh; sh.index = shard_index; sh.count = shard_count;
     const int rc = groth16_sums_impl(c, pk, DevScalars{w->buf.as<uint32_t>(), w->n}, DevScalars{px->buf.as<uint32_t>(), px->n}, sh, sums);
+    if (rc != GS_OK) return rc;
+    inf[0] = g1_to_affine_std(sums.at, out_sums) ? 1 : 0;
+    inf[1] = g1_to_affine_std(sums.bacgamma1, out_sums + 8) ? 1 : 0;
+    inf[2] = g2_to_affine_std(sums.bacgamma2, out_sums + 16) ? 1 : 0;
+    inf[3] = g1_to_affine_std(sums.bacdelta, out_sums + 32) ? 1 : 0;
+    inf[4] = g1_to_affine_std(sums.h, out_sums + 40) ? 1 : 0;
+    return GS_OK;
+  }, true, false, hpk);
+}
+
+static void r1cs_values_dev(Ctx& c, R1csObj& o, const uint32_t* w_dev);
+static bool hx_shape(size_t n, size_t nz);
+// Strong scaling without a replicated polynomial stage ("run on GPU 0 and broadcast hx shards"), in two
+// entry points.  gs_groth16_witness_values: ONE rank (the proof's owner; with a stream of proofs the ranks take turns) turns the
+// resident witness into the n values H(n+1..2n) -- the whole polynomial stage of the evaluation-basis route -- as a resident scalar
+// vector (*hv_inout as gs_r1cs_px's px_inout); *violated = number of roots of Z at which the witness breaks a constraint (the values are
+// then meaningless: take gs_r1cs_px + gs_groth16_prove_partials).  The owner scatters slice k of the vector to rank k
+// (gs_scalars_clone between the logical devices of one process, gs_scalars_scatter over RCCL between processes), and ...
+int gs_groth16_witness_values(gs_handle hpk, gs_handle hr1cs, gs_handle hw, gs_handle* hv_inout, uint32_t* violated) {
+  return guarded([&](Ctx& c) -> int {
+    GrothPkObj* pk = c.get<GrothPkObj>(hpk, Kind::GrothPk);
+    R1csObj* o = c.get<R1csObj>(hr1cs, Kind::R1cs);
+    Scalars* w = c.get<Scalars>(hw, Kind::Scalars);
+    if (!pk || !o || !w || !hv_inout || !violated) return fail(GS_ERR_ARG, "gs_groth16_witness_values: bad handle or null output");
+    if (w->n != o->m) return fail(GS_ERR_SHAPE, "len(w) = %zu but the system has %zu variables", w->n, o->m);
+    if (!hx_shape(o->n, pk->nz) || pk->n_eval != o->n)
+      return fail(GS_ERR_SHAPE, "gs_groth16_witness_values: the key has no evaluation-basis array for a system of %zu constraints", o->n);
+    Scalars* hv = nullptr;
+    if (*hv_inout) {
+      hv = c.get<Scalars>(*hv_inout, Kind::Scalars);
+      if (!hv || hv->n != o->n) return fail(GS_ERR_ARG, "gs_groth16_witness_values: the output handle does not hold n = %zu values", o->n);
+    } else {
+      auto fresh = std::make_unique<Scalars>();
+      fresh->n = o->n;
+      fresh->buf.alloc(o->n * 32);
+      hv = fresh.get();
+      *hv_inout = c.put(std::move(fresh));
+    }
+    StreamScope sc(c, c.aux_stream[1]);             // the stream that carries every proof's polynomial stage (gs_r1cs_px)
+    PhaseTimer t(c.stream);
+    ProveState& ps = prove_state(c);
+    uint32_t* bad = ps.bad_dev.as<uint32_t>() + Ctx::kBlockingSlot;
+    r1cs_values_dev(c, *o, w->buf.as<uint32_t>());
+    r1cs_check_dev(c, o->vals.as<uint32_t>(), o->n, pk->nz - 1, bad);
+    hx_values_dev(c, o->vals.as<uint32_t>(), o->n, pk->nz - 1, hv->buf.as<uint32_t>());
+    GS_HIP(hipMemcpyAsync(ps.bad_host + Ctx::kBlockingSlot, bad, 4, hipMemcpyDeviceToHost, c.stream));
+    t.stop();
+    GS_HIP(hipStreamSynchronize(c.stream));
+    *violated = ps.bad_host[Ctx::kBlockingSlot];
+    if (!c.any_inflight()) reset_timing(c);
+    c.timing.poly_ms = t.ms();
+    c.timing.total_ms = c.timing.poly_ms;
+    return GS_OK;
+  }, true, true, hpk);
+}
+
+// ... every rank sums its term ranges: the four sums over its slice of w as gs_groth16_prove_partials does, the fifth over ITS slice
+// of H's values (`hv_slice`: the n_e values of the key slice's evaluation-basis range) -- no polynomial work at all on this rank.
+int gs_groth16_prove_partials_values(gs_handle hpk, gs_handle hw, gs_handle hv_slice, size_t shard_index, size_t shard_count,
+                                     uint64_t out_sums[48], int inf[5]) {
+  return guarded([&](Ctx& c) -> int {
+    GrothPkObj* pk = c.get<GrothPkObj>(hpk, Kind::GrothPk);
+    Scalars* w = c.get<Scalars>(hw, Kind::Scalars);
+    Scalars* hv = c.get<Scalars>(hv_slice, Kind::Scalars);
+    if (!pk || !w || !hv) return fail(GS_ERR_ARG, "gs_groth16_prove_partials_values: bad handle");
+    if (!out_sums || !inf || shard_count == 0 || shard_index >= shard_count) return fail(GS_ERR_ARG, "gs_groth16_prove_partials_values: bad shard or null output");
+    if (pk->n_eval == 0) return fail(GS_ERR_SHAPE, "gs_groth16_prove_partials_values: the key has no evaluation-basis array");
+    Shard sh; sh.index = shard_index; sh.count = shard_count;
+    size_t lo, hi;
+    if (pk->shard_count > 1) { lo = pk->e_lo; hi = pk->e_lo + pk->n_e; } else shard_range(pk->n_eval, sh, lo, hi);
+    if (hv->n != hi - lo) return fail(GS_ERR_SHAPE, "gs_groth16_prove_partials_values: shard %zu of %zu covers %zu of the %zu values, the vector holds %zu",
+                                      shard_index, shard_count, hi - lo, pk->n_eval, hv->n);
+    reset_timing(c);
+    GrothSums sums;
+    DevScalars dh{nullptr, 0};
+    dh.hv_slice = hv->buf.as<uint32_t>();
+    const int rc = groth16_sums_impl(c, pk, DevScalars{w->buf.as<uint32_t>(), w->n}, dh, sh, sums);
     if (rc != GS_OK) return rc;
     inf[0] = g1_to_affine_std(sums.at, out_sums) ? 1 : 0;
     inf[1] = g1_to_affine_std(sums.bacgamma1, out_sums + 8) ? 1 : 0;

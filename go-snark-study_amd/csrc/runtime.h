@@ -122,6 +122,12 @@ constexpr int kHandleDevShift = 56;
 constexpr int kMaxLogicalDevices = 64;
 inline int handle_device(gs_handle h) { return (int)(h >> kHandleDevShift); }
 
+// Handle and ticket numbers are unique for the LIFETIME OF THE PROCESS, not of a gs_init session: after gs_shutdown + gs_init a
+// stale handle of the earlier session (a Python object's destructor, a cached Go key) must fail with GS_ERR_ARG, never alias -- and
+// gs_free -- an object of the new session.
+inline std::atomic<uint64_t>& handle_counter() { static std::atomic<uint64_t> v{1}; return v; }
+inline std::atomic<uint64_t>& ticket_counter() { static std::atomic<uint64_t> v{1}; return v; }
+
 struct Ctx {
   int logical = 0;                // index in gs_init's device list (several entries may name the same physical device)
   int device = -1;                // HIP ordinal
@@ -142,7 +148,6 @@ struct Ctx {
   hipEvent_t stage_ev[kStageBuffers] = {};
   hipStream_t copy_stream = nullptr;                 // gs_scalars_upload (lazy)
   std::unique_ptr<InFlightBase> inflight[kMaxInFlight];
-  uint64_t next_ticket = 1;
   // Consecutive pipelined operations swap the two tail streams: the reduction tails are chains of dependent point additions
   // (latency, not throughput), so the tails of operation k + 1 may run beside those of operation k instead of queueing behind
   // them -- at 2^16 the G2 tail (1.2 ms) was longer than the accumulations of a whole proof (0.9 ms) and set the pace.
@@ -153,12 +158,11 @@ struct Ctx {
     if (mode == 1 || (mode == 2 && n <= kTailFlipMaxTerms)) tail_flip ^= 1u;
   }
   static constexpr uint32_t kTailFlipMaxTerms = 1u << 18;
-  uint64_t new_ticket() { return ((uint64_t)logical << kHandleDevShift) | next_ticket++; }
+  uint64_t new_ticket() { return ((uint64_t)logical << kHandleDevShift) | ticket_counter()++; }
   int free_parity() const { for (int p = 0; p < kMaxInFlight; ++p) if (!inflight[p]) return p; return -1; }
   bool any_inflight() const { for (int p = 0; p < kMaxInFlight; ++p) if (inflight[p]) return true; return false; }
   static constexpr size_t kPinnedBytes = 256 * 1024;
   std::mutex mu;
-  uint64_t next_handle = 1;
   std::unordered_map<uint64_t, std::shared_ptr<Object>> objs;     // in-flight operations hold references: gs_free defers
   int window_bits = 0;           // 0 = auto
   bool eval_basis = true;        // gs_set_eval_basis: witness route over H's values when the key has an evaluation-basis array
@@ -185,7 +189,7 @@ struct Ctx {
     return std::static_pointer_cast<O>(it->second);
   }
   gs_handle put(std::shared_ptr<Object> o) {
-    uint64_t h = ((uint64_t)logical << kHandleDevShift) | next_handle++;
+    uint64_t h = ((uint64_t)logical << kHandleDevShift) | handle_counter()++;
     objs[h] = std::move(o);
     return h;
   }
@@ -202,10 +206,13 @@ struct Ctx {
 };
 
 // ---- the contexts of this process: one per entry of gs_init's device list ------------------------------------------
+// `mu` guards the vector (gs_init / gs_shutdown write it).  Entry points copy the shared_ptr of their context under `mu` and hold it
+// for the duration of the call, so a concurrent gs_shutdown can neither free a context under a running call nor race with the
+// lookup: the call then finds ready = false under the context's own lock.  Lock order: Registry::mu before Ctx::mu, and never
+// Registry::mu while holding a Ctx::mu.
 struct Registry {
-  std::mutex mu;                                  // guards `ctxs` (gs_init / gs_shutdown)
-  std::vector<std::unique_ptr<Ctx>> ctxs;
-  Ctx none;                                       // what the entry points see before gs_init (ready = false)
+  std::mutex mu;
+  std::vector<std::shared_ptr<Ctx>> ctxs;
 };
 inline Registry& registry() {
   static Registry r;
@@ -216,12 +223,19 @@ inline int& current_logical() {
   static thread_local int v = 0;
   return v;
 }
-inline Ctx& ctx_at(int logical) {
+// the context of a logical device, or null; *count (optional) = number of logical devices
+inline std::shared_ptr<Ctx> ctx_ref(int logical, size_t* count = nullptr) {
   Registry& r = registry();
-  if (logical < 0 || (size_t)logical >= r.ctxs.size()) return r.none;
-  return *r.ctxs[logical];
+  std::lock_guard<std::mutex> lk(r.mu);
+  if (count) *count = r.ctxs.size();
+  if (logical < 0 || (size_t)logical >= r.ctxs.size()) return nullptr;
+  return r.ctxs[logical];
 }
-inline Ctx& ctx() { return ctx_at(current_logical()); }
+inline size_t logical_device_count() {
+  Registry& r = registry();
+  std::lock_guard<std::mutex> lk(r.mu);
+  return r.ctxs.size();
+}
 
 // Every entry point: pick the context (the one `route` lives on when a handle is given, else the calling thread's current
 // logical device), lock it, check init, translate exceptions into status codes.
@@ -229,11 +243,15 @@ inline Ctx& ctx() { return ctx_at(current_logical()); }
 // (it QUEUES behind them; their results stay in their own pinned slots until gs_*_end collects them).
 template <class F>
 int guarded(F&& f, bool need_init = true, bool allow_inflight = false, gs_handle route = 0) {
-  Ctx& c = route ? ctx_at(handle_device(route)) : ctx();
+  size_t ndev = 0;
+  const int logical = route ? handle_device(route) : current_logical();
+  std::shared_ptr<Ctx> pc = ctx_ref(logical, &ndev);
+  static Ctx none;                                // what an entry point sees before gs_init (ready = false); only its lock is used
+  Ctx& c = pc ? *pc : none;
   std::lock_guard<std::mutex> lk(c.mu);
   if (need_init && !c.ready) {
-    if (registry().ctxs.empty()) return fail(GS_ERR_NOT_INIT, "gs_init has not been called (or failed)");
-    return fail(GS_ERR_ARG, "no logical device %d (gs_init listed %zu)", route ? handle_device(route) : current_logical(), registry().ctxs.size());
+    if (ndev == 0) return fail(GS_ERR_NOT_INIT, "gs_init has not been called (or failed)");
+    return fail(GS_ERR_ARG, "no logical device %d (gs_init listed %zu)", logical, ndev);
   }
   // the HIP current device is per host thread: callers (goroutines, worker threads) may arrive on any thread
   if (c.ready) (void)hipSetDevice(c.device);
@@ -254,13 +272,16 @@ inline void reset_timing(Ctx& c) { c.timing = gs_timing{}; }
 // (std::lock: no ordering deadlock), the source drained, the HIP current device set to the target's.
 template <class F>
 int guarded_pair(gs_handle route, int target, F&& f) {
-  if (registry().ctxs.empty()) return fail(GS_ERR_NOT_INIT, "gs_init has not been called (or failed)");
-  Ctx& src = ctx_at(handle_device(route));
-  Ctx& dst = ctx_at(target);
-  if (!src.ready) return fail(GS_ERR_ARG, "bad handle (no logical device %d)", handle_device(route));
-  if (!dst.ready) return fail(GS_ERR_ARG, "no logical device %d (gs_init listed %zu)", target, registry().ctxs.size());
+  size_t ndev = 0;
+  std::shared_ptr<Ctx> ps = ctx_ref(handle_device(route), &ndev), pd = ctx_ref(target);
+  if (ndev == 0) return fail(GS_ERR_NOT_INIT, "gs_init has not been called (or failed)");
+  if (!ps) return fail(GS_ERR_ARG, "bad handle (no logical device %d)", handle_device(route));
+  if (!pd) return fail(GS_ERR_ARG, "no logical device %d (gs_init listed %zu)", target, ndev);
+  Ctx& src = *ps;
+  Ctx& dst = *pd;
   std::unique_lock<std::mutex> l1(src.mu, std::defer_lock), l2(dst.mu, std::defer_lock);
   if (&src == &dst) l1.lock(); else std::lock(l1, l2);
+  if (!src.ready || !dst.ready) return fail(GS_ERR_NOT_INIT, "the library was shut down");
   try {
     (void)hipSetDevice(src.device);
     src.drain();
@@ -274,6 +295,15 @@ int guarded_pair(gs_handle route, int target, F&& f) {
   } catch (const std::exception& e) {
     return fail(GS_ERR_ARG, "%s", e.what());
   }
+}
+
+// Device-to-device copy between two contexts (key slices, clones).  Same physical GPU: a plain copy; different GPUs:
+// hipMemcpyPeerAsync, which is correct with or without peer access (gs_init enables it where the driver allows; without it the
+// runtime stages through the host) -- a plain hipMemcpyDeviceToDevice between devices without peer access is unspecified.
+inline void copy_between(Ctx& dst, void* d, const Ctx& src, const void* s, size_t bytes) {
+  if (!bytes) return;
+  if (dst.device == src.device) GS_HIP(hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToDevice, dst.stream));
+  else GS_HIP(hipMemcpyPeerAsync(d, dst.device, s, src.device, bytes, dst.stream));
 }
 
 // run a section of engine calls on another stream of the context

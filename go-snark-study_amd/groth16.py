@@ -344,6 +344,66 @@ def prove_multi(dev_pks, w_handles, px_handles, r, s):
     return _proof_from_words(out, inf), bool(used.value)
 
 
+def witness_values(dev_pk, dev_r1cs, w_handle, hv_handle=None):
+    """The proof owner's polynomial stage (gs_groth16_witness_values): resident sparse R1CS + witness -> the n values H(n+1..2n) as a
+    resident scalar vector.  Returns (hv_handle, violated); violated != 0 means the witness breaks a constraint and the values are void."""
+    import ctypes
+    h = capi.Handle(hv_handle.h if hv_handle is not None else 0)
+    bad = ctypes.c_uint32(0)
+    capi.check(capi.load_library().gs_groth16_witness_values(capi.Handle(dev_pk.handle.h), capi.Handle(dev_r1cs.handle.h), capi.Handle(w_handle.h),
+                                                             ctypes.byref(h), ctypes.byref(bad)))
+    return (hv_handle if hv_handle is not None else capi.DeviceHandle(h.value)), int(bad.value)
+
+
+def prove_partials_values(dev_pk, w_handle, hv_slice, shard_index, shard_count):
+    """gs_groth16_prove_partials_values: this rank's five sums, the fifth over its slice of H's values (no polynomial work here)."""
+    import ctypes
+    out = np.zeros(48, dtype=np.uint64)
+    inf = (ctypes.c_int * 5)()
+    capi.check(capi.load_library().gs_groth16_prove_partials_values(capi.Handle(dev_pk.handle.h), capi.Handle(w_handle.h), capi.Handle(hv_slice.h),
+                                                                    shard_index, shard_count, capi.ptr64(out), inf))
+    v = capi.u64_to_ints(out)
+    pts = [None if inf[0] else (v[0], v[1]), None if inf[1] else (v[2], v[3]),
+           None if inf[2] else ((v[4], v[5]), (v[6], v[7])), None if inf[3] else (v[8], v[9]), None if inf[4] else (v[10], v[11])]
+    return pts, SUM_IS_G2
+
+
+def scatter_values(hv_handle, ndev):
+    """The owner's scatter between the logical devices of this process: slice d of the contiguous split of H's values -> device d."""
+    n = len(hv_handle)
+    out = []
+    for d in range(ndev):
+        lo, hi = _shard_range(n, ndev, d)
+        out.append(capi.scalars_clone(hv_handle, d, lo, hi - lo))
+    return out
+
+
+def prove_multi_values(dev_pks, w_handles, hv_slices, r, s):
+    """One proof over the logical devices of this process with the polynomial stage done ONCE (gs_groth16_prove_multi_values):
+    hv_slices[d] = device d's slice of H's values (scatter_values).  Returns (Proof, used_rccl)."""
+    import ctypes
+    out = np.zeros(32, dtype=np.uint64)
+    inf = (ctypes.c_int * 3)()
+    used = ctypes.c_int(0)
+    rs = capi.ints_to_u64([r % R, s % R])
+    capi.check(capi.load_library().gs_groth16_prove_multi_values(capi._harr([k.handle for k in dev_pks]), capi._harr(w_handles), capi._harr(hv_slices),
+                                                                 len(dev_pks), capi.ptr64(rs[0]), capi.ptr64(rs[1]), capi.ptr64(out), inf,
+                                                                 ctypes.byref(used)))
+    return _proof_from_words(out, inf), bool(used.value)
+
+
+def prove_sharded_values_rccl(dev_pk, w_handle, hv_slice, r, s):
+    """One process per GPU, values route (gs_groth16_prove_sharded_values): this rank's slice of H's values came from the owner
+    through capi.scalars_scatter; the 416-byte records are gathered inside the library."""
+    import ctypes
+    out = np.zeros(32, dtype=np.uint64)
+    inf = (ctypes.c_int * 3)()
+    rs = capi.ints_to_u64([r % R, s % R])
+    capi.check(capi.load_library().gs_groth16_prove_sharded_values(capi.Handle(dev_pk.handle.h), capi.Handle(w_handle.h), capi.Handle(hv_slice.h),
+                                                                   capi.ptr64(rs[0]), capi.ptr64(rs[1]), capi.ptr64(out), inf))
+    return _proof_from_words(out, inf)
+
+
 def prove_sharded_rccl(dev_pk, w_handle, px_handle, r, s):
     """One process per GPU, gathered INSIDE the library over the communicator of capi.comm_init_rank
     (gs_groth16_prove_sharded).  Every rank returns the same Proof."""

@@ -231,6 +231,9 @@ int gs_groth16_prove_witness_begin(gs_handle pk, gs_handle r1cs, gs_handle w, co
  * gs_free'd -- they are released when the ticket has been collected. */
 int gs_groth16_prove_begin(gs_handle pk, gs_handle w, gs_handle px, const uint64_t r[4], const uint64_t s[4], uint64_t* ticket);
 int gs_groth16_prove_end(uint64_t ticket, uint64_t out_proof[32], int inf[3]);
+/* Abandon a ticket of any kind (proof or MSM) without collecting its result: waits for its device work, frees its slot and the
+ * references it holds.  An error path that cannot call the matching _end must call this, or the slot stays occupied. */
+int gs_ticket_cancel(uint64_t ticket);
 
 /* One proof over several GPUs: every rank holds the key (or just its slice of it, below) and the resident w / px, takes shard `shard_index` of
  * `shard_count` of the term ranges (contiguous, first ranges one longer when they do not divide), computes H(x) locally
@@ -350,6 +353,22 @@ int gs_groth16_prove_multi(const gs_handle* pk, const gs_handle* w, const gs_han
  * library; every rank returns the complete result.  pk is the full key or this rank's slice; bases / scalars hold this
  * rank's shard of the term range. */
 int gs_groth16_prove_sharded(gs_handle pk, gs_handle w, gs_handle px, const uint64_t r[4], const uint64_t s[4], uint64_t out_proof[32], int inf[3]);
+/* Strong scaling WITHOUT a replicated polynomial stage ("run on GPU 0 and broadcast hx shards"), for keys with an
+ * evaluation-basis array (gs_groth16_pk_set_eval; slices carry their share of it).  Per proof ONE rank -- the owner; over a stream of
+ * proofs the ranks take turns -- runs gs_groth16_witness_values: resident sparse R1CS + witness -> the n values H(n+1), ..., H(2n)
+ * as a resident scalar vector (*hv_inout: 0 = create; *violated = number of roots of Z at which the witness breaks a constraint: the
+ * values are then meaningless and the proof must take gs_r1cs_px + the px entry points).  The owner scatters the vector -- slice k
+ * of the contiguous split to rank k: gs_scalars_clone between the logical devices of one process, gs_scalars_scatter (ncclSend /
+ * ncclRecv, one group) between processes -- and every rank sums ONLY its term ranges: gs_groth16_prove_partials_values (four sums
+ * over its slice of w, the fifth over its slice of the values; record layout of gs_groth16_prove_partials), wrapped with the
+ * exchange and the tail by gs_groth16_prove_multi_values / gs_groth16_prove_sharded_values.  Same proof as every other route. */
+int gs_groth16_witness_values(gs_handle pk, gs_handle r1cs, gs_handle w, gs_handle* hv_inout, uint32_t* violated);
+int gs_groth16_prove_partials_values(gs_handle pk, gs_handle w, gs_handle hv_slice, size_t shard_index, size_t shard_count,
+                                     uint64_t out_sums[48], int inf[5]);
+int gs_groth16_prove_multi_values(const gs_handle* pk, const gs_handle* w, const gs_handle* hv_slices, int ndev, const uint64_t r[4], const uint64_t s[4],
+                                  uint64_t out_proof[32], int inf[3], int* used_rccl);
+int gs_groth16_prove_sharded_values(gs_handle pk, gs_handle w, gs_handle hv_slice, const uint64_t r[4], const uint64_t s[4], uint64_t out_proof[32], int inf[3]);
+int gs_scalars_scatter(gs_handle full_on_root, size_t total, int root, gs_handle* slice_inout);
 int gs_msm_g1_sharded(gs_handle bases, gs_handle scalars, uint64_t out_affine[8], int* is_inf);
 int gs_msm_g2_sharded(gs_handle bases, gs_handle scalars, uint64_t out_affine[16], int* is_inf);
 /* A batch of independent proofs (configs[4]; no collective): proof i reads w[i] / px[i], runs on the logical device those

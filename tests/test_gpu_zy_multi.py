@@ -131,6 +131,65 @@ def test_one_process_per_gpu_gather_inside_the_library_world_1(inst):
     capi.comm_destroy()
 
 
+@pytest.mark.parametrize("n", [2, 3, 8])
+def test_values_route_polynomial_stage_on_one_owner_then_scattered(inst, n):
+    """strong scaling without the replicated H(x).  The proof's owner (they take turns: owner = proof index mod n)
+    turns the witness into H's n values ONCE (gs_groth16_witness_values), scatters slice d to logical device d, and every device sums
+    only its term ranges (gs_groth16_prove_multi_values): the single-device proof, with key slices that carry their share of the
+    evaluation-basis array.  A violated constraint is reported by the owner instead of producing values."""
+    from gosnark_amd import r1csqap
+    capi.comm_destroy()
+    full = inst.device_pk()
+    assert capi.pk_eval_count(full.handle) == inst.n
+    pks = [groth16.ShardPkTo(full, d, n, d) for d in range(n)]
+    assert sum(capi.pk_eval_count(k.handle) for k in pks) == inst.n
+    ws = [capi.scalars_clone(inst.w, d) for d in range(n)]
+    for proof in range(3):
+        owner = proof % n
+        r, s = synth.field_elems(2, 500 + 10 * n + proof)
+        want = groth16.prove_resident(full, inst.w, inst.px, r, s)
+        capi.set_device(owner)
+        try:
+            dev = r1csqap.DeviceR1CS(*inst.r1cs, inst.m)          # the owner needs the sparse system (every rank keeps it: they rotate)
+        finally:
+            capi.set_device(0)
+        hv, bad = groth16.witness_values(pks[owner], dev, ws[owner])
+        assert bad == 0 and len(hv) == inst.n and capi.handle_device(hv) == owner
+        slices = groth16.scatter_values(hv, n)
+        got, used = groth16.prove_multi_values(pks, ws, slices, r, s)
+        assert _same(got, want) and used is False
+        if proof == 0:                                            # ... and piecewise, as one process per GPU would
+            parts = [groth16.prove_partials_values(pks[d], ws[d], slices[d], d, n)[0] for d in range(n)]
+            combined = [capi.sum_affine([parts[k][i] for k in range(n)], g2=g2) for i, g2 in enumerate(groth16.SUM_IS_G2)]
+            assert _same(groth16.finish(pks[0], combined, r, s), want)
+            with pytest.raises(capi.GosnarkHipError, match="covers"):
+                groth16.prove_partials_values(pks[0], ws[0], capi.scalars_clone(hv, 0), 0, n)       # all n values where a slice belongs
+    w_bad = inst.w_host.copy()
+    w_bad[5] = (4242, 0, 0, 0)
+    _, bad = groth16.witness_values(pks[0], r1csqap.DeviceR1CS(*inst.r1cs, inst.m), capi.scalars_upload(w_bad))
+    assert bad > 0
+
+
+def test_values_route_one_process_per_gpu_world_1(inst):
+    """The rank-mode entry points of the values route at world size 1: gs_scalars_scatter (ncclSend / ncclRecv group, here only the
+    root's own copy) and gs_groth16_prove_sharded_values (record gather through the 1-rank communicator)."""
+    from gosnark_amd import r1csqap
+    capi.comm_destroy()
+    capi.set_device(0)
+    capi.comm_init_rank(capi.comm_unique_id(), 1, 0)
+    before = capi.comm_info()["collectives"]
+    r, s = synth.field_elems(2, 321)
+    want = groth16.prove_resident(inst.device_pk(), inst.w, inst.px, r, s)
+    hv, bad = groth16.witness_values(inst.device_pk(), r1csqap.DeviceR1CS(*inst.r1cs, inst.m), inst.w)
+    assert bad == 0
+    mine = capi.scalars_scatter(hv, inst.n, 0)
+    assert len(mine) == inst.n and np.array_equal(capi.scalars_download(mine), capi.scalars_download(hv))
+    got = groth16.prove_sharded_values_rccl(inst.device_pk(), inst.w, mine, r, s)
+    assert _same(got, want)
+    assert capi.comm_info()["collectives"] == before + 2
+    capi.comm_destroy()
+
+
 def test_torch_distributed_nccl_branch_runs_at_world_1(inst, monkeypatch):
     """parallel.allgather_points over torch.distributed's nccl (= RCCL) backend, forced at world size 1."""
     import torch
