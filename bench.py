@@ -159,6 +159,27 @@ def pipelined(begin, end, count, depth, on_done=None):
             on_done()
 
 
+def build_stamp():
+    """Which library this line was measured with: gs_version() (carries the compile flags) + the source commit recorded by
+    __graft_entry__.build() next to the library (the GPU box has no .git)."""
+    import hashlib
+    stamp = {"library": capi.version()}
+    try:
+        lib = os.environ.get("GS_LIB") or os.path.join(ROOT, "go-snark-study_amd", "libgosnark_hip.so")
+        sha = hashlib.sha256(open(lib, "rb").read()).hexdigest()
+        with open(os.path.join(ROOT, "go-snark-study_amd", "BUILD_INFO.json")) as f:
+            info = json.load(f)
+        if info.get("lib_sha256") == sha:
+            stamp["source_commit"] = info.get("commit")
+            if info.get("sources_modified_since_commit"):
+                stamp["sources_modified_since_commit"] = info["sources_modified_since_commit"]
+        else:
+            stamp["source_commit"] = "stale: the library was rebuilt after BUILD_INFO.json was written"
+    except (OSError, ValueError):
+        stamp["source_commit"] = None
+    return stamp
+
+
 def time_calls(fn, count):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -661,6 +682,7 @@ def main():
                              "per peer, one ncclSend per xGMI link in one group) runs on the communicator's stream beside the sums and is not priced.  NOT measured: "
                              "no multi-GPU hardware is reachable from this run." % (tail_ms, vr["scatter_payload_bytes_per_peer"])}
             out["sharding"] = shard_info
+        out["build"] = build_stamp()
         for k, v in extras.items():
             out[k] = v
         if proof_verified:

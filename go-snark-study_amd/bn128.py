@@ -4,6 +4,7 @@ Points are Jacobian tuples of Python ints exactly like the reference's [3]*big.I
 [3][2]*big.Int; results come back in the affine normal form [x, y, 1]."""
 from . import capi
 
+Q = 21888242871839275222246405745257275088696311157297823662689037894645226208583      # bn128.go:40-45
 G1_ZERO = (0, 0, 0)
 G2_ZERO = ((0, 0), (0, 0), (0, 0))
 
@@ -36,6 +37,25 @@ class _Group:
     def Affine(self, p):                     # g1.go:157-170 / g2.go:183-200
         q = self.MSM([p], [1])
         return None if q == self._jac(None) else (q[0], q[1])
+
+    def IsZero(self, p):                     # g1.go:28-30 / g2.go:28-30: only Z is tested
+        return p[2] == (0, 0) if self.g2 else p[2] == 0
+
+    def Neg(self, p):                        # g1.go:91-96 / g2.go:91-97: (X, -Y, Z) -- a sign flip, no field product: host side
+        if self.g2:
+            return (p[0], ((-p[1][0]) % Q, (-p[1][1]) % Q), p[2])
+        return (p[0], (-p[1]) % Q, p[2])
+
+    def Sub(self, a, b):                     # g1.go:98-100 / g2.go:99-101
+        return self.Add(a, self.Neg(b))
+
+    def Double(self, p):                     # g1.go:101-138 / g2.go:103-140: the complete addition doubles (device: xyzz_dbl_affine)
+        return self.Add(p, p)
+
+    def Equal(self, p1, p2):                 # g1.go:172-193 / g2.go:202-223, on the affine normal form
+        if self.IsZero(p1) or self.IsZero(p2):
+            return self.IsZero(p1) and self.IsZero(p2)
+        return self.Affine(p1) == self.Affine(p2)
 
 
 G1 = _Group(False)

@@ -224,7 +224,10 @@ int sum_affine(const uint64_t* pts, const int* inf, size_t n, uint64_t* out, int
 
 extern "C" {
 
-const char* gs_version(void) { return "gosnark-hip 0.1 gfx950 (9x29-bit Montgomery, XYZZ Pippenger)"; }
+#ifndef GS_BUILD_FLAGS
+#define GS_BUILD_FLAGS "unknown"
+#endif
+const char* gs_version(void) { return "gosnark-hip 0.3 gfx950 (9x29-bit Montgomery, XYZZ Pippenger, evaluation-basis keys); built with " GS_BUILD_FLAGS; }
 const char* gs_last_error(void) { return last_error_ref().c_str(); }
 
 // One context per entry of `devices` (a "logical device": its own streams, workspaces, handle table and lock).  The same

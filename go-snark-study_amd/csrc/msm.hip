@@ -109,7 +109,7 @@ void build_plan(Ctx& c, int slot, const uint32_t* scalars_dev, uint32_t n, MsmPl
   pb.offsets.ensure(ncount * 4);
   pb.entries.ensure(((size_t)plan.maxchunks + 1) * plan.chunk * 4);
   pb.chunk_bucket.ensure((size_t)plan.maxchunks * 4);
-  pb.heavy_list.ensure((size_t)kMaxHeavy * 4);
+  pb.heavy_list.ensure((size_t)plan.nbuckets * 4);         // one slot per bucket: the list cannot overflow
   pb.counters.ensure(16);
   const size_t lds = (size_t)std::min<uint32_t>(plan.B, kRangeBuckets) * 4;
   static const int sort_block = getenv("GS_SORT_BLOCK") ? std::max(64, std::min(kSortBlock, atoi(getenv("GS_SORT_BLOCK")))) : kSortBlock;

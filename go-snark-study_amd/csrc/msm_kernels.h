@@ -337,7 +337,8 @@ __global__ void __launch_bounds__(kScanBlock) k_scan_add(uint32_t* __restrict__ 
 // chunk_bucket[t] = bucket holding entry t*chunk.  Buckets cut into more than kHeavySpan + 1 pieces are listed
 // for a block-wide tree combine (k_heavy_combine), the others are combined by whoever reads them.
 constexpr uint32_t kHeavySpan = 64;
-constexpr uint32_t kMaxHeavy = 1u << 16;
+// (The heavy list has one slot per BUCKET -- a bucket is listed at most once -- so it cannot overflow; round 2's fixed cap of 2^16
+// entries silently dropped buckets beyond it at c >= 18.)
 
 __global__ void __launch_bounds__(256) k_chunk_map(const uint32_t* __restrict__ offsets, uint32_t nbuckets, uint32_t chunk,
                                                     uint32_t* __restrict__ chunk_bucket, uint32_t* __restrict__ heavy_list,
@@ -349,8 +350,7 @@ __global__ void __launch_bounds__(256) k_chunk_map(const uint32_t* __restrict__ 
   const uint32_t t0 = (o0 + chunk - 1) / chunk, t1 = (o1 + chunk - 1) / chunk;   // chunks starting inside [o0, o1)
   for (uint32_t t = t0; t < t1; ++t) chunk_bucket[t] = b;
   if ((o1 - 1) / chunk - o0 / chunk > kHeavySpan) {
-    const uint32_t slot = atomicAdd(heavy_count, 1u);
-    if (slot < kMaxHeavy) heavy_list[slot] = b;
+    heavy_list[atomicAdd(heavy_count, 1u)] = b;          // < nbuckets slots are ever taken
   }
 }
 
@@ -475,7 +475,7 @@ __global__ void __launch_bounds__(kHeavyBlock, GS_TAIL_WAVES) k_heavy_combine(Ac
   constexpr int pw = PointIO<T>::kXyzzWords;
   __shared__ uint32_t sh[kHeavyBlock * pw];
   const AccJob job = jobs.j[blockIdx.y];
-  const uint32_t nheavy = min(*heavy_count, kMaxHeavy);
+  const uint32_t nheavy = *heavy_count;
   for (uint32_t h = blockIdx.x; h < nheavy; h += gridDim.x) {
     const uint32_t b = heavy_list[h];
     const uint32_t tf = offsets[b] / chunk, tl = (offsets[b + 1] - 1) / chunk;

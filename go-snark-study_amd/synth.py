@@ -115,6 +115,16 @@ def quotient_instance(n, seed):
     return QuotientInstance(n, seed)
 
 
+def sqchain_witness(n, x, extra_vars=0):
+    """The satisfying assignment of sqchain_r1cs(n, x) alone ([m, 4] uint64): another proof of the same circuit."""
+    wit = [1, x % R]
+    for k in range(1, n):
+        wit.append((wit[k] * wit[k] + k) % R)
+    for e in range(extra_vars):
+        wit.append((x * 31337 + e + 5) % R)
+    return capi.ints_to_u64(wit)
+
+
 def sqchain_r1cs(n, x, extra_vars=0):
     """SURVEY 8d's synthetic circuit: variables [one, s_1 = x (public), s_2 .. s_n] (m = n + 1, NPublic = 1);
     constraint k = 1..n-1:  s_k * s_k = s_{k+1} - k * one;  constraint n:  one * one = one.

@@ -21,7 +21,7 @@ import (
 	"github.com/arnaucube/go-snark-study/circuitcompiler"
 	"github.com/arnaucube/go-snark-study/groth16"
 
-	"gosnarkhip"
+	"github.com/arnaucube/go-snark-study-hip/gosnarkhip"
 )
 
 // Device is the logical device the package's functions use.
@@ -42,6 +42,8 @@ type entry struct {
 	key  *gosnarkhip.Groth16Key
 	r1cs *gosnarkhip.R1CS // the circuit's sparse system, uploaded by the first GenerateProofsFromWitness
 	used uint64
+	refs int  // proofs that are using key / r1cs right now (pinned: eviction and Release* only mark the entry dead)
+	dead bool // evicted or released while pinned: freed by the last unpin
 }
 
 var (
@@ -57,24 +59,55 @@ func idOf(pk *groth16.Pk) (keyID, error) {
 	return keyID{&pk.G1.At[0], &pk.PowersTauDelta[0], len(pk.G1.At)}, nil
 }
 
-func remember(id keyID, k *gosnarkhip.Groth16Key) {
-	clock++
-	keys[id] = &entry{key: k, used: clock}
-	for len(keys) > MaxResidentKeys { // evict the least recently used key and give its HBM back
-		var old keyID
-		var oldest uint64 = ^uint64(0)
-		for i, e := range keys {
-			if e.used < oldest {
-				old, oldest = i, e.used
-			}
-		}
-		_ = keys[old].r1cs.Free()
-		_ = keys[old].key.Free()
-		delete(keys, old)
+// drop removes an entry from the cache and frees its device objects -- at once when no proof uses them, otherwise when the
+// last of those proofs unpins it (ADVICE r2: a concurrent GenerateProofs must never see its key freed under it).  mu held.
+func drop(id keyID, e *entry) {
+	delete(keys, id)
+	if e.refs > 0 {
+		e.dead = true
+		return
+	}
+	_ = e.r1cs.Free()
+	_ = e.key.Free()
+}
+
+// unpin ends a proof's use of an entry.
+func unpin(e *entry) {
+	mu.Lock()
+	defer mu.Unlock()
+	e.refs--
+	if e.dead && e.refs == 0 {
+		_ = e.r1cs.Free()
+		_ = e.key.Free()
 	}
 }
 
-func deviceKey(circuit circuitcompiler.Circuit, pk *groth16.Pk) (*gosnarkhip.Groth16Key, error) {
+// remember caches a resident key (pinned once for the caller when pin is set) and evicts least-recently-used entries. mu held.
+func remember(id keyID, k *gosnarkhip.Groth16Key, pin bool) *entry {
+	clock++
+	e := &entry{key: k, used: clock}
+	if pin {
+		e.refs = 1
+	}
+	keys[id] = e
+	for len(keys) > MaxResidentKeys { // evict the least recently used key and give its HBM back
+		var old keyID
+		var oldest uint64 = ^uint64(0)
+		for i, c := range keys {
+			if c != e && c.used < oldest {
+				old, oldest = i, c.used
+			}
+		}
+		if oldest == ^uint64(0) {
+			break
+		}
+		drop(old, keys[old])
+	}
+	return e
+}
+
+// deviceKey returns the cache entry of pk, PINNED: the caller must unpin(e) when its proof is done.
+func deviceKey(circuit circuitcompiler.Circuit, pk *groth16.Pk) (*entry, error) {
 	id, err := idOf(pk)
 	if err != nil {
 		return nil, err
@@ -84,7 +117,8 @@ func deviceKey(circuit circuitcompiler.Circuit, pk *groth16.Pk) (*gosnarkhip.Gro
 	if e, ok := keys[id]; ok {
 		clock++
 		e.used = clock
-		return e.key, nil
+		e.refs++
+		return e, nil
 	}
 	k, err := gosnarkhip.NewGroth16Key(Device, gosnarkhip.Groth16KeyParts{
 		At: pk.G1.At, BACGamma1: pk.G1.BACGamma, BACDelta: pk.BACDelta, PowersTauDelta: pk.PowersTauDelta,
@@ -96,8 +130,7 @@ func deviceKey(circuit circuitcompiler.Circuit, pk *groth16.Pk) (*gosnarkhip.Gro
 	if err != nil {
 		return nil, err
 	}
-	remember(id, k)
-	return k, nil
+	return remember(id, k, true), nil
 }
 
 // ReleaseKey frees the resident copy of pk (if any); ReleaseAll frees every cached key.
@@ -109,18 +142,14 @@ func ReleaseKey(pk *groth16.Pk) {
 	mu.Lock()
 	defer mu.Unlock()
 	if e, ok := keys[id]; ok {
-		_ = e.r1cs.Free()
-		_ = e.key.Free()
-		delete(keys, id)
+		drop(id, e)
 	}
 }
 func ReleaseAll() {
 	mu.Lock()
 	defer mu.Unlock()
 	for id, e := range keys {
-		_ = e.r1cs.Free()
-		_ = e.key.Free()
-		delete(keys, id)
+		drop(id, e)
 	}
 }
 
@@ -143,11 +172,12 @@ func GenerateProofs(circuit circuitcompiler.Circuit, pk groth16.Pk, w []*big.Int
 // C call sequence: tests/c/groth16_generateproofs.c.
 func GenerateProofsWithRS(circuit circuitcompiler.Circuit, pk *groth16.Pk, w, px []*big.Int, r, s *big.Int) (groth16.Proof, error) {
 	var proof groth16.Proof
-	k, err := deviceKey(circuit, pk)
+	e, err := deviceKey(circuit, pk)
 	if err != nil {
 		return proof, err // callers may fall back to groth16.GenerateProofs (the CPU reference)
 	}
-	proof.PiA, proof.PiB, proof.PiC, err = k.Prove(w, px, r, s, groth16.Utils.FqR.Q)
+	defer unpin(e)
+	proof.PiA, proof.PiB, proof.PiC, err = e.key.Prove(w, px, r, s, groth16.Utils.FqR.Q)
 	return proof, err
 }
 
@@ -172,11 +202,13 @@ func GenerateProofsFromWitness(circuit circuitcompiler.Circuit, pk groth16.Pk, w
 func GenerateProofsFromWitnessWithRS(circuit circuitcompiler.Circuit, pk *groth16.Pk, w []*big.Int, r, s *big.Int) (groth16.Proof, error) {
 	var proof groth16.Proof
 	order := groth16.Utils.FqR.Q
-	k, err := deviceKey(circuit, pk)
+	e, err := deviceKey(circuit, pk)
 	if err != nil {
 		return proof, err
 	}
-	q, err := deviceR1CS(circuit, pk)
+	defer unpin(e)
+	k := e.key
+	q, err := deviceR1CS(circuit, e)
 	if err != nil {
 		return proof, err
 	}
@@ -190,17 +222,10 @@ func GenerateProofsFromWitnessWithRS(circuit circuitcompiler.Circuit, pk *groth1
 }
 
 // deviceR1CS returns the circuit's resident sparse system, uploading circuit.R1CS on first use (cached with the key).
-func deviceR1CS(circuit circuitcompiler.Circuit, pk *groth16.Pk) (*gosnarkhip.R1CS, error) {
-	id, err := idOf(pk)
-	if err != nil {
-		return nil, err
-	}
-	mu.Lock()
+func deviceR1CS(circuit circuitcompiler.Circuit, e *entry) (*gosnarkhip.R1CS, error) {
+	mu.Lock() // e is pinned by the caller; the lock serialises the one-time upload
 	defer mu.Unlock()
-	e, ok := keys[id]
-	if !ok {
-		return nil, errors.New("groth16hip: key not resident")
-	}
+	var err error
 	if e.r1cs != nil {
 		return e.r1cs, nil
 	}
@@ -281,7 +306,7 @@ func generateTrustedSetupWithToxic(setup groth16.Setup, witnessLength int, circu
 	setup.Vk.G2.Beta, setup.Vk.G2.Gamma, setup.Vk.G2.Delta = vk.G2Beta, vk.G2Gamma, vk.G2Delta
 	if id, err := idOf(&setup.Pk); err == nil {
 		mu.Lock()
-		remember(id, k)
+		remember(id, k, false)
 		mu.Unlock()
 	}
 	return setup, nil

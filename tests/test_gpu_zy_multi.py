@@ -401,3 +401,44 @@ def test_config_5_2p18_proofs_round_robin_over_8_logical_devices_against_the_gol
         h.free()
     for k in pks:
         k.handle.free()
+
+
+def test_config_5_batch_of_64_proofs_with_distinct_witnesses():
+    """BASELINE configs[4] as worded -- "batch of 64 independent 2^18-constraint Groth16 proofs, one proof per GPU" -- with 64 DIFFERENT
+    witnesses (round 2 shared one witness): the sqchain circuit is the same, so one key serves all (one replica per
+    logical device), every proof has its own public input x_i, witness, px (from the sparse system on the device) and randomness.
+    Each of the 64 proofs must verify against the device-built vk for ITS x_i and for no other; four of them are compared with the
+    single-device blocking prover as well."""
+    from gosnark_amd import r1csqap
+    n, ndev, nproofs = 1 << 18, 8, 64
+    capi.set_device(0)
+    inst = synth.sqchain_setup_instance(n, 0xC0F4)
+    pks = [groth16.ShardPkTo(inst.device_pk(), 0, 1, d) for d in range(ndev)]
+    devs = []
+    for d in range(ndev):
+        capi.set_device(d)
+        devs.append(r1csqap.DeviceR1CS(*inst.r1cs, inst.m))
+    capi.set_device(0)
+    xs = synth.field_elems(nproofs, 0xC0F5)
+    ws, pxs, rs = [], [], []
+    for i, x in enumerate(xs):
+        w = synth.sqchain_witness(n, x)
+        d = i % ndev
+        capi.set_device(d)
+        ws.append(capi.scalars_upload(w))
+        pxs.append(devs[d].ComputePxResident(ws[-1]))
+        rs.append(tuple(synth.field_elems(2, 0xC100 + i)))
+    capi.set_device(0)
+    assert len({capi.scalars_download(w)[2].tobytes() for w in ws[:8]}) == 8          # the witnesses really differ
+    got = groth16.prove_batch(pks, ws, pxs, rs)
+    assert len(got) == nproofs
+    for i, p in enumerate(got):
+        assert groth16.VerifyProof(inst.vk, p, [xs[i]]) is True, i
+        assert groth16.VerifyProof(inst.vk, p, [xs[(i + 1) % nproofs]]) is False, i
+    for i in (0, 9, 31, 63):
+        w0, px0 = capi.scalars_clone(ws[i], 0), capi.scalars_clone(pxs[i], 0)
+        assert _same(got[i], groth16.prove_resident(inst.device_pk(), w0, px0, *rs[i])), i
+    for h in ws + pxs:
+        h.free()
+    for k in pks:
+        k.handle.free()
