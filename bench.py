@@ -159,6 +159,49 @@ def pipelined(begin, end, count, depth, on_done=None):
             on_done()
 
 
+def live_pmc_traffic(args):
+    """HBM traffic of the dominant kernel, measured NOW: bench.py cannot attach counters to itself, so it runs itself twice more under
+    rocprofv3 -- one --pmc pass per counter (FETCH_SIZE takes 3 of the 4 TCC slots, WRITE_SIZE 2: they cannot share a pass; no tracing
+    domain is combined with --pmc) -- on the same workload with ONE step, and averages the counter over the k_bucket_accumulate<G1>
+    dispatches (the 3-array launch over w and the 1-array launch over h: the mix the timed region averages).  Counter unit: KB.
+    Returns (dict, None) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if os.environ.get("GS_BENCH_NO_LIVE_PMC") == "1":
+        return None, "GS_BENCH_NO_LIVE_PMC=1"
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    res = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="gs_pmc_", dir="/tmp")
+        try:
+            cmd = [exe, "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
+                   "--log2n", str(args.log2n), "--steps", "1", "--warmup", "0", "--reps", "1", "--settle-ms", "0", "--cpu-log2n", "0", "--no-extras", "--no-check"]
+            env = dict(os.environ, TMPDIR="/tmp", GS_BENCH_NO_LIVE_PMC="1")
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300, check=True)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if not files:
+                return None, "rocprofv3 wrote no counter_collection.csv for %s" % ctr
+            vals = []
+            with open(files[0]) as f:
+                for row in csv.DictReader(f):
+                    if row.get("Counter_Name") == ctr and "k_bucket_accumulate<gs::FqTag>" in row.get("Kernel_Name", ""):
+                        vals.append(float(row["Counter_Value"]))
+            if not vals:
+                return None, "no k_bucket_accumulate<G1> dispatch in the %s pass" % ctr
+            res[ctr] = (sum(vals) / len(vals) * 1024.0, len(vals))
+        except (OSError, subprocess.SubprocessError, ValueError, KeyError) as e:
+            return None, "%s pass failed: %s" % (ctr, type(e).__name__)
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return {"fetch_bytes_per_launch_raw": res["FETCH_SIZE"][0], "write_bytes_per_launch_raw": res["WRITE_SIZE"][0],
+            "dispatches_averaged": [res["FETCH_SIZE"][1], res["WRITE_SIZE"][1]]}, None
+
+
 def build_stamp():
     """Which library this line was measured with: gs_version() (carries the compile flags) + the source commit recorded by
     __graft_entry__.build() next to the library (the GPU box has no .git)."""
@@ -649,7 +692,19 @@ def main():
                                           "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                           "note": "SURVEY 8d: Groth16 672 B per constraint per proof (544 n MSM + 128 n H stage), Pinocchio 960 B; wall time per step"}
             out["device_ms_per_step"] = {k: tm_acc[k] / total_steps for k in ("total_ms", "poly_ms", "plan_ms", "accumulate_ms", "reduce_ms", "acc_g1_ms", "acc_g2_ms")}
+            live, why = (live_pmc_traffic(args) if (world == 1 and plain_prove and not args.no_extras) else (None, "only the default single-GPU run measures it"))
+            if live:
+                # raw counters: the guide's x2 correction of FETCH_SIZE is calibrated for wide coalesced streams; this kernel's reads are 64-byte
+                # gathers, so the raw sum is `traffic` and the x2-corrected read side is given as the upper bound
+                out["roofline"]["traffic"] = live["fetch_bytes_per_launch_raw"] + live["write_bytes_per_launch_raw"]
+                out["roofline"]["traffic_upper_bound_fetch_x2"] = 2 * live["fetch_bytes_per_launch_raw"] + live["write_bytes_per_launch_raw"]
+                out["roofline"]["traffic_source"] = ("measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (two separate passes of this script, one step each, "
+                                                     "no tracing domains), counter x 1024 B averaged over %d / %d k_bucket_accumulate<G1> dispatches"
+                                                     % tuple(live["dispatches_averaged"]))
+                out["roofline"]["traffic_over_algorithmic"] = out["roofline"]["traffic"] / bytes_per_launch if bytes_per_launch else None
             try:
+                if live:
+                    raise OSError("measured live")
                 with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
                     pmc = json.load(f).get(workload)
                 if pmc and pmc.get("window_bits") not in (None, cbits):
@@ -659,7 +714,7 @@ def main():
                 elif pmc:      # measured offline with rocprofv3 --pmc (bench.py cannot attach counters to itself)
                     out["roofline"]["traffic"] = pmc["fetch_bytes_per_launch_raw"] + pmc["write_bytes_per_launch_raw"]
                     out["roofline"]["traffic_source"] = ("profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, raw counters; measured at commit %s, "
-                                                         "window width %s)" % (pmc.get("commit", "?"), pmc.get("window_bits", "?")))
+                                                         "window width %s) -- the live passes did not run: %s" % (pmc.get("commit", "?"), pmc.get("window_bits", "?"), why))
             except OSError:
                 pass
         if shard_info:
