@@ -125,6 +125,8 @@ _SIGS = {
     "gs_groth16_prove_sharded": [Handle, Handle, Handle, u64p, u64p, u64p, intp],
     "gs_groth16_witness_values": [Handle, Handle, Handle, ctypes.POINTER(Handle), ctypes.POINTER(ctypes.c_uint32)],
     "gs_groth16_prove_partials_values": [Handle, Handle, Handle, ctypes.c_size_t, ctypes.c_size_t, u64p, intp],
+    "gs_groth16_partials_values_begin": [Handle, Handle, Handle, ctypes.c_size_t, ctypes.c_size_t, u64p],
+    "gs_groth16_partials_end": [ctypes.c_uint64, u64p, intp],
     "gs_groth16_prove_multi_values": [ctypes.POINTER(Handle), ctypes.POINTER(Handle), ctypes.POINTER(Handle), ctypes.c_int, u64p, u64p, u64p, intp, intp],
     "gs_groth16_prove_sharded_values": [Handle, Handle, Handle, u64p, u64p, u64p, intp],
     "gs_scalars_scatter": [Handle, ctypes.c_size_t, ctypes.c_int, ctypes.POINTER(Handle)],

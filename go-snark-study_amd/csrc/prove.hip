@@ -790,6 +790,8 @@ int gs_groth16_prove_end(uint64_t ticket, uint64_t out_proof[32], int inf[3]) {
     if (parity < 0) return fail(GS_ERR_ARG, "gs_groth16_prove_end: unknown ticket %llu", (unsigned long long)ticket);
     if (!dynamic_cast<GrothInFlight*>(c.inflight[parity].get()))
       return fail(GS_ERR_ARG, "gs_groth16_prove_end: ticket %llu belongs to an MSM (use gs_msm_end)", (unsigned long long)ticket);
+    if (!static_cast<GrothInFlight*>(c.inflight[parity].get())->with_tail)
+      return fail(GS_ERR_ARG, "gs_groth16_prove_end: ticket %llu is a partial-sums operation (use gs_groth16_partials_end)", (unsigned long long)ticket);
     std::unique_ptr<InFlightBase> base = std::move(c.inflight[parity]);
     GrothInFlight& st = static_cast<GrothInFlight&>(*base);
     reset_timing(c);
@@ -901,6 +903,58 @@ int gs_groth16_prove_partials_values(gs_handle hpk, gs_handle hw, gs_handle hv_s
     inf[4] = g1_to_affine_std(sums.h, out_sums + 40) ? 1 : 0;
     return GS_OK;
   }, true, false, hpk);
+}
+
+// The same, pipelined (a rank streams its shards of consecutive proofs: the plan and accumulations of shard work k + 1 queue behind
+// those of k): gs_groth16_partials_values_begin enqueues and returns a ticket, gs_groth16_partials_end collects the five sums.
+int gs_groth16_partials_values_begin(gs_handle hpk, gs_handle hw, gs_handle hv_slice, size_t shard_index, size_t shard_count, uint64_t* ticket) {
+  return guarded([&](Ctx& c) -> int {
+    GrothPkObj* pk = c.get<GrothPkObj>(hpk, Kind::GrothPk);
+    Scalars* w = c.get<Scalars>(hw, Kind::Scalars);
+    Scalars* hv = c.get<Scalars>(hv_slice, Kind::Scalars);
+    if (!pk || !w || !hv || !ticket) return fail(GS_ERR_ARG, "gs_groth16_partials_values_begin: bad handle or null ticket");
+    if (shard_count == 0 || shard_index >= shard_count) return fail(GS_ERR_ARG, "gs_groth16_partials_values_begin: bad shard");
+    if (pk->n_eval == 0) return fail(GS_ERR_SHAPE, "gs_groth16_partials_values_begin: the key has no evaluation-basis array");
+    Shard sh; sh.index = shard_index; sh.count = shard_count;
+    size_t lo, hi;
+    if (pk->shard_count > 1) { lo = pk->e_lo; hi = pk->e_lo + pk->n_e; } else shard_range(pk->n_eval, sh, lo, hi);
+    if (hv->n != hi - lo) return fail(GS_ERR_SHAPE, "gs_groth16_partials_values_begin: the shard covers %zu values, the vector holds %zu", hi - lo, hv->n);
+    const int parity = c.free_parity();
+    if (parity < 0) return fail(GS_ERR_BUSY, "gs_groth16_partials_values_begin: three operations are already outstanding; collect one first");
+    auto st = std::make_unique<GrothInFlight>();
+    st->pk = pk;
+    st->keep = {c.share<Object>(hpk, Kind::GrothPk), c.share<Object>(hw, Kind::Scalars), c.share<Object>(hv_slice, Kind::Scalars)};
+    DevScalars dh{nullptr, 0};
+    dh.hv_slice = hv->buf.as<uint32_t>();
+    const int rc = groth16_enqueue(c, pk, DevScalars{w->buf.as<uint32_t>(), w->n}, dh, sh, parity, false, true, *st);
+    if (rc != GS_OK) return rc;
+    st->ticket = c.new_ticket();
+    *ticket = st->ticket;
+    c.inflight[parity] = std::move(st);
+    return GS_OK;
+  }, true, true, hpk);
+}
+
+int gs_groth16_partials_end(uint64_t ticket, uint64_t out_sums[48], int inf[5]) {
+  return guarded([&](Ctx& c) -> int {
+    if (!out_sums || !inf) return fail(GS_ERR_ARG, "null argument");
+    int parity = -1;
+    for (int p = 0; p < Ctx::kMaxInFlight; ++p) if (c.inflight[p] && c.inflight[p]->ticket == ticket) parity = p;
+    if (parity < 0) return fail(GS_ERR_ARG, "gs_groth16_partials_end: unknown ticket %llu", (unsigned long long)ticket);
+    GrothInFlight* g = dynamic_cast<GrothInFlight*>(c.inflight[parity].get());
+    if (!g || g->with_tail) return fail(GS_ERR_ARG, "gs_groth16_partials_end: ticket %llu is not a partial-sums operation", (unsigned long long)ticket);
+    std::unique_ptr<InFlightBase> base = std::move(c.inflight[parity]);
+    reset_timing(c);
+    GrothSums sums;
+    const int rc = groth16_collect(c, *g, sums);
+    if (rc != GS_OK) return rc;
+    inf[0] = g1_to_affine_std(sums.at, out_sums) ? 1 : 0;
+    inf[1] = g1_to_affine_std(sums.bacgamma1, out_sums + 8) ? 1 : 0;
+    inf[2] = g2_to_affine_std(sums.bacgamma2, out_sums + 16) ? 1 : 0;
+    inf[3] = g1_to_affine_std(sums.bacdelta, out_sums + 32) ? 1 : 0;
+    inf[4] = g1_to_affine_std(sums.h, out_sums + 40) ? 1 : 0;
+    return GS_OK;
+  }, true, true, ticket);
 }
 
 // ... and the O(1) tail of groth16.go:253-275 on the combined sums (same layout as gs_groth16_prove_partials emits).

@@ -368,6 +368,26 @@ def prove_partials_values(dev_pk, w_handle, hv_slice, shard_index, shard_count):
     return pts, SUM_IS_G2
 
 
+def partials_values_begin(dev_pk, w_handle, hv_slice, shard_index, shard_count):
+    """gs_groth16_partials_values_begin -> ticket (collect with partials_end)."""
+    import ctypes
+    t = ctypes.c_uint64(0)
+    capi.check(capi.load_library().gs_groth16_partials_values_begin(capi.Handle(dev_pk.handle.h), capi.Handle(w_handle.h), capi.Handle(hv_slice.h),
+                                                                    shard_index, shard_count, ctypes.cast(ctypes.byref(t), capi.u64p)))
+    return t.value
+
+
+def partials_end(ticket):
+    """gs_groth16_partials_end -> the five sums as prove_partials returns them."""
+    import ctypes
+    out = np.zeros(48, dtype=np.uint64)
+    inf = (ctypes.c_int * 5)()
+    capi.check(capi.load_library().gs_groth16_partials_end(ctypes.c_uint64(ticket), capi.ptr64(out), inf))
+    v = capi.u64_to_ints(out)
+    return [None if inf[0] else (v[0], v[1]), None if inf[1] else (v[2], v[3]),
+            None if inf[2] else ((v[4], v[5]), (v[6], v[7])), None if inf[3] else (v[8], v[9]), None if inf[4] else (v[10], v[11])]
+
+
 def scatter_values(hv_handle, ndev):
     """The owner's scatter between the logical devices of this process: slice d of the contiguous split of H's values -> device d."""
     n = len(hv_handle)

@@ -365,6 +365,9 @@ int gs_groth16_prove_sharded(gs_handle pk, gs_handle w, gs_handle px, const uint
 int gs_groth16_witness_values(gs_handle pk, gs_handle r1cs, gs_handle w, gs_handle* hv_inout, uint32_t* violated);
 int gs_groth16_prove_partials_values(gs_handle pk, gs_handle w, gs_handle hv_slice, size_t shard_index, size_t shard_count,
                                      uint64_t out_sums[48], int inf[5]);
+/* ... pipelined: a rank streams its shards of consecutive proofs through the three slots (begin enqueues, end collects the five sums). */
+int gs_groth16_partials_values_begin(gs_handle pk, gs_handle w, gs_handle hv_slice, size_t shard_index, size_t shard_count, uint64_t* ticket);
+int gs_groth16_partials_end(uint64_t ticket, uint64_t out_sums[48], int inf[5]);
 int gs_groth16_prove_multi_values(const gs_handle* pk, const gs_handle* w, const gs_handle* hv_slices, int ndev, const uint64_t r[4], const uint64_t s[4],
                                   uint64_t out_proof[32], int inf[3], int* used_rccl);
 int gs_groth16_prove_sharded_values(gs_handle pk, gs_handle w, gs_handle hv_slice, const uint64_t r[4], const uint64_t s[4], uint64_t out_proof[32], int inf[3]);

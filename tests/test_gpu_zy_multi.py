@@ -162,6 +162,11 @@ def test_values_route_polynomial_stage_on_one_owner_then_scattered(inst, n):
             parts = [groth16.prove_partials_values(pks[d], ws[d], slices[d], d, n)[0] for d in range(n)]
             combined = [capi.sum_affine([parts[k][i] for k in range(n)], g2=g2) for i, g2 in enumerate(groth16.SUM_IS_G2)]
             assert _same(groth16.finish(pks[0], combined, r, s), want)
+            # ... and pipelined: three shard tickets of device 0 in flight; a proof ticket's collector refuses them
+            t = [groth16.partials_values_begin(pks[0], ws[0], slices[0], 0, n) for _ in range(3)]
+            with pytest.raises(capi.GosnarkHipError, match="partial-sums"):
+                groth16.prove_end(t[0])
+            assert all(groth16.partials_end(x) == parts[0] for x in t)
             with pytest.raises(capi.GosnarkHipError, match="covers"):
                 groth16.prove_partials_values(pks[0], ws[0], capi.scalars_clone(hv, 0), 0, n)       # all n values where a slice belongs
     w_bad = inst.w_host.copy()
