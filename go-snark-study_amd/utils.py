@@ -310,6 +310,11 @@ def GrothSetupToBinary(path, circuit, pk, vk):
         z = np.zeros((pk.nvars - 1, 4), dtype=np.uint64)
         capi.check(lib.gs_groth16_pk_export(capi.Handle(pk.handle.h), 6, capi.ptr64(z), z.shape[0]))
         sec["Z"] = z
+        ne = capi.pk_eval_count(pk.handle)
+        if ne:           # optional section: the evaluation-basis copy of PowersTauDelta (only whoever knew tau can produce it)
+            e = np.zeros((ne, 12), dtype=np.uint64)
+            capi.check(lib.gs_groth16_pk_export(capi.Handle(pk.handle.h), 7, capi.ptr64(e), ne))
+            sec["PowersTauDeltaEval"] = e
     else:
         sec["G1.At"] = capi.g1_points_to_u64(pk.G1_At)
         sec["G1.BACGamma"] = capi.g1_points_to_u64(pk.G1_BACGamma)
@@ -378,6 +383,10 @@ def UploadGrothPkBinary(path, shard=None):
     z = np.ascontiguousarray(sec["Z"], dtype=np.uint64)
     if shard is None:
         dev = groth16.device_pk_from_handles(at, b1, b2, cd, pt, abd[0], abd[1], abd[2], bd[0], bd[1], z, nvars, npublic)
+        if "PowersTauDeltaEval" in sec:          # the witness route then runs its h-MSM over H's values (gs_groth16_pk_set_eval)
+            e = capi.g1_upload(np.ascontiguousarray(sec["PowersTauDeltaEval"], dtype=np.uint64))
+            capi.check(capi.load_library().gs_groth16_pk_set_eval(capi.Handle(dev.handle.h), capi.Handle(e.h)))
+            e.free()
     else:
         dev = groth16.device_pk_shard_from_handles(at, b1, b2, cd, pt, abd[0], abd[1], abd[2], bd[0], bd[1], z, nvars, npublic, nptd,
                                                    shard[0], shard[1])
@@ -402,6 +411,11 @@ def SetupToBinary(path, circuit, pk, vk=None):
         z = np.zeros((pk.nvars - 1, 4), dtype=np.uint64)
         capi.check(lib.gs_pinocchio_pk_export(capi.Handle(pk.h), 8, capi.ptr64(z), z.shape[0]))
         sec["Z"] = z
+        ne = capi.pk_eval_count(pk.handle)
+        if ne:           # optional section: the evaluation-basis copy of G1T
+            e = np.zeros((ne, 12), dtype=np.uint64)
+            capi.check(lib.gs_pinocchio_pk_export(capi.Handle(pk.h), 9, capi.ptr64(e), ne))
+            sec["G1TEval"] = e
     else:
         for name, _, words in _PIN_ARRAYS:
             pts = getattr(pk, name)
@@ -441,4 +455,9 @@ def UploadPkBinary(path):
     capi.check(capi.load_library().gs_pinocchio_pk_create(
         H(g1["A"]), H(g1["Ap"]), H(b2), H(g1["Bp"]), H(g1["C"]), H(g1["Cp"]), H(g1["Kp"]), H(g1["G1T"]),
         capi.ptr64(z), z.shape[0], nvars, npublic, ctypes.byref(h)))
-    return snark.Circuit(nvars, npublic), snark.DevicePk(capi.DeviceHandle(h.value), nvars, npublic)
+    dev = snark.DevicePk(capi.DeviceHandle(h.value), nvars, npublic)
+    if "G1TEval" in sec:
+        e = capi.g1_upload(np.ascontiguousarray(sec["G1TEval"], dtype=np.uint64))
+        capi.check(capi.load_library().gs_pinocchio_pk_set_eval(capi.Handle(dev.h), capi.Handle(e.h)))
+        e.free()
+    return snark.Circuit(nvars, npublic), dev

@@ -417,3 +417,324 @@ func VerifySetStrict(on bool) {
 	}
 	C.gs_verify_set_strict(v)
 }
+
+// ---- the rest of the header, so that every entry point of include/gosnark_hip.h has a Go name ---------------------------------
+
+// Len is the element count of a resident base array or scalar vector.
+func Len(h Handle) (int, error) {
+	var n C.size_t
+	err := call(func() C.int { return C.gs_len(C.gs_handle(h), &n) })
+	return int(n), err
+}
+
+// CurrentDevice is the calling OS thread's current logical device (gs_get_device).
+func CurrentDevice() int { return int(C.gs_get_device()) }
+
+// DownloadG1 / DownloadG2 read a resident base array back as affine Jacobian triples.
+func DownloadG1(h Handle, n int) ([][3]*big.Int, error) {
+	buf := make([]uint64, 12*n)
+	if err := call(func() C.int { return C.gs_g1_download(C.gs_handle(h), ptr(buf), C.size_t(n)) }); err != nil {
+		return nil, err
+	}
+	out := make([][3]*big.Int, n)
+	for i := range out {
+		out[i] = G1FromJacobian(buf[12*i:])
+	}
+	return out, nil
+}
+func DownloadG2(h Handle, n int) ([][3][2]*big.Int, error) {
+	buf := make([]uint64, 24*n)
+	if err := call(func() C.int { return C.gs_g2_download(C.gs_handle(h), ptr(buf), C.size_t(n)) }); err != nil {
+		return nil, err
+	}
+	out := make([][3][2]*big.Int, n)
+	for i := range out {
+		out[i] = G2FromJacobian(buf[24*i:])
+	}
+	return out, nil
+}
+
+// FixedBaseG1 / FixedBaseG2: k_i * G for every scalar, resident (the MulScalar(Utils.Bn.G1.G, k) loops of the trusted setups,
+// groth16.go:139-175): synthetic keys and tests.
+func FixedBaseG1(device int, scalars []*big.Int, order *big.Int) (Handle, error) {
+	buf, err := Scalars(scalars, order)
+	if err != nil {
+		return 0, err
+	}
+	var h C.gs_handle
+	err = onDevice(device, func() C.int { return C.gs_g1_fixed_base(ptr(buf), C.size_t(len(scalars)), &h) })
+	runtime.KeepAlive(buf)
+	return Handle(h), err
+}
+func FixedBaseG2(device int, scalars []*big.Int, order *big.Int) (Handle, error) {
+	buf, err := Scalars(scalars, order)
+	if err != nil {
+		return 0, err
+	}
+	var h C.gs_handle
+	err = onDevice(device, func() C.int { return C.gs_g2_fixed_base(ptr(buf), C.size_t(len(scalars)), &h) })
+	runtime.KeepAlive(buf)
+	return Handle(h), err
+}
+
+// Timing mirrors gs_timing: device time of the last prove / MSM call on a logical device (HIP events on the library's streams).
+type Timing struct {
+	TotalMs, PlanMs, AccumulateMs, ReduceMs, PolyMs, H2DMs, AccG1Ms, AccG2Ms float32
+	AccG1Launches, AccG2Launches                                               uint32
+	AccG1Terms, AccG2Terms, AccG1Adds, AccG2Adds                               uint64
+	WindowBits, Fallbacks                                                      uint32
+}
+
+func timingFromC(t *C.gs_timing) Timing {
+	return Timing{float32(t.total_ms), float32(t.plan_ms), float32(t.accumulate_ms), float32(t.reduce_ms), float32(t.poly_ms), float32(t.h2d_ms),
+		float32(t.acc_g1_ms), float32(t.acc_g2_ms), uint32(t.acc_g1_launches), uint32(t.acc_g2_launches), uint64(t.acc_g1_terms), uint64(t.acc_g2_terms),
+		uint64(t.acc_g1_adds), uint64(t.acc_g2_adds), uint32(t.window_bits), uint32(t.fallbacks)}
+}
+
+// LastTiming (current logical device of the calling thread) / DeviceTiming (a named one).
+func LastTiming() (Timing, error) {
+	var t C.gs_timing
+	err := call(func() C.int { return C.gs_last_timing(&t) })
+	return timingFromC(&t), err
+}
+func DeviceTiming(device int) (Timing, error) {
+	var t C.gs_timing
+	err := call(func() C.int { return C.gs_device_timing(C.int(device), &t) })
+	return timingFromC(&t), err
+}
+
+// CommInfo reports the communicator: ranks, this process's rank (-1 in local mode), local mode, collectives completed.
+func CommInfo() (nranks, rank int, local bool, collectives uint64) {
+	var n, r, l C.int
+	var c C.uint64_t
+	C.gs_comm_info(&n, &r, &l, &c)
+	return int(n), int(r), l != 0, uint64(c)
+}
+
+// CommAllGather gathers `send` (the same length on every rank) from all ranks: recv gets nranks blocks.
+func CommAllGather(send []byte, nranks int) ([]byte, error) {
+	if len(send) == 0 {
+		return nil, nil
+	}
+	recv := make([]byte, len(send)*nranks)
+	err := call(func() C.int { return C.gs_comm_allgather(unsafe.Pointer(&send[0]), C.size_t(len(send)), unsafe.Pointer(&recv[0])) })
+	runtime.KeepAlive(send)
+	return recv, err
+}
+
+// Partials holds a rank's five raw sums (gs_groth16_prove_partials layout: At | G1.BACGamma | G2.BACGamma | BACDelta | h) and flags.
+type Partials struct {
+	Sums [48]uint64
+	Inf  [5]int32
+}
+
+func partialsCall(f func(out *C.uint64_t, inf *C.int) C.int) (Partials, error) {
+	var p Partials
+	var inf [5]C.int
+	err := call(func() C.int { return f((*C.uint64_t)(unsafe.Pointer(&p.Sums[0])), &inf[0]) })
+	for i := range inf {
+		p.Inf[i] = int32(inf[i])
+	}
+	return p, err
+}
+
+// ProvePartials: the five sums over this rank's term ranges, px route (gs_groth16_prove_partials).
+func (k *Groth16Key) ProvePartials(w, px Handle, shard, count int) (Partials, error) {
+	return partialsCall(func(out *C.uint64_t, inf *C.int) C.int {
+		return C.gs_groth16_prove_partials(C.gs_handle(k.h), C.gs_handle(w), C.gs_handle(px), C.size_t(shard), C.size_t(count), out, inf)
+	})
+}
+
+// ProvePartialsValues: the same on the values route (hvSlice = this rank's slice of H's values); PartialsValuesBegin / PartialsEnd
+// are the pipelined form (three in flight per device).
+func (k *Groth16Key) ProvePartialsValues(w, hvSlice Handle, shard, count int) (Partials, error) {
+	return partialsCall(func(out *C.uint64_t, inf *C.int) C.int {
+		return C.gs_groth16_prove_partials_values(C.gs_handle(k.h), C.gs_handle(w), C.gs_handle(hvSlice), C.size_t(shard), C.size_t(count), out, inf)
+	})
+}
+func (k *Groth16Key) PartialsValuesBegin(w, hvSlice Handle, shard, count int) (uint64, error) {
+	var t C.uint64_t
+	err := call(func() C.int {
+		return C.gs_groth16_partials_values_begin(C.gs_handle(k.h), C.gs_handle(w), C.gs_handle(hvSlice), C.size_t(shard), C.size_t(count), &t)
+	})
+	return uint64(t), err
+}
+func PartialsEnd(ticket uint64) (Partials, error) {
+	return partialsCall(func(out *C.uint64_t, inf *C.int) C.int { return C.gs_groth16_partials_end(C.uint64_t(ticket), out, inf) })
+}
+
+// SumAffineG1 / SumAffineG2: the exchange step's complete additions of gathered partial points (host arithmetic).
+func SumAffineG1(pts []uint64, inf []int32) ([3]*big.Int, error) {
+	n := len(inf)
+	ci := make([]C.int, n)
+	for i, v := range inf {
+		ci[i] = C.int(v)
+	}
+	var out [8]uint64
+	var oi C.int
+	err := call(func() C.int { return C.gs_g1_sum_affine(ptr(pts), &ci[0], C.size_t(n), (*C.uint64_t)(unsafe.Pointer(&out[0])), &oi) })
+	runtime.KeepAlive(pts)
+	return G1FromAffine(out[:], oi != 0), err
+}
+func SumAffineG2(pts []uint64, inf []int32) ([3][2]*big.Int, error) {
+	n := len(inf)
+	ci := make([]C.int, n)
+	for i, v := range inf {
+		ci[i] = C.int(v)
+	}
+	var out [16]uint64
+	var oi C.int
+	err := call(func() C.int { return C.gs_g2_sum_affine(ptr(pts), &ci[0], C.size_t(n), (*C.uint64_t)(unsafe.Pointer(&out[0])), &oi) })
+	runtime.KeepAlive(pts)
+	return G2FromAffine(out[:], oi != 0), err
+}
+
+// Finish applies the O(1) tail of groth16.go:253-275 to combined sums (gs_groth16_finish).
+func (k *Groth16Key) Finish(p Partials, r, s, order *big.Int) (piA [3]*big.Int, piB [3][2]*big.Int, piC [3]*big.Int, err error) {
+	rs, err := Scalars([]*big.Int{r, s}, order)
+	if err != nil {
+		return
+	}
+	var inf5 [5]C.int
+	for i, v := range p.Inf {
+		inf5[i] = C.int(v)
+	}
+	var out [32]uint64
+	var inf [3]C.int
+	err = call(func() C.int {
+		return C.gs_groth16_finish(C.gs_handle(k.h), (*C.uint64_t)(unsafe.Pointer(&p.Sums[0])), &inf5[0], ptr(rs[0:]), ptr(rs[4:]), (*C.uint64_t)(unsafe.Pointer(&out[0])), &inf[0])
+	})
+	runtime.KeepAlive(rs)
+	if err != nil {
+		return
+	}
+	piA, piB, piC = groth16ProofFromWords(out[:], inf[:])
+	return
+}
+
+// ShardLocal cuts slice `index` of `count` out of a resident full key on the SAME logical device (gs_groth16_pk_shard).
+func (k *Groth16Key) ShardLocal(index, count int) (*Groth16Key, error) {
+	var h C.gs_handle
+	err := call(func() C.int { return C.gs_groth16_pk_shard(C.gs_handle(k.h), C.size_t(index), C.size_t(count), &h) })
+	if err != nil {
+		return nil, err
+	}
+	return &Groth16Key{Handle(h), k.NVars, k.NPublic}, nil
+}
+
+// NewGroth16KeyShard assembles a key slice from base handles that hold exactly the slices (gs_groth16_pk_create_shard): a rank
+// that loads only its share of a key file never sees the full key.  parts carries the single elements, Z, NVars, NPublic.
+func NewGroth16KeyShard(at, bacGamma1, bacGamma2, bacDelta, ptd Handle, parts Groth16KeyParts, nptdTotal, index, count int, order *big.Int) (*Groth16Key, error) {
+	singles1, err := G1Points([][3]*big.Int{parts.Alpha, parts.Beta, parts.Delta})
+	if err != nil {
+		return nil, err
+	}
+	singles2, err := G2Points([][3][2]*big.Int{parts.Beta2, parts.Delta2})
+	if err != nil {
+		return nil, err
+	}
+	z, err := Scalars(parts.Z, order)
+	if err != nil {
+		return nil, err
+	}
+	var h C.gs_handle
+	err = call(func() C.int {
+		return C.gs_groth16_pk_create_shard(C.gs_handle(at), C.gs_handle(bacGamma1), C.gs_handle(bacGamma2), C.gs_handle(bacDelta), C.gs_handle(ptd),
+			ptr(singles1[0:]), ptr(singles1[12:]), ptr(singles1[24:]), ptr(singles2[0:]), ptr(singles2[24:]), ptr(z), C.size_t(len(parts.Z)),
+			C.size_t(parts.NVars), C.size_t(parts.NPublic), C.size_t(nptdTotal), C.size_t(index), C.size_t(count), &h)
+	})
+	runtime.KeepAlive(singles1)
+	runtime.KeepAlive(singles2)
+	runtime.KeepAlive(z)
+	if err != nil {
+		return nil, err
+	}
+	return &Groth16Key{Handle(h), parts.NVars, parts.NPublic}, nil
+}
+
+// ProveResident: groth16.GenerateProofs with w and px already resident (what bench.py times, blocking).
+func (k *Groth16Key) ProveResident(w, px Handle, r, s, order *big.Int) (piA [3]*big.Int, piB [3][2]*big.Int, piC [3]*big.Int, err error) {
+	rs, err := Scalars([]*big.Int{r, s}, order)
+	if err != nil {
+		return
+	}
+	var out [32]uint64
+	var inf [3]C.int
+	err = call(func() C.int {
+		return C.gs_groth16_prove_resident(C.gs_handle(k.h), C.gs_handle(w), C.gs_handle(px), ptr(rs[0:]), ptr(rs[4:]), (*C.uint64_t)(unsafe.Pointer(&out[0])), &inf[0])
+	})
+	runtime.KeepAlive(rs)
+	if err != nil {
+		return
+	}
+	piA, piB, piC = groth16ProofFromWords(out[:], inf[:])
+	return
+}
+
+// ProveR1CS: px from the resident sparse system and the proof in one call (gs_groth16_prove_r1cs); px = 0 creates the vector.
+func (k *Groth16Key) ProveR1CS(q *R1CS, w, px Handle, r, s, order *big.Int) (piA [3]*big.Int, piB [3][2]*big.Int, piC [3]*big.Int, pxOut Handle, err error) {
+	rs, err := Scalars([]*big.Int{r, s}, order)
+	if err != nil {
+		return
+	}
+	var out [32]uint64
+	var inf [3]C.int
+	h := C.gs_handle(px)
+	err = call(func() C.int {
+		return C.gs_groth16_prove_r1cs(C.gs_handle(k.h), C.gs_handle(q.h), C.gs_handle(w), &h, ptr(rs[0:]), ptr(rs[4:]), (*C.uint64_t)(unsafe.Pointer(&out[0])), &inf[0])
+	})
+	runtime.KeepAlive(rs)
+	pxOut = Handle(h)
+	if err != nil {
+		return
+	}
+	piA, piB, piC = groth16ProofFromWords(out[:], inf[:])
+	return
+}
+
+// ProveMultiValues: one proof over the logical devices of this process on the values route (gs_groth16_prove_multi_values).
+func ProveMultiValues(keys []*Groth16Key, w, hvSlices []Handle, r, s, order *big.Int) (piA [3]*big.Int, piB [3][2]*big.Int, piC [3]*big.Int, usedRCCL bool, err error) {
+	n := len(keys)
+	if n == 0 || len(w) != n || len(hvSlices) != n {
+		err = errors.New("gosnark-hip: ProveMultiValues needs one key, w and slice of H's values per device")
+		return
+	}
+	kh := make([]Handle, n)
+	for d, k := range keys {
+		kh[d] = k.h
+	}
+	rs, err := Scalars([]*big.Int{r, s}, order)
+	if err != nil {
+		return
+	}
+	var out [32]uint64
+	var inf [3]C.int
+	var used C.int
+	err = call(func() C.int {
+		return C.gs_groth16_prove_multi_values(handles(kh), handles(w), handles(hvSlices), C.int(n), ptr(rs[0:]), ptr(rs[4:]), (*C.uint64_t)(unsafe.Pointer(&out[0])), &inf[0], &used)
+	})
+	runtime.KeepAlive(kh)
+	runtime.KeepAlive(rs)
+	if err != nil {
+		return
+	}
+	piA, piB, piC = groth16ProofFromWords(out[:], inf[:])
+	usedRCCL = used != 0
+	return
+}
+
+// MSMG2Multi is MSMG1Multi over G2.
+func MSMG2Multi(bases, scalars []Handle) (p [3][2]*big.Int, usedRCCL bool, err error) {
+	if len(bases) == 0 || len(bases) != len(scalars) {
+		err = errors.New("gosnark-hip: MSMG2Multi needs one base and one scalar shard per device")
+		return
+	}
+	var out [16]uint64
+	var inf, used C.int
+	err = call(func() C.int {
+		return C.gs_msm_g2_multi(handles(bases), handles(scalars), C.int(len(bases)), (*C.uint64_t)(unsafe.Pointer(&out[0])), &inf, &used)
+	})
+	runtime.KeepAlive(bases)
+	runtime.KeepAlive(scalars)
+	return G2FromAffine(out[:], inf != 0), used != 0, err
+}

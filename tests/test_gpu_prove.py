@@ -904,6 +904,34 @@ def test_eval_basis_round_trips_through_export_and_attach():
         groth16.SetEvalBasis(foreign, arrays["PowersTauDeltaEval"][:n - 2])     # neither deg Z nor deg Z + 1 points
 
 
+def test_binary_key_container_carries_the_evaluation_basis(tmp_path):
+    """The binary key file written from a device-built key has the optional PowersTauDeltaEval / G1TEval sections; a key uploaded
+    from it (file -> memmap -> HBM) takes the evaluation-basis witness route and gives the same proof as the key it came from."""
+    from gosnark_amd import synth, utils
+    n = 300
+    inst = synth.sqchain_setup_instance(n, 0x4F20)
+    dev = r1csqap.DeviceR1CS(*inst.r1cs, inst.m)
+    r, s = synth.field_elems(2, 616)
+    want = groth16.prove_from_witness(inst.device_pk(), dev, inst.w, r, s)
+    path = str(tmp_path / "groth.key")
+    utils.GrothSetupToBinary(path, groth16.Circuit(inst.m, 1), inst.device_pk(), inst.vk)
+    assert utils.ReadBinary(path)[3]["PowersTauDeltaEval"].shape == (n, 12)
+    _, loaded = utils.UploadGrothPkBinary(path)
+    assert capi.pk_eval_count(loaded.handle) == n
+    got = groth16.prove_from_witness(loaded, dev, inst.w, r, s)
+    assert (got.PiA, got.PiB, got.PiC) == (want.PiA, want.PiB, want.PiC) and capi.last_timing()["fallbacks"] == 0
+    pin = synth.sqchain_pinocchio_instance(n, 0x4F21)
+    pdev = r1csqap.DeviceR1CS(*pin.r1cs, pin.m)
+    pwant = snark.prove_from_witness(pin.device_pk(), pdev, pin.w)
+    ppath = str(tmp_path / "pinocchio.key")
+    utils.SetupToBinary(ppath, snark.Circuit(pin.m, 1), pin.device_pk(), pin.vk)
+    _, ploaded = utils.UploadPkBinary(ppath)
+    assert capi.pk_eval_count(ploaded.handle) == n
+    pgot = snark.prove_from_witness(ploaded, pdev, pin.w)
+    # (a resident Pinocchio key's A / Ap hold infinity for i <= NPublic, and that is what the file carries: same sums)
+    assert all(getattr(pgot, k) == getattr(pwant, k) for k in snark.Proof.FIELDS)
+
+
 def test_witness_to_proof_falls_back_to_the_exact_quotient_for_a_violated_constraint():
     """A witness that breaks a constraint makes A B - C a non-multiple of Z: the reference still returns floor(px / Z) (remainder
     discarded, groth16.go:266).  gs_groth16_prove_witness detects the violation and takes that route: same (meaningless) proof."""
