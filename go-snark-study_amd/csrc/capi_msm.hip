@@ -251,6 +251,9 @@ static void ctx_create(Ctx& c, int logical, int device) {
     else GS_HIP(hipStreamCreateWithPriority(&a, hipStreamNonBlocking, no_prio ? least : greatest));
   }
   for (auto& p : c.pinned) GS_HIP(hipHostMalloc(&p, Ctx::kPinnedBytes, hipHostMallocDefault));
+  c.bad_dev.alloc(Ctx::kSlots * 4);
+  GS_HIP(hipHostMalloc(reinterpret_cast<void**>(&c.bad_host), Ctx::kSlots * 4, hipHostMallocDefault));
+  memset(c.bad_host, 0, Ctx::kSlots * 4);
   c.stream = c.main_stream;
   c.ready = true;
 }
@@ -274,6 +277,9 @@ static void ctx_destroy(Ctx& c) {
     if (pp) (void)hipHostFree(pp);
     pp = nullptr;
   }
+  if (c.bad_host) (void)hipHostFree(c.bad_host);
+  c.bad_host = nullptr;
+  c.bad_dev.release();
   if (c.copy_stream) (void)hipStreamDestroy(c.copy_stream);
   c.copy_stream = nullptr;
   for (int b = 0; b < Ctx::kStageBuffers; ++b) {

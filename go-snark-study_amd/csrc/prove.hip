@@ -47,14 +47,6 @@ struct DevScalars {            // a scalar vector used by a prove call (not owne
 struct ProveState {
   DevBuf hx[Ctx::kSlots];                       // hx = floor(px / Z) -- or H's values on the evaluation-basis route --, one per slot (standard form)
   DevBuf up_w, up_px, up_a, up_b, up_o;         // uploads of host operands / results (blocking entry points only)
-  DevBuf bad_dev;                               // violated-constraint counters of the evaluation-basis route, one word per slot ...
-  uint32_t* bad_host = nullptr;                 // ... and their pinned host copies (written by an async copy behind the check kernel)
-  ProveState() {
-    bad_dev.alloc(Ctx::kSlots * 4);
-    GS_HIP(hipHostMalloc(reinterpret_cast<void**>(&bad_host), Ctx::kSlots * 4, hipHostMallocDefault));
-    memset(bad_host, 0, Ctx::kSlots * 4);
-  }
-  ~ProveState() { if (bad_host && !process_exiting()) (void)hipHostFree(bad_host); }
 };
 ProveState& prove_state(Ctx& c) { return c.state<ProveState>(c.prove_state); }
 
@@ -205,10 +197,9 @@ int groth16_enqueue(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, const S
     bool have_hx = false;
     if (px.hv_slice) have_hx = true;                                           // H's values came from another rank
     else if (eval) {                                                           // H's values, for the evaluation-basis table
-      ProveState& ps = prove_state(c);
-      px.produce_hv(c, hxbuf.as<uint32_t>(), ps.bad_dev.as<uint32_t>() + parity);
-      GS_HIP(hipMemcpyAsync(ps.bad_host + parity, ps.bad_dev.as<uint32_t>() + parity, 4, hipMemcpyDeviceToHost, c.stream));
-      st.bad_host = ps.bad_host + parity;
+      px.produce_hv(c, hxbuf.as<uint32_t>(), c.bad_dev.as<uint32_t>() + parity);
+      GS_HIP(hipMemcpyAsync(c.bad_host + parity, c.bad_dev.as<uint32_t>() + parity, 4, hipMemcpyDeviceToHost, c.stream));
+      st.bad_host = c.bad_host + parity;
       have_hx = true;
     }
     if (!have_hx && px.produce_hx && nh) have_hx = px.produce_hx(c, hxbuf.as<uint32_t>());  // H from the constraint values (satisfying witness)
@@ -426,10 +417,9 @@ int pinocchio_enqueue(Ctx& c, PinocchioPkObj* pk, DevScalars w, DevScalars px, i
     st.tpoly = std::make_shared<PhaseTimer>(c.stream);
     bool have_hx = false;
     if (eval) {                                                                 // H's values, for the evaluation-basis table
-      ProveState& ps = prove_state(c);
-      px.produce_hv(c, hxbuf.as<uint32_t>(), ps.bad_dev.as<uint32_t>() + parity);
-      GS_HIP(hipMemcpyAsync(ps.bad_host + parity, ps.bad_dev.as<uint32_t>() + parity, 4, hipMemcpyDeviceToHost, c.stream));
-      st.bad_host = ps.bad_host + parity;
+      px.produce_hv(c, hxbuf.as<uint32_t>(), c.bad_dev.as<uint32_t>() + parity);
+      GS_HIP(hipMemcpyAsync(c.bad_host + parity, c.bad_dev.as<uint32_t>() + parity, 4, hipMemcpyDeviceToHost, c.stream));
+      st.bad_host = c.bad_host + parity;
       have_hx = true;
     }
     if (!have_hx && px.produce_hx && nh) have_hx = px.produce_hx(c, hxbuf.as<uint32_t>());   // H from the constraint values (satisfying witness)
@@ -858,15 +848,14 @@ int gs_groth16_witness_values(gs_handle hpk, gs_handle hr1cs, gs_handle hw, gs_h
     }
     StreamScope sc(c, c.aux_stream[1]);             // the stream that carries every proof's polynomial stage (gs_r1cs_px)
     PhaseTimer t(c.stream);
-    ProveState& ps = prove_state(c);
-    uint32_t* bad = ps.bad_dev.as<uint32_t>() + Ctx::kBlockingSlot;
+    uint32_t* bad = c.bad_dev.as<uint32_t>() + Ctx::kBlockingSlot;
     r1cs_values_dev(c, *o, w->buf.as<uint32_t>());
     r1cs_check_dev(c, o->vals.as<uint32_t>(), o->n, pk->nz - 1, bad);
     hx_values_dev(c, o->vals.as<uint32_t>(), o->n, pk->nz - 1, hv->buf.as<uint32_t>());
-    GS_HIP(hipMemcpyAsync(ps.bad_host + Ctx::kBlockingSlot, bad, 4, hipMemcpyDeviceToHost, c.stream));
+    GS_HIP(hipMemcpyAsync(c.bad_host + Ctx::kBlockingSlot, bad, 4, hipMemcpyDeviceToHost, c.stream));
     t.stop();
     GS_HIP(hipStreamSynchronize(c.stream));
-    *violated = ps.bad_host[Ctx::kBlockingSlot];
+    *violated = c.bad_host[Ctx::kBlockingSlot];
     if (!c.any_inflight()) reset_timing(c);
     c.timing.poly_ms = t.ms();
     c.timing.total_ms = c.timing.poly_ms;

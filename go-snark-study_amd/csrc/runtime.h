@@ -142,6 +142,10 @@ struct Ctx {
   static constexpr int kSlots = kMaxInFlight + 1;    // + one set for the blocking entry points (serialised by `mu`), so a blocking
   static constexpr int kBlockingSlot = kMaxInFlight; //   call made while tickets are outstanding never touches their result staging
   void* pinned[3 * kSlots] = {};                     // host staging of the result downloads (3 per slot)
+  // violated-constraint counters of the witness routes, one word per slot: device words + their pinned host copies (an async copy
+  // behind the check kernel writes them; the collector reads them).  Context-owned, so they outlive gs_trim while tickets are out.
+  DevBuf bad_dev;
+  uint32_t* bad_host = nullptr;
   static constexpr int kStageBuffers = 2;            // pinned staging of uploads from pageable caller memory (hostcopy.h), lazy
   static constexpr size_t kStageBytes = 4u << 20;
   void* stage[kStageBuffers] = {};

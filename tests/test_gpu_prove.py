@@ -959,6 +959,14 @@ def test_witness_to_proof_falls_back_to_the_exact_quotient_for_a_violated_constr
         assert (got.PiA, got.PiB, got.PiC) == (want.PiA, want.PiB, want.PiC), on
         assert [(p.PiA, p.PiB, p.PiC) for p in res] == [(q.PiA, q.PiB, q.PiC) for q in (good, want, good)], on
     assert not groth16.VerifyProof(inst.vk, got, capi.u64_to_ints(w_bad[1:2]))
+    # gs_trim between begin and end drops every cached workspace; the violated-constraint word of the ticket is context-owned
+    # and survives: the bad ticket is still detected and repeated exactly, the good one still collected
+    t_bad = groth16.prove_witness_begin(inst.device_pk(), dev, wh, r, s)
+    t_good = groth16.prove_witness_begin(inst.device_pk(), dev, inst.w, r, s)
+    capi.trim()
+    p_bad, p_good = groth16.prove_end(t_bad), groth16.prove_end(t_good)
+    assert (p_bad.PiA, p_bad.PiB, p_bad.PiC) == (want.PiA, want.PiB, want.PiC)
+    assert (p_good.PiA, p_good.PiB, p_good.PiC) == (good.PiA, good.PiB, good.PiC)
 
 
 def test_memory_accounting_and_table_eviction_leave_results_unchanged():
