@@ -87,3 +87,38 @@ def msm_g1_sharded(bases, scalars, n_local, group=None):
 
 def msm_g2_sharded(bases, scalars, n_local, group=None):
     return msm_sharded(capi.msm_resident(bases, scalars, n_local, g2=True), True, group)
+
+
+# ---- values route: the owner of a proof scatters H's values ------------------------------------------------
+def owner_of(proof_index, world):
+    """The ranks take turns with the polynomial stage: proof i is owned by rank i mod world."""
+    return proof_index % world
+
+
+def scatter_scalars(full_u64, total, root, group=None):
+    """torch.distributed twin of gs_scalars_scatter (same contiguous split: shard_range): rank `root` passes the [total, 4] uint64
+    array, the others None; every rank returns ITS slice.  Backend nccl (= RCCL) on the GPU box, gloo in the CPU tests.  The
+    library's own scatter (ncclSend / ncclRecv between resident vectors, no host round trip) is what bench.py uses; this one is
+    for hosts that already drive their collectives through torch."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    lo, hi = shard_range(total, world, rank)
+    if world == 1:
+        return np.ascontiguousarray(full_u64, dtype=np.uint64).reshape(-1, 4)[lo:hi].copy()
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    # dist.scatter wants equal shapes: pad every slice to the longest (ceil(total / world)) rows of 4 int64 words
+    rows = -(-total // world) if total else 0
+    mine = torch.zeros((max(rows, 1), 4), dtype=torch.int64, device=dev)
+    chunks = None
+    if rank == root:
+        full = np.ascontiguousarray(full_u64, dtype=np.uint64).reshape(-1, 4)
+        if full.shape[0] != total:
+            raise ValueError("scatter_scalars: the root's vector has %d rows, total = %d" % (full.shape[0], total))
+        chunks = []
+        for r in range(world):
+            a, b = shard_range(total, world, r)
+            pad = np.zeros((max(rows, 1), 4), dtype=np.uint64)
+            pad[:b - a] = full[a:b]
+            chunks.append(torch.from_numpy(pad.view(np.int64)).to(dev))
+    dist.scatter(mine, chunks, src=root, group=group)
+    return mine.cpu().numpy().view(np.uint64)[:hi - lo].copy()

@@ -84,3 +84,40 @@ def test_shard_ranges_partition_the_terms():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _scatter_worker(rank, world, port, total, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import gosnark_amd  # noqa: F401
+        from gosnark_amd import parallel
+        import gpu_util as U
+        ok = True
+        for proof in range(world + 1):                    # the owner rotates: every rank is the root once, rank 0 twice
+            root = parallel.owner_of(proof, world)
+            full = U.rand_scalars_u64(total, 100 + proof)          # identical on every rank (seeded): the reference for the check
+            got = parallel.scatter_scalars(full if rank == root else None, total, root)
+            lo, hi = parallel.shard_range(total, world, rank)
+            ok = ok and got.shape == (hi - lo, 4) and np.array_equal(got, full[lo:hi])
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,total", [(2, 37), (3, 8), (3, 2)])
+def test_values_route_scatter_with_rotating_owner(world, total):
+    """The exchange of the strong-scaling route at world size 2 and 3 on CPU: the proof's owner scatters the
+    values of H, every rank receives exactly its slice of the contiguous split -- ragged splits and a rank with an empty slice
+    included -- whoever the owner is."""
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_scatter_worker, args=(r, world, port, total, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    assert all(ret.get(r) for r in range(world)), dict(ret)
