@@ -11,7 +11,7 @@
 #   ab <variant>... [: bench args]    bench.py (--no-check --no-extras --cpu-log2n 0) for the in-tree library and every
 #                                     gpurun_variants/lib_<variant>.so (GS_LIB), two rounds, pipelined + blocking 2^20 and
 #                                     pipelined 2^16 unless bench args are given after ':'       -> ab.txt
-#   env <NAME=VALUE>... [: bench args] same, but the variants are environment settings (e.g. GS_FOLD_MAX=16)  -> ab_env.txt
+#   env <NAME=VALUE[,NAME=VALUE]>... [: bench args] same, but the variants are environment settings (e.g. GS_FOLD_MAX=16)  -> ab_env.txt
 #   stats <name> [bench args]         rocprofv3 --kernel-trace --stats of a bench.py run      -> stats_<name>.csv
 #   trace <name> [bench args]         rocprofv3 --kernel-trace, timeline of the LAST step (start ms, duration ms, kernel)
 #                                     + per-kernel sums; GS_NO_OVERLAP=1 in the environment serialises the streams -> timeline_<name>.txt
@@ -82,7 +82,7 @@ while [ $# -gt 0 ]; do
       for a in "${ARGS[@]}"; do if [ "$a" = ":" ]; then seen=1; elif [ $seen = 0 ]; then VARS+=("$a"); else BARGS+=("$a"); fi; done
       F=$OUT/ab.txt; [ $ACT = env ] && F=$OUT/ab_env.txt
       for round in 1 2; do for v in "" "${VARS[@]}"; do
-        ( if [ -n "$v" ]; then if [ $ACT = ab ]; then export GS_LIB=$ROOT/gpurun_variants/lib_$v.so; else export "$v"; fi; fi
+        ( if [ -n "$v" ]; then if [ $ACT = ab ]; then export GS_LIB=$ROOT/gpurun_variants/lib_$v.so; else for kv in ${v//,/ }; do export "$kv"; done; fi; fi
           if [ ${#BARGS[@]} -gt 0 ]; then echo -n "${BARGS[*]}, ${v:-default}: "; quick_bench "${BARGS[@]}"; else default_ab "${v:-default}"; fi )
       done; done 2>&1 | tee -a "$F" ;;
     stats)
