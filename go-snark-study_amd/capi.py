@@ -134,6 +134,17 @@ _SIGS = {
     "gs_msm_g2_sharded": [Handle, Handle, u64p, intp],
     "gs_groth16_prove_batch": [ctypes.POINTER(Handle), ctypes.c_int, ctypes.POINTER(Handle), ctypes.POINTER(Handle), ctypes.c_size_t,
                                u64p, u64p, u64p, intp],
+    "gs_pinocchio_pk_shard": [Handle, ctypes.c_size_t, ctypes.c_size_t, ctypes.POINTER(Handle)],
+    "gs_pinocchio_pk_shard_to": [Handle, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, ctypes.POINTER(Handle)],
+    "gs_pinocchio_prove_partials": [Handle, Handle, Handle, ctypes.c_size_t, ctypes.c_size_t, u64p, intp],
+    "gs_pinocchio_witness_values": [Handle, Handle, Handle, ctypes.POINTER(Handle), ctypes.POINTER(ctypes.c_uint32)],
+    "gs_pinocchio_prove_partials_values": [Handle, Handle, Handle, ctypes.c_size_t, ctypes.c_size_t, u64p, intp],
+    "gs_pinocchio_combine": [u64p, intp, ctypes.c_size_t, u64p, intp],
+    "gs_pinocchio_prove_multi": [ctypes.POINTER(Handle), ctypes.POINTER(Handle), ctypes.POINTER(Handle), ctypes.c_int, u64p, intp, intp],
+    "gs_pinocchio_prove_multi_values": [ctypes.POINTER(Handle), ctypes.POINTER(Handle), ctypes.POINTER(Handle), ctypes.c_int, u64p, intp, intp],
+    "gs_pinocchio_prove_sharded": [Handle, Handle, Handle, u64p, intp],
+    "gs_pinocchio_prove_sharded_values": [Handle, Handle, Handle, u64p, intp],
+    "gs_pinocchio_prove_batch": [ctypes.POINTER(Handle), ctypes.c_int, ctypes.POINTER(Handle), ctypes.POINTER(Handle), ctypes.c_size_t, u64p, intp],
     "gs_last_timing": [ctypes.POINTER(Timing)],
     "gs_device_timing": [ctypes.c_int, ctypes.POINTER(Timing)],
     "gs_set_window_bits": [ctypes.c_int],

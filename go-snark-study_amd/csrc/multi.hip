@@ -118,6 +118,9 @@ constexpr size_t kProofRecordWords = 52;       // 48 words of sums | inf[5], sha
 struct ProofRecord { uint64_t sums[48]; uint32_t inf[5]; uint32_t shard; uint32_t pad[2]; };
 static_assert(sizeof(ProofRecord) == kProofRecordWords * 8, "the exchanged record is 416 bytes");
 
+struct PinRecord { uint64_t sums[72]; uint32_t inf[8]; uint32_t shard; uint32_t pad; };      // a Pinocchio rank's eight partial sums
+static_assert(sizeof(PinRecord) == 616, "the exchanged Pinocchio record is 616 bytes");
+
 template <int W> struct PointRecord { uint64_t p[W]; uint32_t inf; uint32_t shard; };
 static_assert(sizeof(PointRecord<8>) == 72 && sizeof(PointRecord<16>) == 136, "72 / 136 byte partial-point records");
 
@@ -199,6 +202,54 @@ int check_devices(const gs_handle* a, const gs_handle* b, const gs_handle* c, in
 }
 
 }  // namespace
+
+// Pinocchio: records -> proof, and the two deployment shapes as templates over "how a rank gets its eight sums"
+static int pin_records_to_proof(const std::vector<PinRecord>& all, uint64_t out_proof[72], int inf[8]) {
+  const size_t n = all.size();
+  std::vector<uint64_t> sums(n * 72);
+  std::vector<int> fl(n * 8);
+  for (size_t i = 0; i < n; ++i) {
+    memcpy(&sums[i * 72], all[i].sums, sizeof all[i].sums);
+    for (int k = 0; k < 8; ++k) fl[i * 8 + k] = (int)all[i].inf[k];
+  }
+  return gs_pinocchio_combine(sums.data(), fl.data(), n, out_proof, inf);
+}
+
+template <class Partials>
+static int pinocchio_multi(const gs_handle* pk, const gs_handle* w, const gs_handle* third, int ndev, uint64_t out_proof[72], int inf[8], int* used_rccl,
+                           const char* fn, Partials&& partials) {
+  std::vector<int> phys_of;
+  if (int rc = check_devices(pk, w, third, ndev, fn, phys_of)) return rc;
+  if (!w || !third || !out_proof || !inf) return fail(GS_ERR_ARG, "%s: null argument", fn);
+  std::vector<PinRecord> mine(ndev), all;
+  if (int rc = on_devices(ndev, [&](int d) {
+        int f[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const int rc = partials(d, mine[d].sums, f);
+        for (int k = 0; k < 8; ++k) mine[d].inf[k] = (uint32_t)f[k];
+        mine[d].shard = (uint32_t)d; mine[d].pad = 0;
+        return rc;
+      }, fn)) return rc;
+  if (int rc = exchange(mine, phys_of, all, used_rccl)) return rc;
+  return pin_records_to_proof(all, out_proof, inf);
+}
+
+template <class Partials>
+static int pinocchio_sharded(uint64_t out_proof[72], int inf[8], const char* fn, Partials&& partials) {
+  if (!out_proof || !inf) return fail(GS_ERR_ARG, "%s: null argument", fn);
+  int nranks = 0, rank = -1, local = 0;
+  gs_comm_info(&nranks, &rank, &local, nullptr);
+  if (nranks < 1 || local) return fail(GS_ERR_ARG, "%s: needs the communicator of gs_comm_init_rank (one process per GPU)", fn);
+  PinRecord mine{};
+  int f[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (int rc = partials((size_t)rank, (size_t)nranks, mine.sums, f)) return rc;
+  for (int k = 0; k < 8; ++k) mine.inf[k] = (uint32_t)f[k];
+  mine.shard = (uint32_t)rank;
+  std::vector<PinRecord> all(nranks);
+  if (int rc = gs_comm_allgather(&mine, sizeof mine, all.data())) return rc;
+  for (int i = 0; i < nranks; ++i)
+    if (all[i].shard != (uint32_t)i) return fail(GS_ERR_HIP, "gathered record %d carries shard index %u", i, all[i].shard);
+  return pin_records_to_proof(all, out_proof, inf);
+}
 
 namespace gs {
 void multi_shutdown() {
@@ -418,6 +469,27 @@ int gs_groth16_prove_sharded_values(gs_handle pk, gs_handle w, gs_handle hv_slic
   return gs_groth16_finish(pk, sums, sinf, r, s, out_proof, inf);
 }
 
+// ---- Pinocchio (snark.go:254-289): the same four shapes; a proof is the sum of the ranks' eight partial points, there is no tail ----
+// one process, ndev logical devices: pk[d] the full key or slice d (gs_pinocchio_pk_shard_to), w[d] / px[d] replicas
+int gs_pinocchio_prove_multi(const gs_handle* pk, const gs_handle* w, const gs_handle* px, int ndev, uint64_t out_proof[72], int inf[8], int* used_rccl) {
+  return pinocchio_multi(pk, w, px, ndev, out_proof, inf, used_rccl, "gs_pinocchio_prove_multi",
+                         [&](int d, uint64_t* sums, int* f) { return gs_pinocchio_prove_partials(pk[d], w[d], px[d], (size_t)d, (size_t)ndev, sums, f); });
+}
+// ... hv[d]: device d's slice of H's values (gs_pinocchio_witness_values on the proof's owner, then the scatter)
+int gs_pinocchio_prove_multi_values(const gs_handle* pk, const gs_handle* w, const gs_handle* hv, int ndev, uint64_t out_proof[72], int inf[8], int* used_rccl) {
+  return pinocchio_multi(pk, w, hv, ndev, out_proof, inf, used_rccl, "gs_pinocchio_prove_multi_values",
+                         [&](int d, uint64_t* sums, int* f) { return gs_pinocchio_prove_partials_values(pk[d], w[d], hv[d], (size_t)d, (size_t)ndev, sums, f); });
+}
+// one process per GPU: this rank's shard, the 616-byte records gathered over the communicator of gs_comm_init_rank
+int gs_pinocchio_prove_sharded(gs_handle pk, gs_handle w, gs_handle px, uint64_t out_proof[72], int inf[8]) {
+  return pinocchio_sharded(out_proof, inf, "gs_pinocchio_prove_sharded",
+                           [&](size_t rank, size_t nranks, uint64_t* sums, int* f) { return gs_pinocchio_prove_partials(pk, w, px, rank, nranks, sums, f); });
+}
+int gs_pinocchio_prove_sharded_values(gs_handle pk, gs_handle w, gs_handle hv_slice, uint64_t out_proof[72], int inf[8]) {
+  return pinocchio_sharded(out_proof, inf, "gs_pinocchio_prove_sharded_values",
+                           [&](size_t rank, size_t nranks, uint64_t* sums, int* f) { return gs_pinocchio_prove_partials_values(pk, w, hv_slice, rank, nranks, sums, f); });
+}
+
 // The owner's scatter between processes: rank `root` holds `total` scalars (handle `full`, ignored on the other ranks); every rank
 // -- the root included -- ends up with its slice of the contiguous split of [0, total) (first ranks one longer: the split every
 // sharded entry point uses) in *slice_inout (0 = create).  ncclSend / ncclRecv in one group on the communicator's stream: the
@@ -555,6 +627,46 @@ int gs_groth16_prove_batch(const gs_handle* pk_of_device, int ndev, const gs_han
     }
     return rc;
   }, "gs_groth16_prove_batch");
+}
+
+// snark.GenerateProofs for a batch of independent witnesses (as gs_groth16_prove_batch; the proofs are deterministic: no r, s)
+int gs_pinocchio_prove_batch(const gs_handle* pk_of_device, int ndev, const gs_handle* w, const gs_handle* px, size_t nproofs,
+                             uint64_t* out_proofs /* nproofs x 72 */, int* inf /* nproofs x 8 */) {
+  if (!pk_of_device || ndev < 1 || ndev > kMaxLogicalDevices || (nproofs && (!w || !px || !out_proofs || !inf)))
+    return fail(GS_ERR_ARG, "gs_pinocchio_prove_batch: null argument");
+  std::vector<std::vector<size_t>> work(ndev);
+  for (size_t i = 0; i < nproofs; ++i) {
+    const int ld = handle_device(w[i]);
+    if (ld >= ndev || handle_device(px[i]) != ld || !pk_of_device[ld] || handle_device(pk_of_device[ld]) != ld)
+      return fail(GS_ERR_ARG, "gs_pinocchio_prove_batch: proof %zu: w / px / key do not share one logical device below %d", i, ndev);
+    work[ld].push_back(i);
+  }
+  return on_devices(ndev, [&](int d) -> int {
+    const std::vector<size_t>& q = work[d];
+    std::vector<uint64_t> tickets(q.size(), 0);
+    const size_t depth = Ctx::kMaxInFlight;
+    size_t begun = 0, collected = 0;
+    int rc = GS_OK;
+    for (size_t k = 0; k < q.size() + depth && rc == GS_OK; ++k) {
+      if (k >= depth && collected < begun) {
+        const size_t i = q[collected];
+        rc = gs_pinocchio_prove_end(tickets[collected], out_proofs + i * 72, inf + i * 8);
+        ++collected;
+        if (rc != GS_OK) break;
+      }
+      if (k < q.size()) {
+        const size_t i = q[k];
+        rc = gs_pinocchio_prove_begin(pk_of_device[d], w[i], px[i], &tickets[k]);
+        if (rc == GS_OK) ++begun;
+      }
+    }
+    if (rc != GS_OK) {                                  // leave no ticket behind (as gs_groth16_prove_batch)
+      const std::string first = gs_last_error();
+      for (size_t t = collected; t < begun; ++t) (void)gs_ticket_cancel(tickets[t]);
+      last_error_ref() = first;
+    }
+    return rc;
+  }, "gs_pinocchio_prove_batch");
 }
 
 }  // extern "C"

@@ -29,14 +29,16 @@ struct GrothPkObj : Object {      // groth16.Pk (groth16/groth16.go:15-32), resi
 };
 
 struct PinocchioPkObj : Object {  // snark.Pk (snark.go:16-26), resident
-  size_t nvars = 0, npublic = 0, nz = 0, ng1t = 0;
+  size_t nvars = 0, npublic = 0, nz = 0, ng1t = 0;      // global counts (ng1t = len(G1T))
+  // key slices as GrothPkObj's: the seven per-variable arrays hold entries [w_lo, w_lo + n_w), G1T entries [h_lo, h_lo + n_h)
+  size_t shard_index = 0, shard_count = 1, w_lo = 0, n_w = 0, h_lo = 0, n_h = 0;
   DevBuf a, ap, bp, c, cp, kp, g1t;        // packed affine G1
   DevBuf b2;                               // packed affine G2
   BaseTable t_a, t_ap, t_bp, t_c, t_cp, t_kp, t_g1t, t_b2;
   Divisor z;
   // evaluation-basis copy of G1T (optional, as GrothPkObj::ptd_eval): g1t_eval[j-1] = l_j(tau) * G over the nodes n+1 .. 2n, so that
   // sum_j H(n+j) g1t_eval[j-1] = H(tau) G = sum_i h_i G1T[i]  (snark.go:239-247, 284-286)
-  size_t n_eval = 0;
+  size_t n_eval = 0, e_lo = 0, n_e = 0;     // a slice holds entries [e_lo, e_lo + n_e)
   DevBuf g1t_eval;
   BaseTable t_g1t_eval;
   PinocchioPkObj() : Object(Kind::PinocchioPk) {}

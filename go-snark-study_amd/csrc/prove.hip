@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 #include <functional>
 #include <chrono>
 #include <future>
@@ -358,23 +359,37 @@ struct PinInFlight : InFlightBase {
 
 // snark.GenerateProofs (snark.go:254-289): six G1 sums over w sharing one plan, one G2 sum over w, H(x) = px / Z, one G1 sum
 // over h.  Ticket `parity` owns plan slots 2p / 2p + 1, workspace sets 8p .. 8p + 7 and pinned slots 3p .. 3p + 2.
-int pinocchio_enqueue(Ctx& c, PinocchioPkObj* pk, DevScalars w, DevScalars px, int parity, bool wait_inputs, bool pipelined, PinInFlight& st) {
+// `shard`: the term ranges this call sums over (several GPUs: rank k of N; the eight sums of the ranks add up to the proof).
+int pinocchio_enqueue(Ctx& c, PinocchioPkObj* pk, DevScalars w, DevScalars px, const Shard& shard, int parity, bool wait_inputs, bool pipelined,
+                      PinInFlight& st) {
   DevBuf& hxbuf = prove_state(c).hx[parity];
   if (w.n != pk->nvars) return fail(GS_ERR_SHAPE, "len(w) = %zu but the key has %zu variables", w.n, pk->nvars);
-  const bool eval = (bool)px.produce_hv;        // h-MSM over H's values against g1t_eval (the caller checked the key has one)
+  const bool eval = (bool)px.produce_hv || px.hv_slice;   // h-MSM over H's values against g1t_eval (the caller checked the key has one)
   const size_t nh = eval ? pk->n_eval : quotient_len(px.n, pk->nz);
   if (!eval && nh > pk->ng1t) return fail(GS_ERR_SHAPE, "len(hx) = %zu exceeds len(G1T) = %zu (snark.go:284-286)", nh, pk->ng1t);
+  const bool sliced = pk->shard_count > 1;
+  if (sliced && (shard.index != pk->shard_index || shard.count != pk->shard_count))
+    return fail(GS_ERR_ARG, "this key holds shard %zu of %zu of the term ranges only: call gs_pinocchio_prove_partials with that shard "
+                "(asked for %zu of %zu)", pk->shard_index, pk->shard_count, shard.index, shard.count);
+  size_t wlo, whi, hlo, hhi;                     // exactly groth16_enqueue's ranges
+  shard_range(w.n, shard, wlo, whi);
+  if (sliced && eval) { hlo = pk->e_lo; hhi = pk->e_lo + pk->n_e; }
+  else if (sliced) { hlo = std::min(pk->h_lo, nh); hhi = std::min(pk->h_lo + pk->n_h, nh); }
+  else shard_range(nh, shard, hlo, hhi);
+  const size_t held_lo = eval ? pk->e_lo : pk->h_lo;
+  const size_t wbase = wlo - pk->w_lo, hbase = hlo - std::min(held_lo, hlo);
   {
-    const int cw = choose_window_bits((uint32_t)w.n, c.window_bits), ch = choose_window_bits((uint32_t)std::max<size_t>(nh, 1), c.window_bits);
-    ensure_table_g1(c, pk->t_a, pk->a.as<uint32_t>(), pk->nvars, cw);
-    ensure_table_g1(c, pk->t_ap, pk->ap.as<uint32_t>(), pk->nvars, cw);
-    ensure_table_g1(c, pk->t_bp, pk->bp.as<uint32_t>(), pk->nvars, cw);
-    ensure_table_g1(c, pk->t_c, pk->c.as<uint32_t>(), pk->nvars, cw);
-    ensure_table_g1(c, pk->t_cp, pk->cp.as<uint32_t>(), pk->nvars, cw);
-    ensure_table_g1(c, pk->t_kp, pk->kp.as<uint32_t>(), pk->nvars, cw);
-    ensure_table_g2(c, pk->t_b2, pk->b2.as<uint32_t>(), pk->nvars, cw);
-    if (eval) ensure_table_g1(c, pk->t_g1t_eval, pk->g1t_eval.as<uint32_t>(), pk->n_eval, ch);
-    else ensure_table_g1(c, pk->t_g1t, pk->g1t.as<uint32_t>(), pk->ng1t, ch);
+    const int cw = choose_window_bits((uint32_t)std::max<size_t>(whi - wlo, 1), c.window_bits);
+    const int ch = choose_window_bits((uint32_t)std::max<size_t>(hhi - hlo, 1), c.window_bits);
+    ensure_table_g1(c, pk->t_a, pk->a.as<uint32_t>(), pk->n_w, cw);
+    ensure_table_g1(c, pk->t_ap, pk->ap.as<uint32_t>(), pk->n_w, cw);
+    ensure_table_g1(c, pk->t_bp, pk->bp.as<uint32_t>(), pk->n_w, cw);
+    ensure_table_g1(c, pk->t_c, pk->c.as<uint32_t>(), pk->n_w, cw);
+    ensure_table_g1(c, pk->t_cp, pk->cp.as<uint32_t>(), pk->n_w, cw);
+    ensure_table_g1(c, pk->t_kp, pk->kp.as<uint32_t>(), pk->n_w, cw);
+    ensure_table_g2(c, pk->t_b2, pk->b2.as<uint32_t>(), pk->n_w, cw);
+    if (eval) ensure_table_g1(c, pk->t_g1t_eval, pk->g1t_eval.as<uint32_t>(), pk->n_e, ch);
+    else ensure_table_g1(c, pk->t_g1t, pk->g1t.as<uint32_t>(), pk->n_h, ch);
     hxbuf.ensure(std::max<size_t>(nh, 1) * 32);
   }
   st.total = std::make_unique<PhaseTimer>(c.main_stream);
@@ -390,7 +405,7 @@ int pinocchio_enqueue(Ctx& c, PinocchioPkObj* pk, DevScalars w, DevScalars px, i
   {                                                              // aux 1: plan(w)
     StreamScope sc(c, c.aux_stream[1]);
     st.tplanw = std::make_shared<PhaseTimer>(c.stream);
-    build_plan(c, 2 * parity, w.p, (uint32_t)w.n, plan_w, {{1, true}, {6, false}});
+    build_plan(c, 2 * parity, w.p + wlo * 8, (uint32_t)(whi - wlo), plan_w, {{1, true}, {6, false}});
     st.tplanw->stop();
     GS_HIP(hipEventRecord(st.planw, c.stream));
   }
@@ -400,10 +415,10 @@ int pinocchio_enqueue(Ctx& c, PinocchioPkObj* pk, DevScalars w, DevScalars px, i
     // A and Ap run over i > NPublic only (snark.go:265-268): their first npublic+1 points were forced
     // to infinity at key creation; Bp, C, Cp, Kp and B run over all variables (:270-278).
     if (pipelined) c.next_tails(plan_w.n);
-    msm_enqueue_g2(c, plan_w, {MsmBase{&pk->t_b2, 0}}, ws + 6, pin + 1, st.pend_g2w, c.tail_stream(0));
+    msm_enqueue_g2(c, plan_w, {MsmBase{&pk->t_b2, wbase}}, ws + 6, pin + 1, st.pend_g2w, c.tail_stream(0));
     GS_HIP(hipEventRecord(st.done_g2, c.tail_stream(0)));
-    msm_enqueue_g1(c, plan_w, {MsmBase{&pk->t_a, 0}, MsmBase{&pk->t_ap, 0}, MsmBase{&pk->t_bp, 0}, MsmBase{&pk->t_c, 0},
-                               MsmBase{&pk->t_cp, 0}, MsmBase{&pk->t_kp, 0}}, ws + 0, pin + 0, st.pend_g1w, c.tail_stream(1));
+    msm_enqueue_g1(c, plan_w, {MsmBase{&pk->t_a, wbase}, MsmBase{&pk->t_ap, wbase}, MsmBase{&pk->t_bp, wbase}, MsmBase{&pk->t_c, wbase},
+                               MsmBase{&pk->t_cp, wbase}, MsmBase{&pk->t_kp, wbase}}, ws + 0, pin + 0, st.pend_g1w, c.tail_stream(1));
     GS_HIP(hipEventRecord(st.done_g1w, c.tail_stream(1)));
   }
   {                                                              // aux 1 again: H(x), plan(h)
@@ -416,7 +431,8 @@ int pinocchio_enqueue(Ctx& c, PinocchioPkObj* pk, DevScalars w, DevScalars px, i
     }
     st.tpoly = std::make_shared<PhaseTimer>(c.stream);
     bool have_hx = false;
-    if (eval) {                                                                 // H's values, for the evaluation-basis table
+    if (px.hv_slice) have_hx = true;                                            // H's values came from another rank
+    else if (eval) {                                                            // H's values, for the evaluation-basis table
       px.produce_hv(c, hxbuf.as<uint32_t>(), c.bad_dev.as<uint32_t>() + parity);
       GS_HIP(hipMemcpyAsync(c.bad_host + parity, c.bad_dev.as<uint32_t>() + parity, 4, hipMemcpyDeviceToHost, c.stream));
       st.bad_host = c.bad_host + parity;
@@ -429,14 +445,14 @@ int pinocchio_enqueue(Ctx& c, PinocchioPkObj* pk, DevScalars w, DevScalars px, i
     }
     st.tpoly->stop();
     st.tplanh = std::make_shared<PhaseTimer>(c.stream);
-    build_plan(c, 2 * parity + 1, hxbuf.as<uint32_t>(), (uint32_t)nh, plan_h, {{1, false}});
+    build_plan(c, 2 * parity + 1, px.hv_slice ? px.hv_slice : hxbuf.as<uint32_t>() + hlo * 8, (uint32_t)(hhi - hlo), plan_h, {{1, false}});
     st.tplanh->stop();
     GS_HIP(hipEventRecord(st.planh, c.stream));
   }
   {                                                              // main again: the accumulation over h
     StreamScope sc(c, c.main_stream);
     GS_HIP(hipStreamWaitEvent(c.stream, st.planh, 0));
-    msm_enqueue_g1(c, plan_h, {MsmBase{eval ? &pk->t_g1t_eval : &pk->t_g1t, 0}}, ws + 7, pin + 2, st.pend_h, pipelined ? c.tail_stream(1) : nullptr);   // :284-286
+    msm_enqueue_g1(c, plan_h, {MsmBase{eval ? &pk->t_g1t_eval : &pk->t_g1t, hbase}}, ws + 7, pin + 2, st.pend_h, pipelined ? c.tail_stream(1) : nullptr);   // :284-286
     GS_HIP(hipEventRecord(st.done_h, pipelined ? c.tail_stream(1) : c.main_stream));
   }
   st.total->stop();
@@ -476,10 +492,10 @@ int pinocchio_collect(Ctx& c, PinInFlight& st, uint64_t out[72], int inf[8]) {
   return GS_OK;
 }
 
-int pinocchio_prove_impl(Ctx& c, PinocchioPkObj* pk, DevScalars w, DevScalars px, uint64_t out[72], int inf[8]) {
+int pinocchio_prove_impl(Ctx& c, PinocchioPkObj* pk, DevScalars w, DevScalars px, uint64_t out[72], int inf[8], const Shard& shard = Shard{}) {
   for (;;) {
     PinInFlight st;
-    int rc = pinocchio_enqueue(c, pk, w, px, Ctx::kBlockingSlot, true, false, st);
+    int rc = pinocchio_enqueue(c, pk, w, px, shard, Ctx::kBlockingSlot, true, false, st);
     if (rc != GS_OK) return rc;
     rc = pinocchio_collect(c, st, out, inf);
     if (rc != kRetryExact) return rc;
@@ -826,40 +842,45 @@ static bool hx_shape(size_t n, size_t nz);
 // vector (*hv_inout as gs_r1cs_px's px_inout); *violated = number of roots of Z at which the witness breaks a constraint (the values are
 // then meaningless: take gs_r1cs_px + gs_groth16_prove_partials).  The owner scatters slice k of the vector to rank k
 // (gs_scalars_clone between the logical devices of one process, gs_scalars_scatter over RCCL between processes), and ...
+static int witness_values_impl(Ctx& c, const char* fn, size_t nz, size_t n_eval, gs_handle hr1cs, gs_handle hw, gs_handle* hv_inout, uint32_t* violated) {
+  R1csObj* o = c.get<R1csObj>(hr1cs, Kind::R1cs);
+  Scalars* w = c.get<Scalars>(hw, Kind::Scalars);
+  if (!o || !w || !hv_inout || !violated) return fail(GS_ERR_ARG, "%s: bad handle or null output", fn);
+  if (w->n != o->m) return fail(GS_ERR_SHAPE, "len(w) = %zu but the system has %zu variables", w->n, o->m);
+  if (!hx_shape(o->n, nz) || n_eval != o->n)
+    return fail(GS_ERR_SHAPE, "%s: the key has no evaluation-basis array for a system of %zu constraints", fn, o->n);
+  Scalars* hv = nullptr;
+  if (*hv_inout) {
+    hv = c.get<Scalars>(*hv_inout, Kind::Scalars);
+    if (!hv || hv->n != o->n) return fail(GS_ERR_ARG, "%s: the output handle does not hold n = %zu values", fn, o->n);
+  } else {
+    auto fresh = std::make_unique<Scalars>();
+    fresh->n = o->n;
+    fresh->buf.alloc(o->n * 32);
+    hv = fresh.get();
+    *hv_inout = c.put(std::move(fresh));
+  }
+  StreamScope sc(c, c.aux_stream[1]);             // the stream that carries every proof's polynomial stage (gs_r1cs_px)
+  PhaseTimer t(c.stream);
+  uint32_t* bad = c.bad_dev.as<uint32_t>() + Ctx::kBlockingSlot;
+  r1cs_values_dev(c, *o, w->buf.as<uint32_t>());
+  r1cs_check_dev(c, o->vals.as<uint32_t>(), o->n, nz - 1, bad);
+  hx_values_dev(c, o->vals.as<uint32_t>(), o->n, nz - 1, hv->buf.as<uint32_t>());
+  GS_HIP(hipMemcpyAsync(c.bad_host + Ctx::kBlockingSlot, bad, 4, hipMemcpyDeviceToHost, c.stream));
+  t.stop();
+  GS_HIP(hipStreamSynchronize(c.stream));
+  *violated = c.bad_host[Ctx::kBlockingSlot];
+  if (!c.any_inflight()) reset_timing(c);
+  c.timing.poly_ms = t.ms();
+  c.timing.total_ms = c.timing.poly_ms;
+  return GS_OK;
+}
+
 int gs_groth16_witness_values(gs_handle hpk, gs_handle hr1cs, gs_handle hw, gs_handle* hv_inout, uint32_t* violated) {
   return guarded([&](Ctx& c) -> int {
     GrothPkObj* pk = c.get<GrothPkObj>(hpk, Kind::GrothPk);
-    R1csObj* o = c.get<R1csObj>(hr1cs, Kind::R1cs);
-    Scalars* w = c.get<Scalars>(hw, Kind::Scalars);
-    if (!pk || !o || !w || !hv_inout || !violated) return fail(GS_ERR_ARG, "gs_groth16_witness_values: bad handle or null output");
-    if (w->n != o->m) return fail(GS_ERR_SHAPE, "len(w) = %zu but the system has %zu variables", w->n, o->m);
-    if (!hx_shape(o->n, pk->nz) || pk->n_eval != o->n)
-      return fail(GS_ERR_SHAPE, "gs_groth16_witness_values: the key has no evaluation-basis array for a system of %zu constraints", o->n);
-    Scalars* hv = nullptr;
-    if (*hv_inout) {
-      hv = c.get<Scalars>(*hv_inout, Kind::Scalars);
-      if (!hv || hv->n != o->n) return fail(GS_ERR_ARG, "gs_groth16_witness_values: the output handle does not hold n = %zu values", o->n);
-    } else {
-      auto fresh = std::make_unique<Scalars>();
-      fresh->n = o->n;
-      fresh->buf.alloc(o->n * 32);
-      hv = fresh.get();
-      *hv_inout = c.put(std::move(fresh));
-    }
-    StreamScope sc(c, c.aux_stream[1]);             // the stream that carries every proof's polynomial stage (gs_r1cs_px)
-    PhaseTimer t(c.stream);
-    uint32_t* bad = c.bad_dev.as<uint32_t>() + Ctx::kBlockingSlot;
-    r1cs_values_dev(c, *o, w->buf.as<uint32_t>());
-    r1cs_check_dev(c, o->vals.as<uint32_t>(), o->n, pk->nz - 1, bad);
-    hx_values_dev(c, o->vals.as<uint32_t>(), o->n, pk->nz - 1, hv->buf.as<uint32_t>());
-    GS_HIP(hipMemcpyAsync(c.bad_host + Ctx::kBlockingSlot, bad, 4, hipMemcpyDeviceToHost, c.stream));
-    t.stop();
-    GS_HIP(hipStreamSynchronize(c.stream));
-    *violated = c.bad_host[Ctx::kBlockingSlot];
-    if (!c.any_inflight()) reset_timing(c);
-    c.timing.poly_ms = t.ms();
-    c.timing.total_ms = c.timing.poly_ms;
-    return GS_OK;
+    if (!pk) return fail(GS_ERR_ARG, "gs_groth16_witness_values: bad proving-key handle");
+    return witness_values_impl(c, "gs_groth16_witness_values", pk->nz, pk->n_eval, hr1cs, hw, hv_inout, violated);
   }, true, true, hpk);
 }
 
@@ -996,6 +1017,7 @@ int gs_pinocchio_pk_create(gs_handle a, gs_handle ap, gs_handle b_g2, gs_handle 
     if (npublic + 1 > nvars) return fail(GS_ERR_SHAPE, "NPublic + 1 > NVars");
     auto pk = std::make_unique<PinocchioPkObj>();
     pk->nvars = nvars; pk->npublic = npublic; pk->nz = nz; pk->ng1t = T->n;
+    pk->n_w = nvars; pk->n_h = T->n;                                // a full key
     copy_points(c, A, kG1Aff, pk->a);
     copy_points(c, Ap, kG1Aff, pk->ap);
     copy_points(c, Bp, kG1Aff, pk->bp);
@@ -1038,7 +1060,7 @@ int gs_pinocchio_prove_begin(gs_handle hpk, gs_handle hw, gs_handle hpx, uint64_
     if (parity < 0) return fail(GS_ERR_BUSY, "gs_pinocchio_prove_begin: three operations are already outstanding; call gs_pinocchio_prove_end first");
     auto st = std::make_unique<PinInFlight>();
     st->keep = {c.share<Object>(hpk, Kind::PinocchioPk), c.share<Object>(hw, Kind::Scalars), c.share<Object>(hpx, Kind::Scalars)};
-    const int rc = pinocchio_enqueue(c, pk, DevScalars{w->buf.as<uint32_t>(), w->n}, DevScalars{px->buf.as<uint32_t>(), px->n}, parity, false, true, *st);
+    const int rc = pinocchio_enqueue(c, pk, DevScalars{w->buf.as<uint32_t>(), w->n}, DevScalars{px->buf.as<uint32_t>(), px->n}, Shard{}, parity, false, true, *st);
     if (rc != GS_OK) return rc;
     st->ticket = c.new_ticket();
     *ticket = st->ticket;
@@ -1074,6 +1096,123 @@ int gs_pinocchio_prove_resident(gs_handle hpk, gs_handle hw, gs_handle hpx, uint
     reset_timing(c);
     return pinocchio_prove_impl(c, pk, DevScalars{w->buf.as<uint32_t>(), w->n}, DevScalars{px->buf.as<uint32_t>(), px->n}, out_proof, inf);
   }, true, false, hpk);
+}
+
+// ---- Pinocchio over several GPUs (SURVEY 8e applied to snark.go:254-289) ------------------------------------------------------
+// A Pinocchio proof IS its eight MSM sums (there is no tail): rank k of N sums its term ranges, the eight partial points of the
+// ranks add up to the proof.  Key slices, partial sums (from px, or from the owner's slice of H's values), and the addition.
+static void pin_set_shard(PinocchioPkObj& pk, size_t index, size_t count) {
+  Shard sh; sh.index = index; sh.count = count;
+  size_t lo, hi;
+  pk.shard_index = index; pk.shard_count = count;
+  shard_range(pk.nvars, sh, lo, hi);
+  pk.w_lo = lo; pk.n_w = hi - lo;
+  shard_range(pk.ng1t, sh, lo, hi);
+  pk.h_lo = lo; pk.n_h = hi - lo;
+}
+
+static int pinocchio_pk_shard_impl(Ctx& c, Ctx& from, PinocchioPkObj* full, size_t shard_index, size_t shard_count, gs_handle* out) {
+  if (!full || !out) return fail(GS_ERR_ARG, "gs_pinocchio_pk_shard: bad proving-key handle or null output");
+  if (full->shard_count != 1) return fail(GS_ERR_ARG, "gs_pinocchio_pk_shard: the source key is itself a slice");
+  if (shard_count == 0 || shard_index >= shard_count) return fail(GS_ERR_ARG, "gs_pinocchio_pk_shard: bad shard %zu of %zu", shard_index, shard_count);
+  auto pk = std::make_unique<PinocchioPkObj>();
+  pk->nvars = full->nvars; pk->npublic = full->npublic; pk->nz = full->nz; pk->ng1t = full->ng1t;
+  pin_set_shard(*pk, shard_index, shard_count);
+  // (A / Ap of the full key already hold infinity for i <= NPublic, snark.go:265: the slices inherit it)
+  const DevBuf* src[6] = {&full->a, &full->ap, &full->bp, &full->c, &full->cp, &full->kp};
+  DevBuf* dst[6] = {&pk->a, &pk->ap, &pk->bp, &pk->c, &pk->cp, &pk->kp};
+  for (int i = 0; i < 6; ++i) copy_slice(c, from, PkSrc{src[i], pk->w_lo}, pk->n_w, kG1Aff, *dst[i]);
+  copy_slice(c, from, PkSrc{&full->b2, pk->w_lo}, pk->n_w, kG2Aff, pk->b2);
+  copy_slice(c, from, PkSrc{&full->g1t, pk->h_lo}, pk->n_h, kG1Aff, pk->g1t);
+  if (full->n_eval) {
+    Shard sh; sh.index = shard_index; sh.count = shard_count;
+    size_t lo, hi;
+    shard_range(full->n_eval, sh, lo, hi);
+    pk->n_eval = full->n_eval; pk->e_lo = lo; pk->n_e = hi - lo;
+    copy_slice(c, from, PkSrc{&full->g1t_eval, lo}, pk->n_e, kG1Aff, pk->g1t_eval);
+  }
+  {                                                     // Z travels with every slice
+    DevBuf zc(std::max<size_t>(full->nz, 1) * 32);
+    copy_between(c, zc.p, from, full->z.b_std.p, full->nz * 32);
+    divisor_init(c, pk->z, zc.as<uint32_t>(), full->nz);
+    GS_HIP(hipStreamSynchronize(c.stream));             // `zc` is released here
+  }
+  GS_HIP(hipStreamSynchronize(c.stream));
+  *out = c.put(std::move(pk));
+  return GS_OK;
+}
+
+int gs_pinocchio_pk_shard(gs_handle hfull, size_t shard_index, size_t shard_count, gs_handle* out) {
+  return guarded([&](Ctx& c) -> int {
+    return pinocchio_pk_shard_impl(c, c, c.get<PinocchioPkObj>(hfull, Kind::PinocchioPk), shard_index, shard_count, out);
+  }, true, false, hfull);
+}
+
+int gs_pinocchio_pk_shard_to(gs_handle hfull, size_t shard_index, size_t shard_count, int target_device, gs_handle* out) {
+  return guarded_pair(hfull, target_device, [&](Ctx& src, Ctx& dst) -> int {
+    return pinocchio_pk_shard_impl(dst, src, src.get<PinocchioPkObj>(hfull, Kind::PinocchioPk), shard_index, shard_count, out);
+  });
+}
+
+// the eight sums over this rank's term ranges, in the layout of a proof (PiA | PiAp | PiB | PiBp | PiC | PiCp | PiH | PiKp)
+int gs_pinocchio_prove_partials(gs_handle hpk, gs_handle hw, gs_handle hpx, size_t shard_index, size_t shard_count, uint64_t out_sums[72], int inf[8]) {
+  return guarded([&](Ctx& c) -> int {
+    PinocchioPkObj* pk = c.get<PinocchioPkObj>(hpk, Kind::PinocchioPk);
+    Scalars* w = c.get<Scalars>(hw, Kind::Scalars);
+    Scalars* px = c.get<Scalars>(hpx, Kind::Scalars);
+    if (!pk || !w || !px) return fail(GS_ERR_ARG, "gs_pinocchio_prove_partials: bad handle");
+    if (!out_sums || !inf || shard_count == 0 || shard_index >= shard_count) return fail(GS_ERR_ARG, "gs_pinocchio_prove_partials: bad shard or null output");
+    reset_timing(c);
+    Shard sh; sh.index = shard_index; sh.count = shard_count;
+    return pinocchio_prove_impl(c, pk, DevScalars{w->buf.as<uint32_t>(), w->n}, DevScalars{px->buf.as<uint32_t>(), px->n}, out_sums, inf, sh);
+  }, true, false, hpk);
+}
+
+// the owner's polynomial stage (as gs_groth16_witness_values: the same H, the key only says which Z and how many constraints)
+int gs_pinocchio_witness_values(gs_handle hpk, gs_handle hr1cs, gs_handle hw, gs_handle* hv_inout, uint32_t* violated) {
+  return guarded([&](Ctx& c) -> int {
+    PinocchioPkObj* pk = c.get<PinocchioPkObj>(hpk, Kind::PinocchioPk);
+    if (!pk) return fail(GS_ERR_ARG, "gs_pinocchio_witness_values: bad proving-key handle");
+    return witness_values_impl(c, "gs_pinocchio_witness_values", pk->nz, pk->n_eval, hr1cs, hw, hv_inout, violated);
+  }, true, true, hpk);
+}
+
+// ... and the ranks' sums with PiH over THEIR slice of those values (no polynomial work on this rank)
+int gs_pinocchio_prove_partials_values(gs_handle hpk, gs_handle hw, gs_handle hv_slice, size_t shard_index, size_t shard_count,
+                                       uint64_t out_sums[72], int inf[8]) {
+  return guarded([&](Ctx& c) -> int {
+    PinocchioPkObj* pk = c.get<PinocchioPkObj>(hpk, Kind::PinocchioPk);
+    Scalars* w = c.get<Scalars>(hw, Kind::Scalars);
+    Scalars* hv = c.get<Scalars>(hv_slice, Kind::Scalars);
+    if (!pk || !w || !hv) return fail(GS_ERR_ARG, "gs_pinocchio_prove_partials_values: bad handle");
+    if (!out_sums || !inf || shard_count == 0 || shard_index >= shard_count) return fail(GS_ERR_ARG, "gs_pinocchio_prove_partials_values: bad shard or null output");
+    if (pk->n_eval == 0) return fail(GS_ERR_SHAPE, "gs_pinocchio_prove_partials_values: the key has no evaluation-basis array");
+    Shard sh; sh.index = shard_index; sh.count = shard_count;
+    size_t lo, hi;
+    if (pk->shard_count > 1) { lo = pk->e_lo; hi = pk->e_lo + pk->n_e; } else shard_range(pk->n_eval, sh, lo, hi);
+    if (hv->n != hi - lo) return fail(GS_ERR_SHAPE, "gs_pinocchio_prove_partials_values: shard %zu of %zu covers %zu of the %zu values, the vector holds %zu",
+                                      shard_index, shard_count, hi - lo, pk->n_eval, hv->n);
+    reset_timing(c);
+    DevScalars dh{nullptr, 0};
+    dh.hv_slice = hv->buf.as<uint32_t>();
+    return pinocchio_prove_impl(c, pk, DevScalars{w->buf.as<uint32_t>(), w->n}, dh, out_sums, inf, sh);
+  }, true, false, hpk);
+}
+
+// the addition: n records of eight sums (the layout above, n x 72 words and n x 8 flags) -> the proof.  Host arithmetic on 8 n points.
+int gs_pinocchio_combine(const uint64_t* sums, const int* inf_in, size_t n, uint64_t out_proof[72], int inf[8]) {
+  if (!sums || !inf_in || !out_proof || !inf || n == 0) return fail(GS_ERR_ARG, "gs_pinocchio_combine: null argument or no records");
+  static const int off[8] = {0, 8, 16, 32, 40, 48, 56, 64};
+  std::vector<uint64_t> pts(n * 16);
+  std::vector<int> fl(n);
+  for (int k = 0; k < 8; ++k) {
+    const bool g2 = k == 2;
+    const size_t words = g2 ? 16 : 8;
+    for (size_t i = 0; i < n; ++i) { memcpy(&pts[i * words], sums + i * 72 + off[k], words * 8); fl[i] = inf_in[i * 8 + k]; }
+    const int rc = g2 ? gs_g2_sum_affine(pts.data(), fl.data(), n, out_proof + off[k], &inf[k]) : gs_g1_sum_affine(pts.data(), fl.data(), n, out_proof + off[k], &inf[k]);
+    if (rc != GS_OK) return rc;
+  }
+  return GS_OK;
 }
 
 // PolynomialField.LagrangeInterpolation (r1csqap.go:150-158): n values at the nodes 1..n -> n coefficients.
@@ -1420,7 +1559,7 @@ int gs_pinocchio_prove_witness_begin(gs_handle hpk, gs_handle hr1cs, gs_handle h
         return pinocchio_prove_impl(cc, pk, DevScalars{wdev, nw}, ex, out, inf);
       };
     }
-    const int rc = pinocchio_enqueue(c, pk, DevScalars{wdev, nw}, dp, parity, false, true, *st);
+    const int rc = pinocchio_enqueue(c, pk, DevScalars{wdev, nw}, dp, Shard{}, parity, false, true, *st);
     if (rc != GS_OK) return rc;
     st->ticket = c.new_ticket();
     *ticket = st->ticket;

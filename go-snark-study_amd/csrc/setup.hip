@@ -235,6 +235,7 @@ int gs_pinocchio_setup(size_t n, size_t m, size_t npublic,
     scaled_powers_dev(c, T, one, m - 1, pw.as<uint32_t>());                          // G1T_i = tau^i G1      :239-247
     auto pk = std::make_unique<PinocchioPkObj>();
     pk->nvars = m; pk->npublic = npublic; pk->nz = m - 1; pk->ng1t = m - 1;
+    pk->n_w = m; pk->n_h = m - 1;                                                    // a full key
     DevBuf* g1dst[7] = {&pk->a, nullptr, &pk->c, &pk->ap, &pk->bp, &pk->cp, &pk->kp};   // sb -> B lives in G2
     for (int i = 0; i < 7; ++i) {
       if (!g1dst[i]) continue;
@@ -250,7 +251,7 @@ int gs_pinocchio_setup(size_t n, size_t m, size_t npublic,
     if (eval_basis_scalars(c, n, T, one, lag2, qe)) {
       pk->g1t_eval.alloc(n * 64);
       fixed_base_g1(c, qe.as<uint32_t>(), (uint32_t)n, pk->g1t_eval.as<uint32_t>());
-      pk->n_eval = n;
+      pk->n_eval = n; pk->e_lo = 0; pk->n_e = n;
     }
     DevBuf zc((m - 1) * 32);
     zpoly_dev(c, m - 2, zc.as<uint32_t>());
@@ -338,6 +339,7 @@ int gs_pinocchio_pk_export(gs_handle hpk, int which, uint64_t* jacobian, size_t 
   return guarded([&](Ctx& c) -> int {
     PinocchioPkObj* pk = c.get<PinocchioPkObj>(hpk, Kind::PinocchioPk);
     if (!pk) return fail(GS_ERR_ARG, "gs_pinocchio_pk_export: bad proving-key handle");
+    if (pk->shard_count != 1) return fail(GS_ERR_ARG, "gs_pinocchio_pk_export: the key is a slice (export the full key)");
     const DevBuf* arr[10] = {&pk->a, &pk->ap, &pk->b2, &pk->bp, &pk->c, &pk->cp, &pk->kp, &pk->g1t, nullptr, &pk->g1t_eval};
     if (which == 8) {           // pk.Z: nz coefficients, 4 x u64 each
       if (count != pk->nz || !jacobian) return fail(GS_ERR_ARG, "gs_pinocchio_pk_export: Z has %zu coefficients, asked for %zu", pk->nz, count);
@@ -387,7 +389,7 @@ int gs_pk_eval_count(gs_handle hpk, size_t* count) {
   return guarded([&](Ctx& c) -> int {
     if (!count) return fail(GS_ERR_ARG, "gs_pk_eval_count: null output");
     if (GrothPkObj* g = c.get<GrothPkObj>(hpk, Kind::GrothPk)) { *count = g->n_e; return GS_OK; }
-    if (PinocchioPkObj* p = c.get<PinocchioPkObj>(hpk, Kind::PinocchioPk)) { *count = p->n_eval; return GS_OK; }
+    if (PinocchioPkObj* p = c.get<PinocchioPkObj>(hpk, Kind::PinocchioPk)) { *count = p->n_e; return GS_OK; }
     return fail(GS_ERR_ARG, "gs_pk_eval_count: not a proving-key handle");
   }, true, true, hpk);
 }
@@ -396,6 +398,7 @@ int gs_pinocchio_pk_set_eval(gs_handle hpk, gs_handle hbases) {
     PinocchioPkObj* pk = c.get<PinocchioPkObj>(hpk, Kind::PinocchioPk);
     Bases* b = c.get<Bases>(hbases, Kind::G1Bases);
     if (!pk || !b) return fail(GS_ERR_ARG, "gs_pinocchio_pk_set_eval: bad handle");
+    if (pk->shard_count != 1) return fail(GS_ERR_ARG, "gs_pinocchio_pk_set_eval: the key is a slice (attach the array to the full key, then cut it)");
     const size_t n = b->n;
     if (n < 2 || pk->nz == 0 || (pk->nz - 1 != n - 1 && pk->nz - 1 != n))
       return fail(GS_ERR_SHAPE, "gs_pinocchio_pk_set_eval: %zu points, but deg Z = %zu needs n = deg Z or deg Z + 1 constraints", n, pk->nz ? pk->nz - 1 : 0);
@@ -403,7 +406,7 @@ int gs_pinocchio_pk_set_eval(gs_handle hpk, gs_handle hbases) {
     pk->g1t_eval.alloc(n * 64);
     GS_HIP(hipMemcpyAsync(pk->g1t_eval.p, b->buf.p, n * 64, hipMemcpyDeviceToDevice, c.stream));
     GS_HIP(hipStreamSynchronize(c.stream));
-    pk->n_eval = n;
+    pk->n_eval = n; pk->e_lo = 0; pk->n_e = n;
     return GS_OK;
   }, true, false, hpk);
 }

@@ -117,6 +117,97 @@ def prove_end(ticket):
     return _proof_from_words(out, inf)
 
 
+# ---- several GPUs (SURVEY 8e applied to snark.go:254-289): a proof is the sum of the ranks' eight partial points ----------------
+def ShardPk(dev_pk, shard_index, shard_count, target_device=None):
+    """Slice `shard_index` of `shard_count` of a resident full key (gs_pinocchio_pk_shard), on logical device `target_device` if given
+    (gs_pinocchio_pk_shard_to).  -> DevicePk holding 1 / shard_count of every array."""
+    h = capi.Handle(0)
+    if target_device is None:
+        capi.check(capi.load_library().gs_pinocchio_pk_shard(capi.Handle(dev_pk.h), shard_index, shard_count, ctypes.byref(h)))
+    else:
+        capi.check(capi.load_library().gs_pinocchio_pk_shard_to(capi.Handle(dev_pk.h), shard_index, shard_count, int(target_device), ctypes.byref(h)))
+    return DevicePk(capi.DeviceHandle(h.value), dev_pk.nvars, dev_pk.npublic)
+
+
+def _sums(out, inf):
+    return np.array(out, dtype=np.uint64), [int(x) for x in inf]
+
+
+def prove_partials(dev_pk, w_handle, px_handle, shard_index, shard_count):
+    """The eight sums over shard `shard_index` of the term ranges (gs_pinocchio_prove_partials) -> (72 words, 8 infinity flags),
+    the layout of a proof; add the ranks' records with combine()."""
+    out = np.zeros(72, dtype=np.uint64)
+    inf = (ctypes.c_int * 8)()
+    capi.check(capi.load_library().gs_pinocchio_prove_partials(capi.Handle(dev_pk.h), capi.Handle(w_handle.h), capi.Handle(px_handle.h),
+                                                               shard_index, shard_count, capi.ptr64(out), inf))
+    return _sums(out, inf)
+
+
+def witness_values(dev_pk, dev_r1cs, w_handle, hv_handle=None):
+    """The proof owner's polynomial stage (gs_pinocchio_witness_values) -> (handle of the n values H(n+1..2n), violated)."""
+    h = capi.Handle(hv_handle.h if hv_handle is not None else 0)
+    bad = ctypes.c_uint32(0)
+    capi.check(capi.load_library().gs_pinocchio_witness_values(capi.Handle(dev_pk.h), capi.Handle(dev_r1cs.handle.h), capi.Handle(w_handle.h),
+                                                               ctypes.byref(h), ctypes.byref(bad)))
+    return (hv_handle if hv_handle is not None else capi.DeviceHandle(h.value)), int(bad.value)
+
+
+def prove_partials_values(dev_pk, w_handle, hv_slice, shard_index, shard_count):
+    """gs_pinocchio_prove_partials_values: the eight sums with PiH over this rank's slice of H's values."""
+    out = np.zeros(72, dtype=np.uint64)
+    inf = (ctypes.c_int * 8)()
+    capi.check(capi.load_library().gs_pinocchio_prove_partials_values(capi.Handle(dev_pk.h), capi.Handle(w_handle.h), capi.Handle(hv_slice.h),
+                                                                      shard_index, shard_count, capi.ptr64(out), inf))
+    return _sums(out, inf)
+
+
+def combine(records):
+    """gs_pinocchio_combine: [(72 words, 8 flags)] of every rank -> Proof."""
+    n = len(records)
+    sums = np.ascontiguousarray(np.concatenate([np.asarray(r[0], dtype=np.uint64).reshape(72) for r in records]))
+    fl = (ctypes.c_int * (8 * n))(*[int(x) for r in records for x in r[1]])
+    out = np.zeros(72, dtype=np.uint64)
+    inf = (ctypes.c_int * 8)()
+    capi.check(capi.load_library().gs_pinocchio_combine(capi.ptr64(sums), fl, n, capi.ptr64(out), inf))
+    return _proof_from_words(out, inf)
+
+
+def prove_multi(dev_pks, w_handles, third_handles, values=False):
+    """One proof over len(dev_pks) logical devices of THIS process (gs_pinocchio_prove_multi, or _multi_values when `third_handles`
+    are the devices' slices of H's values instead of replicas of px).  -> (Proof, used_rccl)."""
+    out = np.zeros(72, dtype=np.uint64)
+    inf = (ctypes.c_int * 8)()
+    used = ctypes.c_int(0)
+    lib = capi.load_library()
+    fn = lib.gs_pinocchio_prove_multi_values if values else lib.gs_pinocchio_prove_multi
+    capi.check(fn(capi._harr([k.handle for k in dev_pks]), capi._harr(w_handles), capi._harr(third_handles), len(dev_pks), capi.ptr64(out), inf,
+                  ctypes.byref(used)))
+    return _proof_from_words(out, inf), bool(used.value)
+
+
+def prove_sharded_rccl(dev_pk, w_handle, third_handle, values=False):
+    """One process per GPU, records gathered INSIDE the library over the communicator of capi.comm_init_rank
+    (gs_pinocchio_prove_sharded / _sharded_values).  Every rank returns the same Proof."""
+    out = np.zeros(72, dtype=np.uint64)
+    inf = (ctypes.c_int * 8)()
+    lib = capi.load_library()
+    fn = lib.gs_pinocchio_prove_sharded_values if values else lib.gs_pinocchio_prove_sharded
+    capi.check(fn(capi.Handle(dev_pk.h), capi.Handle(w_handle.h), capi.Handle(third_handle.h), capi.ptr64(out), inf))
+    return _proof_from_words(out, inf)
+
+
+def prove_batch(pk_of_device, w_handles, px_handles):
+    """A batch of independent proofs round-robined over logical devices (gs_pinocchio_prove_batch): proof i runs where w_handles[i]
+    lives, with pk_of_device[that device] (None for unused devices).  No collective."""
+    n = len(w_handles)
+    out = np.zeros((max(n, 1), 72), dtype=np.uint64)
+    inf = (ctypes.c_int * (8 * max(n, 1)))()
+    pks = capi._harr([(k.handle if k is not None else 0) for k in pk_of_device])
+    capi.check(capi.load_library().gs_pinocchio_prove_batch(pks, len(pk_of_device), capi._harr(w_handles), capi._harr(px_handles), n,
+                                                            capi.ptr64(out), inf))
+    return [_proof_from_words(out[i], inf[8 * i:8 * i + 8]) for i in range(n)]
+
+
 class Vk:
     """snark.Vk (snark.go:28-38): affine Jacobian tuples."""
     FIELDS = ("Vka", "Vkb", "Vkc", "G1Kbg", "G2Kbg", "G2Kg", "Vkz")

@@ -380,6 +380,36 @@ int gs_msm_g2_sharded(gs_handle bases, gs_handle scalars, uint64_t out_affine[16
 int gs_groth16_prove_batch(const gs_handle* pk_of_device, int ndev, const gs_handle* w, const gs_handle* px, size_t nproofs,
                            const uint64_t* r, const uint64_t* s, uint64_t* out_proofs, int* inf);
 
+/* ---- snark.GenerateProofs over several GPUs (snark.go:254-289; the scheme above applied to Pinocchio) ----
+ * A Pinocchio proof IS its eight MSM sums -- PiA | PiAp | PiB (G2) | PiBp | PiC | PiCp | PiH | PiKp, snark.go:265-286, there is no
+ * tail -- so rank k of N sums its term ranges and the eight partial points of the ranks add up to the proof (616-byte records).
+ *   gs_pinocchio_pk_shard / _shard_to      a slice of a resident full key: entries [k/N, (k+1)/N) of the seven per-variable arrays,
+ *                                          of G1T and of the evaluation-basis array; Z travels with every slice
+ *   gs_pinocchio_prove_partials            the eight sums of shard k from resident w and px (full key or slice k), proof layout
+ *   gs_pinocchio_witness_values            the proof owner's polynomial stage, as gs_groth16_witness_values (the same H)
+ *   gs_pinocchio_prove_partials_values     the eight sums with PiH over this rank's slice of H's values (no polynomial work here)
+ *   gs_pinocchio_combine                   n records (n x 72 words, n x 8 flags) -> the proof (host additions)
+ *   gs_pinocchio_prove_multi[_values]      one process, ndev logical devices: partials on every device concurrently, exchange
+ *                                          (RCCL when a local communicator spans the devices), addition
+ *   gs_pinocchio_prove_sharded[_values]    one process per GPU: this rank's partials, ncclAllGather of the records, addition;
+ *                                          every rank returns the complete proof
+ *   gs_pinocchio_prove_batch               a batch of independent proofs, three in flight per device, no collective
+ * Same proof as gs_pinocchio_prove_resident with the full key, whatever N. */
+int gs_pinocchio_pk_shard(gs_handle full_pk, size_t shard_index, size_t shard_count, gs_handle* out);
+int gs_pinocchio_pk_shard_to(gs_handle full_pk, size_t shard_index, size_t shard_count, int target_device, gs_handle* out);
+int gs_pinocchio_prove_partials(gs_handle pk, gs_handle w, gs_handle px, size_t shard_index, size_t shard_count, uint64_t out_sums[72], int inf[8]);
+int gs_pinocchio_witness_values(gs_handle pk, gs_handle r1cs, gs_handle w, gs_handle* hv_inout, uint32_t* violated);
+int gs_pinocchio_prove_partials_values(gs_handle pk, gs_handle w, gs_handle hv_slice, size_t shard_index, size_t shard_count,
+                                       uint64_t out_sums[72], int inf[8]);
+int gs_pinocchio_combine(const uint64_t* sums /* n x 72 */, const int* inf_in /* n x 8 */, size_t n, uint64_t out_proof[72], int inf[8]);
+int gs_pinocchio_prove_multi(const gs_handle* pk, const gs_handle* w, const gs_handle* px, int ndev, uint64_t out_proof[72], int inf[8], int* used_rccl);
+int gs_pinocchio_prove_multi_values(const gs_handle* pk, const gs_handle* w, const gs_handle* hv_slices, int ndev, uint64_t out_proof[72], int inf[8],
+                                    int* used_rccl);
+int gs_pinocchio_prove_sharded(gs_handle pk, gs_handle w, gs_handle px, uint64_t out_proof[72], int inf[8]);
+int gs_pinocchio_prove_sharded_values(gs_handle pk, gs_handle w, gs_handle hv_slice, uint64_t out_proof[72], int inf[8]);
+int gs_pinocchio_prove_batch(const gs_handle* pk_of_device, int ndev, const gs_handle* w, const gs_handle* px, size_t nproofs,
+                             uint64_t* out_proofs /* nproofs x 72 */, int* inf /* nproofs x 8 */);
+
 /* ---- timing of the last prove / msm call (device time, HIP events on the library stream) --- */
 typedef struct {
   float total_ms;        /* all device work of the call */

@@ -195,6 +195,119 @@ def test_values_route_one_process_per_gpu_world_1(inst):
     capi.comm_destroy()
 
 
+@pytest.fixture(scope="module")
+def pin():
+    capi.set_device(0)
+    return synth.sqchain_pinocchio_instance(3000, 0xD1CF)        # ragged: 3001 variables, 3000 constraints over 2, 3, 8 shards
+
+
+def _same_pin(p, q):
+    from gosnark_amd import snark
+    return all(getattr(p, k) == getattr(q, k) for k in snark.Proof.FIELDS)
+
+
+@pytest.mark.parametrize("n", [2, 3, 8])
+def test_pinocchio_proof_over_n_logical_devices_is_the_single_device_proof(pin, n):
+    """SURVEY 8e applied to snark.GenerateProofs (snark.go:254-289): a Pinocchio proof is eight plain sums, so the ranks' eight
+    partial points add up to it.  Key slices (1/N of the seven per-variable arrays, of G1T and of the evaluation-basis array) and full
+    replicas; px route and values route (the polynomial stage on ONE owner, its slices scattered); piecewise through
+    gs_pinocchio_prove_partials + gs_pinocchio_combine as one process per GPU would; slices refuse the wrong shard."""
+    from gosnark_amd import r1csqap, snark
+    capi.comm_destroy()
+    full = pin.device_pk()
+    want = snark.prove_resident(full, pin.w, pin.px)
+    assert snark.VerifyProof(pin.vk, want, capi.u64_to_ints(pin.w_host[1:2]))
+    ws = [capi.scalars_clone(pin.w, d) for d in range(n)]
+    pxs = [capi.scalars_clone(pin.px, d) for d in range(n)]
+    slices_pk = [snark.ShardPk(full, d, n, d) for d in range(n)]
+    replicas = [snark.ShardPk(full, 0, 1, d) for d in range(n)]
+    assert sum(capi.pk_eval_count(k.handle) for k in slices_pk) == pin.n == capi.pk_eval_count(full.handle)
+    assert all(capi.handle_device(slices_pk[d].handle) == d for d in range(n))
+    for pks in (slices_pk, replicas):
+        got, used = snark.prove_multi(pks, ws, pxs)
+        assert _same_pin(got, want) and used is False
+    recs = [snark.prove_partials(slices_pk[d], ws[d], pxs[d], d, n) for d in range(n)]
+    assert _same_pin(snark.combine(recs), want)
+    with pytest.raises(capi.GosnarkHipError, match="holds shard"):
+        snark.prove_partials(slices_pk[1], ws[1], pxs[1], 0, n)
+    with pytest.raises(capi.GosnarkHipError, match="slice"):
+        snark.ShardPk(slices_pk[0], 0, 2)
+    # values route: owner = proof index mod n
+    for proof in range(2):
+        owner = (proof + 1) % n
+        capi.set_device(owner)
+        try:
+            dev = r1csqap.DeviceR1CS(*pin.r1cs, pin.m)
+        finally:
+            capi.set_device(0)
+        hv, bad = snark.witness_values(slices_pk[owner], dev, ws[owner])
+        assert bad == 0 and len(hv) == pin.n and capi.handle_device(hv) == owner
+        hs = groth16.scatter_values(hv, n)
+        got, used = snark.prove_multi(slices_pk, ws, hs, values=True)
+        assert _same_pin(got, want) and used is False
+    recs = [snark.prove_partials_values(replicas[d], ws[d], hs[d], d, n) for d in range(n)]
+    assert _same_pin(snark.combine(recs), want)
+    with pytest.raises(capi.GosnarkHipError, match="covers"):
+        snark.prove_partials_values(slices_pk[0], ws[0], capi.scalars_clone(hv, 0), 0, n)
+    w_bad = pin.w_host.copy()
+    w_bad[7] = (99, 0, 0, 0)
+    _, bad = snark.witness_values(full, r1csqap.DeviceR1CS(*pin.r1cs, pin.m), capi.scalars_upload(w_bad))
+    assert bad > 0
+
+
+def test_pinocchio_records_through_rccl_and_rank_mode_world_1(pin):
+    """The 616-byte Pinocchio records through ncclAllGather: a local communicator (one rank per distinct physical device; here one)
+    with the logical devices spread evenly over it, then the one-process-per-GPU entry points at world size 1, px and values route."""
+    from gosnark_amd import r1csqap, snark
+    full = pin.device_pk()
+    want = snark.prove_resident(full, pin.w, pin.px)
+    capi.comm_destroy()
+    capi.comm_init_local()
+    n = 4
+    pks = [snark.ShardPk(full, d, n, d) for d in range(n)]
+    ws = [capi.scalars_clone(pin.w, d) for d in range(n)]
+    pxs = [capi.scalars_clone(pin.px, d) for d in range(n)]
+    before = capi.comm_info()["collectives"]
+    got, used = snark.prove_multi(pks, ws, pxs)
+    assert _same_pin(got, want) and used is True and capi.comm_info()["collectives"] == before + 1
+    capi.comm_destroy()
+    capi.set_device(0)
+    capi.comm_init_rank(capi.comm_unique_id(), 1, 0)
+    before = capi.comm_info()["collectives"]
+    assert _same_pin(snark.prove_sharded_rccl(full, pin.w, pin.px), want)
+    hv, bad = snark.witness_values(full, r1csqap.DeviceR1CS(*pin.r1cs, pin.m), pin.w)
+    mine = capi.scalars_scatter(hv, pin.n, 0)
+    assert bad == 0 and _same_pin(snark.prove_sharded_rccl(full, pin.w, mine, values=True), want)
+    assert capi.comm_info()["collectives"] == before + 3
+    capi.comm_destroy()
+    with pytest.raises(capi.GosnarkHipError, match="communicator"):
+        snark.prove_sharded_rccl(full, pin.w, pin.px)
+
+
+def test_pinocchio_batch_of_independent_proofs_round_robin_over_devices(pin):
+    """gs_pinocchio_prove_batch: 12 proofs with distinct witnesses over 4 logical devices, three in flight per device, equal to
+    the single-device proofs one by one; a bad entry leaves no ticket behind."""
+    from gosnark_amd import r1csqap, snark
+    ndev, nproofs = 4, 12
+    full = pin.device_pk()
+    keys = [snark.ShardPk(full, 0, 1, d) for d in range(ndev)]
+    hosts = [synth.sqchain_witness(pin.n, 1000 + i) for i in range(nproofs)]
+    ws, pxs, want = [], [], []
+    for i, wh in enumerate(hosts):
+        _, _, _, px = r1csqap.ComputePx(*pin.r1cs, wh, pin.m)
+        w0, p0 = capi.scalars_upload(wh), capi.scalars_upload(px)
+        want.append(snark.prove_resident(full, w0, p0))
+        ws.append(capi.scalars_clone(w0, i % ndev)); pxs.append(capi.scalars_clone(p0, i % ndev))
+    assert len({w.PiA for w in want}) == nproofs
+    got = snark.prove_batch(keys, ws, pxs)
+    assert all(_same_pin(g, w) for g, w in zip(got, want))
+    bad_px = list(pxs)
+    bad_px[5] = capi.scalars_clone(capi.scalars_upload(np.zeros((3 * pin.n, 4), dtype=np.uint64)), 5 % ndev)    # len(hx) > len(G1T)
+    with pytest.raises(capi.GosnarkHipError, match="G1T"):
+        snark.prove_batch(keys, ws, bad_px)
+    assert all(_same_pin(g, w) for g, w in zip(snark.prove_batch(keys, ws, pxs), want))     # every slot is free again
+
+
 def test_torch_distributed_nccl_branch_runs_at_world_1(inst, monkeypatch):
     """parallel.allgather_points over torch.distributed's nccl (= RCCL) backend, forced at world size 1."""
     import torch
@@ -345,6 +458,20 @@ def test_plain_c_process_proves_over_three_logical_devices(tmp_path):
     import golden_util as GU
     blob = c_util.write_groth_instance(tmp_path, GU.load("groth_x3"))
     out = c_util.build_and_run("multi_device.c", [str(blob)], tmp_path)
+    assert out.strip().endswith("OK"), out
+    assert "used_rccl=1" in out and "collectives=1" in out
+
+
+def test_plain_c_process_proves_pinocchio_over_three_logical_devices(tmp_path):
+    """go/gosnarkhip/pinocchio_multi.go's call sequences as tests/c/snark_multi_device.c, on the reference's own wasm/index.js
+    Pinocchio fixture (m = 8 variables over 3 slices: ragged): gs_pinocchio_prove_multi through the local RCCL communicator,
+    partial records + gs_pinocchio_combine, gs_pinocchio_prove_batch -- each byte-identical to gs_pinocchio_prove, verifier accepts."""
+    import c_util
+    import golden_util as GU
+    rec = GU.load("pinocchio_x3_fixture")
+    public = [x for x in rec["w"][1:1 + rec["circuit"]["NPublic"]]]
+    blob = c_util.write_pinocchio_instance(tmp_path, rec, public)
+    out = c_util.build_and_run("snark_multi_device.c", [str(blob)], tmp_path)
     assert out.strip().endswith("OK"), out
     assert "used_rccl=1" in out and "collectives=1" in out
 
