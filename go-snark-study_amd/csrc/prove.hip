@@ -87,10 +87,22 @@ struct GrothTailPre {             // the tail products that need no MSM result (
   std::future<G1Xyzz> sdelta;
   G1Xyzz rdelta, rsdelta;
 };
+// The two result-dependent products of the tail, s piA and r piB1 (groth16.go:272-273), only need the sums over w -- which a
+// proof has milliseconds before its sum over h: groth16_collect starts them (two host cores) as soon as the G1 group over w is
+// folded, so that what is left when the device goes idle is a handful of additions and three normalisations.
+struct GrothTailEarly {
+  GrothPkObj* pk = nullptr;                // armed when set (with r, s, pre and the future that fills pre)
+  const uint64_t* r = nullptr; const uint64_t* s = nullptr;
+  GrothTailPre* pre = nullptr;
+  std::future<void>* fpre = nullptr;
+  bool done = false;
+  G1Xyzz piA, piB1, sA, rB;
+};
 struct GrothInFlight : InFlightBase {
   GrothPkObj* pk = nullptr;
   uint64_t r[4] = {0, 0, 0, 0}, s[4] = {0, 0, 0, 0};
   bool with_tail = false;
+  GrothTailEarly early;
   // done_g2 / done_g1w / done_h: one per MSM group, recorded behind that group's reduction tail, so the host can add up a
   // group's partial sums while the later groups are still on the device
   hipEvent_t planw = nullptr, planh = nullptr, done_main = nullptr, done_g2 = nullptr, done_g1w = nullptr, done_h = nullptr;
@@ -245,7 +257,24 @@ int groth16_collect(Ctx& c, GrothInFlight& st, GrothSums& sums) {
     auto f2 = std::async(std::launch::async, [&] { msm_finish_g2(c, st.pend_g2w, g2w); });
     struct Join { std::future<void>& f; ~Join() { if (f.valid()) f.wait(); } } j2{f2};     // a throwing wait below must not outrun the threads
     GS_HIP(hipEventSynchronize(st.done_g1w));
-    auto f1 = std::async(std::launch::async, [&] { msm_finish_g1(c, st.pend_g1w, g1w); });
+    auto f1 = std::async(std::launch::async, [&] {
+      msm_finish_g1(c, st.pend_g1w, g1w);
+      GrothTailEarly& e = st.early;
+      if (!e.pk) return;
+      e.fpre->wait();                                            // r delta, s delta (the owner calls get() after this thread is joined)
+      e.piA = g1w[0];
+      xyzz_madd(e.piA, e.pk->alpha);                             // + alpha          groth16.go:253
+      xyzz_add(e.piA, e.pre->rdelta);                            // + r delta        :254-255
+      e.piB1 = g1w[1];
+      xyzz_madd(e.piB1, e.pk->beta);                             // + beta           :259
+      xyzz_add(e.piB1, e.pre->sdelta.get());                     // + s delta        :261-262
+      const G1Xyzz b1 = e.piB1;
+      const uint64_t* r = e.r;
+      auto f_rB = std::async(std::launch::async, [b1, r] { return g1_mul_scalar(b1, r); });
+      e.sA = g1_mul_scalar(e.piA, e.s);                          // s piA            :272
+      e.rB = f_rB.get();                                         // r piB1           :273
+      e.done = true;
+    });
     Join j1{f1};
     GS_HIP(hipEventSynchronize(st.done_h));
     t1 = host_trace() ? host_now_ms() : 0;
@@ -286,22 +315,28 @@ static void groth16_tail_pre(GrothPkObj* pk, const uint64_t r[4], const uint64_t
   pre.rsdelta = g1_mul_scalar(pre.rdelta, s);
 }
 static void groth16_tail_post(GrothPkObj* pk, const GrothSums& sums, GrothTailPre& pre, const uint64_t r[4], const uint64_t s[4],
-                              uint64_t out_proof[32], int inf[3]) {
-  G1Xyzz piA = sums.at;
-  xyzz_madd(piA, pk->alpha);                                   // + alpha          :253
-  xyzz_add(piA, pre.rdelta);                                   // + r delta        :254-255
-  G1Xyzz piB1 = sums.bacgamma1;
-  xyzz_madd(piB1, pk->beta);                                   // + beta           :259
-  xyzz_add(piB1, pre.sdelta.get());                            // + s delta        :261-262
+                              uint64_t out_proof[32], int inf[3], const GrothTailEarly* early = nullptr) {
+  const bool have = early && early->done;                      // piA, piB1, s piA, r piB1 came from groth16_collect (same sums)
+  G1Xyzz piA, piB1, sA, rB;
   G2Xyzz piB = sums.bacgamma2;
   xyzz_madd(piB, pk->beta2);                                   // + beta2          :260
   xyzz_add(piB, pre.sdelta2.get());                            // + s delta2       :263-264
   G1Xyzz piC = sums.bacdelta;
   xyzz_add(piC, sums.h);                                       // + sum h_i PTD_i  :269-271
-  auto f_rB = std::async(std::launch::async, [piB1, r] { return g1_mul_scalar(piB1, r); });   // two host cores for the two
-  G1Xyzz sA = g1_mul_scalar(piA, s);                                                          // result-dependent products
+  if (have) { piA = early->piA; piB1 = early->piB1; sA = early->sA; rB = early->rB; }
+  else {
+    piA = sums.at;
+    xyzz_madd(piA, pk->alpha);                                 // + alpha          :253
+    xyzz_add(piA, pre.rdelta);                                 // + r delta        :254-255
+    piB1 = sums.bacgamma1;
+    xyzz_madd(piB1, pk->beta);                                 // + beta           :259
+    xyzz_add(piB1, pre.sdelta.get());                          // + s delta        :261-262
+    auto f_rB = std::async(std::launch::async, [piB1, r] { return g1_mul_scalar(piB1, r); });   // two host cores for the two
+    sA = g1_mul_scalar(piA, s);                                                                 // result-dependent products
+    rB = f_rB.get();
+  }
   xyzz_add(piC, sA);                                           // + s piA          :272
-  xyzz_add(piC, f_rB.get());                                   // + r piB1         :273
+  xyzz_add(piC, rB);                                           // + r piB1         :273
   xyzz_add(piC, xyzz_neg(pre.rsdelta));                        // - (r s) delta    :274-275
   inf[0] = g1_to_affine_std(piA, out_proof) ? 1 : 0;
   inf[1] = g2_to_affine_std(piB, out_proof + 8) ? 1 : 0;
@@ -322,21 +357,25 @@ int groth16_prove_impl(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, cons
   GrothSums sums;
   int rc;
   double t1 = 0;
+  GrothTailEarly early;
   {
     GrothInFlight st;
+    st.early.pk = pk; st.early.r = r; st.early.s = s; st.early.pre = &pre; st.early.fpre = &fpre;
     rc = groth16_enqueue(c, pk, w, px, Shard{}, Ctx::kBlockingSlot, true, false, st);
     t1 = host_trace() ? host_now_ms() : 0;
     if (rc == GS_OK) rc = groth16_collect(c, st, sums);
+    early = st.early;
   }
   if (rc == kRetryExact) {                     // violated constraint on the evaluation-basis route: the exact route, blocking
     px.produce_hv = nullptr;
     c.timing.fallbacks += 1;
+    // (the sums over w do not depend on the route: the early products stay valid)
     rc = groth16_sums_impl(c, pk, w, px, Shard{}, sums);
   }
   const double t2 = host_trace() ? host_now_ms() : 0;
   fpre.get();
   if (rc != GS_OK) return rc;
-  groth16_tail_post(pk, sums, pre, r, s, out_proof, inf);
+  groth16_tail_post(pk, sums, pre, r, s, out_proof, inf, &early);
   if (host_trace()) fprintf(stderr, "[gs host] prove: enqueue %.3f ms, collect %.3f ms, tail %.3f ms (entered at %.3f)\n", t1 - t0, t2 - t1, host_now_ms() - t2, t0);
   return GS_OK;
 }
@@ -779,6 +818,7 @@ int gs_groth16_prove_begin(gs_handle hpk, gs_handle hw, gs_handle hpx, const uin
     raw->pk = pk;
     raw->keep = {c.share<Object>(hpk, Kind::GrothPk), c.share<Object>(hw, Kind::Scalars), c.share<Object>(hpx, Kind::Scalars)};
     raw->fpre = std::async(std::launch::async, [raw] { groth16_tail_pre(raw->pk, raw->r, raw->s, raw->pre); });
+    raw->early.pk = pk; raw->early.r = raw->r; raw->early.s = raw->s; raw->early.pre = &raw->pre; raw->early.fpre = &raw->fpre;
     const int rc = groth16_enqueue(c, pk, DevScalars{w->buf.as<uint32_t>(), w->n}, DevScalars{px->buf.as<uint32_t>(), px->n}, Shard{}, parity, false, true, *raw);
     if (rc != GS_OK) return rc;
     st->ticket = c.new_ticket();
@@ -806,7 +846,7 @@ int gs_groth16_prove_end(uint64_t ticket, uint64_t out_proof[32], int inf[3]) {
     if (rc == kRetryExact && st.exact_route) { c.timing.fallbacks += 1; rc = st.exact_route(c, sums); }
     if (rc != GS_OK) return rc;
     st.fpre.get();
-    groth16_tail_post(st.pk, sums, st.pre, st.r, st.s, out_proof, inf);
+    groth16_tail_post(st.pk, sums, st.pre, st.r, st.s, out_proof, inf, &st.early);
     return GS_OK;
   }, true, true, ticket);
 }
@@ -1487,6 +1527,7 @@ int gs_groth16_prove_witness_begin(gs_handle hpk, gs_handle hr1cs, gs_handle hw,
     raw->pk = pk;
     raw->keep = {c.share<Object>(hpk, Kind::GrothPk), c.share<Object>(hr1cs, Kind::R1cs), c.share<Object>(hw, Kind::Scalars)};
     raw->fpre = std::async(std::launch::async, [raw] { groth16_tail_pre(raw->pk, raw->r, raw->s, raw->pre); });
+    raw->early.pk = pk; raw->early.r = raw->r; raw->early.s = raw->s; raw->early.pre = &raw->pre; raw->early.fpre = &raw->fpre;
     const uint32_t* wdev = w->buf.as<uint32_t>();
     const size_t nw = w->n, nz = pk->nz;
     DevScalars dp = witness_scalars(o, wdev, nz, eval, [o](Ctx& cc) { return exact_px_buffer(cc, o); });
