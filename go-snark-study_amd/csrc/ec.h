@@ -171,8 +171,8 @@ GS_HD void xyzz_madd_g1(Xyzz<FqTag>& acc, const Affine<FqTag>& b, bool negate) {
   }
   Fe<ModQ, 2> U2, S2;
   dots2<ModQ>(dot_of(b.x, acc.zz), dot_of(y2, acc.zzz), U2, S2);
-  auto P = sub(U2, acc.x);                              // 2 + 9 + 1 = 12
-  auto R = sub(S2, acc.y);                              // 2 + 5 + 1 = 8
+  auto P = sub_ripple(U2, acc.x);                       // 2 + 9 + 1 = 12
+  auto R = sub_ripple(S2, acc.y);                       // 2 + 5 + 1 = 8
   if (is_zero(P)) {
     if (is_zero(R)) acc = xyzz_dbl_affine<T>(b.x, normalize(y2));
     else xyzz_set_inf(acc);
@@ -205,8 +205,12 @@ GS_HD void xyzz_madd(Xyzz<T>& acc, const Affine<T>& b, bool negate = false) {
   else if constexpr (GS_PAIR != 0 && (GS_G2_MASK & 1) != 0) mul2(b.x, acc.zz, y2, acc.zzz, U2, S2);
   else if constexpr (GS_PAIR != 0) { U2 = mul(b.x, acc.zz); S2 = mul(y2, acc.zzz); }
   else { U2 = smul<T>(b.x, acc.zz); S2 = smul<T>(y2, acc.zzz); }
-  auto P = sub(U2, acc.x);                              // 2 + 9 + 1 = 12
-  auto R = sub(S2, acc.y);                              // 2 + 5 + 1 = 8
+  // (GS_PAIR: the accumulation kernels' instance takes the rippling difference, 8 instructions shorter per coordinate and fully
+  // normalised -- which the Fq2 instance's reduce2 below would otherwise re-establish with a carry pass of its own)
+  typename T::template E<12> P;
+  typename T::template E<8> R;
+  if constexpr (GS_PAIR != 0) { P = sub_ripple(U2, acc.x); R = sub_ripple(S2, acc.y); }
+  else { P = sub(U2, acc.x); R = sub(S2, acc.y); }      // 2 + 9 + 1 = 12,  2 + 5 + 1 = 8
   if (is_zero(P)) {
     if (is_zero(R)) acc = xyzz_dbl_affine<T>(b.x, y2);
     else if constexpr (T::kWords == 8) xyzz_set_inf(acc);
@@ -228,7 +232,7 @@ GS_HD void xyzz_madd(Xyzz<T>& acc, const Affine<T>& b, bool negate = false) {
   } else if constexpr (GS_PAIR != 0) {
     // G2: two Fq2 products at a time = four chains (both coordinates of both): P^2 | R^2, P^3 | Q, ZZ3 | ZZZ3
     typename T::template E<2> PP, RR, PPP, Q, ZZ3, ZZZ3;
-    const auto Pr = reduce2(P), Rr = reduce2(R);        // the Fq2 square takes (2a)(2a + 1) <= 160
+    const auto Pr = reduce2_normal(P), Rr = reduce2_normal(R);   // the Fq2 square takes (2a)(2a + 1) <= 160
     if constexpr ((GS_G2_MASK & 2) != 0) sqr2(Pr, Rr, PP, RR);
     else { PP = sqr(Pr); RR = sqr(Rr); }
     if constexpr ((GS_G2_MASK & 4) != 0) mul2(Pr, PP, acc.x, PP, PPP, Q);

@@ -128,6 +128,23 @@ GS_HD Fe<M, Ba + Bb + 1> sub(const Fe<M, Ba>& a, const Fe<M, Bb>& b) {
   return r;
 }
 
+// The same difference with a RIPPLING carry: limb i takes the carry of limb i - 1 inside its own addition (v_add3_u32), so the
+// separate carry pass of carry_save (shift, mask, add per limb: 24 instructions) shrinks to shift + mask (16) -- 34 instructions
+// instead of 42, at the price of a 16-deep dependency chain that the other chains of a mixed addition cover.  Limbs 0..7 come out
+// below 2^29 exactly.  Used for P and R of the accumulation kernels' mixed additions (ec.h).
+template <class M, int Ba, int Bb>
+GS_HD Fe<M, Ba + Bb + 1> sub_ripple(const Fe<M, Ba>& a, const Fe<M, Bb>& b) {
+  Fe<M, Ba + Bb + 1> r;
+  uint32_t c = 0;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    const uint32_t t = (a.l[i] - b.l[i]) + M::bias(Bb + 1, i) + c;      // >= 0 limb-wise (bias_limbs), < 2^32
+    if (i < NL - 1) { r.l[i] = t & LMASK; c = t >> LB; }
+    else r.l[i] = t;
+  }
+  return r;
+}
+
 // (B+1) p - a
 template <class M, int B>
 GS_HD Fe<M, B + 1> neg(const Fe<M, B>& a) {
@@ -617,10 +634,10 @@ GS_HD Fe<M, 2> mul_sub(const Fe<M, Ba>& a, const Fe<M, Bb>& b, const Fe<M, Bc>& 
 
 // ---- reductions / comparisons ---------------------------------------------------------------
 // value -> value - floor(top/(p_top+1)) * p : lands in [0, 2p).
-template <class M, int B>
-GS_HD Fe<M, 2> reduce2(const Fe<M, B>& a) {
+template <class M, int B, bool kNormal = false>
+GS_HD Fe<M, 2> reduce2(const Fe<M, B>& a) {     // kNormal: the limbs are fully normalised already (sub_ripple): no carry pass
   Fe<M, B> x = a;
-  carry_full(x);
+  if constexpr (!kNormal) carry_full(x);
   // q = floor(x_top / (p_top + 1)) <= floor(x / p); x < B p  =>  q <= B-1
   const uint32_t q = x.l[NL - 1] / (M::kTopLimb + 1u);
   Fe<M, 2> r;
@@ -635,6 +652,8 @@ GS_HD Fe<M, 2> reduce2(const Fe<M, B>& a) {
   r.l[NL - 1] = (uint32_t)((int64_t)x.l[NL - 1] - (int64_t)((uint64_t)q * M::p(NL - 1)) + carry);
   return r;
 }
+
+template <class M, int B> GS_HD Fe<M, 2> reduce2_normal(const Fe<M, B>& a) { return reduce2<M, B, true>(a); }
 
 // canonical representative in [0, p), fully normalised limbs (boundary / comparisons only)
 template <class M, int B>
@@ -663,8 +682,22 @@ GS_HD Fe<M, 1> canon(const Fe<M, B>& a) {
   return r;
 }
 
+// Cheap necessary condition for value == 0 (mod p) on a NEARLY-NORMAL element (limb 0 < 2^29 exactly, limbs 1..7 < 2^29 + 16: what
+// every carry_save leaves), without the rippling carry pass: value = k p has k = floor(top / p_top) for the fully carried top limb,
+// which is l[8] or l[8] + 1, so k is one of two candidates and limb 0 -- exact as it stands -- must equal (k p) mod 2^29 for one of
+// them.  Wrong with probability 2^-28 per candidate on a random element; is_zero then decides exactly.  (The zero test of P in
+// every mixed addition took a full carry pass + the multiple check: ~30 instructions; this is ~9.)
+template <class M, int B>
+GS_HD bool maybe_zero(const Fe<M, B>& a) {
+  const uint32_t k = a.l[NL - 1] / M::kTopLimb;
+  const uint32_t c0 = (uint32_t)(k * M::p(0)) & LMASK, c1 = (c0 + M::p(0)) & LMASK;
+  const uint32_t l0 = a.l[0] & LMASK;
+  return l0 == c0 || l0 == c1;
+}
+
 template <class M, int B>
 GS_HD bool is_zero(const Fe<M, B>& a) {        // value == 0 (mod p), exact
+  if (!maybe_zero(a)) return false;
   Fe<M, B> x = a;
   carry_full(x);
   // if x = k p then k = floor(x_top / p_top) exactly (k < p_top)

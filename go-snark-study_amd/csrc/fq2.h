@@ -24,6 +24,9 @@ template <int Ba, int Bb> GS_HD Fq2e<Ba + Bb + 1> sub(const Fq2e<Ba>& a, const F
 template <int B> GS_HD Fq2e<2 * B> dbl(const Fq2e<B>& a) { return {dbl(a.c0), dbl(a.c1)}; }
 template <int B> GS_HD Fq2e<B + 1> neg(const Fq2e<B>& a) { return {neg(a.c0), neg(a.c1)}; }
 template <int B> GS_HD Fq2e<2> reduce2(const Fq2e<B>& a) { return {reduce2(a.c0), reduce2(a.c1)}; }
+// the rippling difference (fp29.h: limbs come out fully normalised) and the reduction that relies on it
+template <int Ba, int Bb> GS_HD Fq2e<Ba + Bb + 1> sub_ripple(const Fq2e<Ba>& a, const Fq2e<Bb>& b) { return {sub_ripple(a.c0, b.c0), sub_ripple(a.c1, b.c1)}; }
+template <int B> GS_HD Fq2e<2> reduce2_normal(const Fq2e<B>& a) { return {reduce2_normal(a.c0), reduce2_normal(a.c1)}; }
 // a - b - 2 c with one carry pass per coordinate (fp29.h)
 template <int Ba, int Bb, int Bc> GS_HD Fq2e<Ba + Bb + 2 * Bc + 1> sub_b_2c(const Fq2e<Ba>& a, const Fq2e<Bb>& b, const Fq2e<Bc>& c) {
   return {sub_b_2c(a.c0, b.c0, c.c0), sub_b_2c(a.c1, b.c1, c.c1)};

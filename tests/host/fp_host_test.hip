@@ -40,6 +40,13 @@ static std::string run(const std::string& op, const std::string& ha, const std::
   else if (op == "add") out = from_mont(add(a, b));
   else if (op == "sub") out = from_mont(sub(a, b));
   else if (op == "neg") out = from_mont(neg(a));
+  else if (op == "subr") {       // rippling difference: same value as sub, limbs 0..7 below 2^29 exactly; reduce2 without its carry pass on top
+    auto t = sub_ripple(add(add(a, b), c), d);
+    bool normal = true;
+    for (int i = 0; i < NL - 1; ++i) normal = normal && t.l[i] < (1u << LB);
+    if (!normal) return std::string("limbs");
+    out = from_mont(reduce2_normal(t));
+  }
   else if (op == "dbl") out = from_mont(dbl(a));
   else if (op == "inv") out = from_mont(inv(a));
   else if (op == "muladd") out = from_mont(mul_add(a, b, c, d));
@@ -48,6 +55,10 @@ static std::string run(const std::string& op, const std::string& ha, const std::
   else if (op == "iszero") {   // (a - b) == 0 ?  and is (a+b-c) zero?
     bool z1 = is_zero(sub(a, b)), z2 = is_zero(sub(add(a, b), c));
     return std::string(z1 ? "1" : "0") + (z2 ? "1" : "0");
+  } else if (op == "iszero4") {   // 4a - b and 4a - b + c - d: multiples k p with k up to 9 when they vanish (the prefilter's two candidates)
+    auto f = dbl(dbl(a));                                    // bound 8
+    bool z1 = is_zero(sub(f, b)), z2 = is_zero(sub(add(sub(f, b), c), d)), m1 = maybe_zero(sub(f, b));
+    return std::string(z1 ? "1" : "0") + (z2 ? "1" : "0") + (m1 || !z1 ? "1" : "0");
   } else if (op == "chain") {
     // ((a+b) - c) * ((a - b) + 2d)  with lazily bounded operands, squared, minus a*d
     auto t1 = sub(add(a, b), c);                 // bound 2+2+2+1 = 7

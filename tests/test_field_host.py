@@ -33,6 +33,7 @@ def test_field_ops_match_python(exe, f):
         "dbl": lambda a, b, c, d: 2 * a % p,
         "muladd": lambda a, b, c, d: (a * b + c * d) % p,
         "roundtrip": lambda a, b, c, d: a % p,
+        "subr": lambda a, b, c, d: (a + b + c - d) % p,
         "reduce2": lambda a, b, c, d: (a + b + c) % p,
         "chain": lambda a, b, c, d: ((2 * (((a + b) - c) * ((a - b) + 2 * d))) ** 2 - a * d) % p,
         "lazy12": lambda a, b, c, d: ((a + b + c + d + a + c) * (a + b + c + d + d)) % p,
@@ -84,6 +85,23 @@ def test_is_zero_exact(exe, f):
         c = (a + b) % p if rng.random() < 0.5 else rng.randrange(p)
         lines.append("%s iszero %x %x %x 0" % (f, a, b, c))
         want.append(("1" if a == b else "0") + ("1" if (a + b - c) % p == 0 else "0"))
+    assert hostbuild.run_lines(exe, lines) == want
+
+
+@pytest.mark.parametrize("f", ["q", "r"])
+def test_is_zero_on_larger_multiples_of_p(exe, f):
+    """is_zero = cheap limb-0 prefilter (maybe_zero: two candidates for k in value = k p) + exact check: values that vanish as
+    k p for k = 3..9 in nearly-normal form, values that do not, and the prefilter never says no to a true zero."""
+    p = MODS[f]
+    rng = random.Random(6)
+    lines, want = [], []
+    for _ in range(400):
+        a = rng.choice([0, 1, p - 1, p >> 1, (p >> 2) + 1]) if rng.random() < 0.2 else rng.randrange(p)
+        b = 4 * a % p if rng.random() < 0.5 else rng.randrange(p)
+        c = rng.randrange(p)
+        d = (4 * a - b + c) % p if rng.random() < 0.5 else rng.randrange(p)
+        lines.append("%s iszero4 %x %x %x %x" % (f, a, b, c, d))
+        want.append(("1" if (4 * a - b) % p == 0 else "0") + ("1" if (4 * a - b + c - d) % p == 0 else "0") + "1")
     assert hostbuild.run_lines(exe, lines) == want
 
 
