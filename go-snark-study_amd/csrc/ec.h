@@ -256,6 +256,63 @@ GS_HD void xyzz_madd(Xyzz<T>& acc, const Affine<T>& b, bool negate = false) {
   }
 }
 
+// The accumulator of k_bucket_accumulate<G2>: an Xyzz whose y is typed with bound 2 instead of 5.  Every y the accumulation loop
+// produces IS below 2p (first point: +-y2; mixed addition: one Montgomery reduction per coordinate), only the doubling of the rare
+// P == Q case leaves 5 -- and with y < 2p the difference R = S2 - Y1 stays below 5p, inside what the Fq2 square (2a)(2a + 1) <= 160 and
+// the four-term Y3 take, so R needs no reduce2 (two coordinates x ~60 instructions per addition; P keeps its reduction: X1 < 9p).
+template <class T>
+struct XyzzAcc {
+  typename T::template E<9> x;
+  typename T::template E<2> y, zz, zzz;
+};
+template <class T> GS_HD bool is_inf(const XyzzAcc<T>& p) { return T::limbs_all_zero(p.zz); }
+template <class T> GS_HD XyzzAcc<T> xyzz_acc_inf() {
+  XyzzAcc<T> r;
+  r.x = T::template zero<9>(); r.y = T::template zero<2>(); r.zz = T::template zero<2>(); r.zzz = T::template zero<2>();
+  return r;
+}
+template <class T> GS_HD Xyzz<T> to_xyzz(const XyzzAcc<T>& a) {
+  Xyzz<T> r;
+  r.x = a.x; r.y = relax<5>(a.y); r.zz = a.zz; r.zzz = a.zzz;
+  return r;
+}
+// acc += +-(x2, y2), the G2 steps of xyzz_madd below on the tighter accumulator
+template <class T>
+GS_HD void xyzz_madd(XyzzAcc<T>& acc, const Affine<T>& b, bool negate = false) {
+  static_assert(GS_PAIR != 0 && T::kWords != 8, "the tight accumulator is the G2 accumulation kernel's");
+  if (is_inf(b)) return;
+  const auto y2 = select(negate, neg(b.y), relax<2>(b.y));
+  if (is_inf(acc)) {
+    acc.x = relax<9>(b.x); acc.y = y2;
+    acc.zz = relax<2>(T::one()); acc.zzz = relax<2>(T::one());
+    return;
+  }
+  typename T::template E<2> U2, S2;
+  if constexpr ((GS_G2_MASK & 1) != 0) mul2(b.x, acc.zz, y2, acc.zzz, U2, S2);
+  else { U2 = mul(b.x, acc.zz); S2 = mul(y2, acc.zzz); }
+  const auto P = sub_ripple(U2, acc.x);                 // 2 + 9 + 1 = 12
+  const auto R = sub_ripple(S2, acc.y);                 // 2 + 2 + 1 = 5
+  if (is_zero(P)) {
+    if (is_zero(R)) {
+      const Xyzz<T> d = xyzz_dbl_affine<T>(b.x, y2);
+      acc.x = d.x; acc.y = reduce2(d.y); acc.zz = d.zz; acc.zzz = d.zzz;
+    } else acc = xyzz_acc_inf<T>();
+    return;
+  }
+  typename T::template E<2> PP, RR, PPP, Q, ZZ3, ZZZ3;
+  const auto Pr = reduce2_normal(P);                    // the Fq2 square takes (2a)(2a + 1) <= 160: P < 12p does not fit, R < 5p does
+  if constexpr ((GS_G2_MASK & 2) != 0) sqr2(Pr, R, PP, RR);
+  else { PP = sqr(Pr); RR = sqr(R); }
+  if constexpr ((GS_G2_MASK & 4) != 0) mul2(Pr, PP, acc.x, PP, PPP, Q);
+  else { PPP = mul(Pr, PP); Q = mul(acc.x, PP); }
+  const auto X3 = sub_b_2c(RR, PPP, Q);                 // RR - PPP - 2 Q, one carry pass per coordinate: 2 + 2 + 4 + 1 = 9
+  const auto Y3 = mul_sub(R, sub(Q, X3), acc.y, PPP);   // (5, 12, 2, 2): 60 + 72 + 6 + 6 = 144 <= 160
+  if constexpr ((GS_G2_MASK & 8) != 0) mul2(acc.zz, PP, acc.zzz, PPP, ZZ3, ZZZ3);
+  else { ZZ3 = mul(acc.zz, PP); ZZZ3 = mul(acc.zzz, PPP); }
+  acc.zz = ZZ3; acc.zzz = ZZZ3;
+  acc.x = X3; acc.y = Y3;
+}
+
 // 2 * acc   [dbl-2008-s-1: 6M + 4S... a = 0]
 template <class T>
 GS_HD void xyzz_dbl(Xyzz<T>& acc) {

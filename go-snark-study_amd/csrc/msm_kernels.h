@@ -399,7 +399,12 @@ __global__ void __launch_bounds__(256, AccTuning<T>::kMinWaves) k_bucket_accumul
   uint32_t b = chunk_bucket[t];
   uint32_t bend = offsets[b + 1];
   bool started_before = offsets[b] < beg;
-  Xyzz<T> acc = xyzz_inf<T>();
+  // G2: the accumulator with y typed below 2p (ec.h, XyzzAcc: R then needs no reduction); G1 has no reductions to save
+  constexpr bool kTight = GS_PAIR != 0 && T::kWords != 8;
+  using Acc = std::conditional_t<kTight, XyzzAcc<T>, Xyzz<T>>;
+  auto acc_inf = [] { if constexpr (kTight) return xyzz_acc_inf<T>(); else return xyzz_inf<T>(); };
+  auto acc_store = [](uint32_t* p, const Acc& a) { if constexpr (kTight) store_xyzz<T>(p, to_xyzz(a)); else store_xyzz<T>(p, a); };
+  Acc acc = acc_inf();
   const uint4* e4 = reinterpret_cast<const uint4*>(entries + beg);      // beg is a multiple of 4 entries = 16 B
   // Software pipeline: the table point of entry e+1 is requested before the 8M+2S of entry e, so the random
   // 64/128-byte gather (HBM miss ~900 cycles) is covered by ~4000 cycles of arithmetic of the same wave.
@@ -420,9 +425,9 @@ __global__ void __launch_bounds__(256, AccTuning<T>::kMinWaves) k_bucket_accumul
     RawAffine<T> curp;
     if constexpr (kPre) curp = nextp;
     if (e >= bend) {                                                     // bucket b is complete
-      store_xyzz<T>((started_before ? job.heads + (size_t)t * pw : job.buckets + (size_t)b * pw), acc);
+      acc_store((started_before ? job.heads + (size_t)t * pw : job.buckets + (size_t)b * pw), acc);
       started_before = false;
-      acc = xyzz_inf<T>();
+      acc = acc_inf();
       b = nb; bend = offsets[b + 1];
     }
     if (e + 1 < end) {                                                   // issue the next gather
@@ -442,7 +447,7 @@ __global__ void __launch_bounds__(256, AccTuning<T>::kMinWaves) k_bucket_accumul
   }
   uint32_t* dst = (bend > end) ? job.tails + (size_t)t * pw
                                : (started_before ? job.heads + (size_t)t * pw : job.buckets + (size_t)b * pw);
-  store_xyzz<T>(dst, acc);
+  acc_store(dst, acc);
 }
 
 // the sum of bucket b, wherever its pieces are

@@ -41,9 +41,18 @@ static void rd_elem(std::istringstream& ss, Fq2e<2>& e) { e.c0 = rd(ss); e.c1 = 
 static std::string show(const Fe<ModQ, 1>& e) { return hex_of(e); }
 static std::string show(const Fq2e<1>& e) { return hex_of(e.c0) + " " + hex_of(e.c1); }
 
+// the accumulation kernel's own accumulator: G2 takes the tight one (ec.h XyzzAcc), G1 the plain Xyzz
+template <class T> struct TightOf { using type = Xyzz<T>; static type inf() { return xyzz_inf<T>(); } static Xyzz<T> plain(const type& a) { return a; } };
+template <> struct TightOf<Fq2Tag> {
+  using type = XyzzAcc<Fq2Tag>;
+  static type inf() { return xyzz_acc_inf<Fq2Tag>(); }
+  static Xyzz<Fq2Tag> plain(const type& a) { return to_xyzz(a); }
+};
+
 template <class T>
 static void run(const std::string& op, int n) {
   Xyzz<T> acc = xyzz_inf<T>();
+  typename TightOf<T>::type tight = TightOf<T>::inf();
   for (int i = 0; i < n; ++i) {
     std::string line; std::getline(std::cin, line);
     std::istringstream ss(line);
@@ -58,11 +67,14 @@ static void run(const std::string& op, int n) {
       xyzz_add(acc, t);
     } else if (op == "maddsum") {
       xyzz_madd(acc, a, sign != 0);
+    } else if (op == "maddacc") {          // the same chain through the kernel's accumulator type
+      xyzz_madd(tight, a, sign != 0);
     } else if (op == "small") {
       const uint32_t small[8] = {k[0], 0, 0, 0, 0, 0, 0, 0};
       xyzz_add(acc, xyzz_mul_words_w4(xyzz_from_affine(a), small));
     }
   }
+  if (op == "maddacc") acc = TightOf<T>::plain(tight);
   Affine<T> r = xyzz_to_affine(acc);
   if (is_inf(r)) std::cout << "inf\n";
   else std::cout << show(r.x) << " " << show(r.y) << "\n";

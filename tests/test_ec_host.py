@@ -90,6 +90,25 @@ def test_complete_addition_doubling_and_cancellation(exe, g):
 
 
 @pytest.mark.parametrize("g", ["g1", "g2"])
+def test_accumulation_kernel_accumulator_type(exe, g):
+    """k_bucket_accumulate's own accumulator (G2: ec.h XyzzAcc, y typed below 2p so that R needs no reduction; G1: the plain Xyzz)
+    through the same chains: random points with negations and infinities, then doubling (whose y must come back below 2p),
+    cancellation, restart from infinity and further additions on top of a doubled point."""
+    G, gen = (O.G1, O.G1_GEN) if g == "g1" else (O.G2, O.G2_GEN)
+    rng = random.Random(14)
+    terms = [(rand_pt(rng, G, gen, 0.2), 1, rng.randrange(2)) for _ in range(40)]
+    assert ask(exe, g, "maddacc", terms, G) == ref_sum(G, terms)
+    p = G.MulScalar(gen, 987654321)
+    p2 = G.Add(G.MulScalar(gen, 987654000), G.MulScalar(gen, 321))            # same point, different Z
+    q = G.MulScalar(gen, 55555)
+    assert ask(exe, g, "maddacc", [(p, 1, 0), (p2, 1, 0)], G) == G.Affine(G.Double(p))
+    assert ask(exe, g, "maddacc", [(p, 1, 0), (p2, 1, 1)], G) is None
+    chain = [(p, 1, 0), (p2, 1, 0), (q, 1, 1), (p, 1, 0), (q, 1, 0), (p2, 1, 1), (p, 1, 1), (p2, 1, 1), (q, 1, 0), (q, 1, 0)]
+    assert ask(exe, g, "maddacc", chain, G) == ref_sum(G, chain)
+    assert ask(exe, g, "maddacc", [], G) is None
+
+
+@pytest.mark.parametrize("g", ["g1", "g2"])
 def test_small_scalar_mul(exe, g):
     G, gen = (O.G1, O.G1_GEN) if g == "g1" else (O.G2, O.G2_GEN)
     rng = random.Random(13)
