@@ -266,9 +266,25 @@ struct XyzzAcc {
   typename T::template E<2> y, zz, zzz;
 };
 template <class T> GS_HD bool is_inf(const XyzzAcc<T>& p) { return T::limbs_all_zero(p.zz); }
+// Constants assigned to the accumulator inside a RARE branch (zeros of a reset, the limbs of `one` at a bucket's first point) are
+// phi inputs of the merged accumulator, and the compiler materialises them as v_mov in FRONT of the branch: 72 of them per
+// iteration of the G2 loop.  Passing each limb through an empty volatile asm inside the branch pins the v_mov there.
+#ifndef GS_G2_OPAQUE
+#define GS_G2_OPAQUE 1
+#endif
+template <class M, int B> GS_HD void pin_in_branch(Fe<M, B>& a) {
+#if defined(__HIP_DEVICE_COMPILE__) && GS_G2_OPAQUE
+#pragma unroll
+  for (int i = 0; i < NL; ++i) asm volatile("" : "+v"(a.l[i]));
+#else
+  (void)a;
+#endif
+}
+template <int B> GS_HD void pin_in_branch(Fq2e<B>& a) { pin_in_branch(a.c0); pin_in_branch(a.c1); }
 template <class T> GS_HD XyzzAcc<T> xyzz_acc_inf() {
   XyzzAcc<T> r;
   r.x = T::template zero<9>(); r.y = T::template zero<2>(); r.zz = T::template zero<2>(); r.zzz = T::template zero<2>();
+  pin_in_branch(r.x); pin_in_branch(r.y); pin_in_branch(r.zz); pin_in_branch(r.zzz);
   return r;
 }
 template <class T> GS_HD Xyzz<T> to_xyzz(const XyzzAcc<T>& a) {
@@ -285,6 +301,7 @@ GS_HD void xyzz_madd(XyzzAcc<T>& acc, const Affine<T>& b, bool negate = false) {
   if (is_inf(acc)) {
     acc.x = relax<9>(b.x); acc.y = y2;
     acc.zz = relax<2>(T::one()); acc.zzz = relax<2>(T::one());
+    pin_in_branch(acc.zz); pin_in_branch(acc.zzz);
     return;
   }
   typename T::template E<2> U2, S2;
