@@ -98,9 +98,12 @@ GS_HD void mul2(const Fq2e<Ba>& a, const Fq2e<Bb>& b, const Fq2e<Bc>& c, const F
 }
 template <int Ba, int Bb>
 GS_HD void sqr2(const Fq2e<Ba>& a, const Fq2e<Bb>& b, Fq2e<2>& aa, Fq2e<2>& bb) {
-  const auto sa = add_lazy(a.c0, a.c1), sb = add_lazy(b.c0, b.c1);
-  const auto da = sub_lazy(a.c0, a.c1), db = sub_lazy(b.c0, b.c1);
-  const auto ta = dbl_lazy(a.c0), tb = dbl_lazy(b.c0);
+  const auto sa = add_lazy(a.c0, a.c1);
+  const auto sb = add_lazy(b.c0, b.c1);
+  const auto da = sub_lazy(a.c0, a.c1);
+  const auto db = sub_lazy(b.c0, b.c1);
+  const auto ta = dbl_lazy(a.c0);
+  const auto tb = dbl_lazy(b.c0);
   const Dot<1> ch[4] = {dot_of(sa, da), dot_of(ta, a.c1), dot_of(sb, db), dot_of(tb, b.c1)};
   Fe<ModQ, 2> r[4];
   dots_uniform<ModQ, 4, 1>(ch, r);

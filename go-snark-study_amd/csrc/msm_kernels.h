@@ -382,7 +382,13 @@ template <class T> struct AccTuning;
 #define GS_G2_TOUCH 0            // measured: a one-word touch of the next point's line does not pay for G2 (3.96 vs 4.07 ms)
 #endif
 template <> struct AccTuning<FqTag> { static constexpr int kMinWaves = GS_G1_WAVES; static constexpr bool kRegisterPrefetch = GS_G1_PREFETCH != 0; static constexpr bool kTouch = true; };
-template <> struct AccTuning<Fq2Tag> { static constexpr int kMinWaves = 2; static constexpr bool kRegisterPrefetch = false; static constexpr bool kTouch = GS_G2_TOUCH != 0; };
+#ifndef GS_G2_WAVES
+#define GS_G2_WAVES 2
+#endif
+#ifndef GS_G2_PREFETCH
+#define GS_G2_PREFETCH 0
+#endif
+template <> struct AccTuning<Fq2Tag> { static constexpr int kMinWaves = GS_G2_WAVES; static constexpr bool kRegisterPrefetch = GS_G2_PREFETCH != 0; static constexpr bool kTouch = GS_G2_TOUCH != 0; };
 
 template <class T>
 __global__ void __launch_bounds__(256, AccTuning<T>::kMinWaves) k_bucket_accumulate(AccJobs jobs, const uint32_t* __restrict__ offsets,
