@@ -93,6 +93,18 @@ bool g2_to_affine_std(const G2Xyzz& p, uint64_t out[16]);
 // k * P with a 256-bit scalar in ABI words (reduced mod r first)
 G1Xyzz g1_mul_scalar(const G1Xyzz& p, const uint64_t k[4]);
 G2Xyzz g2_mul_scalar(const G2Xyzz& p, const uint64_t k[4]);
+// Host-side fixed-base multiplication for points that stay the same for the life of a key (delta, delta2 of groth16.Pk): a table
+// of d * 16^w * P (w < 64, d = 1..15; 960 points, built once in ~1.5 ms for G1 / ~5 ms for G2) turns k * P into at most 64 additions
+// instead of 256 doublings + 64 additions -- the prover tail has four such products per proof (groth16.go:254-264, 274-275).
+template <class T>
+struct HostFixedBase {
+  std::vector<Xyzz<T>> win;        // win[15 w + d - 1] = d * 16^w * P
+  void build(const Affine<T>& p);
+  Xyzz<T> mul(const uint64_t k[4]) const;
+};
+extern template struct HostFixedBase<FqTag>;
+extern template struct HostFixedBase<Fq2Tag>;
+
 void fr_canon_words(const uint64_t k[4], uint32_t out[8]);
 
 }  // namespace gs

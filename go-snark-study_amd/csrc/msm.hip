@@ -424,4 +424,32 @@ G2Xyzz g2_mul_scalar(const G2Xyzz& p, const uint64_t k[4]) {
   return xyzz_mul_words_w4(p, w);
 }
 
+template <class T>
+void HostFixedBase<T>::build(const Affine<T>& p) {
+  win.assign(64 * 15, xyzz_inf<T>());
+  Xyzz<T> base = xyzz_from_affine(p);
+  for (int w = 0; w < 64; ++w) {
+    Xyzz<T> run = base;
+    for (int d = 1; d <= 15; ++d) {
+      win[15 * w + d - 1] = run;
+      if (d < 15) xyzz_add(run, base);
+    }
+    for (int j = 0; j < 4; ++j) xyzz_dbl(base);          // 16^(w+1) * P
+  }
+}
+template <class T>
+Xyzz<T> HostFixedBase<T>::mul(const uint64_t k[4]) const {
+  uint32_t w[8];
+  fr_canon_words(k, w);
+  Xyzz<T> acc = xyzz_inf<T>();
+  for (int nib = 0; nib < 64; ++nib) {
+    const uint32_t v = (w[nib >> 3] >> ((nib & 7) * 4)) & 15u;
+    if (v) xyzz_add(acc, win[15 * nib + v - 1]);
+  }
+  return acc;
+}
+template struct HostFixedBase<FqTag>;
+template struct HostFixedBase<Fq2Tag>;
+
+
 }  // namespace gs

@@ -1,5 +1,6 @@
 // Internal: device-resident proving keys and the prover drivers (implemented in prove.hip).
 #pragma once
+#include <mutex>
 #include "msm.h"
 #include "poly.h"
 #include "runtime.h"
@@ -17,6 +18,10 @@ struct GrothPkObj : Object {      // groth16.Pk (groth16/groth16.go:15-32), resi
   BaseTable t_at, t_bacgamma1, t_bacdelta, t_ptd, t_bacgamma2;   // their window tables (built on the first prove)
   G1Affine alpha, beta, delta;             // host, Montgomery
   G2Affine beta2, delta2;
+  // host-side window tables of delta / delta2 for the tail's result-independent products (built on the first proof of the key)
+  std::once_flag fixed_once;
+  HostFixedBase<FqTag> delta_fixed;
+  HostFixedBase<Fq2Tag> delta2_fixed;
   Divisor z;                               // pk.Z with cached 1/rev(Z) series + spectrum
   // Evaluation-basis copy of PowersTauDelta (optional; gs_groth16_setup builds it, gs_groth16_pk_set_eval attaches one):
   //   ptd_eval[j-1] = l_j(tau) * Z(tau) / delta * G,  l_j = Lagrange basis over the nodes n+1 .. 2n  (j = 1..n_eval = #constraints)

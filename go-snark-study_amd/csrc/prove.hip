@@ -307,12 +307,16 @@ int groth16_sums_impl(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, const
 
 // --- the O(1) tail on host cores (groth16.go:253-275) ----------------------------------------------------
 static void groth16_tail_pre(GrothPkObj* pk, const uint64_t r[4], const uint64_t s[4], GrothTailPre& pre) {
-  const G1Xyzz delta = xyzz_from_affine(pk->delta);
-  const G2Xyzz delta2 = xyzz_from_affine(pk->delta2);
-  pre.sdelta2 = std::async(std::launch::async, [delta2, s] { return g2_mul_scalar(delta2, s); });
-  pre.sdelta = std::async(std::launch::async, [delta, s] { return g1_mul_scalar(delta, s); });
-  pre.rdelta = g1_mul_scalar(delta, r);
-  pre.rsdelta = g1_mul_scalar(pre.rdelta, s);
+  // r delta, s delta, s delta2, (r s) delta: multiples of points that belong to the KEY -- fixed-base window tables (msm.h), built by
+  // whichever proof of the key comes first; ~64 additions each instead of 256 doublings + 64 additions
+  std::call_once(pk->fixed_once, [pk] { pk->delta_fixed.build(pk->delta); pk->delta2_fixed.build(pk->delta2); });
+  uint64_t s_copy[4] = {s[0], s[1], s[2], s[3]};
+  pre.sdelta2 = std::async(std::launch::async, [pk, s_copy] { return pk->delta2_fixed.mul(s_copy); });
+  pre.sdelta = std::async(std::launch::deferred, [pk, s_copy] { return pk->delta_fixed.mul(s_copy); });   // ~60 us: no thread of its own
+  pre.rdelta = pk->delta_fixed.mul(r);
+  uint64_t rs[4];
+  fr_mul_words(r, s, rs);
+  pre.rsdelta = pk->delta_fixed.mul(rs);                       // (r s) delta = s (r delta)
 }
 static void groth16_tail_post(GrothPkObj* pk, const GrothSums& sums, GrothTailPre& pre, const uint64_t r[4], const uint64_t s[4],
                               uint64_t out_proof[32], int inf[3], const GrothTailEarly* early = nullptr) {
