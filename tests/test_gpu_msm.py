@@ -78,6 +78,24 @@ def test_g1_msm_degenerate_inputs_complete_addition():
     assert capi.msm(h, capi.ints_to_u64(big)) == U.ref_msm_affine(O.G1, pts, big)
 
 
+def test_g2_msm_degenerate_inputs_complete_addition():
+    """The G2 accumulation kernel keeps its own accumulator type (ec.h XyzzAcc, y below 2p): the same degenerate chains as the G1
+    test -- P + P inside a bucket (the doubling whose y has to be reduced back), P + (-P), everything cancelling, further points on
+    top of a doubled one -- plus many copies, so that chunks start, continue and end inside such runs."""
+    p = O.G2.MulScalar(O.G2_GEN, 987654321)
+    q = O.G2.Neg(p)
+    t = O.G2.MulScalar(O.G2_GEN, 4242)
+    pts = [p, p, p, q, p, q, q, p, t, t, p, t]
+    ks = [5, 5, 5, 5, 7, 7, 3, O.R - 2, 5, 5, 5, 7]
+    h = capi.g2_upload(capi.g2_points_to_u64(pts))
+    assert capi.msm(h, capi.ints_to_u64(ks), g2=True) == U.ref_msm_affine(O.G2, pts, ks)
+    assert capi.msm(h, capi.ints_to_u64([9, 0, 0, 9] + [0] * 8), g2=True) is None
+    many = [p, q, t] * 50 + [p] * 40                       # 190 points, a handful of distinct scalars: long runs of equal points per bucket
+    mk = [3, 3, 3] * 50 + [3] * 20 + [O.R - 3] * 20
+    hm = capi.g2_upload(capi.g2_points_to_u64(many))
+    assert capi.msm(hm, capi.ints_to_u64(mk), g2=True) == U.ref_msm_affine(O.G2, many, mk)
+
+
 @pytest.mark.parametrize("c", [8, 9, 11, 16, 17, 18, 20])
 def test_g1_msm_every_window_width(c):
     rng = random.Random(300 + c)
