@@ -8,6 +8,9 @@
 #    ncclAllGather of the 416-byte records, gs_scalars_scatter's ncclSend/ncclRecv group): tests/test_gpu_zy_multi.py;
 # 3. with more than one visible GPU: the same command line WITHOUT the sharing switch (RCCL over N physical devices:
 #    ncclCommInitRank with nranks > 1 and the in-library gather between processes) for prove and prove_sharded.
+# 0. (round 4) the PLAIN form the driver uses at N = 1 -- `python bench.py --gpus N`, no launcher, WORLD_SIZE unset -- which drives the
+#    N devices from one process (logical devices on the visible GPUs when there are fewer than N) and must print ONE line with
+#    `value` (weak), `strong.prove_sharded_*` (both routes), `strong.msm_sharded_2^22`, `rccl` and `devices`.
 # Prints one line per step; exit status != 0 when a step fails.
 set -u
 N=${1:-2}
@@ -27,6 +30,23 @@ step() {   # step "<title>" <share:0|1> <bench args...>: the driver's command li
     || { echo "   FAILED (no JSON line):"; echo "$out" | tail -5; fail=1; }
 }
 
+plain() {  # plain "<title>" <bench args...>
+  local title=$1; shift
+  echo "== $title"
+  local out
+  if ! out=$(env -u WORLD_SIZE -u RANK -u LOCAL_RANK python bench.py --gpus "$N" "$@" 2>&1); then
+    echo "   FAILED (exit status):"; echo "$out" | tail -5; fail=1; return
+  fi
+  echo "$out" | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.readline())
+s=d['strong']; k=[x for x in s if x.startswith('prove_sharded')][0]
+need=[s[k]['px_route']['proof_equals_single_device'], s[k]['values_route']['proof_equals_single_device'], s['msm_sharded_2^22']['equals_naive_loop_golden']]
+print('   n_gpus', d['n_gpus'], '| weak %.4g %s' % (d['value'], d['unit']), '| strong px %.2f ms, values %.2f ms, msm 2^22 %.2f ms' % (s[k]['px_route']['ms_per_step'], s[k]['values_route']['ms_per_step'], s['msm_sharded_2^22']['ms_per_step']), '| rccl', d['rccl'].get('ranks_seen'), 'rank(s),', d['rccl'].get('collectives'), 'collectives | checks', need)
+assert d['n_gpus']==$N and all(need) and 'devices' in d and 'rccl' in d
+" || { echo "   FAILED (line incomplete):"; echo "$out" | tail -5; fail=1; }
+}
+plain "plain form, one process over $N devices: weak + strong + rccl in ONE line" --steps 3 --warmup 1 --reps 1 --log2n 16
 step "driver command line, $N ranks sharing GPU 0 (gloo): weak scaling, independent proofs" 1 --steps 3 --warmup 1 --reps 1 --log2n 16 --cpu-log2n 0 --no-extras
 step "same, ONE proof sharded over the $N ranks (host gather): strong scaling" 1 --workload prove_sharded --steps 3 --warmup 1 --reps 1 --log2n 16 --cpu-log2n 0
 echo "== rank-mode entry points at world size 1 (RCCL communicator, gather, scatter)"
