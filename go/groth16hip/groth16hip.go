@@ -89,6 +89,9 @@ func remember(id keyID, k *gosnarkhip.Groth16Key, pin bool) *entry {
 	if pin {
 		e.refs = 1
 	}
+	if prev, ok := keys[id]; ok { // the same backing arrays were uploaded again (a setup re-run in place): the old device key must not leak
+		drop(id, prev)
+	}
 	keys[id] = e
 	for len(keys) > MaxResidentKeys { // evict the least recently used key and give its HBM back
 		var old keyID

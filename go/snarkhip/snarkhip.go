@@ -79,6 +79,9 @@ func remember(id keyID, k *gosnarkhip.PinocchioKey, pin bool) *entry { // mu hel
 	if pin {
 		e.refs = 1
 	}
+	if prev, ok := keys[id]; ok { // the same backing arrays were uploaded again (a setup re-run in place): the old device key must not leak
+		drop(id, prev)
+	}
 	keys[id] = e
 	for len(keys) > MaxResidentKeys {
 		var old keyID

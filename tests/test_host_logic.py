@@ -102,3 +102,33 @@ def test_shard_split_is_the_same_everywhere():
             assert all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
             sizes = [hi - lo for lo, hi in ranges]
             assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+
+
+def test_go_layer_matches_the_c_abi_mechanically(tmp_path):
+    """tools/check_go_abi.py: every C.gs_* call of go/**/*.go has the arity and the per-position kind (handle /
+    pointer / scalar type) of its prototype in include/gosnark_hip.h, every prototype is bound, and every INTEGRATION.md row's C driver
+    calls the entry points its Go functions reach.  The checker must also FAIL when an argument is dropped or two are swapped."""
+    import shutil
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import check_go_abi as chk
+    errs, stats = chk.check()
+    assert errs == [], errs
+    assert stats["prototypes"] == stats["bound"] >= 112 and stats["go_calls"] >= stats["prototypes"]
+    assert stats["unresolved_arguments"] <= stats["go_calls"] // 4 and stats["integration_rows_checked"] >= 10
+    shutil.copytree(chk.GO_DIR, tmp_path / "go")
+    seams = tmp_path / "go" / "gosnarkhip" / "seams.go"
+    good = seams.read_text()
+    call = "C.gs_zpoly(C.size_t(deg), ptr(out))"
+    assert call in good
+    saved = chk.GO_DIR
+    try:
+        chk.GO_DIR = str(tmp_path / "go")
+        seams.write_text(good.replace(call, "C.gs_zpoly(ptr(out))", 1))
+        assert any("called with 1 arguments" in e for e in chk.check()[0])
+        seams.write_text(good.replace(call, "C.gs_zpoly(ptr(out), C.size_t(deg))", 1))
+        assert any("argument 1" in e and "wants a scalar" in e for e in chk.check()[0])
+        seams.write_text(good.replace(call, "C.gs_zpoly(C.int(deg), ptr(out))", 1))
+        assert any("is C.int, the header wants size_t" in e for e in chk.check()[0])
+    finally:
+        chk.GO_DIR = saved
