@@ -155,6 +155,36 @@ def cpu_baseline_reference_wasm():
                       "tests/golden/wasm_groth_rand_m17.json" % (n, n + 1, out["prove_ms"] / 1e3)}
 
 
+def witness_digit_stats(w_u64, c, tm):
+    """What the MSM plan sees in a witness (host restatement of k_digits' signed-digit recoding, msm_kernels.h next_digit): the share
+    of zero digits (skipped: no bucket addition), the heaviest bucket, and the buckets the plan cuts into more than 64 chunks
+    (k_heavy_combine's block-wide tree).  Uniform 254-bit scalars: zero share 2^-c, every bucket ~ n W / 2^(c-1) entries."""
+    w = np.ascontiguousarray(w_u64, dtype=np.uint64).reshape(-1, 4)
+    n = w.shape[0]
+    W, B = 254 // c + 1, 1 << (c - 1)
+    carry = np.zeros(n, dtype=np.int64)
+    counts = np.zeros(B + 1, dtype=np.int64)
+    zeros = 0
+    for win in range(W):
+        lo = win * c
+        word, off = lo // 64, lo % 64
+        raw = (w[:, word] >> np.uint64(off)).astype(np.uint64)
+        if off + c > 64 and word + 1 < 4:
+            raw |= w[:, word + 1] << np.uint64(64 - off)
+        raw = (raw & np.uint64((1 << c) - 1)).astype(np.int64) + carry
+        carry = (raw > B).astype(np.int64)
+        d = np.abs(raw - carry * 2 * B)
+        zeros += int((d == 0).sum())
+        counts += np.bincount(d, minlength=B + 1)
+    entries = int(counts[1:].sum())
+    chunk = 32 if entries >= (1 << 23) else 16          # msm.hip choose_chunk (before its heavy-bucket growth)
+    return {"window_bits": c, "digits": n * W, "zero_digit_share": zeros / float(n * W), "bucket_additions_per_base_array": entries,
+            "heaviest_bucket_entries": int(counts[1:].max()), "median_bucket_entries": float(np.median(counts[1:])),
+            "buckets_cut_into_more_than_64_chunks": int((counts[1:] > 65 * chunk).sum()),
+            "note": "host restatement of the plan's digit recoding over the witness (the sums over w: 4 of the 5 MSMs); gs_timing's *_adds count "
+                    "digits, not non-zero digits, so roofline_valu of this instance OVERSTATES the additions by the zero share"}
+
+
 def pipelined(begin, end, count, depth, on_done=None):
     tickets = []
     for _ in range(count):
@@ -820,9 +850,11 @@ def main():
                          "(gs_scalars_scatter) and every rank sums only its term ranges (gs_groth16_prove_sharded_values)")
     ap.add_argument("--logical-shards", type=int, default=0,
                     help="prove_sharded / msm_sharded on ONE GPU: that many logical devices in this process (configs[3] stand-in, SURVEY 8e)")
-    ap.add_argument("--instance", default="setup", choices=["setup", "sqchain", "random"],
+    ap.add_argument("--instance", default="setup", choices=["setup", "realistic", "sqchain", "random"],
                     help="setup: sqchain R1CS + structured trusted setup on the device + px from the sparse system (a complete, "
-                         "checkable instance, SURVEY 8d); sqchain: same R1CS with key points k_i*G; random: uniform w / px")
+                         "checkable instance, SURVEY 8d); realistic: the same machinery on an R1CS whose witness has the shape the reference's "
+                         "CalculateWitness produces (circuit.go:158-182: about half zeros and ones, most of the rest below 2^32, few full-width "
+                         "values); sqchain: same R1CS with key points k_i*G; random: uniform w / px")
     ap.add_argument("--pipeline", type=int, default=3, choices=[1, 2, 3],
                     help="operations in flight per GPU (prove / msm_g1 workloads): >= 2 = gs_groth16_prove_begin/_end (gs_msm_g1_begin/"
                          "gs_msm_end), the next operation's plan and accumulations are queued behind the current one's; 1 = one "
@@ -837,9 +869,6 @@ def main():
     ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the strong-scaling figures (`strong`) of the line")
     ap.add_argument("--strong-budget-s", type=int, default=240, help="N > 1: a strong-scaling section that runs longer than this is abandoned "
                                                                       "and the line is printed without it")
-    ap.add_argument("--witness", default="uniform", choices=["uniform", "realistic"],
-                    help="msm_g1 / prove with --instance random: uniform 254-bit scalars, or the shape circuit.go:158-182 produces "
-                         "(about half zeros and ones, most of the rest below 2^32)")
     args = ap.parse_args()
 
     if args.gpus > 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1:
@@ -903,10 +932,11 @@ def main():
         # sections below one instance every rank holds.
         key_seed = 0x5EED0002 if args.instance == "setup" else seed
         inst = (synth.sqchain_setup_instance(n, key_seed) if args.instance == "setup" else
+                synth.realistic_setup_instance(n, seed) if args.instance == "realistic" else
                 synth.sqchain_instance(n, seed) if args.instance == "sqchain" else synth.random_instance(n, seed))
         pk = inst.device_pk()
         w_dev, px_dev = inst.w, inst.px
-        x_pub = capi.u64_to_ints(inst.w_host[1:2])[0] if args.instance == "setup" else None
+        x_pub = capi.u64_to_ints(inst.w_host[1:2])[0] if args.instance in ("setup", "realistic") else None
         if args.instance == "setup" and rank > 0 and not one_job:
             from gosnark_amd import r1csqap as _rq
             x_pub = synth.field_elems(1, key_seed + 4242 + rank)[0]
@@ -1046,7 +1076,7 @@ def main():
     total_steps = args.steps * len(rep_elapsed)
 
     proof_verified = None
-    if args.workload == "prove" and not logical and args.instance == "setup" and not args.no_check:
+    if args.workload == "prove" and not logical and args.instance in ("setup", "realistic") and not args.no_check:
         # Product verifier (groth16.VerifyProof -> gs_groth16_verify, host side), outside the timed region, on EVERY rank:
         # the proof of this rank's instance against the vk its device setup produced, for the right public input and a wrong one.
         p_last = step()
@@ -1070,7 +1100,7 @@ def main():
             raise SystemExit("bench.py: snark.VerifyProof rejected the proof of the benchmarked instance (or accepted a wrong public input)")
         proof_verified = "snark.VerifyProof (five pairing equations) accepted each rank's proof against its device-built vk and rejected a wrong public input (%d/%d ranks)" % (world, world)
     proof_check = None
-    if rank == 0 and world == 1 and args.cpu_log2n > 0 and plain_prove and args.instance == "setup" and not args.no_check:
+    if rank == 0 and world == 1 and args.cpu_log2n > 0 and plain_prove and args.instance in ("setup", "realistic") and not args.no_check:
         # Outside the timed region, part of the checker/baseline leg (the only place bench.py touches oracle/): the toxic
         # values of the synthetic setup are known, so the proof the benchmarked instance must produce is known in closed form.
         proof_check = checker_leg_proof(step(), inst, r_, s_)
@@ -1089,7 +1119,9 @@ def main():
         extras["host_buffers_ms_per_step"] = time_calls(lambda: capi.check(lib.gs_groth16_prove(
             capi.Handle(pk.handle.h), capi.ptr64(inst.w_host), inst.w_host.shape[0], capi.ptr64(inst.px_host), inst.px_host.shape[0],
             capi.ptr64(rs[0]), capi.ptr64(rs[1]), capi.ptr64(outp), infp)), 3)
-        if args.instance == "setup":
+        if args.instance == "realistic":
+            extras["witness_digits"] = witness_digit_stats(inst.w_host, window_bits[0], capi.last_timing())
+        if args.instance in ("setup", "realistic"):
             # witness -> proof: px rebuilt from the resident sparse R1CS every time (gs_groth16_prove_r1cs; r1csqap.go:161-210 + groth16.go:225-278)
             from gosnark_amd import r1csqap
             dr = r1csqap.DeviceR1CS(*inst.r1cs, inst.m)

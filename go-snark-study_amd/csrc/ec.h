@@ -376,6 +376,72 @@ GS_HD void xyzz_add(Xyzz<T>& acc, const Xyzz<T>& b) {
   acc.x = X3; acc.y = Y3;
 }
 
+// acc += B for a point B that lives in MEMORY (HBM or LDS) as the raw limbs store_xyzz writes [x | y | zz | zzz], cw words per
+// coordinate.  Same formulas as xyzz_add, ordered so that each coordinate of B is loaded where it is used and is dead two products
+// later, with a compiler barrier in front of every load (the scheduler may not hoist the loads to the top and keep 72 / 144 more
+// registers alive): the tail kernels of the MSM (bucket combine, reduction trees) hold ONE point in registers plus the temporaries
+// of the formula -- round 3's two-operand form needed 317-388 VGPRs for G2, one wave per SIMD.
+// The doubling case (B == acc as points) doubles B's copy in memory, so acc's own coordinates need not survive to the test.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define GS_MEM_FENCE() asm volatile("" ::: "memory")
+#else
+#define GS_MEM_FENCE() do {} while (0)
+#endif
+template <class T, int B>
+GS_HD typename T::template E<B> load_coord(const uint32_t* p) {
+  typename T::template E<B> e;
+  if constexpr (T::kWords == 8) {
+#pragma unroll
+    for (int i = 0; i < NL; ++i) e.l[i] = p[i];
+  } else {
+#pragma unroll
+    for (int i = 0; i < NL; ++i) { e.c0.l[i] = p[i]; e.c1.l[i] = p[NL + i]; }
+  }
+  return e;
+}
+template <class T>
+GS_HD Xyzz<T> load_point(const uint32_t* b) {
+  constexpr int cw = (T::kWords == 8 ? 1 : 2) * NL;
+  Xyzz<T> r;
+  r.x = load_coord<T, 9>(b); r.y = load_coord<T, 5>(b + cw); r.zz = load_coord<T, 2>(b + 2 * cw); r.zzz = load_coord<T, 2>(b + 3 * cw);
+  return r;
+}
+template <class T>
+GS_HD void xyzz_add_mem(Xyzz<T>& acc, const uint32_t* b) {
+  constexpr int cw = (T::kWords == 8 ? 1 : 2) * NL;
+  const auto bzz = load_coord<T, 2>(b + 2 * cw);
+  if (T::limbs_all_zero(bzz)) return;                   // B = infinity
+  if (is_inf(acc)) { acc = load_point<T>(b); return; }
+  const auto U1 = smul<T>(acc.x, bzz);
+  const auto Tz = smul<T>(acc.zz, bzz);                 // ZZ1 ZZ2
+  GS_MEM_FENCE();
+  const auto bx = load_coord<T, 9>(b);
+  const auto U2 = smul<T>(bx, acc.zz);
+  const auto P = sub(U2, U1);                           // 5
+  GS_MEM_FENCE();
+  const auto bzzz = load_coord<T, 2>(b + 3 * cw);
+  const auto S1 = smul<T>(acc.y, bzzz);
+  const auto Vz = smul<T>(acc.zzz, bzzz);               // ZZZ1 ZZZ2
+  GS_MEM_FENCE();
+  const auto by = load_coord<T, 5>(b + cw);
+  const auto S2 = smul<T>(by, acc.zzz);
+  const auto R = sub(S2, S1);                           // 5
+  if (is_zero(P)) {
+    if (is_zero(R)) { acc = load_point<T>(b); xyzz_dbl(acc); }
+    else acc = xyzz_inf<T>();
+    return;
+  }
+  const auto PP = ssqr<T>(P);
+  const auto Q = smul<T>(U1, PP);
+  const auto PPP = smul<T>(P, PP);
+  acc.zz = smul<T>(Tz, PP);
+  acc.zzz = smul<T>(Vz, PPP);
+  const auto RR = ssqr<T>(R);
+  const auto X3 = sub(RR, add(PPP, dbl(Q)));            // 9
+  acc.y = relax<5>(smul_sub<T>(R, sub(Q, X3), S1, PPP));
+  acc.x = X3;
+}
+
 template <class T>
 GS_HD Xyzz<T> xyzz_neg(const Xyzz<T>& a) {
   Xyzz<T> r = a;

@@ -43,8 +43,7 @@ class HostCopyPool {                       // process-wide; workers sleep on a c
  private:
   HostCopyPool() {
     unsigned hw = std::thread::hardware_concurrency();
-    const char* env = getenv("GS_COPY_THREADS");
-    int want = env ? atoi(env) : 4;
+    int want = (int)run_knob("GS_COPY_THREADS", 4, 1, 64);
     if (hw && (unsigned)want > hw) want = (int)hw;
     for (int i = 1; i < want; ++i) workers_.emplace_back([this] { loop(); });
     for (auto& t : workers_) t.detach();

@@ -21,10 +21,10 @@ static inline dim3 grid1(size_t n, int block = 256) { return dim3((unsigned)((n 
 // additions per term instead of 16.  GS_WINDOW_COST_BUCKET (in mixed additions per bucket) tunes the model for experiments.
 int choose_window_bits(uint32_t n, int forced) {
   if (forced >= 8 && forced <= kMaxWindowBits) return forced;
-  static const double per_bucket = getenv("GS_WINDOW_COST_BUCKET") ? atof(getenv("GS_WINDOW_COST_BUCKET")) : 6.0;
+  static const double per_bucket = dev_knob_f("GS_WINDOW_COST_BUCKET", 6.0, 0.0, 64.0);
   // The model stops at 17 bits: wider windows need 4+ bucket ranges in the sort and a deeper reduce, and measured end to end they
   // lose what the shorter accumulation wins (2^22-constraint proof: c = 17 37.8 ms, 18 41.3 ms, 20 41.6 ms; 2^20: 9.1 / 9.6 / 9.9).
-  static const int auto_max = getenv("GS_AUTO_MAX_C") ? atoi(getenv("GS_AUTO_MAX_C")) : 17;
+  static const int auto_max = (int)dev_knob("GS_AUTO_MAX_C", 17, 8, kMaxWindowBits);
   int best = 8;
   double best_cost = 1e300;
   for (int c = 8; c <= std::min(kMaxWindowBits, std::max(8, auto_max)); ++c) {
@@ -61,7 +61,7 @@ static MsmState& msm_state(Ctx& c) { return c.state<MsmState>(c.msm_state); }
 //   serially by one combine thread, and past kHeavySpan by the block-wide tree)
 static uint32_t choose_chunk(uint64_t entries, uint32_t nbuckets, const std::vector<LaunchShape>& users) {
   (void)users;
-  static const int forced = getenv("GS_CHUNK") ? atoi(getenv("GS_CHUNK")) : 0;          // experiments only (multiple of 4)
+  static const int forced = (int)dev_knob("GS_CHUNK", 0, 4, 1024, 4);                     // development builds only (a multiple of 4)
   if (forced >= 4 && forced % 4 == 0) return (uint32_t)forced;
   uint32_t chunk = entries >= (1ull << 23) ? 32u : 16u;
   while (chunk < 1024u && entries / std::max<uint32_t>(nbuckets, 1u) > 32ull * chunk) chunk *= 2;
@@ -95,7 +95,7 @@ void build_plan(Ctx& c, int slot, const uint32_t* scalars_dev, uint32_t n, MsmPl
   pp.stride = (n + 63u) & ~63u;
   // R >= 4 bucket ranges: partition by (window, range) first (msm_kernels.h); with two ranges reading the digit matrix twice is
   // cheaper than writing and re-reading 8-byte records
-  static const uint32_t part_min_r = getenv("GS_PART_MIN_R") ? (uint32_t)atoi(getenv("GS_PART_MIN_R")) : 4u;
+  static const uint32_t part_min_r = (uint32_t)dev_knob("GS_PART_MIN_R", 4, 2, 64);
   const bool wide = pp.R >= part_min_r;
   const uint32_t nparts = (uint32_t)plan.W * pp.R;
   if (wide && nparts > kMaxParts) throw HipError{hipErrorInvalidValue, "too many (window, range) partitions", __LINE__};
@@ -112,7 +112,7 @@ void build_plan(Ctx& c, int slot, const uint32_t* scalars_dev, uint32_t n, MsmPl
   pb.heavy_list.ensure((size_t)plan.nbuckets * 4);         // one slot per bucket: the list cannot overflow
   pb.counters.ensure(16);
   const size_t lds = (size_t)std::min<uint32_t>(plan.B, kRangeBuckets) * 4;
-  static const int sort_block = getenv("GS_SORT_BLOCK") ? std::max(64, std::min(kSortBlock, atoi(getenv("GS_SORT_BLOCK")))) : kSortBlock;
+  static const int sort_block = (int)dev_knob("GS_SORT_BLOCK", kSortBlock, 64, kSortBlock, 64);
   if (!ms.lds_attr_set) {       // B <= 2^15 counters = 128 KiB of the CU's 160 KiB LDS
     GS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hist), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     GS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
@@ -166,7 +166,7 @@ static void ensure_table(Ctx& c, BaseTable& t, const uint32_t* row0, size_t n, i
   const uint32_t* src = row0 ? row0 : t.rows.as<uint32_t>();
   if (!src || (!row0 && t.n != n)) throw HipError{hipErrorInvalidValue, "window table rebuild without its points", __LINE__};
   if (n) {
-    static const bool per_row = getenv("GS_TABLE_PER_ROW") != nullptr;      // the one-inversion-per-row builder, for comparison
+    static const bool per_row = dev_flag("GS_TABLE_PER_ROW");               // the one-inversion-per-row builder, for comparison
     if (per_row || W <= 2) {
       hipLaunchKernelGGL(k_build_table<T>, grid1(n), dim3(256), 0, c.stream, src, (uint32_t)n, cbits, W, fresh.as<uint32_t>());
     } else {
@@ -207,9 +207,10 @@ static void msm_enqueue(Ctx& c, const MsmPlan& plan, const std::vector<MsmBase>&
   // Measured (profiles/r02_ab_reduce_depth.txt): tails of a 2^20 proof alone 2.44 -> 1.9 ms against (16 pairs, L = 16).
   // (32 pairs only from 2^19 terms on: a 2^17 / 2^18 proof takes 1.6 / 2.7 ms, and three host additions per pair for five jobs then
   // make the host the pace-setter in some repetitions -- median 2.0 vs 1.6 ms at 2^17 with the same best case.)
-  static const uint32_t fold_env = getenv("GS_FOLD_MAX") ? (uint32_t)std::max(1, atoi(getenv("GS_FOLD_MAX"))) : 0u;
+  static const uint32_t fold_env = (uint32_t)dev_knob("GS_FOLD_MAX", 0, 1, 256);
   const uint32_t fold_max = fold_env ? fold_env : (plan.n >= (1u << 19) ? 32u : 16u);
-  static const uint32_t l_min = getenv("GS_REDUCE_L") ? (uint32_t)std::max(1, atoi(getenv("GS_REDUCE_L"))) : 4u;
+  // (a power of two: the reduce multiplies by L through log2(L) doublings, and the host fold by 256 L likewise)
+  static const uint32_t l_min = (uint32_t)dev_knob("GS_REDUCE_L", 4, 1, 32, 1, true);
   int L = (int)std::max<uint32_t>(1u, std::min<uint32_t>(l_min, plan.B / kReduceBlock));
   while (L < 32 && plan.B / ((uint32_t)kReduceBlock * (uint32_t)L) > fold_max) L *= 2;
   const uint32_t nblk = (plan.B + kReduceBlock * L - 1) / (kReduceBlock * L);

@@ -57,12 +57,18 @@ struct PolyState {
   // factorial tables fact[i] = i!, invfact[i] = 1 / i! for i <= fact_top (Montgomery), grown on demand
   size_t fact_top = 0;
   DevBuf fact, invfact;
-  // tables of the direct H route (hx_direct_dev), per (n, deg Z)
+  // tables of the direct H route (hx_direct_dev), per (n, deg Z).  A few circuit sizes stay cached side by side (a Go key cache
+  // with several keys, a batch over two circuits): with ONE entry alternating sizes rebuilt the tables for every proof and the
+  // rebuild freed buffers that queued kernels of earlier tickets still read.
   struct HxTables {
     size_t n = 0, dz = 0, N = 0;
+    uint64_t stamp = 0;
     DevBuf inv_spec, shift_spec, t1, t2;         // spectra of 1/(t+1) and (-n)^t/t! (size N), value scalings (n each)
     DevBuf conv, hv, g, bad;                     // workspaces: 3 N, n, n; the violated-constraint counter (one word)
-  } hx;
+  };
+  static constexpr int kHxSlots = 4;
+  HxTables hx[kHxSlots];
+  uint64_t hx_clock = 0;
 };
 static PolyState& poly_state(Ctx& c) { return c.state<PolyState>(c.poly_state); }
 
@@ -394,8 +400,15 @@ static bool hx_shape_ok(size_t n, size_t dz) { return n >= 2 && (dz == n - 1 || 
 // tables of one (n, deg Z): once (synchronises the stream when it builds)
 static PolyState::HxTables& hx_tables(Ctx& c, size_t n, size_t dz) {
   PolyState& ps = poly_state(c);
-  PolyState::HxTables& hx = ps.hx;
-  if (hx.n == n && hx.dz == dz) return hx;
+  PolyState::HxTables* slot = &ps.hx[0];
+  for (auto& e : ps.hx) {
+    if (e.n == n && e.dz == dz) { e.stamp = ++ps.hx_clock; return e; }
+    if (e.n == 0 ? slot->n != 0 : (slot->n != 0 && e.stamp < slot->stamp)) slot = &e;      // an empty slot, else the least recently used
+  }
+  PolyState::HxTables& hx = *slot;
+  // Every user of these tables enqueues on the polynomial stream (c.stream here): before a victim's buffers go, whatever is queued
+  // on it must have run -- stated here instead of leaning on hipFree's device-wide synchronisation.
+  if (hx.n != 0) GS_HIP(hipStreamSynchronize(c.stream));
   const int logN = ceil_log2(2 * n);
   const size_t N = (size_t)1 << logN;
   Fe<ModR, 1> r2;
@@ -424,6 +437,7 @@ static PolyState::HxTables& hx_tables(Ctx& c, size_t n, size_t dz) {
   GS_HIP(hipGetLastError());
   GS_HIP(hipStreamSynchronize(c.stream));              // `pw` is released here
   hx.n = n; hx.dz = dz; hx.N = N;
+  hx.stamp = ++ps.hx_clock;
   return hx;
 }
 

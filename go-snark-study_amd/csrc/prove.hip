@@ -48,6 +48,7 @@ struct DevScalars {            // a scalar vector used by a prove call (not owne
 struct ProveState {
   DevBuf hx[Ctx::kSlots];                       // hx = floor(px / Z) -- or H's values on the evaluation-basis route --, one per slot (standard form)
   DevBuf up_w, up_px, up_a, up_b, up_o;         // uploads of host operands / results (blocking entry points only)
+  DevBuf exact_px[Ctx::kSlots];                 // px of the exact witness route, one per slot (allocated only if that route is ever taken)
 };
 ProveState& prove_state(Ctx& c) { return c.state<ProveState>(c.prove_state); }
 
@@ -182,8 +183,9 @@ int groth16_enqueue(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, const S
   }
   // Host order: the accumulations over w are enqueued BEFORE the block that may copy px from pageable host memory -- that copy
   // stages through the runtime inside the call (~5 ms for 64 MiB), and the device must already have its 7 ms of work by then.
+  hipStream_t used_acc[3] = {nullptr, nullptr, nullptr};
   {                                                              // main: the accumulations over w, back to back
-    StreamScope sc(c, c.main_stream);
+    StreamScope sc(c, used_acc[0] = c.acc_stream());
     GS_HIP(hipStreamWaitEvent(c.stream, st.planw, 0));
     // BACDelta's first npublic+1 entries are forced to infinity at key creation, so the reference's
     // loop from NPublic+1 (:248-250) equals a full-range MSM sharing w's plan.
@@ -192,6 +194,10 @@ int groth16_enqueue(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, const S
     if (pipelined) c.next_tails(plan_w.n);
     msm_enqueue_g2(c, plan_w, {MsmBase{&pk->t_bacgamma2, wbase}}, ws + 4, pin + 1, st.pend_g2w, c.tail_stream(0));
     GS_HIP(hipEventRecord(st.done_g2, c.tail_stream(0)));
+  }
+  {
+    StreamScope sc(c, used_acc[1] = c.acc_stream());
+    if (c.stream != used_acc[0]) GS_HIP(hipStreamWaitEvent(c.stream, st.planw, 0));
     msm_enqueue_g1(c, plan_w, {MsmBase{&pk->t_at, wbase}, MsmBase{&pk->t_bacgamma1, wbase}, MsmBase{&pk->t_bacdelta, wbase}}, ws + 0, pin + 0,
                    st.pend_g1w, c.tail_stream(1));
     GS_HIP(hipEventRecord(st.done_g1w, c.tail_stream(1)));
@@ -227,13 +233,22 @@ int groth16_enqueue(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, const S
     GS_HIP(hipEventRecord(st.planh, c.stream));
   }
   {                                                              // main again: the accumulation over h
-    StreamScope sc(c, c.main_stream);
+    StreamScope sc(c, used_acc[2] = c.acc_stream());
     GS_HIP(hipStreamWaitEvent(c.stream, st.planh, 0));
     // a lone proof finishes soonest with the last tail right behind its accumulation; in a pipeline that tail must not sit
     // in front of the next proof's accumulations
     msm_enqueue_g1(c, plan_h, {MsmBase{eval ? &pk->t_ptd_eval : &pk->t_ptd, hbase}}, ws + 3, pin + 2, st.pend_h, pipelined ? c.tail_stream(1) : nullptr);   // :269-271
-    GS_HIP(hipEventRecord(st.done_h, pipelined ? c.tail_stream(1) : c.main_stream));
+    GS_HIP(hipEventRecord(st.done_h, pipelined ? c.tail_stream(1) : c.stream));
   }
+  for (hipStream_t a : used_acc)                                 // (two accumulation streams: the main stream's end mark covers both)
+    if (a && a != c.main_stream) {
+      hipEvent_t ev;
+      GS_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+      GS_HIP(hipEventRecord(ev, a));
+      GS_HIP(hipStreamWaitEvent(c.main_stream, ev, 0));
+      GS_HIP(hipEventDestroy(ev));
+      break;
+    }
   st.total->stop();
   GS_HIP(hipEventRecord(st.done_main, c.main_stream));
   return GS_OK;
@@ -243,7 +258,7 @@ int groth16_enqueue(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, const S
 static double host_now_ms() {
   return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
-static bool host_trace() { static const bool on = getenv("GS_HOST_TRACE") != nullptr; return on; }
+static bool host_trace() { static const bool on = run_flag("GS_HOST_TRACE"); return on; }
 
 int groth16_collect(Ctx& c, GrothInFlight& st, GrothSums& sums) {
   const double t0 = host_trace() ? host_now_ms() : 0;
@@ -1484,12 +1499,16 @@ static DevScalars witness_scalars(R1csObj* o, const uint32_t* wdev, size_t nz, b
   dp.produce = [o, wdev, px_buffer](Ctx& cc) { r1cs_px_dev(cc, *o, wdev, px_buffer(cc)); };
   return dp;
 }
-// px of the exact route lives in the blocking entry points' staging buffer (allocated only if that route is ever taken)
-static uint32_t* exact_px_buffer(Ctx& c, R1csObj* o) {
+// px of the exact route: one buffer per slot (the three tickets and the blocking entry points), allocated only if that route is
+// ever taken.  Round 3 handed every in-flight ticket -- and the blocking entry points' host uploads -- the SAME staging buffer and
+// leaned on all polynomial stages being serialised on one stream; a slot's buffer is only ever touched by the
+// operation that owns the slot, and a slot is re-used only after its operation was collected.
+static uint32_t* exact_px_buffer(Ctx& c, R1csObj* o, int slot) {
   const size_t npx = 2 * o->n - 1;
   o->prod.ensure(npx * 32);
-  prove_state(c).up_px.ensure(npx * 32);
-  return prove_state(c).up_px.as<uint32_t>();
+  DevBuf& b = prove_state(c).exact_px[slot % Ctx::kSlots];
+  b.ensure(npx * 32);
+  return b.as<uint32_t>();
 }
 
 int gs_groth16_prove_witness(gs_handle hpk, gs_handle hr1cs, gs_handle hw, const uint64_t r[4], const uint64_t s[4], uint64_t out_proof[32], int inf[3]) {
@@ -1503,7 +1522,7 @@ int gs_groth16_prove_witness(gs_handle hpk, gs_handle hr1cs, gs_handle hw, const
     reset_timing(c);
     const uint32_t* wdev = w->buf.as<uint32_t>();
     const bool eval = c.eval_basis && pk->shard_count == 1 && pk->n_eval == o->n && hx_shape(o->n, pk->nz);
-    uint32_t* pxdev = exact_px_buffer(c, o);
+    uint32_t* pxdev = exact_px_buffer(c, o, Ctx::kBlockingSlot);
     DevScalars dp = witness_scalars(o, wdev, pk->nz, eval, [pxdev](Ctx&) { return pxdev; });
     dp.p = pxdev;
     return groth16_prove_impl(c, pk, DevScalars{wdev, w->n}, dp, r, s, out_proof, inf);
@@ -1534,13 +1553,13 @@ int gs_groth16_prove_witness_begin(gs_handle hpk, gs_handle hr1cs, gs_handle hw,
     raw->early.pk = pk; raw->early.r = raw->r; raw->early.s = raw->s; raw->early.pre = &raw->pre; raw->early.fpre = &raw->fpre;
     const uint32_t* wdev = w->buf.as<uint32_t>();
     const size_t nw = w->n, nz = pk->nz;
-    DevScalars dp = witness_scalars(o, wdev, nz, eval, [o](Ctx& cc) { return exact_px_buffer(cc, o); });
+    DevScalars dp = witness_scalars(o, wdev, nz, eval, [o, parity](Ctx& cc) { return exact_px_buffer(cc, o, parity); });
     if (!eval) {                               // the monomial route may have to write px at once (its check is a host wait inside enqueue)
-      dp.p = exact_px_buffer(c, o);
+      dp.p = exact_px_buffer(c, o, parity);
     } else {
       dp.produce_hx = nullptr; dp.produce = nullptr;
       raw->exact_route = [pk, o, wdev, nw, nz](Ctx& cc, GrothSums& sums) {
-        uint32_t* pxdev = exact_px_buffer(cc, o);
+        uint32_t* pxdev = exact_px_buffer(cc, o, Ctx::kBlockingSlot);     // the retry is a blocking proof at collection time
         DevScalars ex = witness_scalars(o, wdev, nz, false, [pxdev](Ctx&) { return pxdev; });
         ex.p = pxdev;
         return groth16_sums_impl(cc, pk, DevScalars{wdev, nw}, ex, Shard{}, sums);
@@ -1570,7 +1589,7 @@ int gs_pinocchio_prove_witness(gs_handle hpk, gs_handle hr1cs, gs_handle hw, uin
     reset_timing(c);
     const uint32_t* wdev = w->buf.as<uint32_t>();
     const bool eval = c.eval_basis && pk->n_eval == o->n && hx_shape(o->n, pk->nz);
-    uint32_t* pxdev = exact_px_buffer(c, o);
+    uint32_t* pxdev = exact_px_buffer(c, o, Ctx::kBlockingSlot);
     DevScalars dp = witness_scalars(o, wdev, pk->nz, eval, [pxdev](Ctx&) { return pxdev; });
     dp.p = pxdev;
     return pinocchio_prove_impl(c, pk, DevScalars{wdev, w->n}, dp, out_proof, inf);
@@ -1592,13 +1611,13 @@ int gs_pinocchio_prove_witness_begin(gs_handle hpk, gs_handle hr1cs, gs_handle h
     st->keep = {c.share<Object>(hpk, Kind::PinocchioPk), c.share<Object>(hr1cs, Kind::R1cs), c.share<Object>(hw, Kind::Scalars)};
     const uint32_t* wdev = w->buf.as<uint32_t>();
     const size_t nw = w->n, nz = pk->nz;
-    DevScalars dp = witness_scalars(o, wdev, nz, eval, [o](Ctx& cc) { return exact_px_buffer(cc, o); });
+    DevScalars dp = witness_scalars(o, wdev, nz, eval, [o, parity](Ctx& cc) { return exact_px_buffer(cc, o, parity); });
     if (!eval) {
-      dp.p = exact_px_buffer(c, o);
+      dp.p = exact_px_buffer(c, o, parity);
     } else {
       dp.produce_hx = nullptr; dp.produce = nullptr;
       st->exact_route = [pk, o, wdev, nw, nz](Ctx& cc, uint64_t* out, int* inf) {
-        uint32_t* pxdev = exact_px_buffer(cc, o);
+        uint32_t* pxdev = exact_px_buffer(cc, o, Ctx::kBlockingSlot);     // the retry is a blocking proof at collection time
         DevScalars ex = witness_scalars(o, wdev, nz, false, [pxdev](Ctx&) { return pxdev; });
         ex.p = pxdev;
         return pinocchio_prove_impl(cc, pk, DevScalars{wdev, nw}, ex, out, inf);

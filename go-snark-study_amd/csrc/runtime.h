@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "../../include/gosnark_hip.h"
+#include "knobs.h"
 
 namespace gs {
 
@@ -134,6 +135,11 @@ struct Ctx {
   bool ready = false;
   hipStream_t stream = nullptr;   // the stream every engine function enqueues on (switched by StreamScope)
   hipStream_t main_stream = nullptr;
+  // Development experiment (GS_ACC_STREAMS=2, dev builds): consecutive accumulation launches alternate between two streams, so the
+  // next launch may start while the previous one drains.  Product builds: acc2 == main_stream, i.e. one stream, back to back.
+  hipStream_t acc2 = nullptr;
+  unsigned acc_flip = 0;
+  hipStream_t acc_stream() { return (acc2 && acc2 != main_stream && (acc_flip++ & 1u)) ? acc2 : main_stream; }
   // 0 / 2: reduction tails, 1: plans and H(x).  (A fourth stream for plan(w) was tried and LOST 5 %: beyond four streams two of
   // them share a hardware queue, and the sort of the next proof then queues behind a reduction tail.)
   static constexpr int kAuxStreams = 3;
@@ -158,7 +164,7 @@ struct Ctx {
   unsigned tail_flip = 0;
   hipStream_t tail_stream(int which) { return aux_stream[((which ^ (int)(tail_flip & 1u)) & 1) ? 2 : 0]; }
   void next_tails(uint32_t n) {                     // called once per pipelined operation of n terms
-    static const int mode = getenv("GS_TAIL_FLIP") ? atoi(getenv("GS_TAIL_FLIP")) : 1;      // 0 never, 1 always, 2 by size
+    static const int mode = (int)run_knob("GS_TAIL_FLIP", 1, 0, 2);                        // 0 never, 1 always, 2 by size (same results)
     if (mode == 1 || (mode == 2 && n <= kTailFlipMaxTerms)) tail_flip ^= 1u;
   }
   static constexpr uint32_t kTailFlipMaxTerms = 1u << 18;
@@ -205,6 +211,7 @@ struct Ctx {
   // wait for everything enqueued on this context (outstanding tickets keep their results in their pinned slots)
   void drain() {
     if (main_stream) GS_HIP(hipStreamSynchronize(main_stream));
+    if (acc2 && acc2 != main_stream) GS_HIP(hipStreamSynchronize(acc2));
     for (auto a : aux_stream) if (a && a != main_stream) GS_HIP(hipStreamSynchronize(a));
   }
 };
@@ -245,13 +252,20 @@ inline size_t logical_device_count() {
 // logical device), lock it, check init, translate exceptions into status codes.
 // allow_inflight = false: the call uses workspaces that outstanding tickets also use, so it first waits for their device work
 // (it QUEUES behind them; their results stay in their own pinned slots until gs_*_end collects them).
+// What an entry point sees before gs_init (ready = false; only its lock is used).  ONE object for every instantiation of guarded<F>:
+// as a function-local static of the template each of the ~100 lambdas had a full Ctx of its own, and calls made before gs_init
+// locked different mutexes depending on the entry point.
+inline Ctx& none_ctx() {
+  static Ctx none;
+  return none;
+}
+
 template <class F>
 int guarded(F&& f, bool need_init = true, bool allow_inflight = false, gs_handle route = 0) {
   size_t ndev = 0;
   const int logical = route ? handle_device(route) : current_logical();
   std::shared_ptr<Ctx> pc = ctx_ref(logical, &ndev);
-  static Ctx none;                                // what an entry point sees before gs_init (ready = false); only its lock is used
-  Ctx& c = pc ? *pc : none;
+  Ctx& c = pc ? *pc : none_ctx();
   std::lock_guard<std::mutex> lk(c.mu);
   if (need_init && !c.ready) {
     if (ndev == 0) return fail(GS_ERR_NOT_INIT, "gs_init has not been called (or failed)");

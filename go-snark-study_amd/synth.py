@@ -272,6 +272,94 @@ def sqchain_setup_instance(n, seed, extra_vars=0):
     return SqchainSetupInstance(n, seed, extra_vars)
 
 
+def realistic_r1cs(n, seed):
+    """A satisfiable R1CS whose WITNESS has the shape the reference's CalculateWitness produces (circuitcompiler/circuit.go:158-182:
+    flags, selectors and small intermediate values dominate; few wires are full-width field elements) -- VERDICT r3 next #6.
+    Variables [one, x (public), v_2 .. v_n] (m = n + 1, NPublic = 1); constraint j = 1..n-1 introduces variable j + 1 as one of
+      bit   (~50 %)  v * v = v,          v in {0, 1}
+      small (~40 %)  v * one = v,        v < 2^32            (stand-in for a range-checked value)
+      chain (~10 %)  p * p = v - j one,  p the previous chain variable (x at first): full-width values, as in sqchain_r1cs
+    and constraint n is one * one = one.  Returns (a_csr, b_csr, c_csr, w [m,4] uint64, counts)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    x = field_elems(1, seed + 10)[0]
+    kind = rng.random(n - 1)                                   # constraint j = 1..n-1 <-> kind[j - 1]
+    is_bit, is_chain = kind < 0.5, kind >= 0.9
+    is_small = ~is_bit & ~is_chain
+    j = np.arange(1, n, dtype=np.int64)
+    var = j + 1
+    # previous chain variable of every constraint (1 = x before the first chain constraint)
+    last = np.where(is_chain, var, 0)
+    prev = np.concatenate(([1], np.maximum.accumulate(np.maximum(last, 1))[:-1]))
+    a_col = np.where(is_chain, prev, var)
+    b_col = np.where(is_chain, prev, np.where(is_small, 0, var))
+    one = np.zeros((n, 4), dtype=np.uint64)
+    one[:, 0] = 1
+    rowptr = np.arange(n + 1, dtype=np.uint32)
+    a = (rowptr, np.concatenate((a_col, [0])).astype(np.uint32), one)
+    b = (rowptr, np.concatenate((b_col, [0])).astype(np.uint32), one.copy())
+    # C: one entry {v: 1}, chain rows two entries {one: -j, v: 1} (columns sorted); last row {one: 1}
+    per_row = np.concatenate((np.where(is_chain, 2, 1), [1])).astype(np.uint32)
+    c_rowptr = np.zeros(n + 1, dtype=np.uint32)
+    c_rowptr[1:] = np.cumsum(per_row)
+    nnz = int(c_rowptr[n])
+    c_col = np.zeros(nnz, dtype=np.uint32)
+    c_val = np.zeros((nnz, 4), dtype=np.uint64)
+    first = c_rowptr[:-1][:n - 1]
+    c_col[first[~is_chain]] = var[~is_chain]
+    c_val[first[~is_chain], 0] = 1
+    ch = np.nonzero(is_chain)[0]
+    c_col[first[ch]] = 0
+    c_val[first[ch]] = capi.ints_to_u64([(R - int(k)) % R for k in j[ch]]) if ch.size else np.zeros((0, 4), dtype=np.uint64)
+    c_col[first[ch] + 1] = var[ch]
+    c_val[first[ch] + 1, 0] = 1
+    c_col[nnz - 1] = 0
+    c_val[nnz - 1, 0] = 1
+    c = (c_rowptr, c_col, c_val)
+    # witness
+    w = np.zeros((n + 1, 4), dtype=np.uint64)
+    w[0, 0] = 1
+    w[1] = capi.ints_to_u64([x])[0]
+    w[var[is_bit], 0] = rng.integers(0, 2, size=int(is_bit.sum()), dtype=np.uint64)
+    w[var[is_small], 0] = rng.integers(0, 2**32, size=int(is_small.sum()), dtype=np.uint64)
+    cur, vals = x, []
+    for k in j[ch]:
+        cur = (cur * cur + int(k)) % R
+        vals.append(cur)
+    if vals:
+        w[var[ch]] = capi.ints_to_u64(vals)
+    counts = {"bit": int(is_bit.sum()), "small": int(is_small.sum()), "full_width": int(is_chain.sum()) + 1,
+              "zeros": int((w[:, 0] == 0).sum() if True else 0)}
+    counts["zeros"] = int(((w == 0).all(axis=1)).sum())
+    counts["ones"] = int(((w[:, 0] == 1) & (w[:, 1:] == 0).all(axis=1)).sum())
+    return a, b, c, w, counts
+
+
+class RealisticSetupInstance(SqchainSetupInstance):
+    """SqchainSetupInstance's machinery (device trusted setup from seeded toxic values, px from the sparse system, the closed-form
+    proof) on realistic_r1cs: the heavy-bucket / zero-digit paths of the MSM plan under load instead of uniform 254-bit scalars."""
+
+    def __init__(self, n, seed):
+        from . import r1csqap
+        self.n, self.m, self.seed = n, n + 1, seed
+        self.toxic = field_elems(5, seed + 20)
+        a, b, c, w, self.counts = realistic_r1cs(n, seed)
+        self.r1cs = (a, b, c)
+        self.w_host = w
+        self._pk, self.vk = groth16.GenerateTrustedSetupSparse(n, self.m, 1, a, b, c, self.toxic)
+        self.ax_host, self.bx_host, self.cx_host, self.px_host = r1csqap.ComputePx(a, b, c, w, self.m)
+        self.w = capi.scalars_upload(self.w_host)
+        self.px = capi.scalars_upload(self.px_host)
+
+    def describe(self):
+        return ("realistic-witness R1CS (%(bit)d bit constraints v^2 = v, %(small)d small values < 2^32, %(full_width)d full-width chain values: "
+                "%(zeros)d zeros and %(ones)d ones among the witness entries), structured trusted setup on the device, px from the sparse system"
+                % self.counts) + "; seed 0x%X" % self.seed
+
+
+def realistic_setup_instance(n, seed):
+    return RealisticSetupInstance(n, seed)
+
+
 class SqchainPinocchioInstance:
     """The same sqchain(n) system under the Pinocchio protocol (snark.go): device trusted setup from 8 seeded toxic values
     (gs_pinocchio_setup = snark.go:98-251), resident witness and px.  The verifier (snark.VerifyProof, five pairing

@@ -116,7 +116,7 @@ def test_snark_setup_prove_verify_c_sequence(tmp_path):
     blob = c_util.write_pinocchio_instance(tmp_path, rec)
     r1cs = c_util.write_r1cs(tmp_path, (O.X3_R1CS_A, O.X3_R1CS_B, O.X3_R1CS_C), 1, pinocchio_toxic())
     out = tmp_path / "setup.bin"
-    assert c_util.build_and_run("snark_setup_prove_verify.c", [str(r1cs), str(blob), str(out)], tmp_path).strip() == "OK"
+    assert c_util.build_and_run("snark_setup_prove_verify.c", [str(r1cs), str(blob), str(out)], tmp_path).strip().endswith("OK")    # (RCCL prints its version banner when the rank-mode communicator is created)
     raw = c_util.read_words(out)
     pr, spk, svk = rec["proof"], rec["setup"]["Pk"], rec["setup"]["Vk"]
     want = aff1(pr["PiA"]) + aff1(pr["PiAp"]) + aff2(pr["PiB"]) + aff1(pr["PiBp"]) + aff1(pr["PiC"]) + aff1(pr["PiCp"]) + aff1(pr["PiH"]) + aff1(pr["PiKp"])

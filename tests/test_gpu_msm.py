@@ -3,6 +3,7 @@
 Oracle = literal restatement of `acc = Add(acc, MulScalar(base_i, k_i))`
 (groth16.go:243-250 / g1.go:140-155 / g2.go:142-181): oracle/ref_py.py for tiny n,
 oracle/gs_oracle.c beyond.  Bit-exact on the affine coordinates (integers mod q)."""
+import os
 import random
 
 import numpy as np
@@ -440,3 +441,31 @@ def test_uploads_from_pageable_memory_across_the_staging_pieces(n):
     assert capi.msm(bases, sc) == capi.msm_resident(bases, h, n)
     h.free()
     bases.free()
+
+
+def test_hostile_environment_cannot_change_a_result():
+    """every environment variable the library knows, set to a value that round 3's raw atoi() would have used
+    (GS_REDUCE_L=3 gave a wrong MSM with status 0), in a FRESH process (the knobs are read once): a 2^12-term G1 MSM, a 2^10-term G2 MSM
+    and a pipelined x^3 + x + 5 proof must equal what this process computes, which the tests above pin to the oracle."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, json; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import gosnark_amd; from gosnark_amd import capi, synth, groth16; import gpu_util as U\n"
+        "capi.init(0)\n"
+        "b1 = capi.g1_fixed_base(U.rand_scalars_u64(4096, 611)); k1 = U.rand_scalars_u64(4096, 511)\n"
+        "b2 = capi.g2_fixed_base(U.rand_scalars_u64(1024, 701)); k2 = U.rand_scalars_u64(1024, 700)\n"
+        "inst = synth.sqchain_setup_instance(256, 99); r, s = synth.field_elems(2, 5)\n"
+        "p = groth16.prove_end(groth16.prove_begin(inst.device_pk(), inst.w, inst.px, r, s))\n"
+        "print(json.dumps([capi.msm(b1, k1), capi.msm(b2, k2, g2=True), [p.PiA, p.PiB, p.PiC]]))\n" % (root, os.path.join(root, "tests")))
+    hostile = {"GS_REDUCE_L": "3", "GS_CHUNK": "7", "GS_FOLD_MAX": "-5", "GS_AUTO_MAX_C": "99", "GS_SORT_BLOCK": "1", "GS_PART_MIN_R": "0",
+               "GS_WINDOW_COST_BUCKET": "nan", "GS_TABLE_PER_ROW": "x", "GS_TAIL_FLIP": "77", "GS_COPY_THREADS": "-3", "GS_ACC_STREAMS": "9",
+               "GS_NO_PRIORITY": "1"}
+
+    def run(env):
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, **env), timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return json.loads(out.stdout.strip().splitlines()[-1])
+    assert run(hostile) == run({})

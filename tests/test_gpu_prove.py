@@ -829,6 +829,41 @@ def test_witness_to_proof_without_px_equals_the_px_route(n, extra):
         assert (got.PiC[0], got.PiC[1]) == C.g1_affine(C.g1_mul_scalar(O.G1_GEN, c))
 
 
+@pytest.mark.parametrize("logn", [12, 18])
+def test_realistic_witness_distribution_matches_the_closed_form(logn):
+    """a witness of the shape the reference's CalculateWitness produces (circuitcompiler/circuit.go:158-182: about
+    half zeros and ones, most of the rest below 2^32, few full-width values) instead of uniform 254-bit scalars -- >80 % of the
+    plan's digits are zero (skipped) and the buckets of the digits 1 and of the small values' low windows are cut into thousands of
+    chunks (k_heavy_combine).  px route, both witness routes and three pipelined tickets give the closed-form proof of the setup's
+    toxic values; the verifier accepts it for the right public input only."""
+    from gosnark_amd import synth
+    n = 1 << logn
+    inst = synth.realistic_setup_instance(n, 0x7EA1 + logn)
+    assert inst.counts["zeros"] + inst.counts["ones"] > 0.4 * n and inst.counts["full_width"] < 0.15 * n
+    r, s = synth.field_elems(2, 9300 + logn)
+    pk = inst.device_pk()
+    want = groth16.prove_resident(pk, inst.w, inst.px, r, s)
+    a, b, c = inst.expected_proof_scalars(r, s)
+    assert (want.PiA[0], want.PiA[1]) == C.g1_affine(C.g1_mul_scalar(O.G1_GEN, a))
+    assert (want.PiB[0], want.PiB[1]) == C.g2_affine(C.g2_mul_scalar(O.G2_GEN, b))
+    assert (want.PiC[0], want.PiC[1]) == C.g1_affine(C.g1_mul_scalar(O.G1_GEN, c))
+    dev = r1csqap.DeviceR1CS(*inst.r1cs, inst.m)
+    for on in (True, False):
+        capi.set_eval_basis(on)
+        try:
+            got = groth16.prove_from_witness(pk, dev, inst.w, r, s)
+        finally:
+            capi.set_eval_basis(True)
+        assert (got.PiA, got.PiB, got.PiC) == (want.PiA, want.PiB, want.PiC), on
+        assert capi.last_timing()["fallbacks"] == 0
+    tickets = [groth16.prove_begin(pk, inst.w, inst.px, r, s) for _ in range(3)]
+    for t in tickets:
+        p = groth16.prove_end(t)
+        assert (p.PiA, p.PiB, p.PiC) == (want.PiA, want.PiB, want.PiC)
+    x = capi.u64_to_ints(inst.w_host[1:2])[0]
+    assert groth16.VerifyProof(inst.vk, want, [x]) is True and groth16.VerifyProof(inst.vk, want, [(x + 1) % O.R]) is False
+
+
 @pytest.mark.parametrize("logn", [18, 20])
 def test_witness_route_at_config_sizes_equals_px_route_and_closed_form(logn):
     """the witness -> proof routes at 2^18 (BASELINE configs[4]) and 2^20 (configs[2], the headline size), inside
@@ -1196,6 +1231,17 @@ def test_small_mirrors_of_the_reference_seams():
     al, be, ga, _ = O.PF.R1CSToQAP(O.X3_R1CS_A, O.X3_R1CS_B, O.X3_R1CS_C)
     w = list(O.X3_WITNESS)
     assert pf.CombinePolynomials(w, al, be, ga) == tuple(O.PF.CombinePolynomials(w, al, be, ga))
+    # ragged inputs, as the reference's Add / Mul loop treats them: polynomials of different lengths, more polynomials than
+    # witness entries (the reference iterates i < len(r)); too few polynomials / an empty witness are errors, not silent truncation
+    rag_a = [[3, 1, 4, 1, 5], [9, 2], [6], [5, 3, 5, 8]]
+    rag_b = [[2, 7], [1, 8, 2, 8], [1, 8, 2], [8]]
+    rag_c = [[1, 4, 1], [4, 2, 1, 3, 5, 6], [2, 3], [7, 3, 0, 9]]
+    rr = [O.R - 5, 11, 0]
+    assert pf.CombinePolynomials(rr, rag_a, rag_b, rag_c) == tuple(O.PF.CombinePolynomials(rr, rag_a, rag_b, rag_c))
+    with pytest.raises(ValueError):
+        pf.CombinePolynomials([1, 2, 3, 4, 5], rag_a, rag_b, rag_c)
+    with pytest.raises(ValueError):
+        pf.CombinePolynomials([], rag_a, rag_b, rag_c)
     opk = GU.groth_pk(GU.load("groth_x3")["setup"])
     P, Qp = opk.G1_At[2], opk.G1_At[3]
     assert bn128.G1.Double(P) == jac_affine_g1(O.G1.Double(P))

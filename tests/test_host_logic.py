@@ -132,3 +132,32 @@ def test_go_layer_matches_the_c_abi_mechanically(tmp_path):
         assert any("is C.int, the header wants size_t" in e for e in chk.check()[0])
     finally:
         chk.GO_DIR = saved
+
+
+def test_environment_knobs_are_validated_or_compiled_out(tmp_path):
+    """go-snark-study_amd/csrc/knobs.h: in the product build (no -DGS_DEV_KNOBS) the tuning variables are not read
+    at all; in a development build a value the algorithm cannot take (GS_REDUCE_L=3: not a power of two, GS_CHUNK=7: not a multiple
+    of 4, out of range, not a number) falls back to the default; the always-on switches parse strictly.  And no source file of the
+    library calls getenv() itself."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "go-snark-study_amd", "csrc")
+    for f in os.listdir(csrc):
+        if f.endswith((".hip", ".h")) and f != "knobs.h":
+            assert "getenv" not in open(os.path.join(csrc, f)).read(), f
+    src = os.path.join(root, "tests", "host", "knobs_host_test.cpp")
+    lines = ["dev GS_REDUCE_L 4 1 32 1 1", "dev GS_CHUNK 0 4 1024 4 0", "dev GS_FOLD_MAX 0 1 256 1 0", "dev GS_AUTO_MAX_C 17 8 20 1 0",
+             "run GS_TAIL_FLIP 1 0 2 1 0", "run GS_COPY_THREADS 4 1 64 1 0", "devflag GS_TABLE_PER_ROW 0 0 0 1 0"]
+    hostile = {"GS_REDUCE_L": "3", "GS_CHUNK": "7", "GS_FOLD_MAX": "-5", "GS_AUTO_MAX_C": "99", "GS_TAIL_FLIP": "77", "GS_COPY_THREADS": "4x",
+               "GS_TABLE_PER_ROW": "1"}
+    benign = {"GS_REDUCE_L": "8", "GS_CHUNK": "48", "GS_FOLD_MAX": "16", "GS_AUTO_MAX_C": "19", "GS_TAIL_FLIP": "2", "GS_COPY_THREADS": "6",
+              "GS_TABLE_PER_ROW": "1"}
+    defaults = ["4", "0", "0", "17", "1", "4", "0"]
+    for flags, env, want in (([], hostile, defaults), ([], benign, defaults[:4] + ["2", "6", "0"]),                       # product build
+                             (["-DGS_DEV_KNOBS"], hostile, defaults[:6] + ["1"]), (["-DGS_DEV_KNOBS"], benign, ["8", "48", "16", "19", "2", "6", "1"])):
+        exe = tmp_path / ("knobs" + ("_dev" if flags else ""))
+        if not exe.exists():
+            subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", csrc] + flags + [src, "-o", str(exe)])
+        out = subprocess.run([str(exe)], input="\n".join(lines) + "\n", capture_output=True, text=True, check=True,
+                             env=dict(os.environ, **env)).stdout.split()
+        assert out == want, (flags, env, out)
