@@ -181,8 +181,10 @@ def witness_digit_stats(w_u64, c, tm):
     return {"window_bits": c, "digits": n * W, "zero_digit_share": zeros / float(n * W), "bucket_additions_per_base_array": entries,
             "heaviest_bucket_entries": int(counts[1:].max()), "median_bucket_entries": float(np.median(counts[1:])),
             "buckets_cut_into_more_than_64_chunks": int((counts[1:] > 65 * chunk).sum()),
-            "note": "host restatement of the plan's digit recoding over the witness (the sums over w: 4 of the 5 MSMs); gs_timing's *_adds count "
-                    "digits, not non-zero digits, so roofline_valu of this instance OVERSTATES the additions by the zero share"}
+            "gs_timing_of_the_last_proof": {k: tm.get(k) for k in ("plan_digits", "plan_entries", "heavy_buckets")},
+            "note": "host restatement of the plan's digit recoding over the witness (the sums over w: 4 of the 5 MSMs), beside what the plans themselves "
+                    "counted on the device for the last proof (gs_timing: all five sums, the uniform h-scalars included); acc_*_adds and roofline_valu "
+                    "count the non-zero digits only"}
 
 
 def pipelined(begin, end, count, depth, on_done=None):
@@ -1051,7 +1053,7 @@ def main():
             run_steps(max(1, min(args.steps, 4)))
     run_steps(args.warmup)
     tm_keys = ("acc_g1_ms", "acc_g1_launches", "acc_g1_terms", "acc_g1_adds", "acc_g2_ms", "acc_g2_terms", "acc_g2_adds",
-               "total_ms", "plan_ms", "accumulate_ms", "reduce_ms", "poly_ms")
+               "total_ms", "plan_ms", "accumulate_ms", "reduce_ms", "poly_ms", "plan_digits", "plan_entries", "heavy_buckets")
     tm_acc = {k: 0.0 for k in tm_keys}
     window_bits = [0]
 
@@ -1210,13 +1212,16 @@ def main():
             # addition = 1467 mads; a term takes one addition per digit position (floor(254 / c) + 1 of them).
             out["roofline_valu"] = {"bound": "valu-int-mad", "kernel": "k_bucket_accumulate<G1>", "achieved": mads, "peak": MAD_PEAK_T,
                                     "unit": "T lane-mad/s", "frac": mads / MAD_PEAK_T,
-                                    "note": "mixed additions per launch (gs_timing.acc_g1_adds) x 1467 v_mad_u64_u32; window width c = %d -> %d additions "
-                                            "per term; peak from tools/ubench_valu.hip (profiles/r01_ubench_valu.txt)" % (cbits, 254 // max(cbits, 1) + 1)}
+                                    "note": "mixed additions per launch (gs_timing.acc_g1_adds: the non-zero digits the plan counted) x 1467 v_mad_u64_u32; window width "
+                                            "c = %d -> at most %d additions per term; peak from tools/ubench_valu.hip (profiles/r01_ubench_valu.txt)" % (cbits, 254 // max(cbits, 1) + 1)}
             out["roofline_whole_step"] = {"bound": "hbm", "algorithmic_bytes_per_step": step_bytes,
                                           "achieved": step_bytes / (elapsed / args.steps) / 1e9,
                                           "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                           "note": "SURVEY 8d: Groth16 672 B per constraint per proof (544 n MSM + 128 n H stage), Pinocchio 960 B; wall time per step"}
             out["device_ms_per_step"] = {k: tm_acc[k] / total_steps for k in ("total_ms", "poly_ms", "plan_ms", "accumulate_ms", "reduce_ms", "acc_g1_ms", "acc_g2_ms")}
+            if tm_acc["plan_digits"]:
+                out["plan_per_step"] = {"digits": tm_acc["plan_digits"] / total_steps, "bucket_additions": tm_acc["plan_entries"] / total_steps,
+                                        "zero_digit_share": 1.0 - tm_acc["plan_entries"] / tm_acc["plan_digits"], "heavy_buckets": tm_acc["heavy_buckets"] / total_steps}
             live, why = (live_pmc_traffic(args) if (world == 1 and plain_prove and not args.no_extras) else (None, "only the default single-GPU run measures it"))
             if live:
                 # raw counters: the guide's x2 correction of FETCH_SIZE is calibrated for wide coalesced streams; this kernel's reads are 64-byte

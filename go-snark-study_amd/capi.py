@@ -28,7 +28,8 @@ class Timing(ctypes.Structure):
                 + [("acc_g1_launches", ctypes.c_uint32), ("acc_g2_launches", ctypes.c_uint32),
                    ("acc_g1_terms", ctypes.c_uint64), ("acc_g2_terms", ctypes.c_uint64),
                    ("acc_g1_adds", ctypes.c_uint64), ("acc_g2_adds", ctypes.c_uint64),
-                   ("window_bits", ctypes.c_uint32), ("fallbacks", ctypes.c_uint32)])
+                   ("window_bits", ctypes.c_uint32), ("fallbacks", ctypes.c_uint32),
+                   ("plan_digits", ctypes.c_uint64), ("plan_entries", ctypes.c_uint64), ("heavy_buckets", ctypes.c_uint32), ("reserved", ctypes.c_uint32)])
 
 
 class Memory(ctypes.Structure):

@@ -334,19 +334,21 @@ GS_HD void xyzz_madd(XyzzAcc<T>& acc, const Affine<T>& b, bool negate = false) {
 template <class T>
 GS_HD void xyzz_dbl(Xyzz<T>& acc) {
   if (is_inf(acc)) return;
+  // (ordered for short live ranges -- V, W and y die as early as the formulas allow: the reduction tails run at <= 256 VGPRs)
   auto U = dbl(acc.y);                                  // 10
   auto V = ssqr<T>(U);
   auto W = smul<T>(U, V);
   auto S = smul<T>(acc.x, V);
+  acc.zz = smul<T>(V, acc.zz);
+  const auto Wy = smul<T>(W, acc.y);
+  acc.zzz = smul<T>(W, acc.zzz);
   auto xx = ssqr<T>(acc.x);
   auto M = add(dbl(xx), xx);                            // 6
   auto MM = ssqr<T>(M);
   auto X3 = sub(MM, dbl(S));                            // 7
   auto t = smul<T>(M, sub(S, X3));
-  auto Y3 = sub(t, smul<T>(W, acc.y));                  // 5
-  acc.zz = smul<T>(V, acc.zz);
-  acc.zzz = smul<T>(W, acc.zzz);
-  acc.x = relax<9>(X3); acc.y = Y3;
+  acc.y = sub(t, Wy);                                   // 5
+  acc.x = relax<9>(X3);
 }
 
 // acc += b   [add-2008-s: 12M + 2S], complete
@@ -409,21 +411,25 @@ GS_HD Xyzz<T> load_point(const uint32_t* b) {
 template <class T>
 GS_HD void xyzz_add_mem(Xyzz<T>& acc, const uint32_t* b) {
   constexpr int cw = (T::kWords == 8 ? 1 : 2) * NL;
+  // G1 has the registers to request all four coordinates at once (one memory latency per addition, as round 3's two-operand form);
+  // G2 keeps ONE coordinate in flight ahead of the products that consume the previous one (the latency hides behind ~2 products).
+  constexpr bool kAllAtOnce = T::kWords == 8;
   const auto bzz = load_coord<T, 2>(b + 2 * cw);
+  auto bx = load_coord<T, 9>(b);
+  typename T::template E<2> bzzz;
+  typename T::template E<5> by;
+  if constexpr (kAllAtOnce) { bzzz = load_coord<T, 2>(b + 3 * cw); by = load_coord<T, 5>(b + cw); }
   if (T::limbs_all_zero(bzz)) return;                   // B = infinity
   if (is_inf(acc)) { acc = load_point<T>(b); return; }
   const auto U1 = smul<T>(acc.x, bzz);
   const auto Tz = smul<T>(acc.zz, bzz);                 // ZZ1 ZZ2
-  GS_MEM_FENCE();
-  const auto bx = load_coord<T, 9>(b);
+  if constexpr (!kAllAtOnce) { GS_MEM_FENCE(); bzzz = load_coord<T, 2>(b + 3 * cw); }
   const auto U2 = smul<T>(bx, acc.zz);
   const auto P = sub(U2, U1);                           // 5
-  GS_MEM_FENCE();
-  const auto bzzz = load_coord<T, 2>(b + 3 * cw);
+  if constexpr (!kAllAtOnce) { GS_MEM_FENCE(); by = load_coord<T, 5>(b + cw); }
   const auto S1 = smul<T>(acc.y, bzzz);
   const auto Vz = smul<T>(acc.zzz, bzzz);               // ZZZ1 ZZZ2
-  GS_MEM_FENCE();
-  const auto by = load_coord<T, 5>(b + cw);
+  if constexpr (!kAllAtOnce) GS_MEM_FENCE();
   const auto S2 = smul<T>(by, acc.zzz);
   const auto R = sub(S2, S1);                           // 5
   if (is_zero(P)) {

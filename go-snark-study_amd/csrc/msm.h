@@ -62,6 +62,8 @@ struct MsmPending {
   uint32_t nblk = 0, n = 0;
   bool g2 = false;
   bool folded = false;             // the device folded the workgroup pairs: one XYZZ point per job in the pinned slot
+  const void* pinned_slot = nullptr;   // where this group's results land; the plan's statistics follow them at stats_off
+  size_t stats_off = 0;
   std::shared_ptr<PhaseTimer> tacc, tker, tred;
 };
 // tail_stream: where the window merge / reduction / download go (nullptr = c.stream)

@@ -60,9 +60,11 @@ static MsmState& msm_state(Ctx& c) { return c.state<MsmState>(c.msm_state); }
 //   2^22 terms: chunk 32 48.7, 64 40.7 -- a bucket should not be cut into more than ~32 chunks (its partials are added up
 //   serially by one combine thread, and past kHeavySpan by the block-wide tree)
 static uint32_t choose_chunk(uint64_t entries, uint32_t nbuckets, const std::vector<LaunchShape>& users) {
-  (void)users;
   static const int forced = (int)dev_knob("GS_CHUNK", 0, 4, 1024, 4);                     // development builds only (a multiple of 4)
   if (forced >= 4 && forced % 4 == 0) return (uint32_t)forced;
+  // (development builds: another chunk size for plans whose only user is ONE G1 launch of one base array -- the sum over h)
+  static const int forced_h = (int)dev_knob("GS_CHUNK_H", 0, 4, 1024, 4);
+  if (forced_h && users.size() == 1 && users[0].njobs == 1 && !users[0].g2) return (uint32_t)forced_h;
   uint32_t chunk = entries >= (1ull << 23) ? 32u : 16u;
   while (chunk < 1024u && entries / std::max<uint32_t>(nbuckets, 1u) > 32ull * chunk) chunk *= 2;
   return chunk;
@@ -217,13 +219,17 @@ static void msm_enqueue(Ctx& c, const MsmPlan& plan, const std::vector<MsmBase>&
   p.L = L; p.nblk = nblk;
   p.folded = nblk > fold_max;                             // wide windows: the pairs are folded on the device (k_pair_reduce)
   if (nblk > (uint32_t)kReduceBlock) throw HipError{hipErrorInvalidValue, "too many reduce workgroups for one fold", __LINE__};
-  const size_t pair_bytes = (size_t)njobs * nblk * 2 * pw * 4, final_bytes = (size_t)njobs * pw * 4;
-  const size_t out_bytes = p.folded ? final_bytes : pair_bytes;
+  // result staging: [pairs | finals | stats], downloaded in ONE copy: pairs .. stats (host fold) or finals .. stats (device fold).
+  // stats = {bucket entries of the plan, buckets combined by the heavy tree} (k_bucket_combine writes them; gs_timing reports them)
+  const size_t pair_bytes = (size_t)njobs * nblk * 2 * pw * 4, final_bytes = (size_t)njobs * pw * 4, stats_bytes = 16;
+  const size_t out_bytes = (p.folded ? final_bytes : pair_bytes + final_bytes) + stats_bytes;
   if (out_bytes > Ctx::kPinnedBytes) throw HipError{hipErrorInvalidValue, "MSM result staging too small", __LINE__};
+  p.stats_off = out_bytes - stats_bytes;
   AccJobs jobs{};
   DevBuf& outb = c.ws_out[ws_base % Ctx::kWsSets];
-  outb.ensure(pair_bytes + final_bytes);
+  outb.ensure(pair_bytes + final_bytes + stats_bytes);
   uint32_t* finals = outb.as<uint32_t>() + pair_bytes / 4;
+  uint32_t* stats = finals + final_bytes / 4;
   for (int j = 0; j < njobs; ++j) {
     const BaseTable* t = bases[j].table;
     if (!t || t->c != plan.c || bases[j].off + plan.n > t->n)
@@ -258,7 +264,8 @@ static void msm_enqueue(Ctx& c, const MsmPlan& plan, const std::vector<MsmBase>&
   // to do, and on the accumulation stream even an empty launch waited ~0.5 ms for register space)
   hipLaunchKernelGGL(k_heavy_combine<T>, dim3(64, njobs), dim3(kHeavyBlock), 0, ts,
                      jobs, plan.offsets, plan.heavy_list, plan.heavy_count, plan.chunk);
-  hipLaunchKernelGGL(k_bucket_combine<T>, dim3((plan.B + 255) / 256, njobs), dim3(256), 0, ts, jobs, plan.offsets, plan.B, plan.chunk);
+  hipLaunchKernelGGL(k_bucket_combine<T>, dim3((plan.B + 255) / 256, njobs), dim3(256), 0, ts, jobs, plan.offsets, plan.B, plan.chunk,
+                     plan.heavy_count, stats);
   hipLaunchKernelGGL(k_block_reduce<T>, dim3(nblk, njobs), dim3(kReduceBlock), 0, ts, jobs, plan.B, L);
   if (p.folded) {
     int log2_span = 0;
@@ -267,6 +274,7 @@ static void msm_enqueue(Ctx& c, const MsmPlan& plan, const std::vector<MsmBase>&
   }
   GS_HIP(hipGetLastError());
   GS_HIP(hipMemcpyAsync(c.pinned[slot], p.folded ? (const void*)finals : outb.p, out_bytes, hipMemcpyDeviceToHost, ts));
+  p.pinned_slot = c.pinned[slot];
   p.tred->stop();
 }
 
@@ -291,10 +299,17 @@ void msm_book_timing(Ctx& c, const MsmPending& p) {
   std::lock_guard<std::mutex> lk(c.timing_mu);
   c.timing.accumulate_ms += p.tacc->ms();
   const uint64_t terms = (uint64_t)p.n * p.njobs;
-  if (!p.g2) { c.timing.acc_g1_ms += p.tker->ms(); c.timing.acc_g1_launches += 1; c.timing.acc_g1_terms += terms; c.timing.acc_g1_adds += terms * p.W; }
-  else { c.timing.acc_g2_ms += p.tker->ms(); c.timing.acc_g2_launches += 1; c.timing.acc_g2_terms += terms; c.timing.acc_g2_adds += terms * p.W; }
   c.timing.window_bits = (uint32_t)p.c;
   c.timing.reduce_ms += p.tred->ms();
+  // the plan's own counts travel behind the group's results (the download has completed: tred's stop event follows it): a term
+  // has one digit per window, a zero digit costs nothing, every other one is exactly one mixed addition of the accumulation kernel
+  const uint32_t* st = reinterpret_cast<const uint32_t*>(static_cast<const char*>(p.pinned_slot) + p.stats_off);
+  const uint64_t adds = p.pinned_slot ? (uint64_t)st[0] * p.njobs : terms * p.W;
+  if (!p.g2) { c.timing.acc_g1_ms += p.tker->ms(); c.timing.acc_g1_launches += 1; c.timing.acc_g1_terms += terms; c.timing.acc_g1_adds += adds; }
+  else { c.timing.acc_g2_ms += p.tker->ms(); c.timing.acc_g2_launches += 1; c.timing.acc_g2_terms += terms; c.timing.acc_g2_adds += adds; }
+  c.timing.plan_digits += terms * p.W;
+  c.timing.plan_entries += adds;
+  if (p.pinned_slot) c.timing.heavy_buckets += st[1];
 }
 
 template <class T>

@@ -456,6 +456,12 @@ __global__ void __launch_bounds__(256, AccTuning<T>::kMinWaves) k_bucket_accumul
   acc_store(dst, acc);
 }
 
+// ---- the tails: bucket combine + reduction ---------------------------------------------------------------------------------
+// Every point addition of the tail kernels takes its second operand straight from memory (ec.h, xyzz_add_mem): a thread holds
+// ONE point in registers plus the temporaries of the formula, whatever it adds up.  Round 3's form (both operands and, in the
+// reduction, two running points in registers) took 317-512 VGPRs for G2 -- one wave per SIMD, beside which no accumulation wave
+// fits; see DESIGN.md section 5 for what the new kernels take.
+
 // the sum of bucket b, wherever its pieces are
 template <class T>
 GS_HD Xyzz<T> load_bucket(const AccJob& job, const uint32_t* __restrict__ offsets, uint32_t b, uint32_t chunk) {
@@ -465,19 +471,14 @@ GS_HD Xyzz<T> load_bucket(const AccJob& job, const uint32_t* __restrict__ offset
   const uint32_t tf = o0 / chunk, tl = (o1 - 1) / chunk;
   if (tf == tl || tl - tf > kHeavySpan) return load_xyzz<T>(job.buckets + (size_t)b * pw);
   Xyzz<T> acc = load_xyzz<T>(job.heads + (size_t)tl * pw);
-  for (uint32_t t = tf; t < tl; ++t) {
-    const Xyzz<T> p = load_xyzz<T>(job.tails + (size_t)t * pw);
-    xyzz_add(acc, p);
-  }
+  for (uint32_t t = tf; t < tl; ++t) xyzz_add_mem<T>(acc, job.tails + (size_t)t * pw);
   return acc;
 }
 
-// one block per heavy bucket (grid-stride over the device-side list): tails[first..last) + heads[last] -> buckets[b]
-// Registers of the reduction-tail kernels: left alone the Fq2 instances take 256 VGPRs + 59..133 AGPRs = ONE wave per SIMD, and
-// such a wave cannot share a SIMD with any accumulation wave (160 / 256 registers each of 512).  GS_TAIL_WAVES = 2 caps them at 256.
 #ifndef GS_TAIL_WAVES
-#define GS_TAIL_WAVES 1
+#define GS_TAIL_WAVES 2          // <= 256 VGPRs: a tail wave shares its SIMD with an accumulation wave
 #endif
+// one block per heavy bucket (grid-stride over the device-side list): tails[first..last) + heads[last] -> buckets[b]
 constexpr int kHeavyBlock = 128;
 template <class T>
 __global__ void __launch_bounds__(kHeavyBlock, GS_TAIL_WAVES) k_heavy_combine(AccJobs jobs, const uint32_t* __restrict__ offsets,
@@ -491,16 +492,12 @@ __global__ void __launch_bounds__(kHeavyBlock, GS_TAIL_WAVES) k_heavy_combine(Ac
     const uint32_t b = heavy_list[h];
     const uint32_t tf = offsets[b] / chunk, tl = (offsets[b + 1] - 1) / chunk;
     Xyzz<T> acc = xyzz_inf<T>();
-    for (uint32_t t = tf + threadIdx.x; t <= tl; t += kHeavyBlock) {
-      const Xyzz<T> p = load_xyzz<T>((t == tl ? job.heads : job.tails) + (size_t)t * pw);
-      xyzz_add(acc, p);
-    }
+    for (uint32_t t = tf + threadIdx.x; t <= tl; t += kHeavyBlock) xyzz_add_mem<T>(acc, (t == tl ? job.heads : job.tails) + (size_t)t * pw);
     store_xyzz<T>(sh + threadIdx.x * pw, acc);
     __syncthreads();
     for (int half = kHeavyBlock / 2; half >= 1; half >>= 1) {
-      if ((int)threadIdx.x < half) {
-        Xyzz<T> o = load_xyzz<T>(sh + (threadIdx.x + half) * pw);
-        xyzz_add(acc, o);
+      if ((int)threadIdx.x < half) {                           // reads [half, 2 half), writes [0, half): no hazard inside a level
+        xyzz_add_mem<T>(acc, sh + (threadIdx.x + half) * pw);
         store_xyzz<T>(sh + threadIdx.x * pw, acc);
       }
       __syncthreads();
@@ -510,13 +507,15 @@ __global__ void __launch_bounds__(kHeavyBlock, GS_TAIL_WAVES) k_heavy_combine(Ac
   }
 }
 
-// ---- bucket combine + reduction ---------------------------------------------------------------------------
 // merged[b] = the pieces of bucket b (it spans ~ n W / (B * chunk) chunks).  Thanks to the window tables all W
 // digit positions share one bucket set, so the MSM is simply sum_b (b + 1) * merged[b]: no per-window
-// reduction and no Horner recombination.
+// reduction and no Horner recombination.  Thread (0, 0, 0) also leaves what the plan found for gs_timing:
+// stats[0] = bucket entries (= non-zero digits = additions one base array costs), stats[1] = buckets combined by the heavy tree.
 template <class T>
-__global__ void __launch_bounds__(256, GS_TAIL_WAVES) k_bucket_combine(AccJobs jobs, const uint32_t* __restrict__ offsets, uint32_t B, uint32_t chunk) {
+__global__ void __launch_bounds__(256, GS_TAIL_WAVES) k_bucket_combine(AccJobs jobs, const uint32_t* __restrict__ offsets, uint32_t B, uint32_t chunk,
+                                                                     const uint32_t* __restrict__ heavy_count, uint32_t* __restrict__ stats) {
   const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b == 0 && blockIdx.y == 0) { stats[0] = offsets[B]; stats[1] = *heavy_count; }
   if (b >= B) return;
   const AccJob job = jobs.j[blockIdx.y];
   store_xyzz<T>(job.merged + (size_t)b * PointIO<T>::kXyzzWords, load_bucket<T>(job, offsets, b, chunk));
@@ -524,9 +523,11 @@ __global__ void __launch_bounds__(256, GS_TAIL_WAVES) k_bucket_combine(AccJobs j
 
 // One workgroup of 256 threads reduces 256 * L consecutive buckets to the pair
 //   A = sum_j (j + 1) * merged[base + j],  S = sum_j merged[base + j]        (j local to the workgroup)
-// thread t: running sums over its L buckets -> (acc_t, run_t); suffix scan of run_t in LDS gives
-// R_t = sum_{t' >= t} run_t', and sum_t t * run_t = sum_{t >= 1} R_t; then a tree sum.  The host adds the
-// (at most 16) pairs: result = sum_blk A_blk + 256 L * sum_blk blk * S_blk.
+// Thread t owns L buckets.  Pass 1 turns them IN PLACE into their suffix sums run_j = sum_{j' >= j} merged[j'] (L - 1 additions),
+// pass 2 adds the suffix sums up: acc_t = sum_j run_j = sum_j (j + 1) merged[j] (L - 1 additions, parked in the thread's last
+// slot) -- one point in registers in either pass.  Then a suffix scan of run_0 over the workgroup in LDS gives
+// R_t = sum_{t' >= t} run_0(t'), and sum_t t * run_0(t) = sum_{t >= 1} R_t; value_t = acc_t + L R_t, and a tree sum.  The host adds
+// the (at most 32) pairs: result = sum_blk A_blk + 256 L * sum_blk blk * S_blk.
 constexpr int kReduceBlock = 256;
 template <class T>
 __global__ void __launch_bounds__(kReduceBlock, GS_TAIL_WAVES) k_block_reduce(AccJobs jobs, uint32_t B, int L) {
@@ -535,47 +536,53 @@ __global__ void __launch_bounds__(kReduceBlock, GS_TAIL_WAVES) k_block_reduce(Ac
   const AccJob job = jobs.j[blockIdx.y];
   const uint32_t t = threadIdx.x;
   const uint32_t base = (blockIdx.x * kReduceBlock + t) * (uint32_t)L;
-  Xyzz<T> run = xyzz_inf<T>(), acc = xyzz_inf<T>();
-  for (int j = L - 1; j >= 0; --j) {
-    if (base + (uint32_t)j < B) {
-      const Xyzz<T> bk = load_xyzz<T>(job.merged + (size_t)(base + (uint32_t)j) * pw);
-      xyzz_add(run, bk);
+  const bool any = base < B;                                   // (B and L are powers of two: all L buckets exist or none)
+  uint32_t* mine = job.merged + (size_t)base * pw;
+  Xyzz<T> R = xyzz_inf<T>();
+  if (any) {
+    R = load_xyzz<T>(mine + (size_t)(L - 1) * pw);
+    for (int j = L - 2; j >= 0; --j) {                         // pass 1: suffix sums, in place
+      xyzz_add_mem<T>(R, mine + (size_t)j * pw);
+      store_xyzz<T>(mine + (size_t)j * pw, R);
     }
-    xyzz_add(acc, run);
+    if (L > 1) {                                               // pass 2: their sum, parked in the last slot (L = 1: it is there already)
+      GS_MEM_FENCE();
+      Xyzz<T> acc = load_xyzz<T>(mine + (size_t)(L - 1) * pw);
+      for (int j = L - 2; j >= 0; --j) xyzz_add_mem<T>(acc, mine + (size_t)j * pw);
+      store_xyzz<T>(mine + (size_t)(L - 1) * pw, acc);
+      GS_MEM_FENCE();
+      R = load_xyzz<T>(mine);                                  // run_0 again
+    }
   }
-  // suffix (inclusive) scan of run over the workgroup
-  Xyzz<T> R = run;
+  // suffix (inclusive) scan of run_0 over the workgroup: the additions read their operand from LDS, the writes follow a barrier
   store_xyzz<T>(sh + t * pw, R);
   __syncthreads();
   for (int off = 1; off < kReduceBlock; off <<= 1) {
-    Xyzz<T> o = xyzz_inf<T>();
     const bool has = t + (uint32_t)off < (uint32_t)kReduceBlock;
-    if (has) o = load_xyzz<T>(sh + (t + off) * pw);
+    if (has) xyzz_add_mem<T>(R, sh + (t + off) * pw);
     __syncthreads();
-    if (has) { xyzz_add(R, o); store_xyzz<T>(sh + t * pw, R); }
+    if (has) store_xyzz<T>(sh + t * pw, R);
     __syncthreads();
   }
-  // value_t = acc_t + L * R_t (t >= 1), acc_0 for t = 0
   if (t == 0) store_xyzz<T>(job.out + ((size_t)blockIdx.x * 2 + 1) * pw, R);     // S = R_0
+  // value_t = acc_t + L * R_t (t >= 1), acc_0 for t = 0
+  if (t >= 1) { for (int l = L; l > 1; l >>= 1) xyzz_dbl(R); }
+  else R = xyzz_inf<T>();
+  if (any) xyzz_add_mem<T>(R, mine + (size_t)(L - 1) * pw);
   __syncthreads();
-  if (t >= 1) {
-    for (int l = L; l > 1; l >>= 1) xyzz_dbl(R);
-    xyzz_add(acc, R);
-  }
-  store_xyzz<T>(sh + t * pw, acc);
+  store_xyzz<T>(sh + t * pw, R);
   __syncthreads();
   for (int half = kReduceBlock / 2; half >= 1; half >>= 1) {
     if ((int)t < half) {
-      const Xyzz<T> o = load_xyzz<T>(sh + (t + half) * pw);
-      xyzz_add(acc, o);
-      store_xyzz<T>(sh + t * pw, acc);
+      xyzz_add_mem<T>(R, sh + (t + half) * pw);
+      store_xyzz<T>(sh + t * pw, R);
     }
     __syncthreads();
   }
-  if (t == 0) store_xyzz<T>(job.out + (size_t)blockIdx.x * 2 * pw, acc);          // A
+  if (t == 0) store_xyzz<T>(job.out + (size_t)blockIdx.x * 2 * pw, R);          // A
 }
 
-// Second level, for wide windows (more than 16 reduce workgroups per job): one workgroup per job folds the nblk <= 256
+// Second level, for wide windows (more than 32 reduce workgroups per job): one workgroup per job folds the nblk <= 256
 // pairs (A_blk, S_blk) into the job's result  sum_blk A_blk + (256 L) * sum_blk blk * S_blk  -- the suffix-scan identity
 // again (sum_blk blk * S_blk = sum_{blk >= 1} R_blk with R_blk = sum_{b' >= blk} S_b'), then log2(256 L) doublings -- so the
 // host receives ONE point per job however many buckets there were.
@@ -585,39 +592,42 @@ __global__ void __launch_bounds__(kReduceBlock, GS_TAIL_WAVES) k_pair_reduce(Acc
   __shared__ uint32_t sh[kReduceBlock * pw];
   const AccJob job = jobs.j[blockIdx.y];
   const uint32_t t = threadIdx.x;
-  Xyzz<T> A = xyzz_inf<T>(), R = xyzz_inf<T>();
-  if (t < nblk) {
-    A = load_xyzz<T>(job.out + (size_t)t * 2 * pw);
-    R = load_xyzz<T>(job.out + ((size_t)t * 2 + 1) * pw);
-  }
+  Xyzz<T> R = xyzz_inf<T>();
+  if (t < nblk) R = load_xyzz<T>(job.out + ((size_t)t * 2 + 1) * pw);
   store_xyzz<T>(sh + t * pw, R);
   __syncthreads();
   for (int off = 1; off < kReduceBlock; off <<= 1) {                 // inclusive suffix scan of S
-    Xyzz<T> o = xyzz_inf<T>();
     const bool has = t + (uint32_t)off < (uint32_t)kReduceBlock;
-    if (has) o = load_xyzz<T>(sh + (t + off) * pw);
+    if (has) xyzz_add_mem<T>(R, sh + (t + off) * pw);
     __syncthreads();
-    if (has) { xyzz_add(R, o); store_xyzz<T>(sh + t * pw, R); }
+    if (has) store_xyzz<T>(sh + t * pw, R);
     __syncthreads();
   }
   if (t == 0) R = xyzz_inf<T>();                                     // the sum runs over blk >= 1
-  for (int pass = 0; pass < 2; ++pass) {                             // tree sums: first of R (weighted part), then of A
-    Xyzz<T>& v = pass == 0 ? R : A;
-    store_xyzz<T>(sh + t * pw, v);
+  for (int pass = 0; pass < 2; ++pass) {                             // tree sums: first of R (the weighted part), then of A
+    if (pass == 1) {
+      if (t == 0) {                                                  // (256 L) * sum_{blk >= 1} R_blk, kept in LDS slot 0's place: park it in `final_out`
+        for (int k = 0; k < log2_span; ++k) xyzz_dbl(R);
+        store_xyzz<T>(job.final_out, R);
+      }
+      R = xyzz_inf<T>();
+      if (t < nblk) R = load_xyzz<T>(job.out + (size_t)t * 2 * pw);
+    }
+    __syncthreads();
+    store_xyzz<T>(sh + t * pw, R);
     __syncthreads();
     for (int half = kReduceBlock / 2; half >= 1; half >>= 1) {
       if ((int)t < half) {
-        const Xyzz<T> o = load_xyzz<T>(sh + (t + half) * pw);
-        xyzz_add(v, o);
-        store_xyzz<T>(sh + t * pw, v);
+        xyzz_add_mem<T>(R, sh + (t + half) * pw);
+        store_xyzz<T>(sh + t * pw, R);
       }
       __syncthreads();
     }
   }
   if (t == 0) {
-    for (int k = 0; k < log2_span; ++k) xyzz_dbl(R);
-    xyzz_add(A, R);
-    store_xyzz<T>(job.final_out, A);
+    GS_MEM_FENCE();
+    xyzz_add_mem<T>(R, job.final_out);
+    store_xyzz<T>(job.final_out, R);
   }
 }
 

@@ -483,12 +483,15 @@ type Timing struct {
 	AccG1Launches, AccG2Launches                                               uint32
 	AccG1Terms, AccG2Terms, AccG1Adds, AccG2Adds                               uint64
 	WindowBits, Fallbacks                                                      uint32
+	PlanDigits, PlanEntries                                                    uint64 // digits / non-zero digits (= real bucket additions) x base arrays
+	HeavyBuckets                                                               uint32
 }
 
 func timingFromC(t *C.gs_timing) Timing {
 	return Timing{float32(t.total_ms), float32(t.plan_ms), float32(t.accumulate_ms), float32(t.reduce_ms), float32(t.poly_ms), float32(t.h2d_ms),
 		float32(t.acc_g1_ms), float32(t.acc_g2_ms), uint32(t.acc_g1_launches), uint32(t.acc_g2_launches), uint64(t.acc_g1_terms), uint64(t.acc_g2_terms),
-		uint64(t.acc_g1_adds), uint64(t.acc_g2_adds), uint32(t.window_bits), uint32(t.fallbacks)}
+		uint64(t.acc_g1_adds), uint64(t.acc_g2_adds), uint32(t.window_bits), uint32(t.fallbacks),
+		uint64(t.plan_digits), uint64(t.plan_entries), uint32(t.heavy_buckets)}
 }
 
 // LastTiming (current logical device of the calling thread) / DeviceTiming (a named one).

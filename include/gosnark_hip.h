@@ -424,10 +424,17 @@ typedef struct {
   uint32_t acc_g1_launches, acc_g2_launches;
   uint64_t acc_g1_terms; /* (terms x base arrays) those G1 launches consumed */
   uint64_t acc_g2_terms;
-  uint64_t acc_g1_adds;  /* mixed point additions those G1 launches performed = terms x base arrays x digit positions (windows) */
+  uint64_t acc_g1_adds;  /* mixed point additions those G1 launches performed = NON-ZERO digits of their plans x base arrays (counted by the plan) */
   uint64_t acc_g2_adds;
   uint32_t window_bits;  /* Pippenger window width c of the last plan; every term costs floor(254 / c) + 1 additions */
   uint32_t fallbacks;    /* witness-route calls that had to repeat on the exact px route because the witness violates a constraint */
+  /* What the plans of the call found in their scalars (summed over the MSM groups, per base array): a term has one digit per window;
+   * a ZERO digit costs nothing, every other one is one bucket addition.  Uniform scalars: plan_entries ~ plan_digits; a witness full
+   * of 0 / 1 / small values: a fraction of it. */
+  uint64_t plan_digits;   /* terms x windows x base arrays */
+  uint64_t plan_entries;  /* non-zero digits x base arrays = mixed additions the accumulation kernels really performed */
+  uint32_t heavy_buckets; /* buckets cut into more than 64 chunks (0/1-heavy witnesses), combined by a block-wide tree */
+  uint32_t reserved;
 } gs_timing;
 int gs_last_timing(gs_timing* out);                         /* the calling thread's current logical device */
 int gs_device_timing(int logical_device, gs_timing* out);

@@ -88,7 +88,7 @@ __global__ void k_fq2(int op, const uint32_t* a, const uint32_t* b, uint32_t* ou
 
 // points: Jacobian standard-form triples in, affine Jacobian [x, y, 1] / [0, 0, 0] out.
 // op: 0 madd (P + Q, Q affine)  1 madd with negate (P - Q)  2 dbl (2 P)  3 add (P + Q, both XYZZ)  4 k * P (k = first 8 words of Q.x)
-//     5 on_curve(P) -> [flag, 0, ..]
+//     5 on_curve(P) -> [flag, 0, ..]   6 add with the second operand in memory (xyzz_add_mem, the MSM tail kernels' addition)
 template <class T>
 __global__ void k_curve(int op, const uint32_t* a, const uint32_t* b, uint32_t* out, uint32_t n) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -107,6 +107,14 @@ __global__ void k_curve(int op, const uint32_t* a, const uint32_t* b, uint32_t* 
     case 3: { Xyzz<T> q = xyzz_from_affine(Q); xyzz_dbl(q); xyzz_madd(q, Q, true); xyzz_add(acc, q); break; }   // Q presented as 2Q - Q: a non-trivial XYZZ operand
     case 4: { uint32_t k[8]; for (int j = 0; j < 8; ++j) k[j] = pb[j]; scalar_canon(k); acc = xyzz_mul_words_w4(acc, k); break; }
     case 5: o[0] = on_curve(P) ? 1u : 0u; return;
+    case 6: {                                    // the tails' form: second operand read from MEMORY coordinate by coordinate (both XYZZ non-trivial)
+      uint32_t buf[PointIO<T>::kXyzzWords];
+      Xyzz<T> q = xyzz_from_affine(Q); xyzz_dbl(q); xyzz_madd(q, Q, true);
+      store_xyzz<T>(buf, q);
+      if (!is_inf(P)) { xyzz_dbl(acc); xyzz_madd(acc, P, true); }
+      xyzz_add_mem<T>(acc, buf);
+      break;
+    }
   }
   const Affine<T> r = xyzz_to_affine(acc);
   if (is_inf(r)) return;

@@ -120,7 +120,8 @@ def test_g1_point_operations_on_the_device():
     fp, fq = [c for p in P for c in p], [c for p in Q for c in p]
     aff = lambda p: (lambda a: [0, 0, 0] if a is None else [a[0], a[1], 1])(G.Affine(p))       # noqa: E731
     for op, f in ((0, lambda p, q: _ref_add(G, O.G1_ZERO, p, q)), (1, lambda p, q: _ref_add(G, O.G1_ZERO, p, G.Neg(q))),
-                  (2, lambda p, q: G.Double(p) if not G.IsZero(p) else p), (3, lambda p, q: _ref_add(G, O.G1_ZERO, p, q))):
+                  (2, lambda p, q: G.Double(p) if not G.IsZero(p) else p), (3, lambda p, q: _ref_add(G, O.G1_ZERO, p, q)),
+                  (6, lambda p, q: _ref_add(G, O.G1_ZERO, p, q))):            # 6: xyzz_add_mem, the tail kernels' memory-operand addition
         got = run(3, op, fp, fq, 3)
         want = [c for p, q in zip(P, Q) for c in aff(f(p, q))]
         assert got == want, "op %d" % op
@@ -143,7 +144,8 @@ def test_g2_point_operations_on_the_device():
     flat = lambda L: [c for p in L for xy in p for c in xy]                 # noqa: E731
     aff = lambda p: (lambda a: [0] * 6 if a is None else [a[0][0], a[0][1], a[1][0], a[1][1], 1, 0])(G.Affine(p))   # noqa: E731
     for op, f in ((0, lambda p, q: _ref_add(G, O.G2_ZERO, p, q)), (1, lambda p, q: _ref_add(G, O.G2_ZERO, p, G.Neg(q))),
-                  (2, lambda p, q: G.Double(p) if not G.IsZero(p) else p), (3, lambda p, q: _ref_add(G, O.G2_ZERO, p, q))):
+                  (2, lambda p, q: G.Double(p) if not G.IsZero(p) else p), (3, lambda p, q: _ref_add(G, O.G2_ZERO, p, q)),
+                  (6, lambda p, q: _ref_add(G, O.G2_ZERO, p, q))):
         got = run(4, op, flat(P), flat(Q), 6)
         want = [c for p, q in zip(P, Q) for c in aff(f(p, q))]
         assert got == want, "op %d" % op
