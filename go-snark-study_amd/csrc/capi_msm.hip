@@ -246,11 +246,21 @@ static void ctx_create(Ctx& c, int logical, int device) {
   // and a starved plan(h) would stall the last accumulation (seen in an earlier timeline).
   int least = 0, greatest = 0;
   GS_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+  constexpr long kTailPriorityDefault = 1;
   const bool no_overlap = run_flag("GS_NO_OVERLAP");                // debugging aid: everything on the main stream (same results)
   const bool no_prio = run_flag("GS_NO_PRIORITY");
-  for (auto& a : c.aux_stream) {
-    if (no_overlap) a = c.main_stream;
-    else GS_HIP(hipStreamCreateWithPriority(&a, hipStreamNonBlocking, no_prio ? least : greatest));
+  // GS_TAIL_PRIORITY (same results, scheduling only): queue priority of the two reduction-tail streams -- 0 = highest, like the
+  // plan / H(x) stream (rounds 1-3), 1 = the default priority of the accumulation stream, 2 = lowest.  Round 4's tail kernels fit
+  // beside an accumulation wave (<= 256 VGPRs), so they no longer need help to be placed; at small sizes they got in the way of
+  // the plans and NTT passes that set the pace (profiles/r04_ab_tail_priority.txt).
+  const long tail_prio = run_knob("GS_TAIL_PRIORITY", kTailPriorityDefault, 0, 2);
+  for (int i = 0; i < Ctx::kAuxStreams; ++i) {
+    hipStream_t& a = c.aux_stream[i];
+    if (no_overlap) { a = c.main_stream; continue; }
+    int prio = greatest;
+    if (i != 1 && tail_prio == 1) prio = (least + greatest) / 2;
+    if (i != 1 && tail_prio == 2) prio = least;
+    GS_HIP(hipStreamCreateWithPriority(&a, hipStreamNonBlocking, no_prio ? least : prio));
   }
   for (auto& p : c.pinned) GS_HIP(hipHostMalloc(&p, Ctx::kPinnedBytes, hipHostMallocDefault));
   c.bad_dev.alloc(Ctx::kSlots * 4);

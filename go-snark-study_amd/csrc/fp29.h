@@ -370,9 +370,12 @@ GS_HD Fe<M, 2> dot4(const Fe<M, Ba>& a, const Fe<M, Bb>& b, const Fe<M, Bc>& c, 
 // compiler breaks the chain for instruction-level parallelism -- products into a second accumulator, then a 64-bit add per
 // column (17 v_lshl_add_u64 per product, ~7 % of the kernel's issue cycles: tools/ubench_valu2.hip prices the add like a
 // multiply-add) -- and pinning the chain (GS_CHAIN) trades the adds for one s_nop wait state per dependent pair.  Two (or three)
-// INDEPENDENT dot products computed together avoid both: their multiply-adds alternate in program order, so no instruction
-// depends on its predecessor, nothing is re-associated and no wait state is needed.  A point addition has such pairs everywhere
-// (U2 | S2, P^2 | R^2, P^3 | Q, and the two coordinates of every Fq2 product).
+// INDEPENDENT dot products computed together avoid the re-association and most of the waiting: their multiply-adds alternate in
+// program order, so no instruction depends on its predecessor.  A point addition has such pairs everywhere (U2 | S2, P^2 | R^2,
+// P^3 | Q, and the two coordinates of every Fq2 product).  (Round 3 claimed "no wait state is needed" here.  The ISA says otherwise --
+// the compiler still pads every round of the chains with one s_nop: v_mad A; v_mad B; s_nop 0; v_mad A -- and round 4 measured it,
+// tools/snop -> profiles/r04_ab_snop.txt: the padding is required (with it deleted the hardware interlocks, same results, no faster),
+// and a two-chain product costs 3-4 % more than a three-chain one at 2 and at 3 waves per SIMD.)
 // GS_STEP pins an accumulator after one multiply-add (device code; volatile, so the alternation survives scheduling).
 #ifndef GS_PAIR
 #define GS_PAIR 1

@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <future>
+#include <type_traits>
 
 #include "msm_kernels.h"
 
@@ -262,16 +263,23 @@ static void msm_enqueue(Ctx& c, const MsmPlan& plan, const std::vector<MsmBase>&
   p.tred = std::make_shared<PhaseTimer>(ts);
   // (the block-wide tree for buckets cut into very many chunks belongs to the tail too: with uniform scalars it finds nothing
   // to do, and on the accumulation stream even an empty launch waited ~0.5 ms for register space)
-  hipLaunchKernelGGL(k_heavy_combine<T>, dim3(64, njobs), dim3(kHeavyBlock), 0, ts,
-                     jobs, plan.offsets, plan.heavy_list, plan.heavy_count, plan.chunk);
-  hipLaunchKernelGGL(k_bucket_combine<T>, dim3((plan.B + 255) / 256, njobs), dim3(256), 0, ts, jobs, plan.offsets, plan.B, plan.chunk,
-                     plan.heavy_count, stats);
-  hipLaunchKernelGGL(k_block_reduce<T>, dim3(nblk, njobs), dim3(kReduceBlock), 0, ts, jobs, plan.B, L);
-  if (p.folded) {
-    int log2_span = 0;
-    while ((1u << log2_span) < (uint32_t)kReduceBlock * (uint32_t)L) ++log2_span;
-    hipLaunchKernelGGL(k_pair_reduce<T>, dim3(1, njobs), dim3(kReduceBlock), 0, ts, jobs, nblk, log2_span);
-  }
+  // small MSMs: one tail wave per SIMD (msm_kernels.h, kAlone); from 2^19 terms on the tails share their SIMDs with accumulation waves
+  static const long alone_below_log2 = dev_knob("GS_TAIL_ALONE_LOG2", 19, 0, 32);
+  const bool alone = plan.n < (1ull << alone_below_log2);
+  auto launch_tails = [&](auto alone_tag) {
+    constexpr bool kAlone = decltype(alone_tag)::value;
+    hipLaunchKernelGGL((k_heavy_combine<T, kAlone>), dim3(64, njobs), dim3(kHeavyBlock), 0, ts,
+                       jobs, plan.offsets, plan.heavy_list, plan.heavy_count, plan.chunk);
+    hipLaunchKernelGGL((k_bucket_combine<T, kAlone>), dim3((plan.B + 255) / 256, njobs), dim3(256), 0, ts, jobs, plan.offsets, plan.B, plan.chunk,
+                       plan.heavy_count, stats);
+    hipLaunchKernelGGL((k_block_reduce<T, kAlone>), dim3(nblk, njobs), dim3(kReduceBlock), 0, ts, jobs, plan.B, L);
+    if (p.folded) {
+      int log2_span = 0;
+      while ((1u << log2_span) < (uint32_t)kReduceBlock * (uint32_t)L) ++log2_span;
+      hipLaunchKernelGGL((k_pair_reduce<T, kAlone>), dim3(1, njobs), dim3(kReduceBlock), 0, ts, jobs, nblk, log2_span);
+    }
+  };
+  if (alone) launch_tails(std::true_type{}); else launch_tails(std::false_type{});
   GS_HIP(hipGetLastError());
   GS_HIP(hipMemcpyAsync(c.pinned[slot], p.folded ? (const void*)finals : outb.p, out_bytes, hipMemcpyDeviceToHost, ts));
   p.pinned_slot = c.pinned[slot];

@@ -390,8 +390,16 @@ template <> struct AccTuning<FqTag> { static constexpr int kMinWaves = GS_G1_WAV
 #endif
 template <> struct AccTuning<Fq2Tag> { static constexpr int kMinWaves = GS_G2_WAVES; static constexpr bool kRegisterPrefetch = GS_G2_PREFETCH != 0; static constexpr bool kTouch = GS_G2_TOUCH != 0; };
 
+// (GS_ACC_MAXWAVES_G1 / _G2: experiment -- cap the waves per SIMD of the accumulation kernels, as the tail kernels' kAlone does)
+#ifndef GS_ACC_MAXWAVES_G1
+#define GS_ACC_MAXWAVES_G1 8
+#endif
+#ifndef GS_ACC_MAXWAVES_G2
+#define GS_ACC_MAXWAVES_G2 8
+#endif
+template <class T> constexpr int acc_max_waves() { return T::kWords == 8 ? GS_ACC_MAXWAVES_G1 : GS_ACC_MAXWAVES_G2; }
 template <class T>
-__global__ void __launch_bounds__(256, AccTuning<T>::kMinWaves) k_bucket_accumulate(AccJobs jobs, const uint32_t* __restrict__ offsets,
+__global__ void __attribute__((amdgpu_flat_work_group_size(1, 256), amdgpu_waves_per_eu(acc_max_waves<T>() < AccTuning<T>::kMinWaves ? acc_max_waves<T>() : AccTuning<T>::kMinWaves, acc_max_waves<T>()))) k_bucket_accumulate(AccJobs jobs, const uint32_t* __restrict__ offsets,
                                                             const uint32_t* __restrict__ entries,
                                                             const uint32_t* __restrict__ chunk_bucket, uint32_t nbuckets, uint32_t chunk) {
   constexpr int pw = PointIO<T>::kXyzzWords;
@@ -475,13 +483,22 @@ GS_HD Xyzz<T> load_bucket(const AccJob& job, const uint32_t* __restrict__ offset
   return acc;
 }
 
+// Two instances of every tail kernel (round 4, profiles/r04_ab_tails_alone.txt):
+//   kAlone = false  <= 256 VGPRs, so a tail wave shares its SIMD with an accumulation wave: right when the chip is FULL (2^19 terms and
+//                   up: the tails are throughput work in the shadow of the accumulations);
+//   kAlone = true   the backend pads the register count so that at most ONE such wave lives on a SIMD: right when the chip is mostly
+//                   EMPTY (small MSMs: the tails are chains of dependent additions that set the pace, and the workgroup dispatcher
+//                   otherwise packs several tail waves -- and the next proof's sort / NTT waves -- onto the same SIMDs while other
+//                   CUs idle: 2^16 / 2^17 / 2^18 proofs 1.00 / 1.58 / 2.69 -> 0.93 / 1.42 / 2.46 ms).
 #ifndef GS_TAIL_WAVES
-#define GS_TAIL_WAVES 2          // <= 256 VGPRs: a tail wave shares its SIMD with an accumulation wave
+#define GS_TAIL_WAVES 2
 #endif
+#define GS_TAIL_KERNEL(block, alone) \
+  __global__ void __attribute__((amdgpu_flat_work_group_size(1, block), amdgpu_waves_per_eu((alone) ? 1 : GS_TAIL_WAVES, (alone) ? 1 : 8)))
 // one block per heavy bucket (grid-stride over the device-side list): tails[first..last) + heads[last] -> buckets[b]
 constexpr int kHeavyBlock = 128;
-template <class T>
-__global__ void __launch_bounds__(kHeavyBlock, GS_TAIL_WAVES) k_heavy_combine(AccJobs jobs, const uint32_t* __restrict__ offsets,
+template <class T, bool kAlone>
+GS_TAIL_KERNEL(kHeavyBlock, kAlone) k_heavy_combine(AccJobs jobs, const uint32_t* __restrict__ offsets,
                                                                 const uint32_t* __restrict__ heavy_list,
                                                                 const uint32_t* __restrict__ heavy_count, uint32_t chunk) {
   constexpr int pw = PointIO<T>::kXyzzWords;
@@ -511,8 +528,8 @@ __global__ void __launch_bounds__(kHeavyBlock, GS_TAIL_WAVES) k_heavy_combine(Ac
 // digit positions share one bucket set, so the MSM is simply sum_b (b + 1) * merged[b]: no per-window
 // reduction and no Horner recombination.  Thread (0, 0, 0) also leaves what the plan found for gs_timing:
 // stats[0] = bucket entries (= non-zero digits = additions one base array costs), stats[1] = buckets combined by the heavy tree.
-template <class T>
-__global__ void __launch_bounds__(256, GS_TAIL_WAVES) k_bucket_combine(AccJobs jobs, const uint32_t* __restrict__ offsets, uint32_t B, uint32_t chunk,
+template <class T, bool kAlone>
+GS_TAIL_KERNEL(256, kAlone) k_bucket_combine(AccJobs jobs, const uint32_t* __restrict__ offsets, uint32_t B, uint32_t chunk,
                                                                      const uint32_t* __restrict__ heavy_count, uint32_t* __restrict__ stats) {
   const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b == 0 && blockIdx.y == 0) { stats[0] = offsets[B]; stats[1] = *heavy_count; }
@@ -529,8 +546,8 @@ __global__ void __launch_bounds__(256, GS_TAIL_WAVES) k_bucket_combine(AccJobs j
 // R_t = sum_{t' >= t} run_0(t'), and sum_t t * run_0(t) = sum_{t >= 1} R_t; value_t = acc_t + L R_t, and a tree sum.  The host adds
 // the (at most 32) pairs: result = sum_blk A_blk + 256 L * sum_blk blk * S_blk.
 constexpr int kReduceBlock = 256;
-template <class T>
-__global__ void __launch_bounds__(kReduceBlock, GS_TAIL_WAVES) k_block_reduce(AccJobs jobs, uint32_t B, int L) {
+template <class T, bool kAlone>
+GS_TAIL_KERNEL(kReduceBlock, kAlone) k_block_reduce(AccJobs jobs, uint32_t B, int L) {
   constexpr int pw = PointIO<T>::kXyzzWords;
   __shared__ uint32_t sh[kReduceBlock * pw];
   const AccJob job = jobs.j[blockIdx.y];
@@ -586,8 +603,8 @@ __global__ void __launch_bounds__(kReduceBlock, GS_TAIL_WAVES) k_block_reduce(Ac
 // pairs (A_blk, S_blk) into the job's result  sum_blk A_blk + (256 L) * sum_blk blk * S_blk  -- the suffix-scan identity
 // again (sum_blk blk * S_blk = sum_{blk >= 1} R_blk with R_blk = sum_{b' >= blk} S_b'), then log2(256 L) doublings -- so the
 // host receives ONE point per job however many buckets there were.
-template <class T>
-__global__ void __launch_bounds__(kReduceBlock, GS_TAIL_WAVES) k_pair_reduce(AccJobs jobs, uint32_t nblk, int log2_span) {
+template <class T, bool kAlone>
+GS_TAIL_KERNEL(kReduceBlock, kAlone) k_pair_reduce(AccJobs jobs, uint32_t nblk, int log2_span) {
   constexpr int pw = PointIO<T>::kXyzzWords;
   __shared__ uint32_t sh[kReduceBlock * pw];
   const AccJob job = jobs.j[blockIdx.y];
