@@ -769,7 +769,15 @@ def main_one_process(args):
     capi.set_device(0)
     inst = synth.sqchain_setup_instance(n, seed)
     pk0 = inst.device_pk()
-    pks = [pk0] + [groth16.ShardPkTo(pk0, 0, 1, d) for d in range(1, N)]         # full replicas (copied GPU to GPU)
+    pks, replica_note = [pk0], "GPU-to-GPU copies of device 0's key (gs_groth16_pk_shard_to)"
+    for d in range(1, N):
+        try:
+            pks.append(groth16.ShardPkTo(pk0, 0, 1, d))                           # a full replica, copied GPU to GPU
+        except Exception as e:          # noqa: BLE001 -- peer copies have never met a second physical GPU: build the same key in place
+            capi.set_device(d)
+            pks.append(synth.sqchain_setup_instance(n, seed).device_pk())
+            capi.set_device(0)
+            replica_note = "peer copy failed (%s): the same deterministic setup was run on the device instead" % str(e)[:120]
     xs = [capi.u64_to_ints(inst.w_host[1:2])[0]] + synth.field_elems(N - 1, seed + 4242)
     ws, pxs = [inst.w], [inst.px]
     for d in range(1, N):
@@ -817,6 +825,7 @@ def main_one_process(args):
     out["roofline"], out["roofline_valu"] = accumulate_roofline(tm)
     out["proof_verified"] = "groth16.VerifyProof accepted each device's last proof for its own public input and rejected it for another's (%d/%d devices)" % (N, N)
     out["launch"] = "one process, no launcher (WORLD_SIZE unset)"
+    out["config"]["key_replicas"] = replica_note
     out["devices"] = device_report(devs)
     out["build"] = build_stamp()
     guard.line = out
