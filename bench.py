@@ -187,6 +187,30 @@ def witness_digit_stats(w_u64, c, tm):
                     "count the non-zero digits only"}
 
 
+def cpus_granted():
+    """What the container really gives this process (os.cpu_count() reports the host's threads): the scheduler affinity and the cgroup
+    CPU quota, so that `cpu_baseline_all_cores` can be read for what it is."""
+    info = {"os_cpu_count": os.cpu_count()}
+    try:
+        info["sched_affinity"] = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                txt = f.read().split()
+            if path.endswith("cpu.max"):
+                info["cgroup_quota_cpus"] = None if txt[0] == "max" else float(txt[0]) / float(txt[1])
+            else:
+                q = float(txt[0])
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                    info["cgroup_quota_cpus"] = None if q < 0 else q / float(g.read())
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return info
+
+
 def pipelined(begin, end, count, depth, on_done=None):
     tickets = []
     for _ in range(count):
@@ -1288,6 +1312,7 @@ def main():
             out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(args.cpu_log2n + 3, seed + 2000)
             # the container may grant fewer CPUs than os.cpu_count() reports: state what the threads actually bought
             out["cpu_baseline_all_cores"]["speedup_vs_1_core"] = out["cpu_baseline_all_cores"]["value"] / out["cpu_baseline"]["value"]
+            out["cpu_baseline_all_cores"]["cpus_granted"] = cpus_granted()
             if args.workload != "prove":
                 out["cpu_baseline"]["note"] = "baseline is the Groth16 prove sample; 1 constraint ~ 4 G1 + 1 G2 terms"
             if plain_prove and not args.no_extras:
