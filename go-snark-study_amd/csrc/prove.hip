@@ -174,8 +174,17 @@ int groth16_enqueue(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, const S
   MsmPlan plan_w, plan_h;
   // The main stream carries NOTHING but the ALU-bound bucket accumulations (G2, then the three G1 arrays over w, then h),
   // so with two proofs in flight it never idles: both plans, H(x) and every combine/reduce tail run on the aux streams.
+  // plan(w) of a pipelined proof on its own stream (aux 2, the tails then share aux 0) where the polynomial stage is long: on aux 1 the
+  // NEXT proof's plan(w) queues behind this proof's H stage and plan(h), and the accumulation stream then waits ~0.3 ms twice per proof.
+  // Measured (profiles/r04_ab_plan_w_stream.txt): witness route at 2^20 10.2-10.3 -> 9.9 ms, px route at 2^22 35.5 -> 34.9 ms, but the
+  // px route at 2^20 (H(x) is only 0.7 ms there) 8.7-8.9 -> 9.0-9.1: hence the rule.  GS_PLANW_STREAM: 0 never, 1 this rule, 2 always.
+  static const long planw_mode = run_knob("GS_PLANW_STREAM", 1, 0, 2);
+  const bool from_witness = (bool)px.produce_hv || (bool)px.produce_hx || (bool)px.produce;   // (not hv_slice: no polynomial work here)
+  c.planw_own = pipelined && c.aux_stream[2] != c.aux_stream[1] &&
+                (planw_mode == 2 || (planw_mode == 1 && (whi - wlo) >= ((size_t)1 << 19) && (from_witness || (whi - wlo) >= ((size_t)1 << 21))));
+  struct ResetPlanW { Ctx& c; ~ResetPlanW() { c.planw_own = false; } } reset_planw{c};
   {                                                              // aux 1: plan(w), then H(x), plan(h)
-    StreamScope sc(c, c.aux_stream[1]);
+    StreamScope sc(c, c.planw_stream());
     st.tplanw = std::make_shared<PhaseTimer>(c.stream);
     build_plan(c, 0 + 2 * parity, w.p + wlo * 8, (uint32_t)(whi - wlo), plan_w, {{1, true}, {3, false}});
     st.tplanw->stop();

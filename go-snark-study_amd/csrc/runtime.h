@@ -162,7 +162,11 @@ struct Ctx {
   // (latency, not throughput), so the tails of operation k + 1 may run beside those of operation k instead of queueing behind
   // them -- at 2^16 the G2 tail (1.2 ms) was longer than the accumulations of a whole proof (0.9 ms) and set the pace.
   unsigned tail_flip = 0;
-  hipStream_t tail_stream(int which) { return aux_stream[((which ^ (int)(tail_flip & 1u)) & 1) ? 2 : 0]; }
+  // Large pipelined proofs with a long polynomial stage (prove.hip, GS_PLANW_STREAM): plan(w) of the NEXT proof on aux 2, so that it no
+  // longer queues behind this proof's H stage and plan(h) on aux 1; every tail then shares aux 0.
+  bool planw_own = false;
+  hipStream_t tail_stream(int which) { return planw_own ? aux_stream[0] : aux_stream[((which ^ (int)(tail_flip & 1u)) & 1) ? 2 : 0]; }
+  hipStream_t planw_stream() { return planw_own ? aux_stream[2] : aux_stream[1]; }
   void next_tails(uint32_t n) {                     // called once per pipelined operation of n terms
     static const int mode = (int)run_knob("GS_TAIL_FLIP", 1, 0, 2);                        // 0 never, 1 always, 2 by size (same results)
     if (mode == 1 || (mode == 2 && n <= kTailFlipMaxTerms)) tail_flip ^= 1u;
