@@ -127,6 +127,22 @@ struct GrothInFlight : InFlightBase {
 
 static void groth16_tail_pre(GrothPkObj* pk, const uint64_t r[4], const uint64_t s[4], GrothTailPre& pre);
 
+// plan(w) of a pipelined proof on its own stream (aux 2, the tails then share aux 0) where the polynomial stage is long: on aux 1 the
+// NEXT proof's plan(w) queues behind this proof's H stage and plan(h), and the accumulation stream then waits ~0.3 ms twice per proof.
+// Measured (profiles/r04_ab_plan_w_stream.txt): witness route at 2^20 10.2-10.3 -> 9.8 ms, at 2^19 5.55 -> 5.17, px route at 2^22 35.9 ->
+// 35.4 ms, but the px route at 2^20 (H(x) is only 0.7 ms there) 8.7-8.9 -> 9.0-9.1: hence the rule.  GS_PLANW_STREAM: 0 never, 1 this
+// rule, 2 always (identical results).  The scope object resets the choice when the enqueue function returns.
+struct PlanWStream {
+  Ctx& c;
+  PlanWStream(Ctx& ctx_, bool pipelined, size_t nterms, const DevScalars& px) : c(ctx_) {
+    static const long mode = run_knob("GS_PLANW_STREAM", 1, 0, 2);
+    const bool from_witness = (bool)px.produce_hv || (bool)px.produce_hx || (bool)px.produce;   // (not hv_slice: no polynomial work here)
+    c.planw_own = pipelined && c.aux_stream[2] != c.aux_stream[1] &&
+                  (mode == 2 || (mode == 1 && nterms >= ((size_t)1 << 19) && (from_witness || nterms >= ((size_t)1 << 21))));
+  }
+  ~PlanWStream() { c.planw_own = false; }
+};
+
 // Enqueue every device operation of one proof (no host wait).  `wait_inputs`: w / px were uploaded on the main stream
 // in this call, so the aux streams must order themselves behind that point.
 int groth16_enqueue(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, const Shard& shard, int parity, bool wait_inputs, bool pipelined,
@@ -174,15 +190,7 @@ int groth16_enqueue(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, const S
   MsmPlan plan_w, plan_h;
   // The main stream carries NOTHING but the ALU-bound bucket accumulations (G2, then the three G1 arrays over w, then h),
   // so with two proofs in flight it never idles: both plans, H(x) and every combine/reduce tail run on the aux streams.
-  // plan(w) of a pipelined proof on its own stream (aux 2, the tails then share aux 0) where the polynomial stage is long: on aux 1 the
-  // NEXT proof's plan(w) queues behind this proof's H stage and plan(h), and the accumulation stream then waits ~0.3 ms twice per proof.
-  // Measured (profiles/r04_ab_plan_w_stream.txt): witness route at 2^20 10.2-10.3 -> 9.9 ms, px route at 2^22 35.5 -> 34.9 ms, but the
-  // px route at 2^20 (H(x) is only 0.7 ms there) 8.7-8.9 -> 9.0-9.1: hence the rule.  GS_PLANW_STREAM: 0 never, 1 this rule, 2 always.
-  static const long planw_mode = run_knob("GS_PLANW_STREAM", 1, 0, 2);
-  const bool from_witness = (bool)px.produce_hv || (bool)px.produce_hx || (bool)px.produce;   // (not hv_slice: no polynomial work here)
-  c.planw_own = pipelined && c.aux_stream[2] != c.aux_stream[1] &&
-                (planw_mode == 2 || (planw_mode == 1 && (whi - wlo) >= ((size_t)1 << 19) && (from_witness || (whi - wlo) >= ((size_t)1 << 21))));
-  struct ResetPlanW { Ctx& c; ~ResetPlanW() { c.planw_own = false; } } reset_planw{c};
+  PlanWStream planw_scope(c, pipelined, whi - wlo, px);
   {                                                              // aux 1: plan(w), then H(x), plan(h)
     StreamScope sc(c, c.planw_stream());
     st.tplanw = std::make_shared<PhaseTimer>(c.stream);
@@ -469,8 +477,9 @@ int pinocchio_enqueue(Ctx& c, PinocchioPkObj* pk, DevScalars w, DevScalars px, c
   }
   const int ws = 8 * parity, pin = 3 * parity;
   MsmPlan plan_w, plan_h;
-  {                                                              // aux 1: plan(w)
-    StreamScope sc(c, c.aux_stream[1]);
+  PlanWStream planw_scope(c, pipelined, whi - wlo, px);
+  {                                                              // aux 1 (or its own stream, PlanWStream): plan(w)
+    StreamScope sc(c, c.planw_stream());
     st.tplanw = std::make_shared<PhaseTimer>(c.stream);
     build_plan(c, 2 * parity, w.p + wlo * 8, (uint32_t)(whi - wlo), plan_w, {{1, true}, {6, false}});
     st.tplanw->stop();
