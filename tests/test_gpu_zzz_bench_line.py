@@ -60,6 +60,17 @@ def test_two_ranks_under_torch_distributed_run_print_the_same_keys():
     assert d["launch"].startswith("torch.distributed.run") and "gloo" in d["strong"]["exchange"]
 
 
+def test_multi_ranks_reexecutes_the_plain_command_line_under_the_launcher():
+    """`python bench.py --gpus 2 --multi ranks` with no WORLD_SIZE: bench.py re-executes itself under torch.distributed.run (one rank per
+    GPU; both on GPU 0 here) and the line comes from rank 0 of that job."""
+    env = dict(os.environ, GS_BENCH_SHARE_GPU="1", MASTER_ADDR="127.0.0.1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    d = _line([sys.executable, "bench.py", "--gpus", "2", "--multi", "ranks", "--steps", "2", "--warmup", "1", "--reps", "1", "--log2n", "12", "--cpu-log2n", "0",
+               "--no-strong"], env)
+    assert d["n_gpus"] == 2 and d["launch"].startswith("torch.distributed.run") and "strong" not in d and d["value"] > 0
+
+
 def test_single_gpu_line_keeps_its_contract():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     d = _line([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--reps", "1", "--log2n", "12", "--cpu-log2n", "8", "--no-extras"], dict(env, GS_BENCH_NO_LIVE_PMC="1"))
