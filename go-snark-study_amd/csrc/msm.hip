@@ -270,6 +270,8 @@ static void msm_enqueue(Ctx& c, const MsmPlan& plan, const std::vector<MsmBase>&
     constexpr bool kAlone = decltype(alone_tag)::value;
     hipLaunchKernelGGL((k_heavy_combine<T, kAlone>), dim3(64, njobs), dim3(kHeavyBlock), 0, ts,
                        jobs, plan.offsets, plan.heavy_list, plan.heavy_count, plan.chunk);
+    hipLaunchKernelGGL((k_heavy_finish<T, kAlone>), dim3(16, njobs), dim3(kHeavyBlock), 0, ts,
+                       jobs, plan.offsets, plan.heavy_list, plan.heavy_count, plan.chunk);
     hipLaunchKernelGGL((k_bucket_combine<T, kAlone>), dim3((plan.B + 255) / 256, njobs), dim3(256), 0, ts, jobs, plan.offsets, plan.B, plan.chunk,
                        plan.heavy_count, stats);
     hipLaunchKernelGGL((k_block_reduce<T, kAlone>), dim3(nblk, njobs), dim3(kReduceBlock), 0, ts, jobs, plan.B, L);

@@ -495,8 +495,23 @@ GS_HD Xyzz<T> load_bucket(const AccJob& job, const uint32_t* __restrict__ offset
 #endif
 #define GS_TAIL_KERNEL(block, alone) \
   __global__ void __attribute__((amdgpu_flat_work_group_size(1, block), amdgpu_waves_per_eu((alone) ? 1 : GS_TAIL_WAVES, (alone) ? 1 : 8)))
-// one block per heavy bucket (grid-stride over the device-side list): tails[first..last) + heads[last] -> buckets[b]
+// Heavy buckets (cut into more than kHeavySpan + 1 chunks: the buckets of the digits 0/1-heavy witnesses are full of) are summed by
+// the whole grid, in two steps.  Round 4: a witness of the shape the reference's CalculateWitness produces puts a quarter of all entries
+// into ONE bucket (262 545 entries = 8 205 chunks at 2^20); with one workgroup per bucket that was a chain of 64 dependent additions per
+// thread on a single workgroup while 63 others idled -- 1.78 ms for G2, the longest kernel of such a proof.  Now every heavy bucket is cut
+// into kHeavySlices slices of consecutive chunks; k_heavy_combine sums (bucket, slice) items grid-wide and parks each slice's sum in
+// the slice's first chunk slot (its own, by then consumed), k_heavy_finish adds the <= 16 slice sums of a bucket with 16 lanes.
 constexpr int kHeavyBlock = 128;
+constexpr int kHeavySlices = 16;
+// chunks [c0, c1) of slice s of a bucket whose pieces are chunks tf .. tl (empty when c0 > tl)
+GS_HD void heavy_slice(uint32_t tf, uint32_t tl, uint32_t s, uint32_t& c0, uint32_t& c1) {
+  const uint32_t len = (tl - tf + 1 + kHeavySlices - 1) / kHeavySlices;
+  c0 = tf + s * len;
+  c1 = min(c0 + len, tl + 1);
+}
+// where chunk t keeps its piece of a bucket that spans tf .. tl: the last chunk holds a head, the others tails
+GS_HD uint32_t* heavy_slot(const AccJob& job, uint32_t t, uint32_t tl, int pw) { return (t == tl ? job.heads : job.tails) + (size_t)t * pw; }
+
 template <class T, bool kAlone>
 GS_TAIL_KERNEL(kHeavyBlock, kAlone) k_heavy_combine(AccJobs jobs, const uint32_t* __restrict__ offsets,
                                                                 const uint32_t* __restrict__ heavy_list,
@@ -504,12 +519,15 @@ GS_TAIL_KERNEL(kHeavyBlock, kAlone) k_heavy_combine(AccJobs jobs, const uint32_t
   constexpr int pw = PointIO<T>::kXyzzWords;
   __shared__ uint32_t sh[kHeavyBlock * pw];
   const AccJob job = jobs.j[blockIdx.y];
-  const uint32_t nheavy = *heavy_count;
-  for (uint32_t h = blockIdx.x; h < nheavy; h += gridDim.x) {
-    const uint32_t b = heavy_list[h];
+  const uint32_t nitems = *heavy_count * (uint32_t)kHeavySlices;
+  for (uint32_t item = blockIdx.x; item < nitems; item += gridDim.x) {
+    const uint32_t b = heavy_list[item / kHeavySlices];
     const uint32_t tf = offsets[b] / chunk, tl = (offsets[b + 1] - 1) / chunk;
+    uint32_t c0, c1;
+    heavy_slice(tf, tl, item % kHeavySlices, c0, c1);
+    if (c0 > tl) continue;                                         // (uniform over the workgroup)
     Xyzz<T> acc = xyzz_inf<T>();
-    for (uint32_t t = tf + threadIdx.x; t <= tl; t += kHeavyBlock) xyzz_add_mem<T>(acc, (t == tl ? job.heads : job.tails) + (size_t)t * pw);
+    for (uint32_t t = c0 + threadIdx.x; t < c1; t += kHeavyBlock) xyzz_add_mem<T>(acc, heavy_slot(job, t, tl, pw));
     store_xyzz<T>(sh + threadIdx.x * pw, acc);
     __syncthreads();
     for (int half = kHeavyBlock / 2; half >= 1; half >>= 1) {
@@ -519,7 +537,41 @@ GS_TAIL_KERNEL(kHeavyBlock, kAlone) k_heavy_combine(AccJobs jobs, const uint32_t
       }
       __syncthreads();
     }
-    if (threadIdx.x == 0) store_xyzz<T>(job.buckets + (size_t)b * pw, acc);
+    if (threadIdx.x == 0) store_xyzz<T>(heavy_slot(job, c0, tl, pw), acc);      // the slice's own first slot: every piece of it has been read
+    __syncthreads();
+  }
+}
+// buckets[b] = the sum of the slice sums of heavy bucket b: 16 lanes per bucket, 8 buckets per workgroup
+template <class T, bool kAlone>
+GS_TAIL_KERNEL(kHeavyBlock, kAlone) k_heavy_finish(AccJobs jobs, const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ heavy_list,
+                                                   const uint32_t* __restrict__ heavy_count, uint32_t chunk) {
+  constexpr int pw = PointIO<T>::kXyzzWords;
+  constexpr uint32_t per = kHeavyBlock / kHeavySlices;
+  __shared__ uint32_t sh[kHeavyBlock * pw];
+  const AccJob job = jobs.j[blockIdx.y];
+  const uint32_t nheavy = *heavy_count;
+  const uint32_t lane = threadIdx.x % kHeavySlices;
+  for (uint32_t g = blockIdx.x; g * per < nheavy; g += gridDim.x) {
+    const uint32_t h = g * per + threadIdx.x / kHeavySlices;
+    Xyzz<T> acc = xyzz_inf<T>();
+    uint32_t b = 0;
+    if (h < nheavy) {
+      b = heavy_list[h];
+      const uint32_t tf = offsets[b] / chunk, tl = (offsets[b + 1] - 1) / chunk;
+      uint32_t c0, c1;
+      heavy_slice(tf, tl, lane, c0, c1);
+      if (c0 <= tl) acc = load_xyzz<T>(heavy_slot(job, c0, tl, pw));
+    }
+    store_xyzz<T>(sh + threadIdx.x * pw, acc);
+    __syncthreads();
+    for (int half = kHeavySlices / 2; half >= 1; half >>= 1) {
+      if ((int)lane < half) {
+        xyzz_add_mem<T>(acc, sh + (threadIdx.x + half) * pw);
+        store_xyzz<T>(sh + threadIdx.x * pw, acc);
+      }
+      __syncthreads();
+    }
+    if (lane == 0 && h < nheavy) store_xyzz<T>(job.buckets + (size_t)b * pw, acc);
     __syncthreads();
   }
 }

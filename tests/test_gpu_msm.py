@@ -224,6 +224,45 @@ def test_msm_skewed_witness_heavy_buckets(g2):
             capi.set_window_bits(0)
 
 
+@pytest.mark.parametrize("g2", [False, True])
+def test_several_heavy_buckets_of_every_size_through_the_sliced_tree(g2):
+    """Round 4's heavy path (k_heavy_combine over (bucket, slice) items + k_heavy_finish): heavy buckets of very different sizes in one
+    MSM -- one that holds 40 % of all terms, some of a few hundred chunks, and some just over the 64-chunk threshold, where most of a
+    bucket's 16 slices hold 4-5 chunks and the last ones are partly or wholly empty -- beside ordinary buckets, against the C oracle's
+    naive loop over the same points; in both forms of the tail kernels (the MSM is small: one wave per SIMD) and pipelined."""
+    n = 1 << (14 if g2 else 15)
+    rng = random.Random(4242 + g2)
+    uni = U.u64_rows_to_ints(U.rand_scalars_u64(n, 79))
+    small = [(1, 0.40), (2, 0.15), (3, 0.10), (5, 0.05), (7, 0.0335), (O.R - 2, 0.034)]      # value, share of the terms
+    ks = []
+    for i in range(n):
+        x, acc = rng.random(), 0.0
+        v = uni[i]
+        for val, share in small:
+            acc += share
+            if x < acc:
+                v = val
+                break
+        ks.append(v)
+    ks = capi.ints_to_u64(ks)
+    if g2:
+        bases = capi.g2_fixed_base(U.rand_scalars_u64(n, 80))
+        want = C.g2_affine(C.g2_msm_naive(capi.g2_download(bases), ks, threads=8))
+    else:
+        bases = capi.g1_fixed_base(U.rand_scalars_u64(n, 80))
+        want = C.g1_affine(C.g1_msm_naive(capi.g1_download(bases), ks, threads=8))
+    sc = capi.scalars_upload(ks)
+    for c in (0, 10, 16):
+        capi.set_window_bits(c)
+        try:
+            assert capi.msm(bases, ks, g2=g2) == want, c
+            assert capi.last_timing()["heavy_buckets"] >= 2, c       # (the chunk size follows the window width: at least the two largest stay heavy)
+            tickets = [capi.msm_begin(bases, sc, n, g2=g2) for _ in range(3)]
+            assert all(capi.msm_end(t) == want for t in tickets), c
+        finally:
+            capi.set_window_bits(0)
+
+
 def test_reference_g1_g2_tests_through_the_c_abi():
     """bn128/g1_test.go:14-31 and g2_test.go:12-25 through the mirror gosnark_amd.bn128 (MulScalar / Add as MSM calls):
     g*33 + g*44 == g*77, and the affine KAT of 77*G1 the reference pins."""

@@ -1,0 +1,9 @@
+set -x
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+bash tools/gpu_run.sh r4p tests
+bash tools/gpu_run.sh r4p ab preheavy : --instance realistic --steps 10 --warmup 3 --reps 5
+bash tools/gpu_run.sh r4p ab preheavy : --instance realistic --pipeline 1 --steps 10 --warmup 3 --reps 3
+bash tools/gpu_run.sh r4p ab preheavy : --instance realistic --workload prove_witness --steps 10 --warmup 3 --reps 3
+bash tools/gpu_run.sh r4p ab preheavy : --steps 10 --warmup 3 --reps 3
+bash tools/gpu_run.sh r4p trace realistic --instance realistic --steps 6 --warmup 2 --reps 1 --cpu-log2n 0 --no-extras --no-check
