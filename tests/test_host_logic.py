@@ -161,3 +161,13 @@ def test_environment_knobs_are_validated_or_compiled_out(tmp_path):
         out = subprocess.run([str(exe)], input="\n".join(lines) + "\n", capture_output=True, text=True, check=True,
                              env=dict(os.environ, **env)).stdout.split()
         assert out == want, (flags, env, out)
+
+
+def test_heavy_bucket_slices_partition_every_span():
+    """msm_kernels.h heavy_slice, compiled for the host (tests/host/heavy_slice_test.hip): the 16 slices of a heavy bucket are
+    consecutive, disjoint and cover its chunks exactly once for every span from kHeavySpan + 2 chunks up."""
+    import subprocess
+    import hostbuild
+    exe = hostbuild.build("heavy_slice_test")
+    out = subprocess.run([exe], capture_output=True, text=True, check=True).stdout
+    assert out.startswith("OK"), out
