@@ -599,7 +599,7 @@ def strong_one_process(args, ndev, inst, r_, s_, guard):
     guard.disarm()
     return strong
 
-def strong_ranks(args, world, rank, share, inst, pk_full, r_, s_, guard):
+def strong_ranks(args, world, rank, share, inst, pk_full, r_, s_, guard, cpu_collectives=None):
     """BASELINE configs[3] with one process per GPU (strong scaling; every rank holds the same instance): ONE 2^log2n proof through
     gs_groth16_prove_sharded (every rank computes H(x)) and through the values route (owner = proof index mod N runs
     gs_groth16_witness_values, gs_scalars_scatter = one ncclSend/ncclRecv group, gs_groth16_prove_sharded_values), and ONE 2^22-term G1
@@ -608,7 +608,7 @@ def strong_ranks(args, world, rank, share, inst, pk_full, r_, s_, guard):
     torch.distributed twins of the exchanges instead (RCCL refuses two ranks on one device).  Every rank runs this; rank 0 reports."""
     from gosnark_amd import parallel, r1csqap
     n, K = inst.n, max(3, min(args.steps, 5))
-    tdev = "cpu" if share else "cuda"
+    tdev = "cpu" if (share if cpu_collectives is None else cpu_collectives) else "cuda"
     strong = {"mode": "one process per GPU, %d ranks" % world, "steps": K}
     if guard.line is not None:
         guard.line["strong"] = strong
@@ -926,15 +926,27 @@ def main():
     # development aid for 1-GPU boxes: GS_BENCH_SHARE_GPU=1 maps every rank to device 0 and uses gloo, so the multi-process
     # code path (barriers, max-over-ranks timing, the partial-point gather) can be exercised without a second GPU
     share = os.environ.get("GS_BENCH_SHARE_GPU") == "1"
+    launch_notes = []
+    if not share and world > torch.cuda.device_count():
+        # more ranks than visible GPUs: the ranks share what there is (RCCL refuses two ranks on one device -> gloo for the barriers)
+        share = True
+        launch_notes.append("%d ranks on %d visible GPU(s): ranks share devices, gloo collectives" % (world, torch.cuda.device_count()))
     if share:
-        local = 0
+        local = local % max(torch.cuda.device_count(), 1) if os.environ.get("GS_BENCH_SHARE_GPU") != "1" else 0
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if share:
+        cpu_collectives = share
+        if not share:
+            try:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            except Exception as e:      # noqa: BLE001 -- torch's RCCL group only carries barriers and two-word reductions: gloo does that too
+                launch_notes.append("torch.distributed nccl group failed (%s): gloo instead" % str(e)[:120])
+                cpu_collectives = True
+        if cpu_collectives:
             dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if world == 1:
+        cpu_collectives = False
     guard = LineGuard(rank)
     logical = args.logical_shards if (args.logical_shards > 1 and world == 1 and args.workload in ("prove_sharded", "msm_sharded")) else 0
     capi.init([local] * logical if logical else local)
@@ -1103,7 +1115,7 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share else "cuda")
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if cpu_collectives else "cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         rep_elapsed.append(elapsed)
@@ -1117,7 +1129,7 @@ def main():
         p_last = step()
         good = groth16.VerifyProof(inst.vk, p_last, [x_pub]) and not groth16.VerifyProof(inst.vk, p_last, [(x_pub + 1) % R])
         if world > 1:
-            t = torch.tensor([1.0 if good else 0.0], dtype=torch.float64, device="cpu" if share else "cuda")
+            t = torch.tensor([1.0 if good else 0.0], dtype=torch.float64, device="cpu" if cpu_collectives else "cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
             good = bool(t.item() == 1.0)
         if not good:
@@ -1128,7 +1140,7 @@ def main():
         p_last = step()
         good = _snark.VerifyProof(inst.vk, p_last, inst.public) and not _snark.VerifyProof(inst.vk, p_last, [(inst.public[0] + 1) % R])
         if world > 1:
-            t = torch.tensor([1.0 if good else 0.0], dtype=torch.float64, device="cpu" if share else "cuda")
+            t = torch.tensor([1.0 if good else 0.0], dtype=torch.float64, device="cpu" if cpu_collectives else "cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
             good = bool(t.item() == 1.0)
         if not good:
@@ -1319,14 +1331,14 @@ def main():
                 out["cpu_baseline_reference_wasm"] = cpu_baseline_reference_wasm()
     if world > 1 and plain_prove and args.instance == "setup" and not args.no_strong:
         guard.line = out if rank == 0 else None
-        strong = strong_ranks(args, world, rank, share, inst, pk, r_, s_, guard)
+        strong = strong_ranks(args, world, rank, share, inst, pk, r_, s_, guard, cpu_collectives)
         if rank == 0:
             out["strong"] = strong
             out["rccl"] = rccl_report("rank: ncclCommInitRank, one process per GPU (gs_comm_init_rank)", strong.get("communicator_error"))
             out["rccl"]["torch_process_group_backend"] = dist.get_backend()
     if rank == 0:
         if world > 1:
-            out["launch"] = "torch.distributed.run, one rank per GPU (WORLD_SIZE=%d)" % world
+            out["launch"] = "torch.distributed.run, one rank per GPU (WORLD_SIZE=%d)" % world + ("; " + "; ".join(launch_notes) if launch_notes else "")
             out["devices"] = device_report([0] * world if share else list(range(world)))
         import ctypes
         ctypes.CDLL(None).fflush(None)       # anything native libraries left in C stdio (RCCL's version banner) goes out BEFORE the line
