@@ -238,8 +238,6 @@ static void ctx_create(Ctx& c, int logical, int device) {
   c.device = device;
   GS_HIP(hipSetDevice(device));
   GS_HIP(hipStreamCreateWithFlags(&c.main_stream, hipStreamNonBlocking));
-  c.acc2 = c.main_stream;
-  if (dev_knob("GS_ACC_STREAMS", 1, 1, 2) == 2) GS_HIP(hipStreamCreateWithFlags(&c.acc2, hipStreamNonBlocking));
   // The aux streams carry the latency-/bandwidth-bound shadow work of a proof (NTT passes, plan kernels, bucket
   // combine / reduction tails) next to the ALU-bound accumulations on the main stream.  They get the HIGHEST queue
   // priority: their kernels are short but hard to place (k_hist wants 128 KiB of LDS and 16 wave slots of one CU),
@@ -282,8 +280,6 @@ static void ctx_destroy(Ctx& c) {
     if (a && a != c.main_stream) (void)hipStreamDestroy(a);
     a = nullptr;
   }
-  if (c.acc2 && c.acc2 != c.main_stream) (void)hipStreamDestroy(c.acc2);
-  c.acc2 = nullptr;
   if (c.main_stream) (void)hipStreamDestroy(c.main_stream);
   c.main_stream = nullptr;
   c.stream = nullptr;

@@ -390,16 +390,8 @@ template <> struct AccTuning<FqTag> { static constexpr int kMinWaves = GS_G1_WAV
 #endif
 template <> struct AccTuning<Fq2Tag> { static constexpr int kMinWaves = GS_G2_WAVES; static constexpr bool kRegisterPrefetch = GS_G2_PREFETCH != 0; static constexpr bool kTouch = GS_G2_TOUCH != 0; };
 
-// (GS_ACC_MAXWAVES_G1 / _G2: experiment -- cap the waves per SIMD of the accumulation kernels, as the tail kernels' kAlone does)
-#ifndef GS_ACC_MAXWAVES_G1
-#define GS_ACC_MAXWAVES_G1 8
-#endif
-#ifndef GS_ACC_MAXWAVES_G2
-#define GS_ACC_MAXWAVES_G2 8
-#endif
-template <class T> constexpr int acc_max_waves() { return T::kWords == 8 ? GS_ACC_MAXWAVES_G1 : GS_ACC_MAXWAVES_G2; }
 template <class T>
-__global__ void __attribute__((amdgpu_flat_work_group_size(1, 256), amdgpu_waves_per_eu(acc_max_waves<T>() < AccTuning<T>::kMinWaves ? acc_max_waves<T>() : AccTuning<T>::kMinWaves, acc_max_waves<T>()))) k_bucket_accumulate(AccJobs jobs, const uint32_t* __restrict__ offsets,
+__global__ void __launch_bounds__(256, AccTuning<T>::kMinWaves) k_bucket_accumulate(AccJobs jobs, const uint32_t* __restrict__ offsets,
                                                             const uint32_t* __restrict__ entries,
                                                             const uint32_t* __restrict__ chunk_bucket, uint32_t nbuckets, uint32_t chunk) {
   constexpr int pw = PointIO<T>::kXyzzWords;

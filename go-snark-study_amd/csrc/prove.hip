@@ -200,9 +200,8 @@ int groth16_enqueue(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, const S
   }
   // Host order: the accumulations over w are enqueued BEFORE the block that may copy px from pageable host memory -- that copy
   // stages through the runtime inside the call (~5 ms for 64 MiB), and the device must already have its 7 ms of work by then.
-  hipStream_t used_acc[3] = {nullptr, nullptr, nullptr};
   {                                                              // main: the accumulations over w, back to back
-    StreamScope sc(c, used_acc[0] = c.acc_stream());
+    StreamScope sc(c, c.main_stream);
     GS_HIP(hipStreamWaitEvent(c.stream, st.planw, 0));
     // BACDelta's first npublic+1 entries are forced to infinity at key creation, so the reference's
     // loop from NPublic+1 (:248-250) equals a full-range MSM sharing w's plan.
@@ -211,10 +210,6 @@ int groth16_enqueue(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, const S
     if (pipelined) c.next_tails(plan_w.n);
     msm_enqueue_g2(c, plan_w, {MsmBase{&pk->t_bacgamma2, wbase}}, ws + 4, pin + 1, st.pend_g2w, c.tail_stream(0));
     GS_HIP(hipEventRecord(st.done_g2, c.tail_stream(0)));
-  }
-  {
-    StreamScope sc(c, used_acc[1] = c.acc_stream());
-    if (c.stream != used_acc[0]) GS_HIP(hipStreamWaitEvent(c.stream, st.planw, 0));
     msm_enqueue_g1(c, plan_w, {MsmBase{&pk->t_at, wbase}, MsmBase{&pk->t_bacgamma1, wbase}, MsmBase{&pk->t_bacdelta, wbase}}, ws + 0, pin + 0,
                    st.pend_g1w, c.tail_stream(1));
     GS_HIP(hipEventRecord(st.done_g1w, c.tail_stream(1)));
@@ -250,22 +245,13 @@ int groth16_enqueue(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, const S
     GS_HIP(hipEventRecord(st.planh, c.stream));
   }
   {                                                              // main again: the accumulation over h
-    StreamScope sc(c, used_acc[2] = c.acc_stream());
+    StreamScope sc(c, c.main_stream);
     GS_HIP(hipStreamWaitEvent(c.stream, st.planh, 0));
     // a lone proof finishes soonest with the last tail right behind its accumulation; in a pipeline that tail must not sit
     // in front of the next proof's accumulations
     msm_enqueue_g1(c, plan_h, {MsmBase{eval ? &pk->t_ptd_eval : &pk->t_ptd, hbase}}, ws + 3, pin + 2, st.pend_h, pipelined ? c.tail_stream(1) : nullptr);   // :269-271
-    GS_HIP(hipEventRecord(st.done_h, pipelined ? c.tail_stream(1) : c.stream));
+    GS_HIP(hipEventRecord(st.done_h, pipelined ? c.tail_stream(1) : c.main_stream));
   }
-  for (hipStream_t a : used_acc)                                 // (two accumulation streams: the main stream's end mark covers both)
-    if (a && a != c.main_stream) {
-      hipEvent_t ev;
-      GS_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-      GS_HIP(hipEventRecord(ev, a));
-      GS_HIP(hipStreamWaitEvent(c.main_stream, ev, 0));
-      GS_HIP(hipEventDestroy(ev));
-      break;
-    }
   st.total->stop();
   GS_HIP(hipEventRecord(st.done_main, c.main_stream));
   return GS_OK;

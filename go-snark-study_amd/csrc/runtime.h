@@ -135,11 +135,6 @@ struct Ctx {
   bool ready = false;
   hipStream_t stream = nullptr;   // the stream every engine function enqueues on (switched by StreamScope)
   hipStream_t main_stream = nullptr;
-  // Development experiment (GS_ACC_STREAMS=2, dev builds): consecutive accumulation launches alternate between two streams, so the
-  // next launch may start while the previous one drains.  Product builds: acc2 == main_stream, i.e. one stream, back to back.
-  hipStream_t acc2 = nullptr;
-  unsigned acc_flip = 0;
-  hipStream_t acc_stream() { return (acc2 && acc2 != main_stream && (acc_flip++ & 1u)) ? acc2 : main_stream; }
   // 0 / 2: reduction tails, 1: plans and H(x).  (A fourth stream for plan(w) was tried and LOST 5 %: beyond four streams two of
   // them share a hardware queue, and the sort of the next proof then queues behind a reduction tail.)
   static constexpr int kAuxStreams = 3;
@@ -215,7 +210,6 @@ struct Ctx {
   // wait for everything enqueued on this context (outstanding tickets keep their results in their pinned slots)
   void drain() {
     if (main_stream) GS_HIP(hipStreamSynchronize(main_stream));
-    if (acc2 && acc2 != main_stream) GS_HIP(hipStreamSynchronize(acc2));
     for (auto a : aux_stream) if (a && a != main_stream) GS_HIP(hipStreamSynchronize(a));
   }
 };
