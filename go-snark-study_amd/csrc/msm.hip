@@ -88,7 +88,10 @@ void build_plan(Ctx& c, int slot, const uint32_t* scalars_dev, uint32_t n, MsmPl
   // slices: enough (window, slice, range) workgroups to cover the 256 CUs, never less than 16384 scalars per slice, and a
   // histogram matrix hist[W * S][B] of at most 64 MiB
   {
-    const uint32_t want = (256u + plan.W * pp.R - 1) / (plan.W * pp.R);
+    // (round 4: FLOOR, not ceiling -- a histogram / scatter workgroup holds 128 KiB of LDS, so exactly one fits a CU, and at c = 17
+    //  the ceiling gave 15 windows x 2 ranges x 9 slices = 270 workgroups for 256 CUs: fourteen stragglers ran a second round of the
+    //  whole kernel, k_scatter 0.26 ms instead of ~0.15; 8 slices = 240 workgroups finish in one)
+    const uint32_t want = std::max<uint32_t>(1u, 256u / (plan.W * pp.R));
     const uint32_t by_size = std::max<uint32_t>(1u, (n + 16383u) / 16384u);
     const uint32_t by_mem = std::max<uint32_t>(1u, (uint32_t)((64ull << 20) / ((uint64_t)plan.B * plan.W * 4)));
     pp.S = std::max<uint32_t>(1u, std::min(std::min<uint32_t>(16u, std::max<uint32_t>(want, 1u)), std::min(by_size, by_mem)));
