@@ -61,6 +61,8 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E, /opt/skills/guides/MI355X_MICROAR
 MAD_PEAK_T = 31.5              # T lane-mad/s, v_mad_u64_u32, measured: tools/ubench_valu.hip -> profiles/r01_ubench_valu.txt
 G1_TERM_BYTES = 96             # 32 B scalar + 64 B affine base per G1 MSM term
 MADS_PER_MIXED_ADD = 1467      # 6 products (162 mads) + 2 squarings (126) + one two-term product (243)
+VALU_PER_MIXED_ADD = 2090      # SQ_INSTS_VALU per G1 mixed addition (profiles/r03_/r04_pmc_sq_accumulate_prove.txt)
+ISSUE_PEAK_G = 1024 * 2.4 / 4  # G wave-instructions/s: 256 CUs x 4 SIMDs, one wave64 VALU instruction per 4 cycles, nominal 2.4 GHz
 R = groth16.R
 
 
@@ -1259,6 +1261,14 @@ def main():
                                     "unit": "T lane-mad/s", "frac": mads / MAD_PEAK_T,
                                     "note": "mixed additions per launch (gs_timing.acc_g1_adds: the non-zero digits the plan counted) x 1467 v_mad_u64_u32; window width "
                                             "c = %d -> at most %d additions per term; peak from tools/ubench_valu.hip (profiles/r01_ubench_valu.txt)" % (cbits, 254 // max(cbits, 1) + 1)}
+            # ... and the limit under that one: a 64-wide wave occupies its 16-lane SIMD for 4 cycles per VALU instruction, whatever the
+            # instruction; the G1 mixed addition is 2090 of them (SQ_INSTS_VALU, profiles/r04_pmc_sq_accumulate_prove.txt)
+            wave_instr = tm_acc["acc_g1_adds"] / launches / 64.0 * VALU_PER_MIXED_ADD / avg_launch_s if avg_launch_s > 0 else 0.0
+            out["roofline_issue"] = {"bound": "valu-issue", "kernel": "k_bucket_accumulate<G1>", "achieved": wave_instr / 1e9, "peak": ISSUE_PEAK_G,
+                                     "unit": "G wave-instructions/s", "frac": wave_instr / 1e9 / ISSUE_PEAK_G,
+                                     "note": "2090 VALU instructions per mixed addition x additions / 64 lanes; peak = 1024 SIMDs x 2.4 GHz nominal / 4 cycles per wave64 "
+                                             "instruction.  The chip sustains ~1.85 GHz under this load (GRBM_GUI_ACTIVE / kernel time), i.e. ~0.9 of what its "
+                                             "actual clock can issue: the kernel is instruction-issue bound, and only fewer instructions make it faster"}
             out["roofline_whole_step"] = {"bound": "hbm", "algorithmic_bytes_per_step": step_bytes,
                                           "achieved": step_bytes / (elapsed / args.steps) / 1e9,
                                           "peak": HBM_PEAK_GBS, "unit": "GB/s",
