@@ -508,3 +508,15 @@ def test_hostile_environment_cannot_change_a_result():
         assert out.returncode == 0, out.stderr[-2000:]
         return json.loads(out.stdout.strip().splitlines()[-1])
     assert run(hostile) == run({})
+
+
+def test_randomised_degenerate_sums_equal_their_closed_form():
+    """tools/stress_msm_random.py for a few seconds (hundreds of random cases): duplicate bases, negated pairs, points at infinity, zeros /
+    ones / repeated values among the scalars, G1 and G2, two window widths each, blocking and pipelined -- partial sums that coincide
+    or cancel in the tail kernels' memory-operand addition.  Expected values are (sum_i +-k_i b_i) * G, complete by construction (the
+    naive reference loop is not: its Add has no P == Q branch)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_msm_random.py"), "8", "7"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "all equal the closed form" in out.stdout, (out.stdout[-500:], out.stderr[-1500:])
