@@ -41,6 +41,25 @@
 
 namespace gs {
 
+// Issue priority of a kernel's waves (s_setprio, 0 = default .. 3): the arbiter of a SIMD prefers the higher-priority wave whenever
+// both have an instruction ready.  The accumulation kernels keep every SIMD's multiplier busy; a latency-bound kernel
+// that shares the SIMD (plan, NTT pass) issues little but, at equal priority, waits behind the accumulation wave for every slot --
+// k_digits 0.025 ms alone, 0.46 ms beside an accumulation (profiles/r04_timeline_msm_g1_steady.txt).  Measured: profiles/r04_ab_wave_priority.txt.
+#ifndef GS_PRIO_PLAN
+#define GS_PRIO_PLAN 0
+#endif
+#ifndef GS_PRIO_POLY
+#define GS_PRIO_POLY 0
+#endif
+#ifndef GS_PRIO_TAIL
+#define GS_PRIO_TAIL 0
+#endif
+template <int P> __device__ __forceinline__ void wave_priority() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (P > 0) __builtin_amdgcn_s_setprio(P);
+#endif
+}
+
 constexpr int NL = 9;
 constexpr int LB = 29;
 constexpr uint32_t LMASK = (1u << LB) - 1u;

@@ -59,6 +59,7 @@ GS_HD int32_t next_digit(const uint32_t (&k)[8], const PlanParams& pp, int w, ui
 // ---- plan, step 1: scalars -> digit matrix digits[w][i] = d + B - 1, read once, coalesced ------------------------
 using digit_t = uint32_t;
 __global__ void __launch_bounds__(256) k_digits(const uint32_t* __restrict__ scalars, PlanParams pp, digit_t* __restrict__ digits) {
+  wave_priority<GS_PRIO_PLAN>();
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= pp.n) return;
   uint32_t k[8];
@@ -79,6 +80,7 @@ __global__ void __launch_bounds__(256) k_digits(const uint32_t* __restrict__ sca
 constexpr int kSortBlock = 1024;      // upper bound; the launch picks 256 .. 1024 threads (msm.hip: sort_block)
 
 __global__ void __launch_bounds__(kSortBlock) k_hist(const digit_t* __restrict__ digits, PlanParams pp, uint32_t* __restrict__ hist) {
+  wave_priority<GS_PRIO_PLAN>();
   extern __shared__ uint32_t sh[];
   const uint32_t w = blockIdx.x, s = blockIdx.y, r = blockIdx.z;
   const uint32_t nb = min(pp.B, kRangeBuckets), base = r << kRangeLog;
@@ -103,6 +105,7 @@ __global__ void __launch_bounds__(kSortBlock) k_hist(const digit_t* __restrict__
 // (All windows share one bucket set -- see the window tables below -- so a bucket's entries are the
 // concatenation of its (window, slice) runs.)
 __global__ void __launch_bounds__(256) k_colscan(uint32_t* __restrict__ hist, PlanParams pp, uint32_t* __restrict__ totals) {
+  wave_priority<GS_PRIO_PLAN>();
   const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= pp.B) return;
   uint32_t* col = hist + b;
@@ -116,6 +119,7 @@ __global__ void __launch_bounds__(256) k_colscan(uint32_t* __restrict__ hist, Pl
 // entry = sign (bit 31) | window (bits 30..26) | term index (bits 25..0)
 __global__ void __launch_bounds__(kSortBlock) k_scatter(const digit_t* __restrict__ digits, PlanParams pp, const uint32_t* __restrict__ hist,
                                                          const uint32_t* __restrict__ offsets, uint32_t* __restrict__ entries) {
+  wave_priority<GS_PRIO_PLAN>();
   extern __shared__ uint32_t sh[];
   const uint32_t w = blockIdx.x, s = blockIdx.y, r = blockIdx.z;
   const uint32_t nb = min(pp.B, kRangeBuckets), base = r << kRangeLog;
@@ -155,6 +159,7 @@ GS_HD void load_scalar_canon(const uint32_t* __restrict__ scalars, uint32_t i, u
 }
 
 __global__ void __launch_bounds__(kPartBlock) k_part_count(const uint32_t* __restrict__ scalars, PlanParams pp, uint32_t* __restrict__ part_count) {
+  wave_priority<GS_PRIO_PLAN>();
   __shared__ uint32_t cnt[kMaxParts];
   const uint32_t nparts = (uint32_t)pp.W * pp.R;
   for (uint32_t t = threadIdx.x; t < nparts; t += kPartBlock) cnt[t] = 0;
@@ -176,6 +181,7 @@ __global__ void __launch_bounds__(kPartBlock) k_part_count(const uint32_t* __res
 // part_base[0 .. nparts] = exclusive prefix of the partition sizes; cursors start at zero
 __global__ void __launch_bounds__(64) k_part_scan(uint32_t* __restrict__ part_count, uint32_t nparts, uint32_t* __restrict__ part_base,
                                                     uint32_t* __restrict__ part_cursor) {
+  wave_priority<GS_PRIO_PLAN>();
   if (blockIdx.x != 0 || threadIdx.x != 0) return;
   uint32_t run = 0;
   for (uint32_t t = 0; t < nparts; ++t) { part_base[t] = run; run += part_count[t]; part_cursor[t] = 0; part_count[t] = 0; }
@@ -184,6 +190,7 @@ __global__ void __launch_bounds__(64) k_part_scan(uint32_t* __restrict__ part_co
 
 __global__ void __launch_bounds__(kPartBlock) k_part_scatter(const uint32_t* __restrict__ scalars, PlanParams pp, const uint32_t* __restrict__ part_base,
                                                               uint32_t* __restrict__ part_cursor, uint2* __restrict__ recs) {
+  wave_priority<GS_PRIO_PLAN>();
   __shared__ uint32_t cnt[kMaxParts];      // this workgroup's records per partition, then its write cursor in each
   const uint32_t nparts = (uint32_t)pp.W * pp.R;
   for (uint32_t t = threadIdx.x; t < nparts; t += kPartBlock) cnt[t] = 0;
@@ -244,6 +251,7 @@ GS_HD void part_slice(const uint32_t* __restrict__ part_base, const PlanParams& 
 
 __global__ void __launch_bounds__(kSortBlock) k_hist_part(const uint2* __restrict__ recs, const uint32_t* __restrict__ part_base, PlanParams pp,
                                                            uint32_t* __restrict__ hist) {
+  wave_priority<GS_PRIO_PLAN>();
   extern __shared__ uint32_t sh[];
   uint32_t w, r, s;
   if (!part_of_block(blockIdx.x, pp, w, r, s)) return;
@@ -261,6 +269,7 @@ __global__ void __launch_bounds__(kSortBlock) k_hist_part(const uint2* __restric
 __global__ void __launch_bounds__(kSortBlock) k_scatter_part(const uint2* __restrict__ recs, const uint32_t* __restrict__ part_base, PlanParams pp,
                                                               const uint32_t* __restrict__ hist, const uint32_t* __restrict__ offsets,
                                                               uint32_t* __restrict__ entries) {
+  wave_priority<GS_PRIO_PLAN>();
   extern __shared__ uint32_t sh[];
   uint32_t w, r, s;
   if (!part_of_block(blockIdx.x, pp, w, r, s)) return;
@@ -283,6 +292,7 @@ constexpr int kScanTile = kScanBlock * kScanPerThread;
 
 __global__ void __launch_bounds__(kScanBlock) k_scan_tiles(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
                                                             uint32_t* __restrict__ tile_sums, uint32_t n) {
+  wave_priority<GS_PRIO_PLAN>();
   __shared__ uint32_t sh[kScanBlock];
   const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * kScanPerThread;
   uint32_t v[kScanPerThread], sum = 0;
@@ -303,6 +313,7 @@ __global__ void __launch_bounds__(kScanBlock) k_scan_tiles(const uint32_t* __res
 }
 
 __global__ void __launch_bounds__(1024) k_scan_tile_sums(uint32_t* __restrict__ tile_sums, uint32_t ntiles, uint32_t* __restrict__ total) {
+  wave_priority<GS_PRIO_PLAN>();
   // single block: sequential-per-thread chunks + block scan; ntiles <= 1024 * 64
   __shared__ uint32_t sh[1024];
   const uint32_t per = (ntiles + 1023u) / 1024u;
@@ -323,6 +334,7 @@ __global__ void __launch_bounds__(1024) k_scan_tile_sums(uint32_t* __restrict__ 
 }
 
 __global__ void __launch_bounds__(kScanBlock) k_scan_add(uint32_t* __restrict__ out, const uint32_t* __restrict__ tile_sums, uint32_t n) {
+  wave_priority<GS_PRIO_PLAN>();
   const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * kScanPerThread;
   const uint32_t add = tile_sums[blockIdx.x];
 #pragma unroll
@@ -343,6 +355,7 @@ constexpr uint32_t kHeavySpan = 64;
 __global__ void __launch_bounds__(256) k_chunk_map(const uint32_t* __restrict__ offsets, uint32_t nbuckets, uint32_t chunk,
                                                     uint32_t* __restrict__ chunk_bucket, uint32_t* __restrict__ heavy_list,
                                                     uint32_t* __restrict__ heavy_count) {
+  wave_priority<GS_PRIO_PLAN>();
   const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= nbuckets) return;
   const uint32_t o0 = offsets[b], o1 = offsets[b + 1];
@@ -508,6 +521,7 @@ template <class T, bool kAlone>
 GS_TAIL_KERNEL(kHeavyBlock, kAlone) k_heavy_combine(AccJobs jobs, const uint32_t* __restrict__ offsets,
                                                                 const uint32_t* __restrict__ heavy_list,
                                                                 const uint32_t* __restrict__ heavy_count, uint32_t chunk) {
+  wave_priority<GS_PRIO_TAIL>();
   constexpr int pw = PointIO<T>::kXyzzWords;
   __shared__ uint32_t sh[kHeavyBlock * pw];
   const AccJob job = jobs.j[blockIdx.y];
@@ -537,6 +551,7 @@ GS_TAIL_KERNEL(kHeavyBlock, kAlone) k_heavy_combine(AccJobs jobs, const uint32_t
 template <class T, bool kAlone>
 GS_TAIL_KERNEL(kHeavyBlock, kAlone) k_heavy_finish(AccJobs jobs, const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ heavy_list,
                                                    const uint32_t* __restrict__ heavy_count, uint32_t chunk) {
+  wave_priority<GS_PRIO_TAIL>();
   constexpr int pw = PointIO<T>::kXyzzWords;
   constexpr uint32_t per = kHeavyBlock / kHeavySlices;
   __shared__ uint32_t sh[kHeavyBlock * pw];
@@ -575,6 +590,7 @@ GS_TAIL_KERNEL(kHeavyBlock, kAlone) k_heavy_finish(AccJobs jobs, const uint32_t*
 template <class T, bool kAlone>
 GS_TAIL_KERNEL(256, kAlone) k_bucket_combine(AccJobs jobs, const uint32_t* __restrict__ offsets, uint32_t B, uint32_t chunk,
                                                                      const uint32_t* __restrict__ heavy_count, uint32_t* __restrict__ stats) {
+  wave_priority<GS_PRIO_TAIL>();
   const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b == 0 && blockIdx.y == 0) { stats[0] = offsets[B]; stats[1] = *heavy_count; }
   if (b >= B) return;
@@ -592,6 +608,7 @@ GS_TAIL_KERNEL(256, kAlone) k_bucket_combine(AccJobs jobs, const uint32_t* __res
 constexpr int kReduceBlock = 256;
 template <class T, bool kAlone>
 GS_TAIL_KERNEL(kReduceBlock, kAlone) k_block_reduce(AccJobs jobs, uint32_t B, int L) {
+  wave_priority<GS_PRIO_TAIL>();
   constexpr int pw = PointIO<T>::kXyzzWords;
   __shared__ uint32_t sh[kReduceBlock * pw];
   const AccJob job = jobs.j[blockIdx.y];
@@ -649,6 +666,7 @@ GS_TAIL_KERNEL(kReduceBlock, kAlone) k_block_reduce(AccJobs jobs, uint32_t B, in
 // host receives ONE point per job however many buckets there were.
 template <class T, bool kAlone>
 GS_TAIL_KERNEL(kReduceBlock, kAlone) k_pair_reduce(AccJobs jobs, uint32_t nblk, int log2_span) {
+  wave_priority<GS_PRIO_TAIL>();
   constexpr int pw = PointIO<T>::kXyzzWords;
   __shared__ uint32_t sh[kReduceBlock * pw];
   const AccJob job = jobs.j[blockIdx.y];

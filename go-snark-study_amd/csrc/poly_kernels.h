@@ -197,6 +197,7 @@ GS_HD void ntt_dit_butterfly(int step, int nsteps, Bfly (&x)[N], const Fe<ModR, 
 
 template <bool kInverse>
 __global__ void __launch_bounds__(256) k_ntt_pass(uint32_t* __restrict__ x, const uint32_t* __restrict__ tw, int tw_logn, int s_lo, int k, int clog) {
+  wave_priority<GS_PRIO_POLY>();
   __shared__ uint32_t sh[NL * kNttTile];
   const uint32_t R = 1u << k, C = 1u << clog, E = R << clog;
   const uint32_t tile = blockIdx.x;
@@ -286,12 +287,14 @@ __global__ void __launch_bounds__(256) k_ntt_pass(uint32_t* __restrict__ x, cons
 // out[i] = a[i] * b[i] (Montgomery product: a b / R)
 __global__ void __launch_bounds__(256) k_pw_mul(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b,
                                                  uint32_t* __restrict__ out, uint32_t n) {
+  wave_priority<GS_PRIO_POLY>();
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   store_fr(out + (size_t)i * 8, mul(load_fr(a + (size_t)i * 8), load_fr(b + (size_t)i * 8)));
 }
 // out[i] = a[i] * k
 __global__ void __launch_bounds__(256) k_pw_mul_const(const uint32_t* __restrict__ a, FrConst k, uint32_t* __restrict__ out, uint32_t n) {
+  wave_priority<GS_PRIO_POLY>();
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   store_fr(out + (size_t)i * 8, mul(load_fr(a + (size_t)i * 8), from_const(k)));
@@ -309,6 +312,7 @@ __global__ void __launch_bounds__(256) k_addsub(const uint32_t* __restrict__ a, 
 // dst[i] = src[first + count - 1 - i] for i < count, 0 for count <= i < total
 __global__ void __launch_bounds__(256) k_copy_reversed(const uint32_t* __restrict__ src, uint32_t first, uint32_t count,
                                                         uint32_t* __restrict__ dst, uint32_t total) {
+  wave_priority<GS_PRIO_POLY>();
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   uint4* d = reinterpret_cast<uint4*>(dst + (size_t)i * 8);
@@ -435,6 +439,7 @@ constexpr uint32_t kSpmvLongRow = 512, kSpmvLongCap = 4096;
 __global__ void __launch_bounds__(256) k_spmv(const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ col, const uint32_t* __restrict__ val,
                                                const uint32_t* __restrict__ x_mont, uint32_t nrows, uint32_t ncols, uint32_t* __restrict__ out,
                                                uint32_t* __restrict__ long_rows /* [0] = count, then up to kSpmvLongCap row indices */) {
+  wave_priority<GS_PRIO_POLY>();
   const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= nrows) return;
   const uint32_t lo = rowptr[r], hi = rowptr[r + 1];
@@ -455,6 +460,7 @@ __global__ void __launch_bounds__(256) k_spmv(const uint32_t* __restrict__ rowpt
 __global__ void __launch_bounds__(256) k_spmv_long(const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ col, const uint32_t* __restrict__ val,
                                                     const uint32_t* __restrict__ x_mont, uint32_t ncols, uint32_t* __restrict__ out,
                                                     const uint32_t* __restrict__ long_rows) {
+  wave_priority<GS_PRIO_POLY>();
   __shared__ uint32_t sh[NL * 256];
   const uint32_t count = min(long_rows[0], kSpmvLongCap);
   for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
@@ -612,6 +618,7 @@ __global__ void __launch_bounds__(256) k_hx_shift_table(const uint32_t* __restri
 // u[v*N + j] = vals[v*n + j] * w[j] for j < n, 0 up to N (three vectors at once); standard form in, standard out
 __global__ void __launch_bounds__(256) k_hx_weigh(const uint32_t* __restrict__ vals, const uint32_t* __restrict__ weights, uint32_t n, uint32_t N, uint32_t nvec,
                                                    uint32_t* __restrict__ u) {
+  wave_priority<GS_PRIO_POLY>();
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N * nvec) return;
   const uint32_t v = i / N, j = i - v * N;
@@ -620,6 +627,7 @@ __global__ void __launch_bounds__(256) k_hx_weigh(const uint32_t* __restrict__ v
 }
 // spectra times the cached kernel spectrum, for nvec vectors of N
 __global__ void __launch_bounds__(256) k_pw_mul_bcast(uint32_t* __restrict__ x, const uint32_t* __restrict__ spec, uint32_t N, uint32_t nvec) {
+  wave_priority<GS_PRIO_POLY>();
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N * nvec) return;
   store_fr(x + (size_t)i * 8, mul(load_fr(x + (size_t)i * 8), load_fr(spec + (size_t)(i % N) * 8)));
@@ -627,6 +635,7 @@ __global__ void __launch_bounds__(256) k_pw_mul_bcast(uint32_t* __restrict__ x, 
 // hv[k-1] = convA convB t1 - convC t2 at the nodes n + k (conv_X = x[X * N + n + k - 2], the middle of the cyclic convolutions)
 __global__ void __launch_bounds__(256) k_hx_values(const uint32_t* __restrict__ conv, const uint32_t* __restrict__ t1, const uint32_t* __restrict__ t2, uint32_t n,
                                                     uint32_t N, uint32_t* __restrict__ hv) {
+  wave_priority<GS_PRIO_POLY>();
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const size_t at = (size_t)(n - 1 + i);
@@ -637,6 +646,7 @@ __global__ void __launch_bounds__(256) k_hx_values(const uint32_t* __restrict__ 
 }
 // a_j b_j == c_j at every root j of Z (j = 1..dz)?  bad[0] counts the violations
 __global__ void __launch_bounds__(256) k_r1cs_check(const uint32_t* __restrict__ vals, uint32_t n, uint32_t dz, const FrConst r2, uint32_t* __restrict__ bad) {
+  wave_priority<GS_PRIO_POLY>();
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= dz || j >= n) return;
   const Fr2 ab = mul(mul(load_fr(vals + (size_t)j * 8), load_fr(vals + ((size_t)n + j) * 8)), from_const(r2));      // standard a b
@@ -644,6 +654,7 @@ __global__ void __launch_bounds__(256) k_r1cs_check(const uint32_t* __restrict__
 }
 // Taylor shift, step 1: p[i'] = g[n-1-i'] (n-1-i')! for i' < n, zero padded to N
 __global__ void __launch_bounds__(256) k_hx_shift_in(const uint32_t* __restrict__ g, const uint32_t* __restrict__ fact, uint32_t n, uint32_t N, uint32_t* __restrict__ p) {
+  wave_priority<GS_PRIO_POLY>();
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   if (i < n) store_fr(p + (size_t)i * 8, mul(load_fr(g + (size_t)(n - 1 - i) * 8), load_fr(fact + (size_t)(n - 1 - i) * 8)));
@@ -652,6 +663,7 @@ __global__ void __launch_bounds__(256) k_hx_shift_in(const uint32_t* __restrict_
 // step 2: h[j] = conv[n-1-j] / (j! N), canonical standard form
 __global__ void __launch_bounds__(256) k_hx_shift_out(const uint32_t* __restrict__ conv, const uint32_t* __restrict__ invfact, FrConst inv_N, uint32_t n, uint32_t nh,
                                                        uint32_t* __restrict__ h) {
+  wave_priority<GS_PRIO_POLY>();
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= nh) return;
   store_fr_canon(h + (size_t)j * 8, canon(mul(mul(load_fr(conv + (size_t)(n - 1 - j) * 8), load_fr(invfact + (size_t)j * 8)), from_const(inv_N))));
