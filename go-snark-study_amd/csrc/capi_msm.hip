@@ -143,22 +143,32 @@ int msm_begin(Ctx& c, Kind kind, gs_handle hb, size_t off, gs_handle hs, size_t 
   st->g2 = T::kWords == 16;
   st->keep = {c.share<Object>(hb, kind), c.share<Object>(hs, Kind::Scalars)};
   MsmPlan plan;
+  // GS_MSM_TICKET_STREAMS (scheduling only, same results): 0 = every ticket's plan on aux 1, tails alternating between aux 0 / aux 2;
+  // 1 = ticket slot p keeps its plan AND its tail on aux p, so the plans of consecutive tickets run beside each other instead of
+  // back to back (profiles/r04_timeline_msm_g1_steady.txt: the plan stream is the busy one of the MSM pipeline); 2 (default) = 1 above
+  // 3 * 2^20 terms.  Measured (profiles/r04_ab_msm_ticket_streams.txt): 2^22 terms 5.69-5.88 -> 5.29-5.39 ms per MSM, 2^21 and below
+  // unchanged within 2 % -- there the plans and tails cost the accumulation as much beside it as they would behind it.
+  static const long ticket_mode = run_knob("GS_MSM_TICKET_STREAMS", 2, 0, 2);
+  const bool ticket_streams = ticket_mode == 1 || (ticket_mode == 2 && n >= ((size_t)3 << 20));
+  hipStream_t plan_stream = ticket_streams ? c.aux_stream[parity % Ctx::kAuxStreams] : c.aux_stream[1];
   {
-    StreamScope ss(c, c.aux_stream[1]);
+    StreamScope ss(c, plan_stream);
     st->tplan = std::make_shared<PhaseTimer>(c.stream);
     build_plan(c, 2 * parity, sc->buf.as<uint32_t>() + soff * 8, (uint32_t)n, plan, {{1, st->g2}});
     st->tplan->stop();
     GS_HIP(hipEventRecord(st->planned, c.stream));
   }
+  hipStream_t tail = nullptr;
   {
     StreamScope ss(c, c.main_stream);
     GS_HIP(hipStreamWaitEvent(c.stream, st->planned, 0));
     std::vector<MsmBase> bases{MsmBase{tab, off}};
-    c.next_tails((uint32_t)n);                               // consecutive small MSMs reduce on alternating tail streams
-    if constexpr (T::kWords == 8) msm_enqueue_g1(c, plan, bases, 8 * parity, 3 * parity, st->pend, c.tail_stream(0));
-    else msm_enqueue_g2(c, plan, bases, 8 * parity + 4, 3 * parity, st->pend, c.tail_stream(0));
+    if (!ticket_streams) c.next_tails((uint32_t)n);          // consecutive small MSMs reduce on alternating tail streams
+    tail = ticket_streams ? plan_stream : c.tail_stream(0);
+    if constexpr (T::kWords == 8) msm_enqueue_g1(c, plan, bases, 8 * parity, 3 * parity, st->pend, tail);
+    else msm_enqueue_g2(c, plan, bases, 8 * parity + 4, 3 * parity, st->pend, tail);
   }
-  GS_HIP(hipEventRecord(st->done, c.tail_stream(0)));
+  GS_HIP(hipEventRecord(st->done, tail));
   st->ticket = c.new_ticket();
   *ticket = st->ticket;
   c.inflight[parity] = std::move(st);

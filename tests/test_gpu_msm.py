@@ -500,7 +500,7 @@ def test_hostile_environment_cannot_change_a_result():
         "p = groth16.prove_end(groth16.prove_begin(inst.device_pk(), inst.w, inst.px, r, s))\n"
         "print(json.dumps([capi.msm(b1, k1), capi.msm(b2, k2, g2=True), [p.PiA, p.PiB, p.PiC]]))\n" % (root, os.path.join(root, "tests")))
     hostile = {"GS_REDUCE_L": "3", "GS_CHUNK": "7", "GS_FOLD_MAX": "-5", "GS_AUTO_MAX_C": "99", "GS_SORT_BLOCK": "1", "GS_PART_MIN_R": "0",
-               "GS_WINDOW_COST_BUCKET": "nan", "GS_TABLE_PER_ROW": "x", "GS_TAIL_FLIP": "77", "GS_TAIL_PRIORITY": "9", "GS_CHUNK_H": "5", "GS_TAIL_ALONE_LOG2": "99", "GS_COPY_THREADS": "-3", "GS_PLANW_STREAM": "7",
+               "GS_WINDOW_COST_BUCKET": "nan", "GS_TABLE_PER_ROW": "x", "GS_TAIL_FLIP": "77", "GS_TAIL_PRIORITY": "9", "GS_CHUNK_H": "5", "GS_TAIL_ALONE_LOG2": "99", "GS_COPY_THREADS": "-3", "GS_PLANW_STREAM": "7", "GS_MSM_TICKET_STREAMS": "5",
                "GS_NO_PRIORITY": "1"}
 
     def run(env):
