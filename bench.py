@@ -11,10 +11,13 @@ before the timed region.  The timed region (K steps between barrier + synchroniz
 times; `ms_per_step` / `value` are the MEDIAN repetition, every repetition is listed.
 
 N > 1 starts however it is invoked:
-  * under torch.distributed.run (WORLD_SIZE = N in the environment): one rank per GPU, RCCL between processes;
+  * under torch.distributed.run (WORLD_SIZE = N in the environment): one rank per GPU; the control plane (barriers, the max over
+    ranks, the communicator's unique id) runs on gloo, RCCL carries the data plane (the strong section's in-library communicator,
+    ncclCommInitRank + ncclAllGather + ncclSend/ncclRecv, and a torch nccl-group all_reduce probe) AFTER the weak-scaling line is parked
+    in the watchdog, so no RCCL problem of a first multi-GPU run can take the line with it;
   * plainly -- `python bench.py --gpus N` -- ONE process drives the N devices through the library's own multi-device
     entry points (gs_init(devs, N), gs_groth16_prove_batch, gs_groth16_prove_multi[_values], gs_msm_g1_multi; the
-    records travel through the communicator of gs_comm_init_local = ncclCommInitAll).  With fewer than N GPUs visible
+    records travel through the communicator of gs_comm_init_local = ncclCommInitAll, created after the weak-scaling line is parked).  With fewer than N GPUs visible
     the N devices are logical devices spread over the visible ones (and the line says so); `--multi ranks` re-executes
     the same command line under torch.distributed.run instead.
 Either way `value` is the WEAK-scaling figure: every GPU proves independent instances of the same circuit with its own
@@ -940,15 +943,13 @@ def main():
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        cpu_collectives = share
-        if not share:
-            try:
-                dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-            except Exception as e:      # noqa: BLE001 -- torch's RCCL group only carries barriers and two-word reductions: gloo does that too
-                launch_notes.append("torch.distributed nccl group failed (%s): gloo instead" % str(e)[:120])
-                cpu_collectives = True
-        if cpu_collectives:
-            dist.init_process_group("gloo")
+        # Control plane (barriers, max-over-ranks of a few words, the communicator's unique id) on gloo, ALWAYS: the weak-scaling
+        # workload has no data-path collective, so nothing before its line is parked in the watchdog may depend on a library that has
+        # never met these GPUs.  RCCL carries the data plane -- the strong section's in-library communicator (ncclCommInitRank,
+        # ncclAllGather, ncclSend/ncclRecv) and a torch nccl-group probe -- each behind the watchdog, after the line exists.
+        cpu_collectives = True
+        dist.init_process_group("gloo")
+        launch_notes.append("control plane (barriers, max over ranks) on gloo; RCCL: the in-library communicator of the strong section and a torch nccl-group all_reduce probe")
     if world == 1:
         cpu_collectives = False
     guard = LineGuard(rank)
@@ -1343,11 +1344,24 @@ def main():
                 out["cpu_baseline_reference_wasm"] = cpu_baseline_reference_wasm()
     if world > 1 and plain_prove and args.instance == "setup" and not args.no_strong:
         guard.line = out if rank == 0 else None
+        torch_rccl = None
+        if not share:       # torch's own RCCL group, exercised once: a sum of ones over the ranks (after the line is parked: a hang costs this probe only)
+            guard.arm(min(120, args.strong_budget_s), "torch.distributed nccl group (RCCL): all_reduce probe")
+            try:
+                g = dist.new_group(backend="nccl")
+                t = torch.ones(1, dtype=torch.float32, device="cuda")
+                dist.all_reduce(t, group=g)
+                torch.cuda.synchronize()
+                torch_rccl = {"all_reduce_of_ones": float(t.item()), "ranks": world, "ok": int(t.item()) == world}
+            except Exception as e:      # noqa: BLE001
+                torch_rccl = _err(e)
+            guard.disarm()
         strong = strong_ranks(args, world, rank, share, inst, pk, r_, s_, guard, cpu_collectives)
         if rank == 0:
             out["strong"] = strong
             out["rccl"] = rccl_report("rank: ncclCommInitRank, one process per GPU (gs_comm_init_rank)", strong.get("communicator_error"))
             out["rccl"]["torch_process_group_backend"] = dist.get_backend()
+            out["rccl"]["torch_nccl_group_probe"] = torch_rccl
     if rank == 0:
         if world > 1:
             out["launch"] = "torch.distributed.run, one rank per GPU (WORLD_SIZE=%d)" % world + ("; " + "; ".join(launch_notes) if launch_notes else "")
