@@ -1253,3 +1253,16 @@ def test_small_mirrors_of_the_reference_seams():
     assert bn128.G2.Double(P2) == jac_affine_g2(O.G2.Double(P2))
     assert bn128.G2.Sub(P2, Q2) == jac_affine_g2(O.G2.Sub(P2, Q2))
     assert bn128.G2.Equal(P2, bn128.G2.Add(bn128.G2.Sub(P2, Q2), Q2)) and bn128.G2.IsZero(bn128.G2.Sub(Q2, Q2))
+
+
+@pytest.mark.gpu
+def test_random_interleavings_of_every_pipelined_operation():
+    """tools/soak_mixed.py for a few seconds: Groth16 tickets from px and from the witness (2^16 .. 2^20, uniform and realistic), Pinocchio
+    tickets, G1 / G2 MSM tickets from 2^12 to 2^22 terms (both sides of the 3 * 2^20 ticket-stream rule) in RANDOM order with one to three
+    in flight -- each result must equal the blocking call's.  Round 4 assigns streams by rule per operation; runs of one kind of operation
+    cannot see a buffer or stream handed from one kind to another too early.  (400 s of it: profiles/r04_soak_mixed.txt, 18 729 operations.)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "soak_mixed.py"), "10", "3"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "every result equal to its blocking twin" in out.stdout, (out.stdout[-800:], out.stderr[-1500:])
