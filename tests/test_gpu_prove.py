@@ -1261,6 +1261,7 @@ def test_random_interleavings_of_every_pipelined_operation():
     tickets, G1 / G2 MSM tickets from 2^12 to 2^22 terms (both sides of the 3 * 2^20 ticket-stream rule) in RANDOM order with one to three
     in flight -- each result must equal the blocking call's.  Round 4 assigns streams by rule per operation; runs of one kind of operation
     cannot see a buffer or stream handed from one kind to another too early.  (400 s of it: profiles/r04_soak_mixed.txt, 18 729 operations.)"""
+    import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
