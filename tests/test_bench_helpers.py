@@ -79,3 +79,18 @@ def test_gpus_n_without_a_launcher_is_not_refused():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True, text=True, env=env, timeout=600)
     msg = out.stdout + out.stderr
     assert out.returncode != 0 and "needs an MI355X" in msg and "launch with" not in msg
+
+
+def test_nothing_before_the_parked_line_touches_rccl():
+    """The property the first real multi-GPU run relies on: in the launcher-free form the communicator is created AFTER
+    the weak-scaling line is parked in the watchdog, and under torch.distributed.run the process group is gloo (control plane) -- RCCL only
+    appears in the guarded sections that follow.  A source-order check: the forms cannot be executed with two GPUs from the test box."""
+    import inspect
+    b = _bench()
+    one = inspect.getsource(b.main_one_process)
+    assert 0 < one.index("guard.line = out") < one.index("capi.comm_init_local()")
+    assert one.index("guard.arm(args.strong_budget_s, \"gs_comm_init_local") < one.index("capi.comm_init_local()")
+    ranks = inspect.getsource(b.main)
+    assert 'init_process_group("gloo")' in ranks and 'init_process_group("nccl"' not in ranks
+    parked = ranks.index("guard.line = out if rank == 0 else None")
+    assert parked < ranks.index('dist.new_group(backend="nccl")') < ranks.index("strong = strong_ranks(")
