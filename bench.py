@@ -69,12 +69,12 @@ ISSUE_PEAK_G = 1024 * 2.4 / 4  # G wave-instructions/s: 256 CUs x 4 SIMDs, one w
 R = groth16.R
 
 
-def checker_leg_proof(proof, inst, r_, s_):
+def checker_leg_proof(proof, inst, r_, s_, w_host=None):
     """Checker leg (with cpu_baseline below the only users of oracle/ in this file; never inside the timed region):
     PiA, PiB, PiC of the benchmarked instance against a*G1, b*G2, c*G1 computed by the C oracle's MulScalar from the
-    closed-form scalars of synth.SqchainSetupInstance.expected_proof_scalars."""
+    closed-form scalars of synth.SqchainSetupInstance.expected_proof_scalars (w_host: another witness of the same circuit)."""
     from oracle import c_oracle as C, ref_py as O
-    ea, eb, ec = inst.expected_proof_scalars(r_, s_)
+    ea, eb, ec = inst.expected_proof_scalars(r_, s_, w_host)
     ok = ((proof.PiA[0], proof.PiA[1]) == C.g1_affine(C.g1_mul_scalar(O.G1_GEN, ea)) and
           (proof.PiB[0], proof.PiB[1]) == C.g2_affine(C.g2_mul_scalar(O.G2_GEN, eb)) and
           (proof.PiC[0], proof.PiC[1]) == C.g1_affine(C.g1_mul_scalar(O.G1_GEN, ec)))
@@ -214,6 +214,154 @@ def cpus_granted():
         except (OSError, ValueError, IndexError):
             continue
     return info
+
+
+def stream_distinct_host(inst, pk, n, r_, s_, distinct=8, steps=16, reps=3, check=True):
+    """the reference's call shape at the pipelined rate.  `distinct` different satisfying witnesses of the
+    benchmarked circuit rotate; every step brings ANOTHER one in pageable host memory (groth16.GenerateProofs gets a fresh w -- and
+    px -- per call, groth16/groth16.go:225, cli/main.go:480-501); three proofs in flight.  Four ways in, each timed:
+      witness_host   gs_groth16_prove_witness_host_begin (32 MiB per proof at 2^20; the slot's own device buffers, copy stream)
+      px_host        gs_groth16_prove_host_begin (w and px: 96 MiB per proof)
+      update         gs_scalars_update into four rotating resident vectors + gs_groth16_prove_witness_begin
+      resident       the same rotation with every witness uploaded beforehand (the figure the others are compared with)
+    Afterwards (outside every timed region) each of the `distinct` proofs of the witness_host stream is checked against ITS closed
+    form from the setup's toxic values and by groth16.VerifyProof against ITS public input (and rejected for another's)."""
+    from gosnark_amd import r1csqap
+    dr = r1csqap.DeviceR1CS(*inst.r1cs, inst.m)
+    xs = synth.field_elems(distinct, inst.seed + 9000)
+    ws = [synth.sqchain_witness(n, x) for x in xs]                      # plain numpy arrays: pageable host memory
+    w_res = [capi.scalars_upload(w) for w in ws]
+    pxs = []
+    for h in w_res:                                                     # px of every witness, back in host memory
+        ph = dr.ComputePxResident(h)
+        pxs.append(capi.scalars_download(ph))
+        ph.free()
+    rot = [capi.scalars_upload(ws[k]) for k in range(4)]
+    proofs = {}
+
+    def run(begin_k, count, keep=None):
+        tickets = []
+        for i in range(count):
+            k = i % distinct
+            tickets.append((k, begin_k(k, i)))
+            if len(tickets) == 3:
+                kk, t = tickets.pop(0)
+                p = groth16.prove_end(t)
+                if keep is not None:
+                    keep[kk] = p
+        while tickets:
+            kk, t = tickets.pop(0)
+            p = groth16.prove_end(t)
+            if keep is not None:
+                keep[kk] = p
+
+    def upd(k, i):
+        capi.scalars_update(rot[i % 4], ws[k])
+        return groth16.prove_witness_begin(pk, dr, rot[i % 4], r_, s_)
+    modes = {
+        "witness_host": lambda k, i: groth16.prove_witness_host_begin(pk, dr, ws[k], r_, s_),
+        "px_host": lambda k, i: groth16.prove_host_begin(pk, ws[k], pxs[k], r_, s_),
+        "update": upd,
+        "resident": lambda k, i: groth16.prove_witness_begin(pk, dr, w_res[k], r_, s_),
+        "px_resident_same_witness": lambda k, i: groth16.prove_begin(pk, inst.w, inst.px, r_, s_),
+    }
+    out = {"distinct_witnesses": distinct, "steps_per_repetition": steps, "proofs_in_flight": 3,
+           "bytes_per_proof": {"witness_host": int(ws[0].nbytes), "px_host": int(ws[0].nbytes + pxs[0].nbytes)}}
+    for name, fn in modes.items():
+        run(fn, 2 * distinct, proofs if name == "witness_host" else None)      # warm: the slots' buffers exist after the first lap
+        a0 = capi.alloc_counters()
+        samples = []
+        for _ in range(reps):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run(fn, steps)
+            torch.cuda.synchronize()
+            samples.append((time.perf_counter() - t0) / steps * 1e3)
+        a1 = capi.alloc_counters()
+        out[name] = {"ms_per_proof": statistics.median(samples), "ms_per_proof_reps": samples, "constraints_per_s": n / statistics.median(samples) * 1e3,
+                     "hipMalloc_calls_in_timed_steps": a1[0] - a0[0], "hipFree_calls_in_timed_steps": a1[1] - a0[1]}
+    out["witness_host_over_resident"] = out["witness_host"]["ms_per_proof"] / out["resident"]["ms_per_proof"]
+    out["px_host_over_px_resident"] = out["px_host"]["ms_per_proof"] / out["px_resident_same_witness"]["ms_per_proof"]
+    if check:
+        ok_v = 0
+        for k in range(distinct):
+            p = proofs[k]
+            checker_leg_proof(p, inst, r_, s_, ws[k])                   # raises SystemExit on a mismatch
+            if groth16.VerifyProof(inst.vk, p, [xs[k]]) and not groth16.VerifyProof(inst.vk, p, [xs[(k + 1) % distinct]]):
+                ok_v += 1
+        if ok_v != distinct:
+            raise SystemExit("bench.py: groth16.VerifyProof rejected a proof of the distinct-witness stream (%d of %d accepted)" % (ok_v, distinct))
+        out["checked"] = ("each of the %d streamed proofs equals the closed form of ITS witness (toxic values of the setup) and is accepted by "
+                          "groth16.VerifyProof for its own public input and rejected for its neighbour's" % distinct)
+    for h in w_res + rot:
+        h.free()
+    dr.handle.free()
+    return out
+
+
+def cold_path(inst, pk, n, r_, s_, ref_proof):
+    """the reference's other call shape -- load a key, prove ONCE (cli/main.go:330-349).  The resident key is
+    written to a binary key file and loaded back (np.memmap -> gs_g1_upload / gs_g2_upload -> gs_groth16_pk_create: what a CLI does);
+    `cold_ms` = gs_groth16_pk_create (+ gs_groth16_pk_set_eval) -> first proof collected, the uploads are given beside it.  Under
+    table policy `auto` the first proof is summed table-free; under `always` (rounds 1-4) it first builds 5.6 GiB of window tables."""
+    import tempfile
+    from gosnark_amd import utils
+    path = os.path.join(tempfile.gettempdir(), "gs_cold_key_%d.bin" % os.getpid())
+    utils.GrothSetupToBinary(path, groth16.Circuit(pk.nvars, pk.npublic), pk, None)
+    out = {"key_file_bytes": os.path.getsize(path)}
+    try:
+        for policy in ("auto", "always"):
+            capi.set_table_policy(policy)
+            protocol, nvars, npublic, sec = utils.ReadBinary(path)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            up1 = lambda k: capi.g1_upload(np.ascontiguousarray(sec[k], dtype=np.uint64))     # noqa: E731
+            at, b1, cd, pt = up1("G1.At"), up1("G1.BACGamma"), up1("BACDelta"), up1("PowersTauDelta")
+            b2 = capi.g2_upload(np.ascontiguousarray(sec["G2.BACGamma"], dtype=np.uint64))
+            ev = up1("PowersTauDeltaEval") if "PowersTauDeltaEval" in sec else None
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            abd, bd = utils._g1_tuples(sec["G1.ABD"]), utils._g2_tuples(sec["G2.BD"])
+            k2 = groth16.device_pk_from_handles(at, b1, b2, cd, pt, abd[0], abd[1], abd[2], bd[0], bd[1], np.ascontiguousarray(sec["Z"], dtype=np.uint64),
+                                                nvars, npublic)
+            if ev is not None:
+                capi.check(capi.load_library().gs_groth16_pk_set_eval(capi.Handle(k2.handle.h), capi.Handle(ev.h)))
+            t2 = time.perf_counter()
+            p = groth16.prove_resident(k2, inst.w, inst.px, r_, s_)
+            t3 = time.perf_counter()
+            if (p.PiA, p.PiB, p.PiC) != (ref_proof.PiA, ref_proof.PiB, ref_proof.PiC):
+                raise SystemExit("bench.py: the first proof of the freshly loaded key (table policy %s) differs from the warm key's" % policy)
+            obj_b, tab_b = capi.handle_bytes(k2.handle)
+            p2 = groth16.prove_resident(k2, inst.w, inst.px, r_, s_)
+            t4 = time.perf_counter()
+            out[policy] = {"cold_ms": (t3 - t1) * 1e3, "pk_create_ms": (t2 - t1) * 1e3, "first_proof_ms": (t3 - t2) * 1e3, "second_proof_ms": (t4 - t3) * 1e3,
+                           "key_upload_ms": (t1 - t0) * 1e3, "key_bytes_after_first_proof": obj_b, "table_bytes_after_first_proof": tab_b,
+                           "first_proof_equals_warm_key": True, "second_proof_equals": (p2.PiA, p2.PiB, p2.PiC) == (p.PiA, p.PiB, p.PiC)}
+            for h in (at, b1, cd, pt, b2) + ((ev,) if ev is not None else ()):
+                h.free()
+            k2.handle.free()
+            del sec
+        # steady state without tables at all (policy never): what a key costs when its 5.6 GiB are not spent
+        capi.set_table_policy("never")
+        capi.release_tables(pk.handle)
+        pipelined(lambda: groth16.prove_begin(pk, inst.w, inst.px, r_, s_), groth16.prove_end, 6, 3)
+        samples = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            pipelined(lambda: groth16.prove_begin(pk, inst.w, inst.px, r_, s_), groth16.prove_end, 10, 3)
+            torch.cuda.synchronize()
+            samples.append((time.perf_counter() - t0) / 10 * 1e3)
+        tm = capi.last_timing()
+        p = groth16.prove_resident(pk, inst.w, inst.px, r_, s_)
+        out["table_free_steady"] = {"ms_per_proof": statistics.median(samples), "ms_per_proof_reps": samples, "window_bits": tm["window_bits"],
+                                    "table_bytes": capi.handle_bytes(pk.handle)[1],
+                                    "proof_equals_table_route": (p.PiA, p.PiB, p.PiC) == (ref_proof.PiA, ref_proof.PiB, ref_proof.PiC)}
+    finally:
+        capi.set_table_policy("always")
+        if os.path.exists(path):
+            os.remove(path)
+    return out
 
 
 def pipelined(begin, end, count, depth, on_done=None):
@@ -904,6 +1052,8 @@ def main():
     ap.add_argument("--no-check", action="store_true", help="skip the closed-form proof check of the `setup` instance")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra measurements of the default single-GPU run")
     ap.add_argument("--cpu-log2n", type=int, default=13, help="constraints of the CPU-baseline sample (0 = skip every CPU baseline)")
+    ap.add_argument("--table-policy", default="always", choices=["auto", "always", "never"],
+                    help="gs_set_table_policy for the timed workload (always: window tables, the steady state of rounds 1-4; never: table-free)")
     ap.add_argument("--window-bits", type=int, default=0, help="force the Pippenger window width (0 = the library's choice)")
     ap.add_argument("--multi", default="one-process", choices=["one-process", "ranks"],
                     help="--gpus N > 1 WITHOUT a launcher (WORLD_SIZE unset): one-process = this process drives the N devices through the library's "
@@ -955,6 +1105,9 @@ def main():
     guard = LineGuard(rank)
     logical = args.logical_shards if (args.logical_shards > 1 and world == 1 and args.workload in ("prove_sharded", "msm_sharded")) else 0
     capi.init([local] * logical if logical else local)
+    # Steady state = a key whose window tables exist (gs_set_table_policy `always`: built inside the first, untimed, warm-up proof, as
+    # in rounds 1-4).  The library's default is `auto`; the cold path and the table-free steady state are measured in the extras.
+    capi.set_table_policy(args.table_policy)
     if args.window_bits or os.environ.get("GS_BENCH_C"):
         capi.set_window_bits(args.window_bits or int(os.environ["GS_BENCH_C"]))
 
@@ -1219,6 +1372,10 @@ def main():
                     capi.set_eval_basis(True)
             pxh.free()
             dr.handle.free()
+        if args.instance == "setup" and args.table_policy == "always":
+            extras["stream_distinct_host"] = stream_distinct_host(inst, pk, n, r_, s_, check=args.cpu_log2n > 0 and not args.no_check)
+            extras["stream_distinct_host"]["resident_same_witness_ms_per_proof"] = extras.get("from_r1cs_pipelined_ms_per_step")
+            extras["cold"] = cold_path(inst, pk, n, r_, s_, step())
         extras["msm_g1"] = msm_extras(seed + 5000)
 
     out = None

@@ -34,7 +34,7 @@ class Timing(ctypes.Structure):
 
 class Memory(ctypes.Structure):
     _fields_ = [(n, ctypes.c_uint64) for n in ("device_total_bytes", "device_free_bytes", "library_bytes", "object_bytes", "table_bytes",
-                                               "workspace_bytes", "objects", "reserved")]
+                                               "workspace_bytes", "objects", "evictions")]
 
 
 def lib_path():
@@ -55,6 +55,7 @@ _SIGS = {
     "gs_g2_fixed_base": [u64p, ctypes.c_size_t, ctypes.POINTER(Handle)],
     "gs_scalars_upload": [u64p, ctypes.c_size_t, ctypes.POINTER(Handle)],
     "gs_scalars_download": [Handle, u64p, ctypes.c_size_t],
+    "gs_scalars_update": [Handle, u64p, ctypes.c_size_t],
     "gs_msm_g1": [Handle, u64p, ctypes.c_size_t, ctypes.c_size_t, u64p, intp],
     "gs_msm_g2": [Handle, u64p, ctypes.c_size_t, ctypes.c_size_t, u64p, intp],
     "gs_msm_g1_resident": [Handle, ctypes.c_size_t, Handle, ctypes.c_size_t, ctypes.c_size_t, u64p, intp],
@@ -88,6 +89,12 @@ _SIGS = {
     "gs_pinocchio_prove_witness_begin": [Handle, Handle, Handle, u64p],
     "gs_groth16_prove_begin": [Handle, Handle, Handle, u64p, u64p, u64p],
     "gs_groth16_prove_end": [ctypes.c_uint64, u64p, intp],
+    "gs_groth16_prove_host_begin": [Handle, u64p, ctypes.c_size_t, u64p, ctypes.c_size_t, u64p, u64p, u64p],
+    "gs_groth16_prove_witness_host_begin": [Handle, Handle, u64p, ctypes.c_size_t, u64p, u64p, u64p],
+    "gs_groth16_prove_witness_host": [Handle, Handle, u64p, ctypes.c_size_t, u64p, u64p, u64p, intp],
+    "gs_pinocchio_prove_host_begin": [Handle, u64p, ctypes.c_size_t, u64p, ctypes.c_size_t, u64p],
+    "gs_pinocchio_prove_witness_host_begin": [Handle, Handle, u64p, ctypes.c_size_t, u64p],
+    "gs_pinocchio_prove_witness_host": [Handle, Handle, u64p, ctypes.c_size_t, u64p, intp],
     "gs_ticket_cancel": [ctypes.c_uint64],
     "gs_groth16_pk_create_shard": [Handle, Handle, Handle, Handle, Handle, u64p, u64p, u64p, u64p, u64p, u64p, ctypes.c_size_t,
                                    ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, ctypes.POINTER(Handle)],
@@ -153,6 +160,11 @@ _SIGS = {
     "gs_memory_query": [ctypes.POINTER(Memory)],
     "gs_handle_bytes": [Handle, u64p, u64p],
     "gs_release_tables": [Handle],
+    "gs_set_table_policy": [ctypes.c_int],
+    "gs_build_tables": [Handle, ctypes.c_int],
+    "gs_set_memory_limit": [ctypes.c_uint64],
+    "gs_alloc_counters": [u64p, u64p],
+    "gs_abi_sizes": [ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)],
     "gs_trim": [],
     "gs_verify_set_strict": [ctypes.c_int],
     "gs_pairing": [u64p, u64p, u64p],
@@ -193,6 +205,13 @@ def load_library():
         lib.gs_version.restype = ctypes.c_char_p
         lib.gs_shutdown.restype = None
         lib.gs_comm_destroy.restype = None
+        # gs_timing / gs_memory are written through our pointers: a library built from another revision of the header must not
+        # be handed these structs (gs_timing grew by 24 bytes in round 4 without anything noticing)
+        tb, mb = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        lib.gs_abi_sizes(ctypes.byref(tb), ctypes.byref(mb))
+        if tb.value != ctypes.sizeof(Timing) or mb.value != ctypes.sizeof(Memory):
+            raise GosnarkHipError(-1, "%s writes gs_timing / gs_memory of %d / %d bytes, this binding expects %d / %d: rebuild the library"
+                                  % (path, tb.value, mb.value, ctypes.sizeof(Timing), ctypes.sizeof(Memory)))
         _LIB = lib
         return lib
 
@@ -449,6 +468,40 @@ def handle_bytes(h):
 def release_tables(h):
     """gs_release_tables: drop the window tables of a key / base array (rebuilt on its next use)."""
     check(load_library().gs_release_tables(Handle(_raw(h))))
+
+
+TABLE_POLICY = {"auto": 0, "always": 1, "never": 2}
+
+
+def set_table_policy(policy):
+    """gs_set_table_policy: "auto" (table-free until a base array's second use, then a background build), "always" (build inside
+    the first call), "never" (table-free only).  Results never depend on it."""
+    init()
+    check(load_library().gs_set_table_policy(TABLE_POLICY[policy] if isinstance(policy, str) else int(policy)))
+
+
+def build_tables(h, route=0):
+    """gs_build_tables: build the window tables of a key / base array now (blocking).  route: 0 all, 1 px routes only, 2 witness
+    routes only."""
+    check(load_library().gs_build_tables(Handle(_raw(h)), int(route)))
+
+
+def set_memory_limit(nbytes):
+    """gs_set_memory_limit (development / test hook): cap on the device bytes the library may hold, 0 = none."""
+    check(load_library().gs_set_memory_limit(ctypes.c_uint64(int(nbytes))))
+
+
+def alloc_counters():
+    """gs_alloc_counters -> (hipMalloc calls, hipFree calls) the library has made so far."""
+    a, b = ctypes.c_uint64(0), ctypes.c_uint64(0)
+    check(load_library().gs_alloc_counters(ctypes.cast(ctypes.byref(a), u64p), ctypes.cast(ctypes.byref(b), u64p)))
+    return int(a.value), int(b.value)
+
+
+def scalars_update(handle, s_u64):
+    """gs_scalars_update: overwrite a resident scalar vector in place (same length) -- no allocation, no device-wide sync."""
+    a = np.ascontiguousarray(s_u64, dtype=np.uint64).reshape(-1, 4)
+    check(load_library().gs_scalars_update(Handle(_raw(handle)), ptr64(a), a.shape[0]))
 
 
 def trim():

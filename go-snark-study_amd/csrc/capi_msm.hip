@@ -83,18 +83,17 @@ int msm_resident(Ctx& c, Kind kind, gs_handle hb, size_t off, const uint32_t* sc
   // window table of this base array for the width the plan will use (built on first use, kept resident)
   if (!b->table) b->table = std::make_shared<BaseTable>();
   BaseTable* tab = static_cast<BaseTable*>(b->table.get());
-  const int cbits = choose_window_bits((uint32_t)n, c.window_bits);
-  if constexpr (T::kWords == 8) ensure_table_g1(c, *tab, b->buf.as<uint32_t>(), b->n, cbits);
-  else ensure_table_g2(c, *tab, b->buf.as<uint32_t>(), b->n, cbits);
+  int cbits = 0;
+  const bool tabled = prepare_tables(c, {TableRef{tab, b->buf.as<uint32_t>(), b->n, T::kWords == 16}}, (uint32_t)n, &cbits);
   PhaseTimer total(c.stream);
   MsmPlan plan;
   {
     PhaseTimer tp(c.stream);
-    build_plan(c, 2 * Ctx::kBlockingSlot, scalars_dev, (uint32_t)n, plan, {{1, T::kWords == 16}});
+    build_plan(c, 2 * Ctx::kBlockingSlot, scalars_dev, (uint32_t)n, plan, {{1, T::kWords == 16}}, cbits, !tabled);
     tp.stop();
     c.timing.plan_ms += tp.ms();
   }
-  std::vector<MsmBase> bases{MsmBase{tab, off}};
+  std::vector<MsmBase> bases{MsmBase{tab, off, b->buf.as<uint32_t>(), b->n}};
   bool inf;
   if constexpr (T::kWords == 8) {
     std::vector<G1Xyzz> r;
@@ -136,9 +135,8 @@ int msm_begin(Ctx& c, Kind kind, gs_handle hb, size_t off, gs_handle hs, size_t 
   if (parity < 0) return fail(GS_ERR_BUSY, "gs_msm_begin: three operations are already outstanding");
   if (!b->table) b->table = std::make_shared<BaseTable>();
   BaseTable* tab = static_cast<BaseTable*>(b->table.get());
-  const int cbits = choose_window_bits((uint32_t)n, c.window_bits);
-  if constexpr (T::kWords == 8) ensure_table_g1(c, *tab, b->buf.as<uint32_t>(), b->n, cbits);
-  else ensure_table_g2(c, *tab, b->buf.as<uint32_t>(), b->n, cbits);
+  int cbits = 0;
+  const bool tabled = prepare_tables(c, {TableRef{tab, b->buf.as<uint32_t>(), b->n, T::kWords == 16}}, (uint32_t)n, &cbits);
   auto st = std::make_unique<MsmInFlight>();
   st->g2 = T::kWords == 16;
   st->keep = {c.share<Object>(hb, kind), c.share<Object>(hs, Kind::Scalars)};
@@ -154,7 +152,7 @@ int msm_begin(Ctx& c, Kind kind, gs_handle hb, size_t off, gs_handle hs, size_t 
   {
     StreamScope ss(c, plan_stream);
     st->tplan = std::make_shared<PhaseTimer>(c.stream);
-    build_plan(c, 2 * parity, sc->buf.as<uint32_t>() + soff * 8, (uint32_t)n, plan, {{1, st->g2}});
+    build_plan(c, 2 * parity, sc->buf.as<uint32_t>() + soff * 8, (uint32_t)n, plan, {{1, st->g2}}, cbits, !tabled);
     st->tplan->stop();
     GS_HIP(hipEventRecord(st->planned, c.stream));
   }
@@ -162,13 +160,14 @@ int msm_begin(Ctx& c, Kind kind, gs_handle hb, size_t off, gs_handle hs, size_t 
   {
     StreamScope ss(c, c.main_stream);
     GS_HIP(hipStreamWaitEvent(c.stream, st->planned, 0));
-    std::vector<MsmBase> bases{MsmBase{tab, off}};
+    std::vector<MsmBase> bases{MsmBase{tab, off, b->buf.as<uint32_t>(), b->n}};
     if (!ticket_streams) c.next_tails((uint32_t)n);          // consecutive small MSMs reduce on alternating tail streams
     tail = ticket_streams ? plan_stream : c.tail_stream(0);
     if constexpr (T::kWords == 8) msm_enqueue_g1(c, plan, bases, 8 * parity, 3 * parity, st->pend, tail);
     else msm_enqueue_g2(c, plan, bases, 8 * parity + 4, 3 * parity, st->pend, tail);
   }
   GS_HIP(hipEventRecord(st->done, tail));
+  sc->mark_read(plan_stream);                          // gs_scalars_update on this vector waits for the plan's digit pass
   st->ticket = c.new_ticket();
   *ticket = st->ticket;
   c.inflight[parity] = std::move(st);
@@ -275,6 +274,7 @@ static void ctx_create(Ctx& c, int logical, int device) {
   GS_HIP(hipHostMalloc(reinterpret_cast<void**>(&c.bad_host), Ctx::kSlots * 4, hipHostMallocDefault));
   memset(c.bad_host, 0, Ctx::kSlots * 4);
   c.stream = c.main_stream;
+  c.table_policy = (int)run_knob("GS_TABLE_POLICY", 0, 0, 2);      // initial value of gs_set_table_policy (same results either way)
   c.ready = true;
 }
 
@@ -302,6 +302,8 @@ static void ctx_destroy(Ctx& c) {
   c.bad_dev.release();
   if (c.copy_stream) (void)hipStreamDestroy(c.copy_stream);
   c.copy_stream = nullptr;
+  if (c.table_stream) (void)hipStreamDestroy(c.table_stream);
+  c.table_stream = nullptr;
   for (int b = 0; b < Ctx::kStageBuffers; ++b) {
     if (c.stage[b]) (void)hipHostFree(c.stage[b]);
     if (c.stage_ev[b]) (void)hipEventDestroy(c.stage_ev[b]);
@@ -440,6 +442,30 @@ int gs_scalars_upload(const uint64_t* s, size_t n, gs_handle* out) {
     *out = c.put(std::move(o));
     return GS_OK;
   }, true, true);
+}
+// Overwrite a resident vector IN PLACE with n = its length new scalars from caller memory: no hipMalloc, no hipFree (which would
+// synchronise the whole device under outstanding tickets).  The copy runs on the copy stream behind every device read of the vector
+// that pipelined operations enqueued before this call (Scalars::reads) and has landed when the call returns, so whatever is
+// enqueued afterwards sees the new values.  With >= 4 vectors rotating under three tickets the wait is nil: a ticket's last read of
+// its witness is its plan's digit pass, long before it is collected.
+int gs_scalars_update(gs_handle h, const uint64_t* s, size_t n) {
+  return guarded([&](Ctx& c) -> int {
+    Scalars* o = c.get<Scalars>(h, Kind::Scalars);
+    if (!o) return fail(GS_ERR_ARG, "gs_scalars_update: bad handle");
+    if (n != o->n || (n && !s)) return fail(GS_ERR_ARG, "gs_scalars_update: the vector holds %zu scalars, the call brings %zu", o->n, n);
+    if (!n) return GS_OK;
+    if (!c.copy_stream) GS_HIP(hipStreamCreateWithFlags(&c.copy_stream, hipStreamNonBlocking));
+    for (auto& r : o->reads) GS_HIP(hipStreamWaitEvent(c.copy_stream, r.ev, 0));
+    staged_h2d(c, o->buf.p, s, n * 32, c.copy_stream);
+    GS_HIP(hipStreamSynchronize(c.copy_stream));
+    return GS_OK;
+  }, true, true, h);
+}
+// how often the library called hipMalloc / hipFree so far (process-wide): a proof stream in steady state moves neither
+int gs_alloc_counters(uint64_t* allocs, uint64_t* frees) {
+  if (allocs) *allocs = devbuf_allocs().load();
+  if (frees) *frees = devbuf_frees().load();
+  return GS_OK;
 }
 int gs_scalars_download(gs_handle h, uint64_t* out, size_t n) {
   return guarded([&](Ctx& c) -> int {

@@ -17,7 +17,11 @@ struct MsmPlan {                 // digits of one scalar vector, bucket-sorted (
   uint32_t n = 0;
   int c = 0, W = 0;
   uint32_t B = 0;                // buckets per window
-  uint32_t nbuckets = 0;         // W * B
+  // Bucket sets.  Window-table route: ONE set of B buckets for all windows (digit d of window j adds row j of the table, i.e.
+  // 2^(c j) P_i, into bucket d).  Table-free route: a set per window, bucket id = window * B + (|d| - 1), every window adds the
+  // base point itself; the window sums are recombined by Horner on the host.  nbuckets = B or W * B accordingly.
+  bool table_free = false;
+  uint32_t nbuckets = 0;
   uint32_t chunk = 32;           // entries per accumulate thread (16 or 32; always a multiple of 4)
   uint32_t maxchunks = 0;        // upper bound of the number of chunks (the exact count stays on the device)
   const uint32_t* offsets = nullptr;        // nbuckets + 1 (offsets[nbuckets] = number of entries)
@@ -29,28 +33,58 @@ struct MsmPlan {                 // digits of one scalar vector, bucket-sorted (
 
 constexpr int kMaxWindowBits = 20;
 int choose_window_bits(uint32_t n, int forced);
+// the table-free route's width: every window owns a bucket set, so the optimum is narrower; 9 .. 16 (one LDS histogram range, and
+// a reduce workgroup never straddles two windows)
+constexpr int kMinFreeWindowBits = 9, kMaxFreeWindowBits = 16;
+int choose_window_bits_free(uint32_t n, int forced);
 
 // Window table of a base array: rows[j][i] = 2^(c j) * P_i (packed affine), j < W = 254 / c + 1.
 struct BaseTable {
   DevBuf rows;
   size_t n = 0;
   int c = 0, W = 0;
+  uint64_t last_use = 0;           // Ctx::call_clock of the last call that used the array (LRU order of evict_tables_for)
+  uint32_t uses = 0;               // proofs / MSMs that found no table since it last had one (table policy auto)
+  // a build in the background (table policy auto): complete when `pending_done` has fired, installed by the next call that looks
+  DevBuf pending;
+  int pending_c = 0;
+  size_t pending_n = 0;
+  hipEvent_t pending_done = nullptr;
+  bool ready(size_t n_, int c_) const { return rows.p != nullptr && n == n_ && c == c_; }
+  void drop() { rows.release(); n = 0; c = 0; W = 0; }
+  BaseTable() = default;
+  BaseTable(const BaseTable&) = delete;
+  BaseTable& operator=(const BaseTable&) = delete;
+  ~BaseTable() { if (pending_done && !process_exiting()) (void)hipEventDestroy(pending_done); }
 };
 // (Re)build `t` for window width c from row 0 (`row0` = packed affine points; pass nullptr to rebuild from the
 // table's own row 0).  No-op when the table already matches.
 void ensure_table_g1(Ctx& c, BaseTable& t, const uint32_t* row0, size_t n, int cbits);
 void ensure_table_g2(Ctx& c, BaseTable& t, const uint32_t* row0, size_t n, int cbits);
 
-struct MsmBase {                 // one job of an MSM launch: a window table and the first term's offset in it
-  const BaseTable* table;
-  size_t off;
+// The base arrays one plan will be multiplied with (a proof's At / BACGamma / BACDelta / BACGamma2 over w; one array for an MSM).
+struct TableRef { BaseTable* t; const uint32_t* row0; size_t n; bool g2; };
+// Decides how the group is summed THIS time and prepares it: true = window tables, all of width *cbits and resident (built now
+// under policy `always`, or found); false = table-free with *cbits from choose_window_bits_free -- and, under policy `auto`, the
+// tables are built in the background once the arrays have been used twice.  Stamps the tables for the LRU.
+bool prepare_tables(Ctx& c, const std::vector<TableRef>& group, uint32_t nterms, int* cbits);
+// wait for / drop a background build (gs_release_tables, gs_build_tables)
+void table_settle(Ctx& c, BaseTable& t, bool install);
+
+struct MsmBase {                 // one job of an MSM launch
+  const BaseTable* table;        // window-table route: the table ...
+  size_t off;                    // ... and the first term's offset in it (or in `points`)
+  const uint32_t* points = nullptr;   // table-free route: the base array itself (packed affine), `npoints` of them
+  size_t npoints = 0;
 };
 
 // A launch that will consume a plan: how many base arrays it sums at once and whether they are G2.
 struct LaunchShape { int njobs; bool g2; };
 // scalars_dev: n x 8 u32 words (standard form, any 256-bit value).  slot: 0..3 (four plans may be alive).  `users`: the
 // launches that will run on this plan (decides the chunk size: whole wave rounds for every one of them).
-void build_plan(Ctx& c, int slot, const uint32_t* scalars_dev, uint32_t n, MsmPlan& plan, const std::vector<LaunchShape>& users);
+// cbits: the width prepare_tables chose; table_free: its route.
+void build_plan(Ctx& c, int slot, const uint32_t* scalars_dev, uint32_t n, MsmPlan& plan, const std::vector<LaunchShape>& users, int cbits = 0,
+                bool table_free = false);
 
 // One launch sequence for up to 8 base arrays sharing a plan (their tables must have been built for plan.c).
 // msm_enqueue_* only ENQUEUES on c.stream (kernels + the async download of the <= 16 workgroup pairs per
@@ -59,6 +93,8 @@ void build_plan(Ctx& c, int slot, const uint32_t* scalars_dev, uint32_t n, MsmPl
 // ws_base: first of the 8 workspace sets to use (groups in flight together must not share sets).
 struct MsmPending {
   int njobs = 0, L = 1, slot = 0, c = 0, W = 0;
+  bool table_free = false;         // per-window bucket sets: the pairs come grouped by window, the host recombines by Horner
+  uint32_t nblk_window = 0;        // reduce workgroups per window on that route
   uint32_t nblk = 0, n = 0;
   bool g2 = false;
   bool folded = false;             // the device folded the workgroup pairs: one XYZZ point per job in the pinned slot

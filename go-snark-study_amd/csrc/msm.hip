@@ -36,6 +36,22 @@ int choose_window_bits(uint32_t n, int forced) {
   return best;
 }
 
+// Table-free route: every window has its own bucket set, so a bucket costs per WINDOW: cost(c) = n W + k W 2^(c-1) with k ~ 3 mixed
+// additions per bucket (one combine, two complete additions of the reduce).  2^20 terms: c = 16 (16.8 M + 1.6 M additions against the
+// 15.7 M + 0.2 M of the 17-bit window tables: ~1.15x); 2^16 terms: c = 13.
+int choose_window_bits_free(uint32_t n, int forced) {
+  if (forced) return std::min(kMaxFreeWindowBits, std::max(kMinFreeWindowBits, forced));
+  static const double per_bucket = dev_knob_f("GS_WINDOW_COST_BUCKET_FREE", 3.0, 0.0, 64.0);
+  int best = kMinFreeWindowBits;
+  double best_cost = 1e300;
+  for (int c = kMinFreeWindowBits; c <= kMaxFreeWindowBits; ++c) {
+    const int W = 254 / c + 1;
+    const double cost = (double)W * ((double)n + per_bucket * (double)(1u << (c - 1)));
+    if (cost < best_cost) { best_cost = cost; best = c; }
+  }
+  return best;
+}
+
 static void exclusive_scan(Ctx& c, PlanBuffers& pb, const uint32_t* in, uint32_t* out, uint32_t n) {
   const uint32_t ntiles = (n + kScanTile - 1) / kScanTile;
   pb.tiles.ensure((size_t)ntiles * 4);
@@ -48,6 +64,7 @@ static void exclusive_scan(Ctx& c, PlanBuffers& pb, const uint32_t* in, uint32_t
 struct MsmState {                                  // per context (device memory belongs to one device)
   PlanBuffers plan_slots[2 * Ctx::kSlots];         // (w, h) x slots
   DevBuf table_scratch;                            // slab of the batched window-table builder
+  DevBuf table_scratch_bg;                         // ... and of the builds that run in the background on the table stream
   bool lds_attr_set = false;
 };
 static MsmState& msm_state(Ctx& c) { return c.state<MsmState>(c.msm_state); }
@@ -71,20 +88,25 @@ static uint32_t choose_chunk(uint64_t entries, uint32_t nbuckets, const std::vec
   return chunk;
 }
 
-void build_plan(Ctx& c, int slot, const uint32_t* scalars_dev, uint32_t n, MsmPlan& plan, const std::vector<LaunchShape>& users) {
+void build_plan(Ctx& c, int slot, const uint32_t* scalars_dev, uint32_t n, MsmPlan& plan, const std::vector<LaunchShape>& users, int cbits,
+                bool table_free) {
   MsmState& ms = msm_state(c);
   PlanBuffers& pb = ms.plan_slots[slot % (2 * Ctx::kSlots)];
   plan.n = n;
-  plan.c = choose_window_bits(n, c.window_bits);
+  plan.table_free = table_free;
+  plan.c = cbits ? cbits : (table_free ? choose_window_bits_free(n, c.window_bits) : choose_window_bits(n, c.window_bits));
+  if (table_free && (plan.c < kMinFreeWindowBits || plan.c > kMaxFreeWindowBits))
+    throw HipError{hipErrorInvalidValue, "table-free plan outside 9..16 window bits", __LINE__};
   plan.W = 254 / plan.c + 1;
   plan.B = 1u << (plan.c - 1);
-  plan.nbuckets = plan.B;                      // one bucket set for all windows (window tables)
+  plan.nbuckets = table_free ? (uint32_t)plan.W * plan.B : plan.B;      // one bucket set for all windows (window tables), or one per window
   plan.chunk = choose_chunk((uint64_t)n * plan.W, plan.nbuckets, users);
   plan.maxchunks = (uint32_t)(((size_t)n * plan.W + plan.chunk - 1) / plan.chunk) + 1;
   const size_t ncount = (size_t)plan.nbuckets + 1;
   PlanParams pp{};
   pp.n = n; pp.c = plan.c; pp.W = plan.W; pp.B = plan.B;
   pp.R = std::max<uint32_t>(1u, plan.B >> kRangeLog);      // bucket ranges of 2^15 counters (one LDS histogram each)
+  pp.tf = table_free ? 1u : 0u;
   // slices: enough (window, slice, range) workgroups to cover the 256 CUs, never less than 16384 scalars per slice, and a
   // histogram matrix hist[W * S][B] of at most 64 MiB
   {
@@ -95,7 +117,7 @@ void build_plan(Ctx& c, int slot, const uint32_t* scalars_dev, uint32_t n, MsmPl
     const uint32_t by_size = std::max<uint32_t>(1u, (n + 16383u) / 16384u);
     const uint32_t by_mem = std::max<uint32_t>(1u, (uint32_t)((64ull << 20) / ((uint64_t)plan.B * plan.W * 4)));
     pp.S = std::max<uint32_t>(1u, std::min(std::min<uint32_t>(16u, std::max<uint32_t>(want, 1u)), std::min(by_size, by_mem)));
-    if (pp.R == 1) pp.S = std::max<uint32_t>(1u, std::min<uint32_t>(16u, by_size));     // narrow windows: as before
+    if (pp.R == 1 && !table_free) pp.S = std::max<uint32_t>(1u, std::min<uint32_t>(16u, by_size));     // narrow windows: as before
   }
   pp.slice = (n + pp.S - 1) / pp.S;
   pp.stride = (n + 63u) & ~63u;
@@ -142,7 +164,8 @@ void build_plan(Ctx& c, int slot, const uint32_t* scalars_dev, uint32_t n, MsmPl
   } else if (n > 0) {
     hipLaunchKernelGGL(k_digits, grid1(n), dim3(256), 0, c.stream, scalars_dev, pp, pb.digits.as<digit_t>());
     hipLaunchKernelGGL(k_hist, dim3(plan.W, pp.S, pp.R), dim3(sort_block), lds, c.stream, pb.digits.as<digit_t>(), pp, pb.hist.as<uint32_t>());
-    hipLaunchKernelGGL(k_colscan, grid1(plan.B), dim3(256), 0, c.stream, pb.hist.as<uint32_t>(), pp, pb.totals.as<uint32_t>());
+    if (table_free) hipLaunchKernelGGL(k_colscan_windows, grid1(plan.nbuckets), dim3(256), 0, c.stream, pb.hist.as<uint32_t>(), pp, pb.totals.as<uint32_t>());
+    else hipLaunchKernelGGL(k_colscan, grid1(plan.B), dim3(256), 0, c.stream, pb.hist.as<uint32_t>(), pp, pb.totals.as<uint32_t>());
   } else {
     GS_HIP(hipMemsetAsync(pb.totals.p, 0, ncount * 4, c.stream));
   }
@@ -163,38 +186,116 @@ void build_plan(Ctx& c, int slot, const uint32_t* scalars_dev, uint32_t n, MsmPl
   plan.heavy_count = pb.counters.as<uint32_t>();
 }
 
+// Enqueue the kernels that fill `fresh` (W rows of n points) from row 0 on `stream`.
 template <class T>
-static void ensure_table(Ctx& c, BaseTable& t, const uint32_t* row0, size_t n, int cbits) {
-  if (t.c == cbits && t.n == n && t.rows.p) return;
+static void enqueue_table_build(Ctx& c, hipStream_t stream, DevBuf& scratch, const uint32_t* src, size_t n, int cbits, DevBuf& fresh) {
   constexpr size_t aw = PointIO<T>::kAffineWords;
   const int W = 254 / cbits + 1;
-  DevBuf fresh(std::max<size_t>(n, 1) * W * aw * 4);
-  const uint32_t* src = row0 ? row0 : t.rows.as<uint32_t>();
-  if (!src || (!row0 && t.n != n)) throw HipError{hipErrorInvalidValue, "window table rebuild without its points", __LINE__};
+  fresh.alloc(std::max<size_t>(n, 1) * W * aw * 4);
   if (n) {
     static const bool per_row = dev_flag("GS_TABLE_PER_ROW");               // the one-inversion-per-row builder, for comparison
     if (per_row || W <= 2) {
-      hipLaunchKernelGGL(k_build_table<T>, grid1(n), dim3(256), 0, c.stream, src, (uint32_t)n, cbits, W, fresh.as<uint32_t>());
+      hipLaunchKernelGGL(k_build_table<T>, grid1(n), dim3(256), 0, stream, src, (uint32_t)n, cbits, W, fresh.as<uint32_t>());
     } else {
       // slabs of 2^18 points: (W - 1) rows of [XYZZ | running product] raw limbs per point (<= 1.4 GiB for G2), reused per slab
       constexpr size_t sw = PointIO<T>::kXyzzWords + PointIO<T>::kXyzzWords / 4;
       const size_t slab = std::min<size_t>(n, (size_t)1 << 18);
-      DevBuf& scratch = msm_state(c).table_scratch;
       scratch.ensure(slab * (size_t)(W - 1) * sw * 4);
       for (size_t first = 0; first < n; first += slab) {
         const size_t count = std::min(slab, n - first);
-        hipLaunchKernelGGL(k_build_table_batched<T>, grid1(count), dim3(256), 0, c.stream, src, (uint32_t)n, (uint32_t)first, (uint32_t)count, cbits, W,
+        hipLaunchKernelGGL(k_build_table_batched<T>, grid1(count), dim3(256), 0, stream, src, (uint32_t)n, (uint32_t)first, (uint32_t)count, cbits, W,
                            fresh.as<uint32_t>(), scratch.as<uint32_t>());
       }
     }
   }
   GS_HIP(hipGetLastError());
+}
+
+template <class T>
+static void ensure_table(Ctx& c, BaseTable& t, const uint32_t* row0, size_t n, int cbits) {
+  if (t.c == cbits && t.n == n && t.rows.p) return;
+  table_settle(c, t, false);                    // a background build of another width: superseded
+  const uint32_t* src = row0 ? row0 : t.rows.as<uint32_t>();
+  if (!src || (!row0 && t.n != n)) throw HipError{hipErrorInvalidValue, "window table rebuild without its points", __LINE__};
+  DevBuf fresh;
+  enqueue_table_build<T>(c, c.stream, msm_state(c).table_scratch, src, n, cbits, fresh);
   GS_HIP(hipStreamSynchronize(c.stream));       // the old rows (possibly the source) are released below
   t.rows = std::move(fresh);
-  t.n = n; t.c = cbits; t.W = W;
+  t.n = n; t.c = cbits; t.W = 254 / cbits + 1;
+  t.uses = 0;
 }
 void ensure_table_g1(Ctx& c, BaseTable& t, const uint32_t* row0, size_t n, int cbits) { ensure_table<FqTag>(c, t, row0, n, cbits); }
 void ensure_table_g2(Ctx& c, BaseTable& t, const uint32_t* row0, size_t n, int cbits) { ensure_table<Fq2Tag>(c, t, row0, n, cbits); }
+
+// ---- when a base array gets its table (gs_set_table_policy) ---------------------------------------------------------------------
+// The reference proves ONCE per key load (cli/main.go:330-349); 15-row tables cost ~140 ms and 15x the key's memory at 2^20 -- fifteen
+// proofs' worth of work before the first one.  Under `auto` a base array is summed table-free until it has been used
+// kTableAfterUses times; then its table is built on the table stream (lowest priority, behind and beside the proofs that keep
+// running table-free) and the first call that finds the build complete switches over.
+constexpr uint32_t kTableAfterUses = 2;
+
+void table_settle(Ctx& c, BaseTable& t, bool install) {
+  if (!t.pending.p) return;
+  if (c.table_stream) GS_HIP(hipStreamSynchronize(c.table_stream));
+  if (install) {
+    t.rows = std::move(t.pending);
+    t.n = t.pending_n; t.c = t.pending_c; t.W = 254 / t.pending_c + 1;
+    t.uses = 0;
+  } else t.pending.release();
+  t.pending_c = 0; t.pending_n = 0;
+}
+
+static void start_background_build(Ctx& c, BaseTable& t, const TableRef& r, int cbits) {
+  if (!c.table_stream) {
+    int least = 0, greatest = 0;
+    GS_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    GS_HIP(hipStreamCreateWithPriority(&c.table_stream, hipStreamNonBlocking, least));
+  }
+  if (!t.pending_done) GS_HIP(hipEventCreateWithFlags(&t.pending_done, hipEventDisableTiming));
+  DevBuf& scratch = msm_state(c).table_scratch_bg;
+  try {
+    if (r.g2) enqueue_table_build<Fq2Tag>(c, c.table_stream, scratch, r.row0, r.n, cbits, t.pending);
+    else enqueue_table_build<FqTag>(c, c.table_stream, scratch, r.row0, r.n, cbits, t.pending);
+  } catch (const HipError& e) {
+    if (e.e != hipErrorOutOfMemory) throw;      // no room for a table: keep summing table-free
+    t.pending.release();
+    return;
+  }
+  t.pending_c = cbits; t.pending_n = r.n;
+  GS_HIP(hipEventRecord(t.pending_done, c.table_stream));
+}
+
+bool prepare_tables(Ctx& c, const std::vector<TableRef>& group, uint32_t nterms, int* cbits) {
+  const int cb = choose_window_bits(std::max<uint32_t>(nterms, 1u), c.window_bits);
+  bool all_ready = true;
+  for (const TableRef& r : group) {
+    BaseTable& t = *r.t;
+    t.last_use = c.call_clock;
+    if (t.pending.p && hipEventQuery(t.pending_done) == hipSuccess) {          // a background build came through
+      if (t.pending_c == cb && t.pending_n == r.n) table_settle(c, t, true); else table_settle(c, t, false);
+    }
+    (void)hipGetLastError();                                                   // hipErrorNotReady is not an error
+    all_ready = all_ready && t.ready(r.n, cb);
+  }
+  if (all_ready) { *cbits = cb; return true; }
+  if (c.table_policy == 1) {                                                   // always: inside the call, as rounds 1-4 did
+    for (const TableRef& r : group) {
+      if (r.g2) ensure_table_g2(c, *r.t, r.row0, r.n, cb); else ensure_table_g1(c, *r.t, r.row0, r.n, cb);
+    }
+    *cbits = cb;
+    return true;
+  }
+  if (c.table_policy == 0) {
+    for (const TableRef& r : group) {
+      BaseTable& t = *r.t;
+      if (t.ready(r.n, cb)) continue;
+      t.uses += 1;
+      if (t.uses >= kTableAfterUses && !t.pending.p && r.n) start_background_build(c, t, r, cb);
+    }
+  }
+  *cbits = choose_window_bits_free(std::max<uint32_t>(nterms, 1u), c.window_bits);
+  return false;
+}
 
 template <class T>
 static void msm_enqueue(Ctx& c, const MsmPlan& plan, const std::vector<MsmBase>& bases, int ws_base, int slot, MsmPending& p,
@@ -219,10 +320,19 @@ static void msm_enqueue(Ctx& c, const MsmPlan& plan, const std::vector<MsmBase>&
   static const uint32_t l_min = (uint32_t)dev_knob("GS_REDUCE_L", 4, 1, 32, 1, true);
   int L = (int)std::max<uint32_t>(1u, std::min<uint32_t>(l_min, plan.B / kReduceBlock));
   while (L < 32 && plan.B / ((uint32_t)kReduceBlock * (uint32_t)L) > fold_max) L *= 2;
-  const uint32_t nblk = (plan.B + kReduceBlock * L - 1) / (kReduceBlock * L);
+  uint32_t nblk = (plan.B + kReduceBlock * L - 1) / (kReduceBlock * L);
+  if (plan.table_free) {
+    // Per-window bucket sets (B >= 256 = one reduce workgroup, a power of two: a workgroup never straddles two windows).  The same
+    // kernel reduces all W * B buckets; workgroup blk belongs to window blk / (B / (256 L)) and the host folds each window's pairs,
+    // then recombines the window sums by Horner.  L = 16 keeps the pairs of a 6-job Pinocchio group inside the pinned slot.
+    L = (int)std::max<uint32_t>(1u, std::min<uint32_t>(16u, plan.B / kReduceBlock));
+    p.nblk_window = plan.B / ((uint32_t)kReduceBlock * (uint32_t)L);
+    nblk = p.nblk_window * (uint32_t)plan.W;
+    p.table_free = true;
+  }
   p.L = L; p.nblk = nblk;
-  p.folded = nblk > fold_max;                             // wide windows: the pairs are folded on the device (k_pair_reduce)
-  if (nblk > (uint32_t)kReduceBlock) throw HipError{hipErrorInvalidValue, "too many reduce workgroups for one fold", __LINE__};
+  p.folded = !plan.table_free && nblk > fold_max;         // wide windows: the pairs are folded on the device (k_pair_reduce)
+  if (p.folded && nblk > (uint32_t)kReduceBlock) throw HipError{hipErrorInvalidValue, "too many reduce workgroups for one fold", __LINE__};
   // result staging: [pairs | finals | stats], downloaded in ONE copy: pairs .. stats (host fold) or finals .. stats (device fold).
   // stats = {bucket entries of the plan, buckets combined by the heavy tree} (k_bucket_combine writes them; gs_timing reports them)
   const size_t pair_bytes = (size_t)njobs * nblk * 2 * pw * 4, final_bytes = (size_t)njobs * pw * 4, stats_bytes = 16;
@@ -236,15 +346,25 @@ static void msm_enqueue(Ctx& c, const MsmPlan& plan, const std::vector<MsmBase>&
   uint32_t* stats = finals + final_bytes / 4;
   for (int j = 0; j < njobs; ++j) {
     const BaseTable* t = bases[j].table;
-    if (!t || t->c != plan.c || bases[j].off + plan.n > t->n)
-      throw HipError{hipErrorInvalidValue, "MSM base table does not match the plan", __LINE__};
+    const uint32_t* points = nullptr;
+    uint32_t row_stride = 0;
+    if (plan.table_free) {               // every window adds the base point itself: "row" w of a table with stride 0
+      if (!bases[j].points || bases[j].off + plan.n > bases[j].npoints)
+        throw HipError{hipErrorInvalidValue, "MSM base array does not cover the plan", __LINE__};
+      points = bases[j].points + bases[j].off * aw;
+    } else {
+      if (!t || t->c != plan.c || !t->rows.p || bases[j].off + plan.n > t->n)
+        throw HipError{hipErrorInvalidValue, "MSM base table does not match the plan", __LINE__};
+      points = t->rows.as<uint32_t>() + bases[j].off * aw;
+      row_stride = (uint32_t)t->n;
+    }
     DevBuf& bk = c.ws_buckets[(ws_base + j) % Ctx::kWsSets];
     DevBuf& mg = c.ws_chunks[(ws_base + j) % Ctx::kWsSets];
     DevBuf& pt = c.ws_partials[(ws_base + j) % Ctx::kWsSets];
     bk.ensure((size_t)plan.nbuckets * pw * 4);
-    mg.ensure((size_t)plan.B * pw * 4);
+    mg.ensure((size_t)plan.nbuckets * pw * 4);
     pt.ensure((size_t)plan.maxchunks * 2 * pw * 4);
-    jobs.j[j] = AccJob{t->rows.as<uint32_t>() + bases[j].off * aw, (uint32_t)t->n, bk.as<uint32_t>(), pt.as<uint32_t>(),
+    jobs.j[j] = AccJob{points, row_stride, bk.as<uint32_t>(), pt.as<uint32_t>(),
                        pt.as<uint32_t>() + (size_t)plan.maxchunks * pw, mg.as<uint32_t>(),
                        outb.as<uint32_t>() + (size_t)j * nblk * 2 * pw, finals + (size_t)j * pw};
   }
@@ -275,9 +395,9 @@ static void msm_enqueue(Ctx& c, const MsmPlan& plan, const std::vector<MsmBase>&
                        jobs, plan.offsets, plan.heavy_list, plan.heavy_count, plan.chunk);
     hipLaunchKernelGGL((k_heavy_finish<T, kAlone>), dim3(16, njobs), dim3(kHeavyBlock), 0, ts,
                        jobs, plan.offsets, plan.heavy_list, plan.heavy_count, plan.chunk);
-    hipLaunchKernelGGL((k_bucket_combine<T, kAlone>), dim3((plan.B + 255) / 256, njobs), dim3(256), 0, ts, jobs, plan.offsets, plan.B, plan.chunk,
-                       plan.heavy_count, stats);
-    hipLaunchKernelGGL((k_block_reduce<T, kAlone>), dim3(nblk, njobs), dim3(kReduceBlock), 0, ts, jobs, plan.B, L);
+    hipLaunchKernelGGL((k_bucket_combine<T, kAlone>), dim3((plan.nbuckets + 255) / 256, njobs), dim3(256), 0, ts, jobs, plan.offsets, plan.nbuckets,
+                       plan.chunk, plan.heavy_count, stats);
+    hipLaunchKernelGGL((k_block_reduce<T, kAlone>), dim3(nblk, njobs), dim3(kReduceBlock), 0, ts, jobs, plan.nbuckets, L);
     if (p.folded) {
       int log2_span = 0;
       while ((1u << log2_span) < (uint32_t)kReduceBlock * (uint32_t)L) ++log2_span;
@@ -325,6 +445,18 @@ void msm_book_timing(Ctx& c, const MsmPending& p) {
   if (p.pinned_slot) c.timing.heavy_buckets += st[1];
 }
 
+// table-free route: the pairs of a job come window by window (nblk_window each); S_w = sum_pairs of window w, and the result is
+// sum_w 2^(c w) S_w by Horner from the top window down (W c doublings + W additions on a host core).
+template <class T>
+static Xyzz<T> sum_pairs_windows(const Xyzz<T>* pr, const MsmPending& p) {
+  Xyzz<T> acc = xyzz_inf<T>();
+  for (int w = p.W; w-- > 0;) {
+    for (int k = 0; k < p.c; ++k) xyzz_dbl(acc);
+    xyzz_add(acc, sum_pairs<T>(pr + (size_t)w * p.nblk_window * 2, p.nblk_window, p.L));
+  }
+  return acc;
+}
+
 template <class T>
 static void msm_finish(Ctx& c, const MsmPending& p, std::vector<Xyzz<T>>& out) {
   if (p.njobs <= 0) { out.assign(-p.njobs, xyzz_inf<T>()); return; }
@@ -334,10 +466,13 @@ static void msm_finish(Ctx& c, const MsmPending& p, std::vector<Xyzz<T>>& out) {
     for (int j = 0; j < p.njobs; ++j) out[j] = pairs[j];
     return;
   }
+  auto one = [pairs, &p](int j) {
+    const Xyzz<T>* pr = pairs + (size_t)j * p.nblk * 2;
+    return p.table_free ? sum_pairs_windows<T>(pr, p) : sum_pairs<T>(pr, p.nblk, p.L);
+  };
   std::vector<std::future<Xyzz<T>>> fut;
-  for (int j = 1; j < p.njobs; ++j)
-    fut.push_back(std::async(std::launch::async, [=] { return sum_pairs<T>(pairs + (size_t)j * p.nblk * 2, p.nblk, p.L); }));
-  out[0] = sum_pairs<T>(pairs, p.nblk, p.L);
+  for (int j = 1; j < p.njobs; ++j) fut.push_back(std::async(std::launch::async, [one, j] { return one(j); }));
+  out[0] = one(0);
   for (int j = 1; j < p.njobs; ++j) out[j] = fut[j - 1].get();
 }
 

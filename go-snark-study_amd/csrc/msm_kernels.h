@@ -40,6 +40,7 @@ struct PlanParams {
   uint32_t slice;    // scalars per slice
   uint32_t stride;   // row stride of the digit matrix (elements)
   uint32_t R;        // bucket ranges of kRangeBuckets counters each (B <= 2^15: one range; c = 20: sixteen)
+  uint32_t tf;       // table-free route: a bucket set PER WINDOW (bucket id = w * B + |d| - 1; msm.h, MsmPlan) instead of one for all
 };
 // One histogram / scatter workgroup keeps the counters of ONE bucket range in LDS (2^15 u32 = 128 KiB of the CU's 160 KiB) and
 // counts the digits of its (window, slice) that fall into it; wide windows (c > 16) take R = B / 2^15 such workgroups per
@@ -115,6 +116,19 @@ __global__ void __launch_bounds__(256) k_colscan(uint32_t* __restrict__ hist, Pl
   totals[b] = run;
 }
 
+// The table-free route keeps the windows apart: hist[q][b], q = w*S + s  ->  exclusive prefix over the SLICES of window w only;
+// totals[w * B + b] = the entries of bucket (w, b).  (B <= 2^15 on that route: one range.)
+__global__ void __launch_bounds__(256) k_colscan_windows(uint32_t* __restrict__ hist, PlanParams pp, uint32_t* __restrict__ totals) {
+  wave_priority<GS_PRIO_PLAN>();
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (uint32_t)pp.W * pp.B) return;
+  const uint32_t w = i / pp.B, b = i % pp.B;
+  uint32_t* col = hist + (size_t)w * pp.S * pp.B + b;
+  uint32_t run = 0;
+  for (uint32_t q = 0; q < pp.S; ++q) { const uint32_t t = col[(size_t)q * pp.B]; col[(size_t)q * pp.B] = run; run += t; }
+  totals[i] = run;
+}
+
 // ---- plan, step 4: counting-sort scatter; the cursors of the workgroup's bucket range live in LDS -------------------
 // entry = sign (bit 31) | window (bits 30..26) | term index (bits 25..0)
 __global__ void __launch_bounds__(kSortBlock) k_scatter(const digit_t* __restrict__ digits, PlanParams pp, const uint32_t* __restrict__ hist,
@@ -124,7 +138,8 @@ __global__ void __launch_bounds__(kSortBlock) k_scatter(const digit_t* __restric
   const uint32_t w = blockIdx.x, s = blockIdx.y, r = blockIdx.z;
   const uint32_t nb = min(pp.B, kRangeBuckets), base = r << kRangeLog;
   const uint32_t* pre = hist + ((size_t)w * pp.S + s) * pp.B + base;
-  for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) sh[b] = offsets[base + b] + pre[b];
+  const uint32_t* off = offsets + (pp.tf ? (size_t)w * pp.B : (size_t)0);      // table-free: window w's own bucket set
+  for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) sh[b] = off[base + b] + pre[b];
   __syncthreads();
   const uint32_t lo = s * pp.slice, hi = min(pp.n, lo + pp.slice);
   const digit_t* row = digits + (size_t)w * pp.stride;

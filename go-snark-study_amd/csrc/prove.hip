@@ -31,6 +31,8 @@ struct DevScalars {            // a scalar vector used by a prove call (not owne
   size_t n;
   const uint64_t* host = nullptr;   // if set: `p` is a staging buffer that still has to be filled from here, on the stream
                                     // that consumes it (so the PCIe copy of px overlaps the accumulations over w)
+  hipStream_t host_stream = nullptr;   // ... or (host-buffer tickets) on this stream, with the consumer waiting for `host_done`,
+  hipEvent_t host_done = nullptr;      //     so that the DMA does not queue behind the previous proof's polynomial stage
   std::function<void(Ctx&)> produce;   // if set: `p` is an output buffer this call still has to compute, on the stream that
                                        // consumes it (px from the resident R1CS, behind the accumulations over w)
   std::function<bool(Ctx&, uint32_t*)> produce_hx;   // if set: try to compute hx = px / Z directly (poly.h: hx_direct_dev) into the given
@@ -49,6 +51,10 @@ struct ProveState {
   DevBuf hx[Ctx::kSlots];                       // hx = floor(px / Z) -- or H's values on the evaluation-basis route --, one per slot (standard form)
   DevBuf up_w, up_px, up_a, up_b, up_o;         // uploads of host operands / results (blocking entry points only)
   DevBuf exact_px[Ctx::kSlots];                 // px of the exact witness route, one per slot (allocated only if that route is ever taken)
+  // Host-buffer tickets (gs_*_host_begin): every in-flight slot owns the device copies of ITS w / px.  Grow-only, so a stream of
+  // proofs from host memory allocates nothing after its first lap over the slots (gs_alloc_counters); a slot is re-used only after
+  // its ticket was collected, i.e. after every device read of these buffers.
+  DevBuf slot_w[Ctx::kSlots], slot_px[Ctx::kSlots];
 };
 ProveState& prove_state(Ctx& c) { return c.state<ProveState>(c.prove_state); }
 
@@ -99,8 +105,44 @@ struct GrothTailEarly {
   bool done = false;
   G1Xyzz piA, piB1, sA, rB;
 };
+// The streams ONE proof's device work is enqueued on, decided once per proof (round 4 toggled a context flag between two
+// evaluations of an accessor instead).  plan(w) of a pipelined proof gets its own stream (aux 2, every tail then shares aux 0) where
+// the polynomial stage is long: on aux 1 the NEXT proof's plan(w) queues behind this proof's H stage and plan(h), and the
+// accumulation stream then waits ~0.3 ms twice per proof.  Measured (profiles/r04_ab_plan_w_stream.txt): witness route at 2^20
+// 10.2-10.3 -> 9.8 ms, at 2^19 5.55 -> 5.17, px route at 2^22 35.9 -> 35.4 ms, but the px route at 2^20 (H(x) is only 0.7 ms there)
+// 8.7-8.9 -> 9.0-9.1: hence the rule.  GS_PLANW_STREAM: 0 never, 1 this rule, 2 always (identical results).
+struct ProofStreams {
+  hipStream_t planw = nullptr, poly = nullptr, tail_g2 = nullptr, tail_g1 = nullptr;
+};
+struct DevScalars;
+static ProofStreams proof_streams(Ctx& c, bool pipelined, size_t nterms, bool from_witness) {
+  static const long mode = run_knob("GS_PLANW_STREAM", 1, 0, 2);
+  const bool own = pipelined && c.aux_stream[2] != c.aux_stream[1] &&
+                   (mode == 2 || (mode == 1 && nterms >= ((size_t)1 << 19) && (from_witness || nterms >= ((size_t)1 << 21))));
+  if (pipelined) c.next_tails((uint32_t)nterms);      // consecutive pipelined operations swap the two tail streams
+  ProofStreams ps;
+  ps.poly = c.aux_stream[1];
+  ps.planw = own ? c.aux_stream[2] : c.aux_stream[1];
+  ps.tail_g2 = own ? c.aux_stream[0] : c.tail_stream(0);
+  ps.tail_g1 = own ? c.aux_stream[0] : c.tail_stream(1);
+  return ps;
+}
+
+// Inputs that arrive in host memory with a ticket (gs_*_host_begin): staged on the copy stream into the slot's own buffers.
+struct HostInputs {
+  hipEvent_t w_done = nullptr, px_done = nullptr;       // recorded on the copy stream behind the last DMA of w / px
+  std::shared_ptr<PhaseTimer> th2d;                     // read when the ticket is collected (a read here would wait for the copy)
+  void create() {
+    if (!w_done) GS_HIP(hipEventCreateWithFlags(&w_done, hipEventDisableTiming));
+    if (!px_done) GS_HIP(hipEventCreateWithFlags(&px_done, hipEventDisableTiming));
+  }
+  ~HostInputs() { for (hipEvent_t e : {w_done, px_done}) if (e) (void)hipEventDestroy(e); }
+};
+
 struct GrothInFlight : InFlightBase {
   GrothPkObj* pk = nullptr;
+  ProofStreams streams;
+  HostInputs in;
   uint64_t r[4] = {0, 0, 0, 0}, s[4] = {0, 0, 0, 0};
   bool with_tail = false;
   GrothTailEarly early;
@@ -127,22 +169,6 @@ struct GrothInFlight : InFlightBase {
 
 static void groth16_tail_pre(GrothPkObj* pk, const uint64_t r[4], const uint64_t s[4], GrothTailPre& pre);
 
-// plan(w) of a pipelined proof on its own stream (aux 2, the tails then share aux 0) where the polynomial stage is long: on aux 1 the
-// NEXT proof's plan(w) queues behind this proof's H stage and plan(h), and the accumulation stream then waits ~0.3 ms twice per proof.
-// Measured (profiles/r04_ab_plan_w_stream.txt): witness route at 2^20 10.2-10.3 -> 9.8 ms, at 2^19 5.55 -> 5.17, px route at 2^22 35.9 ->
-// 35.4 ms, but the px route at 2^20 (H(x) is only 0.7 ms there) 8.7-8.9 -> 9.0-9.1: hence the rule.  GS_PLANW_STREAM: 0 never, 1 this
-// rule, 2 always (identical results).  The scope object resets the choice when the enqueue function returns.
-struct PlanWStream {
-  Ctx& c;
-  PlanWStream(Ctx& ctx_, bool pipelined, size_t nterms, const DevScalars& px) : c(ctx_) {
-    static const long mode = run_knob("GS_PLANW_STREAM", 1, 0, 2);
-    const bool from_witness = (bool)px.produce_hv || (bool)px.produce_hx || (bool)px.produce;   // (not hv_slice: no polynomial work here)
-    c.planw_own = pipelined && c.aux_stream[2] != c.aux_stream[1] &&
-                  (mode == 2 || (mode == 1 && nterms >= ((size_t)1 << 19) && (from_witness || nterms >= ((size_t)1 << 21))));
-  }
-  ~PlanWStream() { c.planw_own = false; }
-};
-
 // Enqueue every device operation of one proof (no host wait).  `wait_inputs`: w / px were uploaded on the main stream
 // in this call, so the aux streams must order themselves behind that point.
 int groth16_enqueue(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, const Shard& shard, int parity, bool wait_inputs, bool pipelined,
@@ -166,17 +192,15 @@ int groth16_enqueue(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, const S
   } else shard_range(nh, shard, hlo, hhi);
   const size_t held_lo = eval ? pk->e_lo : pk->h_lo;
   const size_t wbase = wlo - pk->w_lo, hbase = hlo - std::min(held_lo, hlo);      // offsets into the arrays this key holds
-  {
-    const int cw = choose_window_bits((uint32_t)std::max<size_t>(whi - wlo, 1), c.window_bits);
-    const int ch = choose_window_bits((uint32_t)std::max<size_t>(hhi - hlo, 1), c.window_bits);
-    ensure_table_g1(c, pk->t_at, pk->at.as<uint32_t>(), pk->n_w, cw);
-    ensure_table_g1(c, pk->t_bacgamma1, pk->bacgamma1.as<uint32_t>(), pk->n_w, cw);
-    ensure_table_g1(c, pk->t_bacdelta, pk->bacdelta.as<uint32_t>(), pk->n_w, cw);
-    ensure_table_g2(c, pk->t_bacgamma2, pk->bacgamma2.as<uint32_t>(), pk->n_w, cw);
-    if (eval) ensure_table_g1(c, pk->t_ptd_eval, pk->ptd_eval.as<uint32_t>(), pk->n_e, ch);
-    else ensure_table_g1(c, pk->t_ptd, pk->ptd.as<uint32_t>(), pk->n_h, ch);
-    hxbuf.ensure(std::max<size_t>(nh, 1) * 32);
-  }
+  // window tables or table-free, per plan (msm.h, prepare_tables: the four arrays over w share one plan, so they go one way together)
+  int cw = 0, ch = 0;
+  const bool tab_w = prepare_tables(c, {TableRef{&pk->t_at, pk->at.as<uint32_t>(), pk->n_w, false}, TableRef{&pk->t_bacgamma1, pk->bacgamma1.as<uint32_t>(), pk->n_w, false},
+                                        TableRef{&pk->t_bacdelta, pk->bacdelta.as<uint32_t>(), pk->n_w, false},
+                                        TableRef{&pk->t_bacgamma2, pk->bacgamma2.as<uint32_t>(), pk->n_w, true}}, (uint32_t)(whi - wlo), &cw);
+  const bool tab_h = prepare_tables(c, {eval ? TableRef{&pk->t_ptd_eval, pk->ptd_eval.as<uint32_t>(), pk->n_e, false}
+                                             : TableRef{&pk->t_ptd, pk->ptd.as<uint32_t>(), pk->n_h, false}}, (uint32_t)(hhi - hlo), &ch);
+  hxbuf.ensure(std::max<size_t>(nh, 1) * 32);
+  auto base_w = [&](BaseTable& t, const DevBuf& pts) { return MsmBase{&t, wbase, pts.as<uint32_t>(), pk->n_w}; };
   st.pk = pk;
   st.total = std::make_unique<PhaseTimer>(c.main_stream);
   if (wait_inputs) {
@@ -190,11 +214,16 @@ int groth16_enqueue(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, const S
   MsmPlan plan_w, plan_h;
   // The main stream carries NOTHING but the ALU-bound bucket accumulations (G2, then the three G1 arrays over w, then h),
   // so with two proofs in flight it never idles: both plans, H(x) and every combine/reduce tail run on the aux streams.
-  PlanWStream planw_scope(c, pipelined, whi - wlo, px);
-  {                                                              // aux 1: plan(w), then H(x), plan(h)
-    StreamScope sc(c, c.planw_stream());
+  const ProofStreams ps = proof_streams(c, pipelined, whi - wlo, (bool)px.produce_hv || (bool)px.produce_hx || (bool)px.produce);   // (not hv_slice: no polynomial work here)
+  st.streams = ps;
+  if (w.host_done) {                                             // w was staged on the copy stream (host-buffer ticket): its readers wait for the DMA
+    GS_HIP(hipStreamWaitEvent(ps.planw, w.host_done, 0));
+    if (ps.poly != ps.planw) GS_HIP(hipStreamWaitEvent(ps.poly, w.host_done, 0));
+  }
+  {                                                              // aux 1 (or aux 2, proof_streams): plan(w)
+    StreamScope sc(c, ps.planw);
     st.tplanw = std::make_shared<PhaseTimer>(c.stream);
-    build_plan(c, 0 + 2 * parity, w.p + wlo * 8, (uint32_t)(whi - wlo), plan_w, {{1, true}, {3, false}});
+    build_plan(c, 0 + 2 * parity, w.p + wlo * 8, (uint32_t)(whi - wlo), plan_w, {{1, true}, {3, false}}, cw, !tab_w);
     st.tplanw->stop();
     GS_HIP(hipEventRecord(st.planw, c.stream));
   }
@@ -207,18 +236,21 @@ int groth16_enqueue(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, const S
     // loop from NPublic+1 (:248-250) equals a full-range MSM sharing w's plan.
     // G2 first: its accumulation (2 waves/SIMD, 256 VGPRs) is the one a foreign wave hurts most, and its long
     // combine/reduce tail then hides behind the G1 accumulations.
-    if (pipelined) c.next_tails(plan_w.n);
-    msm_enqueue_g2(c, plan_w, {MsmBase{&pk->t_bacgamma2, wbase}}, ws + 4, pin + 1, st.pend_g2w, c.tail_stream(0));
-    GS_HIP(hipEventRecord(st.done_g2, c.tail_stream(0)));
-    msm_enqueue_g1(c, plan_w, {MsmBase{&pk->t_at, wbase}, MsmBase{&pk->t_bacgamma1, wbase}, MsmBase{&pk->t_bacdelta, wbase}}, ws + 0, pin + 0,
-                   st.pend_g1w, c.tail_stream(1));
-    GS_HIP(hipEventRecord(st.done_g1w, c.tail_stream(1)));
+    msm_enqueue_g2(c, plan_w, {base_w(pk->t_bacgamma2, pk->bacgamma2)}, ws + 4, pin + 1, st.pend_g2w, ps.tail_g2);
+    GS_HIP(hipEventRecord(st.done_g2, ps.tail_g2));
+    msm_enqueue_g1(c, plan_w, {base_w(pk->t_at, pk->at), base_w(pk->t_bacgamma1, pk->bacgamma1), base_w(pk->t_bacdelta, pk->bacdelta)}, ws + 0, pin + 0,
+                   st.pend_g1w, ps.tail_g1);
+    GS_HIP(hipEventRecord(st.done_g1w, ps.tail_g1));
   }
   // (Starting H(x) and plan(h) of a lone proof beside plan(w) on another stream instead of behind it was tried: the blocking proof
   // got SLOWER, 11.5-11.7 vs 11.0-11.25 ms -- the NTT passes then overlap the G2 accumulation's first milliseconds more densely.)
   {                                                              // aux 1 again: (late upload of px,) H(x), plan(h)
-    StreamScope sc(c, c.aux_stream[1]);
-    if (px.host && px.n) {     // the device is already busy with ~8 ms of accumulations: this copy is off the critical path
+    StreamScope sc(c, ps.poly);
+    if (px.host && px.n && px.host_stream) {   // host-buffer ticket: on the copy stream, beside whatever aux 1 still carries of the previous proof
+      staged_h2d(c, const_cast<uint32_t*>(px.p), px.host, px.n * 32, px.host_stream);
+      GS_HIP(hipEventRecord(px.host_done, px.host_stream));
+      GS_HIP(hipStreamWaitEvent(c.stream, px.host_done, 0));
+    } else if (px.host && px.n) {     // the device is already busy with ~8 ms of accumulations: this copy is off the critical path
       PhaseTimer th(c.stream);
       staged_h2d(c, const_cast<uint32_t*>(px.p), px.host, px.n * 32, c.stream);
       th.stop();
@@ -240,7 +272,7 @@ int groth16_enqueue(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, const S
     }
     st.tpoly->stop();
     st.tplanh = std::make_shared<PhaseTimer>(c.stream);
-    build_plan(c, 1 + 2 * parity, px.hv_slice ? px.hv_slice : hxbuf.as<uint32_t>() + hlo * 8, (uint32_t)(hhi - hlo), plan_h, {{1, false}});
+    build_plan(c, 1 + 2 * parity, px.hv_slice ? px.hv_slice : hxbuf.as<uint32_t>() + hlo * 8, (uint32_t)(hhi - hlo), plan_h, {{1, false}}, ch, !tab_h);
     st.tplanh->stop();
     GS_HIP(hipEventRecord(st.planh, c.stream));
   }
@@ -249,8 +281,9 @@ int groth16_enqueue(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, const S
     GS_HIP(hipStreamWaitEvent(c.stream, st.planh, 0));
     // a lone proof finishes soonest with the last tail right behind its accumulation; in a pipeline that tail must not sit
     // in front of the next proof's accumulations
-    msm_enqueue_g1(c, plan_h, {MsmBase{eval ? &pk->t_ptd_eval : &pk->t_ptd, hbase}}, ws + 3, pin + 2, st.pend_h, pipelined ? c.tail_stream(1) : nullptr);   // :269-271
-    GS_HIP(hipEventRecord(st.done_h, pipelined ? c.tail_stream(1) : c.main_stream));
+    msm_enqueue_g1(c, plan_h, {eval ? MsmBase{&pk->t_ptd_eval, hbase, pk->ptd_eval.as<uint32_t>(), pk->n_e} : MsmBase{&pk->t_ptd, hbase, pk->ptd.as<uint32_t>(), pk->n_h}},
+                   ws + 3, pin + 2, st.pend_h, pipelined ? ps.tail_g1 : nullptr);   // :269-271
+    GS_HIP(hipEventRecord(st.done_h, pipelined ? ps.tail_g1 : c.main_stream));
   }
   st.total->stop();
   GS_HIP(hipEventRecord(st.done_main, c.main_stream));
@@ -305,6 +338,7 @@ int groth16_collect(Ctx& c, GrothInFlight& st, GrothSums& sums) {
   c.timing.poly_ms += st.tpoly->ms();
   c.timing.plan_ms += st.tplanw->ms() + st.tplanh->ms();
   c.timing.total_ms += st.total->ms();
+  if (st.in.th2d) c.timing.h2d_ms += st.in.th2d->ms();
   sums.at = g1w[0]; sums.bacgamma1 = g1w[1]; sums.bacdelta = g1w[2]; sums.h = g1h[0]; sums.bacgamma2 = g2w[0];
   // evaluation-basis route: H's values only determine H when A B - C vanishes at every root of Z
   if (st.bad_host && *st.bad_host != 0) return kRetryExact;
@@ -404,6 +438,8 @@ int groth16_prove_impl(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, cons
 
 // One Pinocchio proof in flight: same stream layout as a Groth16 proof (main = accumulations only).
 struct PinInFlight : InFlightBase {
+  ProofStreams streams;
+  HostInputs in;
   hipEvent_t planw = nullptr, planh = nullptr, done_main = nullptr, done_g2 = nullptr, done_g1w = nullptr, done_h = nullptr;   // as GrothInFlight
   std::unique_ptr<PhaseTimer> total;
   MsmPending pend_g1w, pend_g2w, pend_h;
@@ -439,20 +475,14 @@ int pinocchio_enqueue(Ctx& c, PinocchioPkObj* pk, DevScalars w, DevScalars px, c
   else shard_range(nh, shard, hlo, hhi);
   const size_t held_lo = eval ? pk->e_lo : pk->h_lo;
   const size_t wbase = wlo - pk->w_lo, hbase = hlo - std::min(held_lo, hlo);
-  {
-    const int cw = choose_window_bits((uint32_t)std::max<size_t>(whi - wlo, 1), c.window_bits);
-    const int ch = choose_window_bits((uint32_t)std::max<size_t>(hhi - hlo, 1), c.window_bits);
-    ensure_table_g1(c, pk->t_a, pk->a.as<uint32_t>(), pk->n_w, cw);
-    ensure_table_g1(c, pk->t_ap, pk->ap.as<uint32_t>(), pk->n_w, cw);
-    ensure_table_g1(c, pk->t_bp, pk->bp.as<uint32_t>(), pk->n_w, cw);
-    ensure_table_g1(c, pk->t_c, pk->c.as<uint32_t>(), pk->n_w, cw);
-    ensure_table_g1(c, pk->t_cp, pk->cp.as<uint32_t>(), pk->n_w, cw);
-    ensure_table_g1(c, pk->t_kp, pk->kp.as<uint32_t>(), pk->n_w, cw);
-    ensure_table_g2(c, pk->t_b2, pk->b2.as<uint32_t>(), pk->n_w, cw);
-    if (eval) ensure_table_g1(c, pk->t_g1t_eval, pk->g1t_eval.as<uint32_t>(), pk->n_e, ch);
-    else ensure_table_g1(c, pk->t_g1t, pk->g1t.as<uint32_t>(), pk->n_h, ch);
-    hxbuf.ensure(std::max<size_t>(nh, 1) * 32);
-  }
+  int cw = 0, ch = 0;                          // window tables or table-free, per plan (as groth16_enqueue)
+  auto ref1 = [&](BaseTable& t, const DevBuf& pts) { return TableRef{&t, pts.as<uint32_t>(), pk->n_w, false}; };
+  const bool tab_w = prepare_tables(c, {ref1(pk->t_a, pk->a), ref1(pk->t_ap, pk->ap), ref1(pk->t_bp, pk->bp), ref1(pk->t_c, pk->c), ref1(pk->t_cp, pk->cp),
+                                        ref1(pk->t_kp, pk->kp), TableRef{&pk->t_b2, pk->b2.as<uint32_t>(), pk->n_w, true}}, (uint32_t)(whi - wlo), &cw);
+  const bool tab_h = prepare_tables(c, {eval ? TableRef{&pk->t_g1t_eval, pk->g1t_eval.as<uint32_t>(), pk->n_e, false}
+                                             : TableRef{&pk->t_g1t, pk->g1t.as<uint32_t>(), pk->n_h, false}}, (uint32_t)(hhi - hlo), &ch);
+  hxbuf.ensure(std::max<size_t>(nh, 1) * 32);
+  auto base_w = [&](BaseTable& t, const DevBuf& pts) { return MsmBase{&t, wbase, pts.as<uint32_t>(), pk->n_w}; };
   st.total = std::make_unique<PhaseTimer>(c.main_stream);
   if (wait_inputs) {
     hipEvent_t start;
@@ -463,11 +493,16 @@ int pinocchio_enqueue(Ctx& c, PinocchioPkObj* pk, DevScalars w, DevScalars px, c
   }
   const int ws = 8 * parity, pin = 3 * parity;
   MsmPlan plan_w, plan_h;
-  PlanWStream planw_scope(c, pipelined, whi - wlo, px);
-  {                                                              // aux 1 (or its own stream, PlanWStream): plan(w)
-    StreamScope sc(c, c.planw_stream());
+  const ProofStreams ps = proof_streams(c, pipelined, whi - wlo, (bool)px.produce_hv || (bool)px.produce_hx || (bool)px.produce);
+  st.streams = ps;
+  if (w.host_done) {                                             // host-buffer ticket: w's readers wait for its DMA
+    GS_HIP(hipStreamWaitEvent(ps.planw, w.host_done, 0));
+    if (ps.poly != ps.planw) GS_HIP(hipStreamWaitEvent(ps.poly, w.host_done, 0));
+  }
+  {                                                              // aux 1 (or its own stream, proof_streams): plan(w)
+    StreamScope sc(c, ps.planw);
     st.tplanw = std::make_shared<PhaseTimer>(c.stream);
-    build_plan(c, 2 * parity, w.p + wlo * 8, (uint32_t)(whi - wlo), plan_w, {{1, true}, {6, false}});
+    build_plan(c, 2 * parity, w.p + wlo * 8, (uint32_t)(whi - wlo), plan_w, {{1, true}, {6, false}}, cw, !tab_w);
     st.tplanw->stop();
     GS_HIP(hipEventRecord(st.planw, c.stream));
   }
@@ -476,16 +511,19 @@ int pinocchio_enqueue(Ctx& c, PinocchioPkObj* pk, DevScalars w, DevScalars px, c
     GS_HIP(hipStreamWaitEvent(c.stream, st.planw, 0));
     // A and Ap run over i > NPublic only (snark.go:265-268): their first npublic+1 points were forced
     // to infinity at key creation; Bp, C, Cp, Kp and B run over all variables (:270-278).
-    if (pipelined) c.next_tails(plan_w.n);
-    msm_enqueue_g2(c, plan_w, {MsmBase{&pk->t_b2, wbase}}, ws + 6, pin + 1, st.pend_g2w, c.tail_stream(0));
-    GS_HIP(hipEventRecord(st.done_g2, c.tail_stream(0)));
-    msm_enqueue_g1(c, plan_w, {MsmBase{&pk->t_a, wbase}, MsmBase{&pk->t_ap, wbase}, MsmBase{&pk->t_bp, wbase}, MsmBase{&pk->t_c, wbase},
-                               MsmBase{&pk->t_cp, wbase}, MsmBase{&pk->t_kp, wbase}}, ws + 0, pin + 0, st.pend_g1w, c.tail_stream(1));
-    GS_HIP(hipEventRecord(st.done_g1w, c.tail_stream(1)));
+    msm_enqueue_g2(c, plan_w, {base_w(pk->t_b2, pk->b2)}, ws + 6, pin + 1, st.pend_g2w, ps.tail_g2);
+    GS_HIP(hipEventRecord(st.done_g2, ps.tail_g2));
+    msm_enqueue_g1(c, plan_w, {base_w(pk->t_a, pk->a), base_w(pk->t_ap, pk->ap), base_w(pk->t_bp, pk->bp), base_w(pk->t_c, pk->c),
+                               base_w(pk->t_cp, pk->cp), base_w(pk->t_kp, pk->kp)}, ws + 0, pin + 0, st.pend_g1w, ps.tail_g1);
+    GS_HIP(hipEventRecord(st.done_g1w, ps.tail_g1));
   }
   {                                                              // aux 1 again: H(x), plan(h)
-    StreamScope sc(c, c.aux_stream[1]);
-    if (px.host && px.n) {     // the accumulations over w are already enqueued: this copy is off the critical path
+    StreamScope sc(c, ps.poly);
+    if (px.host && px.n && px.host_stream) {   // host-buffer ticket: on the copy stream (groth16_enqueue)
+      staged_h2d(c, const_cast<uint32_t*>(px.p), px.host, px.n * 32, px.host_stream);
+      GS_HIP(hipEventRecord(px.host_done, px.host_stream));
+      GS_HIP(hipStreamWaitEvent(c.stream, px.host_done, 0));
+    } else if (px.host && px.n) {     // the accumulations over w are already enqueued: this copy is off the critical path
       PhaseTimer th(c.stream);
       staged_h2d(c, const_cast<uint32_t*>(px.p), px.host, px.n * 32, c.stream);
       th.stop();
@@ -507,15 +545,16 @@ int pinocchio_enqueue(Ctx& c, PinocchioPkObj* pk, DevScalars w, DevScalars px, c
     }
     st.tpoly->stop();
     st.tplanh = std::make_shared<PhaseTimer>(c.stream);
-    build_plan(c, 2 * parity + 1, px.hv_slice ? px.hv_slice : hxbuf.as<uint32_t>() + hlo * 8, (uint32_t)(hhi - hlo), plan_h, {{1, false}});
+    build_plan(c, 2 * parity + 1, px.hv_slice ? px.hv_slice : hxbuf.as<uint32_t>() + hlo * 8, (uint32_t)(hhi - hlo), plan_h, {{1, false}}, ch, !tab_h);
     st.tplanh->stop();
     GS_HIP(hipEventRecord(st.planh, c.stream));
   }
   {                                                              // main again: the accumulation over h
     StreamScope sc(c, c.main_stream);
     GS_HIP(hipStreamWaitEvent(c.stream, st.planh, 0));
-    msm_enqueue_g1(c, plan_h, {MsmBase{eval ? &pk->t_g1t_eval : &pk->t_g1t, hbase}}, ws + 7, pin + 2, st.pend_h, pipelined ? c.tail_stream(1) : nullptr);   // :284-286
-    GS_HIP(hipEventRecord(st.done_h, pipelined ? c.tail_stream(1) : c.main_stream));
+    msm_enqueue_g1(c, plan_h, {eval ? MsmBase{&pk->t_g1t_eval, hbase, pk->g1t_eval.as<uint32_t>(), pk->n_e} : MsmBase{&pk->t_g1t, hbase, pk->g1t.as<uint32_t>(), pk->n_h}},
+                   ws + 7, pin + 2, st.pend_h, pipelined ? ps.tail_g1 : nullptr);   // :284-286
+    GS_HIP(hipEventRecord(st.done_h, pipelined ? ps.tail_g1 : c.main_stream));
   }
   st.total->stop();
   GS_HIP(hipEventRecord(st.done_main, c.main_stream));
@@ -541,6 +580,7 @@ int pinocchio_collect(Ctx& c, PinInFlight& st, uint64_t out[72], int inf[8]) {
   c.timing.poly_ms += st.tpoly->ms();
   c.timing.plan_ms += st.tplanw->ms() + st.tplanh->ms();
   c.timing.total_ms += st.total->ms();
+  if (st.in.th2d) c.timing.h2d_ms += st.in.th2d->ms();
   if (st.bad_host && *st.bad_host != 0) return kRetryExact;   // evaluation-basis route on a witness that violates a constraint
   // output order: PiA | PiAp | PiB | PiBp | PiC | PiCp | PiH | PiKp
   inf[0] = g1_to_affine_std(g1w[0], out) ? 1 : 0;
@@ -585,6 +625,46 @@ const uint32_t* upload_tmp(Ctx& c, DevBuf& buf, const uint64_t* host, size_t n) 
 void download(Ctx& c, uint64_t* host, const void* dev, size_t n) {
   if (n) GS_HIP(hipMemcpyAsync(host, dev, n * 32, hipMemcpyDeviceToHost, c.stream));
   GS_HIP(hipStreamSynchronize(c.stream));
+}
+
+// ---- host-buffer tickets -----------------------------------------------------------------------------------------------------
+// The reference hands GenerateProofs a FRESH w (and px) in host memory on every call (groth16/groth16.go:225, cli/main.go:480-501).
+// gs_scalars_upload + gs_*_begin + gs_free costs a hipMalloc, a blocking copy and a hipFree (a device-wide synchronisation) per proof
+// and breaks a pipeline of three; a host-buffer ticket instead stages the caller's arrays into buffers its SLOT owns (grow-only:
+// nothing is allocated or freed once the three slots have been used), on the copy stream, and the streams that read them wait for
+// the copy's event -- the DMA of proof k + 3 runs beside the accumulations of proofs k + 1 and k + 2.  The caller's arrays are
+// consumed when _begin returns (cgo pointer rule).
+static void ensure_copy_stream(Ctx& c) {
+  if (!c.copy_stream) GS_HIP(hipStreamCreateWithFlags(&c.copy_stream, hipStreamNonBlocking));
+}
+// w: staged at once (everything of a proof starts with plan(w))
+DevScalars stage_slot_w(Ctx& c, int parity, const uint64_t* host, size_t n, HostInputs& in) {
+  ensure_copy_stream(c);
+  in.create();
+  in.th2d = std::make_shared<PhaseTimer>(c.copy_stream);
+  DevBuf& b = prove_state(c).slot_w[parity];
+  b.ensure(std::max<size_t>(n, 1) * 32);
+  if (n) staged_h2d(c, b.p, host, n * 32, c.copy_stream);
+  GS_HIP(hipEventRecord(in.w_done, c.copy_stream));
+  DevScalars d{b.as<uint32_t>(), n};
+  d.host_done = in.w_done;
+  return d;
+}
+// px: staged by the enqueue function AFTER the accumulations over w were queued (they do not need it), on the copy stream
+DevScalars slot_px_from_host(Ctx& c, int parity, const uint64_t* host, size_t n, HostInputs& in) {
+  ensure_copy_stream(c);
+  in.create();
+  DevBuf& b = prove_state(c).slot_px[parity];
+  b.ensure(std::max<size_t>(n, 1) * 32);
+  DevScalars d{b.as<uint32_t>(), n, host};
+  d.host_stream = c.copy_stream;
+  d.host_done = in.px_done;
+  return d;
+}
+// a resident vector that a ticket reads: gs_scalars_update must wait for these points (runtime.h, Scalars::reads)
+void mark_ticket_reads(const ProofStreams& ps, Scalars* w, Scalars* px_or_hv) {
+  if (w) { w->mark_read(ps.planw); if (ps.poly != ps.planw) w->mark_read(ps.poly); }
+  if (px_or_hv) px_or_hv->mark_read(ps.poly);
 }
 
 }  // namespace
@@ -825,29 +905,52 @@ int gs_groth16_prove_resident(gs_handle hpk, gs_handle hw, gs_handle hpx, const 
 // Pipelined proving: begin enqueues a whole proof and returns; end waits for THAT proof only and runs its tail.  With two
 // proofs outstanding the device never idles between proofs (the next plan/accumulations are already queued) and the host
 // tail of proof k overlaps the device work of proof k+1.
+// `w_host` / `px_host` non-null: the host-buffer form (gs_groth16_prove_host_begin), hw / hpx are ignored then.
+static int groth16_begin_impl(Ctx& c, const char* fn, gs_handle hpk, gs_handle hw, gs_handle hpx, const uint64_t* w_host, size_t nw,
+                              const uint64_t* px_host, size_t npx, const uint64_t r[4], const uint64_t s[4], uint64_t* ticket) {
+  const bool host = w_host != nullptr || px_host != nullptr;
+  GrothPkObj* pk = c.get<GrothPkObj>(hpk, Kind::GrothPk);
+  Scalars* w = host ? nullptr : c.get<Scalars>(hw, Kind::Scalars);
+  Scalars* px = host ? nullptr : c.get<Scalars>(hpx, Kind::Scalars);
+  if (!pk || (!host && (!w || !px))) return fail(GS_ERR_ARG, "%s: bad handle", fn);
+  if (!r || !s || !ticket || (host && ((nw && !w_host) || (npx && !px_host)))) return fail(GS_ERR_ARG, "null argument");
+  if (host && (nw >= (1ull << 31) || npx >= (1ull << 31))) return fail(GS_ERR_ARG, "%s: too many scalars", fn);
+  if (host && nw != pk->nvars) return fail(GS_ERR_SHAPE, "len(w) = %zu but the key has %zu variables", nw, pk->nvars);   // before anything is staged
+  const int parity = c.free_parity();
+  if (parity < 0) return fail(GS_ERR_BUSY, "%s: three operations are already outstanding; call gs_groth16_prove_end first", fn);
+  auto st = std::make_unique<GrothInFlight>();
+  memcpy(st->r, r, 32); memcpy(st->s, s, 32);
+  st->with_tail = true;
+  GrothInFlight* raw = st.get();
+  raw->pk = pk;
+  raw->keep = {c.share<Object>(hpk, Kind::GrothPk)};
+  if (!host) { raw->keep.push_back(c.share<Object>(hw, Kind::Scalars)); raw->keep.push_back(c.share<Object>(hpx, Kind::Scalars)); }
+  raw->fpre = std::async(std::launch::async, [raw] { groth16_tail_pre(raw->pk, raw->r, raw->s, raw->pre); });
+  raw->early.pk = pk; raw->early.r = raw->r; raw->early.s = raw->s; raw->early.pre = &raw->pre; raw->early.fpre = &raw->fpre;
+  const DevScalars dw = host ? stage_slot_w(c, parity, w_host, nw, raw->in) : DevScalars{w->buf.as<uint32_t>(), w->n};
+  const DevScalars dp = host ? slot_px_from_host(c, parity, px_host, npx, raw->in) : DevScalars{px->buf.as<uint32_t>(), px->n};
+  const int rc = groth16_enqueue(c, pk, dw, dp, Shard{}, parity, false, true, *raw);
+  if (rc != GS_OK) return rc;
+  if (raw->in.th2d) raw->in.th2d->stop();
+  mark_ticket_reads(raw->streams, w, px);
+  st->ticket = c.new_ticket();
+  *ticket = st->ticket;
+  c.inflight[parity] = std::move(st);
+  return GS_OK;
+}
+
 int gs_groth16_prove_begin(gs_handle hpk, gs_handle hw, gs_handle hpx, const uint64_t r[4], const uint64_t s[4], uint64_t* ticket) {
   return guarded([&](Ctx& c) -> int {
-    GrothPkObj* pk = c.get<GrothPkObj>(hpk, Kind::GrothPk);
-    Scalars* w = c.get<Scalars>(hw, Kind::Scalars);
-    Scalars* px = c.get<Scalars>(hpx, Kind::Scalars);
-    if (!pk || !w || !px) return fail(GS_ERR_ARG, "gs_groth16_prove_begin: bad handle");
-    if (!r || !s || !ticket) return fail(GS_ERR_ARG, "null argument");
-    const int parity = c.free_parity();
-    if (parity < 0) return fail(GS_ERR_BUSY, "gs_groth16_prove_begin: three operations are already outstanding; call gs_groth16_prove_end first");
-    auto st = std::make_unique<GrothInFlight>();
-    memcpy(st->r, r, 32); memcpy(st->s, s, 32);
-    st->with_tail = true;
-    GrothInFlight* raw = st.get();
-    raw->pk = pk;
-    raw->keep = {c.share<Object>(hpk, Kind::GrothPk), c.share<Object>(hw, Kind::Scalars), c.share<Object>(hpx, Kind::Scalars)};
-    raw->fpre = std::async(std::launch::async, [raw] { groth16_tail_pre(raw->pk, raw->r, raw->s, raw->pre); });
-    raw->early.pk = pk; raw->early.r = raw->r; raw->early.s = raw->s; raw->early.pre = &raw->pre; raw->early.fpre = &raw->fpre;
-    const int rc = groth16_enqueue(c, pk, DevScalars{w->buf.as<uint32_t>(), w->n}, DevScalars{px->buf.as<uint32_t>(), px->n}, Shard{}, parity, false, true, *raw);
-    if (rc != GS_OK) return rc;
-    st->ticket = c.new_ticket();
-    *ticket = st->ticket;
-    c.inflight[parity] = std::move(st);
-    return GS_OK;
+    return groth16_begin_impl(c, "gs_groth16_prove_begin", hpk, hw, hpx, nullptr, 0, nullptr, 0, r, s, ticket);
+  }, true, true, hpk);
+}
+
+// groth16.GenerateProofs' own call shape, pipelined: w and px in caller memory, new ones with every call (host-buffer ticket, above).
+int gs_groth16_prove_host_begin(gs_handle hpk, const uint64_t* w, size_t nw, const uint64_t* px, size_t npx, const uint64_t r[4], const uint64_t s[4],
+                                uint64_t* ticket) {
+  return guarded([&](Ctx& c) -> int {
+    if (!w || !px) return fail(GS_ERR_ARG, "gs_groth16_prove_host_begin: null w or px");
+    return groth16_begin_impl(c, "gs_groth16_prove_host_begin", hpk, 0, 0, w, nw, px, npx, r, s, ticket);
   }, true, true, hpk);
 }
 
@@ -1001,6 +1104,7 @@ int gs_groth16_partials_values_begin(gs_handle hpk, gs_handle hw, gs_handle hv_s
     dh.hv_slice = hv->buf.as<uint32_t>();
     const int rc = groth16_enqueue(c, pk, DevScalars{w->buf.as<uint32_t>(), w->n}, dh, sh, parity, false, true, *st);
     if (rc != GS_OK) return rc;
+    mark_ticket_reads(st->streams, w, hv);
     st->ticket = c.new_ticket();
     *ticket = st->ticket;
     c.inflight[parity] = std::move(st);
@@ -1113,22 +1217,43 @@ int gs_pinocchio_prove(gs_handle hpk, const uint64_t* w, size_t nw, const uint64
 }
 
 // Pipelined Pinocchio proving: same ticket discipline as gs_groth16_prove_begin / _end (they share the three slots).
+static int pinocchio_begin_impl(Ctx& c, const char* fn, gs_handle hpk, gs_handle hw, gs_handle hpx, const uint64_t* w_host, size_t nw,
+                                const uint64_t* px_host, size_t npx, uint64_t* ticket) {
+  const bool host = w_host != nullptr || px_host != nullptr;
+  PinocchioPkObj* pk = c.get<PinocchioPkObj>(hpk, Kind::PinocchioPk);
+  Scalars* w = host ? nullptr : c.get<Scalars>(hw, Kind::Scalars);
+  Scalars* px = host ? nullptr : c.get<Scalars>(hpx, Kind::Scalars);
+  if (!pk || (!host && (!w || !px)) || !ticket) return fail(GS_ERR_ARG, "%s: bad handle or null ticket", fn);
+  if (host && ((nw && !w_host) || (npx && !px_host))) return fail(GS_ERR_ARG, "null argument");
+  if (host && (nw >= (1ull << 31) || npx >= (1ull << 31))) return fail(GS_ERR_ARG, "%s: too many scalars", fn);
+  if (host && nw != pk->nvars) return fail(GS_ERR_SHAPE, "len(w) = %zu but the key has %zu variables", nw, pk->nvars);
+  const int parity = c.free_parity();
+  if (parity < 0) return fail(GS_ERR_BUSY, "%s: three operations are already outstanding; call gs_pinocchio_prove_end first", fn);
+  auto st = std::make_unique<PinInFlight>();
+  st->keep = {c.share<Object>(hpk, Kind::PinocchioPk)};
+  if (!host) { st->keep.push_back(c.share<Object>(hw, Kind::Scalars)); st->keep.push_back(c.share<Object>(hpx, Kind::Scalars)); }
+  const DevScalars dw = host ? stage_slot_w(c, parity, w_host, nw, st->in) : DevScalars{w->buf.as<uint32_t>(), w->n};
+  const DevScalars dp = host ? slot_px_from_host(c, parity, px_host, npx, st->in) : DevScalars{px->buf.as<uint32_t>(), px->n};
+  const int rc = pinocchio_enqueue(c, pk, dw, dp, Shard{}, parity, false, true, *st);
+  if (rc != GS_OK) return rc;
+  if (st->in.th2d) st->in.th2d->stop();
+  mark_ticket_reads(st->streams, w, px);
+  st->ticket = c.new_ticket();
+  *ticket = st->ticket;
+  c.inflight[parity] = std::move(st);
+  return GS_OK;
+}
+
 int gs_pinocchio_prove_begin(gs_handle hpk, gs_handle hw, gs_handle hpx, uint64_t* ticket) {
   return guarded([&](Ctx& c) -> int {
-    PinocchioPkObj* pk = c.get<PinocchioPkObj>(hpk, Kind::PinocchioPk);
-    Scalars* w = c.get<Scalars>(hw, Kind::Scalars);
-    Scalars* px = c.get<Scalars>(hpx, Kind::Scalars);
-    if (!pk || !w || !px || !ticket) return fail(GS_ERR_ARG, "gs_pinocchio_prove_begin: bad handle or null ticket");
-    const int parity = c.free_parity();
-    if (parity < 0) return fail(GS_ERR_BUSY, "gs_pinocchio_prove_begin: three operations are already outstanding; call gs_pinocchio_prove_end first");
-    auto st = std::make_unique<PinInFlight>();
-    st->keep = {c.share<Object>(hpk, Kind::PinocchioPk), c.share<Object>(hw, Kind::Scalars), c.share<Object>(hpx, Kind::Scalars)};
-    const int rc = pinocchio_enqueue(c, pk, DevScalars{w->buf.as<uint32_t>(), w->n}, DevScalars{px->buf.as<uint32_t>(), px->n}, Shard{}, parity, false, true, *st);
-    if (rc != GS_OK) return rc;
-    st->ticket = c.new_ticket();
-    *ticket = st->ticket;
-    c.inflight[parity] = std::move(st);
-    return GS_OK;
+    return pinocchio_begin_impl(c, "gs_pinocchio_prove_begin", hpk, hw, hpx, nullptr, 0, nullptr, 0, ticket);
+  }, true, true, hpk);
+}
+
+int gs_pinocchio_prove_host_begin(gs_handle hpk, const uint64_t* w, size_t nw, const uint64_t* px, size_t npx, uint64_t* ticket) {
+  return guarded([&](Ctx& c) -> int {
+    if (!w || !px) return fail(GS_ERR_ARG, "gs_pinocchio_prove_host_begin: null w or px");
+    return pinocchio_begin_impl(c, "gs_pinocchio_prove_host_begin", hpk, 0, 0, w, nw, px, npx, ticket);
   }, true, true, hpk);
 }
 
@@ -1535,47 +1660,89 @@ int gs_groth16_prove_witness(gs_handle hpk, gs_handle hr1cs, gs_handle hw, const
 
 // The same, pipelined: a ticket for gs_groth16_prove_end (which also runs the exact route, blocking, should the witness turn out
 // to violate a constraint).  With an evaluation-basis key nothing in here waits for the device.
+static int groth16_witness_begin_impl(Ctx& c, const char* fn, gs_handle hpk, gs_handle hr1cs, gs_handle hw, const uint64_t* w_host, size_t nw_host,
+                                      const uint64_t r[4], const uint64_t s[4], uint64_t* ticket) {
+  GrothPkObj* pk = c.get<GrothPkObj>(hpk, Kind::GrothPk);
+  R1csObj* o = c.get<R1csObj>(hr1cs, Kind::R1cs);
+  Scalars* w = w_host ? nullptr : c.get<Scalars>(hw, Kind::Scalars);
+  if (!pk || !o || (!w_host && !w)) return fail(GS_ERR_ARG, "%s: bad handle", fn);
+  if (!r || !s || !ticket) return fail(GS_ERR_ARG, "null argument");
+  const size_t nw = w_host ? nw_host : w->n;
+  if (nw != o->m) return fail(GS_ERR_SHAPE, "len(w) = %zu but the system has %zu variables", nw, o->m);
+  if (nw != pk->nvars) return fail(GS_ERR_SHAPE, "len(w) = %zu but the key has %zu variables", nw, pk->nvars);
+  if (pk->shard_count != 1) return fail(GS_ERR_ARG, "%s: the key is a slice", fn);
+  const int parity = c.free_parity();
+  if (parity < 0) return fail(GS_ERR_BUSY, "%s: three operations are already outstanding; call gs_groth16_prove_end first", fn);
+  const bool eval = c.eval_basis && pk->n_eval == o->n && hx_shape(o->n, pk->nz);
+  auto st = std::make_unique<GrothInFlight>();
+  memcpy(st->r, r, 32); memcpy(st->s, s, 32);
+  st->with_tail = true;
+  GrothInFlight* raw = st.get();
+  raw->pk = pk;
+  raw->keep = {c.share<Object>(hpk, Kind::GrothPk), c.share<Object>(hr1cs, Kind::R1cs)};
+  if (w) raw->keep.push_back(c.share<Object>(hw, Kind::Scalars));
+  raw->fpre = std::async(std::launch::async, [raw] { groth16_tail_pre(raw->pk, raw->r, raw->s, raw->pre); });
+  raw->early.pk = pk; raw->early.r = raw->r; raw->early.s = raw->s; raw->early.pre = &raw->pre; raw->early.fpre = &raw->fpre;
+  // (a host witness lives in the slot's buffer until the ticket is collected -- the exact-route retry below still finds it there)
+  const DevScalars dw = w_host ? stage_slot_w(c, parity, w_host, nw, raw->in) : DevScalars{w->buf.as<uint32_t>(), nw};
+  const uint32_t* wdev = dw.p;
+  const size_t nz = pk->nz;
+  DevScalars dp = witness_scalars(o, wdev, nz, eval, [o, parity](Ctx& cc) { return exact_px_buffer(cc, o, parity); });
+  if (!eval) {                               // the monomial route may have to write px at once (its check is a host wait inside enqueue)
+    dp.p = exact_px_buffer(c, o, parity);
+  } else {
+    dp.produce_hx = nullptr; dp.produce = nullptr;
+    raw->exact_route = [pk, o, wdev, nw, nz](Ctx& cc, GrothSums& sums) {
+      uint32_t* pxdev = exact_px_buffer(cc, o, Ctx::kBlockingSlot);     // the retry is a blocking proof at collection time
+      DevScalars ex = witness_scalars(o, wdev, nz, false, [pxdev](Ctx&) { return pxdev; });
+      ex.p = pxdev;
+      return groth16_sums_impl(cc, pk, DevScalars{wdev, nw}, ex, Shard{}, sums);
+    };
+  }
+  const int rc = groth16_enqueue(c, pk, dw, dp, Shard{}, parity, false, true, *raw);
+  if (rc != GS_OK) return rc;
+  if (raw->in.th2d) raw->in.th2d->stop();
+  mark_ticket_reads(raw->streams, w, nullptr);
+  st->ticket = c.new_ticket();
+  *ticket = st->ticket;
+  c.inflight[parity] = std::move(st);
+  return GS_OK;
+}
+
 int gs_groth16_prove_witness_begin(gs_handle hpk, gs_handle hr1cs, gs_handle hw, const uint64_t r[4], const uint64_t s[4], uint64_t* ticket) {
+  return guarded([&](Ctx& c) -> int {
+    return groth16_witness_begin_impl(c, "gs_groth16_prove_witness_begin", hpk, hr1cs, hw, nullptr, 0, r, s, ticket);
+  }, true, true, hpk);
+}
+
+// The reference's call shape for a server that keeps circuit and key resident: every call brings a NEW witness in host memory
+// (cli/main.go:480-501 computes w per proof) and nothing else -- a host-buffer ticket (see stage_slot_w).  Collect with gs_groth16_prove_end.
+int gs_groth16_prove_witness_host_begin(gs_handle hpk, gs_handle hr1cs, const uint64_t* w, size_t nw, const uint64_t r[4], const uint64_t s[4],
+                                        uint64_t* ticket) {
+  return guarded([&](Ctx& c) -> int {
+    if (!w) return fail(GS_ERR_ARG, "gs_groth16_prove_witness_host_begin: null witness");
+    if (nw >= (1ull << 31)) return fail(GS_ERR_ARG, "gs_groth16_prove_witness_host_begin: too many scalars");
+    return groth16_witness_begin_impl(c, "gs_groth16_prove_witness_host_begin", hpk, hr1cs, 0, w, nw, r, s, ticket);
+  }, true, true, hpk);
+}
+
+// ... and the blocking form: witness in host memory -> proof (the upload is part of the call, as in gs_groth16_prove).
+int gs_groth16_prove_witness_host(gs_handle hpk, gs_handle hr1cs, const uint64_t* w, size_t nw, const uint64_t r[4], const uint64_t s[4],
+                                  uint64_t out_proof[32], int inf[3]) {
   return guarded([&](Ctx& c) -> int {
     GrothPkObj* pk = c.get<GrothPkObj>(hpk, Kind::GrothPk);
     R1csObj* o = c.get<R1csObj>(hr1cs, Kind::R1cs);
-    Scalars* w = c.get<Scalars>(hw, Kind::Scalars);
-    if (!pk || !o || !w) return fail(GS_ERR_ARG, "gs_groth16_prove_witness_begin: bad handle");
-    if (!r || !s || !ticket) return fail(GS_ERR_ARG, "null argument");
-    if (w->n != o->m) return fail(GS_ERR_SHAPE, "len(w) = %zu but the system has %zu variables", w->n, o->m);
-    if (pk->shard_count != 1) return fail(GS_ERR_ARG, "gs_groth16_prove_witness_begin: the key is a slice");
-    const int parity = c.free_parity();
-    if (parity < 0) return fail(GS_ERR_BUSY, "gs_groth16_prove_witness_begin: three operations are already outstanding; call gs_groth16_prove_end first");
-    const bool eval = c.eval_basis && pk->n_eval == o->n && hx_shape(o->n, pk->nz);
-    auto st = std::make_unique<GrothInFlight>();
-    memcpy(st->r, r, 32); memcpy(st->s, s, 32);
-    st->with_tail = true;
-    GrothInFlight* raw = st.get();
-    raw->pk = pk;
-    raw->keep = {c.share<Object>(hpk, Kind::GrothPk), c.share<Object>(hr1cs, Kind::R1cs), c.share<Object>(hw, Kind::Scalars)};
-    raw->fpre = std::async(std::launch::async, [raw] { groth16_tail_pre(raw->pk, raw->r, raw->s, raw->pre); });
-    raw->early.pk = pk; raw->early.r = raw->r; raw->early.s = raw->s; raw->early.pre = &raw->pre; raw->early.fpre = &raw->fpre;
-    const uint32_t* wdev = w->buf.as<uint32_t>();
-    const size_t nw = w->n, nz = pk->nz;
-    DevScalars dp = witness_scalars(o, wdev, nz, eval, [o, parity](Ctx& cc) { return exact_px_buffer(cc, o, parity); });
-    if (!eval) {                               // the monomial route may have to write px at once (its check is a host wait inside enqueue)
-      dp.p = exact_px_buffer(c, o, parity);
-    } else {
-      dp.produce_hx = nullptr; dp.produce = nullptr;
-      raw->exact_route = [pk, o, wdev, nw, nz](Ctx& cc, GrothSums& sums) {
-        uint32_t* pxdev = exact_px_buffer(cc, o, Ctx::kBlockingSlot);     // the retry is a blocking proof at collection time
-        DevScalars ex = witness_scalars(o, wdev, nz, false, [pxdev](Ctx&) { return pxdev; });
-        ex.p = pxdev;
-        return groth16_sums_impl(cc, pk, DevScalars{wdev, nw}, ex, Shard{}, sums);
-      };
-    }
-    const int rc = groth16_enqueue(c, pk, DevScalars{wdev, nw}, dp, Shard{}, parity, false, true, *raw);
-    if (rc != GS_OK) return rc;
-    st->ticket = c.new_ticket();
-    *ticket = st->ticket;
-    c.inflight[parity] = std::move(st);
-    return GS_OK;
-  }, true, true, hpk);
+    if (!pk || !o) return fail(GS_ERR_ARG, "gs_groth16_prove_witness_host: bad handle");
+    if (!w || !r || !s || !out_proof || !inf) return fail(GS_ERR_ARG, "null argument");
+    if (nw != o->m) return fail(GS_ERR_SHAPE, "len(w) = %zu but the system has %zu variables", nw, o->m);
+    reset_timing(c);
+    const uint32_t* wdev = upload_tmp(c, prove_state(c).up_w, w, nw);
+    const bool eval = c.eval_basis && pk->shard_count == 1 && pk->n_eval == o->n && hx_shape(o->n, pk->nz);
+    uint32_t* pxdev = exact_px_buffer(c, o, Ctx::kBlockingSlot);
+    DevScalars dp = witness_scalars(o, wdev, pk->nz, eval, [pxdev](Ctx&) { return pxdev; });
+    dp.p = pxdev;
+    return groth16_prove_impl(c, pk, DevScalars{wdev, nw}, dp, r, s, out_proof, inf);
+  }, true, false, hpk);
 }
 
 // snark.GenerateProofs straight from the witness (the Pinocchio twin of gs_groth16_prove_witness): CombinePolynomials + Div
@@ -1600,40 +1767,78 @@ int gs_pinocchio_prove_witness(gs_handle hpk, gs_handle hr1cs, gs_handle hw, uin
   }, true, false, hpk);
 }
 
+static int pinocchio_witness_begin_impl(Ctx& c, const char* fn, gs_handle hpk, gs_handle hr1cs, gs_handle hw, const uint64_t* w_host, size_t nw_host,
+                                        uint64_t* ticket) {
+  PinocchioPkObj* pk = c.get<PinocchioPkObj>(hpk, Kind::PinocchioPk);
+  R1csObj* o = c.get<R1csObj>(hr1cs, Kind::R1cs);
+  Scalars* w = w_host ? nullptr : c.get<Scalars>(hw, Kind::Scalars);
+  if (!pk || !o || (!w_host && !w) || !ticket) return fail(GS_ERR_ARG, "%s: bad handle or null ticket", fn);
+  const size_t nw = w_host ? nw_host : w->n;
+  if (nw != o->m) return fail(GS_ERR_SHAPE, "len(w) = %zu but the system has %zu variables", nw, o->m);
+  if (nw != pk->nvars) return fail(GS_ERR_SHAPE, "len(w) = %zu but the key has %zu variables", nw, pk->nvars);
+  if (pk->nz == 0) return fail(GS_ERR_SHAPE, "the key has no Z");
+  const int parity = c.free_parity();
+  if (parity < 0) return fail(GS_ERR_BUSY, "%s: three operations are already outstanding; call gs_pinocchio_prove_end first", fn);
+  const bool eval = c.eval_basis && pk->n_eval == o->n && hx_shape(o->n, pk->nz);
+  auto st = std::make_unique<PinInFlight>();
+  st->keep = {c.share<Object>(hpk, Kind::PinocchioPk), c.share<Object>(hr1cs, Kind::R1cs)};
+  if (w) st->keep.push_back(c.share<Object>(hw, Kind::Scalars));
+  const DevScalars dw = w_host ? stage_slot_w(c, parity, w_host, nw, st->in) : DevScalars{w->buf.as<uint32_t>(), nw};
+  const uint32_t* wdev = dw.p;
+  const size_t nz = pk->nz;
+  DevScalars dp = witness_scalars(o, wdev, nz, eval, [o, parity](Ctx& cc) { return exact_px_buffer(cc, o, parity); });
+  if (!eval) {
+    dp.p = exact_px_buffer(c, o, parity);
+  } else {
+    dp.produce_hx = nullptr; dp.produce = nullptr;
+    st->exact_route = [pk, o, wdev, nw, nz](Ctx& cc, uint64_t* out, int* inf) {
+      uint32_t* pxdev = exact_px_buffer(cc, o, Ctx::kBlockingSlot);     // the retry is a blocking proof at collection time
+      DevScalars ex = witness_scalars(o, wdev, nz, false, [pxdev](Ctx&) { return pxdev; });
+      ex.p = pxdev;
+      return pinocchio_prove_impl(cc, pk, DevScalars{wdev, nw}, ex, out, inf);
+    };
+  }
+  const int rc = pinocchio_enqueue(c, pk, dw, dp, Shard{}, parity, false, true, *st);
+  if (rc != GS_OK) return rc;
+  if (st->in.th2d) st->in.th2d->stop();
+  mark_ticket_reads(st->streams, w, nullptr);
+  st->ticket = c.new_ticket();
+  *ticket = st->ticket;
+  c.inflight[parity] = std::move(st);
+  return GS_OK;
+}
+
 int gs_pinocchio_prove_witness_begin(gs_handle hpk, gs_handle hr1cs, gs_handle hw, uint64_t* ticket) {
+  return guarded([&](Ctx& c) -> int {
+    return pinocchio_witness_begin_impl(c, "gs_pinocchio_prove_witness_begin", hpk, hr1cs, hw, nullptr, 0, ticket);
+  }, true, true, hpk);
+}
+
+// host-buffer tickets of snark.GenerateProofs (see gs_groth16_prove_witness_host_begin / gs_groth16_prove_host_begin)
+int gs_pinocchio_prove_witness_host_begin(gs_handle hpk, gs_handle hr1cs, const uint64_t* w, size_t nw, uint64_t* ticket) {
+  return guarded([&](Ctx& c) -> int {
+    if (!w) return fail(GS_ERR_ARG, "gs_pinocchio_prove_witness_host_begin: null witness");
+    if (nw >= (1ull << 31)) return fail(GS_ERR_ARG, "gs_pinocchio_prove_witness_host_begin: too many scalars");
+    return pinocchio_witness_begin_impl(c, "gs_pinocchio_prove_witness_host_begin", hpk, hr1cs, 0, w, nw, ticket);
+  }, true, true, hpk);
+}
+
+int gs_pinocchio_prove_witness_host(gs_handle hpk, gs_handle hr1cs, const uint64_t* w, size_t nw, uint64_t out_proof[72], int inf[8]) {
   return guarded([&](Ctx& c) -> int {
     PinocchioPkObj* pk = c.get<PinocchioPkObj>(hpk, Kind::PinocchioPk);
     R1csObj* o = c.get<R1csObj>(hr1cs, Kind::R1cs);
-    Scalars* w = c.get<Scalars>(hw, Kind::Scalars);
-    if (!pk || !o || !w || !ticket) return fail(GS_ERR_ARG, "gs_pinocchio_prove_witness_begin: bad handle or null ticket");
-    if (w->n != o->m) return fail(GS_ERR_SHAPE, "len(w) = %zu but the system has %zu variables", w->n, o->m);
+    if (!pk || !o) return fail(GS_ERR_ARG, "gs_pinocchio_prove_witness_host: bad handle");
+    if (!w || !out_proof || !inf) return fail(GS_ERR_ARG, "null argument");
+    if (nw != o->m) return fail(GS_ERR_SHAPE, "len(w) = %zu but the system has %zu variables", nw, o->m);
     if (pk->nz == 0) return fail(GS_ERR_SHAPE, "the key has no Z");
-    const int parity = c.free_parity();
-    if (parity < 0) return fail(GS_ERR_BUSY, "gs_pinocchio_prove_witness_begin: three operations are already outstanding; call gs_pinocchio_prove_end first");
+    reset_timing(c);
+    const uint32_t* wdev = upload_tmp(c, prove_state(c).up_w, w, nw);
     const bool eval = c.eval_basis && pk->n_eval == o->n && hx_shape(o->n, pk->nz);
-    auto st = std::make_unique<PinInFlight>();
-    st->keep = {c.share<Object>(hpk, Kind::PinocchioPk), c.share<Object>(hr1cs, Kind::R1cs), c.share<Object>(hw, Kind::Scalars)};
-    const uint32_t* wdev = w->buf.as<uint32_t>();
-    const size_t nw = w->n, nz = pk->nz;
-    DevScalars dp = witness_scalars(o, wdev, nz, eval, [o, parity](Ctx& cc) { return exact_px_buffer(cc, o, parity); });
-    if (!eval) {
-      dp.p = exact_px_buffer(c, o, parity);
-    } else {
-      dp.produce_hx = nullptr; dp.produce = nullptr;
-      st->exact_route = [pk, o, wdev, nw, nz](Ctx& cc, uint64_t* out, int* inf) {
-        uint32_t* pxdev = exact_px_buffer(cc, o, Ctx::kBlockingSlot);     // the retry is a blocking proof at collection time
-        DevScalars ex = witness_scalars(o, wdev, nz, false, [pxdev](Ctx&) { return pxdev; });
-        ex.p = pxdev;
-        return pinocchio_prove_impl(cc, pk, DevScalars{wdev, nw}, ex, out, inf);
-      };
-    }
-    const int rc = pinocchio_enqueue(c, pk, DevScalars{wdev, nw}, dp, Shard{}, parity, false, true, *st);
-    if (rc != GS_OK) return rc;
-    st->ticket = c.new_ticket();
-    *ticket = st->ticket;
-    c.inflight[parity] = std::move(st);
-    return GS_OK;
-  }, true, true, hpk);
+    uint32_t* pxdev = exact_px_buffer(c, o, Ctx::kBlockingSlot);
+    DevScalars dp = witness_scalars(o, wdev, pk->nz, eval, [pxdev](Ctx&) { return pxdev; });
+    dp.p = pxdev;
+    return pinocchio_prove_impl(c, pk, DevScalars{wdev, nw}, dp, out_proof, inf);
+  }, true, false, hpk);
 }
 
 }  // extern "C"

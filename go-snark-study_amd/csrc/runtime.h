@@ -58,6 +58,28 @@ inline std::atomic<uint64_t>& devbuf_bytes() {
   return v;
 }
 
+// Allocation bookkeeping (gs_alloc_counters): how often the library went to hipMalloc / hipFree.  The steady state of a prover that
+// streams proofs -- resident or host-buffer tickets -- performs neither (tests/test_gpu_stream_host.py).
+inline std::atomic<uint64_t>& devbuf_allocs() { static std::atomic<uint64_t> v{0}; return v; }
+inline std::atomic<uint64_t>& devbuf_frees() { static std::atomic<uint64_t> v{0}; return v; }
+// gs_set_memory_limit: a cap on devbuf_bytes() (0 = none) -- a development / test hook that makes "out of device memory" reachable
+// without filling 288 GB; an allocation that would exceed it is treated exactly like hipErrorOutOfMemory.
+inline std::atomic<uint64_t>& devbuf_limit() { static std::atomic<uint64_t> v{0}; return v; }
+// Called when hipMalloc reports out of memory (or the cap is hit): drop least-recently-used window tables of the calling thread's
+// context that no ticket and not the running call hold, until `need` bytes were freed or nothing is left (capi_mem.hip).
+bool evict_tables_for(size_t need);
+
+inline void* dev_malloc(size_t n) {
+  for (int attempt = 0;; ++attempt) {
+    void* q = nullptr;
+    const uint64_t cap = devbuf_limit().load();
+    hipError_t e = (cap && devbuf_bytes().load() + n > cap) ? hipErrorOutOfMemory : hipMalloc(&q, n);
+    if (e == hipSuccess) { devbuf_allocs() += 1; return q; }
+    (void)hipGetLastError();
+    if (e != hipErrorOutOfMemory || attempt > 0 || !evict_tables_for(n)) throw HipError{e, "hipMalloc", __LINE__};
+  }
+}
+
 struct DevBuf {
   void* p = nullptr;
   size_t bytes = 0;
@@ -71,15 +93,29 @@ struct DevBuf {
     return *this;
   }
   ~DevBuf() { release(); }
+  // The new buffer exists before the old one goes (a failed allocation leaves the object as it was).  Only when even eviction
+  // cannot make room for both is the old one given up first -- its contents are scratch for every caller of alloc / ensure.
   void alloc(size_t n) {
-    release();
     if (n == 0) n = 16;
-    GS_HIP(hipMalloc(&p, n));
+    void* q = nullptr;
+    try { q = dev_malloc(n); }
+    catch (const HipError&) {
+      if (!p) throw;
+      release();
+      q = dev_malloc(n);
+    }
+    release();
+    p = q;
     bytes = n;
     devbuf_bytes() += n;
   }
   void ensure(size_t n) { if (n > bytes) alloc(n + n / 8); }      // grow-only workspace
-  void release() { if (p) { if (!process_exiting()) (void)hipFree(p); devbuf_bytes() -= bytes; p = nullptr; bytes = 0; } }
+  void release() {
+    if (p) {
+      if (!process_exiting()) { (void)hipFree(p); devbuf_frees() += 1; }
+      devbuf_bytes() -= bytes; p = nullptr; bytes = 0;
+    }
+  }
   template <class U> U* as() const { return reinterpret_cast<U*>(p); }
 };
 
@@ -107,7 +143,21 @@ struct R1csObj : Object {        // sparse R1CS resident on the device: A, B, C 
 struct Scalars : Object {        // n x 8 u32 words, standard form, resident
   DevBuf buf;
   size_t n = 0;
+  // gs_scalars_update overwrites the vector IN PLACE, so it must come after every device read enqueued before it.  A pipelined
+  // operation that reads the vector leaves, per stream it read it on, an event behind its last reader (in-order streams: a later
+  // record on the same stream supersedes the earlier one); the update makes its copy wait for them.  Blocking entry points have
+  // finished reading when they return and leave nothing.
+  struct ReadMark { hipStream_t stream; hipEvent_t ev; };
+  std::vector<ReadMark> reads;
+  void mark_read(hipStream_t s) {
+    for (auto& r : reads) if (r.stream == s) { GS_HIP(hipEventRecord(r.ev, s)); return; }
+    hipEvent_t ev;
+    GS_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    GS_HIP(hipEventRecord(ev, s));
+    reads.push_back(ReadMark{s, ev});
+  }
   Scalars() : Object(Kind::Scalars) {}
+  ~Scalars() override { if (!process_exiting()) for (auto& r : reads) (void)hipEventDestroy(r.ev); }
 };
 
 // a proof whose device work has been enqueued but not collected yet (prove.hip)
@@ -157,11 +207,9 @@ struct Ctx {
   // (latency, not throughput), so the tails of operation k + 1 may run beside those of operation k instead of queueing behind
   // them -- at 2^16 the G2 tail (1.2 ms) was longer than the accumulations of a whole proof (0.9 ms) and set the pace.
   unsigned tail_flip = 0;
-  // Large pipelined proofs with a long polynomial stage (prove.hip, GS_PLANW_STREAM): plan(w) of the NEXT proof on aux 2, so that it no
-  // longer queues behind this proof's H stage and plan(h) on aux 1; every tail then shares aux 0.
-  bool planw_own = false;
-  hipStream_t tail_stream(int which) { return planw_own ? aux_stream[0] : aux_stream[((which ^ (int)(tail_flip & 1u)) & 1) ? 2 : 0]; }
-  hipStream_t planw_stream() { return planw_own ? aux_stream[2] : aux_stream[1]; }
+  // (Which stream carries plan(w) and which the tails is decided once per proof by prove.hip's proof_streams(); the context only
+  //  keeps the alternation state of the two tail streams.)
+  hipStream_t tail_stream(int which) { return aux_stream[((which ^ (int)(tail_flip & 1u)) & 1) ? 2 : 0]; }
   void next_tails(uint32_t n) {                     // called once per pipelined operation of n terms
     static const int mode = (int)run_knob("GS_TAIL_FLIP", 1, 0, 2);                        // 0 never, 1 always, 2 by size (same results)
     if (mode == 1 || (mode == 2 && n <= kTailFlipMaxTerms)) tail_flip ^= 1u;
@@ -173,7 +221,15 @@ struct Ctx {
   static constexpr size_t kPinnedBytes = 256 * 1024;
   std::mutex mu;
   std::unordered_map<uint64_t, std::shared_ptr<Object>> objs;     // in-flight operations hold references: gs_free defers
+  uint64_t call_clock = 0;       // one tick per entry-point call on this context: window tables stamp it when a call uses them (LRU
+                                 // order for evict_tables_for; a table stamped with the running call's tick is never its victim)
+  uint64_t evictions = 0;        // window tables dropped by evict_tables_for so far
   int window_bits = 0;           // 0 = auto
+  // gs_set_table_policy -- when a base array gets its 15-row window table (msm.h, prepare_tables): 0 auto (sum table-free until the
+  // array has been used twice, then build in the background and switch when the build is through), 1 always (build on first use,
+  // inside the call: rounds 1-4), 2 never
+  int table_policy = 0;
+  hipStream_t table_stream = nullptr;   // background table builds (lazy, lowest priority)
   bool eval_basis = true;        // gs_set_eval_basis: witness route over H's values when the key has an evaluation-basis array
   gs_timing timing{};
   std::mutex timing_mu;          // msm_finish of several groups may run on different host threads
@@ -258,6 +314,18 @@ inline Ctx& none_ctx() {
   return none;
 }
 
+// the context the calling host thread is inside of (set by guarded / guarded_pair for the duration of the call): what
+// evict_tables_for() may take tables from -- its lock is held, so its handle table and tickets cannot change under the evictor
+inline Ctx*& current_ctx() {
+  static thread_local Ctx* c = nullptr;
+  return c;
+}
+struct CurrentCtxScope {
+  Ctx* saved;
+  explicit CurrentCtxScope(Ctx* c) : saved(current_ctx()) { current_ctx() = c; }
+  ~CurrentCtxScope() { current_ctx() = saved; }
+};
+
 template <class F>
 int guarded(F&& f, bool need_init = true, bool allow_inflight = false, gs_handle route = 0) {
   size_t ndev = 0;
@@ -271,6 +339,8 @@ int guarded(F&& f, bool need_init = true, bool allow_inflight = false, gs_handle
   }
   // the HIP current device is per host thread: callers (goroutines, worker threads) may arrive on any thread
   if (c.ready) (void)hipSetDevice(c.device);
+  CurrentCtxScope scope(c.ready ? &c : nullptr);
+  c.call_clock += 1;
   try {
     if (need_init && !allow_inflight && c.any_inflight()) c.drain();
     return f(c);
@@ -298,6 +368,8 @@ int guarded_pair(gs_handle route, int target, F&& f) {
   std::unique_lock<std::mutex> l1(src.mu, std::defer_lock), l2(dst.mu, std::defer_lock);
   if (&src == &dst) l1.lock(); else std::lock(l1, l2);
   if (!src.ready || !dst.ready) return fail(GS_ERR_NOT_INIT, "the library was shut down");
+  CurrentCtxScope scope(&dst);                  // allocations of a pair call land on the target
+  dst.call_clock += 1;
   try {
     (void)hipSetDevice(src.device);
     src.drain();

@@ -376,7 +376,8 @@ int gs_groth16_pk_set_eval(gs_handle hpk, gs_handle hbases) {
     const size_t n = b->n;
     if (n < 2 || pk->nz == 0 || (pk->nz - 1 != n - 1 && pk->nz - 1 != n))
       return fail(GS_ERR_SHAPE, "gs_groth16_pk_set_eval: %zu points, but deg Z = %zu needs n = deg Z or deg Z + 1 constraints", n, pk->nz ? pk->nz - 1 : 0);
-    pk->t_ptd_eval = BaseTable{};
+    table_settle(c, pk->t_ptd_eval, false);
+    pk->t_ptd_eval.drop();
     pk->ptd_eval.alloc(n * 64);
     GS_HIP(hipMemcpyAsync(pk->ptd_eval.p, b->buf.p, n * 64, hipMemcpyDeviceToDevice, c.stream));
     GS_HIP(hipStreamSynchronize(c.stream));
@@ -402,7 +403,8 @@ int gs_pinocchio_pk_set_eval(gs_handle hpk, gs_handle hbases) {
     const size_t n = b->n;
     if (n < 2 || pk->nz == 0 || (pk->nz - 1 != n - 1 && pk->nz - 1 != n))
       return fail(GS_ERR_SHAPE, "gs_pinocchio_pk_set_eval: %zu points, but deg Z = %zu needs n = deg Z or deg Z + 1 constraints", n, pk->nz ? pk->nz - 1 : 0);
-    pk->t_g1t_eval = BaseTable{};
+    table_settle(c, pk->t_g1t_eval, false);
+    pk->t_g1t_eval.drop();
     pk->g1t_eval.alloc(n * 64);
     GS_HIP(hipMemcpyAsync(pk->g1t_eval.p, b->buf.p, n * 64, hipMemcpyDeviceToDevice, c.stream));
     GS_HIP(hipStreamSynchronize(c.stream));

@@ -271,6 +271,49 @@ def prove_witness_begin(dev_pk, dev_r1cs, w_handle, r, s):
     return t.value
 
 
+def _u64_rows(x):
+    """ints or an [n, 4] uint64 array -> contiguous [n, 4] uint64 (standard form)"""
+    if isinstance(x, np.ndarray):
+        return np.ascontiguousarray(x, dtype=np.uint64).reshape(-1, 4)
+    return capi.ints_to_u64([v % R for v in x])
+
+
+def prove_host_begin(dev_pk, w, px, r, s):
+    """groth16.GenerateProofs' own call shape at the pipelined rate (gs_groth16_prove_host_begin): w and px in HOST memory (ints or
+    [n, 4] uint64 arrays), new ones every call, staged into the ticket slot's own device buffers -> ticket for prove_end."""
+    import ctypes
+    wa, pa = _u64_rows(w), _u64_rows(px)
+    rs = capi.ints_to_u64([r % R, s % R])
+    t = ctypes.c_uint64(0)
+    capi.check(capi.load_library().gs_groth16_prove_host_begin(capi.Handle(dev_pk.handle.h), capi.ptr64(wa), wa.shape[0], capi.ptr64(pa), pa.shape[0],
+                                                               capi.ptr64(rs[0]), capi.ptr64(rs[1]), ctypes.cast(ctypes.byref(t), capi.u64p)))
+    return t.value
+
+
+def prove_witness_host_begin(dev_pk, dev_r1cs, w, r, s):
+    """A fresh witness in HOST memory against the resident sparse R1CS (gs_groth16_prove_witness_host_begin) -> ticket for prove_end."""
+    import ctypes
+    wa = _u64_rows(w)
+    rs = capi.ints_to_u64([r % R, s % R])
+    t = ctypes.c_uint64(0)
+    capi.check(capi.load_library().gs_groth16_prove_witness_host_begin(capi.Handle(dev_pk.handle.h), capi.Handle(dev_r1cs.handle.h), capi.ptr64(wa),
+                                                                       wa.shape[0], capi.ptr64(rs[0]), capi.ptr64(rs[1]),
+                                                                       ctypes.cast(ctypes.byref(t), capi.u64p)))
+    return t.value
+
+
+def prove_from_witness_host(dev_pk, dev_r1cs, w, r, s):
+    """Blocking: host witness -> proof (gs_groth16_prove_witness_host)."""
+    import ctypes
+    wa = _u64_rows(w)
+    rs = capi.ints_to_u64([r % R, s % R])
+    out = np.zeros(32, dtype=np.uint64)
+    inf = (ctypes.c_int * 3)()
+    capi.check(capi.load_library().gs_groth16_prove_witness_host(capi.Handle(dev_pk.handle.h), capi.Handle(dev_r1cs.handle.h), capi.ptr64(wa), wa.shape[0],
+                                                                 capi.ptr64(rs[0]), capi.ptr64(rs[1]), capi.ptr64(out), inf))
+    return _proof_from_words(out, inf)
+
+
 def SetEvalBasis(dev_pk, points):
     """Attach an evaluation-basis copy of PowersTauDelta (n Jacobian int triples, e.g. read from a key file) to a resident key:
     gs_groth16_pk_set_eval.  The witness route then runs its h-MSM over H's values (no interpolation)."""

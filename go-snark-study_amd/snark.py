@@ -94,6 +94,40 @@ def prove_witness_begin(dev_pk, dev_r1cs, w_handle):
     return t.value
 
 
+def _u64_rows(x):
+    if isinstance(x, np.ndarray):
+        return np.ascontiguousarray(x, dtype=np.uint64).reshape(-1, 4)
+    return capi.ints_to_u64([v % R for v in x])
+
+
+def prove_host_begin(dev_pk, w, px):
+    """snark.GenerateProofs' own call shape, pipelined (gs_pinocchio_prove_host_begin): w and px in host memory -> ticket for prove_end."""
+    wa, pa = _u64_rows(w), _u64_rows(px)
+    t = ctypes.c_uint64(0)
+    capi.check(capi.load_library().gs_pinocchio_prove_host_begin(capi.Handle(dev_pk.h), capi.ptr64(wa), wa.shape[0], capi.ptr64(pa), pa.shape[0],
+                                                                 ctypes.cast(ctypes.byref(t), capi.u64p)))
+    return t.value
+
+
+def prove_witness_host_begin(dev_pk, dev_r1cs, w):
+    """A fresh host witness against the resident sparse R1CS (gs_pinocchio_prove_witness_host_begin) -> ticket for prove_end."""
+    wa = _u64_rows(w)
+    t = ctypes.c_uint64(0)
+    capi.check(capi.load_library().gs_pinocchio_prove_witness_host_begin(capi.Handle(dev_pk.h), capi.Handle(dev_r1cs.handle.h), capi.ptr64(wa),
+                                                                         wa.shape[0], ctypes.cast(ctypes.byref(t), capi.u64p)))
+    return t.value
+
+
+def prove_from_witness_host(dev_pk, dev_r1cs, w):
+    """Blocking: host witness -> proof (gs_pinocchio_prove_witness_host)."""
+    wa = _u64_rows(w)
+    out = np.zeros(72, dtype=np.uint64)
+    inf = (ctypes.c_int * 8)()
+    capi.check(capi.load_library().gs_pinocchio_prove_witness_host(capi.Handle(dev_pk.h), capi.Handle(dev_r1cs.handle.h), capi.ptr64(wa), wa.shape[0],
+                                                                   capi.ptr64(out), inf))
+    return _proof_from_words(out, inf)
+
+
 def SetEvalBasis(dev_pk, points):
     """Attach an evaluation-basis copy of G1T (n Jacobian int triples) to a resident key: gs_pinocchio_pk_set_eval."""
     arr = capi.ints_to_u64([c for p in points for c in p]).reshape(-1, 12)

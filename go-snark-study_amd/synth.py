@@ -213,14 +213,13 @@ class SqchainSetupInstance:
         return ("sqchain(n) R1CS (s_k^2 = s_{k+1} - k), satisfying witness, structured trusted setup on the device from seeded "
                 "toxic values (gs_groth16_setup), px = A(x)B(x) - C(x) from the sparse system; seed 0x%X" % self.seed)
 
-    def expected_proof_scalars(self, r, s):
-        """Discrete logs (to the base G1 / G2 generators) of the proof elements groth16.go:243-275 must produce:
-           a = A(tau) + Kalpha + r Kdelta,  b = B(tau) + Kbeta + s Kdelta,
-           c = [ sum_{i>l} w_i (Kbeta a_i + Kalpha b_i + c_i)(tau) + A(tau) B(tau) - C(tau) ] / Kdelta + s a + r b - r s Kdelta
-        with A(tau) = sum_j (A w)_j L_j(tau) over the nodes 1..n (H Z = A B - C because the witness satisfies the R1CS)."""
-        n, m = self.n, self.m
-        T, Ka, Kb, Kg, Kd = self.toxic
-        w = capi.u64_to_ints(self.w_host)
+    def _closed_form_tables(self):
+        """What the closed form needs of the circuit and the setup alone (cached: bench.py checks several witnesses of one instance):
+        L_j(tau) over the nodes 1..n, the CSR matrices as Python ints, and a_i(tau), b_i(tau), c_i(tau) for the public i <= 1."""
+        if getattr(self, "_cf", None) is not None:
+            return self._cf
+        n = self.n
+        T = self.toxic[0]
         # L_j(tau) = M(tau) / ((tau - j) M'(j)),  M'(j) = (-1)^(n-j) (j-1)! (n-j)!
         fact = [1] * (n + 1)
         for k in range(1, n + 1):
@@ -239,25 +238,38 @@ class SqchainSetupInstance:
         for i in range(n - 1, -1, -1):
             lag[i] = mt * (inv * pre[i] % R) % R
             inv = inv * den[i] % R
+        mats, lows = [], []
+        for rp, cl, vl in self.r1cs:
+            rp, cl, vals = [int(x) for x in rp], [int(x) for x in cl], capi.u64_to_ints(vl)
+            low = [0, 0]
+            for j in range(n):
+                for e in range(rp[j], rp[j + 1]):
+                    if cl[e] <= 1:
+                        low[cl[e]] = (low[cl[e]] + vals[e] * lag[j]) % R       # a_i(tau) for i <= NPublic
+            mats.append((rp, cl, vals))
+            lows.append(low)
+        self._cf = (lag, mats, lows)
+        return self._cf
 
-        def rows(csr):
-            rp, cl, vl = csr
-            vals = capi.u64_to_ints(vl)
-            return rp, cl, vals
-        sums, lows = [], []
-        for csr in self.r1cs:
-            rp, cl, vals = rows(csr)
-            tot, low = 0, [0, 0]
+    def expected_proof_scalars(self, r, s, w_host=None):
+        """Discrete logs (to the base G1 / G2 generators) of the proof elements groth16.go:243-275 must produce:
+           a = A(tau) + Kalpha + r Kdelta,  b = B(tau) + Kbeta + s Kdelta,
+           c = [ sum_{i>l} w_i (Kbeta a_i + Kalpha b_i + c_i)(tau) + A(tau) B(tau) - C(tau) ] / Kdelta + s a + r b - r s Kdelta
+        with A(tau) = sum_j (A w)_j L_j(tau) over the nodes 1..n (H Z = A B - C because the witness satisfies the R1CS).
+        w_host: another satisfying witness of the same circuit ([m, 4] uint64; default: the instance's own)."""
+        n = self.n
+        T, Ka, Kb, Kg, Kd = self.toxic
+        w = capi.u64_to_ints(self.w_host if w_host is None else w_host)
+        lag, mats, lows = self._closed_form_tables()
+        sums = []
+        for rp, cl, vals in mats:
+            tot = 0
             for j in range(n):
                 acc = 0
-                for e in range(int(rp[j]), int(rp[j + 1])):
-                    k = int(cl[e])
-                    acc += vals[e] * w[k]
-                    if k <= 1:
-                        low[k] = (low[k] + vals[e] * lag[j]) % R       # a_i(tau) for i <= NPublic
-                tot = (tot + acc % R * lag[j]) % R
-            sums.append(tot)
-            lows.append(low)
+                for e in range(rp[j], rp[j + 1]):
+                    acc += vals[e] * w[cl[e]]
+                tot += acc % R * lag[j]
+            sums.append(tot % R)
         At, Bt, Ct = sums
         a = (At + Ka + r * Kd) % R
         b = (Bt + Kb + s * Kd) % R

@@ -18,6 +18,7 @@ type Memory struct {
 	Tables                  uint64 // their window tables
 	Workspaces              uint64 // bucket sets, chunk partials, staging
 	Handles                 uint64 // live handles
+	Evictions               uint64 // window tables dropped because an allocation found no memory
 }
 
 // MemoryOf queries logical device `device`.
@@ -25,7 +26,7 @@ func MemoryOf(device int) (Memory, error) {
 	var m C.gs_memory
 	err := onDevice(device, func() C.int { return C.gs_memory_query(&m) })
 	return Memory{uint64(m.device_total_bytes), uint64(m.device_free_bytes), uint64(m.library_bytes), uint64(m.object_bytes),
-		uint64(m.table_bytes), uint64(m.workspace_bytes), uint64(m.objects)}, err
+		uint64(m.table_bytes), uint64(m.workspace_bytes), uint64(m.objects), uint64(m.evictions)}, err
 }
 
 // HandleBytes returns what one handle holds: its own data and its window tables.

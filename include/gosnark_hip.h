@@ -103,6 +103,11 @@ int gs_g2_fixed_base(const uint64_t* scalars /* n x 4 */, size_t n, gs_handle* o
 /* ---- resident scalar vectors ------------------------------------------------------------- */
 int gs_scalars_upload(const uint64_t* scalars /* n x 4 */, size_t n, gs_handle* out);
 int gs_scalars_download(gs_handle scalars, uint64_t* out /* n x 4 */, size_t n);
+/* Overwrite a resident vector IN PLACE with n = its length new scalars (a server's next witness into the handle of an earlier one):
+ * no hipMalloc, no hipFree -- gs_scalars_upload + gs_free per proof costs both, and hipFree synchronises the whole device under the
+ * outstanding tickets.  The copy is ordered behind every device read of the vector that pipelined operations enqueued before the
+ * call and has landed when the call returns.  With four vectors rotating under three tickets it never waits. */
+int gs_scalars_update(gs_handle scalars, const uint64_t* values /* n x 4 */, size_t n);
 
 /* Copies of [off, off + n) of a resident vector / base array onto another logical device (device-to-device; across xGMI
  * when the two are different GPUs).  How the shards of a term range are handed to the devices that will sum them. */
@@ -231,6 +236,21 @@ int gs_groth16_prove_witness_begin(gs_handle pk, gs_handle r1cs, gs_handle w, co
  * gs_free'd -- they are released when the ticket has been collected. */
 int gs_groth16_prove_begin(gs_handle pk, gs_handle w, gs_handle px, const uint64_t r[4], const uint64_t s[4], uint64_t* ticket);
 int gs_groth16_prove_end(uint64_t ticket, uint64_t out_proof[32], int inf[3]);
+/* HOST-BUFFER TICKETS: the reference's own call shape -- groth16.GenerateProofs(circuit, pk, w, px) gets a NEW w (and px) in host
+ * memory with every call (groth16/groth16.go:225; cli/main.go:480-501 computes them per proof) -- at the pipelined rate.  The
+ * arrays are staged into device buffers that the ticket's SLOT owns (grow-only: once the three slots have been used a stream of
+ * proofs performs no hipMalloc and no hipFree, see gs_alloc_counters) on a copy stream of their own, and the kernels that read
+ * them wait for the copy's event: the PCIe transfer of proof k + 3 runs beside the accumulations of proofs k + 1 and k + 2.  The
+ * caller's arrays have been consumed when the call returns.  Collect with gs_groth16_prove_end; same three slots per device.
+ *   gs_groth16_prove_host_begin          w and px from the host (32 + 64 MiB at 2^20 constraints)
+ *   gs_groth16_prove_witness_host_begin  w only, against a resident sparse R1CS (gs_r1cs_upload): the witness routes above
+ *   gs_groth16_prove_witness_host        the blocking form of the latter (the upload is part of the call, as in gs_groth16_prove) */
+int gs_groth16_prove_host_begin(gs_handle pk, const uint64_t* w, size_t nw, const uint64_t* px, size_t npx, const uint64_t r[4], const uint64_t s[4],
+                                uint64_t* ticket);
+int gs_groth16_prove_witness_host_begin(gs_handle pk, gs_handle r1cs, const uint64_t* w, size_t nw, const uint64_t r[4], const uint64_t s[4],
+                                        uint64_t* ticket);
+int gs_groth16_prove_witness_host(gs_handle pk, gs_handle r1cs, const uint64_t* w, size_t nw, const uint64_t r[4], const uint64_t s[4],
+                                  uint64_t out_proof[32], int inf[3]);
 /* Abandon a ticket of any kind (proof or MSM) without collecting its result: waits for its device work, frees its slot and the
  * references it holds.  An error path that cannot call the matching _end must call this, or the slot stays occupied. */
 int gs_ticket_cancel(uint64_t ticket);
@@ -316,6 +336,10 @@ int gs_pinocchio_prove_witness_begin(gs_handle pk, gs_handle r1cs, gs_handle w, 
  * Groth16 proofs, Pinocchio proofs and MSMs). */
 int gs_pinocchio_prove_begin(gs_handle pk, gs_handle w, gs_handle px, uint64_t* ticket);
 int gs_pinocchio_prove_end(uint64_t ticket, uint64_t out_proof[72], int inf[8]);
+/* host-buffer tickets of snark.GenerateProofs (snark.go:254): as the Groth16 ones above; collect with gs_pinocchio_prove_end */
+int gs_pinocchio_prove_host_begin(gs_handle pk, const uint64_t* w, size_t nw, const uint64_t* px, size_t npx, uint64_t* ticket);
+int gs_pinocchio_prove_witness_host_begin(gs_handle pk, gs_handle r1cs, const uint64_t* w, size_t nw, uint64_t* ticket);
+int gs_pinocchio_prove_witness_host(gs_handle pk, gs_handle r1cs, const uint64_t* w, size_t nw, uint64_t out_proof[72], int inf[8]);
 
 /* ---- several GPUs (BASELINE configs[3] "MSM sharded across 8 GPUs" and configs[4] "one proof per GPU") ----------
  * The prover's sums run over independent terms (groth16.go:243-250,269-271): each device sums one contiguous shard of the
@@ -450,12 +474,36 @@ typedef struct {
   uint64_t table_bytes;       /* window tables of those handles */
   uint64_t workspace_bytes;   /* bucket sets, chunk partials, result staging, fixed-base tables (plan / polynomial caches: in library_bytes) */
   uint64_t objects;           /* live handles on the current logical device */
-  uint64_t reserved;
+  uint64_t evictions;         /* window tables this logical device dropped because an allocation found no memory (was `reserved`: same size) */
 } gs_memory;
 int gs_memory_query(gs_memory* out);
 int gs_handle_bytes(gs_handle h, uint64_t* object_bytes, uint64_t* table_bytes);     /* either pointer may be NULL */
 /* Free the window tables of a key or base array (queues behind outstanding tickets); results of later calls are unchanged. */
 int gs_release_tables(gs_handle h);
+/* WHEN a base array gets its window table (every logical device; results never depend on it):
+ *   0 auto (default)  the reference proves once per key load (cli/main.go:330-349), and the tables of a 2^20 key cost ~140 ms and
+ *                     5.6 GiB -- fifteen proofs' worth -- before the first proof.  An array without a table is summed TABLE-FREE
+ *                     (a bucket set per window, every window adds the base point itself, the window sums recombined by Horner:
+ *                     ~1.2x the additions); from its second use on its table is built in the background on a low-priority
+ *                     stream while proofs keep running table-free, and the first call that finds it complete switches over.
+ *   1 always          the table is built inside the first call that needs it (rounds 1-4)
+ *   2 never           table-free only (0.4 GiB per 2^20 key instead of 6; what 2^24 constraints on one GPU use)
+ * gs_build_tables builds them NOW (blocking, whatever the policy): a server warming a key it will prove with for hours, and what
+ * bench.py's steady-state numbers are measured on.  route: 0 = everything the key can use, 1 = only what the px routes need,
+ * 2 = only what the witness routes need (the evaluation-basis array instead of PowersTauDelta / G1T); ignored for base arrays. */
+int gs_set_table_policy(int policy);
+int gs_build_tables(gs_handle h, int route);
+/* Out of device memory is not fatal while window tables exist: an allocation that fails evicts least-recently-used tables of the
+ * logical device (never one a ticket or the running call holds), retries once, and only then returns GS_ERR_HIP; an evicted table
+ * comes back the way the policy says.  gs_memory.evictions counts them.  gs_set_memory_limit caps the device bytes the library may
+ * hold (0 = no cap) -- a development / test hook that makes the condition reachable without filling 288 GB. */
+int gs_set_memory_limit(uint64_t bytes);
+/* hipMalloc / hipFree calls the library has made so far (process-wide): a stream of pipelined proofs -- resident or host-buffer
+ * tickets -- moves neither in steady state.  Either pointer may be NULL. */
+int gs_alloc_counters(uint64_t* allocs, uint64_t* frees);
+/* sizeof(gs_timing), sizeof(gs_memory) of THIS library: both structs are written through caller pointers, and a binding compiled
+ * against another revision of this header can tell before it passes a short buffer (gs_timing grew in round 4). */
+int gs_abi_sizes(size_t* timing_bytes, size_t* memory_bytes);
 /* Free every cached workspace of the current logical device (bucket sets, plan buffers, NTT twiddles, node trees, factorial
  * tables); rebuilt on demand.  Handles and their tables stay. */
 int gs_trim(void);

@@ -144,9 +144,27 @@ def test_prove_batch_c_sequence_two_logical_devices(tmp_path):
 
 
 def test_memory_eviction_c_sequence(tmp_path):
-    """go/gosnarkhip.MemoryOf / HandleBytes / ReleaseTables / Trim == tests/c/memory_eviction.c."""
+    """go/gosnarkhip.MemoryOf / HandleBytes / ReleaseTables / Trim + SetTablePolicy / SetMemoryLimit == tests/c/memory_eviction.c
+    (round 5: two keys under a memory cap evict each other's idle window tables instead of failing; a ticket's key is never the victim)."""
     blob = c_util.write_groth_instance(tmp_path, GU.load("groth_x3"))
     assert c_util.build_and_run("memory_eviction.c", [str(blob)], tmp_path).strip().endswith("OK")
+
+
+def test_stream_host_c_sequence_reproduces_both_reference_proofs(tmp_path):
+    """go/gosnarkhip/stream.go == tests/c/stream_host.c: host-buffer tickets (w + px, w alone, both protocols), gs_scalars_update under
+    an outstanding ticket, no allocation in a steady lap, a fresh key's first proof table-free under the default policy, gs_build_tables,
+    policy never; the proofs written out are the reference prover's (wasm goldens)."""
+    g, p = GU.load("groth_x3"), GU.load("pinocchio_x3_setup")
+    gblob = c_util.write_groth_instance(tmp_path, g)
+    pblob = c_util.write_pinocchio_instance(tmp_path, p)
+    r1cs = c_util.write_r1cs(tmp_path, (O.X3_R1CS_A, O.X3_R1CS_B, O.X3_R1CS_C), 1, [])
+    out = tmp_path / "proofs.bin"
+    assert c_util.build_and_run("stream_host.c", [str(r1cs), str(gblob), str(pblob), str(out)], tmp_path).strip() == "OK"
+    raw = c_util.read_words(out)
+    assert words(raw[:32]) == aff1(g["proof"]["PiA"]) + aff2(g["proof"]["PiB"]) + aff1(g["proof"]["PiC"])
+    pr = p["proof"]
+    assert words(raw[32:104]) == aff1(pr["PiA"]) + aff1(pr["PiAp"]) + aff2(pr["PiB"]) + aff1(pr["PiBp"]) + aff1(pr["PiC"]) + \
+        aff1(pr["PiCp"]) + aff1(pr["PiH"]) + aff1(pr["PiKp"])
 
 
 def test_witness_to_proof_c_sequence_reproduces_both_reference_proofs(tmp_path):

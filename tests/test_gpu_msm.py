@@ -18,11 +18,14 @@ from oracle import ref_py as O
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", autouse=True)
-def _init():
+@pytest.fixture(scope="module", autouse=True, params=["always", "never"])
+def _init(request):
+    """every test twice: on window tables and table-free (see tests/test_gpu_prove.py)"""
     capi.init()
-    yield
+    capi.set_table_policy(request.param)
+    yield request.param
     capi.set_window_bits(0)
+    capi.set_table_policy("auto")
 
 
 def test_upload_download_affine_normal_form():

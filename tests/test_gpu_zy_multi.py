@@ -22,6 +22,7 @@ NLOG = 8
 def eight_logical_devices():
     capi.shutdown()
     capi.init([0] * NLOG)
+    capi.set_table_policy("always")        # (the routes themselves: tests/test_gpu_prove.py runs every test on both)
     assert capi.device_count() == NLOG
     yield
     capi.comm_destroy()

@@ -137,6 +137,23 @@ def local_types(body):
     for m in re.finditer(r"\bvar\s+([\w,\s]+?)\s+(\[\w*\])?C\.(\w+)", body):
         for name in m.group(1).split(","):
             types[name.strip()] = ("array:" if m.group(2) else "") + m.group(3)
+    # parameters of function literals and of the enclosing function: `func(out *C.uint64_t, inf *C.int) C.int { ... }`,
+    # `func f(o *C.uint64_t, n C.size_t)` -- a `*C.T` parameter is a pointer, a `C.T` one a scalar / handle of that type
+    for m in re.finditer(r"\bfunc\b[^()]*\(([^()]*)\)", body):
+        pending = []
+        for part in m.group(1).split(","):
+            toks = part.split()
+            if not toks:
+                continue
+            if len(toks) == 1:                 # `a, b *C.T`: the type follows a later name
+                pending.append(toks[0])
+                continue
+            name, typ = toks[0], " ".join(toks[1:])
+            mt = re.fullmatch(r"(\*?)C\.(\w+)", typ)
+            for nm in pending + [name]:
+                if mt and re.fullmatch(r"\w+", nm):
+                    types[nm] = ("ptr:" if mt.group(1) else "") + mt.group(2)
+            pending = []
     for m in re.finditer(r"(?m)([\w,\s]+?)\s*:=\s*(.+)$", body):
         names = [n.strip() for n in m.group(1).split(",")]
         vals = split_top(m.group(2))
@@ -145,6 +162,9 @@ def local_types(body):
                 mv = re.match(r"\s*C\.(\w+)\(", v)
                 if mv and re.fullmatch(r"\w+", n):
                     types[n] = mv.group(1)
+                mp = re.match(r"\s*\(\*C\.(\w+)\)\(", v)      # o := (*C.uint64_t)(unsafe.Pointer(&out[0]))
+                if mp and re.fullmatch(r"\w+", n):
+                    types[n] = "ptr:" + mp.group(1)
     return types
 
 
@@ -159,10 +179,14 @@ def arg_kind(expr, types):
         return ("handle", "gs_handle") if t == "gs_handle" else ("scalar", t)
     if e.startswith("&"):
         return "pointer", None
+    if re.fullmatch(r"\d+", e):                  # an untyped integer constant converts to whatever scalar the parameter is
+        return "scalar", None
     if re.fullmatch(r"\w+", e) and e in types:
         t = types[e]
         if t.startswith("array:"):
             return None, None
+        if t.startswith("ptr:"):
+            return "pointer", None
         return ("handle", "gs_handle") if t == "gs_handle" else ("scalar", t)
     if e.startswith("unsafe.Pointer(") or e.startswith("(*") or e.startswith("handles(") or e.startswith("hptr("):
         return "pointer", None
