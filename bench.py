@@ -1483,6 +1483,12 @@ def main():
                              "NOT measured: no multi-GPU hardware is reachable from this run." % (tail_ms, vr["scatter_payload_bytes_per_peer"])}
             out["sharding"] = shard_info
         out["build"] = build_stamp()
+        try:       # what the library holds after the run (gs_memory_query): key data, window tables (0 under --table-policy never), workspaces
+            mq = capi.memory_query()
+            out["memory"] = {k: mq[k] for k in ("device_total_bytes", "device_free_bytes", "library_bytes", "object_bytes", "table_bytes", "workspace_bytes", "evictions")}
+            out["memory"]["table_policy"] = args.table_policy
+        except capi.GosnarkHipError:
+            pass
         for k, v in extras.items():
             out[k] = v
         if proof_verified:

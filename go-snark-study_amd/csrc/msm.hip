@@ -436,13 +436,15 @@ void msm_book_timing(Ctx& c, const MsmPending& p) {
   c.timing.reduce_ms += p.tred->ms();
   // the plan's own counts travel behind the group's results (the download has completed: tred's stop event follows it): a term
   // has one digit per window, a zero digit costs nothing, every other one is exactly one mixed addition of the accumulation kernel
-  const uint32_t* st = reinterpret_cast<const uint32_t*>(static_cast<const char*>(p.pinned_slot) + p.stats_off);
-  const uint64_t adds = p.pinned_slot ? (uint64_t)st[0] * p.njobs : terms * p.W;
+  const uint32_t* st = p.pinned_slot ? reinterpret_cast<const uint32_t*>(static_cast<const char*>(p.pinned_slot) + p.stats_off) : nullptr;
+  const uint64_t adds = st ? (uint64_t)st[0] * p.njobs : terms * p.W;
   if (!p.g2) { c.timing.acc_g1_ms += p.tker->ms(); c.timing.acc_g1_launches += 1; c.timing.acc_g1_terms += terms; c.timing.acc_g1_adds += adds; }
   else { c.timing.acc_g2_ms += p.tker->ms(); c.timing.acc_g2_launches += 1; c.timing.acc_g2_terms += terms; c.timing.acc_g2_adds += adds; }
   c.timing.plan_digits += terms * p.W;
   c.timing.plan_entries += adds;
-  if (p.pinned_slot) c.timing.heavy_buckets += st[1];
+  // (per MSM GROUP: the G2 and the G1 group over w share one plan, so a proof books that plan's heavy buckets twice -- what the
+  //  heavy-bucket kernels really processed, once per group; include/gosnark_hip.h says so)
+  if (st) c.timing.heavy_buckets += st[1];
 }
 
 // table-free route: the pairs of a job come window by window (nblk_window each); S_w = sum_pairs of window w, and the result is

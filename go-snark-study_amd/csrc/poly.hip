@@ -64,11 +64,14 @@ struct PolyState {
     size_t n = 0, dz = 0, N = 0;
     uint64_t stamp = 0;
     DevBuf inv_spec, shift_spec, t1, t2;         // spectra of 1/(t+1) and (-n)^t/t! (size N), value scalings (n each)
-    DevBuf conv, hv, g, bad;                     // workspaces: 3 N, n, n; the violated-constraint counter (one word)
   };
   static constexpr int kHxSlots = 4;
   HxTables hx[kHxSlots];
   uint64_t hx_clock = 0;
+  // The workspaces of the H stage are shared by the slots (one set per slot kept ~1.9 GB per cached size at 2^22
+  // constraints): 3 N, n, n elements and the violated-constraint word, grown to the largest size seen.  Every user enqueues on the
+  // polynomial stream (aux 1), so stream order keeps consecutive proofs of different sizes apart.
+  DevBuf hx_conv, hx_hv, hx_g, hx_bad;
 };
 static PolyState& poly_state(Ctx& c) { return c.state<PolyState>(c.poly_state); }
 
@@ -408,7 +411,10 @@ static PolyState::HxTables& hx_tables(Ctx& c, size_t n, size_t dz) {
   PolyState::HxTables& hx = *slot;
   // Every user of these tables enqueues on the polynomial stream (c.stream here): before a victim's buffers go, whatever is queued
   // on it must have run -- stated here instead of leaning on hipFree's device-wide synchronisation.
-  if (hx.n != 0) GS_HIP(hipStreamSynchronize(c.stream));
+  if (hx.n != 0) {
+    GS_HIP(hipStreamSynchronize(c.stream));
+    if (c.aux_stream[1] && c.aux_stream[1] != c.stream) GS_HIP(hipStreamSynchronize(c.aux_stream[1]));   // (whoever the caller is)
+  }
   const int logN = ceil_log2(2 * n);
   const size_t N = (size_t)1 << logN;
   Fe<ModR, 1> r2;
@@ -419,7 +425,11 @@ static PolyState::HxTables& hx_tables(Ctx& c, size_t n, size_t dz) {
   ensure_factorials(c, 2 * n);
   hx = PolyState::HxTables{};
   hx.inv_spec.alloc(N * 32); hx.shift_spec.alloc(N * 32); hx.t1.alloc(n * 32); hx.t2.alloc(n * 32);
-  hx.conv.alloc(3 * N * 32); hx.hv.alloc(n * 32); hx.g.alloc(n * 32); hx.bad.alloc(16);
+  if (ps.hx_conv.p && (3 * N * 32 > ps.hx_conv.bytes || n * 32 > ps.hx_hv.bytes)) {      // growing: earlier proofs' H stages may still use the old ones
+    GS_HIP(hipStreamSynchronize(c.stream));
+    if (c.aux_stream[1] && c.aux_stream[1] != c.stream) GS_HIP(hipStreamSynchronize(c.aux_stream[1]));
+  }
+  ps.hx_conv.ensure(3 * N * 32); ps.hx_hv.ensure(n * 32); ps.hx_g.ensure(n * 32); ps.hx_bad.ensure(16);
   hipLaunchKernelGGL(k_hx_tables, grid1(N), dim3(256), 0, c.stream, ps.fact.as<uint32_t>(), ps.invfact.as<uint32_t>(), (uint32_t)n, (uint32_t)dz, (uint32_t)N,
                      inv_N, r2c, hx.inv_spec.as<uint32_t>(), hx.t1.as<uint32_t>(), hx.t2.as<uint32_t>());
   // (-n)^t, t < n, in standard form (scale 1), then / t!
@@ -458,7 +468,7 @@ bool hx_values_dev(Ctx& c, const uint32_t* vals_std, size_t n, size_t dz, uint32
   NodeTree& t = ensure_tree(c, n, true);
   const int logN = ceil_log2(2 * n);
   const size_t N = hx.N;
-  uint32_t* conv = hx.conv.as<uint32_t>();
+  uint32_t* conv = poly_state(c).hx_conv.as<uint32_t>();
   hipLaunchKernelGGL(k_hx_weigh, grid1(3 * N), dim3(256), 0, c.stream, vals_std, t.weights.as<uint32_t>(), (uint32_t)n, (uint32_t)N, 3u, conv);
   ntt_forward_n(c, conv, 3 * N, logN);
   hipLaunchKernelGGL(k_pw_mul_bcast, grid1(3 * N), dim3(256), 0, c.stream, conv, hx.inv_spec.as<uint32_t>(), (uint32_t)N, 3u);
@@ -476,9 +486,9 @@ void hx_from_values_dev(Ctx& c, const uint32_t* hv_std, size_t n, size_t dz, uin
   const int logN = ceil_log2(2 * n);
   const size_t N = hx.N, nh = 2 * n - 1 - dz;
   const FrConst inv_N = inv_n_const(logN, 0);
-  uint32_t* conv = hx.conv.as<uint32_t>();
-  interpolate_dev(c, hv_std, n, 1, hx.g.as<uint32_t>());
-  hipLaunchKernelGGL(k_hx_shift_in, grid1(N), dim3(256), 0, c.stream, hx.g.as<uint32_t>(), ps.fact.as<uint32_t>(), (uint32_t)n, (uint32_t)N, conv);
+  uint32_t* conv = poly_state(c).hx_conv.as<uint32_t>();
+  interpolate_dev(c, hv_std, n, 1, poly_state(c).hx_g.as<uint32_t>());
+  hipLaunchKernelGGL(k_hx_shift_in, grid1(N), dim3(256), 0, c.stream, poly_state(c).hx_g.as<uint32_t>(), ps.fact.as<uint32_t>(), (uint32_t)n, (uint32_t)N, conv);
   ntt_forward(c, conv, logN, logN);
   hipLaunchKernelGGL(k_pw_mul, grid1(N), dim3(256), 0, c.stream, conv, hx.shift_spec.as<uint32_t>(), conv, (uint32_t)N);
   ntt_inverse_unscaled(c, conv, logN, logN);
@@ -493,12 +503,12 @@ bool hx_direct_dev(Ctx& c, const uint32_t* vals_std, size_t n, size_t dz, uint32
   if (!hx_shape_ok(n, dz)) return false;
   PolyState::HxTables& hx = hx_tables(c, n, dz);
   uint32_t nbad = 0;                                    // the flag word lives with the tables: no allocation on the per-proof path
-  r1cs_check_dev(c, vals_std, n, dz, hx.bad.as<uint32_t>());
-  GS_HIP(hipMemcpyAsync(&nbad, hx.bad.p, 4, hipMemcpyDeviceToHost, c.stream));
+  r1cs_check_dev(c, vals_std, n, dz, poly_state(c).hx_bad.as<uint32_t>());
+  GS_HIP(hipMemcpyAsync(&nbad, poly_state(c).hx_bad.p, 4, hipMemcpyDeviceToHost, c.stream));
   GS_HIP(hipStreamSynchronize(c.stream));
   if (nbad) return false;
-  hx_values_dev(c, vals_std, n, dz, hx.hv.as<uint32_t>());
-  hx_from_values_dev(c, hx.hv.as<uint32_t>(), n, dz, hx_out);
+  hx_values_dev(c, vals_std, n, dz, poly_state(c).hx_hv.as<uint32_t>());
+  hx_from_values_dev(c, poly_state(c).hx_hv.as<uint32_t>(), n, dz, hx_out);
   return true;
 }
 

@@ -105,6 +105,19 @@ struct GrothTailEarly {
   bool done = false;
   G1Xyzz piA, piB1, sA, rB;
 };
+// GS_HOST_STAGE (scheduling only, same results): how a host-buffer ticket's arrays reach its slot.
+//   0  copy stream + event: the kernels that read the vector wait for the copy's event on their own streams
+//   1  copy stream, and the host waits for the copy to land before it enqueues the readers (what gs_scalars_update + _begin does)
+//   2  on the stream of the first reader itself (w: the plan(w) stream, px: the polynomial stream); other readers wait for its event
+// Measured at 2^20, three in flight, eight rotating witnesses (profiles/r05_ab_host_stage.txt; resident: 10.03-10.07 / px 8.84-9.01 ms):
+//   witness from the host   0: 11.2-11.3   1: 10.12-10.17   2: 10.1-11.0        w + px from the host   0: 10.9   1: 9.45-9.51   2: 11.4-11.5
+// The cross-stream event of mode 0 costs more than the host wait of mode 1 (the host has nothing else to do: the device is busy with the
+// two tickets before this one), hence 1.
+static long host_stage_mode() {
+  static const long mode = run_knob("GS_HOST_STAGE", 1, 0, 2);
+  return mode;
+}
+// w: staged at once (everything of a proof starts with plan(w))
 // The streams ONE proof's device work is enqueued on, decided once per proof (round 4 toggled a context flag between two
 // evaluations of an accessor instead).  plan(w) of a pipelined proof gets its own stream (aux 2, every tail then shares aux 0) where
 // the polynomial stage is long: on aux 1 the NEXT proof's plan(w) queues behind this proof's H stage and plan(h), and the
@@ -216,7 +229,11 @@ int groth16_enqueue(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, const S
   // so with two proofs in flight it never idles: both plans, H(x) and every combine/reduce tail run on the aux streams.
   const ProofStreams ps = proof_streams(c, pipelined, whi - wlo, (bool)px.produce_hv || (bool)px.produce_hx || (bool)px.produce);   // (not hv_slice: no polynomial work here)
   st.streams = ps;
-  if (w.host_done) {                                             // w was staged on the copy stream (host-buffer ticket): its readers wait for the DMA
+  if (w.host && w.host_done) {                                   // host-buffer ticket, GS_HOST_STAGE=2: w is copied on the plan(w) stream itself
+    staged_h2d(c, const_cast<uint32_t*>(w.p), w.host, w.n * 32, ps.planw);
+    GS_HIP(hipEventRecord(w.host_done, ps.planw));
+    if (ps.poly != ps.planw) GS_HIP(hipStreamWaitEvent(ps.poly, w.host_done, 0));
+  } else if (w.host_done) {                                      // w was staged on the copy stream: its readers wait for the DMA
     GS_HIP(hipStreamWaitEvent(ps.planw, w.host_done, 0));
     if (ps.poly != ps.planw) GS_HIP(hipStreamWaitEvent(ps.poly, w.host_done, 0));
   }
@@ -248,8 +265,13 @@ int groth16_enqueue(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, const S
     StreamScope sc(c, ps.poly);
     if (px.host && px.n && px.host_stream) {   // host-buffer ticket: on the copy stream, beside whatever aux 1 still carries of the previous proof
       staged_h2d(c, const_cast<uint32_t*>(px.p), px.host, px.n * 32, px.host_stream);
-      GS_HIP(hipEventRecord(px.host_done, px.host_stream));
-      GS_HIP(hipStreamWaitEvent(c.stream, px.host_done, 0));
+      if (host_stage_mode() == 1) GS_HIP(hipStreamSynchronize(px.host_stream));
+      else {
+        GS_HIP(hipEventRecord(px.host_done, px.host_stream));
+        GS_HIP(hipStreamWaitEvent(c.stream, px.host_done, 0));
+      }
+    } else if (px.host && px.n && pipelined) {      // host-buffer ticket, GS_HOST_STAGE=2: in stream order on the polynomial stream, no host wait
+      staged_h2d(c, const_cast<uint32_t*>(px.p), px.host, px.n * 32, c.stream);
     } else if (px.host && px.n) {     // the device is already busy with ~8 ms of accumulations: this copy is off the critical path
       PhaseTimer th(c.stream);
       staged_h2d(c, const_cast<uint32_t*>(px.p), px.host, px.n * 32, c.stream);
@@ -495,7 +517,11 @@ int pinocchio_enqueue(Ctx& c, PinocchioPkObj* pk, DevScalars w, DevScalars px, c
   MsmPlan plan_w, plan_h;
   const ProofStreams ps = proof_streams(c, pipelined, whi - wlo, (bool)px.produce_hv || (bool)px.produce_hx || (bool)px.produce);
   st.streams = ps;
-  if (w.host_done) {                                             // host-buffer ticket: w's readers wait for its DMA
+  if (w.host && w.host_done) {                                   // host-buffer ticket, GS_HOST_STAGE=2: w is copied on the plan(w) stream itself
+    staged_h2d(c, const_cast<uint32_t*>(w.p), w.host, w.n * 32, ps.planw);
+    GS_HIP(hipEventRecord(w.host_done, ps.planw));
+    if (ps.poly != ps.planw) GS_HIP(hipStreamWaitEvent(ps.poly, w.host_done, 0));
+  } else if (w.host_done) {                                      // w was staged on the copy stream: its readers wait for the DMA
     GS_HIP(hipStreamWaitEvent(ps.planw, w.host_done, 0));
     if (ps.poly != ps.planw) GS_HIP(hipStreamWaitEvent(ps.poly, w.host_done, 0));
   }
@@ -521,8 +547,13 @@ int pinocchio_enqueue(Ctx& c, PinocchioPkObj* pk, DevScalars w, DevScalars px, c
     StreamScope sc(c, ps.poly);
     if (px.host && px.n && px.host_stream) {   // host-buffer ticket: on the copy stream (groth16_enqueue)
       staged_h2d(c, const_cast<uint32_t*>(px.p), px.host, px.n * 32, px.host_stream);
-      GS_HIP(hipEventRecord(px.host_done, px.host_stream));
-      GS_HIP(hipStreamWaitEvent(c.stream, px.host_done, 0));
+      if (host_stage_mode() == 1) GS_HIP(hipStreamSynchronize(px.host_stream));
+      else {
+        GS_HIP(hipEventRecord(px.host_done, px.host_stream));
+        GS_HIP(hipStreamWaitEvent(c.stream, px.host_done, 0));
+      }
+    } else if (px.host && px.n && pipelined) {      // host-buffer ticket, GS_HOST_STAGE=2 (groth16_enqueue)
+      staged_h2d(c, const_cast<uint32_t*>(px.p), px.host, px.n * 32, c.stream);
     } else if (px.host && px.n) {     // the accumulations over w are already enqueued: this copy is off the critical path
       PhaseTimer th(c.stream);
       staged_h2d(c, const_cast<uint32_t*>(px.p), px.host, px.n * 32, c.stream);
@@ -637,17 +668,24 @@ void download(Ctx& c, uint64_t* host, const void* dev, size_t n) {
 static void ensure_copy_stream(Ctx& c) {
   if (!c.copy_stream) GS_HIP(hipStreamCreateWithFlags(&c.copy_stream, hipStreamNonBlocking));
 }
-// w: staged at once (everything of a proof starts with plan(w))
 DevScalars stage_slot_w(Ctx& c, int parity, const uint64_t* host, size_t n, HostInputs& in) {
   ensure_copy_stream(c);
   in.create();
-  in.th2d = std::make_shared<PhaseTimer>(c.copy_stream);
   DevBuf& b = prove_state(c).slot_w[parity];
   b.ensure(std::max<size_t>(n, 1) * 32);
-  if (n) staged_h2d(c, b.p, host, n * 32, c.copy_stream);
-  GS_HIP(hipEventRecord(in.w_done, c.copy_stream));
   DevScalars d{b.as<uint32_t>(), n};
-  d.host_done = in.w_done;
+  if (host_stage_mode() == 2) {          // copied by the enqueue function on the plan(w) stream
+    d.host = host;
+    d.host_done = in.w_done;
+    return d;
+  }
+  in.th2d = std::make_shared<PhaseTimer>(c.copy_stream);
+  if (n) staged_h2d(c, b.p, host, n * 32, c.copy_stream);
+  if (host_stage_mode() == 1) GS_HIP(hipStreamSynchronize(c.copy_stream));
+  else {
+    GS_HIP(hipEventRecord(in.w_done, c.copy_stream));
+    d.host_done = in.w_done;
+  }
   return d;
 }
 // px: staged by the enqueue function AFTER the accumulations over w were queued (they do not need it), on the copy stream
@@ -656,8 +694,13 @@ DevScalars slot_px_from_host(Ctx& c, int parity, const uint64_t* host, size_t n,
   in.create();
   DevBuf& b = prove_state(c).slot_px[parity];
   b.ensure(std::max<size_t>(n, 1) * 32);
+  if (host_stage_mode() == 1) {          // landed before anything of the proof is enqueued (the device is busy with the tickets before this one)
+    if (n) staged_h2d(c, b.p, host, n * 32, c.copy_stream);
+    GS_HIP(hipStreamSynchronize(c.copy_stream));
+    return DevScalars{b.as<uint32_t>(), n};
+  }
   DevScalars d{b.as<uint32_t>(), n, host};
-  d.host_stream = c.copy_stream;
+  d.host_stream = host_stage_mode() == 2 ? nullptr : c.copy_stream;      // (nullptr: on the polynomial stream itself, as the blocking entry points do)
   d.host_done = in.px_done;
   return d;
 }

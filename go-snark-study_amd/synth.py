@@ -339,8 +339,7 @@ def realistic_r1cs(n, seed):
         vals.append(cur)
     if vals:
         w[var[ch]] = capi.ints_to_u64(vals)
-    counts = {"bit": int(is_bit.sum()), "small": int(is_small.sum()), "full_width": int(is_chain.sum()) + 1,
-              "zeros": int((w[:, 0] == 0).sum() if True else 0)}
+    counts = {"bit": int(is_bit.sum()), "small": int(is_small.sum()), "full_width": int(is_chain.sum()) + 1}
     counts["zeros"] = int(((w == 0).all(axis=1)).sum())
     counts["ones"] = int(((w[:, 0] == 1) & (w[:, 1:] == 0).all(axis=1)).sum())
     return a, b, c, w, counts

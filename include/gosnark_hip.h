@@ -457,7 +457,8 @@ typedef struct {
    * of 0 / 1 / small values: a fraction of it. */
   uint64_t plan_digits;   /* terms x windows x base arrays */
   uint64_t plan_entries;  /* non-zero digits x base arrays = mixed additions the accumulation kernels really performed */
-  uint32_t heavy_buckets; /* buckets cut into more than 64 chunks (0/1-heavy witnesses), combined by a block-wide tree */
+  uint32_t heavy_buckets; /* buckets cut into more than 64 chunks (0/1-heavy witnesses), combined by a block-wide tree; summed per MSM GROUP
+                           * (a proof's G2 and G1 groups over w share one plan: its heavy buckets count once for each) */
   uint32_t reserved;
 } gs_timing;
 int gs_last_timing(gs_timing* out);                         /* the calling thread's current logical device */
