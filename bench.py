@@ -65,7 +65,13 @@ MAD_PEAK_T = 31.5              # T lane-mad/s, v_mad_u64_u32, measured: tools/ub
 G1_TERM_BYTES = 96             # 32 B scalar + 64 B affine base per G1 MSM term
 MADS_PER_MIXED_ADD = 1467      # 6 products (162 mads) + 2 squarings (126) + one two-term product (243)
 VALU_PER_MIXED_ADD = 2090      # SQ_INSTS_VALU per G1 mixed addition (profiles/r03_/r04_pmc_sq_accumulate_prove.txt)
-ISSUE_PEAK_G = 1024 * 2.4 / 4  # G wave-instructions/s: 256 CUs x 4 SIMDs, one wave64 VALU instruction per 4 cycles, nominal 2.4 GHz
+# What bounds the dominant kernel (round 5, profiles/r05_pmc_sq_issue_breakdown.txt): not issue slots but POWER.  Real shader cycles per
+# wave64 instruction per SIMD (tools/ubench_issue.hip, s_memtime): v_mad_u64_u32 3.15, other VOP3 3.1, VOP2 2.07 -- the G1 addition's
+# mix (tools/isa_histogram.py: 1474 : 313 : 337) sums to 6305 cycles, and fp29.h's own products in a bare loop on random data run AT
+# that bound (604 cycles per product, tools/ubench_mulmod.hip) -- but at the 1.35 GHz the power budget leaves such a loop: 207 VALU
+# instructions per 447 ns per SIMD.  That rate, chip-wide, is the peak below; the kernel itself leaves 30 % of its cycles empty and runs
+# at 1.84 GHz instead.  (Round 4 priced every VALU instruction at 4 cycles of the NOMINAL 2.4 GHz: neither figure was right.)
+ISSUE_PEAK_G = 1024 * 0.463    # G wave-instructions/s: 1024 SIMDs x 463 M/s (the dots3 product loop)
 R = groth16.R
 
 
@@ -1426,9 +1432,12 @@ def main():
             wave_instr = tm_acc["acc_g1_adds"] / launches / 64.0 * VALU_PER_MIXED_ADD / avg_launch_s if avg_launch_s > 0 else 0.0
             out["roofline_issue"] = {"bound": "valu-issue", "kernel": "k_bucket_accumulate<G1>", "achieved": wave_instr / 1e9, "peak": ISSUE_PEAK_G,
                                      "unit": "G wave-instructions/s", "frac": wave_instr / 1e9 / ISSUE_PEAK_G,
-                                     "note": "2090 VALU instructions per mixed addition x additions / 64 lanes; peak = 1024 SIMDs x 2.4 GHz nominal / 4 cycles per wave64 "
-                                             "instruction.  The chip sustains ~1.85 GHz under this load (GRBM_GUI_ACTIVE / kernel time), i.e. ~0.9 of what its "
-                                             "actual clock can issue: the kernel is instruction-issue bound, and only fewer instructions make it faster"}
+                                     "note": "2090 VALU instructions per mixed addition x additions / 64 lanes; peak = the rate at which the chip executes fp29.h's own "
+                                             "Montgomery products (dots3, random data) in a bare loop without loads: 207 VALU instructions per 447 ns per SIMD "
+                                             "(tools/ubench_mulmod.hip: 604 real cycles per product -- the per-class issue bound -- at the 1.35 GHz the power budget "
+                                             "leaves that loop).  The kernel needs 8980 cycles per wave-addition against 6305 for the per-class sum (0.70 in cycles: "
+                                             "12 % of a wave's time is s_waitcnt, 2.65 of 3 waves resident) but runs at 1.84 GHz: power, not issue slots, bounds this "
+                                             "arithmetic (profiles/r05_pmc_sq_issue_breakdown.txt)"}
             out["roofline_whole_step"] = {"bound": "hbm", "algorithmic_bytes_per_step": step_bytes,
                                           "achieved": step_bytes / (elapsed / args.steps) / 1e9,
                                           "peak": HBM_PEAK_GBS, "unit": "GB/s",

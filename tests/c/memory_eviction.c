@@ -49,6 +49,8 @@ int main(int argc, char** argv) {
      *  below is about TABLES) */
     CHECK(gs_release_tables(key));
     CHECK(gs_groth16_prove_resident(key, w, px, g.rs, g.rs + 4, got, inf2));
+    CHECK(gs_groth16_prove_begin(key, w, px, g.rs, g.rs + 4, &t));     /* ... and a ticket slot's workspaces */
+    CHECK(gs_groth16_prove_end(t, got, inf2));
     CHECK(gs_memory_query(&m3));
     /* room for an eighth of a second set of tables (and the few hundred bytes key2's first quotient caches): key2's first proof must
      * drop key's tables (idle, least recently used), one per allocation that does not fit */

@@ -24,6 +24,15 @@ constexpr int ITERS = 1000;
     "v_mad_u64_u32 %0, vcc, %8, %9, %0\n v_mad_u64_u32 %1, vcc, %8, %9, %1\n v_mad_u64_u32 %2, vcc, %8, %9, %2\n v_mad_u64_u32 %3, vcc, %8, %9, %3\n s_nop 0\n" \
     "v_mad_u64_u32 %4, vcc, %8, %9, %4\n v_mad_u64_u32 %5, vcc, %8, %9, %5\n v_mad_u64_u32 %6, vcc, %8, %9, %6\n v_mad_u64_u32 %7, vcc, %8, %9, %7\n" \
     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(x), "v"(y) : "vcc")
+// the same 8 multiply-adds on TWO / THREE accumulators (what a wave of the G1 kernel has: two- and three-chain interleaved products)
+#define MAD8_2CH asm volatile( \
+    "v_mad_u64_u32 %0, vcc, %2, %3, %0\n v_mad_u64_u32 %1, vcc, %2, %3, %1\n v_mad_u64_u32 %0, vcc, %2, %3, %0\n v_mad_u64_u32 %1, vcc, %2, %3, %1\n" \
+    "v_mad_u64_u32 %0, vcc, %2, %3, %0\n v_mad_u64_u32 %1, vcc, %2, %3, %1\n v_mad_u64_u32 %0, vcc, %2, %3, %0\n v_mad_u64_u32 %1, vcc, %2, %3, %1\n" \
+    : "+v"(a0), "+v"(a1) : "v"(x), "v"(y) : "vcc")
+#define MAD9_3CH asm volatile( \
+    "v_mad_u64_u32 %0, vcc, %3, %4, %0\n v_mad_u64_u32 %1, vcc, %3, %4, %1\n v_mad_u64_u32 %2, vcc, %3, %4, %2\n v_mad_u64_u32 %0, vcc, %3, %4, %0\n" \
+    "v_mad_u64_u32 %1, vcc, %3, %4, %1\n v_mad_u64_u32 %2, vcc, %3, %4, %2\n v_mad_u64_u32 %0, vcc, %3, %4, %0\n v_mad_u64_u32 %1, vcc, %3, %4, %1\n" \
+    : "+v"(a0), "+v"(a1), "+v"(a2) : "v"(x), "v"(y) : "vcc")
 #define OTHER4(INS) asm volatile(INS(%0) "\n" INS(%1) "\n" INS(%2) "\n" INS(%3) "\n" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(x))
 #define OTHER4_64(INS) asm volatile(INS(%0) "\n" INS(%1) "\n" INS(%2) "\n" INS(%3) "\n" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(x))
 #define I_ADD(r) "v_add_u32 " #r ", " #r ", " #r
@@ -38,7 +47,7 @@ constexpr int ITERS = 1000;
 
 // instructions of the mode's class(es) one wave issues per loop iteration
 __host__ __device__ constexpr int per_iter(int mode) {
-  return mode == 0 ? 64 : mode <= 8 ? 64 : mode == 9 ? 64 + 14 + 15 : mode == 10 ? 64 + 14 + 15 : mode == 11 ? 64 : 64;
+  return mode == 16 || mode == 17 ? 64 + 12 : mode == 15 ? 64 + 15 + 34 : mode == 9 || mode == 10 || (mode >= 12 && mode <= 14) ? 64 + 14 + 15 : 64;      // (15: + the copies that create the dependence)
 }
 
 template <int MODE>
@@ -77,6 +86,90 @@ __global__ void __launch_bounds__(256, 3) k_issue(uint32_t* out, unsigned long l
     } else if constexpr (MODE == 11) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) NOP4;
+    } else if constexpr (MODE == 16 || MODE == 17) {
+      // multiply-adds whose multiplicands come from 2 x 9 DIFFERENT registers, like acc += a[i] * b[j] of a product (the modes above
+      // multiply the same two registers all the time): does the register file's banking cost issue cycles?  16: 8 chains, 17: 2 chains
+      uint32_t av[9], bv[9];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) { av[i] = x + i * 7u + (uint32_t)it; bv[i] = y ^ (i * 13u); }
+      uint64_t acc[8] = {a0, a1, a2, a3, a4, a5, a6, a7};
+      if constexpr (MODE == 16) {
+        asm volatile("v_mad_u64_u32 %0, vcc, %8, %17, %0\n" "v_mad_u64_u32 %1, vcc, %9, %22, %1\n" "v_mad_u64_u32 %2, vcc, %10, %18, %2\n" "v_mad_u64_u32 %3, vcc, %11, %23, %3\n" "v_mad_u64_u32 %4, vcc, %12, %19, %4\n" "v_mad_u64_u32 %5, vcc, %13, %24, %5\n" "v_mad_u64_u32 %6, vcc, %14, %20, %6\n" "v_mad_u64_u32 %7, vcc, %15, %25, %7\n"
+                     : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7])
+                     : "v"(av[0]), "v"(av[1]), "v"(av[2]), "v"(av[3]), "v"(av[4]), "v"(av[5]), "v"(av[6]), "v"(av[7]), "v"(av[8]), "v"(bv[0]), "v"(bv[1]), "v"(bv[2]), "v"(bv[3]), "v"(bv[4]), "v"(bv[5]), "v"(bv[6]), "v"(bv[7]), "v"(bv[8]) : "vcc");
+        asm volatile("v_mad_u64_u32 %0, vcc, %16, %21, %0\n" "v_mad_u64_u32 %1, vcc, %8, %18, %1\n" "v_mad_u64_u32 %2, vcc, %9, %23, %2\n" "v_mad_u64_u32 %3, vcc, %10, %19, %3\n" "v_mad_u64_u32 %4, vcc, %11, %24, %4\n" "v_mad_u64_u32 %5, vcc, %12, %20, %5\n" "v_mad_u64_u32 %6, vcc, %13, %25, %6\n" "v_mad_u64_u32 %7, vcc, %14, %21, %7\n"
+                     : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7])
+                     : "v"(av[0]), "v"(av[1]), "v"(av[2]), "v"(av[3]), "v"(av[4]), "v"(av[5]), "v"(av[6]), "v"(av[7]), "v"(av[8]), "v"(bv[0]), "v"(bv[1]), "v"(bv[2]), "v"(bv[3]), "v"(bv[4]), "v"(bv[5]), "v"(bv[6]), "v"(bv[7]), "v"(bv[8]) : "vcc");
+        asm volatile("v_mad_u64_u32 %0, vcc, %15, %17, %0\n" "v_mad_u64_u32 %1, vcc, %16, %22, %1\n" "v_mad_u64_u32 %2, vcc, %8, %19, %2\n" "v_mad_u64_u32 %3, vcc, %9, %24, %3\n" "v_mad_u64_u32 %4, vcc, %10, %20, %4\n" "v_mad_u64_u32 %5, vcc, %11, %25, %5\n" "v_mad_u64_u32 %6, vcc, %12, %21, %6\n" "v_mad_u64_u32 %7, vcc, %13, %17, %7\n"
+                     : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7])
+                     : "v"(av[0]), "v"(av[1]), "v"(av[2]), "v"(av[3]), "v"(av[4]), "v"(av[5]), "v"(av[6]), "v"(av[7]), "v"(av[8]), "v"(bv[0]), "v"(bv[1]), "v"(bv[2]), "v"(bv[3]), "v"(bv[4]), "v"(bv[5]), "v"(bv[6]), "v"(bv[7]), "v"(bv[8]) : "vcc");
+        asm volatile("v_mad_u64_u32 %0, vcc, %14, %22, %0\n" "v_mad_u64_u32 %1, vcc, %15, %18, %1\n" "v_mad_u64_u32 %2, vcc, %16, %23, %2\n" "v_mad_u64_u32 %3, vcc, %8, %20, %3\n" "v_mad_u64_u32 %4, vcc, %9, %25, %4\n" "v_mad_u64_u32 %5, vcc, %10, %21, %5\n" "v_mad_u64_u32 %6, vcc, %11, %17, %6\n" "v_mad_u64_u32 %7, vcc, %12, %22, %7\n"
+                     : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7])
+                     : "v"(av[0]), "v"(av[1]), "v"(av[2]), "v"(av[3]), "v"(av[4]), "v"(av[5]), "v"(av[6]), "v"(av[7]), "v"(av[8]), "v"(bv[0]), "v"(bv[1]), "v"(bv[2]), "v"(bv[3]), "v"(bv[4]), "v"(bv[5]), "v"(bv[6]), "v"(bv[7]), "v"(bv[8]) : "vcc");
+        asm volatile("v_mad_u64_u32 %0, vcc, %13, %18, %0\n" "v_mad_u64_u32 %1, vcc, %14, %23, %1\n" "v_mad_u64_u32 %2, vcc, %15, %19, %2\n" "v_mad_u64_u32 %3, vcc, %16, %24, %3\n" "v_mad_u64_u32 %4, vcc, %8, %21, %4\n" "v_mad_u64_u32 %5, vcc, %9, %17, %5\n" "v_mad_u64_u32 %6, vcc, %10, %22, %6\n" "v_mad_u64_u32 %7, vcc, %11, %18, %7\n"
+                     : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7])
+                     : "v"(av[0]), "v"(av[1]), "v"(av[2]), "v"(av[3]), "v"(av[4]), "v"(av[5]), "v"(av[6]), "v"(av[7]), "v"(av[8]), "v"(bv[0]), "v"(bv[1]), "v"(bv[2]), "v"(bv[3]), "v"(bv[4]), "v"(bv[5]), "v"(bv[6]), "v"(bv[7]), "v"(bv[8]) : "vcc");
+        asm volatile("v_mad_u64_u32 %0, vcc, %12, %23, %0\n" "v_mad_u64_u32 %1, vcc, %13, %19, %1\n" "v_mad_u64_u32 %2, vcc, %14, %24, %2\n" "v_mad_u64_u32 %3, vcc, %15, %20, %3\n" "v_mad_u64_u32 %4, vcc, %16, %25, %4\n" "v_mad_u64_u32 %5, vcc, %8, %22, %5\n" "v_mad_u64_u32 %6, vcc, %9, %18, %6\n" "v_mad_u64_u32 %7, vcc, %10, %23, %7\n"
+                     : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7])
+                     : "v"(av[0]), "v"(av[1]), "v"(av[2]), "v"(av[3]), "v"(av[4]), "v"(av[5]), "v"(av[6]), "v"(av[7]), "v"(av[8]), "v"(bv[0]), "v"(bv[1]), "v"(bv[2]), "v"(bv[3]), "v"(bv[4]), "v"(bv[5]), "v"(bv[6]), "v"(bv[7]), "v"(bv[8]) : "vcc");
+        asm volatile("v_mad_u64_u32 %0, vcc, %11, %19, %0\n" "v_mad_u64_u32 %1, vcc, %12, %24, %1\n" "v_mad_u64_u32 %2, vcc, %13, %20, %2\n" "v_mad_u64_u32 %3, vcc, %14, %25, %3\n" "v_mad_u64_u32 %4, vcc, %15, %21, %4\n" "v_mad_u64_u32 %5, vcc, %16, %17, %5\n" "v_mad_u64_u32 %6, vcc, %8, %23, %6\n" "v_mad_u64_u32 %7, vcc, %9, %19, %7\n"
+                     : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7])
+                     : "v"(av[0]), "v"(av[1]), "v"(av[2]), "v"(av[3]), "v"(av[4]), "v"(av[5]), "v"(av[6]), "v"(av[7]), "v"(av[8]), "v"(bv[0]), "v"(bv[1]), "v"(bv[2]), "v"(bv[3]), "v"(bv[4]), "v"(bv[5]), "v"(bv[6]), "v"(bv[7]), "v"(bv[8]) : "vcc");
+        asm volatile("v_mad_u64_u32 %0, vcc, %10, %24, %0\n" "v_mad_u64_u32 %1, vcc, %11, %20, %1\n" "v_mad_u64_u32 %2, vcc, %12, %25, %2\n" "v_mad_u64_u32 %3, vcc, %13, %21, %3\n" "v_mad_u64_u32 %4, vcc, %14, %17, %4\n" "v_mad_u64_u32 %5, vcc, %15, %22, %5\n" "v_mad_u64_u32 %6, vcc, %16, %18, %6\n" "v_mad_u64_u32 %7, vcc, %8, %24, %7\n"
+                     : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7])
+                     : "v"(av[0]), "v"(av[1]), "v"(av[2]), "v"(av[3]), "v"(av[4]), "v"(av[5]), "v"(av[6]), "v"(av[7]), "v"(av[8]), "v"(bv[0]), "v"(bv[1]), "v"(bv[2]), "v"(bv[3]), "v"(bv[4]), "v"(bv[5]), "v"(bv[6]), "v"(bv[7]), "v"(bv[8]) : "vcc");
+      } else {
+        asm volatile("v_mad_u64_u32 %0, vcc, %8, %17, %0\n" "v_mad_u64_u32 %1, vcc, %9, %22, %1\n" "v_mad_u64_u32 %0, vcc, %10, %18, %0\n" "v_mad_u64_u32 %1, vcc, %11, %23, %1\n" "v_mad_u64_u32 %0, vcc, %12, %19, %0\n" "v_mad_u64_u32 %1, vcc, %13, %24, %1\n" "v_mad_u64_u32 %0, vcc, %14, %20, %0\n" "v_mad_u64_u32 %1, vcc, %15, %25, %1\n"
+                     : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7])
+                     : "v"(av[0]), "v"(av[1]), "v"(av[2]), "v"(av[3]), "v"(av[4]), "v"(av[5]), "v"(av[6]), "v"(av[7]), "v"(av[8]), "v"(bv[0]), "v"(bv[1]), "v"(bv[2]), "v"(bv[3]), "v"(bv[4]), "v"(bv[5]), "v"(bv[6]), "v"(bv[7]), "v"(bv[8]) : "vcc");
+        asm volatile("v_mad_u64_u32 %0, vcc, %16, %21, %0\n" "v_mad_u64_u32 %1, vcc, %8, %18, %1\n" "v_mad_u64_u32 %0, vcc, %9, %23, %0\n" "v_mad_u64_u32 %1, vcc, %10, %19, %1\n" "v_mad_u64_u32 %0, vcc, %11, %24, %0\n" "v_mad_u64_u32 %1, vcc, %12, %20, %1\n" "v_mad_u64_u32 %0, vcc, %13, %25, %0\n" "v_mad_u64_u32 %1, vcc, %14, %21, %1\n"
+                     : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7])
+                     : "v"(av[0]), "v"(av[1]), "v"(av[2]), "v"(av[3]), "v"(av[4]), "v"(av[5]), "v"(av[6]), "v"(av[7]), "v"(av[8]), "v"(bv[0]), "v"(bv[1]), "v"(bv[2]), "v"(bv[3]), "v"(bv[4]), "v"(bv[5]), "v"(bv[6]), "v"(bv[7]), "v"(bv[8]) : "vcc");
+        asm volatile("v_mad_u64_u32 %0, vcc, %15, %17, %0\n" "v_mad_u64_u32 %1, vcc, %16, %22, %1\n" "v_mad_u64_u32 %0, vcc, %8, %19, %0\n" "v_mad_u64_u32 %1, vcc, %9, %24, %1\n" "v_mad_u64_u32 %0, vcc, %10, %20, %0\n" "v_mad_u64_u32 %1, vcc, %11, %25, %1\n" "v_mad_u64_u32 %0, vcc, %12, %21, %0\n" "v_mad_u64_u32 %1, vcc, %13, %17, %1\n"
+                     : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7])
+                     : "v"(av[0]), "v"(av[1]), "v"(av[2]), "v"(av[3]), "v"(av[4]), "v"(av[5]), "v"(av[6]), "v"(av[7]), "v"(av[8]), "v"(bv[0]), "v"(bv[1]), "v"(bv[2]), "v"(bv[3]), "v"(bv[4]), "v"(bv[5]), "v"(bv[6]), "v"(bv[7]), "v"(bv[8]) : "vcc");
+        asm volatile("v_mad_u64_u32 %0, vcc, %14, %22, %0\n" "v_mad_u64_u32 %1, vcc, %15, %18, %1\n" "v_mad_u64_u32 %0, vcc, %16, %23, %0\n" "v_mad_u64_u32 %1, vcc, %8, %20, %1\n" "v_mad_u64_u32 %0, vcc, %9, %25, %0\n" "v_mad_u64_u32 %1, vcc, %10, %21, %1\n" "v_mad_u64_u32 %0, vcc, %11, %17, %0\n" "v_mad_u64_u32 %1, vcc, %12, %22, %1\n"
+                     : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7])
+                     : "v"(av[0]), "v"(av[1]), "v"(av[2]), "v"(av[3]), "v"(av[4]), "v"(av[5]), "v"(av[6]), "v"(av[7]), "v"(av[8]), "v"(bv[0]), "v"(bv[1]), "v"(bv[2]), "v"(bv[3]), "v"(bv[4]), "v"(bv[5]), "v"(bv[6]), "v"(bv[7]), "v"(bv[8]) : "vcc");
+        asm volatile("v_mad_u64_u32 %0, vcc, %13, %18, %0\n" "v_mad_u64_u32 %1, vcc, %14, %23, %1\n" "v_mad_u64_u32 %0, vcc, %15, %19, %0\n" "v_mad_u64_u32 %1, vcc, %16, %24, %1\n" "v_mad_u64_u32 %0, vcc, %8, %21, %0\n" "v_mad_u64_u32 %1, vcc, %9, %17, %1\n" "v_mad_u64_u32 %0, vcc, %10, %22, %0\n" "v_mad_u64_u32 %1, vcc, %11, %18, %1\n"
+                     : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7])
+                     : "v"(av[0]), "v"(av[1]), "v"(av[2]), "v"(av[3]), "v"(av[4]), "v"(av[5]), "v"(av[6]), "v"(av[7]), "v"(av[8]), "v"(bv[0]), "v"(bv[1]), "v"(bv[2]), "v"(bv[3]), "v"(bv[4]), "v"(bv[5]), "v"(bv[6]), "v"(bv[7]), "v"(bv[8]) : "vcc");
+        asm volatile("v_mad_u64_u32 %0, vcc, %12, %23, %0\n" "v_mad_u64_u32 %1, vcc, %13, %19, %1\n" "v_mad_u64_u32 %0, vcc, %14, %24, %0\n" "v_mad_u64_u32 %1, vcc, %15, %20, %1\n" "v_mad_u64_u32 %0, vcc, %16, %25, %0\n" "v_mad_u64_u32 %1, vcc, %8, %22, %1\n" "v_mad_u64_u32 %0, vcc, %9, %18, %0\n" "v_mad_u64_u32 %1, vcc, %10, %23, %1\n"
+                     : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7])
+                     : "v"(av[0]), "v"(av[1]), "v"(av[2]), "v"(av[3]), "v"(av[4]), "v"(av[5]), "v"(av[6]), "v"(av[7]), "v"(av[8]), "v"(bv[0]), "v"(bv[1]), "v"(bv[2]), "v"(bv[3]), "v"(bv[4]), "v"(bv[5]), "v"(bv[6]), "v"(bv[7]), "v"(bv[8]) : "vcc");
+        asm volatile("v_mad_u64_u32 %0, vcc, %11, %19, %0\n" "v_mad_u64_u32 %1, vcc, %12, %24, %1\n" "v_mad_u64_u32 %0, vcc, %13, %20, %0\n" "v_mad_u64_u32 %1, vcc, %14, %25, %1\n" "v_mad_u64_u32 %0, vcc, %15, %21, %0\n" "v_mad_u64_u32 %1, vcc, %16, %17, %1\n" "v_mad_u64_u32 %0, vcc, %8, %23, %0\n" "v_mad_u64_u32 %1, vcc, %9, %19, %1\n"
+                     : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7])
+                     : "v"(av[0]), "v"(av[1]), "v"(av[2]), "v"(av[3]), "v"(av[4]), "v"(av[5]), "v"(av[6]), "v"(av[7]), "v"(av[8]), "v"(bv[0]), "v"(bv[1]), "v"(bv[2]), "v"(bv[3]), "v"(bv[4]), "v"(bv[5]), "v"(bv[6]), "v"(bv[7]), "v"(bv[8]) : "vcc");
+        asm volatile("v_mad_u64_u32 %0, vcc, %10, %24, %0\n" "v_mad_u64_u32 %1, vcc, %11, %20, %1\n" "v_mad_u64_u32 %0, vcc, %12, %25, %0\n" "v_mad_u64_u32 %1, vcc, %13, %21, %1\n" "v_mad_u64_u32 %0, vcc, %14, %17, %0\n" "v_mad_u64_u32 %1, vcc, %15, %22, %1\n" "v_mad_u64_u32 %0, vcc, %16, %18, %0\n" "v_mad_u64_u32 %1, vcc, %8, %24, %1\n"
+                     : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7])
+                     : "v"(av[0]), "v"(av[1]), "v"(av[2]), "v"(av[3]), "v"(av[4]), "v"(av[5]), "v"(av[6]), "v"(av[7]), "v"(av[8]), "v"(bv[0]), "v"(bv[1]), "v"(bv[2]), "v"(bv[3]), "v"(bv[4]), "v"(bv[5]), "v"(bv[6]), "v"(bv[7]), "v"(bv[8]) : "vcc");
+      }
+      a0 = acc[0]; a1 = acc[1]; a2 = acc[2]; a3 = acc[3]; a4 = acc[4]; a5 = acc[5]; a6 = acc[6]; a7 = acc[7];
+    } else if constexpr (MODE >= 12 && MODE <= 15) {
+      // the same mix with the multiply-adds on 2 (12), 3 (13) or 1 (14) dependent chains per wave; 15: 2 chains, every other instruction
+      // DEPENDS on the chains' low words (the carry splits / m derivations of a Montgomery column read the accumulator)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (MODE == 12 || MODE == 15) { MAD8_2CH; MAD8_2CH; }
+        if (MODE == 13) { MAD9_3CH; MAD9_3CH; }
+        if (MODE == 14) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0\n v_mad_u64_u32 %0, vcc, %1, %2, %0\n v_mad_u64_u32 %0, vcc, %1, %2, %0\n v_mad_u64_u32 %0, vcc, %1, %2, %0\n"
+                                     "v_mad_u64_u32 %0, vcc, %1, %2, %0\n v_mad_u64_u32 %0, vcc, %1, %2, %0\n v_mad_u64_u32 %0, vcc, %1, %2, %0\n v_mad_u64_u32 %0, vcc, %1, %2, %0\n"
+                                     "v_mad_u64_u32 %0, vcc, %1, %2, %0\n v_mad_u64_u32 %0, vcc, %1, %2, %0\n v_mad_u64_u32 %0, vcc, %1, %2, %0\n v_mad_u64_u32 %0, vcc, %1, %2, %0\n"
+                                     "v_mad_u64_u32 %0, vcc, %1, %2, %0\n v_mad_u64_u32 %0, vcc, %1, %2, %0\n v_mad_u64_u32 %0, vcc, %1, %2, %0\n v_mad_u64_u32 %0, vcc, %1, %2, %0\n"
+                                     : "+v"(a0) : "v"(x), "v"(y) : "vcc");
+        if (MODE == 15) {
+          d0 = a0; d1 = a1;                                  // the shifts below now wait for the chains
+          asm volatile(I_SHR64(%0) "\n" I_SHR64(%1) "\n" : "+v"(d0), "+v"(d1) : "v"(x));
+          c0 = (uint32_t)d0; c1 = (uint32_t)d1;
+          asm volatile(I_AND(%0) "\n" I_AND(%1) "\n" I_MULLO(%2) "\n" I_ADD(%3) "\n" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(x));
+          x ^= c0 & 1u;                                      // ... and the next multiply-adds for them
+        } else {
+          asm volatile(I_SHR64(%0) "\n" I_SHR64(%1) "\n" : "+v"(d0), "+v"(d1) : "v"(x));
+          asm volatile(I_AND(%0) "\n" I_AND(%1) "\n" I_MULLO(%2) "\n" I_ADD(%3) "\n" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(x));
+        }
+      }
+      asm volatile(I_ADD64(%0) "\n" I_ADD64(%1) "\n" : "+v"(d2), "+v"(d3) : "v"(x));
+      asm volatile(I_SHR32(%0) "\n" I_SHR32(%1) "\n" I_SHR32(%2) "\n" : "+v"(c0), "+v"(c1), "+v"(c2) : "v"(x));
     }
   }
   const unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -128,5 +221,11 @@ int main() {
   run<9>("G1-addition mix 64 mad : 14 VOP3 : 15 VOP2", dout, dcyc, blocks);
   run<10>("same mix + one s_nop 0 per eight mads", dout, dcyc, blocks);
   run<11>("s_nop 0", dout, dcyc, blocks);
+  run<12>("mix, multiply-adds on 2 chains per wave", dout, dcyc, blocks);
+  run<13>("mix, multiply-adds on 3 chains per wave", dout, dcyc, blocks);
+  run<14>("mix, multiply-adds on 1 chain per wave", dout, dcyc, blocks);
+  run<15>("mix, 2 chains, the other ops depend on them", dout, dcyc, blocks);
+  run<16>("64 mad on 8 chains, multiplicands from 2 x 9 registers (+ 18 setup ops)", dout, dcyc, blocks);
+  run<17>("64 mad on 2 chains, multiplicands from 2 x 9 registers (+ 18 setup ops)", dout, dcyc, blocks);
   return 0;
 }

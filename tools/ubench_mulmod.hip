@@ -13,6 +13,12 @@
 using namespace gs;
 #define CK(x) do{hipError_t e=(x); if(e!=hipSuccess){printf("HIP error %s at %d\n",hipGetErrorString(e),__LINE__); return 1;}}while(0)
 constexpr int ITERS = 400;
+// round 5: every wave also brackets its loop with s_memtime (the shader clock), so the line reports REAL cycles per product per SIMD and
+// the clock the chip ran at, not wall time x a nominal 2.4 GHz
+__device__ unsigned long long g_span[65536];
+#define SPAN_BEGIN const unsigned long long t0_ = __builtin_amdgcn_s_memtime()
+#define SPAN_END do { const unsigned long long t1_ = __builtin_amdgcn_s_memtime(); \
+                      if (threadIdx.x % 64 == 0) g_span[(blockIdx.x * blockDim.x + threadIdx.x) / 64] = t1_ - t0_; } while (0)
 
 #if defined(__HIP_DEVICE_COMPILE__)
 #define MAD(acc, a, b) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b) : "vcc")
@@ -86,30 +92,37 @@ __device__ __forceinline__ void store3(uint32_t* out, const Fe<ModQ, 2> (&x)[3])
 // every kernel advances three sequences by ITERS products each (3 * ITERS products per thread)
 __global__ void __launch_bounds__(256, 3) k_mul(const uint32_t* in, uint32_t* out) {
   Fe<ModQ, 2> x[3], y; load3(in, x, y);
+  SPAN_BEGIN;
   for (int it = 0; it < ITERS; ++it) { x[0] = mul(x[0], y); x[1] = mul(x[1], y); x[2] = mul(x[2], y); }
+  SPAN_END;
   store3(out, x);
 }
 __global__ void __launch_bounds__(256, 3) k_dots2(const uint32_t* in, uint32_t* out) {
   Fe<ModQ, 2> x[3], y; load3(in, x, y);
+  SPAN_BEGIN;
   for (int it = 0; it < ITERS; it += 2) {            // pairs: (0,1) (2,0) (1,2): three sequences, two chains at a time
     Fe<ModQ, 2> a, b;
     dots2<ModQ>(dot_of(x[0], y), dot_of(x[1], y), a, b); x[0] = a; x[1] = b;
     dots2<ModQ>(dot_of(x[2], y), dot_of(x[0], y), a, b); x[2] = a; x[0] = b;
     dots2<ModQ>(dot_of(x[1], y), dot_of(x[2], y), a, b); x[1] = a; x[2] = b;
   }
+  SPAN_END;
   store3(out, x);
 }
 __global__ void __launch_bounds__(256, 3) k_dots3(const uint32_t* in, uint32_t* out) {
   Fe<ModQ, 2> x[3], y; load3(in, x, y);
+  SPAN_BEGIN;
   for (int it = 0; it < ITERS; ++it) {
     Fe<ModQ, 2> a, b, c;
     dots3<ModQ>(dot_of(x[0], y), dot_of(x[1], y), dot_of(x[2], y), a, b, c); x[0] = a; x[1] = b; x[2] = c;
   }
+  SPAN_END;
   store3(out, x);
 }
 template <int NC>
 __global__ void __launch_bounds__(256, 3) k_asm(const uint32_t* in, uint32_t* out) {
   Fe<ModQ, 2> x[3], y; load3(in, x, y);
+  SPAN_BEGIN;
   if constexpr (NC == 1) {
     for (int it = 0; it < ITERS; ++it)
       for (int c = 0; c < 3; ++c) { Fe<ModQ, 2> a[1] = {x[c]}, b[1] = {y}, r[1]; asm_mul<ModQ, 1>(a, b, r); x[c] = r[0]; }
@@ -125,6 +138,7 @@ __global__ void __launch_bounds__(256, 3) k_asm(const uint32_t* in, uint32_t* ou
   } else {
     for (int it = 0; it < ITERS; ++it) { Fe<ModQ, 2> b[3] = {y, y, y}, r[3]; asm_mul<ModQ, 3>(x, b, r); x[0] = r[0]; x[1] = r[1]; x[2] = r[2]; }
   }
+  SPAN_END;
   store3(out, x);
 }
 
@@ -158,8 +172,15 @@ int main() {
     bool same = true;
     if (ref.empty()) ref = got; else same = ref == got;
     const double prods = (double)nthreads * 3 * ITERS;
-    printf("%-28s %8.3f ms  %7.2f G mulmod/s  %6.1f cycles per product per SIMD @2.4GHz   %s\n", e.name, ms, prods / ms / 1e6,
-           ms * 1e-3 * 2.4e9 * prop.multiProcessorCount * 4 / (prods / 64), same ? "results identical" : "RESULTS DIFFER");
+    const int waves = blocks * threads / 64;
+    std::vector<unsigned long long> span(waves);
+    CK(hipMemcpyFromSymbol(span.data(), HIP_SYMBOL(g_span), waves * sizeof(unsigned long long)));
+    double sum = 0;
+    for (auto v : span) sum += (double)v;
+    const double wave_span = sum / waves;                       // 3 waves per SIMD, each does 3 * ITERS products in its span
+    printf("%-28s %8.3f ms  %7.2f G mulmod/s  %6.1f cycles per product per SIMD @2.4GHz | REAL %6.1f cycles per product per SIMD at %.2f GHz   %s\n", e.name, ms,
+           prods / ms / 1e6, ms * 1e-3 * 2.4e9 * prop.multiProcessorCount * 4 / (prods / 64), wave_span / (3.0 * 3 * ITERS), wave_span / (ms * 1e-3) / 1e9,
+           same ? "results identical" : "RESULTS DIFFER");
   }
   return 0;
 }
