@@ -934,6 +934,7 @@ def main_one_process(args):
     visible = torch.cuda.device_count()
     devs = [d % visible for d in range(N)]
     capi.init(devs)
+    capi.set_table_policy(args.table_policy)       # steady state on window tables (built inside the untimed warm-up), as main()
     if args.window_bits or os.environ.get("GS_BENCH_C"):
         capi.set_window_bits(args.window_bits or int(os.environ["GS_BENCH_C"]))
     guard = LineGuard(0)

@@ -168,7 +168,9 @@ def test_out_of_memory_evicts_idle_tables_instead_of_failing():
             got = groth16.prove_resident(k.device_pk(), k.w, k.px, *rs[i])
             assert same(got, want[i]), (lap, i)
             held = [capi.handle_bytes(x.device_pk().handle)[1] for x in insts]
-            assert held[i] == tab and sum(held) <= tab + tab // 3 + 1
+            now = capi.memory_query()
+            # the prover's own tables are complete, the cap holds, and the three keys together never hold two full sets
+            assert held[i] == tab and now["library_bytes"] <= base["library_bytes"] + tab // 3 and sum(held) < 2 * tab, (lap, i, held, tab)
     m = capi.memory_query()
     assert m["evictions"] >= base["evictions"] + 8 and m["library_bytes"] <= base["library_bytes"] + tab // 3
     # a ticket holds key 2 (the one with tables now): key 0 cannot take them -> a clean GS_ERR_HIP, and the ticket is unharmed
