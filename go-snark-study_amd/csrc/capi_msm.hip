@@ -236,7 +236,7 @@ extern "C" {
 #ifndef GS_BUILD_FLAGS
 #define GS_BUILD_FLAGS "unknown"
 #endif
-const char* gs_version(void) { return "gosnark-hip 0.3 gfx950 (9x29-bit Montgomery, XYZZ Pippenger, evaluation-basis keys); built with " GS_BUILD_FLAGS; }
+const char* gs_version(void) { return "gosnark-hip 0.5 gfx950 (9x29-bit Montgomery, XYZZ Pippenger on window tables or table-free, evaluation-basis keys, host-buffer tickets); built with " GS_BUILD_FLAGS; }
 const char* gs_last_error(void) { return last_error_ref().c_str(); }
 
 // One context per entry of `devices` (a "logical device": its own streams, workspaces, handle table and lock).  The same
