@@ -748,12 +748,10 @@ int gs_poly_div(const uint64_t* a, size_t na, const uint64_t* b, size_t nb, uint
       // rem = (a - q b) mod x^(nb-1)        (r1csqap.go:70-84 returns the final `rem`)
       uint32_t* qb = q + nq * 8;
       poly_mul_dev(c, q, nq, Form::Std, db, nb, Form::Std, qb);
-      uint32_t* rr = qb + (nq + nb) * 8 - 8 * 0;
-      (void)rr;
-      DevBuf rbuf((nb - 1) * 32);
-      poly_addsub_dev(c, da, nb - 1, qb, nb - 1, true, rbuf.as<uint32_t>());
-      poly_canon_dev(c, rbuf.as<uint32_t>(), nb - 1, 0);
-      GS_HIP(hipMemcpyAsync(rem, rbuf.p, (nb - 1) * 32, hipMemcpyDeviceToHost, c.stream));
+      uint32_t* rr = qb + (nq + nb - 1) * 8;              // up_o holds nq + (nq + nb - 1) + (nb - 1) <= nq + na + nb elements: no allocation here
+      poly_addsub_dev(c, da, nb - 1, qb, nb - 1, true, rr);
+      poly_canon_dev(c, rr, nb - 1, 0);
+      GS_HIP(hipMemcpyAsync(rem, rr, (nb - 1) * 32, hipMemcpyDeviceToHost, c.stream));
       GS_HIP(hipStreamSynchronize(c.stream));
     }
     poly_canon_dev(c, q, nq, 0);
