@@ -121,7 +121,7 @@ void ntt_forward_n(Ctx& c, uint32_t* data, size_t total, int logm) {
   if (logm == 0 || total == 0) return;
   Twiddles& tw = ensure_twiddles(c, logm);
   for (const NttPass& p : ntt_schedule(total, logm))
-    hipLaunchKernelGGL(k_ntt_pass<false>, dim3(p.ntiles), dim3(256), 0, c.stream, data, tw.fwd.as<uint32_t>(), tw.logn, p.s_lo, p.k, p.clog);
+    hipLaunchKernelGGL((k_ntt_pass<false, kNttLoadPlain>), dim3(p.ntiles), dim3(256), 0, c.stream, data, tw.fwd.as<uint32_t>(), tw.logn, p.s_lo, p.k, p.clog, NttLoadAux{});
   GS_HIP(hipGetLastError());
 }
 
@@ -130,7 +130,33 @@ void ntt_inverse_unscaled_n(Ctx& c, uint32_t* data, size_t total, int logm) {
   Twiddles& tw = ensure_twiddles(c, logm);
   const std::vector<NttPass> sched = ntt_schedule(total, logm);
   for (auto it = sched.rbegin(); it != sched.rend(); ++it)
-    hipLaunchKernelGGL(k_ntt_pass<true>, dim3(it->ntiles), dim3(256), 0, c.stream, data, tw.inv.as<uint32_t>(), tw.logn, it->s_lo, it->k, it->clog);
+    hipLaunchKernelGGL((k_ntt_pass<true, kNttLoadPlain>), dim3(it->ntiles), dim3(256), 0, c.stream, data, tw.inv.as<uint32_t>(), tw.logn, it->s_lo, it->k, it->clog, NttLoadAux{});
+  GS_HIP(hipGetLastError());
+}
+
+// The batched node-extension convolution of the H-values stage with its two point-wise steps inside the transforms (round 5):
+//   conv[v] = IFFT( FFT(pad(vals[v] . weights)) . spec ),  v < nvec, transforms of size N = 2^logN, un-scaled inverse.
+// The first forward pass builds its input from (vals, weights) -- the zero-padded half is never written or read --, the first inverse
+// pass multiplies by the kernel's spectrum while it loads.
+static void weighed_convolution_dev(Ctx& c, const uint32_t* vals, const uint32_t* weights, size_t n, uint32_t nvec, const uint32_t* spec, int logN,
+                                    uint32_t* conv) {
+  Twiddles& tw = ensure_twiddles(c, logN);
+  const size_t total = (size_t)nvec << logN;
+  const std::vector<NttPass> sched = ntt_schedule(total, logN);
+  bool first = true;
+  for (const NttPass& p : sched) {
+    if (first) hipLaunchKernelGGL((k_ntt_pass<false, kNttLoadWeighed>), dim3(p.ntiles), dim3(256), 0, c.stream, conv, tw.fwd.as<uint32_t>(), tw.logn, p.s_lo, p.k, p.clog,
+                                  NttLoadAux{vals, weights, (uint32_t)n, (uint32_t)logN});
+    else hipLaunchKernelGGL((k_ntt_pass<false, kNttLoadPlain>), dim3(p.ntiles), dim3(256), 0, c.stream, conv, tw.fwd.as<uint32_t>(), tw.logn, p.s_lo, p.k, p.clog, NttLoadAux{});
+    first = false;
+  }
+  first = true;
+  for (auto it = sched.rbegin(); it != sched.rend(); ++it) {
+    if (first) hipLaunchKernelGGL((k_ntt_pass<true, kNttLoadScaled>), dim3(it->ntiles), dim3(256), 0, c.stream, conv, tw.inv.as<uint32_t>(), tw.logn, it->s_lo, it->k, it->clog,
+                                  NttLoadAux{spec, nullptr, 0u, (uint32_t)logN});
+    else hipLaunchKernelGGL((k_ntt_pass<true, kNttLoadPlain>), dim3(it->ntiles), dim3(256), 0, c.stream, conv, tw.inv.as<uint32_t>(), tw.logn, it->s_lo, it->k, it->clog, NttLoadAux{});
+    first = false;
+  }
   GS_HIP(hipGetLastError());
 }
 
@@ -469,10 +495,15 @@ bool hx_values_dev(Ctx& c, const uint32_t* vals_std, size_t n, size_t dz, uint32
   const int logN = ceil_log2(2 * n);
   const size_t N = hx.N;
   uint32_t* conv = poly_state(c).hx_conv.as<uint32_t>();
-  hipLaunchKernelGGL(k_hx_weigh, grid1(3 * N), dim3(256), 0, c.stream, vals_std, t.weights.as<uint32_t>(), (uint32_t)n, (uint32_t)N, 3u, conv);
-  ntt_forward_n(c, conv, 3 * N, logN);
-  hipLaunchKernelGGL(k_pw_mul_bcast, grid1(3 * N), dim3(256), 0, c.stream, conv, hx.inv_spec.as<uint32_t>(), (uint32_t)N, 3u);
-  ntt_inverse_unscaled_n(c, conv, 3 * N, logN);
+  static const bool unfused = dev_flag("GS_HX_UNFUSED");          // development builds: the separate point-wise kernels of rounds 3-4, for A/B
+  if (unfused) {
+    hipLaunchKernelGGL(k_hx_weigh, grid1(3 * N), dim3(256), 0, c.stream, vals_std, t.weights.as<uint32_t>(), (uint32_t)n, (uint32_t)N, 3u, conv);
+    ntt_forward_n(c, conv, 3 * N, logN);
+    hipLaunchKernelGGL(k_pw_mul_bcast, grid1(3 * N), dim3(256), 0, c.stream, conv, hx.inv_spec.as<uint32_t>(), (uint32_t)N, 3u);
+    ntt_inverse_unscaled_n(c, conv, 3 * N, logN);
+  } else {
+    weighed_convolution_dev(c, vals_std, t.weights.as<uint32_t>(), n, 3u, hx.inv_spec.as<uint32_t>(), logN, conv);
+  }
   hipLaunchKernelGGL(k_hx_values, grid1(n), dim3(256), 0, c.stream, conv, hx.t1.as<uint32_t>(), hx.t2.as<uint32_t>(), (uint32_t)n, (uint32_t)N, hv_out);
   GS_HIP(hipGetLastError());
   return true;

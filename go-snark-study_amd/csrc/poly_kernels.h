@@ -195,8 +195,23 @@ GS_HD void ntt_dit_butterfly(int step, int nsteps, Bfly (&x)[N], const Fe<ModR, 
   ntt_dit_step<20, N>(x, w, true, lazy_out, trivial);
 }
 
-template <bool kInverse>
-__global__ void __launch_bounds__(256) k_ntt_pass(uint32_t* __restrict__ x, const uint32_t* __restrict__ tw, int tw_logn, int s_lo, int k, int clog) {
+// What a pass loads (round 5: two point-wise kernels of the H-values stage fused into the pass that follows them):
+//   kNttLoadPlain   x itself
+//   kNttLoadScaled  x[i] * aux0[i & mask]: the spectrum product of a convolution inside the FIRST inverse pass (was k_pw_mul_bcast:
+//                   a read and a write of the whole batch)
+//   kNttLoadWeighed the zero-padded, weighed input of the node-extension convolution inside the FIRST forward pass: element
+//                   (v, j) of vector v is aux0[v * n + j] * aux1[j] for j < n and 0 above (was k_hx_weigh: a write and a re-read of
+//                   the whole batch, half of it zeros)
+constexpr int kNttLoadPlain = 0, kNttLoadScaled = 1, kNttLoadWeighed = 2;
+struct NttLoadAux {
+  const uint32_t* aux0;
+  const uint32_t* aux1;
+  uint32_t n;          // kNttLoadWeighed: values per vector
+  uint32_t logN;       // log2 of the transform size: element i of the batch is (i >> logN, i & (N - 1))
+};
+
+template <bool kInverse, int kLoad = kNttLoadPlain>
+__global__ void __launch_bounds__(256) k_ntt_pass(uint32_t* __restrict__ x, const uint32_t* __restrict__ tw, int tw_logn, int s_lo, int k, int clog, NttLoadAux aux) {
   wave_priority<GS_PRIO_POLY>();
   __shared__ uint32_t sh[NL * kNttTile];
   const uint32_t R = 1u << k, C = 1u << clog, E = R << clog;
@@ -213,7 +228,18 @@ __global__ void __launch_bounds__(256) k_ntt_pass(uint32_t* __restrict__ x, cons
   for (uint32_t e = threadIdx.x; e < E; e += 256) {
     uint32_t q, cc;
     if (s_lo == 0) { q = e & (R - 1); cc = e >> k; } else { cc = e & (C - 1); q = e >> clog; }
-    const Fr2 v = reduce2(load_fr(x + (base + (size_t)q * qstride + (size_t)cc * cstride) * 8));
+    const size_t gi = base + (size_t)q * qstride + (size_t)cc * cstride;
+    Fr2 v;
+    if constexpr (kLoad == kNttLoadWeighed) {
+      const size_t vec = gi >> aux.logN;
+      const uint32_t j = (uint32_t)(gi & (((size_t)1 << aux.logN) - 1));
+      if (j < aux.n) v = mul(load_fr(aux.aux0 + (vec * aux.n + j) * 8), load_fr(aux.aux1 + (size_t)j * 8));
+      else v = fe_zero<ModR, 2>();
+    } else if constexpr (kLoad == kNttLoadScaled) {
+      v = mul(reduce2(load_fr(x + gi * 8)), load_fr(aux.aux0 + (gi & (((size_t)1 << aux.logN) - 1)) * 8));
+    } else {
+      v = reduce2(load_fr(x + gi * 8));
+    }
     const uint32_t le = (q << clog) + cc;
 #pragma unroll
     for (int l = 0; l < NL; ++l) sh[l * kNttTile + le] = v.l[l];
