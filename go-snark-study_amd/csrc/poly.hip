@@ -134,6 +134,21 @@ void ntt_inverse_unscaled_n(Ctx& c, uint32_t* data, size_t total, int logm) {
   GS_HIP(hipGetLastError());
 }
 
+// inverse transform of data[i] * spec[i & (2^logm - 1)] (un-scaled): the point-wise product of a convolution inside the first inverse pass
+static void ntt_inverse_unscaled_of_product_n(Ctx& c, uint32_t* data, size_t total, int logm, const uint32_t* spec) {
+  if (logm == 0 || total == 0) return;
+  Twiddles& tw = ensure_twiddles(c, logm);
+  const std::vector<NttPass> sched = ntt_schedule(total, logm);
+  bool first = true;
+  for (auto it = sched.rbegin(); it != sched.rend(); ++it) {
+    if (first) hipLaunchKernelGGL((k_ntt_pass<true, kNttLoadScaled>), dim3(it->ntiles), dim3(256), 0, c.stream, data, tw.inv.as<uint32_t>(), tw.logn, it->s_lo, it->k, it->clog,
+                                  NttLoadAux{spec, nullptr, 0u, (uint32_t)logm});
+    else hipLaunchKernelGGL((k_ntt_pass<true, kNttLoadPlain>), dim3(it->ntiles), dim3(256), 0, c.stream, data, tw.inv.as<uint32_t>(), tw.logn, it->s_lo, it->k, it->clog, NttLoadAux{});
+    first = false;
+  }
+  GS_HIP(hipGetLastError());
+}
+
 // The batched node-extension convolution of the H-values stage with its two point-wise steps inside the transforms (round 5):
 //   conv[v] = IFFT( FFT(pad(vals[v] . weights)) . spec ),  v < nvec, transforms of size N = 2^logN, un-scaled inverse.
 // The first forward pass builds its input from (vals, weights) -- the zero-padded half is never written or read --, the first inverse
@@ -275,8 +290,8 @@ void poly_quotient_dev(Ctx& c, Divisor& d, const uint32_t* a, size_t na, uint32_
   // A = rev(a)[:k] = a[na-1], a[na-2], ..., a[na-k]  zero padded to N   (standard form)
   hipLaunchKernelGGL(k_copy_reversed, grid1(N), dim3(256), 0, c.stream, a, (uint32_t)(na - k), (uint32_t)k, A, (uint32_t)N);
   ntt_forward(c, A, logn, logn);
-  hipLaunchKernelGGL(k_pw_mul, grid1(N), dim3(256), 0, c.stream, A, d.inv_spec.as<uint32_t>(), A, (uint32_t)N);
-  ntt_inverse_unscaled(c, A, logn, logn);
+  if (logn >= 1) ntt_inverse_unscaled_of_product_n(c, A, N, logn, d.inv_spec.as<uint32_t>());      // (r5: the spectrum product inside the first inverse pass)
+  else hipLaunchKernelGGL(k_pw_mul, grid1(N), dim3(256), 0, c.stream, A, d.inv_spec.as<uint32_t>(), A, (uint32_t)N);
   // scale by 1/N and un-reverse the first k coefficients: quo[i] = A[k-1-i] / N
   poly_state(c).ws_b.ensure(k * 32);
   hipLaunchKernelGGL(k_copy_reversed, grid1(k), dim3(256), 0, c.stream, A, 0u, (uint32_t)k, poly_state(c).ws_b.as<uint32_t>(), (uint32_t)k);
