@@ -662,9 +662,10 @@ void download(Ctx& c, uint64_t* host, const void* dev, size_t n) {
 // The reference hands GenerateProofs a FRESH w (and px) in host memory on every call (groth16/groth16.go:225, cli/main.go:480-501).
 // gs_scalars_upload + gs_*_begin + gs_free costs a hipMalloc, a blocking copy and a hipFree (a device-wide synchronisation) per proof
 // and breaks a pipeline of three; a host-buffer ticket instead stages the caller's arrays into buffers its SLOT owns (grow-only:
-// nothing is allocated or freed once the three slots have been used), on the copy stream, and the streams that read them wait for
-// the copy's event -- the DMA of proof k + 3 runs beside the accumulations of proofs k + 1 and k + 2.  The caller's arrays are
-// consumed when _begin returns (cgo pointer rule).
+// nothing is allocated or freed once the three slots have been used), on the copy stream -- the DMA of proof k + 3 runs beside the
+// accumulations of proofs k + 1 and k + 2 -- and enqueues the proof when the copy has landed (GS_HOST_STAGE above: measured against
+// a cross-stream event and against copying on the readers' own streams).  The caller's arrays are consumed when _begin returns (cgo
+// pointer rule).
 static void ensure_copy_stream(Ctx& c) {
   if (!c.copy_stream) GS_HIP(hipStreamCreateWithFlags(&c.copy_stream, hipStreamNonBlocking));
 }

@@ -239,9 +239,10 @@ int gs_groth16_prove_end(uint64_t ticket, uint64_t out_proof[32], int inf[3]);
 /* HOST-BUFFER TICKETS: the reference's own call shape -- groth16.GenerateProofs(circuit, pk, w, px) gets a NEW w (and px) in host
  * memory with every call (groth16/groth16.go:225; cli/main.go:480-501 computes them per proof) -- at the pipelined rate.  The
  * arrays are staged into device buffers that the ticket's SLOT owns (grow-only: once the three slots have been used a stream of
- * proofs performs no hipMalloc and no hipFree, see gs_alloc_counters) on a copy stream of their own, and the kernels that read
- * them wait for the copy's event: the PCIe transfer of proof k + 3 runs beside the accumulations of proofs k + 1 and k + 2.  The
- * caller's arrays have been consumed when the call returns.  Collect with gs_groth16_prove_end; same three slots per device.
+ * proofs performs no hipMalloc and no hipFree, see gs_alloc_counters) on a copy stream of their own: the PCIe transfer of proof
+ * k + 3 runs beside the accumulations of proofs k + 1 and k + 2, and the call enqueues the proof once the copy has landed (measured:
+ * cheaper than a cross-stream event; the device is busy with the tickets before this one meanwhile).  The caller's arrays have been
+ * consumed when the call returns.  Collect with gs_groth16_prove_end; same three slots per device.
  *   gs_groth16_prove_host_begin          w and px from the host (32 + 64 MiB at 2^20 constraints)
  *   gs_groth16_prove_witness_host_begin  w only, against a resident sparse R1CS (gs_r1cs_upload): the witness routes above
  *   gs_groth16_prove_witness_host        the blocking form of the latter (the upload is part of the call, as in gs_groth16_prove) */
