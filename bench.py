@@ -405,7 +405,8 @@ def live_pmc_traffic(args):
         d = tempfile.mkdtemp(prefix="gs_pmc_", dir="/tmp")
         try:
             cmd = [exe, "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
-                   "--log2n", str(args.log2n), "--steps", "1", "--warmup", "0", "--reps", "1", "--settle-ms", "0", "--cpu-log2n", "0", "--no-extras", "--no-check"]
+                   "--log2n", str(args.log2n), "--table-policy", args.table_policy, "--steps", "1", "--warmup", "0", "--reps", "1", "--settle-ms", "0",
+                   "--cpu-log2n", "0", "--no-extras", "--no-check"]
             env = dict(os.environ, TMPDIR="/tmp", GS_BENCH_NO_LIVE_PMC="1")
             subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300, check=True)
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
