@@ -1048,11 +1048,12 @@ def main():
                          "(gs_scalars_scatter) and every rank sums only its term ranges (gs_groth16_prove_sharded_values)")
     ap.add_argument("--logical-shards", type=int, default=0,
                     help="prove_sharded / msm_sharded on ONE GPU: that many logical devices in this process (configs[3] stand-in, SURVEY 8e)")
-    ap.add_argument("--instance", default="setup", choices=["setup", "realistic", "sqchain", "random"],
+    ap.add_argument("--instance", default="setup", choices=["setup", "realistic", "gates", "sqchain", "random"],
                     help="setup: sqchain R1CS + structured trusted setup on the device + px from the sparse system (a complete, "
                          "checkable instance, SURVEY 8d); realistic: the same machinery on an R1CS whose witness has the shape the reference's "
                          "CalculateWitness produces (circuit.go:158-182: about half zeros and ones, most of the rest below 2^32, few full-width "
-                         "values); sqchain: same R1CS with key points k_i*G; random: uniform w / px")
+                         "values); gates: flattened `*` / `+` gates in the shape of the reference's circuit compiler (circuit.go:84-139): two thirds of "
+                         "the key's B points are infinity, full-width witness; sqchain: same R1CS with key points k_i*G; random: uniform w / px")
     ap.add_argument("--pipeline", type=int, default=3, choices=[1, 2, 3],
                     help="operations in flight per GPU (prove / msm_g1 workloads): >= 2 = gs_groth16_prove_begin/_end (gs_msm_g1_begin/"
                          "gs_msm_end), the next operation's plan and accumulations are queued behind the current one's; 1 = one "
@@ -1146,10 +1147,11 @@ def main():
         key_seed = 0x5EED0002 if args.instance == "setup" else seed
         inst = (synth.sqchain_setup_instance(n, key_seed) if args.instance == "setup" else
                 synth.realistic_setup_instance(n, seed) if args.instance == "realistic" else
+                synth.gates_setup_instance(n, seed) if args.instance == "gates" else
                 synth.sqchain_instance(n, seed) if args.instance == "sqchain" else synth.random_instance(n, seed))
         pk = inst.device_pk()
         w_dev, px_dev = inst.w, inst.px
-        x_pub = capi.u64_to_ints(inst.w_host[1:2])[0] if args.instance in ("setup", "realistic") else None
+        x_pub = capi.u64_to_ints(inst.w_host[1:2])[0] if args.instance in ("setup", "realistic", "gates") else None
         if args.instance == "setup" and rank > 0 and not one_job:
             from gosnark_amd import r1csqap as _rq
             x_pub = synth.field_elems(1, key_seed + 4242 + rank)[0]
@@ -1289,7 +1291,7 @@ def main():
     total_steps = args.steps * len(rep_elapsed)
 
     proof_verified = None
-    if args.workload == "prove" and not logical and args.instance in ("setup", "realistic") and not args.no_check:
+    if args.workload == "prove" and not logical and args.instance in ("setup", "realistic", "gates") and not args.no_check:
         # Product verifier (groth16.VerifyProof -> gs_groth16_verify, host side), outside the timed region, on EVERY rank:
         # the proof of this rank's instance against the vk its device setup produced, for the right public input and a wrong one.
         p_last = step()
@@ -1313,7 +1315,7 @@ def main():
             raise SystemExit("bench.py: snark.VerifyProof rejected the proof of the benchmarked instance (or accepted a wrong public input)")
         proof_verified = "snark.VerifyProof (five pairing equations) accepted each rank's proof against its device-built vk and rejected a wrong public input (%d/%d ranks)" % (world, world)
     proof_check = None
-    if rank == 0 and world == 1 and args.cpu_log2n > 0 and plain_prove and args.instance in ("setup", "realistic") and not args.no_check:
+    if rank == 0 and world == 1 and args.cpu_log2n > 0 and plain_prove and args.instance in ("setup", "realistic", "gates") and not args.no_check:
         # Outside the timed region, part of the checker/baseline leg (the only place bench.py touches oracle/): the toxic
         # values of the synthetic setup are known, so the proof the benchmarked instance must produce is known in closed form.
         proof_check = checker_leg_proof(step(), inst, r_, s_)
@@ -1334,7 +1336,7 @@ def main():
             capi.ptr64(rs[0]), capi.ptr64(rs[1]), capi.ptr64(outp), infp)), 3)
         if args.instance == "realistic":
             extras["witness_digits"] = witness_digit_stats(inst.w_host, window_bits[0], capi.last_timing())
-        if args.instance in ("setup", "realistic"):
+        if args.instance in ("setup", "realistic", "gates"):
             # witness -> proof: px rebuilt from the resident sparse R1CS every time (gs_groth16_prove_r1cs; r1csqap.go:161-210 + groth16.go:225-278)
             from gosnark_amd import r1csqap
             dr = r1csqap.DeviceR1CS(*inst.r1cs, inst.m)

@@ -83,8 +83,11 @@ struct LaunchShape { int njobs; bool g2; };
 // scalars_dev: n x 8 u32 words (standard form, any 256-bit value).  slot: 0..3 (four plans may be alive).  `users`: the
 // launches that will run on this plan (decides the chunk size: whole wave rounds for every one of them).
 // cbits: the width prepare_tables chose; table_free: its route.
+// term_mask / mask_off: bit (mask_off + i) clear drops term i from the plan (see k_digits); window widths below 19 only.
 void build_plan(Ctx& c, int slot, const uint32_t* scalars_dev, uint32_t n, MsmPlan& plan, const std::vector<LaunchShape>& users, int cbits = 0,
-                bool table_free = false);
+                bool table_free = false, const uint32_t* term_mask = nullptr, uint32_t mask_off = 0);
+// which points of one or two packed-affine arrays are finite: mask (ceil(n / 32) words, written) and their number (synchronises the stream)
+uint32_t finite_mask_dev(Ctx& c, const uint32_t* g1_pts, const uint32_t* g2_pts, uint32_t n, uint32_t* mask_dev);
 
 // One launch sequence for up to 8 base arrays sharing a plan (their tables must have been built for plan.c).
 // msm_enqueue_* only ENQUEUES on c.stream (kernels + the async download of the <= 16 workgroup pairs per

@@ -62,7 +62,7 @@ static void exclusive_scan(Ctx& c, PlanBuffers& pb, const uint32_t* in, uint32_t
 }
 
 struct MsmState {                                  // per context (device memory belongs to one device)
-  PlanBuffers plan_slots[2 * Ctx::kSlots];         // (w, h) x slots
+  PlanBuffers plan_slots[3 * Ctx::kSlots];         // (w, h) x slots, then one more per slot: the masked plan over w of keys with sparse B arrays
   DevBuf table_scratch;                            // slab of the batched window-table builder
   DevBuf table_scratch_bg;                         // ... and of the builds that run in the background on the table stream
   bool lds_attr_set = false;
@@ -88,10 +88,24 @@ static uint32_t choose_chunk(uint64_t entries, uint32_t nbuckets, const std::vec
   return chunk;
 }
 
+uint32_t finite_mask_dev(Ctx& c, const uint32_t* g1_pts, const uint32_t* g2_pts, uint32_t n, uint32_t* mask_dev) {
+  const size_t words = ((size_t)n + 31) / 32;
+  GS_HIP(hipMemsetAsync(mask_dev, 0, std::max<size_t>(words, 1) * 4, c.stream));
+  DevBuf cnt(4);
+  GS_HIP(hipMemsetAsync(cnt.p, 0, 4, c.stream));
+  if (n) hipLaunchKernelGGL(k_finite_mask, grid1(n), dim3(256), 0, c.stream, g1_pts, (uint32_t)PointIO<FqTag>::kAffineWords, g2_pts,
+                            (uint32_t)PointIO<Fq2Tag>::kAffineWords, n, mask_dev, cnt.as<uint32_t>());
+  GS_HIP(hipGetLastError());
+  uint32_t host = 0;
+  GS_HIP(hipMemcpyAsync(&host, cnt.p, 4, hipMemcpyDeviceToHost, c.stream));
+  GS_HIP(hipStreamSynchronize(c.stream));
+  return host;
+}
+
 void build_plan(Ctx& c, int slot, const uint32_t* scalars_dev, uint32_t n, MsmPlan& plan, const std::vector<LaunchShape>& users, int cbits,
-                bool table_free) {
+                bool table_free, const uint32_t* term_mask, uint32_t mask_off) {
   MsmState& ms = msm_state(c);
-  PlanBuffers& pb = ms.plan_slots[slot % (2 * Ctx::kSlots)];
+  PlanBuffers& pb = ms.plan_slots[slot % (3 * Ctx::kSlots)];
   plan.n = n;
   plan.table_free = table_free;
   plan.c = cbits ? cbits : (table_free ? choose_window_bits_free(n, c.window_bits) : choose_window_bits(n, c.window_bits));
@@ -125,6 +139,7 @@ void build_plan(Ctx& c, int slot, const uint32_t* scalars_dev, uint32_t n, MsmPl
   // cheaper than writing and re-reading 8-byte records
   static const uint32_t part_min_r = (uint32_t)dev_knob("GS_PART_MIN_R", 4, 2, 64);
   const bool wide = pp.R >= part_min_r;
+  if (wide && term_mask) throw HipError{hipErrorInvalidValue, "masked plans need a window width below 19", __LINE__};
   const uint32_t nparts = (uint32_t)plan.W * pp.R;
   if (wide && nparts > kMaxParts) throw HipError{hipErrorInvalidValue, "too many (window, range) partitions", __LINE__};
   if (!wide) pb.digits.ensure((size_t)std::max<uint32_t>(pp.stride, 64u) * plan.W * sizeof(digit_t));
@@ -162,7 +177,7 @@ void build_plan(Ctx& c, int slot, const uint32_t* scalars_dev, uint32_t n, MsmPl
     hipLaunchKernelGGL(k_hist_part, dim3(8 * pp.S * ((nparts + 7) / 8)), dim3(sort_block), lds, c.stream, pb.recs.as<uint2>(), part_base, pp, pb.hist.as<uint32_t>());
     hipLaunchKernelGGL(k_colscan, grid1(plan.B), dim3(256), 0, c.stream, pb.hist.as<uint32_t>(), pp, pb.totals.as<uint32_t>());
   } else if (n > 0) {
-    hipLaunchKernelGGL(k_digits, grid1(n), dim3(256), 0, c.stream, scalars_dev, pp, pb.digits.as<digit_t>());
+    hipLaunchKernelGGL(k_digits, grid1(n), dim3(256), 0, c.stream, scalars_dev, pp, pb.digits.as<digit_t>(), term_mask, mask_off);
     hipLaunchKernelGGL(k_hist, dim3(plan.W, pp.S, pp.R), dim3(sort_block), lds, c.stream, pb.digits.as<digit_t>(), pp, pb.hist.as<uint32_t>());
     if (table_free) hipLaunchKernelGGL(k_colscan_windows, grid1(plan.nbuckets), dim3(256), 0, c.stream, pb.hist.as<uint32_t>(), pp, pb.totals.as<uint32_t>());
     else hipLaunchKernelGGL(k_colscan, grid1(plan.B), dim3(256), 0, c.stream, pb.hist.as<uint32_t>(), pp, pb.totals.as<uint32_t>());

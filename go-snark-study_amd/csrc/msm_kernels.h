@@ -59,10 +59,20 @@ GS_HD int32_t next_digit(const uint32_t (&k)[8], const PlanParams& pp, int w, ui
 
 // ---- plan, step 1: scalars -> digit matrix digits[w][i] = d + B - 1, read once, coalesced ------------------------
 using digit_t = uint32_t;
-__global__ void __launch_bounds__(256) k_digits(const uint32_t* __restrict__ scalars, PlanParams pp, digit_t* __restrict__ digits) {
+// term_mask (optional): bit (mask_off + i) clear = term i does not take part in this plan (its base points are the point at infinity
+// in every array the plan is for: prove.h, GrothPkObj::b_mask) -- all its digits are written as zero and it never reaches a bucket.
+__global__ void __launch_bounds__(256) k_digits(const uint32_t* __restrict__ scalars, PlanParams pp, digit_t* __restrict__ digits,
+                                                 const uint32_t* __restrict__ term_mask, uint32_t mask_off) {
   wave_priority<GS_PRIO_PLAN>();
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= pp.n) return;
+  if (term_mask) {
+    const uint32_t bit = mask_off + i;
+    if (((term_mask[bit >> 5] >> (bit & 31u)) & 1u) == 0u) {
+      for (int w = 0; w < pp.W; ++w) digits[(size_t)w * pp.stride + i] = (digit_t)(pp.B - 1u);
+      return;
+    }
+  }
   uint32_t k[8];
   const uint4* s4 = reinterpret_cast<const uint4*>(scalars + (size_t)i * 8);
   uint4 lo = s4[0], hi = s4[1];
@@ -73,6 +83,21 @@ __global__ void __launch_bounds__(256) k_digits(const uint32_t* __restrict__ sca
     const int32_t d = next_digit(k, pp, w, carry);
     digits[(size_t)w * pp.stride + i] = (digit_t)(d + (int32_t)pp.B - 1);
   }
+}
+
+// mask[i >> 5] bit (i & 31) = point i of `a` OR of `b` (either may be null) is not the point at infinity (packed affine: all words
+// zero); *count += finite points.  The mask must be zero beforehand.
+__global__ void __launch_bounds__(256) k_finite_mask(const uint32_t* __restrict__ a, uint32_t wa, const uint32_t* __restrict__ b, uint32_t wb, uint32_t n,
+                                                      uint32_t* __restrict__ mask, uint32_t* __restrict__ count) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  bool finite = false;
+  if (i < n) {
+    uint32_t acc = 0;
+    if (a) for (uint32_t k = 0; k < wa; ++k) acc |= a[(size_t)i * wa + k];
+    if (b) for (uint32_t k = 0; k < wb; ++k) acc |= b[(size_t)i * wb + k];
+    finite = acc != 0;
+  }
+  if (finite) { atomicOr(&mask[i >> 5], 1u << (i & 31u)); atomicAdd(count, 1u); }
 }
 
 // ---- plan, step 2: per-(window, slice, range) bucket histogram in LDS -----------------------------------------

@@ -30,8 +30,16 @@ struct GrothPkObj : Object {      // groth16.Pk (groth16/groth16.go:15-32), resi
   size_t n_eval = 0, e_lo = 0, n_e = 0;
   DevBuf ptd_eval;
   BaseTable t_ptd_eval;
+  // Which of the held variables appear in B at all (round 5).  The reference's circuit compiler puts a variable into B only as the
+  // second operand of a multiplication or a divisor (circuitcompiler/circuit.go:110-128: `+` / `-` / `in` rows have B = [one]), so for
+  // its circuits most G1.BACGamma / G2.BACGamma points are the point at infinity.  b_mask has one bit per held variable (set: either
+  // point is finite), b_finite their number: when enough are missing the prover sums B1 and B2 -- 3.8 of a proof's 6.8 job-units --
+  // over a SECOND plan of w that leaves the missing terms out (prove.hip, groth16_enqueue).  Scanned once, when the key is created.
+  DevBuf b_mask;
+  size_t b_finite = 0;
   GrothPkObj() : Object(Kind::GrothPk) {}
 };
+void groth_pk_scan_sparsity(Ctx& c, GrothPkObj& pk);      // fills b_mask / b_finite (synchronises the stream)
 
 struct PinocchioPkObj : Object {  // snark.Pk (snark.go:16-26), resident
   size_t nvars = 0, npublic = 0, nz = 0, ng1t = 0;      // global counts (ng1t = len(G1T))

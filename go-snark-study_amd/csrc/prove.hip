@@ -162,6 +162,12 @@ struct GrothInFlight : InFlightBase {
   // done_g2 / done_g1w / done_h: one per MSM group, recorded behind that group's reduction tail, so the host can add up a
   // group's partial sums while the later groups are still on the device
   hipEvent_t planw = nullptr, planh = nullptr, done_main = nullptr, done_g2 = nullptr, done_g1w = nullptr, done_h = nullptr;
+  // keys with sparse B arrays (prove.h, b_mask): B1 and B2 run over a masked plan of their own; pend_g1w then carries At and BACDelta
+  // only and pend_g1b the sum over G1.BACGamma
+  bool split_b = false;
+  hipEvent_t planb = nullptr, done_g1b = nullptr;
+  MsmPending pend_g1b;
+  std::shared_ptr<PhaseTimer> tplanb;
   std::unique_ptr<PhaseTimer> total;
   MsmPending pend_g1w, pend_g2w, pend_h;
   std::shared_ptr<PhaseTimer> tpoly, tplanw, tplanh;
@@ -172,11 +178,11 @@ struct GrothInFlight : InFlightBase {
   GrothInFlight() {
     GS_HIP(hipEventCreateWithFlags(&planw, hipEventDisableTiming));
     GS_HIP(hipEventCreateWithFlags(&planh, hipEventDisableTiming));
-    for (hipEvent_t* e : {&done_main, &done_g2, &done_g1w, &done_h}) GS_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    for (hipEvent_t* e : {&done_main, &done_g2, &done_g1w, &done_h, &planb, &done_g1b}) GS_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
   }
   ~GrothInFlight() override {
     if (fpre.valid()) fpre.wait();
-    for (hipEvent_t e : {planw, planh, done_main, done_g2, done_g1w, done_h}) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {planw, planh, done_main, done_g2, done_g1w, done_h, planb, done_g1b}) if (e) (void)hipEventDestroy(e);
   }
 };
 
@@ -237,10 +243,28 @@ int groth16_enqueue(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, const S
     GS_HIP(hipStreamWaitEvent(ps.planw, w.host_done, 0));
     if (ps.poly != ps.planw) GS_HIP(hipStreamWaitEvent(ps.poly, w.host_done, 0));
   }
-  {                                                              // aux 1 (or aux 2, proof_streams): plan(w)
+  // Sparse B (prove.h, b_mask): when fewer than 55 % of the key's variables have a B entry, B1 and B2 are summed over a second plan of
+  // w without the others -- one more sort (~0.35 ms at 2^20) against that share of 3.8 of the proof's 6.8 job-units.  Measured at 2^20
+  // (profiles/r05_ab_sparse_b_split.txt): a circuit of the reference compiler's shape (33 % of the variables in B, full-width witness)
+  // 8.3-8.4 -> 6.1-6.2 ms per proof in flight, 8.8 -> 6.9 blocking, witness route 9.15 -> 7.2; the realistic-witness instance (60 % in
+  // B, and the absent variables are the small ones that carry one or two digits anyway) LOSES 3 % -- hence 55, not 90.  (Window
+  // widths of 19 and more -- only by gs_set_window_bits -- keep the single plan: their partition-first sort has no mask.)
+  static const long split_pct = run_knob("GS_SPLIT_B_PERCENT", 55, 0, 100);      // split below this share of finite B points; 0 = never (same results)
+  const size_t nterms_w = whi - wlo;
+  st.split_b = pk->b_mask.p != nullptr && nterms_w >= 4096 && cw < 19 && pk->b_finite * 100 < (size_t)split_pct * pk->n_w;
+  MsmPlan plan_b;
+  {                                                              // aux 1 (or aux 2, proof_streams): plan(w) [, the masked plan for B first: G2 starts the proof]
     StreamScope sc(c, ps.planw);
+    if (st.split_b) {
+      st.tplanb = std::make_shared<PhaseTimer>(c.stream);
+      build_plan(c, 2 * Ctx::kSlots + parity, w.p + wlo * 8, (uint32_t)nterms_w, plan_b, {{1, true}, {1, false}}, cw, !tab_w, pk->b_mask.as<uint32_t>(),
+                 (uint32_t)wbase);
+      st.tplanb->stop();
+      GS_HIP(hipEventRecord(st.planb, c.stream));
+    }
     st.tplanw = std::make_shared<PhaseTimer>(c.stream);
-    build_plan(c, 0 + 2 * parity, w.p + wlo * 8, (uint32_t)(whi - wlo), plan_w, {{1, true}, {3, false}}, cw, !tab_w);
+    build_plan(c, 0 + 2 * parity, w.p + wlo * 8, (uint32_t)nterms_w, plan_w, st.split_b ? std::vector<LaunchShape>{{2, false}} : std::vector<LaunchShape>{{1, true}, {3, false}},
+               cw, !tab_w);
     st.tplanw->stop();
     GS_HIP(hipEventRecord(st.planw, c.stream));
   }
@@ -248,15 +272,22 @@ int groth16_enqueue(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, const S
   // stages through the runtime inside the call (~5 ms for 64 MiB), and the device must already have its 7 ms of work by then.
   {                                                              // main: the accumulations over w, back to back
     StreamScope sc(c, c.main_stream);
-    GS_HIP(hipStreamWaitEvent(c.stream, st.planw, 0));
+    GS_HIP(hipStreamWaitEvent(c.stream, st.split_b ? st.planb : st.planw, 0));
     // BACDelta's first npublic+1 entries are forced to infinity at key creation, so the reference's
     // loop from NPublic+1 (:248-250) equals a full-range MSM sharing w's plan.
     // G2 first: its accumulation (2 waves/SIMD, 256 VGPRs) is the one a foreign wave hurts most, and its long
     // combine/reduce tail then hides behind the G1 accumulations.
-    msm_enqueue_g2(c, plan_w, {base_w(pk->t_bacgamma2, pk->bacgamma2)}, ws + 4, pin + 1, st.pend_g2w, ps.tail_g2);
+    msm_enqueue_g2(c, st.split_b ? plan_b : plan_w, {base_w(pk->t_bacgamma2, pk->bacgamma2)}, ws + 4, pin + 1, st.pend_g2w, ps.tail_g2);
     GS_HIP(hipEventRecord(st.done_g2, ps.tail_g2));
-    msm_enqueue_g1(c, plan_w, {base_w(pk->t_at, pk->at), base_w(pk->t_bacgamma1, pk->bacgamma1), base_w(pk->t_bacdelta, pk->bacdelta)}, ws + 0, pin + 0,
-                   st.pend_g1w, ps.tail_g1);
+    if (st.split_b) {
+      msm_enqueue_g1(c, plan_b, {base_w(pk->t_bacgamma1, pk->bacgamma1)}, ws + 2, 3 * Ctx::kSlots + parity, st.pend_g1b, ps.tail_g1);
+      GS_HIP(hipEventRecord(st.done_g1b, ps.tail_g1));
+      GS_HIP(hipStreamWaitEvent(c.stream, st.planw, 0));
+      msm_enqueue_g1(c, plan_w, {base_w(pk->t_at, pk->at), base_w(pk->t_bacdelta, pk->bacdelta)}, ws + 0, pin + 0, st.pend_g1w, ps.tail_g1);
+    } else {
+      msm_enqueue_g1(c, plan_w, {base_w(pk->t_at, pk->at), base_w(pk->t_bacgamma1, pk->bacgamma1), base_w(pk->t_bacdelta, pk->bacdelta)}, ws + 0, pin + 0,
+                     st.pend_g1w, ps.tail_g1);
+    }
     GS_HIP(hipEventRecord(st.done_g1w, ps.tail_g1));
   }
   // (Starting H(x) and plan(h) of a lone proof beside plan(w) on another stream instead of behind it was tried: the blocking proof
@@ -329,9 +360,14 @@ int groth16_collect(Ctx& c, GrothInFlight& st, GrothSums& sums) {
     GS_HIP(hipEventSynchronize(st.done_g2));
     auto f2 = std::async(std::launch::async, [&] { msm_finish_g2(c, st.pend_g2w, g2w); });
     struct Join { std::future<void>& f; ~Join() { if (f.valid()) f.wait(); } } j2{f2};     // a throwing wait below must not outrun the threads
-    GS_HIP(hipEventSynchronize(st.done_g1w));
+    GS_HIP(hipEventSynchronize(st.done_g1w));       // (the B1 group of a split proof was enqueued before this one on the same tail stream)
     auto f1 = std::async(std::launch::async, [&] {
       msm_finish_g1(c, st.pend_g1w, g1w);
+      if (st.split_b) {                              // g1w = [At, BACDelta]: bring it into the order [At, BACGamma, BACDelta] of the single plan
+        std::vector<G1Xyzz> g1b;
+        msm_finish_g1(c, st.pend_g1b, g1b);
+        g1w.insert(g1w.begin() + 1, g1b[0]);
+      }
       GrothTailEarly& e = st.early;
       if (!e.pk) return;
       e.fpre->wait();                                            // r delta, s delta (the owner calls get() after this thread is joined)
@@ -357,6 +393,7 @@ int groth16_collect(Ctx& c, GrothInFlight& st, GrothSums& sums) {
   GS_HIP(hipEventSynchronize(st.done_main));
   if (host_trace()) fprintf(stderr, "[gs host] collect: wait %.3f ms, fold %.3f ms\n", t1 - t0, host_now_ms() - t1);
   msm_book_timing(c, st.pend_g1w); msm_book_timing(c, st.pend_g2w); msm_book_timing(c, st.pend_h);
+  if (st.split_b) { msm_book_timing(c, st.pend_g1b); c.timing.plan_ms += st.tplanb->ms(); }
   c.timing.poly_ms += st.tpoly->ms();
   c.timing.plan_ms += st.tplanw->ms() + st.tplanh->ms();
   c.timing.total_ms += st.total->ms();
@@ -713,6 +750,11 @@ void mark_ticket_reads(const ProofStreams& ps, Scalars* w, Scalars* px_or_hv) {
 
 }  // namespace
 
+void gs::groth_pk_scan_sparsity(Ctx& c, GrothPkObj& pk) {
+  pk.b_mask.alloc(std::max<size_t>((pk.n_w + 31) / 32, 1) * 4);
+  pk.b_finite = finite_mask_dev(c, pk.bacgamma1.as<uint32_t>(), pk.bacgamma2.as<uint32_t>(), (uint32_t)pk.n_w, pk.b_mask.as<uint32_t>());
+}
+
 extern "C" {
 
 // ---- polynomial field ------------------------------------------------------------------------------------
@@ -850,6 +892,7 @@ static int groth_pk_create_impl(Ctx& c, gs_handle g1_at, gs_handle g1_bacgamma, 
   const uint32_t* dz = upload_tmp(c, prove_state(c).up_a, z, nz);
   divisor_init(c, pk->z, dz, nz);
   GS_HIP(hipStreamSynchronize(c.stream));
+  groth_pk_scan_sparsity(c, *pk);
   *out = c.put(std::move(pk));
   return GS_OK;
 }
@@ -901,6 +944,7 @@ static int groth_pk_shard_impl(Ctx& c, Ctx& from, GrothPkObj* full, size_t shard
     GS_HIP(hipStreamSynchronize(c.stream));             // `zc` is released here
   }
   GS_HIP(hipStreamSynchronize(c.stream));
+  groth_pk_scan_sparsity(c, *pk);
   *out = c.put(std::move(pk));
   return GS_OK;
 }

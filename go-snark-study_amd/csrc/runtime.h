@@ -192,7 +192,8 @@ struct Ctx {
   static constexpr int kMaxInFlight = 3;             // pipelined operations (tickets); each owns one set of workspaces
   static constexpr int kSlots = kMaxInFlight + 1;    // + one set for the blocking entry points (serialised by `mu`), so a blocking
   static constexpr int kBlockingSlot = kMaxInFlight; //   call made while tickets are outstanding never touches their result staging
-  void* pinned[3 * kSlots] = {};                     // host staging of the result downloads (3 per slot)
+  void* pinned[4 * kSlots] = {};                     // host staging of the result downloads: 3 per slot, then one more per slot
+                                                     //   (the B1 group of a proof whose B sums run over their own plan)
   // violated-constraint counters of the witness routes, one word per slot: device words + their pinned host copies (an async copy
   // behind the check kernel writes them; the collector reads them).  Context-owned, so they outlive gs_trim while tickets are out.
   DevBuf bad_dev;

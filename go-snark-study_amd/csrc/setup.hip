@@ -193,6 +193,7 @@ int gs_groth16_setup(size_t n, size_t m, size_t npublic,
       GS_HIP(hipMemcpyAsync(vk_out + 12 + 72, j1.as<uint32_t>() + 24, nic * 96, hipMemcpyDeviceToHost, c.stream));
     }
     GS_HIP(hipStreamSynchronize(c.stream));
+    groth_pk_scan_sparsity(c, *pk);
     *pk_out = c.put(std::move(pk));
     return GS_OK;
   });

@@ -371,6 +371,83 @@ def realistic_setup_instance(n, seed):
     return RealisticSetupInstance(n, seed)
 
 
+def gates_r1cs(n, seed, mul_share=0.5):
+    """A satisfiable R1CS of the shape the reference's circuit compiler emits (circuitcompiler/circuit.go:84-139, GenerateR1CS): every
+    constraint is ONE flattened gate  out = u (op) v  over earlier signals, and
+        `*`:   A = [u],     B = [v],    C = [out]
+        `+`:   A = [u, v],  B = [one],  C = [out]
+    so a signal enters B only as the second operand of a multiplication: with half the gates additions, ~60 % of the variables have
+    b_i(x) = 0 and their G1.BACGamma / G2.BACGamma points are the point at infinity (what GrothPkObj::b_mask is for).
+    Variables [one, x (public), v_2 .. v_n] (m = n + 1, NPublic = 1); constraint j = 1..n-1 defines v_{j+1} from two uniformly chosen
+    earlier variables (index 1..j); constraint n is one * one = one.  The values are full-width field elements after a few products.
+    Returns (a_csr, b_csr, c_csr, w [m,4] uint64, counts)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    x = field_elems(1, seed + 10)[0]
+    j = np.arange(1, n, dtype=np.int64)
+    u = 1 + (rng.random(n - 1) * j).astype(np.int64)           # operands among variables 1 .. j
+    v = 1 + (rng.random(n - 1) * j).astype(np.int64)
+    is_mul = rng.random(n - 1) < mul_share
+    is_mul[: min(8, n - 1)] = True                             # a few products first: the values become full-width at once
+    var = j + 1
+    same = (~is_mul) & (u == v)
+    two = (~is_mul) & (u != v)
+    lo, hi = np.minimum(u, v), np.maximum(u, v)
+    # A: one entry for products (u) and for u + u (value 2), two sorted entries for u + v; last row {one: 1}
+    a_per = np.concatenate((np.where(two, 2, 1), [1])).astype(np.uint32)
+    a_rowptr = np.zeros(n + 1, dtype=np.uint32)
+    a_rowptr[1:] = np.cumsum(a_per)
+    nnz_a = int(a_rowptr[n])
+    a_col = np.zeros(nnz_a, dtype=np.uint32)
+    a_val = np.zeros((nnz_a, 4), dtype=np.uint64)
+    first = a_rowptr[:-1][:n - 1].astype(np.int64)
+    a_col[first] = np.where(two, lo, u)
+    a_val[first, 0] = np.where(same, 2, 1)
+    a_col[first[two] + 1] = hi[two]
+    a_val[first[two] + 1, 0] = 1
+    a_col[nnz_a - 1] = 0
+    a_val[nnz_a - 1, 0] = 1
+    one = np.zeros((n, 4), dtype=np.uint64)
+    one[:, 0] = 1
+    rowptr = np.arange(n + 1, dtype=np.uint32)
+    b = (rowptr, np.concatenate((np.where(is_mul, v, 0), [0])).astype(np.uint32), one)
+    c = (rowptr, np.concatenate((var, [0])).astype(np.uint32), one.copy())
+    wit = [1, x % R] + [0] * (n - 1)
+    ul, vl, ml = u.tolist(), v.tolist(), is_mul.tolist()
+    for k in range(n - 1):
+        wit[k + 2] = (wit[ul[k]] * wit[vl[k]] if ml[k] else wit[ul[k]] + wit[vl[k]]) % R
+    in_b = np.zeros(n + 1, dtype=bool)
+    in_b[0] = True
+    in_b[v[is_mul]] = True
+    counts = {"mul_gates": int(is_mul.sum()), "add_gates": int((~is_mul).sum()), "variables_in_B": int(in_b.sum()), "variables": n + 1}
+    return (a_rowptr, a_col, a_val), b, c, capi.ints_to_u64(wit), counts
+
+
+class GatesSetupInstance(SqchainSetupInstance):
+    """SqchainSetupInstance's machinery (device trusted setup from seeded toxic values, px from the sparse system, the closed-form
+    proof) on gates_r1cs: a circuit of the reference's own shape, whose key has most of its B points at infinity."""
+
+    def __init__(self, n, seed, mul_share=0.5):
+        from . import r1csqap
+        self.n, self.m, self.seed = n, n + 1, seed
+        self.toxic = field_elems(5, seed + 20)
+        a, b, c, w, self.counts = gates_r1cs(n, seed, mul_share)
+        self.r1cs = (a, b, c)
+        self.w_host = w
+        self._pk, self.vk = groth16.GenerateTrustedSetupSparse(n, self.m, 1, a, b, c, self.toxic)
+        self.ax_host, self.bx_host, self.cx_host, self.px_host = r1csqap.ComputePx(a, b, c, w, self.m)
+        self.w = capi.scalars_upload(self.w_host)
+        self.px = capi.scalars_upload(self.px_host)
+
+    def describe(self):
+        return ("flattened-gate R1CS in the shape of the reference's circuit compiler (%(mul_gates)d `*` gates A=[u] B=[v], %(add_gates)d `+` gates "
+                "A=[u,v] B=[one]; %(variables_in_B)d of %(variables)d variables appear in B), full-width witness, structured trusted setup on the device, "
+                "px from the sparse system" % self.counts) + "; seed 0x%X" % self.seed
+
+
+def gates_setup_instance(n, seed, mul_share=0.5):
+    return GatesSetupInstance(n, seed, mul_share)
+
+
 class SqchainPinocchioInstance:
     """The same sqchain(n) system under the Pinocchio protocol (snark.go): device trusted setup from 8 seeded toxic values
     (gs_pinocchio_setup = snark.go:98-251), resident witness and px.  The verifier (snark.VerifyProof, five pairing
