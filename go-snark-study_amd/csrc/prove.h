@@ -54,7 +54,11 @@ struct PinocchioPkObj : Object {  // snark.Pk (snark.go:16-26), resident
   size_t n_eval = 0, e_lo = 0, n_e = 0;     // a slice holds entries [e_lo, e_lo + n_e)
   DevBuf g1t_eval;
   BaseTable t_g1t_eval;
+  // which held variables appear in B (as GrothPkObj::b_mask): B (G2) and B' (G1) of a reference-style circuit are mostly infinity
+  DevBuf b_mask;
+  size_t b_finite = 0;
   PinocchioPkObj() : Object(Kind::PinocchioPk) {}
 };
+void pinocchio_pk_scan_sparsity(Ctx& c, PinocchioPkObj& pk);
 
 }  // namespace gs

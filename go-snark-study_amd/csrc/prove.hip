@@ -500,16 +500,20 @@ struct PinInFlight : InFlightBase {
   ProofStreams streams;
   HostInputs in;
   hipEvent_t planw = nullptr, planh = nullptr, done_main = nullptr, done_g2 = nullptr, done_g1w = nullptr, done_h = nullptr;   // as GrothInFlight
+  bool split_b = false;                                     // as GrothInFlight: B (G2) and B' over the masked plan, the five other G1 sums over w's
+  hipEvent_t planb = nullptr, done_g1b = nullptr;
+  MsmPending pend_g1b;
+  std::shared_ptr<PhaseTimer> tplanb;
   std::unique_ptr<PhaseTimer> total;
   MsmPending pend_g1w, pend_g2w, pend_h;
   std::shared_ptr<PhaseTimer> tpoly, tplanw, tplanh;
   const uint32_t* bad_host = nullptr;                       // as GrothInFlight
   std::function<int(Ctx&, uint64_t*, int*)> exact_route;
   PinInFlight() {
-    for (hipEvent_t* e : {&planw, &planh, &done_main, &done_g2, &done_g1w, &done_h}) GS_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    for (hipEvent_t* e : {&planw, &planh, &done_main, &done_g2, &done_g1w, &done_h, &planb, &done_g1b}) GS_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
   }
   ~PinInFlight() override {
-    for (hipEvent_t e : {planw, planh, done_main, done_g2, done_g1w, done_h}) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {planw, planh, done_main, done_g2, done_g1w, done_h, planb, done_g1b}) if (e) (void)hipEventDestroy(e);
   }
 };
 
@@ -562,22 +566,42 @@ int pinocchio_enqueue(Ctx& c, PinocchioPkObj* pk, DevScalars w, DevScalars px, c
     GS_HIP(hipStreamWaitEvent(ps.planw, w.host_done, 0));
     if (ps.poly != ps.planw) GS_HIP(hipStreamWaitEvent(ps.poly, w.host_done, 0));
   }
-  {                                                              // aux 1 (or its own stream, proof_streams): plan(w)
+  static const long split_pct = run_knob("GS_SPLIT_B_PERCENT", 55, 0, 100);      // as groth16_enqueue
+  const size_t nterms_w = whi - wlo;
+  st.split_b = pk->b_mask.p != nullptr && nterms_w >= 4096 && cw < 19 && pk->b_finite * 100 < (size_t)split_pct * pk->n_w;
+  MsmPlan plan_b;
+  {                                                              // aux 1 (or its own stream, proof_streams): [the masked plan for B, B',] plan(w)
     StreamScope sc(c, ps.planw);
+    if (st.split_b) {
+      st.tplanb = std::make_shared<PhaseTimer>(c.stream);
+      build_plan(c, 2 * Ctx::kSlots + parity, w.p + wlo * 8, (uint32_t)nterms_w, plan_b, {{1, true}, {1, false}}, cw, !tab_w, pk->b_mask.as<uint32_t>(),
+                 (uint32_t)wbase);
+      st.tplanb->stop();
+      GS_HIP(hipEventRecord(st.planb, c.stream));
+    }
     st.tplanw = std::make_shared<PhaseTimer>(c.stream);
-    build_plan(c, 2 * parity, w.p + wlo * 8, (uint32_t)(whi - wlo), plan_w, {{1, true}, {6, false}}, cw, !tab_w);
+    build_plan(c, 2 * parity, w.p + wlo * 8, (uint32_t)nterms_w, plan_w, st.split_b ? std::vector<LaunchShape>{{5, false}} : std::vector<LaunchShape>{{1, true}, {6, false}},
+               cw, !tab_w);
     st.tplanw->stop();
     GS_HIP(hipEventRecord(st.planw, c.stream));
   }
   {                                                              // main: the accumulations over w, back to back
     StreamScope sc(c, c.main_stream);
-    GS_HIP(hipStreamWaitEvent(c.stream, st.planw, 0));
+    GS_HIP(hipStreamWaitEvent(c.stream, st.split_b ? st.planb : st.planw, 0));
     // A and Ap run over i > NPublic only (snark.go:265-268): their first npublic+1 points were forced
     // to infinity at key creation; Bp, C, Cp, Kp and B run over all variables (:270-278).
-    msm_enqueue_g2(c, plan_w, {base_w(pk->t_b2, pk->b2)}, ws + 6, pin + 1, st.pend_g2w, ps.tail_g2);
+    msm_enqueue_g2(c, st.split_b ? plan_b : plan_w, {base_w(pk->t_b2, pk->b2)}, ws + 6, pin + 1, st.pend_g2w, ps.tail_g2);
     GS_HIP(hipEventRecord(st.done_g2, ps.tail_g2));
-    msm_enqueue_g1(c, plan_w, {base_w(pk->t_a, pk->a), base_w(pk->t_ap, pk->ap), base_w(pk->t_bp, pk->bp), base_w(pk->t_c, pk->c),
-                               base_w(pk->t_cp, pk->cp), base_w(pk->t_kp, pk->kp)}, ws + 0, pin + 0, st.pend_g1w, ps.tail_g1);
+    if (st.split_b) {
+      msm_enqueue_g1(c, plan_b, {base_w(pk->t_bp, pk->bp)}, ws + 5, 3 * Ctx::kSlots + parity, st.pend_g1b, ps.tail_g1);
+      GS_HIP(hipEventRecord(st.done_g1b, ps.tail_g1));
+      GS_HIP(hipStreamWaitEvent(c.stream, st.planw, 0));
+      msm_enqueue_g1(c, plan_w, {base_w(pk->t_a, pk->a), base_w(pk->t_ap, pk->ap), base_w(pk->t_c, pk->c), base_w(pk->t_cp, pk->cp), base_w(pk->t_kp, pk->kp)},
+                     ws + 0, pin + 0, st.pend_g1w, ps.tail_g1);
+    } else {
+      msm_enqueue_g1(c, plan_w, {base_w(pk->t_a, pk->a), base_w(pk->t_ap, pk->ap), base_w(pk->t_bp, pk->bp), base_w(pk->t_c, pk->c),
+                                 base_w(pk->t_cp, pk->cp), base_w(pk->t_kp, pk->kp)}, ws + 0, pin + 0, st.pend_g1w, ps.tail_g1);
+    }
     GS_HIP(hipEventRecord(st.done_g1w, ps.tail_g1));
   }
   {                                                              // aux 1 again: H(x), plan(h)
@@ -637,7 +661,14 @@ int pinocchio_collect(Ctx& c, PinInFlight& st, uint64_t out[72], int inf[8]) {
     auto f2 = std::async(std::launch::async, [&] { msm_finish_g2(c, st.pend_g2w, g2w); });
     struct Join { std::future<void>& f; ~Join() { if (f.valid()) f.wait(); } } j2{f2};
     GS_HIP(hipEventSynchronize(st.done_g1w));
-    auto f1 = std::async(std::launch::async, [&] { msm_finish_g1(c, st.pend_g1w, g1w); });
+    auto f1 = std::async(std::launch::async, [&] {
+      msm_finish_g1(c, st.pend_g1w, g1w);
+      if (st.split_b) {                              // g1w = [A, A', C, C', K']: B' goes back to position 2
+        std::vector<G1Xyzz> g1b;
+        msm_finish_g1(c, st.pend_g1b, g1b);
+        g1w.insert(g1w.begin() + 2, g1b[0]);
+      }
+    });
     Join j1{f1};
     GS_HIP(hipEventSynchronize(st.done_h));
     msm_finish_g1(c, st.pend_h, g1h);
@@ -645,6 +676,7 @@ int pinocchio_collect(Ctx& c, PinInFlight& st, uint64_t out[72], int inf[8]) {
   }
   GS_HIP(hipEventSynchronize(st.done_main));
   msm_book_timing(c, st.pend_g1w); msm_book_timing(c, st.pend_g2w); msm_book_timing(c, st.pend_h);
+  if (st.split_b) { msm_book_timing(c, st.pend_g1b); c.timing.plan_ms += st.tplanb->ms(); }
   c.timing.poly_ms += st.tpoly->ms();
   c.timing.plan_ms += st.tplanw->ms() + st.tplanh->ms();
   c.timing.total_ms += st.total->ms();
@@ -753,6 +785,11 @@ void mark_ticket_reads(const ProofStreams& ps, Scalars* w, Scalars* px_or_hv) {
 void gs::groth_pk_scan_sparsity(Ctx& c, GrothPkObj& pk) {
   pk.b_mask.alloc(std::max<size_t>((pk.n_w + 31) / 32, 1) * 4);
   pk.b_finite = finite_mask_dev(c, pk.bacgamma1.as<uint32_t>(), pk.bacgamma2.as<uint32_t>(), (uint32_t)pk.n_w, pk.b_mask.as<uint32_t>());
+}
+
+void gs::pinocchio_pk_scan_sparsity(Ctx& c, PinocchioPkObj& pk) {
+  pk.b_mask.alloc(std::max<size_t>((pk.n_w + 31) / 32, 1) * 4);
+  pk.b_finite = finite_mask_dev(c, pk.bp.as<uint32_t>(), pk.b2.as<uint32_t>(), (uint32_t)pk.n_w, pk.b_mask.as<uint32_t>());
 }
 
 extern "C" {
@@ -1284,6 +1321,7 @@ int gs_pinocchio_pk_create(gs_handle a, gs_handle ap, gs_handle b_g2, gs_handle 
     const uint32_t* dz = upload_tmp(c, prove_state(c).up_a, z, nz);
     divisor_init(c, pk->z, dz, nz);
     GS_HIP(hipStreamSynchronize(c.stream));
+    pinocchio_pk_scan_sparsity(c, *pk);
     *out = c.put(std::move(pk));
     return GS_OK;
   }, true, false, a);
@@ -1412,6 +1450,7 @@ static int pinocchio_pk_shard_impl(Ctx& c, Ctx& from, PinocchioPkObj* full, size
     GS_HIP(hipStreamSynchronize(c.stream));             // `zc` is released here
   }
   GS_HIP(hipStreamSynchronize(c.stream));
+  pinocchio_pk_scan_sparsity(c, *pk);
   *out = c.put(std::move(pk));
   return GS_OK;
 }

@@ -288,6 +288,7 @@ int gs_pinocchio_setup(size_t n, size_t m, size_t npublic,
     force_infinity_points(c, pk->a, npublic + 1, 16);                               // the prover sums A, Ap over i > NPublic (snark.go:265)
     force_infinity_points(c, pk->ap, npublic + 1, 16);
     GS_HIP(hipStreamSynchronize(c.stream));
+    pinocchio_pk_scan_sparsity(c, *pk);
     *pk_out = c.put(std::move(pk));
     return GS_OK;
   });

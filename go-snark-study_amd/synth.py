@@ -475,6 +475,27 @@ class SqchainPinocchioInstance:
                 "(gs_pinocchio_setup), px from the sparse system; seed 0x%X" % self.seed)
 
 
+class GatesPinocchioInstance(SqchainPinocchioInstance):
+    """gates_r1cs under the Pinocchio protocol: B (G2) and B' of its key are mostly the point at infinity (PinocchioPkObj::b_mask)."""
+
+    def __init__(self, n, seed, mul_share=0.5):
+        from . import r1csqap, snark
+        self.n, self.m, self.seed = n, n + 1, seed
+        self.toxic = field_elems(8, seed + 30)
+        a, b, c, w, self.counts = gates_r1cs(n, seed, mul_share)
+        self.r1cs = (a, b, c)
+        self.w_host = w
+        self._pk, self.vk = snark.GenerateTrustedSetupSparse(n, self.m, 1, a, b, c, self.toxic)
+        _, _, _, self.px_host = r1csqap.ComputePx(a, b, c, w, self.m)
+        self.w = capi.scalars_upload(self.w_host)
+        self.px = capi.scalars_upload(self.px_host)
+        self.public = capi.u64_to_ints(self.w_host[1:2])
+
+
+def gates_pinocchio_instance(n, seed, mul_share=0.5):
+    return GatesPinocchioInstance(n, seed, mul_share)
+
+
 class RandomPinocchioInstance:
     """A Pinocchio instance of the reference's shape (m = n + 1, NPublic = 1, len(Z) = len(hx) = n = len(G1T)) whose key points are
     k_i * G for seeded uniform k_i and whose w / px are seeded uniform field elements: what snark.GenerateProofs (snark.go:254-289)

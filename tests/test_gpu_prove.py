@@ -1268,6 +1268,28 @@ def test_keys_with_sparse_b_arrays_sum_b1_and_b2_over_a_masked_plan(n):
     assert same(groth16.finish(pk, parallel.combine_partials(parts, groth16.SUM_IS_G2), r, s))
 
 
+@pytest.mark.parametrize("n", [3000, (1 << 14) + 1])
+def test_pinocchio_keys_with_sparse_b_arrays(n):
+    """The same for snark.GenerateProofs: B (G2) and B' over the masked plan, the five other G1 sums over w's.  snark.VerifyProof's five
+    equations tie B to B' and A, B, C, H together; every entry route gives the same proof; a proof from the key's two slices equals it."""
+    from gosnark_amd import synth
+    pin = synth.gates_pinocchio_instance(n, 0x9200 + n % 89)
+    pk = pin.device_pk()
+    got = snark.prove_resident(pk, pin.w, pin.px)
+    tm = capi.last_timing()
+    assert snark.VerifyProof(pin.vk, got, pin.public) and not snark.VerifyProof(pin.vk, got, [(pin.public[0] + 1) % O.R])
+    windows = 254 // tm["window_bits"] + 1
+    assert (tm["acc_g2_adds"] < 0.5 * windows * n) == (n >= 4096)
+    same = lambda p: all(getattr(p, k) == getattr(got, k) for k in snark.Proof.FIELDS)     # noqa: E731
+    dr = r1csqap.DeviceR1CS(*pin.r1cs, pin.m)
+    assert same(snark.prove_from_witness(pk, dr, pin.w))
+    t = [snark.prove_begin(pk, pin.w, pin.px), snark.prove_witness_host_begin(pk, dr, pin.w_host), snark.prove_host_begin(pk, pin.w_host, pin.px_host)]
+    assert all(same(snark.prove_end(k)) for k in t)
+    slices = [snark.ShardPk(pk, k, 2) for k in range(2)]
+    recs = [snark.prove_partials(slices[k], pin.w, pin.px, k, 2) for k in range(2)]
+    assert same(snark.combine(recs))
+
+
 def test_small_mirrors_of_the_reference_seams():
     """The API names VERDICT r2 found missing, each against the oracle's restatement of the reference: PolynomialField.NewPolZeroAt
     (r1csqap.go:129-147), Transpose (:11-21), the device-side CombinePolynomials (:191-210), and G1 / G2 Double, Neg, Sub, Equal,
