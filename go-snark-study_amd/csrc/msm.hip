@@ -202,8 +202,10 @@ void build_plan(Ctx& c, int slot, const uint32_t* scalars_dev, uint32_t n, MsmPl
 }
 
 // Enqueue the kernels that fill `fresh` (W rows of n points) from row 0 on `stream`.
+// slab_max: points per launch (2^18 = 1024 workgroups; a background build passes 2^17, see start_background_build).
 template <class T>
-static void enqueue_table_build(Ctx& c, hipStream_t stream, DevBuf& scratch, const uint32_t* src, size_t n, int cbits, DevBuf& fresh) {
+static void enqueue_table_build(Ctx& c, hipStream_t stream, DevBuf& scratch, const uint32_t* src, size_t n, int cbits, DevBuf& fresh,
+                                size_t slab_max = (size_t)1 << 18) {
   constexpr size_t aw = PointIO<T>::kAffineWords;
   const int W = 254 / cbits + 1;
   fresh.alloc(std::max<size_t>(n, 1) * W * aw * 4);
@@ -214,7 +216,7 @@ static void enqueue_table_build(Ctx& c, hipStream_t stream, DevBuf& scratch, con
     } else {
       // slabs of 2^18 points: (W - 1) rows of [XYZZ | running product] raw limbs per point (<= 1.4 GiB for G2), reused per slab
       constexpr size_t sw = PointIO<T>::kXyzzWords + PointIO<T>::kXyzzWords / 4;
-      const size_t slab = std::min<size_t>(n, (size_t)1 << 18);
+      const size_t slab = std::min<size_t>(n, slab_max);
       scratch.ensure(slab * (size_t)(W - 1) * sw * 4);
       for (size_t first = 0; first < n; first += slab) {
         const size_t count = std::min(slab, n - first);
@@ -251,7 +253,10 @@ constexpr uint32_t kTableAfterUses = 2;
 
 void table_settle(Ctx& c, BaseTable& t, bool install) {
   if (!t.pending.p) return;
-  if (c.table_stream) GS_HIP(hipStreamSynchronize(c.table_stream));
+  // this table's own build only: the stream may still be busy with the key's other arrays (a proof that found ONE table complete used
+  // to wait here for all five)
+  if (t.pending_done) GS_HIP(hipEventSynchronize(t.pending_done));
+  else if (c.table_stream) GS_HIP(hipStreamSynchronize(c.table_stream));
   if (install) {
     t.rows = std::move(t.pending);
     t.n = t.pending_n; t.c = t.pending_c; t.W = 254 / t.pending_c + 1;
@@ -264,13 +269,27 @@ static void start_background_build(Ctx& c, BaseTable& t, const TableRef& r, int 
   if (!c.table_stream) {
     int least = 0, greatest = 0;
     GS_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-    GS_HIP(hipStreamCreateWithPriority(&c.table_stream, hipStreamNonBlocking, least));
+    static const bool low = run_knob("GS_TABLE_STREAM_LOW", 1, 0, 1) != 0;
+    GS_HIP(hipStreamCreateWithPriority(&c.table_stream, hipStreamNonBlocking, low ? least : 0));
   }
   if (!t.pending_done) GS_HIP(hipEventCreateWithFlags(&t.pending_done, hipEventDisableTiming));
   DevBuf& scratch = msm_state(c).table_scratch_bg;
+  // Points per launch of a background build.  Measured on a fresh 2^20 key, blocking proofs back to back
+  // (profiles/r05_background_build_slabs.txt): slabs of 2^18 / 2^17 / 2^16 / 2^15 points -> the tables serve from proof #10 / #13 / #19 /
+  // #35 on (245 / 288 / 357 / 580 ms after the key arrived), the slowest proof on the way takes 35 / 28 / 26 / 24 ms (table-free and
+  // alone: 10-12).  The table stream has the lowest priority, so smaller slabs mostly starve the build; 2^17 it is.
+  static const size_t slab = (size_t)1 << run_knob("GS_TABLE_BG_SLAB_LOG2", 17, 10, 18);      // (same tables whatever the slab)
   try {
-    if (r.g2) enqueue_table_build<Fq2Tag>(c, c.table_stream, scratch, r.row0, r.n, cbits, t.pending);
-    else enqueue_table_build<FqTag>(c, c.table_stream, scratch, r.row0, r.n, cbits, t.pending);
+    // The slab scratch at its G2 size BEFORE the first launch: the stream's builds share it, and growing it for the fourth array (the
+    // G2 one) released the old buffer -- hipFree waits for the device, i.e. for the three G1 builds just enqueued: that, not the
+    // builds' share of the chip, was most of the 88 ms a fresh 2^20 key's second proof took (now 28).
+    {
+      constexpr size_t sw2 = PointIO<Fq2Tag>::kXyzzWords + PointIO<Fq2Tag>::kXyzzWords / 4;
+      const int W = 254 / cbits + 1;
+      if (W > 2) scratch.ensure(std::min<size_t>(std::max<size_t>(r.n, 1), slab) * (size_t)(W - 1) * sw2 * 4);
+    }
+    if (r.g2) enqueue_table_build<Fq2Tag>(c, c.table_stream, scratch, r.row0, r.n, cbits, t.pending, slab);
+    else enqueue_table_build<FqTag>(c, c.table_stream, scratch, r.row0, r.n, cbits, t.pending, slab);
   } catch (const HipError& e) {
     if (e.e != hipErrorOutOfMemory) throw;      // no room for a table: keep summing table-free
     t.pending.release();

@@ -1,18 +1,34 @@
-"""Time from a fresh resident key to its first proof (window tables are built on the first prove) -- dev tool."""
+"""Time from a fresh resident key to its first proofs -- dev tool.
+    python tools/time_first_proof.py [policy=auto] [log2n=20] [proofs=40]
+Prints every blocking proof's wall time and the window width it ran on (gs_timing.window_bits: the table-free route's differs from
+the table route's), i.e. the whole warm-up transient of a key under the table policy: first proof, the proofs that share the chip
+with the background builds (GS_TABLE_BG_SLAB_LOG2), the switch-over."""
 import sys, time
 sys.path.insert(0, "/root/repo")
 import torch
 import gosnark_amd
 from gosnark_amd import capi, synth, groth16
+policy = sys.argv[1] if len(sys.argv) > 1 else "auto"
+logn = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+count = int(sys.argv[3]) if len(sys.argv) > 3 else 40
 capi.init()
-synth.sqchain_setup_instance(1 << 10, 1)
-for logn in (16, 20):
-    inst = synth.sqchain_setup_instance(1 << logn, 3)
-    r, s = synth.field_elems(2, 5)
-    torch.cuda.synchronize(); t = time.perf_counter()
-    groth16.prove_resident(inst.device_pk(), inst.w, inst.px, r, s)
-    t1 = time.perf_counter() - t
+capi.set_table_policy(policy)
+warm = synth.sqchain_setup_instance(1 << 10, 1)
+groth16.prove_resident(warm.device_pk(), warm.w, warm.px, *synth.field_elems(2, 4))
+inst = synth.sqchain_setup_instance(1 << logn, 3)
+r, s = synth.field_elems(2, 5)
+pk = inst.device_pk()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+rows, first = [], None
+for i in range(count):
     t = time.perf_counter()
-    groth16.prove_resident(inst.device_pk(), inst.w, inst.px, r, s)
-    t2 = time.perf_counter() - t
-    print("2^%d: first proof (tables + proof) %.1f ms, second %.1f ms" % (logn, t1 * 1e3, t2 * 1e3), flush=True)
+    p = groth16.prove_resident(pk, inst.w, inst.px, r, s)
+    dt = (time.perf_counter() - t) * 1e3
+    first = first or p
+    assert (p.PiA, p.PiB, p.PiC) == (first.PiA, first.PiB, first.PiC)
+    rows.append((dt, capi.last_timing()["window_bits"], capi.handle_bytes(pk.handle)[1] >> 20))
+print("policy %s, 2^%d: proof ms (window bits, table MiB):" % (policy, logn), " ".join("%.1f(%d,%d)" % x for x in rows))
+switch = next((i for i, x in enumerate(rows) if x[1] != rows[0][1]), None)
+print("  first %.1f ms, second %.1f ms, sum until the tables serve %.1f ms (proof #%s), steady %.2f ms" % (
+    rows[0][0], rows[1][0], sum(x[0] for x in rows[: (switch or 0)]), switch, min(x[0] for x in rows)), flush=True)
