@@ -1,6 +1,9 @@
 // Host -> device copies from PAGEABLE caller memory (the reference's signatures hand over plain Go slices).  hipMemcpyAsync from
 // pageable memory stages through the runtime on the calling thread at ~12 GB/s; here the staging is ours: a few persistent host
-// threads memcpy 4 MiB pieces into pinned buffers (each context owns two) while the previous piece's DMA is in flight.
+// threads memcpy 16 MiB pieces into pinned buffers (each context owns three) while the previous pieces' DMAs are in flight.
+// Round 5 (profiles/r05_ab_stage_pieces.txt): with 4 MiB pieces and two buffers a host-buffer ticket spent 2.8 + 5.0 ms of host time
+// staging its 32 + 96 MiB (17 GB/s: every piece costs a wake-up of the copy threads, an event wait and a DMA submission, and the
+// number of copy threads made no difference); 16 MiB pieces: 1.8 + 3.3 ms, and the px-from-host stream 1.07x -> 1.05x the resident one.
 #pragma once
 #include <atomic>
 #include <condition_variable>
@@ -43,7 +46,7 @@ class HostCopyPool {                       // process-wide; workers sleep on a c
  private:
   HostCopyPool() {
     unsigned hw = std::thread::hardware_concurrency();
-    int want = (int)run_knob("GS_COPY_THREADS", 4, 1, 64);
+    int want = (int)run_knob("GS_COPY_THREADS", 8, 1, 64);
     if (hw && (unsigned)want > hw) want = (int)hw;
     for (int i = 1; i < want; ++i) workers_.emplace_back([this] { loop(); });
     for (auto& t : workers_) t.detach();
@@ -88,15 +91,18 @@ class HostCopyPool {                       // process-wide; workers sleep on a c
 // flight: it is ordered on the stream like any other operation).  The caller holds the context lock.
 inline void staged_h2d(Ctx& c, void* dst_dev, const void* src_host, size_t bytes, hipStream_t stream) {
   if (bytes < (1u << 20)) { GS_HIP(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, stream)); return; }
-  for (int b = 0; b < Ctx::kStageBuffers; ++b) {
-    if (!c.stage[b]) GS_HIP(hipHostMalloc(&c.stage[b], Ctx::kStageBytes, hipHostMallocDefault));
+  // piece size and buffers in rotation: every piece costs a wake-up of the copy threads, an event wait and a DMA submission
+  static const size_t piece = (size_t)run_knob("GS_STAGE_MIB", 16, 1, (long)(Ctx::kStageBytes >> 20)) << 20;
+  static const int nbuf = (int)run_knob("GS_STAGE_BUFFERS", 3, 2, Ctx::kStageBuffers);
+  for (int b = 0; b < nbuf; ++b) {
+    if (!c.stage[b]) GS_HIP(hipHostMalloc(&c.stage[b], piece, hipHostMallocDefault));
     if (!c.stage_ev[b]) GS_HIP(hipEventCreateWithFlags(&c.stage_ev[b], hipEventDisableTiming));
   }
   HostCopyPool& pool = HostCopyPool::get();
   size_t off = 0;
   for (int i = 0; off < bytes; ++i) {
-    const int b = i % Ctx::kStageBuffers;
-    const size_t len = std::min(Ctx::kStageBytes, bytes - off);
+    const int b = i % nbuf;
+    const size_t len = std::min(piece, bytes - off);
     GS_HIP(hipEventSynchronize(c.stage_ev[b]));                     // the DMA that last read this buffer (no-op on a fresh event)
     pool.copy(c.stage[b], static_cast<const char*>(src_host) + off, len);
     GS_HIP(hipMemcpyAsync(static_cast<char*>(dst_dev) + off, c.stage[b], len, hipMemcpyHostToDevice, stream));

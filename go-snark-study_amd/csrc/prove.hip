@@ -1050,10 +1050,14 @@ static int groth16_begin_impl(Ctx& c, const char* fn, gs_handle hpk, gs_handle h
   if (!host) { raw->keep.push_back(c.share<Object>(hw, Kind::Scalars)); raw->keep.push_back(c.share<Object>(hpx, Kind::Scalars)); }
   raw->fpre = std::async(std::launch::async, [raw] { groth16_tail_pre(raw->pk, raw->r, raw->s, raw->pre); });
   raw->early.pk = pk; raw->early.r = raw->r; raw->early.s = raw->s; raw->early.pre = &raw->pre; raw->early.fpre = &raw->fpre;
+  const double h0 = host_trace() ? host_now_ms() : 0;
   const DevScalars dw = host ? stage_slot_w(c, parity, w_host, nw, raw->in) : DevScalars{w->buf.as<uint32_t>(), w->n};
+  const double h1 = host_trace() ? host_now_ms() : 0;
   const DevScalars dp = host ? slot_px_from_host(c, parity, px_host, npx, raw->in) : DevScalars{px->buf.as<uint32_t>(), px->n};
+  const double h2 = host_trace() ? host_now_ms() : 0;
   const int rc = groth16_enqueue(c, pk, dw, dp, Shard{}, parity, false, true, *raw);
   if (rc != GS_OK) return rc;
+  if (host_trace()) fprintf(stderr, "[gs host] begin: stage w %.3f ms, stage px %.3f ms, enqueue %.3f ms\n", h1 - h0, h2 - h1, host_now_ms() - h2);
   if (raw->in.th2d) raw->in.th2d->stop();
   mark_ticket_reads(raw->streams, w, px);
   st->ticket = c.new_ticket();

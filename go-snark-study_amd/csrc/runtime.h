@@ -198,8 +198,8 @@ struct Ctx {
   // behind the check kernel writes them; the collector reads them).  Context-owned, so they outlive gs_trim while tickets are out.
   DevBuf bad_dev;
   uint32_t* bad_host = nullptr;
-  static constexpr int kStageBuffers = 2;            // pinned staging of uploads from pageable caller memory (hostcopy.h), lazy
-  static constexpr size_t kStageBytes = 4u << 20;
+  static constexpr int kStageBuffers = 4;            // pinned staging of uploads from pageable caller memory (hostcopy.h), lazy: at most 4,
+  static constexpr size_t kStageBytes = 64u << 20;   // of at most 64 MiB (hostcopy.h decides how many and how large)
   void* stage[kStageBuffers] = {};
   hipEvent_t stage_ev[kStageBuffers] = {};
   hipStream_t copy_stream = nullptr;                 // gs_scalars_upload (lazy)

@@ -21,8 +21,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
 else:
     logn = sys.argv[1] if len(sys.argv) > 1 else "20"
     for rnd in range(2):
-        for mode in ("0", "1", "2"):
+        for mode in os.environ.get("GS_AB_MODES", "0,1,2").split(","):
             env = dict(os.environ, GS_HOST_STAGE=mode)
             res = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", logn], env=env, capture_output=True, text=True)
             line = [x for x in res.stdout.splitlines() if x.startswith("{")]
-            print("GS_HOST_STAGE=%s round %d: %s" % (mode, rnd, line[-1] if line else "FAILED " + res.stderr[-400:]), flush=True)
+            print("GS_HOST_STAGE=%s GS_COPY_THREADS=%s round %d: %s" % (mode, os.environ.get("GS_COPY_THREADS", "4"), rnd, line[-1] if line else "FAILED " + res.stderr[-400:]), flush=True)
