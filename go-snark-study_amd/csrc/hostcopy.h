@@ -1,12 +1,16 @@
 // Host -> device copies from PAGEABLE caller memory (the reference's signatures hand over plain Go slices).  hipMemcpyAsync from
 // pageable memory stages through the runtime on the calling thread at ~12 GB/s; here the staging is ours: a few persistent host
-// threads memcpy 16 MiB pieces into pinned buffers (each context owns three) while the previous pieces' DMAs are in flight.
+// threads memcpy 8 MiB pieces into pinned buffers (each context owns three) while the previous pieces' DMAs are in flight.
 // Round 5 (profiles/r05_ab_stage_pieces.txt): with 4 MiB pieces and two buffers a host-buffer ticket spent 2.8 + 5.0 ms of host time
-// staging its 32 + 96 MiB (17 GB/s: every piece costs a wake-up of the copy threads, an event wait and a DMA submission, and the
-// number of copy threads made no difference); 16 MiB pieces: 1.8 + 3.3 ms, and the px-from-host stream 1.07x -> 1.05x the resident one.
+// staging its 32 + 64 MiB of w and px.  The host copies themselves take 0.57 + 1.14 ms (56 GB/s with eight threads, 35 with one); the
+// rest is waiting for DMAs that run at 10-30 GB/s beside the proofs' kernels (alone: 50-57).  8 MiB pieces over three buffers and ONE
+// wait for w and px: the px-from-host stream 1.07x -> 1.02-1.03x the resident one.  Pieces of 16 MiB and more take a slower path
+// in the runtime while the device is busy (in-place updates 10.0 -> 11.0 ms per proof; 32 MiB pieces: 7.5 ms per 32 MiB).
 #pragma once
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
+#include <cstdio>
 #include <cstring>
 #include <mutex>
 #include <thread>
@@ -68,6 +72,12 @@ class HostCopyPool {                       // process-wide; workers sleep on a c
   void loop() {
     uint64_t seen = 0;
     for (;;) {
+      // a staged upload is a train of jobs ~0.3 ms apart: after a job, watch the piece counter for the next one for a while before
+      // sleeping (a futex wake-up costs 50-100 us -- as long as a thread's whole share of a 16 MiB piece)
+      if (seen) {
+        const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(400);
+        while ((next_.load(std::memory_order_relaxed) >> 32) == seen && std::chrono::steady_clock::now() < until) cpu_relax();
+      }
       Job j;
       {
         std::unique_lock<std::mutex> lk(mu_);
@@ -77,6 +87,11 @@ class HostCopyPool {                       // process-wide; workers sleep on a c
       }
       run_pieces(j);
     }
+  }
+  static void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#endif
   }
   std::vector<std::thread> workers_;
   std::mutex job_mu_, mu_;
@@ -92,23 +107,31 @@ class HostCopyPool {                       // process-wide; workers sleep on a c
 inline void staged_h2d(Ctx& c, void* dst_dev, const void* src_host, size_t bytes, hipStream_t stream) {
   if (bytes < (1u << 20)) { GS_HIP(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, stream)); return; }
   // piece size and buffers in rotation: every piece costs a wake-up of the copy threads, an event wait and a DMA submission
-  static const size_t piece = (size_t)run_knob("GS_STAGE_MIB", 16, 1, (long)(Ctx::kStageBytes >> 20)) << 20;
+  static const size_t piece = (size_t)run_knob("GS_STAGE_MIB", 8, 1, (long)(Ctx::kStageBytes >> 20)) << 20;
   static const int nbuf = (int)run_knob("GS_STAGE_BUFFERS", 3, 2, Ctx::kStageBuffers);
   for (int b = 0; b < nbuf; ++b) {
     if (!c.stage[b]) GS_HIP(hipHostMalloc(&c.stage[b], piece, hipHostMallocDefault));
     if (!c.stage_ev[b]) GS_HIP(hipEventCreateWithFlags(&c.stage_ev[b], hipEventDisableTiming));
   }
   HostCopyPool& pool = HostCopyPool::get();
+  static const bool trace = run_flag("GS_HOST_TRACE");
+  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double t_wait = 0, t_copy = 0, t_submit = 0;
   size_t off = 0;
   for (int i = 0; off < bytes; ++i) {
     const int b = i % nbuf;
     const size_t len = std::min(piece, bytes - off);
+    const double t0 = trace ? now() : 0;
     GS_HIP(hipEventSynchronize(c.stage_ev[b]));                     // the DMA that last read this buffer (no-op on a fresh event)
+    const double t1 = trace ? now() : 0;
     pool.copy(c.stage[b], static_cast<const char*>(src_host) + off, len);
+    const double t2 = trace ? now() : 0;
     GS_HIP(hipMemcpyAsync(static_cast<char*>(dst_dev) + off, c.stage[b], len, hipMemcpyHostToDevice, stream));
     GS_HIP(hipEventRecord(c.stage_ev[b], stream));
+    if (trace) { t_wait += t1 - t0; t_copy += t2 - t1; t_submit += now() - t2; }
     off += len;
   }
+  if (trace) fprintf(stderr, "[gs host] staged_h2d %zu MiB: buffer waits %.3f ms, host copies %.3f ms, DMA submissions %.3f ms\n", bytes >> 20, t_wait, t_copy, t_submit);
 }
 
 }  // namespace gs

@@ -738,7 +738,8 @@ void download(Ctx& c, uint64_t* host, const void* dev, size_t n) {
 static void ensure_copy_stream(Ctx& c) {
   if (!c.copy_stream) GS_HIP(hipStreamCreateWithFlags(&c.copy_stream, hipStreamNonBlocking));
 }
-DevScalars stage_slot_w(Ctx& c, int parity, const uint64_t* host, size_t n, HostInputs& in) {
+// px_follows: slot_px_from_host stages px on the same stream right after and waits for both (one DMA tail instead of two)
+DevScalars stage_slot_w(Ctx& c, int parity, const uint64_t* host, size_t n, HostInputs& in, bool px_follows = false) {
   ensure_copy_stream(c);
   in.create();
   DevBuf& b = prove_state(c).slot_w[parity];
@@ -751,7 +752,7 @@ DevScalars stage_slot_w(Ctx& c, int parity, const uint64_t* host, size_t n, Host
   }
   in.th2d = std::make_shared<PhaseTimer>(c.copy_stream);
   if (n) staged_h2d(c, b.p, host, n * 32, c.copy_stream);
-  if (host_stage_mode() == 1) GS_HIP(hipStreamSynchronize(c.copy_stream));
+  if (host_stage_mode() == 1) { if (!px_follows) GS_HIP(hipStreamSynchronize(c.copy_stream)); }
   else {
     GS_HIP(hipEventRecord(in.w_done, c.copy_stream));
     d.host_done = in.w_done;
@@ -1051,7 +1052,7 @@ static int groth16_begin_impl(Ctx& c, const char* fn, gs_handle hpk, gs_handle h
   raw->fpre = std::async(std::launch::async, [raw] { groth16_tail_pre(raw->pk, raw->r, raw->s, raw->pre); });
   raw->early.pk = pk; raw->early.r = raw->r; raw->early.s = raw->s; raw->early.pre = &raw->pre; raw->early.fpre = &raw->fpre;
   const double h0 = host_trace() ? host_now_ms() : 0;
-  const DevScalars dw = host ? stage_slot_w(c, parity, w_host, nw, raw->in) : DevScalars{w->buf.as<uint32_t>(), w->n};
+  const DevScalars dw = host ? stage_slot_w(c, parity, w_host, nw, raw->in, true) : DevScalars{w->buf.as<uint32_t>(), w->n};
   const double h1 = host_trace() ? host_now_ms() : 0;
   const DevScalars dp = host ? slot_px_from_host(c, parity, px_host, npx, raw->in) : DevScalars{px->buf.as<uint32_t>(), px->n};
   const double h2 = host_trace() ? host_now_ms() : 0;
@@ -1360,7 +1361,7 @@ static int pinocchio_begin_impl(Ctx& c, const char* fn, gs_handle hpk, gs_handle
   auto st = std::make_unique<PinInFlight>();
   st->keep = {c.share<Object>(hpk, Kind::PinocchioPk)};
   if (!host) { st->keep.push_back(c.share<Object>(hw, Kind::Scalars)); st->keep.push_back(c.share<Object>(hpx, Kind::Scalars)); }
-  const DevScalars dw = host ? stage_slot_w(c, parity, w_host, nw, st->in) : DevScalars{w->buf.as<uint32_t>(), w->n};
+  const DevScalars dw = host ? stage_slot_w(c, parity, w_host, nw, st->in, true) : DevScalars{w->buf.as<uint32_t>(), w->n};
   const DevScalars dp = host ? slot_px_from_host(c, parity, px_host, npx, st->in) : DevScalars{px->buf.as<uint32_t>(), px->n};
   const int rc = pinocchio_enqueue(c, pk, dw, dp, Shard{}, parity, false, true, *st);
   if (rc != GS_OK) return rc;
