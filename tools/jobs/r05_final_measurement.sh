@@ -12,3 +12,4 @@ bash tools/gpu_run.sh $T stats bench_steps3 --steps 3 --warmup 1 --reps 1 --cpu-
 (timeout 600 python bench.py --instance gates --cpu-log2n 13 --no-extras 2>/dev/null | tail -1) > gpurun_out/$T/bench_line_gates.json; head -c 300 gpurun_out/$T/bench_line_gates.json; echo
 bash tools/gpu_run.sh $T bench 2p16 --log2n 16 --steps 100 --warmup 10 --cpu-log2n 0 --no-extras -- bench 2p18 --log2n 18 --steps 40 --warmup 5 --cpu-log2n 0 --no-extras -- bench 2p22 --log2n 22 --steps 4 --warmup 1 --reps 3 --cpu-log2n 0 --no-extras -- bench realistic --instance realistic --steps 10 --warmup 3 --reps 3 --cpu-log2n 0 --no-extras -- bench witness_pipelined --workload prove_witness --steps 10 --warmup 2 --cpu-log2n 0 -- bench pinocchio --workload prove_pinocchio --steps 10 --warmup 2 --cpu-log2n 0 -- bench msm_g1 --workload msm_g1 --steps 40 --warmup 5 --cpu-log2n 0 -- bench msm_g1_2p16_blocking --workload msm_g1 --log2n 16 --pipeline 1 --steps 200 --warmup 20 --cpu-log2n 0
 (timeout 300 python bench.py --gpus 8 --steps 5 --warmup 2 --reps 2 2>/dev/null | tail -1) > gpurun_out/$T/bench_plain_8_logical.json; head -c 300 gpurun_out/$T/bench_plain_8_logical.json; echo
+timeout 600 python tools/soak_mixed.py 150 7 2>&1 | tail -6 | tee gpurun_out/$T/soak_mixed.txt
