@@ -501,10 +501,14 @@ def test_hostile_environment_cannot_change_a_result():
         "b2 = capi.g2_fixed_base(U.rand_scalars_u64(1024, 701)); k2 = U.rand_scalars_u64(1024, 700)\n"
         "inst = synth.sqchain_setup_instance(256, 99); r, s = synth.field_elems(2, 5)\n"
         "p = groth16.prove_end(groth16.prove_begin(inst.device_pk(), inst.w, inst.px, r, s))\n"
-        "print(json.dumps([capi.msm(b1, k1), capi.msm(b2, k2, g2=True), [p.PiA, p.PiB, p.PiC]]))\n" % (root, os.path.join(root, "tests")))
+        "q = groth16.prove_end(groth16.prove_host_begin(inst.device_pk(), inst.w_host, capi.scalars_download(inst.px), r, s))\n"
+        "print(json.dumps([capi.msm(b1, k1), capi.msm(b2, k2, g2=True), [p.PiA, p.PiB, p.PiC], [q.PiA, q.PiB, q.PiC]]))\n" % (root, os.path.join(root, "tests")))
     hostile = {"GS_REDUCE_L": "3", "GS_CHUNK": "7", "GS_FOLD_MAX": "-5", "GS_AUTO_MAX_C": "99", "GS_SORT_BLOCK": "1", "GS_PART_MIN_R": "0",
                "GS_WINDOW_COST_BUCKET": "nan", "GS_TABLE_PER_ROW": "x", "GS_TAIL_FLIP": "77", "GS_TAIL_PRIORITY": "9", "GS_CHUNK_H": "5", "GS_TAIL_ALONE_LOG2": "99", "GS_COPY_THREADS": "-3", "GS_PLANW_STREAM": "7", "GS_MSM_TICKET_STREAMS": "5",
-               "GS_NO_PRIORITY": "1"}
+               "GS_NO_PRIORITY": "1",
+               # round 5's switches: staging of host buffers, table policy and background builds, the sparse-B threshold
+               "GS_HOST_STAGE": "9", "GS_STAGE_MIB": "0", "GS_STAGE_BUFFERS": "99", "GS_TABLE_POLICY": "7", "GS_TABLE_BG_SLAB_LOG2": "40",
+               "GS_TABLE_STREAM_LOW": "-1", "GS_SPLIT_B_PERCENT": "1000", "GS_CHUNK_MODEL": "5"}
 
     def run(env):
         out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, **env), timeout=600)
