@@ -1268,6 +1268,44 @@ def test_keys_with_sparse_b_arrays_sum_b1_and_b2_over_a_masked_plan(n):
     assert same(groth16.finish(pk, parallel.combine_partials(parts, groth16.SUM_IS_G2), r, s))
 
 
+@pytest.mark.parametrize("finite", ["none", "one", "54%", "56%", "all"])
+def test_b_mask_edge_densities(finite):
+    """The masked plan at its edges: a key whose B arrays hold NO finite point (the masked plan is empty: every kernel behind it sees zero
+    entries), exactly one, a share just below and just above the 55 % threshold, all of them.  Bases are k_i G, so each of the four sums
+    over w has the closed form (sum_i w_i k_i) G whatever plan carried it; gs_timing says which plan did."""
+    n, npub = 5000, 1
+    rng = np.random.Generator(np.random.PCG64(77))
+    ks = {name: U.rand_scalars_u64(n, 9300 + j) for j, name in enumerate(("at", "b", "cd", "ptd"))}
+    keep = {"none": np.zeros(n, bool), "one": np.arange(n) == 1234, "54%": rng.random(n) < 0.54, "56%": rng.random(n) < 0.56,
+            "all": np.ones(n, bool)}[finite]
+    ks["b"][~keep] = (0, 0, 0, 0)                                   # k = 0: the point at infinity in G1.BACGamma AND G2.BACGamma
+    share = keep.mean()
+    at, b1, b2, cd, ptd = (capi.g1_fixed_base(ks["at"]), capi.g1_fixed_base(ks["b"]), capi.g2_fixed_base(ks["b"]), capi.g1_fixed_base(ks["cd"]),
+                           capi.g1_fixed_base(ks["ptd"]))
+    g = lambda k: C.g1_mul_scalar(O.G1_GEN, k)                       # noqa: E731
+    z = U.rand_scalars_u64(n + 1, 9310)
+    pk = groth16.device_pk_from_handles(at, b1, b2, cd, ptd, g(3), g(5), g(7), C.g2_mul_scalar(O.G2_GEN, 5), C.g2_mul_scalar(O.G2_GEN, 7), z, n, npub)
+    w_host, px_host = U.rand_scalars_u64(n, 9320), U.rand_scalars_u64(2 * n - 1, 9321)
+    w, px = capi.scalars_upload(w_host), capi.scalars_upload(px_host)
+    sums, _ = groth16.prove_partials(pk, w, px, 0, 1)
+    tm = capi.last_timing()
+    wi = U.u64_rows_to_ints(w_host)
+    dot = lambda name, lo=0: sum(a * k for a, k in zip(wi[lo:], U.u64_rows_to_ints(ks[name])[lo:])) % O.R     # noqa: E731
+    aff1 = lambda k: C.g1_affine(C.g1_mul_scalar(O.G1_GEN, k)) if k else None                                      # noqa: E731
+    assert sums[0] == aff1(dot("at")) and sums[1] == aff1(dot("b")) and sums[3] == aff1(dot("cd", npub + 1))
+    assert sums[2] == (C.g2_affine(C.g2_mul_scalar(O.G2_GEN, dot("b"))) if dot("b") else None)
+    assert (sums[1] is None) == (finite == "none")
+    windows = 254 // tm["window_bits"] + 1
+    if share < 0.55:                  # B1 / B2 ran over the masked plan: as many G2 additions as the share of finite points
+        assert tm["acc_g2_adds"] <= (share + 0.01) * windows * n + windows, (finite, tm["acc_g2_adds"])
+    else:
+        assert tm["acc_g2_adds"] > 0.9 * windows * n
+    # term ranges: three shards of the key (the mask is read at the shard's offset)
+    parts = [groth16.prove_partials(pk, w, px, k, 3)[0] for k in range(3)]
+    from gosnark_amd import parallel
+    assert parallel.combine_partials(parts, groth16.SUM_IS_G2) == sums
+
+
 @pytest.mark.parametrize("n", [3000, (1 << 14) + 1])
 def test_pinocchio_keys_with_sparse_b_arrays(n):
     """The same for snark.GenerateProofs: B (G2) and B' over the masked plan, the five other G1 sums over w's.  snark.VerifyProof's five
