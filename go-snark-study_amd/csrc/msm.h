@@ -83,9 +83,10 @@ struct LaunchShape { int njobs; bool g2; };
 // scalars_dev: n x 8 u32 words (standard form, any 256-bit value).  slot: 0..3 (four plans may be alive).  `users`: the
 // launches that will run on this plan (decides the chunk size: whole wave rounds for every one of them).
 // cbits: the width prepare_tables chose; table_free: its route.
-// term_mask / mask_off: bit (mask_off + i) clear drops term i from the plan (see k_digits); window widths below 19 only.
+// term_index / index_bias: the plan's n terms are terms term_index[i] - index_bias of the scalar vector and of the base arrays
+// (see k_digits); window widths below 19 only.
 void build_plan(Ctx& c, int slot, const uint32_t* scalars_dev, uint32_t n, MsmPlan& plan, const std::vector<LaunchShape>& users, int cbits = 0,
-                bool table_free = false, const uint32_t* term_mask = nullptr, uint32_t mask_off = 0);
+                bool table_free = false, const uint32_t* term_index = nullptr, uint32_t index_bias = 0);
 // which points of one or two packed-affine arrays are finite: mask (ceil(n / 32) words, written) and their number (synchronises the stream)
 uint32_t finite_mask_dev(Ctx& c, const uint32_t* g1_pts, const uint32_t* g2_pts, uint32_t n, uint32_t* mask_dev);
 

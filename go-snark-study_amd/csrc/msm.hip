@@ -103,7 +103,7 @@ uint32_t finite_mask_dev(Ctx& c, const uint32_t* g1_pts, const uint32_t* g2_pts,
 }
 
 void build_plan(Ctx& c, int slot, const uint32_t* scalars_dev, uint32_t n, MsmPlan& plan, const std::vector<LaunchShape>& users, int cbits,
-                bool table_free, const uint32_t* term_mask, uint32_t mask_off) {
+                bool table_free, const uint32_t* term_index, uint32_t index_bias) {
   MsmState& ms = msm_state(c);
   PlanBuffers& pb = ms.plan_slots[slot % (3 * Ctx::kSlots)];
   plan.n = n;
@@ -139,7 +139,7 @@ void build_plan(Ctx& c, int slot, const uint32_t* scalars_dev, uint32_t n, MsmPl
   // cheaper than writing and re-reading 8-byte records
   static const uint32_t part_min_r = (uint32_t)dev_knob("GS_PART_MIN_R", 4, 2, 64);
   const bool wide = pp.R >= part_min_r;
-  if (wide && term_mask) throw HipError{hipErrorInvalidValue, "masked plans need a window width below 19", __LINE__};
+  if (wide && term_index) throw HipError{hipErrorInvalidValue, "plans over a term list need a window width below 19", __LINE__};
   const uint32_t nparts = (uint32_t)plan.W * pp.R;
   if (wide && nparts > kMaxParts) throw HipError{hipErrorInvalidValue, "too many (window, range) partitions", __LINE__};
   if (!wide) pb.digits.ensure((size_t)std::max<uint32_t>(pp.stride, 64u) * plan.W * sizeof(digit_t));
@@ -177,7 +177,7 @@ void build_plan(Ctx& c, int slot, const uint32_t* scalars_dev, uint32_t n, MsmPl
     hipLaunchKernelGGL(k_hist_part, dim3(8 * pp.S * ((nparts + 7) / 8)), dim3(sort_block), lds, c.stream, pb.recs.as<uint2>(), part_base, pp, pb.hist.as<uint32_t>());
     hipLaunchKernelGGL(k_colscan, grid1(plan.B), dim3(256), 0, c.stream, pb.hist.as<uint32_t>(), pp, pb.totals.as<uint32_t>());
   } else if (n > 0) {
-    hipLaunchKernelGGL(k_digits, grid1(n), dim3(256), 0, c.stream, scalars_dev, pp, pb.digits.as<digit_t>(), term_mask, mask_off);
+    hipLaunchKernelGGL(k_digits, grid1(n), dim3(256), 0, c.stream, scalars_dev, pp, pb.digits.as<digit_t>(), term_index, index_bias);
     hipLaunchKernelGGL(k_hist, dim3(plan.W, pp.S, pp.R), dim3(sort_block), lds, c.stream, pb.digits.as<digit_t>(), pp, pb.hist.as<uint32_t>());
     if (table_free) hipLaunchKernelGGL(k_colscan_windows, grid1(plan.nbuckets), dim3(256), 0, c.stream, pb.hist.as<uint32_t>(), pp, pb.totals.as<uint32_t>());
     else hipLaunchKernelGGL(k_colscan, grid1(plan.B), dim3(256), 0, c.stream, pb.hist.as<uint32_t>(), pp, pb.totals.as<uint32_t>());
@@ -189,7 +189,7 @@ void build_plan(Ctx& c, int slot, const uint32_t* scalars_dev, uint32_t n, MsmPl
     if (wide) hipLaunchKernelGGL(k_scatter_part, dim3(8 * pp.S * ((nparts + 7) / 8)), dim3(sort_block), lds, c.stream, pb.recs.as<uint2>(), part_base, pp,
                                  pb.hist.as<uint32_t>(), pb.offsets.as<uint32_t>(), pb.entries.as<uint32_t>());
     else hipLaunchKernelGGL(k_scatter, dim3(plan.W, pp.S, pp.R), dim3(sort_block), lds, c.stream, pb.digits.as<digit_t>(), pp, pb.hist.as<uint32_t>(),
-                            pb.offsets.as<uint32_t>(), pb.entries.as<uint32_t>());
+                            pb.offsets.as<uint32_t>(), pb.entries.as<uint32_t>(), term_index, index_bias);
     hipLaunchKernelGGL(k_chunk_map, grid1(plan.nbuckets), dim3(256), 0, c.stream, pb.offsets.as<uint32_t>(), plan.nbuckets, plan.chunk,
                        pb.chunk_bucket.as<uint32_t>(), pb.heavy_list.as<uint32_t>(), pb.counters.as<uint32_t>());
   }

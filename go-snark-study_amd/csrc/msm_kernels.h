@@ -59,22 +59,17 @@ GS_HD int32_t next_digit(const uint32_t (&k)[8], const PlanParams& pp, int w, ui
 
 // ---- plan, step 1: scalars -> digit matrix digits[w][i] = d + B - 1, read once, coalesced ------------------------
 using digit_t = uint32_t;
-// term_mask (optional): bit (mask_off + i) clear = term i does not take part in this plan (its base points are the point at infinity
-// in every array the plan is for: prove.h, GrothPkObj::b_mask) -- all its digits are written as zero and it never reaches a bucket.
+// term_index (optional): the plan covers only the listed terms -- compact term i of the plan is term term_index[i] - index_bias of the
+// scalar vector (and of the base arrays: k_scatter writes that id into the entries).  For keys with sparse B arrays (prove.h,
+// GrothPkObj::b_index): the terms whose base points are the point at infinity never enter the digit matrix.
 __global__ void __launch_bounds__(256) k_digits(const uint32_t* __restrict__ scalars, PlanParams pp, digit_t* __restrict__ digits,
-                                                 const uint32_t* __restrict__ term_mask, uint32_t mask_off) {
+                                                 const uint32_t* __restrict__ term_index, uint32_t index_bias) {
   wave_priority<GS_PRIO_PLAN>();
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= pp.n) return;
-  if (term_mask) {
-    const uint32_t bit = mask_off + i;
-    if (((term_mask[bit >> 5] >> (bit & 31u)) & 1u) == 0u) {
-      for (int w = 0; w < pp.W; ++w) digits[(size_t)w * pp.stride + i] = (digit_t)(pp.B - 1u);
-      return;
-    }
-  }
+  const uint32_t src = term_index ? term_index[i] - index_bias : i;
   uint32_t k[8];
-  const uint4* s4 = reinterpret_cast<const uint4*>(scalars + (size_t)i * 8);
+  const uint4* s4 = reinterpret_cast<const uint4*>(scalars + (size_t)src * 8);
   uint4 lo = s4[0], hi = s4[1];
   k[0] = lo.x; k[1] = lo.y; k[2] = lo.z; k[3] = lo.w; k[4] = hi.x; k[5] = hi.y; k[6] = hi.z; k[7] = hi.w;
   scalar_canon(k);
@@ -157,7 +152,8 @@ __global__ void __launch_bounds__(256) k_colscan_windows(uint32_t* __restrict__ 
 // ---- plan, step 4: counting-sort scatter; the cursors of the workgroup's bucket range live in LDS -------------------
 // entry = sign (bit 31) | window (bits 30..26) | term index (bits 25..0)
 __global__ void __launch_bounds__(kSortBlock) k_scatter(const digit_t* __restrict__ digits, PlanParams pp, const uint32_t* __restrict__ hist,
-                                                         const uint32_t* __restrict__ offsets, uint32_t* __restrict__ entries) {
+                                                         const uint32_t* __restrict__ offsets, uint32_t* __restrict__ entries,
+                                                         const uint32_t* __restrict__ term_index, uint32_t index_bias) {
   wave_priority<GS_PRIO_PLAN>();
   extern __shared__ uint32_t sh[];
   const uint32_t w = blockIdx.x, s = blockIdx.y, r = blockIdx.z;
@@ -175,7 +171,8 @@ __global__ void __launch_bounds__(kSortBlock) k_scatter(const digit_t* __restric
       const uint32_t b = (uint32_t)(d < 0 ? -d : d) - 1u;
       if ((b >> kRangeLog) == r) {
         const uint32_t pos = atomicAdd(&sh[b - base], 1u);
-        entries[pos] = i | (w << kWindowShift) | (d < 0 ? kSignBit : 0u);
+        const uint32_t id = term_index ? term_index[i] - index_bias : i;       // (k_digits: the plan's compact term i)
+        entries[pos] = id | (w << kWindowShift) | (d < 0 ? kSignBit : 0u);
       }
     }
   }

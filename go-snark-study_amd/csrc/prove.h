@@ -1,5 +1,6 @@
 // Internal: device-resident proving keys and the prover drivers (implemented in prove.hip).
 #pragma once
+#include <vector>
 #include <mutex>
 #include "msm.h"
 #include "poly.h"
@@ -32,14 +33,17 @@ struct GrothPkObj : Object {      // groth16.Pk (groth16/groth16.go:15-32), resi
   BaseTable t_ptd_eval;
   // Which of the held variables appear in B at all (round 5).  The reference's circuit compiler puts a variable into B only as the
   // second operand of a multiplication or a divisor (circuitcompiler/circuit.go:110-128: `+` / `-` / `in` rows have B = [one]), so for
-  // its circuits most G1.BACGamma / G2.BACGamma points are the point at infinity.  b_mask has one bit per held variable (set: either
-  // point is finite), b_finite their number: when enough are missing the prover sums B1 and B2 -- 3.8 of a proof's 6.8 job-units --
-  // over a SECOND plan of w that leaves the missing terms out (prove.hip, groth16_enqueue).  Scanned once, when the key is created.
-  DevBuf b_mask;
+  // its circuits most G1.BACGamma / G2.BACGamma points are the point at infinity.  b_index lists the held variables of which either
+  // point is finite (ascending, relative to the first held variable; on the device and on the host, where a call cuts its term range out
+  // of it), b_finite is their number: when enough are missing the prover sums B1 and B2 -- 3.8 of a proof's 6.8 job-units -- over a
+  // SECOND plan of w that holds the listed terms only (prove.hip, groth16_enqueue).  Scanned once, when the key is created; keys
+  // without a missing point keep no list.
+  DevBuf b_index;
+  std::vector<uint32_t> b_index_host;
   size_t b_finite = 0;
   GrothPkObj() : Object(Kind::GrothPk) {}
 };
-void groth_pk_scan_sparsity(Ctx& c, GrothPkObj& pk);      // fills b_mask / b_finite (synchronises the stream)
+void groth_pk_scan_sparsity(Ctx& c, GrothPkObj& pk);      // fills b_index / b_finite (synchronises the stream)
 
 struct PinocchioPkObj : Object {  // snark.Pk (snark.go:16-26), resident
   size_t nvars = 0, npublic = 0, nz = 0, ng1t = 0;      // global counts (ng1t = len(G1T))
@@ -54,8 +58,9 @@ struct PinocchioPkObj : Object {  // snark.Pk (snark.go:16-26), resident
   size_t n_eval = 0, e_lo = 0, n_e = 0;     // a slice holds entries [e_lo, e_lo + n_e)
   DevBuf g1t_eval;
   BaseTable t_g1t_eval;
-  // which held variables appear in B (as GrothPkObj::b_mask): B (G2) and B' (G1) of a reference-style circuit are mostly infinity
-  DevBuf b_mask;
+  // which held variables appear in B (as GrothPkObj::b_index): B (G2) and B' (G1) of a reference-style circuit are mostly infinity
+  DevBuf b_index;
+  std::vector<uint32_t> b_index_host;
   size_t b_finite = 0;
   PinocchioPkObj() : Object(Kind::PinocchioPk) {}
 };

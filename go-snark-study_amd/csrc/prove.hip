@@ -152,6 +152,14 @@ struct HostInputs {
   ~HostInputs() { for (hipEvent_t e : {w_done, px_done}) if (e) (void)hipEventDestroy(e); }
 };
 
+// the part of a term list that falls into the held range [base, base + nterms): pointer into the device list and count
+static const uint32_t* term_list_range(const DevBuf& index_dev, const std::vector<uint32_t>& index_host, size_t base, size_t nterms, uint32_t& count) {
+  const auto lo = std::lower_bound(index_host.begin(), index_host.end(), (uint32_t)base);
+  const auto hi = std::lower_bound(lo, index_host.end(), (uint32_t)(base + nterms));
+  count = (uint32_t)(hi - lo);
+  return index_dev.as<uint32_t>() + (lo - index_host.begin());
+}
+
 struct GrothInFlight : InFlightBase {
   GrothPkObj* pk = nullptr;
   ProofStreams streams;
@@ -162,7 +170,7 @@ struct GrothInFlight : InFlightBase {
   // done_g2 / done_g1w / done_h: one per MSM group, recorded behind that group's reduction tail, so the host can add up a
   // group's partial sums while the later groups are still on the device
   hipEvent_t planw = nullptr, planh = nullptr, done_main = nullptr, done_g2 = nullptr, done_g1w = nullptr, done_h = nullptr;
-  // keys with sparse B arrays (prove.h, b_mask): B1 and B2 run over a masked plan of their own; pend_g1w then carries At and BACDelta
+  // keys with sparse B arrays (prove.h, b_index): B1 and B2 run over a plan over the listed terms of their own; pend_g1w then carries At and BACDelta
   // only and pend_g1b the sum over G1.BACGamma
   bool split_b = false;
   hipEvent_t planb = nullptr, done_g1b = nullptr;
@@ -243,7 +251,7 @@ int groth16_enqueue(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, const S
     GS_HIP(hipStreamWaitEvent(ps.planw, w.host_done, 0));
     if (ps.poly != ps.planw) GS_HIP(hipStreamWaitEvent(ps.poly, w.host_done, 0));
   }
-  // Sparse B (prove.h, b_mask): when fewer than 55 % of the key's variables have a B entry, B1 and B2 are summed over a second plan of
+  // Sparse B (prove.h, b_index): when fewer than 55 % of the key's variables have a B entry, B1 and B2 are summed over a second plan of
   // w without the others -- one more sort (~0.35 ms at 2^20) against that share of 3.8 of the proof's 6.8 job-units.  Measured at 2^20
   // (profiles/r05_ab_sparse_b_split.txt): a circuit of the reference compiler's shape (33 % of the variables in B, full-width witness)
   // 8.3-8.4 -> 6.1-6.2 ms per proof in flight, 8.8 -> 6.9 blocking, witness route 9.15 -> 7.2; the realistic-witness instance (60 % in
@@ -251,14 +259,15 @@ int groth16_enqueue(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, const S
   // widths of 19 and more -- only by gs_set_window_bits -- keep the single plan: their partition-first sort has no mask.)
   static const long split_pct = run_knob("GS_SPLIT_B_PERCENT", 55, 0, 100);      // split below this share of finite B points; 0 = never (same results)
   const size_t nterms_w = whi - wlo;
-  st.split_b = pk->b_mask.p != nullptr && nterms_w >= 4096 && cw < 19 && pk->b_finite * 100 < (size_t)split_pct * pk->n_w;
+  st.split_b = pk->b_index.p != nullptr && nterms_w >= 4096 && cw < 19 && pk->b_finite * 100 < (size_t)split_pct * pk->n_w;
   MsmPlan plan_b;
-  {                                                              // aux 1 (or aux 2, proof_streams): plan(w) [, the masked plan for B first: G2 starts the proof]
+  {                                                              // aux 1 (or aux 2, proof_streams): plan(w) [, the plan over the listed terms for B first: G2 starts the proof]
     StreamScope sc(c, ps.planw);
     if (st.split_b) {
       st.tplanb = std::make_shared<PhaseTimer>(c.stream);
-      build_plan(c, 2 * Ctx::kSlots + parity, w.p + wlo * 8, (uint32_t)nterms_w, plan_b, {{1, true}, {1, false}}, cw, !tab_w, pk->b_mask.as<uint32_t>(),
-                 (uint32_t)wbase);
+      uint32_t nb = 0;                                             // the listed terms of this call's range only
+      const uint32_t* list = term_list_range(pk->b_index, pk->b_index_host, wbase, nterms_w, nb);
+      build_plan(c, 2 * Ctx::kSlots + parity, w.p + wlo * 8, nb, plan_b, {{1, true}, {1, false}}, cw, !tab_w, list, (uint32_t)wbase);
       st.tplanb->stop();
       GS_HIP(hipEventRecord(st.planb, c.stream));
     }
@@ -500,7 +509,7 @@ struct PinInFlight : InFlightBase {
   ProofStreams streams;
   HostInputs in;
   hipEvent_t planw = nullptr, planh = nullptr, done_main = nullptr, done_g2 = nullptr, done_g1w = nullptr, done_h = nullptr;   // as GrothInFlight
-  bool split_b = false;                                     // as GrothInFlight: B (G2) and B' over the masked plan, the five other G1 sums over w's
+  bool split_b = false;                                     // as GrothInFlight: B (G2) and B' over the plan over the listed terms, the five other G1 sums over w's
   hipEvent_t planb = nullptr, done_g1b = nullptr;
   MsmPending pend_g1b;
   std::shared_ptr<PhaseTimer> tplanb;
@@ -568,14 +577,15 @@ int pinocchio_enqueue(Ctx& c, PinocchioPkObj* pk, DevScalars w, DevScalars px, c
   }
   static const long split_pct = run_knob("GS_SPLIT_B_PERCENT", 55, 0, 100);      // as groth16_enqueue
   const size_t nterms_w = whi - wlo;
-  st.split_b = pk->b_mask.p != nullptr && nterms_w >= 4096 && cw < 19 && pk->b_finite * 100 < (size_t)split_pct * pk->n_w;
+  st.split_b = pk->b_index.p != nullptr && nterms_w >= 4096 && cw < 19 && pk->b_finite * 100 < (size_t)split_pct * pk->n_w;
   MsmPlan plan_b;
-  {                                                              // aux 1 (or its own stream, proof_streams): [the masked plan for B, B',] plan(w)
+  {                                                              // aux 1 (or its own stream, proof_streams): [the plan over the listed terms for B, B',] plan(w)
     StreamScope sc(c, ps.planw);
     if (st.split_b) {
       st.tplanb = std::make_shared<PhaseTimer>(c.stream);
-      build_plan(c, 2 * Ctx::kSlots + parity, w.p + wlo * 8, (uint32_t)nterms_w, plan_b, {{1, true}, {1, false}}, cw, !tab_w, pk->b_mask.as<uint32_t>(),
-                 (uint32_t)wbase);
+      uint32_t nb = 0;                                             // the listed terms of this call's range only
+      const uint32_t* list = term_list_range(pk->b_index, pk->b_index_host, wbase, nterms_w, nb);
+      build_plan(c, 2 * Ctx::kSlots + parity, w.p + wlo * 8, nb, plan_b, {{1, true}, {1, false}}, cw, !tab_w, list, (uint32_t)wbase);
       st.tplanb->stop();
       GS_HIP(hipEventRecord(st.planb, c.stream));
     }
@@ -783,14 +793,35 @@ void mark_ticket_reads(const ProofStreams& ps, Scalars* w, Scalars* px_or_hv) {
 
 }  // namespace
 
+// the list of the variables with a finite point in either array: the device scans (one bit per variable), the host turns the bits
+// into the ascending index list and uploads it
+static size_t scan_finite_terms(Ctx& c, const uint32_t* g1_pts, const uint32_t* g2_pts, size_t n, DevBuf& index_dev, std::vector<uint32_t>& index_host) {
+  index_host.clear();
+  index_dev.release();
+  if (n == 0) return 0;
+  const size_t words = (n + 31) / 32;
+  DevBuf mask(words * 4);
+  const size_t finite = finite_mask_dev(c, g1_pts, g2_pts, (uint32_t)n, mask.as<uint32_t>());
+  if (finite == n) return finite;                        // nothing missing: no list, no second plan
+  std::vector<uint32_t> bits(words);
+  GS_HIP(hipMemcpyAsync(bits.data(), mask.p, words * 4, hipMemcpyDeviceToHost, c.stream));
+  GS_HIP(hipStreamSynchronize(c.stream));
+  index_host.reserve(finite);
+  for (size_t wd = 0; wd < words; ++wd)
+    for (uint32_t m = bits[wd]; m; m &= m - 1) index_host.push_back((uint32_t)(wd * 32 + (size_t)__builtin_ctz(m)));
+  index_dev.alloc(std::max<size_t>(index_host.size(), 1) * 4);
+  if (!index_host.empty()) {
+    GS_HIP(hipMemcpyAsync(index_dev.p, index_host.data(), index_host.size() * 4, hipMemcpyHostToDevice, c.stream));
+    GS_HIP(hipStreamSynchronize(c.stream));
+  }
+  return finite;
+}
 void gs::groth_pk_scan_sparsity(Ctx& c, GrothPkObj& pk) {
-  pk.b_mask.alloc(std::max<size_t>((pk.n_w + 31) / 32, 1) * 4);
-  pk.b_finite = finite_mask_dev(c, pk.bacgamma1.as<uint32_t>(), pk.bacgamma2.as<uint32_t>(), (uint32_t)pk.n_w, pk.b_mask.as<uint32_t>());
+  pk.b_finite = scan_finite_terms(c, pk.bacgamma1.as<uint32_t>(), pk.bacgamma2.as<uint32_t>(), pk.n_w, pk.b_index, pk.b_index_host);
 }
 
 void gs::pinocchio_pk_scan_sparsity(Ctx& c, PinocchioPkObj& pk) {
-  pk.b_mask.alloc(std::max<size_t>((pk.n_w + 31) / 32, 1) * 4);
-  pk.b_finite = finite_mask_dev(c, pk.bp.as<uint32_t>(), pk.b2.as<uint32_t>(), (uint32_t)pk.n_w, pk.b_mask.as<uint32_t>());
+  pk.b_finite = scan_finite_terms(c, pk.bp.as<uint32_t>(), pk.b2.as<uint32_t>(), pk.n_w, pk.b_index, pk.b_index_host);
 }
 
 extern "C" {

@@ -1231,7 +1231,7 @@ def test_complete_pinocchio_proof_on_a_known_quotient_equals_the_golden_from_out
 def test_keys_with_sparse_b_arrays_sum_b1_and_b2_over_a_masked_plan(n):
     """Round 5: the reference's circuit compiler puts a signal into B only as the second operand of a product
     (circuitcompiler/circuit.go:110-128), so two thirds of the G1/G2.BACGamma points of such a key are the point at infinity.  From 4096
-    variables on the prover sums B1 and B2 over a second plan of w that leaves those variables out (GrothPkObj::b_mask): same proof --
+    variables on the prover sums B1 and B2 over a second plan of w that leaves those variables out (GrothPkObj::b_index: a second plan over the terms with a finite B point): same proof --
     pinned by the closed form of the setup's toxic values and the verifier -- on every entry route, with fewer G2 additions."""
     from gosnark_amd import synth
     inst = synth.gates_setup_instance(n, 0x9100 + n % 97)
