@@ -1205,7 +1205,7 @@ def main():
     elif args.workload == "prove_pinocchio":
         # snark.GenerateProofs (snark.go:254-289): 6 G1 MSMs over w sharing one plan + 1 G2 MSM + px / Z + 1 G1 MSM over h
         from gosnark_amd import snark
-        inst = synth.sqchain_pinocchio_instance(n, seed)
+        inst = synth.gates_pinocchio_instance(n, seed) if args.instance == "gates" else synth.sqchain_pinocchio_instance(n, seed)
         pk = inst.device_pk()
 
         def step():

@@ -476,7 +476,7 @@ class SqchainPinocchioInstance:
 
 
 class GatesPinocchioInstance(SqchainPinocchioInstance):
-    """gates_r1cs under the Pinocchio protocol: B (G2) and B' of its key are mostly the point at infinity (PinocchioPkObj::b_mask)."""
+    """gates_r1cs under the Pinocchio protocol: B (G2) and B' of its key are mostly the point at infinity (PinocchioPkObj::b_index)."""
 
     def __init__(self, n, seed, mul_share=0.5):
         from . import r1csqap, snark
@@ -490,6 +490,11 @@ class GatesPinocchioInstance(SqchainPinocchioInstance):
         self.w = capi.scalars_upload(self.w_host)
         self.px = capi.scalars_upload(self.px_host)
         self.public = capi.u64_to_ints(self.w_host[1:2])
+
+    def describe(self):
+        return ("flattened * / + gates in the shape of the reference's circuit compiler (%d of %d variables in B), satisfying witness, "
+                "Pinocchio trusted setup on the device from seeded toxic values, px from the sparse system; seed 0x%X"
+                % (self.counts["variables_in_B"], self.counts["variables"], self.seed))
 
 
 def gates_pinocchio_instance(n, seed, mul_share=0.5):
