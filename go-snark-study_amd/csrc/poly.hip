@@ -547,7 +547,7 @@ void hx_from_values_dev(Ctx& c, const uint32_t* hv_std, size_t n, size_t dz, uin
 // r1csqap.go:70-84).  hx_out: nh = 2n - 1 - dz coefficients, canonical standard form.
 bool hx_direct_dev(Ctx& c, const uint32_t* vals_std, size_t n, size_t dz, uint32_t* hx_out) {
   if (!hx_shape_ok(n, dz)) return false;
-  PolyState::HxTables& hx = hx_tables(c, n, dz);
+  (void)hx_tables(c, n, dz);                            // makes the cached spectra and the shared workspaces (hx_bad, hx_hv) exist
   uint32_t nbad = 0;                                    // the flag word lives with the tables: no allocation on the per-proof path
   r1cs_check_dev(c, vals_std, n, dz, poly_state(c).hx_bad.as<uint32_t>());
   GS_HIP(hipMemcpyAsync(&nbad, poly_state(c).hx_bad.p, 4, hipMemcpyDeviceToHost, c.stream));
