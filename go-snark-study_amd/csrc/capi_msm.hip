@@ -84,7 +84,8 @@ int msm_resident(Ctx& c, Kind kind, gs_handle hb, size_t off, const uint32_t* sc
   if (!b->table) b->table = std::make_shared<BaseTable>();
   BaseTable* tab = static_cast<BaseTable*>(b->table.get());
   int cbits = 0;
-  const bool tabled = prepare_tables(c, {TableRef{tab, b->buf.as<uint32_t>(), b->n, T::kWords == 16}}, (uint32_t)n, &cbits);
+  double credit = kBuildCreditPerUnitTerm * (T::kWords == 16 ? 2.76 : 1.0) * (double)n;      // policy auto: this call's instalment of the array's table
+  const bool tabled = prepare_tables(c, {TableRef{tab, b->buf.as<uint32_t>(), b->n, T::kWords == 16}}, (uint32_t)n, &cbits, &credit);
   PhaseTimer total(c.stream);
   MsmPlan plan;
   {
@@ -136,7 +137,8 @@ int msm_begin(Ctx& c, Kind kind, gs_handle hb, size_t off, gs_handle hs, size_t 
   if (!b->table) b->table = std::make_shared<BaseTable>();
   BaseTable* tab = static_cast<BaseTable*>(b->table.get());
   int cbits = 0;
-  const bool tabled = prepare_tables(c, {TableRef{tab, b->buf.as<uint32_t>(), b->n, T::kWords == 16}}, (uint32_t)n, &cbits);
+  double credit = kBuildCreditPerUnitTerm * (T::kWords == 16 ? 2.76 : 1.0) * (double)n;      // policy auto: this call's instalment of the array's table
+  const bool tabled = prepare_tables(c, {TableRef{tab, b->buf.as<uint32_t>(), b->n, T::kWords == 16}}, (uint32_t)n, &cbits, &credit);
   auto st = std::make_unique<MsmInFlight>();
   st->g2 = T::kWords == 16;
   st->keep = {c.share<Object>(hb, kind), c.share<Object>(hs, Kind::Scalars)};

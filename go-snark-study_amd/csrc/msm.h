@@ -44,12 +44,20 @@ struct BaseTable {
   size_t n = 0;
   int c = 0, W = 0;
   uint64_t last_use = 0;           // Ctx::call_clock of the last call that used the array (LRU order of evict_tables_for)
+  uint64_t last_table_use = 0;     // ... of the last call that summed it over its TABLE: under policy auto a table that serves is not
+                                   //     replaced by one of another width just because one call wanted that width
   uint32_t uses = 0;               // proofs / MSMs that found no table since it last had one (table policy auto)
-  // a build in the background (table policy auto): complete when `pending_done` has fired, installed by the next call that looks
+  // A build under policy auto (round 6: in instalments).  `pending` holds the rows of the table to be; every call that finds the
+  // array without its table enqueues the next slabs of points [pending_next, ...) on the accumulation stream, as many as its build
+  // credit pays for (msm.hip, prepare_tables), and the call that enqueues the last slab installs the table: its accumulation kernel
+  // runs behind the slabs on the same stream.
   DevBuf pending;
   int pending_c = 0;
-  size_t pending_n = 0;
-  hipEvent_t pending_done = nullptr;
+  size_t pending_n = 0, pending_next = 0;
+  const uint32_t* pending_src = nullptr;      // row 0 (the base array: lives as long as the object that owns this table)
+  bool pending_g2 = false;
+  hipEvent_t pending_done = nullptr;          // recorded behind the last slab
+  bool pending_complete() const { return pending.p != nullptr && pending_next >= pending_n; }
   bool ready(size_t n_, int c_) const { return rows.p != nullptr && n == n_ && c == c_; }
   void drop() { rows.release(); n = 0; c = 0; W = 0; }
   BaseTable() = default;
@@ -65,10 +73,18 @@ void ensure_table_g2(Ctx& c, BaseTable& t, const uint32_t* row0, size_t n, int c
 // The base arrays one plan will be multiplied with (a proof's At / BACGamma / BACDelta / BACGamma2 over w; one array for an MSM).
 struct TableRef { BaseTable* t; const uint32_t* row0; size_t n; bool g2; };
 // Decides how the group is summed THIS time and prepares it: true = window tables, all of width *cbits and resident (built now
-// under policy `always`, or found); false = table-free with *cbits from choose_window_bits_free -- and, under policy `auto`, the
-// tables are built in the background once the arrays have been used twice.  Stamps the tables for the LRU.
-bool prepare_tables(Ctx& c, const std::vector<TableRef>& group, uint32_t nterms, int* cbits);
-// wait for / drop a background build (gs_release_tables, gs_build_tables)
+// under policy `always`, or found); false = table-free with *cbits from choose_window_bits_free.  Under policy `auto` an array that
+// has been used twice gets its table IN INSTALMENTS: every call enqueues, in front of its own accumulations, as many slabs of the
+// pending table as `*credit` pays for (in G1-point builds; a G2 point costs kG2BuildCost of them; the caller grants ~0.06 points per
+// (job-unit x term) of its own work, i.e. a proof pays ~80 % of its own table-free time on top) and takes what it spent off
+// *credit.  Stamps the tables for the LRU.
+constexpr double kG2BuildCost = 2.3;              // a G2 row costs 2.3 G1 rows (45 vs 20 ms per 2^20 points)
+constexpr double kBuildCreditPerUnitTerm = 0.06;  // 20 ms per 2^20 G1 points built / 1.5 ms per 2^20 (job-unit x term) summed table-free: 0.06 -> +80 %
+bool prepare_tables(Ctx& c, const std::vector<TableRef>& group, uint32_t nterms, int* cbits, double* credit = nullptr);
+// the tables one call will use, stamped for the LRU BEFORE any of them is built: an allocation made while the first group's tables are
+// built must not evict the second group's (prepare_tables only stamped the group it was called for)
+void stamp_tables(Ctx& c, std::initializer_list<BaseTable*> tables);
+// wait for a pending build and install it (finishing it first if instalments are missing) or drop it (gs_release_tables, gs_build_tables)
 void table_settle(Ctx& c, BaseTable& t, bool install);
 
 struct MsmBase {                 // one job of an MSM launch
@@ -87,6 +103,9 @@ struct LaunchShape { int njobs; bool g2; };
 // (see k_digits); window widths below 19 only.
 void build_plan(Ctx& c, int slot, const uint32_t* scalars_dev, uint32_t n, MsmPlan& plan, const std::vector<LaunchShape>& users, int cbits = 0,
                 bool table_free = false, const uint32_t* term_index = nullptr, uint32_t index_bias = 0);
+// true when build_plan sorts a plan of this width partition-first (>= GS_PART_MIN_R bucket ranges of 2^15, i.e. c >= 18 as shipped):
+// that sort takes no term list, so callers that would hand build_plan one (the sparse-B plans of prove.hip) must ask first
+bool plan_partitions_first(int cbits);
 // which points of one or two packed-affine arrays are finite: mask (ceil(n / 32) words, written) and their number (synchronises the stream)
 uint32_t finite_mask_dev(Ctx& c, const uint32_t* g1_pts, const uint32_t* g2_pts, uint32_t n, uint32_t* mask_dev);
 

@@ -88,6 +88,17 @@ static uint32_t choose_chunk(uint64_t entries, uint32_t nbuckets, const std::vec
   return chunk;
 }
 
+// R >= 4 bucket ranges: partition by (window, range) first (msm_kernels.h); with two ranges reading the digit matrix twice is
+// cheaper than writing and re-reading 8-byte records
+static uint32_t part_min_ranges() {
+  static const uint32_t v = (uint32_t)dev_knob("GS_PART_MIN_R", 4, 2, 64);
+  return v;
+}
+bool plan_partitions_first(int cbits) {
+  if (cbits < 1) return false;
+  return std::max<uint32_t>(1u, (1u << (cbits - 1)) >> kRangeLog) >= part_min_ranges();
+}
+
 uint32_t finite_mask_dev(Ctx& c, const uint32_t* g1_pts, const uint32_t* g2_pts, uint32_t n, uint32_t* mask_dev) {
   const size_t words = ((size_t)n + 31) / 32;
   GS_HIP(hipMemsetAsync(mask_dev, 0, std::max<size_t>(words, 1) * 4, c.stream));
@@ -135,11 +146,8 @@ void build_plan(Ctx& c, int slot, const uint32_t* scalars_dev, uint32_t n, MsmPl
   }
   pp.slice = (n + pp.S - 1) / pp.S;
   pp.stride = (n + 63u) & ~63u;
-  // R >= 4 bucket ranges: partition by (window, range) first (msm_kernels.h); with two ranges reading the digit matrix twice is
-  // cheaper than writing and re-reading 8-byte records
-  static const uint32_t part_min_r = (uint32_t)dev_knob("GS_PART_MIN_R", 4, 2, 64);
-  const bool wide = pp.R >= part_min_r;
-  if (wide && term_index) throw HipError{hipErrorInvalidValue, "plans over a term list need a window width below 19", __LINE__};
+  const bool wide = plan_partitions_first(plan.c);         // (= pp.R >= GS_PART_MIN_R)
+  if (wide && term_index) throw HipError{hipErrorInvalidValue, "plans over a term list cannot be sorted partition-first (plan_partitions_first)", __LINE__};
   const uint32_t nparts = (uint32_t)plan.W * pp.R;
   if (wide && nparts > kMaxParts) throw HipError{hipErrorInvalidValue, "too many (window, range) partitions", __LINE__};
   if (!wide) pb.digits.ensure((size_t)std::max<uint32_t>(pp.stride, 64u) * plan.W * sizeof(digit_t));
@@ -201,37 +209,43 @@ void build_plan(Ctx& c, int slot, const uint32_t* scalars_dev, uint32_t n, MsmPl
   plan.heavy_count = pb.counters.as<uint32_t>();
 }
 
-// Enqueue the kernels that fill `fresh` (W rows of n points) from row 0 on `stream`.
-// slab_max: points per launch (2^18 = 1024 workgroups; a background build passes 2^17, see start_background_build).
+// Enqueue the kernels that fill rows [first, last) of every row of `rows` (W rows of n points, allocated) from row 0 on `stream`.
+// slab: points per launch (2^18 = 1024 workgroups).
+template <class T>
+static void enqueue_table_slabs(hipStream_t stream, DevBuf& scratch, const uint32_t* src, size_t n, int cbits, DevBuf& rows, size_t first, size_t last,
+                                size_t slab) {
+  const int W = 254 / cbits + 1;
+  if (first >= last) return;
+  static const bool per_row = dev_flag("GS_TABLE_PER_ROW");               // the one-inversion-per-row builder, for comparison
+  if (per_row || W <= 2) {
+    // (whole table at once: this builder has no range form; only reached with W <= 2, i.e. never for BN254 widths <= 20)
+    if (first == 0) hipLaunchKernelGGL(k_build_table<T>, grid1(n), dim3(256), 0, stream, src, (uint32_t)n, cbits, W, rows.as<uint32_t>());
+  } else {
+    // slabs: (W - 1) rows of [XYZZ | running product] raw limbs per point (<= 1.4 GiB for G2 at 2^18 points), reused per slab
+    constexpr size_t sw = PointIO<T>::kXyzzWords + PointIO<T>::kXyzzWords / 4;
+    slab = std::min<size_t>(std::max<size_t>(slab, 1), n);
+    scratch.ensure(slab * (size_t)(W - 1) * sw * 4);
+    for (size_t at = first; at < last; at += slab) {
+      const size_t count = std::min(slab, last - at);
+      hipLaunchKernelGGL(k_build_table_batched<T>, grid1(count), dim3(256), 0, stream, src, (uint32_t)n, (uint32_t)at, (uint32_t)count, cbits, W,
+                         rows.as<uint32_t>(), scratch.as<uint32_t>());
+    }
+  }
+  GS_HIP(hipGetLastError());
+}
 template <class T>
 static void enqueue_table_build(Ctx& c, hipStream_t stream, DevBuf& scratch, const uint32_t* src, size_t n, int cbits, DevBuf& fresh,
                                 size_t slab_max = (size_t)1 << 18) {
   constexpr size_t aw = PointIO<T>::kAffineWords;
   const int W = 254 / cbits + 1;
   fresh.alloc(std::max<size_t>(n, 1) * W * aw * 4);
-  if (n) {
-    static const bool per_row = dev_flag("GS_TABLE_PER_ROW");               // the one-inversion-per-row builder, for comparison
-    if (per_row || W <= 2) {
-      hipLaunchKernelGGL(k_build_table<T>, grid1(n), dim3(256), 0, stream, src, (uint32_t)n, cbits, W, fresh.as<uint32_t>());
-    } else {
-      // slabs of 2^18 points: (W - 1) rows of [XYZZ | running product] raw limbs per point (<= 1.4 GiB for G2), reused per slab
-      constexpr size_t sw = PointIO<T>::kXyzzWords + PointIO<T>::kXyzzWords / 4;
-      const size_t slab = std::min<size_t>(n, slab_max);
-      scratch.ensure(slab * (size_t)(W - 1) * sw * 4);
-      for (size_t first = 0; first < n; first += slab) {
-        const size_t count = std::min(slab, n - first);
-        hipLaunchKernelGGL(k_build_table_batched<T>, grid1(count), dim3(256), 0, stream, src, (uint32_t)n, (uint32_t)first, (uint32_t)count, cbits, W,
-                           fresh.as<uint32_t>(), scratch.as<uint32_t>());
-      }
-    }
-  }
-  GS_HIP(hipGetLastError());
+  enqueue_table_slabs<T>(stream, scratch, src, n, cbits, fresh, 0, n, slab_max);
 }
 
 template <class T>
 static void ensure_table(Ctx& c, BaseTable& t, const uint32_t* row0, size_t n, int cbits) {
   if (t.c == cbits && t.n == n && t.rows.p) return;
-  table_settle(c, t, false);                    // a background build of another width: superseded
+  table_settle(c, t, false);                    // a pending build of another width: superseded
   const uint32_t* src = row0 ? row0 : t.rows.as<uint32_t>();
   if (!src || (!row0 && t.n != n)) throw HipError{hipErrorInvalidValue, "window table rebuild without its points", __LINE__};
   DevBuf fresh;
@@ -247,84 +261,164 @@ void ensure_table_g2(Ctx& c, BaseTable& t, const uint32_t* row0, size_t n, int c
 // ---- when a base array gets its table (gs_set_table_policy) ---------------------------------------------------------------------
 // The reference proves ONCE per key load (cli/main.go:330-349); 15-row tables cost ~140 ms and 15x the key's memory at 2^20 -- fifteen
 // proofs' worth of work before the first one.  Under `auto` a base array is summed table-free until it has been used
-// kTableAfterUses times; then its table is built on the table stream (lowest priority, behind and beside the proofs that keep
-// running table-free) and the first call that finds the build complete switches over.
+// kTableAfterUses times; from then on every call that finds it without a table builds a few more slabs of it.
+//
+// Round 6: IN INSTALMENTS, in front of the call's own accumulations, on the accumulation stream.  Round 5 enqueued
+// all five builds of a key at once on a lowest-priority stream and let the hardware share the chip: proofs 2-10 of a fresh 2^20 key took
+// 19-35 ms each, unpredictably, and a proof could not use a table the moment it was complete.  The work is what it is -- ~125 ms of
+// full-chip time per 2^20 Groth16 key, and whatever runs beside it is slowed by what it takes ("what overlap can and
+// cannot buy") -- so the only choice is how it is spread over the calls: each call gets a build CREDIT proportional to its own work
+// (msm.h, kBuildCreditPerUnitTerm: ~+80 % of a table-free call), spends it on whole slabs of the pending table (the balance, at most one
+// slab either way, stays on the context), and the call that enqueues the last slab installs the table and uses it -- stream order makes
+// that safe without a host wait.  A fresh 2^20 key: 24 ms, then ~16 proofs of <= 2x the steady time, then steady; a proof never waits for
+// more than its own instalment.  GS_TABLE_BUDGET_PCT scales the credit (100 = as described; 100000 = everything inside the second call).
 constexpr uint32_t kTableAfterUses = 2;
+
+template <class T>
+static void enqueue_pending_slabs(Ctx& c, BaseTable& t, size_t first, size_t last, size_t slab) {
+  enqueue_table_slabs<T>(c.main_stream, msm_state(c).table_scratch_bg, t.pending_src, t.pending_n, t.pending_c, t.pending, first, last, slab);
+}
+static size_t instalment_slab(size_t n) {
+  // whole launches of >= 2^12 points (16 workgroups), eight or more per table, at most GS_TABLE_BG_SLAB_LOG2 (2^17: 512 workgroups)
+  static const size_t cap = (size_t)1 << run_knob("GS_TABLE_BG_SLAB_LOG2", 17, 10, 18);
+  size_t s = (n / 8 + 255) & ~(size_t)255;
+  return std::min(cap, std::max<size_t>(s, (size_t)1 << 12));
+}
+// all streams of the context wait for the table's last slab (accumulations run on the main stream, where the slabs are: this is for
+// whatever else may come to read a table)
+static void order_streams_behind(Ctx& c, hipEvent_t ev) {
+  for (auto a : c.aux_stream) if (a && a != c.main_stream) GS_HIP(hipStreamWaitEvent(a, ev, 0));
+}
 
 void table_settle(Ctx& c, BaseTable& t, bool install) {
   if (!t.pending.p) return;
-  // this table's own build only: the stream may still be busy with the key's other arrays (a proof that found ONE table complete used
-  // to wait here for all five)
-  if (t.pending_done) GS_HIP(hipEventSynchronize(t.pending_done));
-  else if (c.table_stream) GS_HIP(hipStreamSynchronize(c.table_stream));
+  if (install && !t.pending_complete()) {              // finish the missing instalments now (gs_build_tables on a key that was warming up)
+    const size_t slab = (size_t)1 << 18;
+    if (t.pending_g2) enqueue_pending_slabs<Fq2Tag>(c, t, t.pending_next, t.pending_n, slab);
+    else enqueue_pending_slabs<FqTag>(c, t, t.pending_next, t.pending_n, slab);
+    t.pending_next = t.pending_n;
+    GS_HIP(hipEventRecord(t.pending_done, c.main_stream));
+  }
+  // this table's own build only
+  if (t.pending_done && t.pending_next > 0) GS_HIP(hipEventSynchronize(t.pending_done));
+  else if (t.pending_next > 0) GS_HIP(hipStreamSynchronize(c.main_stream));
   if (install) {
     t.rows = std::move(t.pending);
     t.n = t.pending_n; t.c = t.pending_c; t.W = 254 / t.pending_c + 1;
     t.uses = 0;
   } else t.pending.release();
-  t.pending_c = 0; t.pending_n = 0;
+  t.pending_c = 0; t.pending_n = 0; t.pending_next = 0; t.pending_src = nullptr;
 }
 
-static void start_background_build(Ctx& c, BaseTable& t, const TableRef& r, int cbits) {
-  if (!c.table_stream) {
-    int least = 0, greatest = 0;
-    GS_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-    static const bool low = run_knob("GS_TABLE_STREAM_LOW", 1, 0, 1) != 0;
-    GS_HIP(hipStreamCreateWithPriority(&c.table_stream, hipStreamNonBlocking, low ? least : 0));
-  }
+// install a table whose last slab has been ENQUEUED (not necessarily executed): everything that reads it is ordered behind the slab
+static void install_enqueued(Ctx& c, BaseTable& t) {
+  if (hipEventQuery(t.pending_done) != hipSuccess) order_streams_behind(c, t.pending_done);
+  (void)hipGetLastError();                                                     // hipErrorNotReady is not an error
+  // (the old rows, if any, are released by the move: hipFree waits for the device, i.e. for every reader of them)
+  t.rows = std::move(t.pending);
+  t.n = t.pending_n; t.c = t.pending_c; t.W = 254 / t.pending_c + 1;
+  t.uses = 0;
+  t.pending_c = 0; t.pending_n = 0; t.pending_next = 0; t.pending_src = nullptr;
+}
+
+static bool begin_pending(Ctx& c, BaseTable& t, const TableRef& r, int cbits) {
   if (!t.pending_done) GS_HIP(hipEventCreateWithFlags(&t.pending_done, hipEventDisableTiming));
-  DevBuf& scratch = msm_state(c).table_scratch_bg;
-  // Points per launch of a background build.  Measured on a fresh 2^20 key, blocking proofs back to back
-  // (profiles/r05_background_build_slabs.txt): slabs of 2^18 / 2^17 / 2^16 / 2^15 points -> the tables serve from proof #10 / #13 / #19 /
-  // #35 on (245 / 288 / 357 / 580 ms after the key arrived), the slowest proof on the way takes 35 / 28 / 26 / 24 ms (table-free and
-  // alone: 10-12).  The table stream has the lowest priority, so smaller slabs mostly starve the build; 2^17 it is.
-  static const size_t slab = (size_t)1 << run_knob("GS_TABLE_BG_SLAB_LOG2", 17, 10, 18);      // (same tables whatever the slab)
+  const int W = 254 / cbits + 1;
+  const size_t aw = r.g2 ? PointIO<Fq2Tag>::kAffineWords : PointIO<FqTag>::kAffineWords;
   try {
-    // The slab scratch at its G2 size BEFORE the first launch: the stream's builds share it, and growing it for the fourth array (the
-    // G2 one) released the old buffer -- hipFree waits for the device, i.e. for the three G1 builds just enqueued: that, not the
-    // builds' share of the chip, was most of the 88 ms a fresh 2^20 key's second proof took (now 28).
-    {
-      constexpr size_t sw2 = PointIO<Fq2Tag>::kXyzzWords + PointIO<Fq2Tag>::kXyzzWords / 4;
-      const int W = 254 / cbits + 1;
-      if (W > 2) scratch.ensure(std::min<size_t>(std::max<size_t>(r.n, 1), slab) * (size_t)(W - 1) * sw2 * 4);
-    }
-    if (r.g2) enqueue_table_build<Fq2Tag>(c, c.table_stream, scratch, r.row0, r.n, cbits, t.pending, slab);
-    else enqueue_table_build<FqTag>(c, c.table_stream, scratch, r.row0, r.n, cbits, t.pending, slab);
+    // the slab scratch at its G2 size BEFORE the first launch: growing it later releases the old buffer, and hipFree waits for the
+    // device -- for the slabs just enqueued (round 5: that, not the builds' share of the chip, was most of a second proof's 88 ms)
+    constexpr size_t sw2 = PointIO<Fq2Tag>::kXyzzWords + PointIO<Fq2Tag>::kXyzzWords / 4;
+    if (W > 2) msm_state(c).table_scratch_bg.ensure(std::min(instalment_slab(r.n), std::max<size_t>(r.n, 1)) * (size_t)(W - 1) * sw2 * 4);
+    t.pending.alloc(std::max<size_t>(r.n, 1) * W * aw * 4);
   } catch (const HipError& e) {
     if (e.e != hipErrorOutOfMemory) throw;      // no room for a table: keep summing table-free
     t.pending.release();
-    return;
+    return false;
   }
-  t.pending_c = cbits; t.pending_n = r.n;
-  GS_HIP(hipEventRecord(t.pending_done, c.table_stream));
+  t.pending_c = cbits; t.pending_n = r.n; t.pending_next = 0; t.pending_src = r.row0; t.pending_g2 = r.g2;
+  return true;
 }
 
-bool prepare_tables(Ctx& c, const std::vector<TableRef>& group, uint32_t nterms, int* cbits) {
-  const int cb = choose_window_bits(std::max<uint32_t>(nterms, 1u), c.window_bits);
+// spend credit on the next slabs of t's pending table; true when the last slab has been enqueued
+static bool advance_pending(Ctx& c, BaseTable& t, double& credit) {
+  const double unit = t.pending_g2 ? kG2BuildCost : 1.0;
+  const size_t slab = instalment_slab(t.pending_n);
+  while (t.pending_next < t.pending_n && credit > 0) {
+    const size_t last = std::min(t.pending_n, t.pending_next + slab);
+    if (t.pending_g2) enqueue_pending_slabs<Fq2Tag>(c, t, t.pending_next, last, slab);
+    else enqueue_pending_slabs<FqTag>(c, t, t.pending_next, last, slab);
+    credit -= (double)(last - t.pending_next) * unit;
+    t.pending_next = last;
+  }
+  if (t.pending_next < t.pending_n) return false;
+  GS_HIP(hipEventRecord(t.pending_done, c.main_stream));
+  return true;
+}
+
+void stamp_tables(Ctx& c, std::initializer_list<BaseTable*> tables) {
+  for (BaseTable* t : tables) if (t) t->last_use = c.call_clock;
+}
+
+bool prepare_tables(Ctx& c, const std::vector<TableRef>& group, uint32_t nterms, int* cbits, double* credit) {
+  int cb = choose_window_bits(std::max<uint32_t>(nterms, 1u), c.window_bits);
+  // A group whose tables are all resident at ONE width next to the model's serves at that width (gs_build_tables sizes a
+  // key's tables for the arrays it holds, a proof asks for the width of its term range -- near a boundary of the model the warmed
+  // table was silently ignored or rebuilt, and callers alternating two MSM lengths over one array flip-flopped it).
+  if (c.window_bits == 0 && !group.empty() && group[0].t->rows.p) {
+    const int tc = group[0].t->c;
+    bool same = tc >= cb - 1 && tc <= cb + 1;
+    for (const TableRef& r : group) same = same && r.t->ready(r.n, tc);
+    if (same) cb = tc;
+  }
   bool all_ready = true;
   for (const TableRef& r : group) {
-    BaseTable& t = *r.t;
-    t.last_use = c.call_clock;
-    if (t.pending.p && hipEventQuery(t.pending_done) == hipSuccess) {          // a background build came through
-      if (t.pending_c == cb && t.pending_n == r.n) table_settle(c, t, true); else table_settle(c, t, false);
-    }
-    (void)hipGetLastError();                                                   // hipErrorNotReady is not an error
-    all_ready = all_ready && t.ready(r.n, cb);
+    r.t->last_use = c.call_clock;
+    all_ready = all_ready && r.t->ready(r.n, cb);
   }
-  if (all_ready) { *cbits = cb; return true; }
+  if (all_ready) {
+    for (const TableRef& r : group) r.t->last_table_use = c.call_clock;
+    *cbits = cb;
+    return true;
+  }
   if (c.table_policy == 1) {                                                   // always: inside the call, as rounds 1-4 did
     for (const TableRef& r : group) {
       if (r.g2) ensure_table_g2(c, *r.t, r.row0, r.n, cb); else ensure_table_g1(c, *r.t, r.row0, r.n, cb);
+      r.t->last_table_use = c.call_clock;
     }
     *cbits = cb;
     return true;
   }
   if (c.table_policy == 0) {
-    for (const TableRef& r : group) {
+    static const double scale = (double)run_knob("GS_TABLE_BUDGET_PCT", 100, 1, 1000000) / 100.0;
+    // what this call may still enqueue: its grant (what an earlier group of the same call left of it) minus the last call's overdraft
+    double avail = (credit ? *credit : 0.0) * scale + c.build_balance;
+    // G2 arrays first: the G2 sum is the longest of a proof, so its table is the one that pays most per call
+    std::vector<const TableRef*> order;
+    for (const TableRef& r : group) if (r.g2) order.push_back(&r);
+    for (const TableRef& r : group) if (!r.g2) order.push_back(&r);
+    for (const TableRef* pr : order) {
+      const TableRef& r = *pr;
       BaseTable& t = *r.t;
       if (t.ready(r.n, cb)) continue;
-      t.uses += 1;
-      if (t.uses >= kTableAfterUses && !t.pending.p && r.n) start_background_build(c, t, r, cb);
+      if (t.pending.p && (t.pending_c != cb || t.pending_n != r.n || t.pending_src != r.row0)) table_settle(c, t, false);   // superseded
+      if (!t.pending.p) {
+        t.uses += 1;
+        // a table of another width that still serves other calls stays (callers alternating two lengths over one array)
+        const bool serving = t.rows.p && c.call_clock - t.last_table_use <= 8;
+        if (t.uses < kTableAfterUses || !r.n || serving) continue;
+        if (!begin_pending(c, t, r, cb)) continue;
+      }
+      if (avail > 0 && advance_pending(c, t, avail)) install_enqueued(c, t);
+    }
+    c.build_balance = std::min(avail, 0.0);                       // an overdraft (less than one slab) comes off the next call's grant
+    if (credit) *credit = std::max(avail, 0.0) / scale;           // the rest of the grant is the call's next group's
+    bool now_ready = true;
+    for (const TableRef& r : group) now_ready = now_ready && r.t->ready(r.n, cb);
+    if (now_ready) {                                              // this call enqueued the last slab: it is the first to use the tables
+      for (const TableRef& r : group) r.t->last_table_use = c.call_clock;
+      *cbits = cb;
+      return true;
     }
   }
   *cbits = choose_window_bits_free(std::max<uint32_t>(nterms, 1u), c.window_bits);

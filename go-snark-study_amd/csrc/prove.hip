@@ -220,16 +220,7 @@ int groth16_enqueue(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, const S
   const size_t held_lo = eval ? pk->e_lo : pk->h_lo;
   const size_t wbase = wlo - pk->w_lo, hbase = hlo - std::min(held_lo, hlo);      // offsets into the arrays this key holds
   // window tables or table-free, per plan (msm.h, prepare_tables: the four arrays over w share one plan, so they go one way together)
-  int cw = 0, ch = 0;
-  const bool tab_w = prepare_tables(c, {TableRef{&pk->t_at, pk->at.as<uint32_t>(), pk->n_w, false}, TableRef{&pk->t_bacgamma1, pk->bacgamma1.as<uint32_t>(), pk->n_w, false},
-                                        TableRef{&pk->t_bacdelta, pk->bacdelta.as<uint32_t>(), pk->n_w, false},
-                                        TableRef{&pk->t_bacgamma2, pk->bacgamma2.as<uint32_t>(), pk->n_w, true}}, (uint32_t)(whi - wlo), &cw);
-  const bool tab_h = prepare_tables(c, {eval ? TableRef{&pk->t_ptd_eval, pk->ptd_eval.as<uint32_t>(), pk->n_e, false}
-                                             : TableRef{&pk->t_ptd, pk->ptd.as<uint32_t>(), pk->n_h, false}}, (uint32_t)(hhi - hlo), &ch);
-  hxbuf.ensure(std::max<size_t>(nh, 1) * 32);
-  auto base_w = [&](BaseTable& t, const DevBuf& pts) { return MsmBase{&t, wbase, pts.as<uint32_t>(), pk->n_w}; };
-  st.pk = pk;
-  st.total = std::make_unique<PhaseTimer>(c.main_stream);
+  // (before any table instalment goes onto the main stream: the plans on the aux streams wait for the inputs, not for the slabs)
   if (wait_inputs) {
     hipEvent_t start;
     GS_HIP(hipEventCreateWithFlags(&start, hipEventDisableTiming));
@@ -237,6 +228,20 @@ int groth16_enqueue(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, const S
     for (auto a : c.aux_stream) GS_HIP(hipStreamWaitEvent(a, start, 0));
     GS_HIP(hipEventDestroy(start));
   }
+  int cw = 0, ch = 0;
+  // every table of the call is stamped before one is built (an allocation for the first group must not evict the second group's), and
+  // under policy `auto` the call grants itself a build credit for its ~6.8 job-units over w and h (msm.h, prepare_tables)
+  stamp_tables(c, {&pk->t_at, &pk->t_bacgamma1, &pk->t_bacdelta, &pk->t_bacgamma2, eval ? &pk->t_ptd_eval : &pk->t_ptd});
+  double credit = kBuildCreditPerUnitTerm * (3.0 + 2.76 + 1.0) * (double)(whi - wlo);
+  const bool tab_w = prepare_tables(c, {TableRef{&pk->t_at, pk->at.as<uint32_t>(), pk->n_w, false}, TableRef{&pk->t_bacgamma1, pk->bacgamma1.as<uint32_t>(), pk->n_w, false},
+                                        TableRef{&pk->t_bacdelta, pk->bacdelta.as<uint32_t>(), pk->n_w, false},
+                                        TableRef{&pk->t_bacgamma2, pk->bacgamma2.as<uint32_t>(), pk->n_w, true}}, (uint32_t)(whi - wlo), &cw, &credit);
+  const bool tab_h = prepare_tables(c, {eval ? TableRef{&pk->t_ptd_eval, pk->ptd_eval.as<uint32_t>(), pk->n_e, false}
+                                             : TableRef{&pk->t_ptd, pk->ptd.as<uint32_t>(), pk->n_h, false}}, (uint32_t)(hhi - hlo), &ch, &credit);
+  hxbuf.ensure(std::max<size_t>(nh, 1) * 32);
+  auto base_w = [&](BaseTable& t, const DevBuf& pts) { return MsmBase{&t, wbase, pts.as<uint32_t>(), pk->n_w}; };
+  st.pk = pk;
+  st.total = std::make_unique<PhaseTimer>(c.main_stream);
   const int ws = 8 * parity, pin = 3 * parity;
   MsmPlan plan_w, plan_h;
   // The main stream carries NOTHING but the ALU-bound bucket accumulations (G2, then the three G1 arrays over w, then h),
@@ -256,10 +261,11 @@ int groth16_enqueue(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, const S
   // (profiles/r05_ab_sparse_b_split.txt): a circuit of the reference compiler's shape (33 % of the variables in B, full-width witness)
   // 8.3-8.4 -> 6.1-6.2 ms per proof in flight, 8.8 -> 6.9 blocking, witness route 9.15 -> 7.2; the realistic-witness instance (60 % in
   // B, and the absent variables are the small ones that carry one or two digits anyway) LOSES 3 % -- hence 55, not 90.  (Window
-  // widths of 19 and more -- only by gs_set_window_bits -- keep the single plan: their partition-first sort has no mask.)
+  // widths of 18 and more -- only by gs_set_window_bits -- keep the single plan: their partition-first sort takes no term list.  ADVICE r5:
+  // the gate used to say `cw < 19` while build_plan partitions from c = 18 on, so a forced width of 18 on a sparse-B key failed every proof.)
   static const long split_pct = run_knob("GS_SPLIT_B_PERCENT", 55, 0, 100);      // split below this share of finite B points; 0 = never (same results)
   const size_t nterms_w = whi - wlo;
-  st.split_b = pk->b_index.p != nullptr && nterms_w >= 4096 && cw < 19 && pk->b_finite * 100 < (size_t)split_pct * pk->n_w;
+  st.split_b = pk->b_index.p != nullptr && nterms_w >= 4096 && !plan_partitions_first(cw) && pk->b_finite * 100 < (size_t)split_pct * pk->n_w;
   MsmPlan plan_b;
   {                                                              // aux 1 (or aux 2, proof_streams): plan(w) [, the plan over the listed terms for B first: G2 starts the proof]
     StreamScope sc(c, ps.planw);
@@ -547,15 +553,6 @@ int pinocchio_enqueue(Ctx& c, PinocchioPkObj* pk, DevScalars w, DevScalars px, c
   else shard_range(nh, shard, hlo, hhi);
   const size_t held_lo = eval ? pk->e_lo : pk->h_lo;
   const size_t wbase = wlo - pk->w_lo, hbase = hlo - std::min(held_lo, hlo);
-  int cw = 0, ch = 0;                          // window tables or table-free, per plan (as groth16_enqueue)
-  auto ref1 = [&](BaseTable& t, const DevBuf& pts) { return TableRef{&t, pts.as<uint32_t>(), pk->n_w, false}; };
-  const bool tab_w = prepare_tables(c, {ref1(pk->t_a, pk->a), ref1(pk->t_ap, pk->ap), ref1(pk->t_bp, pk->bp), ref1(pk->t_c, pk->c), ref1(pk->t_cp, pk->cp),
-                                        ref1(pk->t_kp, pk->kp), TableRef{&pk->t_b2, pk->b2.as<uint32_t>(), pk->n_w, true}}, (uint32_t)(whi - wlo), &cw);
-  const bool tab_h = prepare_tables(c, {eval ? TableRef{&pk->t_g1t_eval, pk->g1t_eval.as<uint32_t>(), pk->n_e, false}
-                                             : TableRef{&pk->t_g1t, pk->g1t.as<uint32_t>(), pk->n_h, false}}, (uint32_t)(hhi - hlo), &ch);
-  hxbuf.ensure(std::max<size_t>(nh, 1) * 32);
-  auto base_w = [&](BaseTable& t, const DevBuf& pts) { return MsmBase{&t, wbase, pts.as<uint32_t>(), pk->n_w}; };
-  st.total = std::make_unique<PhaseTimer>(c.main_stream);
   if (wait_inputs) {
     hipEvent_t start;
     GS_HIP(hipEventCreateWithFlags(&start, hipEventDisableTiming));
@@ -563,6 +560,17 @@ int pinocchio_enqueue(Ctx& c, PinocchioPkObj* pk, DevScalars w, DevScalars px, c
     for (auto a : c.aux_stream) GS_HIP(hipStreamWaitEvent(a, start, 0));
     GS_HIP(hipEventDestroy(start));
   }
+  int cw = 0, ch = 0;                          // window tables or table-free, per plan (as groth16_enqueue)
+  auto ref1 = [&](BaseTable& t, const DevBuf& pts) { return TableRef{&t, pts.as<uint32_t>(), pk->n_w, false}; };
+  stamp_tables(c, {&pk->t_a, &pk->t_ap, &pk->t_bp, &pk->t_c, &pk->t_cp, &pk->t_kp, &pk->t_b2, eval ? &pk->t_g1t_eval : &pk->t_g1t});      // as groth16_enqueue
+  double credit = kBuildCreditPerUnitTerm * (6.0 + 2.76 + 1.0) * (double)(whi - wlo);
+  const bool tab_w = prepare_tables(c, {ref1(pk->t_a, pk->a), ref1(pk->t_ap, pk->ap), ref1(pk->t_bp, pk->bp), ref1(pk->t_c, pk->c), ref1(pk->t_cp, pk->cp),
+                                        ref1(pk->t_kp, pk->kp), TableRef{&pk->t_b2, pk->b2.as<uint32_t>(), pk->n_w, true}}, (uint32_t)(whi - wlo), &cw, &credit);
+  const bool tab_h = prepare_tables(c, {eval ? TableRef{&pk->t_g1t_eval, pk->g1t_eval.as<uint32_t>(), pk->n_e, false}
+                                             : TableRef{&pk->t_g1t, pk->g1t.as<uint32_t>(), pk->n_h, false}}, (uint32_t)(hhi - hlo), &ch, &credit);
+  hxbuf.ensure(std::max<size_t>(nh, 1) * 32);
+  auto base_w = [&](BaseTable& t, const DevBuf& pts) { return MsmBase{&t, wbase, pts.as<uint32_t>(), pk->n_w}; };
+  st.total = std::make_unique<PhaseTimer>(c.main_stream);
   const int ws = 8 * parity, pin = 3 * parity;
   MsmPlan plan_w, plan_h;
   const ProofStreams ps = proof_streams(c, pipelined, whi - wlo, (bool)px.produce_hv || (bool)px.produce_hx || (bool)px.produce);
@@ -577,7 +585,7 @@ int pinocchio_enqueue(Ctx& c, PinocchioPkObj* pk, DevScalars w, DevScalars px, c
   }
   static const long split_pct = run_knob("GS_SPLIT_B_PERCENT", 55, 0, 100);      // as groth16_enqueue
   const size_t nterms_w = whi - wlo;
-  st.split_b = pk->b_index.p != nullptr && nterms_w >= 4096 && cw < 19 && pk->b_finite * 100 < (size_t)split_pct * pk->n_w;
+  st.split_b = pk->b_index.p != nullptr && nterms_w >= 4096 && !plan_partitions_first(cw) && pk->b_finite * 100 < (size_t)split_pct * pk->n_w;
   MsmPlan plan_b;
   {                                                              // aux 1 (or its own stream, proof_streams): [the plan over the listed terms for B, B',] plan(w)
     StreamScope sc(c, ps.planw);

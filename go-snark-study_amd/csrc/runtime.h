@@ -230,7 +230,8 @@ struct Ctx {
   // array has been used twice, then build in the background and switch when the build is through), 1 always (build on first use,
   // inside the call: rounds 1-4), 2 never
   int table_policy = 0;
-  hipStream_t table_stream = nullptr;   // background table builds (lazy, lowest priority)
+  hipStream_t table_stream = nullptr;   // (round 5: background table builds; round 6 builds in instalments on the main stream, msm.hip)
+  double build_balance = 0;             // build credit a call overdrew (less than one slab): taken off the next call's (msm.hip, prepare_tables)
   bool eval_basis = true;        // gs_set_eval_basis: witness route over H's values when the key has an evaluation-basis array
   gs_timing timing{};
   std::mutex timing_mu;          // msm_finish of several groups may run on different host threads

@@ -203,19 +203,35 @@ def FqRRand():
     return int.from_bytes(os.urandom(30), "big") % R
 
 
+GS_ERR_BUSY = -6
+
+
+def _host_scalars(x, what):
+    """The reference's []*big.Int (Python ints: reduced mod r here, negatives rejected -- the reference drops the sign, fq.go:138-140) or an
+    [n, 4] uint64 limb array (taken as it is: the device reduces any value < 2^256) -> contiguous [n, 4] uint64."""
+    if isinstance(x, np.ndarray):
+        return np.ascontiguousarray(x, dtype=np.uint64).reshape(-1, 4)
+    if any(v < 0 for v in x):
+        raise ValueError("negative %s values are not supported (the reference drops the sign, fq.go:138-140)" % what)
+    return capi.ints_to_u64([v % R for v in x])
+
+
 def GenerateProofsWithRS(circuit, pk, w, px, r, s):
-    """groth16.go:225-278 with r, s given instead of drawn at :231-238."""
+    """groth16.go:225-278 with r, s given instead of drawn at :231-238.  Round 6 (as go/groth16hip.GenerateProofsWithRS): w and px travel
+    as a HOST-BUFFER TICKET collected at once (gs_groth16_prove_host_begin + gs_groth16_prove_end: staged into the slot's own device
+    buffers, nothing allocated per proof, concurrent callers pipeline); when all three slots are taken, the blocking entry point."""
     import ctypes
     dev = pk if isinstance(pk, DevicePk) else UploadPk(pk, circuit)
-    # scalars are not canonical in the reference (SURVEY hard part 6): reduce mod r, reject negatives
-    if any(x < 0 for x in w):
-        raise ValueError("negative witness values are not supported (the reference drops the sign, fq.go:138-140)")
-    wa = capi.ints_to_u64([x % R for x in w])
-    pa = capi.ints_to_u64([x % R for x in px])
+    wa, pa = _host_scalars(w, "witness"), _host_scalars(px, "px")
+    try:
+        return prove_end(prove_host_begin(dev, wa, pa, r, s))
+    except capi.GosnarkHipError as e:
+        if e.code != GS_ERR_BUSY:
+            raise
     out = np.zeros(32, dtype=np.uint64)
     inf = (ctypes.c_int * 3)()
     rs = capi.ints_to_u64([r % R, s % R])
-    capi.check(capi.load_library().gs_groth16_prove(capi.Handle(dev.handle.h), capi.ptr64(wa), len(w), capi.ptr64(pa), len(px),
+    capi.check(capi.load_library().gs_groth16_prove(capi.Handle(dev.handle.h), capi.ptr64(wa), wa.shape[0], capi.ptr64(pa), pa.shape[0],
                                                     capi.ptr64(rs[0]), capi.ptr64(rs[1]), capi.ptr64(out), inf))
     return _proof_from_words(out, inf)
 
@@ -223,6 +239,79 @@ def GenerateProofsWithRS(circuit, pk, w, px, r, s):
 def GenerateProofs(circuit, pk, w, px):
     """groth16.GenerateProofs(circuit, pk, w, px) (groth16.go:225)."""
     return GenerateProofsWithRS(circuit, pk, w, px, FqRRand(), FqRRand())
+
+
+def GenerateProofsFromWitnessWithRS(circuit, pk, dev_r1cs, w, r, s):
+    """go/groth16hip.GenerateProofsFromWitnessWithRS: the callers' R1CSToQAP -> CombinePolynomials -> GenerateProofs chain (cli/main.go:480-501)
+    from the witness alone, against the circuit's resident sparse R1CS (r1csqap.DeviceR1CS); a host-buffer ticket collected at once."""
+    dev = pk if isinstance(pk, DevicePk) else UploadPk(pk, circuit)
+    wa = _host_scalars(w, "witness")
+    try:
+        return prove_end(prove_witness_host_begin(dev, dev_r1cs, wa, r, s))
+    except capi.GosnarkHipError as e:
+        if e.code != GS_ERR_BUSY:
+            raise
+    return prove_from_witness_host(dev, dev_r1cs, wa, r, s)
+
+
+class Prover:
+    """The streaming drop-in (go/groth16hip.Prover, tests/c/stream_producer.c): one resident key, a NEW witness per Submit, up to three
+    proofs in flight, proofs back in submission order.
+        p = groth16.NewProver(circuit, pk, dev_r1cs)          # dev_r1cs = None: every Submit brings px
+        for w in witnesses:
+            p.Submit(w)                                       # or p.Submit(w, px)
+            if p.InFlight() == 3: proof = p.Collect()
+        while p.InFlight(): proof = p.Collect()
+    A Submit on a full pipeline first collects the oldest ticket into a done-queue (it never fails with GS_ERR_BUSY)."""
+    MaxInFlight = 3
+
+    def __init__(self, circuit, pk, dev_r1cs=None):
+        self.dev = pk if isinstance(pk, DevicePk) else UploadPk(pk, circuit)
+        self.r1cs = dev_r1cs
+        self.tickets, self.done = [], []
+
+    def _collect_oldest(self):
+        self.done.append(prove_end(self.tickets.pop(0)))
+
+    def SubmitWithRS(self, w, px, r, s):
+        if px is None and self.r1cs is None:
+            raise ValueError("this prover has no resident R1CS: Submit needs px")
+        wa = _host_scalars(w, "witness")
+        pa = None if px is None else _host_scalars(px, "px")
+        while True:
+            if len(self.tickets) >= self.MaxInFlight:
+                self._collect_oldest()
+            try:
+                t = prove_witness_host_begin(self.dev, self.r1cs, wa, r, s) if pa is None else prove_host_begin(self.dev, wa, pa, r, s)
+            except capi.GosnarkHipError as e:
+                if e.code == GS_ERR_BUSY and self.tickets:       # another prover shares the device's slots: make room and retry
+                    self._collect_oldest()
+                    continue
+                raise
+            self.tickets.append(t)
+            return
+
+    def Submit(self, w, px=None):
+        self.SubmitWithRS(w, px, FqRRand(), FqRRand())
+
+    def InFlight(self):
+        return len(self.tickets) + len(self.done)
+
+    def Collect(self):
+        if not self.done:
+            if not self.tickets:
+                raise ValueError("Collect without a submitted proof")
+            self._collect_oldest()
+        return self.done.pop(0)
+
+    def Close(self):
+        for t in self.tickets:
+            capi.ticket_cancel(t)
+        self.tickets, self.done = [], []
+
+
+def NewProver(circuit, pk, dev_r1cs=None):
+    return Prover(circuit, pk, dev_r1cs)
 
 
 def prove_resident(dev_pk, w_handle, px_handle, r, s):

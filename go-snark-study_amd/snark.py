@@ -41,18 +41,95 @@ def UploadPk(pk, circuit):
     return pk._dev
 
 
+GS_ERR_BUSY = -6
+
+
+def _host_scalars(x, what):
+    """ints (reduced mod r here, negatives rejected) or an [n, 4] uint64 limb array (as it is) -> contiguous [n, 4] uint64"""
+    if isinstance(x, np.ndarray):
+        return np.ascontiguousarray(x, dtype=np.uint64).reshape(-1, 4)
+    if any(v < 0 for v in x):
+        raise ValueError("negative %s values are not supported" % what)
+    return capi.ints_to_u64([v % R for v in x])
+
+
 def GenerateProofs(circuit, pk, w, px):
-    """snark.GenerateProofs(circuit, pk, w, px) (snark.go:254-289).  Deterministic."""
+    """snark.GenerateProofs(circuit, pk, w, px) (snark.go:254-289).  Deterministic.  Round 6 (as go/snarkhip.GenerateProofs): a host-buffer
+    ticket collected at once (gs_pinocchio_prove_host_begin + gs_pinocchio_prove_end); the blocking entry point when all slots are taken."""
     dev = pk if isinstance(pk, DevicePk) else UploadPk(pk, circuit)
-    if any(x < 0 for x in w):
-        raise ValueError("negative witness values are not supported")
-    wa = capi.ints_to_u64([x % R for x in w])
-    pa = capi.ints_to_u64([x % R for x in px])
+    wa, pa = _host_scalars(w, "witness"), _host_scalars(px, "px")
+    try:
+        return prove_end(prove_host_begin(dev, wa, pa))
+    except capi.GosnarkHipError as e:
+        if e.code != GS_ERR_BUSY:
+            raise
     out = np.zeros(72, dtype=np.uint64)
     inf = (ctypes.c_int * 8)()
-    capi.check(capi.load_library().gs_pinocchio_prove(capi.Handle(dev.h), capi.ptr64(wa), len(w), capi.ptr64(pa), len(px),
+    capi.check(capi.load_library().gs_pinocchio_prove(capi.Handle(dev.h), capi.ptr64(wa), wa.shape[0], capi.ptr64(pa), pa.shape[0],
                                                       capi.ptr64(out), inf))
     return _proof_from_words(out, inf)
+
+
+def GenerateProofsFromWitness(circuit, pk, dev_r1cs, w):
+    """go/snarkhip.GenerateProofsFromWitness: witness -> proof against the circuit's resident sparse R1CS, a host-buffer ticket collected at once."""
+    dev = pk if isinstance(pk, DevicePk) else UploadPk(pk, circuit)
+    wa = _host_scalars(w, "witness")
+    try:
+        return prove_end(prove_witness_host_begin(dev, dev_r1cs, wa))
+    except capi.GosnarkHipError as e:
+        if e.code != GS_ERR_BUSY:
+            raise
+    return prove_from_witness_host(dev, dev_r1cs, wa)
+
+
+class Prover:
+    """The streaming drop-in (go/snarkhip.Prover; see groth16.Prover): Submit(w[, px]) / Collect(), three proofs in flight."""
+    MaxInFlight = 3
+
+    def __init__(self, circuit, pk, dev_r1cs=None):
+        self.dev = pk if isinstance(pk, DevicePk) else UploadPk(pk, circuit)
+        self.r1cs = dev_r1cs
+        self.tickets, self.done = [], []
+
+    def _collect_oldest(self):
+        self.done.append(prove_end(self.tickets.pop(0)))
+
+    def Submit(self, w, px=None):
+        if px is None and self.r1cs is None:
+            raise ValueError("this prover has no resident R1CS: Submit needs px")
+        wa = _host_scalars(w, "witness")
+        pa = None if px is None else _host_scalars(px, "px")
+        while True:
+            if len(self.tickets) >= self.MaxInFlight:
+                self._collect_oldest()
+            try:
+                t = prove_witness_host_begin(self.dev, self.r1cs, wa) if pa is None else prove_host_begin(self.dev, wa, pa)
+            except capi.GosnarkHipError as e:
+                if e.code == GS_ERR_BUSY and self.tickets:
+                    self._collect_oldest()
+                    continue
+                raise
+            self.tickets.append(t)
+            return
+
+    def InFlight(self):
+        return len(self.tickets) + len(self.done)
+
+    def Collect(self):
+        if not self.done:
+            if not self.tickets:
+                raise ValueError("Collect without a submitted proof")
+            self._collect_oldest()
+        return self.done.pop(0)
+
+    def Close(self):
+        for t in self.tickets:
+            capi.ticket_cancel(t)
+        self.tickets, self.done = [], []
+
+
+def NewProver(circuit, pk, dev_r1cs=None):
+    return Prover(circuit, pk, dev_r1cs)
 
 
 def _proof_from_words(out, inf):

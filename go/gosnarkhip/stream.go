@@ -23,7 +23,7 @@ import (
 // (2) cli/main.go:330-349 loads a key and proves ONCE.  SetTablePolicy(TablesAuto) -- the default -- sums a fresh key
 // table-free instead of first spending ~140 ms and 5.6 GiB on window tables; BuildTables warms a key that will serve for hours.
 //
-// Call sequence of everything in this file = tests/c/stream_host.c.
+// Call sequence of everything in this file = tests/c/stream_host.c; of prover.go (the streaming provers) = tests/c/stream_producer.c.
 
 // UpdateScalars overwrites a resident scalar vector in place (len(vals) must equal its length).  The copy is ordered
 // behind every read of the vector by tickets that are still outstanding and has landed when the call returns.
@@ -37,58 +37,54 @@ func UpdateScalars(h Handle, vals []*big.Int, order *big.Int) error {
 	return err
 }
 
+// packRS packs (r, s) into the 8 words the prover entry points take.
+func packRS(r, s, order *big.Int) (rs [8]uint64, err error) {
+	err = ScalarsInto(rs[:], []*big.Int{r, s}, order)
+	return
+}
+
 // ProveHostBegin is GenerateProofs' own argument list as a pipelined ticket: w and px from host memory, consumed
-// when the call returns.  Collect with ProveEnd.
+// when the call returns.  Collect with ProveEnd.  (Packing: parallel, no Mod, pooled buffers -- pack.go.)
 func (k *Groth16Key) ProveHostBegin(w, px []*big.Int, r, s, order *big.Int) (Groth16Ticket, error) {
-	wb, err := Scalars(w, order)
+	rs, err := packRS(r, s, order)
 	if err != nil {
 		return 0, err
 	}
-	pb, err := Scalars(px, order)
-	if err != nil {
+	wb, pb := LimbPool.Get(4*len(w)), LimbPool.Get(4*len(px))
+	defer LimbPool.Put(wb)
+	defer LimbPool.Put(pb)
+	if err = ScalarsInto(wb, w, order); err != nil {
 		return 0, err
 	}
-	rs, err := Scalars([]*big.Int{r, s}, order)
-	if err != nil {
+	if err = ScalarsInto(pb, px, order); err != nil {
 		return 0, err
 	}
-	var t C.uint64_t
-	err = call(func() C.int {
-		return C.gs_groth16_prove_host_begin(C.gs_handle(k.h), ptr(wb), C.size_t(len(w)), ptr(pb), C.size_t(len(px)), ptr(rs[0:]), ptr(rs[4:]), &t)
-	})
-	runtime.KeepAlive(wb)
-	runtime.KeepAlive(pb)
-	runtime.KeepAlive(rs)
-	return Groth16Ticket(t), err
+	return k.ProveHostBeginLimbs(wb, pb, &rs)
 }
 
 // ProveWitnessHostBegin: a fresh host witness against the resident sparse R1CS (no px at all).  Collect with ProveEnd.
 func (k *Groth16Key) ProveWitnessHostBegin(q *R1CS, w []*big.Int, r, s, order *big.Int) (Groth16Ticket, error) {
-	wb, err := Scalars(w, order)
+	rs, err := packRS(r, s, order)
 	if err != nil {
 		return 0, err
 	}
-	rs, err := Scalars([]*big.Int{r, s}, order)
-	if err != nil {
+	wb := LimbPool.Get(4 * len(w))
+	defer LimbPool.Put(wb)
+	if err = ScalarsInto(wb, w, order); err != nil {
 		return 0, err
 	}
-	var t C.uint64_t
-	err = call(func() C.int {
-		return C.gs_groth16_prove_witness_host_begin(C.gs_handle(k.h), C.gs_handle(q.h), ptr(wb), C.size_t(len(w)), ptr(rs[0:]), ptr(rs[4:]), &t)
-	})
-	runtime.KeepAlive(wb)
-	runtime.KeepAlive(rs)
-	return Groth16Ticket(t), err
+	return k.ProveWitnessHostBeginLimbs(q, wb, &rs)
 }
 
 // ProveWitnessHost is the blocking form: host witness -> proof.
 func (k *Groth16Key) ProveWitnessHost(q *R1CS, w []*big.Int, r, s, order *big.Int) (piA [3]*big.Int, piB [3][2]*big.Int, piC [3]*big.Int, err error) {
-	wb, err := Scalars(w, order)
+	rs, err := packRS(r, s, order)
 	if err != nil {
 		return
 	}
-	rs, err := Scalars([]*big.Int{r, s}, order)
-	if err != nil {
+	wb := LimbPool.Get(4 * len(w))
+	defer LimbPool.Put(wb)
+	if err = ScalarsInto(wb, w, order); err != nil {
 		return
 	}
 	var out [32]uint64
@@ -98,7 +94,6 @@ func (k *Groth16Key) ProveWitnessHost(q *R1CS, w []*big.Int, r, s, order *big.In
 			(*C.uint64_t)(unsafe.Pointer(&out[0])), &inf[0])
 	})
 	runtime.KeepAlive(wb)
-	runtime.KeepAlive(rs)
 	if err != nil {
 		return
 	}
@@ -108,44 +103,36 @@ func (k *Groth16Key) ProveWitnessHost(q *R1CS, w []*big.Int, r, s, order *big.In
 
 // ProveHostBegin / ProveWitnessHostBegin / ProveWitnessHost of snark.GenerateProofs (collect the tickets with PinocchioProveEnd).
 func (k *PinocchioKey) ProveHostBegin(w, px []*big.Int, order *big.Int) (uint64, error) {
-	wb, err := Scalars(w, order)
-	if err != nil {
+	wb, pb := LimbPool.Get(4*len(w)), LimbPool.Get(4*len(px))
+	defer LimbPool.Put(wb)
+	defer LimbPool.Put(pb)
+	if err := ScalarsInto(wb, w, order); err != nil {
 		return 0, err
 	}
-	pb, err := Scalars(px, order)
-	if err != nil {
+	if err := ScalarsInto(pb, px, order); err != nil {
 		return 0, err
 	}
-	var t C.uint64_t
-	err = call(func() C.int {
-		return C.gs_pinocchio_prove_host_begin(C.gs_handle(k.h), ptr(wb), C.size_t(len(w)), ptr(pb), C.size_t(len(px)), &t)
-	})
-	runtime.KeepAlive(wb)
-	runtime.KeepAlive(pb)
-	return uint64(t), err
+	return k.ProveHostBeginLimbs(wb, pb)
 }
 
 func (k *PinocchioKey) ProveWitnessHostBegin(q *R1CS, w []*big.Int, order *big.Int) (uint64, error) {
-	wb, err := Scalars(w, order)
-	if err != nil {
+	wb := LimbPool.Get(4 * len(w))
+	defer LimbPool.Put(wb)
+	if err := ScalarsInto(wb, w, order); err != nil {
 		return 0, err
 	}
-	var t C.uint64_t
-	err = call(func() C.int {
-		return C.gs_pinocchio_prove_witness_host_begin(C.gs_handle(k.h), C.gs_handle(q.h), ptr(wb), C.size_t(len(w)), &t)
-	})
-	runtime.KeepAlive(wb)
-	return uint64(t), err
+	return k.ProveWitnessHostBeginLimbs(q, wb)
 }
 
 func (k *PinocchioKey) ProveWitnessHost(q *R1CS, w []*big.Int, order *big.Int) (PinocchioProof, error) {
-	wb, err := Scalars(w, order)
-	if err != nil {
+	wb := LimbPool.Get(4 * len(w))
+	defer LimbPool.Put(wb)
+	if err := ScalarsInto(wb, w, order); err != nil {
 		return PinocchioProof{}, err
 	}
 	var out [72]uint64
 	var inf [8]C.int
-	err = call(func() C.int {
+	err := call(func() C.int {
 		return C.gs_pinocchio_prove_witness_host(C.gs_handle(k.h), C.gs_handle(q.h), ptr(wb), C.size_t(len(w)), (*C.uint64_t)(unsafe.Pointer(&out[0])), &inf[0])
 	})
 	runtime.KeepAlive(wb)

@@ -132,52 +132,104 @@ func ReleaseAll() {
 	}
 }
 
-// GenerateProofs has the reference's signature and semantics (snark.go:254-289): no randomness, eight proof elements,
-// returned in the affine normal form.  C call sequence: tests/c/snark_generateproofs.c.
-func GenerateProofs(circuit circuitcompiler.Circuit, pk snark.Pk, w []*big.Int, px []*big.Int) (snark.Proof, error) {
+func toProof(p gosnarkhip.PinocchioProof) snark.Proof {
 	var proof snark.Proof
-	e, err := deviceKey(circuit, &pk)
-	if err != nil {
-		return proof, err
-	}
-	defer unpin(e)
-	p, err := e.key.Prove(w, px, snark.Utils.FqR.Q)
-	if err != nil {
-		return proof, err
-	}
 	proof.PiA, proof.PiAp, proof.PiB, proof.PiBp = p.PiA, p.PiAp, p.PiB, p.PiBp
 	proof.PiC, proof.PiCp, proof.PiH, proof.PiKp = p.PiC, p.PiCp, p.PiH, p.PiKp
-	return proof, nil
+	return proof
+}
+
+// GenerateProofs has the reference's signature and semantics (snark.go:254-289): no randomness, eight proof elements,
+// returned in the affine normal form.  Round 6: w and px travel as a host-buffer ticket collected at once (concurrent goroutines
+// pipeline, nothing is allocated per proof); with all three slots taken the blocking entry point runs on the fourth.
+// C call sequence: tests/c/snark_generateproofs.c (blocking form), tests/c/stream_host.c (ticket form).
+func GenerateProofs(circuit circuitcompiler.Circuit, pk snark.Pk, w []*big.Int, px []*big.Int) (snark.Proof, error) {
+	e, err := deviceKey(circuit, &pk)
+	if err != nil {
+		return snark.Proof{}, err
+	}
+	defer unpin(e)
+	order := snark.Utils.FqR.Q
+	var p gosnarkhip.PinocchioProof
+	t, err := e.key.ProveHostBegin(w, px, order)
+	if ge, ok := err.(*gosnarkhip.Error); ok && ge.Busy() {
+		p, err = e.key.Prove(w, px, order)
+	} else if err == nil {
+		p, err = gosnarkhip.PinocchioProveEnd(t)
+	}
+	if err != nil {
+		return snark.Proof{}, err
+	}
+	return toProof(p), nil
 }
 
 // GenerateProofsFromWitness is GenerateProofs for callers that have not computed px (the reference's callers run
 // R1CSToQAP + CombinePolynomials on the CPU first, cli/main.go:330-349): circuit.R1CS is uploaded once per key and
-// H(x) comes from the constraint values of the witness on the device.  C call sequence: tests/c/witness_to_proof.c.
+// H(x) comes from the constraint values of the witness on the device.  Round 6: the witness goes over as a host-buffer ticket
+// (no UploadScalars / Free per proof: that was a hipMalloc, a blocking copy and a hipFree each time).
+// C call sequence: tests/c/witness_to_proof.c (resident form), tests/c/stream_host.c (host-buffer form used here).
 func GenerateProofsFromWitness(circuit circuitcompiler.Circuit, pk snark.Pk, w []*big.Int) (snark.Proof, error) {
-	var proof snark.Proof
 	order := snark.Utils.FqR.Q
 	e, err := deviceKey(circuit, &pk)
 	if err != nil {
-		return proof, err
+		return snark.Proof{}, err
 	}
 	defer unpin(e)
-	k := e.key
 	q, err := deviceR1CS(circuit, e)
 	if err != nil {
-		return proof, err
+		return snark.Proof{}, err
 	}
-	wh, err := gosnarkhip.UploadScalars(Device, w, order)
+	var p gosnarkhip.PinocchioProof
+	t, err := e.key.ProveWitnessHostBegin(q, w, order)
+	if ge, ok := err.(*gosnarkhip.Error); ok && ge.Busy() {
+		p, err = e.key.ProveWitnessHost(q, w, order)
+	} else if err == nil {
+		p, err = gosnarkhip.PinocchioProveEnd(t)
+	}
 	if err != nil {
-		return proof, err
+		return snark.Proof{}, err
 	}
-	defer gosnarkhip.Free(wh)
-	p, err := k.ProveWitness(q, wh)
+	return toProof(p), nil
+}
+
+// Prover is the streaming drop-in (see groth16hip.Prover): one key, many witnesses, three proofs in flight, proofs back in
+// submission order.  C call sequence: tests/c/stream_producer.c (Groth16 twin) / tests/c/stream_host.c (the Pinocchio tickets).
+type Prover struct {
+	e *entry
+	p *gosnarkhip.PinocchioProver
+}
+
+func NewProver(circuit circuitcompiler.Circuit, pk snark.Pk) (*Prover, error) {
+	e, err := deviceKey(circuit, &pk)
 	if err != nil {
-		return proof, err
+		return nil, err
 	}
-	proof.PiA, proof.PiAp, proof.PiB, proof.PiBp = p.PiA, p.PiAp, p.PiB, p.PiBp
-	proof.PiC, proof.PiCp, proof.PiH, proof.PiKp = p.PiC, p.PiCp, p.PiH, p.PiKp
-	return proof, nil
+	var q *gosnarkhip.R1CS
+	if len(circuit.R1CS.A) != 0 {
+		if q, err = deviceR1CS(circuit, e); err != nil {
+			unpin(e)
+			return nil, err
+		}
+	}
+	return &Prover{e: e, p: gosnarkhip.NewPinocchioProver(e.key, q, snark.Utils.FqR.Q)}, nil
+}
+
+// Submit begins the proof of w (px == nil: H(x) from circuit.R1CS on the device); the slices are consumed when it returns.
+func (p *Prover) Submit(w, px []*big.Int) error { return p.p.Submit(w, px) }
+func (p *Prover) InFlight() int                  { return p.p.InFlight() }
+func (p *Prover) Collect() (snark.Proof, error) {
+	g, err := p.p.Collect()
+	if err != nil {
+		return snark.Proof{}, err
+	}
+	return toProof(g), nil
+}
+func (p *Prover) Close() {
+	if p.e != nil {
+		p.p.Close()
+		unpin(p.e)
+		p.e = nil
+	}
 }
 
 func deviceR1CS(circuit circuitcompiler.Circuit, e *entry) (*gosnarkhip.R1CS, error) {

@@ -1268,6 +1268,40 @@ def test_keys_with_sparse_b_arrays_sum_b1_and_b2_over_a_masked_plan(n):
     assert same(groth16.finish(pk, parallel.combine_partials(parts, groth16.SUM_IS_G2), r, s))
 
 
+@pytest.mark.parametrize("cbits", [15, 17, 18, 19])
+def test_sparse_b_keys_under_every_forced_window_width(cbits):
+    """the split of B1 / B2 onto their own term-list plan was gated on `c < 19` while build_plan sorts
+    partition-first -- a sort that takes no term list -- from c = 18 on (B = 2^17 buckets = 4 ranges of 2^15), so gs_set_window_bits(18)
+    on a sparse-B key with its tables resident failed EVERY proof of both protocols with GS_ERR_HIP.  The gate now asks build_plan's own
+    condition (msm.h, plan_partitions_first): 15 and 17 split, 18 and 19 keep the single plan, all four give the proof of the automatic
+    width; the table-free route clamps a forced width to its 9..16 and always splits."""
+    from gosnark_amd import synth
+    n = 1 << 13
+    inst = synth.gates_setup_instance(n, 0x9400)
+    pin = synth.gates_pinocchio_instance(n, 0x9401)
+    pk, ppk = inst.device_pk(), pin.device_pk()
+    r, s = synth.field_elems(2, 9400)
+    want = groth16.prove_resident(pk, inst.w, inst.px, r, s)
+    pwant = snark.prove_resident(ppk, pin.w, pin.px)
+    x = capi.u64_to_ints(inst.w_host[1:2])[0]
+    assert groth16.VerifyProof(inst.vk, want, [x]) and snark.VerifyProof(pin.vk, pwant, pin.public)
+    capi.set_window_bits(cbits)
+    try:
+        got = groth16.prove_resident(pk, inst.w, inst.px, r, s)
+        tm = capi.last_timing()
+        pgot = snark.prove_resident(ppk, pin.w, pin.px)
+        t = [groth16.prove_host_begin(pk, inst.w_host, inst.px_host, r, s), groth16.prove_begin(pk, inst.w, inst.px, r, s)]
+        tick = [groth16.prove_end(k) for k in t]
+    finally:
+        capi.set_window_bits(0)
+    assert (got.PiA, got.PiB, got.PiC) == (want.PiA, want.PiB, want.PiC)
+    assert all((p.PiA, p.PiB, p.PiC) == (want.PiA, want.PiB, want.PiC) for p in tick)
+    assert all(getattr(pgot, k) == getattr(pwant, k) for k in snark.Proof.FIELDS)
+    windows = 254 // tm["window_bits"] + 1
+    split = tm["acc_g2_adds"] < 0.5 * windows * n
+    assert split == (tm["window_bits"] < 18), (cbits, tm["window_bits"], tm["acc_g2_adds"])
+
+
 @pytest.mark.parametrize("finite", ["none", "one", "54%", "56%", "all"])
 def test_b_mask_edge_densities(finite):
     """The masked plan at its edges: a key whose B arrays hold NO finite point (the masked plan is empty: every kernel behind it sees zero

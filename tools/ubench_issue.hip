@@ -11,6 +11,9 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
+#include <algorithm>
+#include <chrono>
+#include <cstdlib>
 #include <vector>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 constexpr int ITERS = 1000;
@@ -43,6 +46,11 @@ constexpr int ITERS = 1000;
 #define I_BFE(r) "v_bfe_u32 " #r ", " #r ", 1, 29"
 #define I_SHR64(r) "v_lshrrev_b64 " #r ", 1, " #r
 #define I_ADD64(r) "v_lshl_add_u64 " #r ", " #r ", 0, " #r
+#define I_FMA64(r) "v_fma_f64 " #r ", " #r ", %4, %4"        /* f <- f / 2 + 1 / 2: stays finite */
+#define I_MULHI24(r) "v_mul_hi_u32_u24 " #r ", " #r ", " #r
+#define I_MAD24(r) "v_mad_u32_u24 " #r ", " #r ", " #r ", " #r
+#define I_MUL24(r) "v_mul_u32_u24 " #r ", " #r ", " #r
+#define I_MULHI(r) "v_mul_hi_u32 " #r ", " #r ", " #r
 #define NOP4 asm volatile("s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n")
 
 // instructions of the mode's class(es) one wave issues per loop iteration
@@ -51,11 +59,14 @@ __host__ __device__ constexpr int per_iter(int mode) {
 }
 
 template <int MODE>
-__global__ void __launch_bounds__(256, 3) k_issue(uint32_t* out, unsigned long long* cyc, uint32_t seed) {
+__global__ void __launch_bounds__(256, 3) k_issue(uint32_t* out, unsigned long long* cyc, uint32_t seed, unsigned long long* real) {
   uint32_t x = seed + threadIdx.x, y = seed * 3u + blockIdx.x;
   uint64_t a0 = x, a1 = y, a2 = 3, a3 = 4, a4 = 5, a5 = 6, a6 = 7, a7 = 8;
   uint32_t c0 = x, c1 = y, c2 = x ^ y, c3 = 11;
   uint64_t d0 = x, d1 = y, d2 = 5, d3 = 9;
+  double f0 = 1.0 + x * 1e-9, f1 = 1.0 + y * 1e-9, f2 = 0.999999, f3 = 1.000001;
+  const double fh = 0.5;
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();        // the constant 100 MHz counter: the wave's own wall time
   const unsigned long long t0 = __builtin_amdgcn_s_memtime();
   for (int it = 0; it < ITERS; ++it) {
     if constexpr (MODE == 0) {
@@ -86,6 +97,18 @@ __global__ void __launch_bounds__(256, 3) k_issue(uint32_t* out, unsigned long l
     } else if constexpr (MODE == 11) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) NOP4;
+    } else if constexpr (MODE >= 18 && MODE <= 22) {
+      // round 6: the instructions the rejected representations would be made of -- f64 FMA on 52-bit limbs
+      // (v_fma_f64, 4 independent chains like OTHER4_64), 24-bit limbs (v_mul_hi_u32_u24 / v_mad_u32_u24 / v_mul_u32_u24), and the
+      // high half of a 32 x 32 product (v_mul_hi_u32) that a saturated-limb product needs
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if (MODE == 18) asm volatile(I_FMA64(%0) "\n" I_FMA64(%1) "\n" I_FMA64(%2) "\n" I_FMA64(%3) "\n" : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3) : "v"(fh));
+        if (MODE == 19) OTHER4(I_MULHI24);
+        if (MODE == 20) OTHER4(I_MAD24);
+        if (MODE == 21) OTHER4(I_MUL24);
+        if (MODE == 22) OTHER4(I_MULHI);
+      }
     } else if constexpr (MODE == 16 || MODE == 17) {
       // multiply-adds whose multiplicands come from 2 x 9 DIFFERENT registers, like acc += a[i] * b[j] of a product (the modes above
       // multiply the same two registers all the time): does the register file's banking cost issue cycles?  16: 8 chains, 17: 2 chains
@@ -173,19 +196,31 @@ __global__ void __launch_bounds__(256, 3) k_issue(uint32_t* out, unsigned long l
     }
   }
   const unsigned long long t1 = __builtin_amdgcn_s_memtime();
-  if (threadIdx.x % 64 == 0) cyc[(blockIdx.x * blockDim.x + threadIdx.x) / 64] = t1 - t0;
-  out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)(a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7) ^ c0 ^ c1 ^ c2 ^ c3 ^ (uint32_t)(d0 ^ d1 ^ d2 ^ d3);
+  const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+  if (threadIdx.x % 64 == 0) { cyc[(blockIdx.x * blockDim.x + threadIdx.x) / 64] = t1 - t0; real[(blockIdx.x * blockDim.x + threadIdx.x) / 64] = r1 - r0; }
+  out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)(a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7) ^ c0 ^ c1 ^ c2 ^ c3 ^ (uint32_t)(d0 ^ d1 ^ d2 ^ d3) ^ (uint32_t)__double_as_longlong(f0 + f1 + f2 + f3);
 }
 
+// g_seconds > 0 (argv: <mode> <seconds>): keep launching ONE mode for that long, so that a power / clock sampler beside the process
+// (tools/power_trace.py) sees a steady state; the line then reports the LAST launch
+static double g_seconds = 0;
+static int g_only = -1;
+// argv[3] = CUs: run on a stream restricted to that many CUs (hipExtStreamCreateWithCUMask; 3 workgroups = 3 waves per SIMD on each of
+// them, the rest of the chip idle).  Round 6: if an instruction costs the same WALL time on 8 CUs as on 256, its price is not set by a
+// chip-wide power or current limit.
+static hipStream_t g_stream = nullptr;
+static unsigned long long* g_real = nullptr;
 template <int MODE>
 int run(const char* what, uint32_t* dout, unsigned long long* dcyc, int blocks) {
+  if (g_only >= 0 && g_only != MODE) return 0;
   hipEvent_t a, b;
   CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
   float ms = 0;
-  for (int rep = 0; rep < 3; ++rep) {
-    CK(hipEventRecord(a));
-    hipLaunchKernelGGL(k_issue<MODE>, dim3(blocks), dim3(256), 0, 0, dout, dcyc, 12345u + rep);
-    CK(hipEventRecord(b)); CK(hipEventSynchronize(b)); CK(hipEventElapsedTime(&ms, a, b));
+  const auto t_begin = std::chrono::steady_clock::now();
+  for (int rep = 0; rep < 3 || std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count() < g_seconds; ++rep) {
+    CK(hipEventRecord(a, g_stream));
+    hipLaunchKernelGGL(k_issue<MODE>, dim3(blocks), dim3(256), 0, g_stream, dout, dcyc, 12345u + rep, g_real);
+    CK(hipEventRecord(b, g_stream)); CK(hipEventSynchronize(b)); CK(hipEventElapsedTime(&ms, a, b));
   }
   const int waves = blocks * 4;
   std::vector<unsigned long long> h(waves);
@@ -193,21 +228,46 @@ int run(const char* what, uint32_t* dout, unsigned long long* dcyc, int blocks) 
   double sum = 0;
   for (auto v : h) sum += (double)v;
   const double wave_cycles = sum / waves;                                 // one wave's span; its SIMD carried 3 such waves in it
-  const double per_instr = wave_cycles / (3.0 * ITERS * per_iter(MODE));
-  printf("%-44s %7.3f ms  %7.3f real cycles per instruction per SIMD  (wave span %.0f cycles -> %.2f GHz effective)\n", what, ms, per_instr, wave_cycles,
-         wave_cycles / (ms * 1e-3) / 1e9);
+  std::vector<unsigned long long> hr(waves);
+  CK(hipMemcpy(hr.data(), g_real, waves * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  double rsum = 0, cmax = 0, cmin = 1e300;
+  for (auto v : hr) rsum += (double)v;
+  for (auto v : h) { cmax = std::max(cmax, (double)v); cmin = std::min(cmin, (double)v); }
+  const double wave_ns = rsum / waves * 10.0;                               // s_memrealtime ticks at 100 MHz
+  const double ghz = wave_cycles / wave_ns;                                 // the clock s_memtime really ticks at: 2.38-2.40 GHz in every loop
+  const double instr = 3.0 * ITERS * per_iter(MODE);                        // instructions a SIMD's three waves issue
+  // Round 6: the three waves of a SIMD do NOT finish together -- issue is oldest-first, the first wave is done after ~40 % of the
+  // kernel, the second after ~70 % (tools/ubench_placement.hip) -- so only the LONGEST span (= the kernel) covers all three waves'
+  // instructions.  Round 5 divided the MEAN span by them ("3.15 real cycles per v_mad_u64_u32") and then the mean span by the
+  // kernel's time ("1.2-1.6 GHz"): both wrong.  Cycles per instruction per SIMD = longest span / instructions; the clock is sclk.
+  printf("%-44s kernel %7.3f ms | %6.3f cycles per instruction per SIMD (longest wave span %.0f cycles / %.0f instructions; kernel time x %.2f GHz gives %.3f) | "
+         "first wave done after %.0f %%, mean wave after %.0f %% of the longest span | s_memtime / s_memrealtime = %.2f GHz\n",
+         what, ms, cmax / instr, cmax, instr, ghz, ms * 1e6 * ghz / instr, 100.0 * cmin / cmax, 100.0 * wave_cycles / cmax, ghz);
   return 0;
 }
 
-int main() {
+int main(int argc, char** argv) {
+  if (argc >= 3) { g_only = atoi(argv[1]); g_seconds = atof(argv[2]); }
   CK(hipSetDevice(0));
   hipDeviceProp_t prop;
   CK(hipGetDeviceProperties(&prop, 0));
-  const int blocks = prop.multiProcessorCount * 3;          // 12 waves per CU = 3 per SIMD, one round
+  int blocks = prop.multiProcessorCount * 3;                // 12 waves per CU = 3 per SIMD, one round
+  if (argc >= 4 && atoi(argv[3]) > 0) {
+    const int cus = atoi(argv[3]);
+    std::vector<uint32_t> mask((prop.multiProcessorCount + 31) / 32, 0u);
+    for (int i = 0; i < cus; ++i) {                         // spread over the mask: one CU per XCD first (the mask interleaves XCDs)
+      const int bit = (int)((long long)i * prop.multiProcessorCount / cus);
+      mask[bit / 32] |= 1u << (bit % 32);
+    }
+    CK(hipExtStreamCreateWithCUMask(&g_stream, (uint32_t)mask.size(), mask.data()));
+    blocks = cus * 3;
+    printf("stream restricted to %d of %d CUs, %d workgroups\n", cus, prop.multiProcessorCount, blocks);
+  }
   uint32_t* dout;
   unsigned long long* dcyc;
   CK(hipMalloc(&dout, (size_t)blocks * 256 * 4));
   CK(hipMalloc(&dcyc, (size_t)blocks * 4 * 8));
+  CK(hipMalloc(&g_real, (size_t)blocks * 4 * 8));
   printf("%s, %d CUs, 3 waves per SIMD, %d iterations; cycles from s_memtime, clock = span / wall time\n", prop.gcnArchName, prop.multiProcessorCount, ITERS);
   run<0>("v_mad_u64_u32 (8 chains)", dout, dcyc, blocks);
   run<1>("v_lshrrev_b64 (VOP3)", dout, dcyc, blocks);
@@ -227,5 +287,10 @@ int main() {
   run<15>("mix, 2 chains, the other ops depend on them", dout, dcyc, blocks);
   run<16>("64 mad on 8 chains, multiplicands from 2 x 9 registers (+ 18 setup ops)", dout, dcyc, blocks);
   run<17>("64 mad on 2 chains, multiplicands from 2 x 9 registers (+ 18 setup ops)", dout, dcyc, blocks);
+  run<18>("v_fma_f64 (4 chains)", dout, dcyc, blocks);
+  run<19>("v_mul_hi_u32_u24 (VOP2)", dout, dcyc, blocks);
+  run<20>("v_mad_u32_u24 (VOP3)", dout, dcyc, blocks);
+  run<21>("v_mul_u32_u24 (VOP2)", dout, dcyc, blocks);
+  run<22>("v_mul_hi_u32 (VOP3)", dout, dcyc, blocks);
   return 0;
 }

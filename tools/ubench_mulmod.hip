@@ -8,6 +8,9 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
+#include <algorithm>
+#include <chrono>
+#include <cstdlib>
 #include <vector>
 #include "fp29.h"
 using namespace gs;
@@ -15,10 +18,14 @@ using namespace gs;
 constexpr int ITERS = 400;
 // round 5: every wave also brackets its loop with s_memtime (the shader clock), so the line reports REAL cycles per product per SIMD and
 // the clock the chip ran at, not wall time x a nominal 2.4 GHz
-__device__ unsigned long long g_span[65536];
-#define SPAN_BEGIN const unsigned long long t0_ = __builtin_amdgcn_s_memtime()
-#define SPAN_END do { const unsigned long long t1_ = __builtin_amdgcn_s_memtime(); \
-                      if (threadIdx.x % 64 == 0) g_span[(blockIdx.x * blockDim.x + threadIdx.x) / 64] = t1_ - t0_; } while (0)
+// round 6: ... and with s_memrealtime (constant 100 MHz), because the "clock" of round 5 -- mean wave span / kernel time -- was an artefact:
+// a SIMD issues oldest-first, its three waves finish after ~40 / 70 / 100 % of the kernel, so only the LONGEST span covers all the
+// products, and s_memtime ticks at sclk (2.38-2.40 GHz by s_memtime / s_memrealtime, = hwmon freq1_input) in every one of these loops
+__device__ unsigned long long g_span[65536], g_real[65536];
+#define SPAN_BEGIN const unsigned long long r0_ = __builtin_amdgcn_s_memrealtime(), t0_ = __builtin_amdgcn_s_memtime()
+#define SPAN_END do { const unsigned long long t1_ = __builtin_amdgcn_s_memtime(), r1_ = __builtin_amdgcn_s_memrealtime(); \
+                      if (threadIdx.x % 64 == 0) { g_span[(blockIdx.x * blockDim.x + threadIdx.x) / 64] = t1_ - t0_; \
+                                                   g_real[(blockIdx.x * blockDim.x + threadIdx.x) / 64] = r1_ - r0_; } } while (0)
 
 #if defined(__HIP_DEVICE_COMPILE__)
 #define MAD(acc, a, b) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b) : "vcc")
@@ -143,7 +150,10 @@ __global__ void __launch_bounds__(256, 3) k_asm(const uint32_t* in, uint32_t* ou
 }
 
 typedef void (*kern_t)(const uint32_t*, uint32_t*);
-int main() {
+// argv: <variant index 0..5> <seconds>: keep launching that one variant for that long (a steady state for tools/power_trace.py)
+int main(int argc, char** argv) {
+  const int only = argc >= 3 ? atoi(argv[1]) : -1;
+  const double seconds = argc >= 3 ? atof(argv[2]) : 0;
   hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
   const int blocks = prop.multiProcessorCount * 3, threads = 256;          // 3 waves per SIMD
   const size_t nthreads = (size_t)blocks * threads;
@@ -159,28 +169,36 @@ int main() {
   std::vector<uint32_t> ref, got(nthreads * 3 * NL);
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   printf("device %s, %d blocks x %d threads, %d products per thread\n", prop.name, blocks, threads, 3 * ITERS);
+  int index = -1;
   for (auto& e : es) {
+    if (only >= 0 && ++index != only) continue;
     hipLaunchKernelGGL(e.k, dim3(blocks), dim3(threads), 0, 0, din, dout);
     CK(hipDeviceSynchronize());
-    CK(hipEventRecord(e0));
-    hipLaunchKernelGGL(e.k, dim3(blocks), dim3(threads), 0, 0, din, dout);
-    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
-    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    float ms = 0;
+    const auto t_begin = std::chrono::steady_clock::now();
+    do {
+      CK(hipEventRecord(e0));
+      hipLaunchKernelGGL(e.k, dim3(blocks), dim3(threads), 0, 0, din, dout);
+      CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+      CK(hipEventElapsedTime(&ms, e0, e1));
+    } while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count() < seconds);
     CK(hipMemcpy(got.data(), dout, got.size() * 4, hipMemcpyDeviceToHost));
     // compare canonical residues: representatives may differ by multiples of p between variants? no -- same algorithm, same
     // intermediate values: bit-identical limbs expected
     bool same = true;
-    if (ref.empty()) ref = got; else same = ref == got;
+    if (ref.empty() || only >= 0) ref = got; else same = ref == got;
     const double prods = (double)nthreads * 3 * ITERS;
     const int waves = blocks * threads / 64;
-    std::vector<unsigned long long> span(waves);
+    std::vector<unsigned long long> span(waves), real(waves);
     CK(hipMemcpyFromSymbol(span.data(), HIP_SYMBOL(g_span), waves * sizeof(unsigned long long)));
-    double sum = 0;
-    for (auto v : span) sum += (double)v;
-    const double wave_span = sum / waves;                       // 3 waves per SIMD, each does 3 * ITERS products in its span
-    printf("%-28s %8.3f ms  %7.2f G mulmod/s  %6.1f cycles per product per SIMD @2.4GHz | REAL %6.1f cycles per product per SIMD at %.2f GHz   %s\n", e.name, ms,
-           prods / ms / 1e6, ms * 1e-3 * 2.4e9 * prop.multiProcessorCount * 4 / (prods / 64), wave_span / (3.0 * 3 * ITERS), wave_span / (ms * 1e-3) / 1e9,
-           same ? "results identical" : "RESULTS DIFFER");
+    CK(hipMemcpyFromSymbol(real.data(), HIP_SYMBOL(g_real), waves * sizeof(unsigned long long)));
+    double sum = 0, rsum = 0, longest = 0;
+    for (auto v : span) { sum += (double)v; longest = std::max(longest, (double)v); }
+    for (auto v : real) rsum += (double)v;
+    const double ghz = sum / (rsum * 10.0);                     // s_memtime ticks per ns of the waves' own wall time
+    printf("%-28s %8.3f ms  %7.2f G mulmod/s | %6.1f cycles per product per SIMD (longest wave span / %d products of 3 waves; kernel time x %.2f GHz: %.1f) | "
+           "mean wave span %.0f %% of the longest | %s\n", e.name, ms, prods / ms / 1e6, longest / (3.0 * 3 * ITERS), 3 * 3 * ITERS, ghz,
+           ms * 1e6 * ghz / (3.0 * 3 * ITERS), 100.0 * sum / waves / longest, same ? "results identical" : "RESULTS DIFFER");
   }
   return 0;
 }

@@ -1,0 +1,81 @@
+// Where do the waves of a "3 workgroups per CU" launch really run, and when?  (Round 6: every "cycles per instruction per SIMD" of
+// tools/ubench_issue.hip / ubench_mulmod.hip assumes 3 waves on every SIMD for the whole kernel; the kernels' event time is 1.4-1.5 x
+// the waves' own s_memrealtime span, so either the waves do not run at the same time or they are not spread 3 per SIMD.)
+// Every wave records s_memrealtime at its first and last instruction, HW_REG_HW_ID (wave / SIMD / CU / SH / SE) and HW_REG_XCC_ID; the
+// host prints the histogram of waves per SIMD, the number of SIMDs used, and the timeline (start and end percentiles in microseconds
+// from the first wave's start) for the multiply-add loop of ubench_issue (mode 0) at 1, 2, 3 and 6 workgroups per CU.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/ubench_placement.hip -o tools/ubench_placement
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+constexpr int ITERS = 1000;
+struct Rec { unsigned long long r0, r1, t0, t1; uint32_t hw, xcc; };
+
+#define MAD8 asm volatile( \
+    "v_mad_u64_u32 %0, vcc, %8, %9, %0\n v_mad_u64_u32 %1, vcc, %8, %9, %1\n v_mad_u64_u32 %2, vcc, %8, %9, %2\n v_mad_u64_u32 %3, vcc, %8, %9, %3\n" \
+    "v_mad_u64_u32 %4, vcc, %8, %9, %4\n v_mad_u64_u32 %5, vcc, %8, %9, %5\n v_mad_u64_u32 %6, vcc, %8, %9, %6\n v_mad_u64_u32 %7, vcc, %8, %9, %7\n" \
+    : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(x), "v"(y) : "vcc")
+
+__global__ void __launch_bounds__(256, 3) k_mad(uint32_t* out, Rec* rec, uint32_t seed) {
+  uint32_t x = seed + threadIdx.x, y = seed * 3u + blockIdx.x;
+  uint64_t a0 = x, a1 = y, a2 = 3, a3 = 4, a4 = 5, a5 = 6, a6 = 7, a7 = 8;
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime(), t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) MAD8;
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  if (threadIdx.x % 64 == 0) {
+    Rec& q = rec[(blockIdx.x * blockDim.x + threadIdx.x) / 64];
+    q.r0 = r0; q.r1 = r1; q.t0 = t0; q.t1 = t1;
+    q.hw = __builtin_amdgcn_s_getreg(4 | (31 << 11));          // HW_REG_HW_ID
+    q.xcc = __builtin_amdgcn_s_getreg(20 | (31 << 11));        // HW_REG_XCC_ID
+  }
+  out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)(a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7);
+}
+
+int main() {
+  CK(hipSetDevice(0));
+  hipDeviceProp_t prop;
+  CK(hipGetDeviceProperties(&prop, 0));
+  const int cus = prop.multiProcessorCount;
+  for (int per_cu : {1, 2, 3, 4, 6}) {
+    const int blocks = cus * per_cu, waves = blocks * 4;
+    uint32_t* dout; Rec* drec;
+    CK(hipMalloc(&dout, (size_t)blocks * 256 * 4)); CK(hipMalloc(&drec, (size_t)waves * sizeof(Rec)));
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    float ms = 0;
+    for (int rep = 0; rep < 3; ++rep) {
+      CK(hipEventRecord(a));
+      hipLaunchKernelGGL(k_mad, dim3(blocks), dim3(256), 0, 0, dout, drec, 777u + rep);
+      CK(hipEventRecord(b)); CK(hipEventSynchronize(b)); CK(hipEventElapsedTime(&ms, a, b));
+    }
+    std::vector<Rec> h(waves);
+    CK(hipMemcpy(h.data(), drec, waves * sizeof(Rec), hipMemcpyDeviceToHost));
+    unsigned long long first = ~0ull, last = 0;
+    std::map<uint64_t, int> per_simd, per_cu_count;
+    std::vector<double> starts, ends, spans, cyc;
+    for (auto& r : h) { first = std::min(first, r.r0); last = std::max(last, r.r1); }
+    for (auto& r : h) {
+      const uint32_t simd = (r.hw >> 4) & 3, cu = (r.hw >> 8) & 15, sh = (r.hw >> 12) & 1, se = (r.hw >> 13) & 7, xcc = r.xcc & 15;
+      const uint64_t cu_key = ((uint64_t)xcc << 16) | (se << 8) | (sh << 4) | cu;
+      per_simd[(cu_key << 4) | simd] += 1; per_cu_count[cu_key] += 1;
+      starts.push_back((r.r0 - first) * 0.01); ends.push_back((r.r1 - first) * 0.01); spans.push_back((r.r1 - r.r0) * 0.01); cyc.push_back((double)(r.t1 - r.t0));
+    }
+    std::map<int, int> hist;
+    for (auto& kv : per_simd) hist[kv.second] += 1;
+    auto pct = [](std::vector<double> v, double q) { std::sort(v.begin(), v.end()); return v[std::min(v.size() - 1, (size_t)(q * v.size()))]; };
+    double cs = 0; for (double v : cyc) cs += v;
+    printf("%d workgroups per CU (%d waves): kernel %.1f us (events); waves on %zu CUs / %zu SIMDs; waves per SIMD histogram:", per_cu, waves, ms * 1e3, per_cu_count.size(), per_simd.size());
+    for (auto& kv : hist) printf(" %dx%d", kv.first, kv.second);
+    printf("\n    starts us p0 %.1f p50 %.1f p90 %.1f p100 %.1f | ends us p0 %.1f p50 %.1f p100 %.1f | wave span us p5 %.1f p50 %.1f p95 %.1f | s_memtime cycles per wave mean %.0f -> %.3f cycles per mad per wave\n",
+           pct(starts, 0), pct(starts, 0.5), pct(starts, 0.9), pct(starts, 1.0), pct(ends, 0), pct(ends, 0.5), pct(ends, 1.0), pct(spans, 0.05), pct(spans, 0.5), pct(spans, 0.95),
+           cs / waves, cs / waves / (64.0 * ITERS));
+    CK(hipFree(dout)); CK(hipFree(drec));
+  }
+  return 0;
+}
