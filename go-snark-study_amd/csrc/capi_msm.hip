@@ -84,13 +84,13 @@ int msm_resident(Ctx& c, Kind kind, gs_handle hb, size_t off, const uint32_t* sc
   if (!b->table) b->table = std::make_shared<BaseTable>();
   BaseTable* tab = static_cast<BaseTable*>(b->table.get());
   int cbits = 0;
-  double credit = kBuildCreditPerUnitTerm * (T::kWords == 16 ? 2.76 : 1.0) * (double)n;      // policy auto: this call's instalment of the array's table
+  double credit = build_credit(T::kWords == 16 ? 2.76 : 1.0, n);      // policy auto: this call's instalment of the array's table
   const bool tabled = prepare_tables(c, {TableRef{tab, b->buf.as<uint32_t>(), b->n, T::kWords == 16}}, (uint32_t)n, &cbits, &credit);
   PhaseTimer total(c.stream);
   MsmPlan plan;
   {
     PhaseTimer tp(c.stream);
-    build_plan(c, 2 * Ctx::kBlockingSlot, scalars_dev, (uint32_t)n, plan, {{1, T::kWords == 16}}, cbits, !tabled);
+    build_plan(c, 2 * c.blocking_slot(), scalars_dev, (uint32_t)n, plan, {{1, T::kWords == 16}}, cbits, !tabled);
     tp.stop();
     c.timing.plan_ms += tp.ms();
   }
@@ -122,6 +122,7 @@ struct MsmInFlight : InFlightBase {
     GS_HIP(hipEventCreateWithFlags(&planned, hipEventDisableTiming));
     GS_HIP(hipEventCreateWithFlags(&done, hipEventDisableTiming));
   }
+  void wait_device() const override { if (done) GS_HIP(hipEventSynchronize(done)); }
   ~MsmInFlight() override { for (hipEvent_t e : {planned, done}) if (e) (void)hipEventDestroy(e); }
 };
 
@@ -137,7 +138,7 @@ int msm_begin(Ctx& c, Kind kind, gs_handle hb, size_t off, gs_handle hs, size_t 
   if (!b->table) b->table = std::make_shared<BaseTable>();
   BaseTable* tab = static_cast<BaseTable*>(b->table.get());
   int cbits = 0;
-  double credit = kBuildCreditPerUnitTerm * (T::kWords == 16 ? 2.76 : 1.0) * (double)n;      // policy auto: this call's instalment of the array's table
+  double credit = build_credit(T::kWords == 16 ? 2.76 : 1.0, n);      // policy auto: this call's instalment of the array's table
   const bool tabled = prepare_tables(c, {TableRef{tab, b->buf.as<uint32_t>(), b->n, T::kWords == 16}}, (uint32_t)n, &cbits, &credit);
   auto st = std::make_unique<MsmInFlight>();
   st->g2 = T::kWords == 16;
@@ -183,7 +184,7 @@ int msm_end(Ctx& c, uint64_t ticket, uint64_t* out_affine, int* is_inf) {
   if (parity < 0) return fail(GS_ERR_ARG, "gs_msm_end: unknown ticket %llu", (unsigned long long)ticket);
   MsmInFlight* st = dynamic_cast<MsmInFlight*>(c.inflight[parity].get());
   if (!st) return fail(GS_ERR_ARG, "gs_msm_end: ticket %llu belongs to a proof (use gs_groth16_prove_end)", (unsigned long long)ticket);
-  std::unique_ptr<InFlightBase> base = std::move(c.inflight[parity]);
+  std::shared_ptr<InFlightBase> base = std::move(c.inflight[parity]);
   GS_HIP(hipEventSynchronize(st->done));
   reset_timing(c);
   c.timing.plan_ms = st->tplan->ms();
@@ -541,6 +542,7 @@ int gs_msm_g2_begin(gs_handle bases, size_t off, gs_handle scalars, size_t soff,
   return guarded([&](Ctx& c) { return msm_begin<Fq2Tag>(c, Kind::G2Bases, bases, off, scalars, soff, n, ticket); }, true, true, bases);
 }
 int gs_msm_end(uint64_t ticket, uint64_t* out_affine, int* is_inf) {
+  wait_ticket_unlocked(ticket);          // the device wait, outside the context lock (runtime.h)
   return guarded([&](Ctx& c) { return msm_end(c, ticket, out_affine, is_inf); }, true, true, ticket);
 }
 

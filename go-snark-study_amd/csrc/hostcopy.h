@@ -26,6 +26,13 @@ class HostCopyPool {                       // process-wide; workers sleep on a c
     static HostCopyPool* p = new HostCopyPool();       // leaked on purpose: worker threads must not be joined from a static destructor
     return *p;
   }
+  // a train of jobs is coming (staged_h2d): the workers may watch for the next job instead of sleeping between two of them
+  struct Train {
+    Train() { get().trains_.fetch_add(1, std::memory_order_relaxed); }
+    ~Train() { get().trains_.fetch_sub(1, std::memory_order_relaxed); }
+    Train(const Train&) = delete;
+    Train& operator=(const Train&) = delete;
+  };
   // dst[0..n) = src[0..n), split over the workers and the calling thread; returns when every byte has been copied
   void copy(void* dst, const void* src, size_t n) {
     if (n < (256u << 10) || workers_.empty()) { memcpy(dst, src, n); return; }
@@ -74,9 +81,12 @@ class HostCopyPool {                       // process-wide; workers sleep on a c
     for (;;) {
       // a staged upload is a train of jobs ~0.3 ms apart: after a job, watch the piece counter for the next one for a while before
       // sleeping (a futex wake-up costs 50-100 us -- as long as a thread's whole share of a 16 MiB piece)
-      if (seen) {
+      // (only while a staged upload is in progress -- `trains_` is raised by staged_h2d for its duration -- so that seven
+      //  cores do not spin for 400 us after the LAST job of every upload, beside the host-side folds and the Go runtime)
+      if (seen && trains_.load(std::memory_order_relaxed) > 0) {
         const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(400);
-        while ((next_.load(std::memory_order_relaxed) >> 32) == seen && std::chrono::steady_clock::now() < until) cpu_relax();
+        while (trains_.load(std::memory_order_relaxed) > 0 && (next_.load(std::memory_order_relaxed) >> 32) == seen &&
+               std::chrono::steady_clock::now() < until) cpu_relax();
       }
       Job j;
       {
@@ -91,6 +101,8 @@ class HostCopyPool {                       // process-wide; workers sleep on a c
   static void cpu_relax() {
 #if defined(__x86_64__) || defined(__i386__)
     __builtin_ia32_pause();
+#else
+    std::this_thread::yield();
 #endif
   }
   std::vector<std::thread> workers_;
@@ -99,6 +111,7 @@ class HostCopyPool {                       // process-wide; workers sleep on a c
   Job job_;
   size_t left_ = 0;
   std::atomic<uint64_t> next_{0};
+  std::atomic<int> trains_{0};
   uint64_t generation_ = 0;
 };
 
@@ -114,6 +127,7 @@ inline void staged_h2d(Ctx& c, void* dst_dev, const void* src_host, size_t bytes
     if (!c.stage_ev[b]) GS_HIP(hipEventCreateWithFlags(&c.stage_ev[b], hipEventDisableTiming));
   }
   HostCopyPool& pool = HostCopyPool::get();
+  HostCopyPool::Train train;
   static const bool trace = run_flag("GS_HOST_TRACE");
   auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   double t_wait = 0, t_copy = 0, t_submit = 0;

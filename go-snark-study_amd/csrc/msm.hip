@@ -83,7 +83,9 @@ static uint32_t choose_chunk(uint64_t entries, uint32_t nbuckets, const std::vec
   // (development builds: another chunk size for plans whose only user is ONE G1 launch of one base array -- the sum over h)
   static const int forced_h = (int)dev_knob("GS_CHUNK_H", 0, 4, 1024, 4);
   if (forced_h && users.size() == 1 && users[0].njobs == 1 && !users[0].g2) return (uint32_t)forced_h;
-  uint32_t chunk = entries >= (1ull << 23) ? 32u : 16u;
+  // (round 6: 64 from 2^27 entries on -- 2^24 constraints table-free.  Every chunk owns a head and a tail partial, 288 B for G1 and 576 B
+  //  for G2: with 32-entry chunks the partials of ONE ticket slot were 17 GB at 2^24, half of what stood between the library and 2^25)
+  uint32_t chunk = entries >= (1ull << 27) ? 64u : entries >= (1ull << 23) ? 32u : 16u;
   while (chunk < 1024u && entries / std::max<uint32_t>(nbuckets, 1u) > 32ull * chunk) chunk *= 2;
   return chunk;
 }
@@ -278,11 +280,14 @@ template <class T>
 static void enqueue_pending_slabs(Ctx& c, BaseTable& t, size_t first, size_t last, size_t slab) {
   enqueue_table_slabs<T>(c.main_stream, msm_state(c).table_scratch_bg, t.pending_src, t.pending_n, t.pending_c, t.pending, first, last, slab);
 }
-static size_t instalment_slab(size_t n) {
-  // whole launches of >= 2^12 points (16 workgroups), eight or more per table, at most GS_TABLE_BG_SLAB_LOG2 (2^17: 512 workgroups)
-  static const size_t cap = (size_t)1 << run_knob("GS_TABLE_BG_SLAB_LOG2", 17, 10, 18);
-  size_t s = (n / 8 + 255) & ~(size_t)255;
-  return std::min(cap, std::max<size_t>(s, (size_t)1 << 12));
+static size_t instalment_slab(size_t n, bool g2) {
+  // As LARGE as possible: a builder thread walks its point through 14 x 17 dependent doublings, ~1.3 ms for a lone wave whatever the
+  // slab holds, so a slab must fill the chip to be worth its launch.  2^18 points for G1 (4 waves per SIMD: 5 ms) and 2^17 for G2
+  // (5.7 ms), the whole table when it is smaller (GS_TABLE_BG_SLAB_LOG2 caps the G1 figure).  Measured on fresh keys
+  // (profiles/r06_auto_instalments.txt): with slabs of n / 8 points a 2^16 key's tables took 75 ms of instalments instead of 9, and
+  // 2^17-point G1 slabs cost a 2^20 key 168 ms against the 130 ms `always` spends in 2^18-point launches.
+  static const size_t cap = (size_t)1 << run_knob("GS_TABLE_BG_SLAB_LOG2", 18, 10, 18);
+  return std::min(g2 ? std::max<size_t>(cap / 2, (size_t)1 << 12) : cap, std::max<size_t>(n, 1));
 }
 // all streams of the context wait for the table's last slab (accumulations run on the main stream, where the slabs are: this is for
 // whatever else may come to read a table)
@@ -329,7 +334,12 @@ static bool begin_pending(Ctx& c, BaseTable& t, const TableRef& r, int cbits) {
     // the slab scratch at its G2 size BEFORE the first launch: growing it later releases the old buffer, and hipFree waits for the
     // device -- for the slabs just enqueued (round 5: that, not the builds' share of the chip, was most of a second proof's 88 ms)
     constexpr size_t sw2 = PointIO<Fq2Tag>::kXyzzWords + PointIO<Fq2Tag>::kXyzzWords / 4;
-    if (W > 2) msm_state(c).table_scratch_bg.ensure(std::min(instalment_slab(r.n), std::max<size_t>(r.n, 1)) * (size_t)(W - 1) * sw2 * 4);
+    if (W > 2) {      // (a G1 slab may be twice a G2 slab's points, and a G1 point's scratch is half a G2 point's: the same bytes)
+      constexpr size_t sw1 = PointIO<FqTag>::kXyzzWords + PointIO<FqTag>::kXyzzWords / 4;
+      const size_t s2 = instalment_slab(r.n, true), s1 = instalment_slab(r.n, false);
+      const size_t bytes = std::max((s2 + s2 / 4) * sw2, (s1 + s1 / 4) * sw1);
+      msm_state(c).table_scratch_bg.ensure(bytes * (size_t)(W - 1) * 4);
+    }
     t.pending.alloc(std::max<size_t>(r.n, 1) * W * aw * 4);
   } catch (const HipError& e) {
     if (e.e != hipErrorOutOfMemory) throw;      // no room for a table: keep summing table-free
@@ -343,11 +353,16 @@ static bool begin_pending(Ctx& c, BaseTable& t, const TableRef& r, int cbits) {
 // spend credit on the next slabs of t's pending table; true when the last slab has been enqueued
 static bool advance_pending(Ctx& c, BaseTable& t, double& credit) {
   const double unit = t.pending_g2 ? kG2BuildCost : 1.0;
-  const size_t slab = instalment_slab(t.pending_n);
-  while (t.pending_next < t.pending_n && credit > 0) {
-    const size_t last = std::min(t.pending_n, t.pending_next + slab);
-    if (t.pending_g2) enqueue_pending_slabs<Fq2Tag>(c, t, t.pending_next, last, slab);
-    else enqueue_pending_slabs<FqTag>(c, t, t.pending_next, last, slab);
+  const size_t slab = instalment_slab(t.pending_n, t.pending_g2);
+  for (;;) {
+    if (t.pending_next >= t.pending_n) break;
+    // (a remainder of up to a quarter slab rides with the last one: a key of 2^k + 1 variables must not end on a one-point launch)
+    const size_t last = t.pending_n - t.pending_next <= slab + slab / 4 ? t.pending_n : t.pending_next + slab;
+    // a slab is bought when the credit covers at least half of it (the call overdraws by at most half a slab, ~2.5 ms at 2^20, and the
+    // next call's grant is that much smaller): the instalments of consecutive calls then differ by one slab at most
+    if (credit < 0.5 * (double)(last - t.pending_next) * unit) break;
+    if (t.pending_g2) enqueue_pending_slabs<Fq2Tag>(c, t, t.pending_next, last, last - t.pending_next);
+    else enqueue_pending_slabs<FqTag>(c, t, t.pending_next, last, last - t.pending_next);
     credit -= (double)(last - t.pending_next) * unit;
     t.pending_next = last;
   }
@@ -392,7 +407,8 @@ bool prepare_tables(Ctx& c, const std::vector<TableRef>& group, uint32_t nterms,
   if (c.table_policy == 0) {
     static const double scale = (double)run_knob("GS_TABLE_BUDGET_PCT", 100, 1, 1000000) / 100.0;
     // what this call may still enqueue: its grant (what an earlier group of the same call left of it) minus the last call's overdraft
-    double avail = (credit ? *credit : 0.0) * scale + c.build_balance;
+    const double grant = credit ? *credit : 0.0;
+    double avail = grant * scale + c.build_balance;
     // G2 arrays first: the G2 sum is the longest of a proof, so its table is the one that pays most per call
     std::vector<const TableRef*> order;
     for (const TableRef& r : group) if (r.g2) order.push_back(&r);
@@ -409,7 +425,7 @@ bool prepare_tables(Ctx& c, const std::vector<TableRef>& group, uint32_t nterms,
         if (t.uses < kTableAfterUses || !r.n || serving) continue;
         if (!begin_pending(c, t, r, cb)) continue;
       }
-      if (avail > 0 && advance_pending(c, t, avail)) install_enqueued(c, t);
+      if (advance_pending(c, t, avail)) install_enqueued(c, t);
     }
     c.build_balance = std::min(avail, 0.0);                       // an overdraft (less than one slab) comes off the next call's grant
     if (credit) *credit = std::max(avail, 0.0) / scale;           // the rest of the grant is the call's next group's
@@ -616,14 +632,14 @@ void msm_finish_g1(Ctx& c, const MsmPending& p, std::vector<G1Xyzz>& out) { msm_
 void msm_finish_g2(Ctx& c, const MsmPending& p, std::vector<G2Xyzz>& out) { msm_finish<Fq2Tag>(c, p, out); }
 void msm_run_g1(Ctx& c, const MsmPlan& plan, const std::vector<MsmBase>& bases, std::vector<G1Xyzz>& out) {
   MsmPending p;
-  msm_enqueue<FqTag>(c, plan, bases, 8 * Ctx::kBlockingSlot, 3 * Ctx::kBlockingSlot, p, nullptr);
+  msm_enqueue<FqTag>(c, plan, bases, 8 * c.blocking_slot(), 3 * c.blocking_slot(), p, nullptr);
   GS_HIP(hipStreamSynchronize(c.stream));
   msm_book_timing(c, p);
   msm_finish<FqTag>(c, p, out);
 }
 void msm_run_g2(Ctx& c, const MsmPlan& plan, const std::vector<MsmBase>& bases, std::vector<G2Xyzz>& out) {
   MsmPending p;
-  msm_enqueue<Fq2Tag>(c, plan, bases, 8 * Ctx::kBlockingSlot + 4, 3 * Ctx::kBlockingSlot, p, nullptr);
+  msm_enqueue<Fq2Tag>(c, plan, bases, 8 * c.blocking_slot() + 4, 3 * c.blocking_slot(), p, nullptr);
   GS_HIP(hipStreamSynchronize(c.stream));
   msm_book_timing(c, p);
   msm_finish<Fq2Tag>(c, p, out);

@@ -126,14 +126,26 @@ static long host_stage_mode() {
 // 8.7-8.9 -> 9.0-9.1: hence the rule.  GS_PLANW_STREAM: 0 never, 1 this rule, 2 always (identical results).
 struct ProofStreams {
   hipStream_t planw = nullptr, poly = nullptr, tail_g2 = nullptr, tail_g1 = nullptr;
+  bool poly_first = false;      // enqueue H(x) and plan(h) right behind plan(w), in front of the accumulations' tails (slot layout below)
 };
 struct DevScalars;
-static ProofStreams proof_streams(Ctx& c, bool pipelined, size_t nterms, bool from_witness) {
+// GS_SLOT_STREAMS (scheduling only, same results; round 6): 1 = a pipelined proof keeps ALL its side work -- plan(w), H(x), plan(h), then the
+// three reduction tails -- on the aux stream of its ticket slot, so the side chains of the three proofs in flight run beside each
+// other instead of queueing on one plan / polynomial stream.  For witnesses full of zeros and small values the accumulations of a 2^20
+// proof are 2.5 ms but plan(w) + H(x) + plan(h) of consecutive proofs on ONE stream take 3.6 ms per proof beside them
+// (profiles/r05_timeline_realistic_px_steady.txt: the accumulation stream idles 0.9 + 0.2 ms per proof waiting for a plan).  0 = the layouts above.
+static ProofStreams proof_streams(Ctx& c, bool pipelined, size_t nterms, bool from_witness, int parity) {
   static const long mode = run_knob("GS_PLANW_STREAM", 1, 0, 2);
-  const bool own = pipelined && c.aux_stream[2] != c.aux_stream[1] &&
-                   (mode == 2 || (mode == 1 && nterms >= ((size_t)1 << 19) && (from_witness || nterms >= ((size_t)1 << 21))));
+  static const long slot_mode = run_knob("GS_SLOT_STREAMS", 0, 0, 1);
   if (pipelined) c.next_tails((uint32_t)nterms);      // consecutive pipelined operations swap the two tail streams
   ProofStreams ps;
+  if (pipelined && slot_mode == 1 && parity >= 0 && parity < Ctx::kAuxStreams && c.aux_stream[parity] != c.main_stream) {
+    ps.planw = ps.poly = ps.tail_g2 = ps.tail_g1 = c.aux_stream[parity];
+    ps.poly_first = true;
+    return ps;
+  }
+  const bool own = pipelined && c.aux_stream[2] != c.aux_stream[1] &&
+                   (mode == 2 || (mode == 1 && nterms >= ((size_t)1 << 19) && (from_witness || nterms >= ((size_t)1 << 21))));
   ps.poly = c.aux_stream[1];
   ps.planw = own ? c.aux_stream[2] : c.aux_stream[1];
   ps.tail_g2 = own ? c.aux_stream[0] : c.tail_stream(0);
@@ -188,6 +200,10 @@ struct GrothInFlight : InFlightBase {
     GS_HIP(hipEventCreateWithFlags(&planh, hipEventDisableTiming));
     for (hipEvent_t* e : {&done_main, &done_g2, &done_g1w, &done_h, &planb, &done_g1b}) GS_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
   }
+  void wait_device() const override {
+    for (hipEvent_t e : {done_g2, done_g1w, done_h, done_main}) if (e) GS_HIP(hipEventSynchronize(e));
+    if (split_b && done_g1b) GS_HIP(hipEventSynchronize(done_g1b));
+  }
   ~GrothInFlight() override {
     if (fpre.valid()) fpre.wait();
     for (hipEvent_t e : {planw, planh, done_main, done_g2, done_g1w, done_h, planb, done_g1b}) if (e) (void)hipEventDestroy(e);
@@ -232,7 +248,7 @@ int groth16_enqueue(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, const S
   // every table of the call is stamped before one is built (an allocation for the first group must not evict the second group's), and
   // under policy `auto` the call grants itself a build credit for its ~6.8 job-units over w and h (msm.h, prepare_tables)
   stamp_tables(c, {&pk->t_at, &pk->t_bacgamma1, &pk->t_bacdelta, &pk->t_bacgamma2, eval ? &pk->t_ptd_eval : &pk->t_ptd});
-  double credit = kBuildCreditPerUnitTerm * (3.0 + 2.76 + 1.0) * (double)(whi - wlo);
+  double credit = build_credit(3.0 + 2.76 + 1.0, whi - wlo);
   const bool tab_w = prepare_tables(c, {TableRef{&pk->t_at, pk->at.as<uint32_t>(), pk->n_w, false}, TableRef{&pk->t_bacgamma1, pk->bacgamma1.as<uint32_t>(), pk->n_w, false},
                                         TableRef{&pk->t_bacdelta, pk->bacdelta.as<uint32_t>(), pk->n_w, false},
                                         TableRef{&pk->t_bacgamma2, pk->bacgamma2.as<uint32_t>(), pk->n_w, true}}, (uint32_t)(whi - wlo), &cw, &credit);
@@ -246,7 +262,7 @@ int groth16_enqueue(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, const S
   MsmPlan plan_w, plan_h;
   // The main stream carries NOTHING but the ALU-bound bucket accumulations (G2, then the three G1 arrays over w, then h),
   // so with two proofs in flight it never idles: both plans, H(x) and every combine/reduce tail run on the aux streams.
-  const ProofStreams ps = proof_streams(c, pipelined, whi - wlo, (bool)px.produce_hv || (bool)px.produce_hx || (bool)px.produce);   // (not hv_slice: no polynomial work here)
+  const ProofStreams ps = proof_streams(c, pipelined, whi - wlo, (bool)px.produce_hv || (bool)px.produce_hx || (bool)px.produce, parity);   // (not hv_slice: no polynomial work here)
   st.streams = ps;
   if (w.host && w.host_done) {                                   // host-buffer ticket, GS_HOST_STAGE=2: w is copied on the plan(w) stream itself
     staged_h2d(c, const_cast<uint32_t*>(w.p), w.host, w.n * 32, ps.planw);
@@ -285,7 +301,8 @@ int groth16_enqueue(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, const S
   }
   // Host order: the accumulations over w are enqueued BEFORE the block that may copy px from pageable host memory -- that copy
   // stages through the runtime inside the call (~5 ms for 64 MiB), and the device must already have its 7 ms of work by then.
-  {                                                              // main: the accumulations over w, back to back
+  // (Slot layout, ps.poly_first: everything of the proof's side chain first -- its tails follow on the same stream.)
+  auto enqueue_acc_w = [&] {                                     // main: the accumulations over w, back to back
     StreamScope sc(c, c.main_stream);
     GS_HIP(hipStreamWaitEvent(c.stream, st.split_b ? st.planb : st.planw, 0));
     // BACDelta's first npublic+1 entries are forced to infinity at key creation, so the reference's
@@ -304,10 +321,10 @@ int groth16_enqueue(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, const S
                      st.pend_g1w, ps.tail_g1);
     }
     GS_HIP(hipEventRecord(st.done_g1w, ps.tail_g1));
-  }
+  };
   // (Starting H(x) and plan(h) of a lone proof beside plan(w) on another stream instead of behind it was tried: the blocking proof
   // got SLOWER, 11.5-11.7 vs 11.0-11.25 ms -- the NTT passes then overlap the G2 accumulation's first milliseconds more densely.)
-  {                                                              // aux 1 again: (late upload of px,) H(x), plan(h)
+  auto enqueue_poly = [&] {                                      // aux 1 again: (late upload of px,) H(x), plan(h)
     StreamScope sc(c, ps.poly);
     if (px.host && px.n && px.host_stream) {   // host-buffer ticket: on the copy stream, beside whatever aux 1 still carries of the previous proof
       staged_h2d(c, const_cast<uint32_t*>(px.p), px.host, px.n * 32, px.host_stream);
@@ -343,7 +360,8 @@ int groth16_enqueue(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, const S
     build_plan(c, 1 + 2 * parity, px.hv_slice ? px.hv_slice : hxbuf.as<uint32_t>() + hlo * 8, (uint32_t)(hhi - hlo), plan_h, {{1, false}}, ch, !tab_h);
     st.tplanh->stop();
     GS_HIP(hipEventRecord(st.planh, c.stream));
-  }
+  };
+  if (ps.poly_first) { enqueue_poly(); enqueue_acc_w(); } else { enqueue_acc_w(); enqueue_poly(); }
   {                                                              // main again: the accumulation over h
     StreamScope sc(c, c.main_stream);
     GS_HIP(hipStreamWaitEvent(c.stream, st.planh, 0));
@@ -422,7 +440,7 @@ int groth16_collect(Ctx& c, GrothInFlight& st, GrothSums& sums) {
 int groth16_sums_impl(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, const Shard& shard, GrothSums& sums) {
   for (;;) {
     GrothInFlight st;
-    int rc = groth16_enqueue(c, pk, w, px, shard, Ctx::kBlockingSlot, true, false, st);
+    int rc = groth16_enqueue(c, pk, w, px, shard, c.blocking_slot(), true, false, st);
     if (rc != GS_OK) return rc;
     rc = groth16_collect(c, st, sums);
     if (rc != kRetryExact) return rc;
@@ -491,7 +509,7 @@ int groth16_prove_impl(Ctx& c, GrothPkObj* pk, DevScalars w, DevScalars px, cons
   {
     GrothInFlight st;
     st.early.pk = pk; st.early.r = r; st.early.s = s; st.early.pre = &pre; st.early.fpre = &fpre;
-    rc = groth16_enqueue(c, pk, w, px, Shard{}, Ctx::kBlockingSlot, true, false, st);
+    rc = groth16_enqueue(c, pk, w, px, Shard{}, c.blocking_slot(), true, false, st);
     t1 = host_trace() ? host_now_ms() : 0;
     if (rc == GS_OK) rc = groth16_collect(c, st, sums);
     early = st.early;
@@ -526,6 +544,10 @@ struct PinInFlight : InFlightBase {
   std::function<int(Ctx&, uint64_t*, int*)> exact_route;
   PinInFlight() {
     for (hipEvent_t* e : {&planw, &planh, &done_main, &done_g2, &done_g1w, &done_h, &planb, &done_g1b}) GS_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
+  }
+  void wait_device() const override {
+    for (hipEvent_t e : {done_g2, done_g1w, done_h, done_main}) if (e) GS_HIP(hipEventSynchronize(e));
+    if (split_b && done_g1b) GS_HIP(hipEventSynchronize(done_g1b));
   }
   ~PinInFlight() override {
     for (hipEvent_t e : {planw, planh, done_main, done_g2, done_g1w, done_h, planb, done_g1b}) if (e) (void)hipEventDestroy(e);
@@ -563,7 +585,7 @@ int pinocchio_enqueue(Ctx& c, PinocchioPkObj* pk, DevScalars w, DevScalars px, c
   int cw = 0, ch = 0;                          // window tables or table-free, per plan (as groth16_enqueue)
   auto ref1 = [&](BaseTable& t, const DevBuf& pts) { return TableRef{&t, pts.as<uint32_t>(), pk->n_w, false}; };
   stamp_tables(c, {&pk->t_a, &pk->t_ap, &pk->t_bp, &pk->t_c, &pk->t_cp, &pk->t_kp, &pk->t_b2, eval ? &pk->t_g1t_eval : &pk->t_g1t});      // as groth16_enqueue
-  double credit = kBuildCreditPerUnitTerm * (6.0 + 2.76 + 1.0) * (double)(whi - wlo);
+  double credit = build_credit(6.0 + 2.76 + 1.0, whi - wlo);
   const bool tab_w = prepare_tables(c, {ref1(pk->t_a, pk->a), ref1(pk->t_ap, pk->ap), ref1(pk->t_bp, pk->bp), ref1(pk->t_c, pk->c), ref1(pk->t_cp, pk->cp),
                                         ref1(pk->t_kp, pk->kp), TableRef{&pk->t_b2, pk->b2.as<uint32_t>(), pk->n_w, true}}, (uint32_t)(whi - wlo), &cw, &credit);
   const bool tab_h = prepare_tables(c, {eval ? TableRef{&pk->t_g1t_eval, pk->g1t_eval.as<uint32_t>(), pk->n_e, false}
@@ -573,7 +595,7 @@ int pinocchio_enqueue(Ctx& c, PinocchioPkObj* pk, DevScalars w, DevScalars px, c
   st.total = std::make_unique<PhaseTimer>(c.main_stream);
   const int ws = 8 * parity, pin = 3 * parity;
   MsmPlan plan_w, plan_h;
-  const ProofStreams ps = proof_streams(c, pipelined, whi - wlo, (bool)px.produce_hv || (bool)px.produce_hx || (bool)px.produce);
+  const ProofStreams ps = proof_streams(c, pipelined, whi - wlo, (bool)px.produce_hv || (bool)px.produce_hx || (bool)px.produce, parity);
   st.streams = ps;
   if (w.host && w.host_done) {                                   // host-buffer ticket, GS_HOST_STAGE=2: w is copied on the plan(w) stream itself
     staged_h2d(c, const_cast<uint32_t*>(w.p), w.host, w.n * 32, ps.planw);
@@ -603,7 +625,7 @@ int pinocchio_enqueue(Ctx& c, PinocchioPkObj* pk, DevScalars w, DevScalars px, c
     st.tplanw->stop();
     GS_HIP(hipEventRecord(st.planw, c.stream));
   }
-  {                                                              // main: the accumulations over w, back to back
+  auto enqueue_acc_w = [&] {                                     // main: the accumulations over w, back to back
     StreamScope sc(c, c.main_stream);
     GS_HIP(hipStreamWaitEvent(c.stream, st.split_b ? st.planb : st.planw, 0));
     // A and Ap run over i > NPublic only (snark.go:265-268): their first npublic+1 points were forced
@@ -621,8 +643,8 @@ int pinocchio_enqueue(Ctx& c, PinocchioPkObj* pk, DevScalars w, DevScalars px, c
                                  base_w(pk->t_cp, pk->cp), base_w(pk->t_kp, pk->kp)}, ws + 0, pin + 0, st.pend_g1w, ps.tail_g1);
     }
     GS_HIP(hipEventRecord(st.done_g1w, ps.tail_g1));
-  }
-  {                                                              // aux 1 again: H(x), plan(h)
+  };
+  auto enqueue_poly = [&] {                                      // aux 1 again: H(x), plan(h)
     StreamScope sc(c, ps.poly);
     if (px.host && px.n && px.host_stream) {   // host-buffer ticket: on the copy stream (groth16_enqueue)
       staged_h2d(c, const_cast<uint32_t*>(px.p), px.host, px.n * 32, px.host_stream);
@@ -658,7 +680,8 @@ int pinocchio_enqueue(Ctx& c, PinocchioPkObj* pk, DevScalars w, DevScalars px, c
     build_plan(c, 2 * parity + 1, px.hv_slice ? px.hv_slice : hxbuf.as<uint32_t>() + hlo * 8, (uint32_t)(hhi - hlo), plan_h, {{1, false}}, ch, !tab_h);
     st.tplanh->stop();
     GS_HIP(hipEventRecord(st.planh, c.stream));
-  }
+  };
+  if (ps.poly_first) { enqueue_poly(); enqueue_acc_w(); } else { enqueue_acc_w(); enqueue_poly(); }
   {                                                              // main again: the accumulation over h
     StreamScope sc(c, c.main_stream);
     GS_HIP(hipStreamWaitEvent(c.stream, st.planh, 0));
@@ -715,7 +738,7 @@ int pinocchio_collect(Ctx& c, PinInFlight& st, uint64_t out[72], int inf[8]) {
 int pinocchio_prove_impl(Ctx& c, PinocchioPkObj* pk, DevScalars w, DevScalars px, uint64_t out[72], int inf[8], const Shard& shard = Shard{}) {
   for (;;) {
     PinInFlight st;
-    int rc = pinocchio_enqueue(c, pk, w, px, shard, Ctx::kBlockingSlot, true, false, st);
+    int rc = pinocchio_enqueue(c, pk, w, px, shard, c.blocking_slot(), true, false, st);
     if (rc != GS_OK) return rc;
     rc = pinocchio_collect(c, st, out, inf);
     if (rc != kRetryExact) return rc;
@@ -1122,6 +1145,7 @@ int gs_groth16_prove_host_begin(gs_handle hpk, const uint64_t* w, size_t nw, con
 }
 
 int gs_groth16_prove_end(uint64_t ticket, uint64_t out_proof[32], int inf[3]) {
+  wait_ticket_unlocked(ticket);          // the device wait, outside the context lock (runtime.h)
   return guarded([&](Ctx& c) -> int {
     if (!out_proof || !inf) return fail(GS_ERR_ARG, "null argument");
     int parity = -1;
@@ -1131,7 +1155,7 @@ int gs_groth16_prove_end(uint64_t ticket, uint64_t out_proof[32], int inf[3]) {
       return fail(GS_ERR_ARG, "gs_groth16_prove_end: ticket %llu belongs to an MSM (use gs_msm_end)", (unsigned long long)ticket);
     if (!static_cast<GrothInFlight*>(c.inflight[parity].get())->with_tail)
       return fail(GS_ERR_ARG, "gs_groth16_prove_end: ticket %llu is a partial-sums operation (use gs_groth16_partials_end)", (unsigned long long)ticket);
-    std::unique_ptr<InFlightBase> base = std::move(c.inflight[parity]);
+    std::shared_ptr<InFlightBase> base = std::move(c.inflight[parity]);
     GrothInFlight& st = static_cast<GrothInFlight&>(*base);
     reset_timing(c);
     GrothSums sums;
@@ -1195,14 +1219,14 @@ static int witness_values_impl(Ctx& c, const char* fn, size_t nz, size_t n_eval,
   }
   StreamScope sc(c, c.aux_stream[1]);             // the stream that carries every proof's polynomial stage (gs_r1cs_px)
   PhaseTimer t(c.stream);
-  uint32_t* bad = c.bad_dev.as<uint32_t>() + Ctx::kBlockingSlot;
+  uint32_t* bad = c.bad_dev.as<uint32_t>() + c.blocking_slot();
   r1cs_values_dev(c, *o, w->buf.as<uint32_t>());
   r1cs_check_dev(c, o->vals.as<uint32_t>(), o->n, nz - 1, bad);
   hx_values_dev(c, o->vals.as<uint32_t>(), o->n, nz - 1, hv->buf.as<uint32_t>());
-  GS_HIP(hipMemcpyAsync(c.bad_host + Ctx::kBlockingSlot, bad, 4, hipMemcpyDeviceToHost, c.stream));
+  GS_HIP(hipMemcpyAsync(c.bad_host + c.blocking_slot(), bad, 4, hipMemcpyDeviceToHost, c.stream));
   t.stop();
   GS_HIP(hipStreamSynchronize(c.stream));
-  *violated = c.bad_host[Ctx::kBlockingSlot];
+  *violated = c.bad_host[c.blocking_slot()];
   if (!c.any_inflight()) reset_timing(c);
   c.timing.poly_ms = t.ms();
   c.timing.total_ms = c.timing.poly_ms;
@@ -1280,6 +1304,7 @@ int gs_groth16_partials_values_begin(gs_handle hpk, gs_handle hw, gs_handle hv_s
 }
 
 int gs_groth16_partials_end(uint64_t ticket, uint64_t out_sums[48], int inf[5]) {
+  wait_ticket_unlocked(ticket);          // the device wait, outside the context lock (runtime.h)
   return guarded([&](Ctx& c) -> int {
     if (!out_sums || !inf) return fail(GS_ERR_ARG, "null argument");
     int parity = -1;
@@ -1287,7 +1312,7 @@ int gs_groth16_partials_end(uint64_t ticket, uint64_t out_sums[48], int inf[5]) 
     if (parity < 0) return fail(GS_ERR_ARG, "gs_groth16_partials_end: unknown ticket %llu", (unsigned long long)ticket);
     GrothInFlight* g = dynamic_cast<GrothInFlight*>(c.inflight[parity].get());
     if (!g || g->with_tail) return fail(GS_ERR_ARG, "gs_groth16_partials_end: ticket %llu is not a partial-sums operation", (unsigned long long)ticket);
-    std::unique_ptr<InFlightBase> base = std::move(c.inflight[parity]);
+    std::shared_ptr<InFlightBase> base = std::move(c.inflight[parity]);
     reset_timing(c);
     GrothSums sums;
     const int rc = groth16_collect(c, *g, sums);
@@ -1426,6 +1451,7 @@ int gs_pinocchio_prove_host_begin(gs_handle hpk, const uint64_t* w, size_t nw, c
 }
 
 int gs_pinocchio_prove_end(uint64_t ticket, uint64_t out_proof[72], int inf[8]) {
+  wait_ticket_unlocked(ticket);          // the device wait, outside the context lock (runtime.h)
   return guarded([&](Ctx& c) -> int {
     if (!out_proof || !inf) return fail(GS_ERR_ARG, "null argument");
     int parity = -1;
@@ -1433,7 +1459,7 @@ int gs_pinocchio_prove_end(uint64_t ticket, uint64_t out_proof[72], int inf[8]) 
     if (parity < 0) return fail(GS_ERR_ARG, "gs_pinocchio_prove_end: unknown ticket %llu", (unsigned long long)ticket);
     if (!dynamic_cast<PinInFlight*>(c.inflight[parity].get()))
       return fail(GS_ERR_ARG, "gs_pinocchio_prove_end: ticket %llu is not a Pinocchio proof", (unsigned long long)ticket);
-    std::unique_ptr<InFlightBase> base = std::move(c.inflight[parity]);
+    std::shared_ptr<InFlightBase> base = std::move(c.inflight[parity]);
     PinInFlight& st = static_cast<PinInFlight&>(*base);
     reset_timing(c);
     int rc = pinocchio_collect(c, st, out_proof, inf);
@@ -1820,7 +1846,7 @@ int gs_groth16_prove_witness(gs_handle hpk, gs_handle hr1cs, gs_handle hw, const
     reset_timing(c);
     const uint32_t* wdev = w->buf.as<uint32_t>();
     const bool eval = c.eval_basis && pk->shard_count == 1 && pk->n_eval == o->n && hx_shape(o->n, pk->nz);
-    uint32_t* pxdev = exact_px_buffer(c, o, Ctx::kBlockingSlot);
+    uint32_t* pxdev = exact_px_buffer(c, o, c.blocking_slot());
     DevScalars dp = witness_scalars(o, wdev, pk->nz, eval, [pxdev](Ctx&) { return pxdev; });
     dp.p = pxdev;
     return groth16_prove_impl(c, pk, DevScalars{wdev, w->n}, dp, r, s, out_proof, inf);
@@ -1862,7 +1888,7 @@ static int groth16_witness_begin_impl(Ctx& c, const char* fn, gs_handle hpk, gs_
   } else {
     dp.produce_hx = nullptr; dp.produce = nullptr;
     raw->exact_route = [pk, o, wdev, nw, nz](Ctx& cc, GrothSums& sums) {
-      uint32_t* pxdev = exact_px_buffer(cc, o, Ctx::kBlockingSlot);     // the retry is a blocking proof at collection time
+      uint32_t* pxdev = exact_px_buffer(cc, o, cc.blocking_slot());     // the retry is a blocking proof at collection time
       DevScalars ex = witness_scalars(o, wdev, nz, false, [pxdev](Ctx&) { return pxdev; });
       ex.p = pxdev;
       return groth16_sums_impl(cc, pk, DevScalars{wdev, nw}, ex, Shard{}, sums);
@@ -1907,7 +1933,7 @@ int gs_groth16_prove_witness_host(gs_handle hpk, gs_handle hr1cs, const uint64_t
     reset_timing(c);
     const uint32_t* wdev = upload_tmp(c, prove_state(c).up_w, w, nw);
     const bool eval = c.eval_basis && pk->shard_count == 1 && pk->n_eval == o->n && hx_shape(o->n, pk->nz);
-    uint32_t* pxdev = exact_px_buffer(c, o, Ctx::kBlockingSlot);
+    uint32_t* pxdev = exact_px_buffer(c, o, c.blocking_slot());
     DevScalars dp = witness_scalars(o, wdev, pk->nz, eval, [pxdev](Ctx&) { return pxdev; });
     dp.p = pxdev;
     return groth16_prove_impl(c, pk, DevScalars{wdev, nw}, dp, r, s, out_proof, inf);
@@ -1929,7 +1955,7 @@ int gs_pinocchio_prove_witness(gs_handle hpk, gs_handle hr1cs, gs_handle hw, uin
     reset_timing(c);
     const uint32_t* wdev = w->buf.as<uint32_t>();
     const bool eval = c.eval_basis && pk->n_eval == o->n && hx_shape(o->n, pk->nz);
-    uint32_t* pxdev = exact_px_buffer(c, o, Ctx::kBlockingSlot);
+    uint32_t* pxdev = exact_px_buffer(c, o, c.blocking_slot());
     DevScalars dp = witness_scalars(o, wdev, pk->nz, eval, [pxdev](Ctx&) { return pxdev; });
     dp.p = pxdev;
     return pinocchio_prove_impl(c, pk, DevScalars{wdev, w->n}, dp, out_proof, inf);
@@ -1961,7 +1987,7 @@ static int pinocchio_witness_begin_impl(Ctx& c, const char* fn, gs_handle hpk, g
   } else {
     dp.produce_hx = nullptr; dp.produce = nullptr;
     st->exact_route = [pk, o, wdev, nw, nz](Ctx& cc, uint64_t* out, int* inf) {
-      uint32_t* pxdev = exact_px_buffer(cc, o, Ctx::kBlockingSlot);     // the retry is a blocking proof at collection time
+      uint32_t* pxdev = exact_px_buffer(cc, o, cc.blocking_slot());     // the retry is a blocking proof at collection time
       DevScalars ex = witness_scalars(o, wdev, nz, false, [pxdev](Ctx&) { return pxdev; });
       ex.p = pxdev;
       return pinocchio_prove_impl(cc, pk, DevScalars{wdev, nw}, ex, out, inf);
@@ -2003,7 +2029,7 @@ int gs_pinocchio_prove_witness_host(gs_handle hpk, gs_handle hr1cs, const uint64
     reset_timing(c);
     const uint32_t* wdev = upload_tmp(c, prove_state(c).up_w, w, nw);
     const bool eval = c.eval_basis && pk->n_eval == o->n && hx_shape(o->n, pk->nz);
-    uint32_t* pxdev = exact_px_buffer(c, o, Ctx::kBlockingSlot);
+    uint32_t* pxdev = exact_px_buffer(c, o, c.blocking_slot());
     DevScalars dp = witness_scalars(o, wdev, pk->nz, eval, [pxdev](Ctx&) { return pxdev; });
     dp.p = pxdev;
     return pinocchio_prove_impl(c, pk, DevScalars{wdev, nw}, dp, out_proof, inf);

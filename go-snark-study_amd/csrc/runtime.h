@@ -164,6 +164,10 @@ struct Scalars : Object {        // n x 8 u32 words, standard form, resident
 struct InFlightBase {
   uint64_t ticket = 0;
   std::vector<std::shared_ptr<Object>> keep;   // the key and scalar vectors this operation reads: gs_free on them is deferred
+  // Block until the operation's device work is through (its completion events; HIP event waits are thread-safe).  Called WITHOUT the
+  // context's lock by wait_ticket_unlocked below, so that a thread that collects a ticket does not keep every other thread's _begin
+  // (and the _end of finished tickets) out for the ~8 ms a 2^20 proof still has to run (round 6).
+  virtual void wait_device() const {}
   virtual ~InFlightBase() = default;
 };
 
@@ -203,7 +207,7 @@ struct Ctx {
   void* stage[kStageBuffers] = {};
   hipEvent_t stage_ev[kStageBuffers] = {};
   hipStream_t copy_stream = nullptr;                 // gs_scalars_upload (lazy)
-  std::unique_ptr<InFlightBase> inflight[kMaxInFlight];
+  std::shared_ptr<InFlightBase> inflight[kMaxInFlight];   // shared: a collector waits for the device on its own reference, outside the lock
   // Consecutive pipelined operations swap the two tail streams: the reduction tails are chains of dependent point additions
   // (latency, not throughput), so the tails of operation k + 1 may run beside those of operation k instead of queueing behind
   // them -- at 2^16 the G2 tail (1.2 ms) was longer than the accumulations of a whole proof (0.9 ms) and set the pace.
@@ -219,6 +223,11 @@ struct Ctx {
   uint64_t new_ticket() { return ((uint64_t)logical << kHandleDevShift) | ticket_counter()++; }
   int free_parity() const { for (int p = 0; p < kMaxInFlight; ++p) if (!inflight[p]) return p; return -1; }
   bool any_inflight() const { for (int p = 0; p < kMaxInFlight; ++p) if (inflight[p]) return true; return false; }
+  // The slot a BLOCKING entry point works in (round 6): a ticket slot that is free -- the call holds the context's lock
+  // until it returns, so no ticket can take the slot under it, and a free slot has no device work or uncollected result -- and only
+  // with three tickets outstanding the fourth set of workspaces.  A caller that mixes tickets and blocking calls used to hold four
+  // sets of bucket / partial workspaces (17 GB each at 2^24 constraints); now the fourth exists only if it is ever needed.
+  int blocking_slot() const { const int p = free_parity(); return p >= 0 ? p : kBlockingSlot; }
   static constexpr size_t kPinnedBytes = 256 * 1024;
   std::mutex mu;
   std::unordered_map<uint64_t, std::shared_ptr<Object>> objs;     // in-flight operations hold references: gs_free defers
@@ -355,6 +364,25 @@ int guarded(F&& f, bool need_init = true, bool allow_inflight = false, gs_handle
   }
 }
 inline void reset_timing(Ctx& c) { c.timing = gs_timing{}; }
+
+// First phase of every gs_*_end: wait for the ticket's device work WITHOUT holding the context's lock (the second phase, under the
+// lock as before, then finds every event complete and only folds the downloaded partial sums).  Round 5's _end waited for the device
+// inside the lock: with two producer threads on one device (tests/c/stream_producer.c) one of them spent the whole run locked out --
+// std::mutex is not fair, and the thread that held it for 8 of every 10 ms won every race for it -- and a goroutine collecting one
+// ticket kept all others from submitting.  An unknown ticket is left for the locked phase to report.
+inline void wait_ticket_unlocked(uint64_t ticket) {
+  std::shared_ptr<Ctx> pc = ctx_ref(handle_device(ticket));
+  if (!pc) return;
+  std::shared_ptr<InFlightBase> op;
+  {
+    std::lock_guard<std::mutex> lk(pc->mu);
+    if (!pc->ready) return;
+    for (auto& f : pc->inflight) if (f && f->ticket == ticket) op = f;
+  }
+  if (!op) return;
+  (void)hipSetDevice(pc->device);
+  try { op->wait_device(); } catch (const HipError&) { (void)hipGetLastError(); }      // the locked phase meets the same error and reports it
+}
 
 // Entry points that move an object from the context `route` lives on to logical device `target`: both contexts locked
 // (std::lock: no ordering deadlock), the source drained, the HIP current device set to the target's.

@@ -106,7 +106,11 @@ int gs_scalars_download(gs_handle scalars, uint64_t* out /* n x 4 */, size_t n);
 /* Overwrite a resident vector IN PLACE with n = its length new scalars (a server's next witness into the handle of an earlier one):
  * no hipMalloc, no hipFree -- gs_scalars_upload + gs_free per proof costs both, and hipFree synchronises the whole device under the
  * outstanding tickets.  The copy is ordered behind every device read of the vector that pipelined operations enqueued before the
- * call and has landed when the call returns.  With four vectors rotating under three tickets it never waits. */
+ * call and has landed when the call returns.  With four vectors rotating under three tickets it never waits.
+ * One exception to "a ticket has read its inputs when the update returns": a WITNESS ticket on a key with an evaluation-basis array
+ * (gs_*_prove_witness_begin) whose witness violates a constraint is proved again, on the exact route, when it is COLLECTED -- from the
+ * resident vector as it is then.  A caller that may submit unsatisfying witnesses must not update a vector before the ticket that
+ * reads it has been collected (host-buffer tickets own their copy and are not affected). */
 int gs_scalars_update(gs_handle scalars, const uint64_t* values /* n x 4 */, size_t n);
 
 /* Copies of [off, off + n) of a resident vector / base array onto another logical device (device-to-device; across xGMI

@@ -3,14 +3,15 @@
  * `nwit` DISTINCT satisfying witnesses in host memory with its own Fr arithmetic, and then streams proofs the way
  * go/groth16hip.Prover does: P producer threads call gs_groth16_prove_witness_host_begin (route 0: w alone, against the resident sparse
  * R1CS) or gs_groth16_prove_host_begin (route 1: w and px) with another witness every time, at most three tickets in flight on the
- * device (a fourth _begin answers GS_ERR_BUSY: the producer collects its own oldest ticket, or yields), and collect with
+ * device (one producer keeps three, two producers one and two; a _begin beyond the device's three answers GS_ERR_BUSY: the producer
+ * collects its own oldest ticket, or yields), and collect with
  * gs_groth16_prove_end.  Every collected proof is compared byte for byte with the proof of ITS witness from the first lap, where each
  * one was made by the blocking entry point and checked by gs_groth16_verify for its own public input (and rejected for its neighbour's).
  *
  *   stream_producer <log2n> <nwit> <seconds> [policy = 1]
  * prints, per (route, producers in {1, 2}): proofs, ms per proof, constraints/s, and how long _begin / _end calls took (mean / max):
- * _begin holds the device context's lock while it stages the witness (csrc/hostcopy.h), so with two producers the second one's calls --
- * including the _end of a finished ticket -- wait for it; the maxima show by how much.  Ends with OK. */
+ * _begin holds the device context's lock while it stages the witness (csrc/hostcopy.h), so with two producers the other one's calls wait
+ * for it (the maxima show by how much); _end waits for the device OUTSIDE the lock (runtime.h, wait_ticket_unlocked).  Ends with OK. */
 #define _POSIX_C_SOURCE 200809L
 #include <pthread.h>
 #include <sched.h>
@@ -85,7 +86,7 @@ static void field_elem(uint64_t out[4], uint64_t* seed) {
 typedef struct {
   gs_handle key, r1cs;
   size_t m, npx, nwit;
-  int route, first, stride;              /* this producer proves witnesses first, first + stride, ... */
+  int route, first, stride, cap;         /* this producer proves witnesses first, first + stride, ...; cap: tickets it keeps in flight */
   uint64_t **w, **px, *rs, *want;        /* want: 32 words + 3 flags per witness */
   double until;
   long done, begins, ends, mismatches;
@@ -105,7 +106,7 @@ static void* produce(void* arg) {
     const int more = now_ms() < p->until;
     if (!more && depth == 0) break;
     int began = 0;
-    if (more && depth < 3) {
+    if (more && depth < p->cap) {
       uint64_t t = 0;
       const double t0 = now_ms();
       const int rc = p->route == 0 ? gs_groth16_prove_witness_host_begin(p->key, p->r1cs, p->w[k], p->m, p->rs, p->rs + 4, &t)
@@ -117,7 +118,7 @@ static void* produce(void* arg) {
         k += (size_t)p->stride; if (k >= p->nwit) k = (size_t)p->first;
       } else if (rc != GS_ERR_BUSY) { printf("FAIL _begin: %d %s\n", rc, gs_last_error()); p->status = 2; return NULL; }
     }
-    if (began && depth < 3 && more) continue;             /* fill the pipeline before collecting */
+    if (began && depth < p->cap && more) continue;        /* fill the pipeline before collecting */
     if (depth == 0) { sched_yield(); continue; }           /* all three slots belong to the other producer */
     const double t0 = now_ms();
     const int rc = gs_groth16_prove_end(fifo_t[0], got, inf);
@@ -209,7 +210,7 @@ int main(int argc, char** argv) {
         const double start = now_ms();
         for (int j = 0; j < P; ++j) {
           pr[j].key = key; pr[j].r1cs = r1cs; pr[j].m = m; pr[j].npx = npx; pr[j].nwit = nwit; pr[j].route = route;
-          pr[j].first = j; pr[j].stride = P; pr[j].w = w; pr[j].px = px; pr[j].rs = rs; pr[j].want = want;
+          pr[j].first = j; pr[j].stride = P; pr[j].cap = (3 + j) / P;      /* the device has three slots: 3 | 1 + 2 */ pr[j].w = w; pr[j].px = px; pr[j].rs = rs; pr[j].want = want;
           pr[j].until = start + (warm ? (seconds < 1 ? seconds : 1.0) : seconds) * 1e3;
         }
         if (!warm) CHECK(gs_alloc_counters(&a0, &f0));
@@ -226,9 +227,9 @@ int main(int argc, char** argv) {
           if (pr[j].begin_max > bx) bx = pr[j].begin_max;
           if (pr[j].end_max > ex) ex = pr[j].end_max;
         }
-        printf("route %s producers %d: %ld proofs in %.0f ms = %.3f ms per proof = %.1f M constraints/s | _begin mean %.2f max %.2f ms, _end mean %.2f max %.2f ms | "
-               "%llu hipMalloc %llu hipFree | %ld mismatches\n", route == 0 ? "witness_host" : "px_host", P, done, wall, wall / (double)(done ? done : 1),
-               (double)n * (double)done / wall / 1e3, bm / (double)(nb ? nb : 1), bx, em / (double)(ne ? ne : 1), ex,
+        printf("route %s producers %d: %ld proofs (%ld + %ld) in %.0f ms = %.3f ms per proof = %.1f M constraints/s | _begin mean %.2f max %.2f ms, _end mean %.2f max %.2f ms | "
+               "%llu hipMalloc %llu hipFree | %ld mismatches\n", route == 0 ? "witness_host" : "px_host", P, done, pr[0].done, P > 1 ? pr[1].done : 0L, wall,
+               wall / (double)(done ? done : 1), (double)n * (double)done / wall / 1e3, bm / (double)(nb ? nb : 1), bx, em / (double)(ne ? ne : 1), ex,
                (unsigned long long)(a1 - a0), (unsigned long long)(f1 - f0), bad);
         if (bad || done == 0) { printf("FAIL: %ld of %ld streamed proofs differ from the first lap's\n", bad, done); return 5; }
       }

@@ -243,3 +243,15 @@ def test_group_ops_c_sequence_equals_the_oracle(tmp_path):
     flat = [c for half in e for pair in half for c in pair]
     assert v[pos:pos + 12] == flat
     assert pos + 12 == len(v)
+
+
+def test_stream_producer_c_sequence(tmp_path):
+    """go/groth16hip.Prover (gosnarkhip.Groth16Prover: Submit / Collect over host-buffer tickets) == tests/c/stream_producer.c: a plain-C
+    process builds sqchain(2^12), runs the device setup, computes 6 distinct witnesses with its own Fr arithmetic and streams them from
+    host memory with 1 and with 2 producer threads, w alone and w + px; every streamed proof equals the blocking entry point's proof of
+    the same witness, each of which gs_groth16_verify accepted for its own public input only.  (At 2^20 with 8 witnesses the same
+    program is the measurement of the C ABI's ingest ceiling: profiles/r06_c_producer.txt.)"""
+    out = c_util.build_and_run("stream_producer.c", ["12", "6", "0.4"], tmp_path, timeout=300)
+    lines = [l for l in out.splitlines() if l.startswith("route ")]
+    assert out.strip().endswith("OK") and len(lines) == 4, out
+    assert all(" 0 mismatches" in l and " 0 hipMalloc 0 hipFree" in l for l in lines), out

@@ -2,8 +2,9 @@
 
 The reference proves once per key load (cli/main.go:330-349); rounds 1-4 spent ~140 ms and 15x the key's memory on window tables before
 a 2^20 key's first proof.  Under the default policy `auto` a base array is summed TABLE-FREE (a bucket set per window, every window
-adds the base point itself, the window sums recombined by Horner on the host) until its second use, then its table is built in the
-background and the first call that finds it complete switches over.  tests/test_gpu_prove.py and tests/test_gpu_msm.py run every
+adds the base point itself, the window sums recombined by Horner on the host) until its second use; from then on every call builds an
+INSTALMENT of the table in front of its own accumulations (round 6: slabs of points on the accumulation stream, paid from a credit
+proportional to the call's own work) and the call that enqueues the last slab installs the table and is the first to use it.  tests/test_gpu_prove.py and tests/test_gpu_msm.py run every
 parity test on both routes; here: the schedule itself, gs_build_tables, every table-free window width, eviction under a memory cap."""
 import time
 
@@ -82,6 +83,101 @@ def test_auto_first_proof_builds_nothing_then_tables_arrive_in_the_background():
     assert capi.handle_bytes(pk.handle)[1] > tab_px >= 8 * 5 * n * 64
     assert same(groth16.prove_resident(pk, inst.w, inst.px, r, s), first) and capi.last_timing()["window_bits"] == table_width
     assert same(groth16.prove_from_witness(pk, dr, inst.w, r, s), first)
+
+
+def test_auto_builds_tables_in_instalments_and_nothing_changes_on_the_way():
+    """Round 6: the transient of a fresh key under `auto` is a deterministic schedule, not a race with a background
+    stream.  Proof 1 builds nothing; from proof 2 on every call allocates / extends the pending tables by whole slabs (the bytes the key
+    holds never shrink), every proof on the way is THE proof, the sums over w switch to their tables before the sum over h does (G2
+    first inside the group), and the whole thing takes a bounded number of calls: the credit is 0.06 G1 points per job-unit x term (~17 calls
+    for a 2^20 key) but never less than 2^18 points per call, so this 2^17 key (826 k point-builds) is warm after 4-5 calls and a 2^13 key
+    after one."""
+    n = 1 << 17
+    inst = synth.sqchain_setup_instance(n, 0x8500)
+    pk = inst.device_pk()
+    r, s = synth.field_elems(2, 85)
+    first = groth16.prove_resident(pk, inst.w, inst.px, r, s)
+    free_width = capi.last_timing()["window_bits"]
+    assert capi.handle_bytes(pk.handle)[1] == 0
+    held, widths, g2_adds = [], [], []
+    for i in range(60):
+        assert same(groth16.prove_resident(pk, inst.w, inst.px, r, s), first), i
+        tm = capi.last_timing()
+        held.append(capi.handle_bytes(pk.handle)[1]); widths.append(tm["window_bits"]); g2_adds.append(tm["acc_g2_adds"])
+        if widths[-1] != free_width:
+            break
+    calls = len(widths)
+    assert widths[-1] != free_width and 3 <= calls <= 12, (calls, widths)
+    assert held[0] > 0 and all(b >= a for a, b in zip(held, held[1:])), held          # pending rows from the second use on, never released
+    # the sums over w went onto their tables (fewer windows = fewer additions) no later than the sum over h did
+    switched_w = next(i for i, a in enumerate(g2_adds) if a < 0.97 * g2_adds[0])
+    assert switched_w <= calls - 1, (switched_w, calls, g2_adds)
+    assert capi.handle_bytes(pk.handle)[1] >= 8 * 5 * n * 64
+    steady = capi.handle_bytes(pk.handle)[1]
+    for _ in range(3):
+        assert same(groth16.prove_resident(pk, inst.w, inst.px, r, s), first) and capi.handle_bytes(pk.handle)[1] == steady
+    # a key that is half-way: gs_build_tables finishes the missing instalments, gs_release_tables drops them -- same proof either way
+    inst2 = synth.sqchain_setup_instance(n, 0x8501)
+    pk2 = inst2.device_pk()
+    want2 = groth16.prove_resident(pk2, inst2.w, inst2.px, r, s)
+    for _ in range(2):
+        assert same(groth16.prove_resident(pk2, inst2.w, inst2.px, r, s), want2)
+    part = capi.handle_bytes(pk2.handle)[1]
+    assert part > 0 and capi.last_timing()["window_bits"] == free_width
+    capi.release_tables(pk2.handle)
+    assert capi.handle_bytes(pk2.handle)[1] == 0 and same(groth16.prove_resident(pk2, inst2.w, inst2.px, r, s), want2)
+    for _ in range(2):
+        assert same(groth16.prove_resident(pk2, inst2.w, inst2.px, r, s), want2)
+    assert capi.handle_bytes(pk2.handle)[1] > 0 and capi.last_timing()["window_bits"] == free_width
+    capi.build_tables(pk2.handle, 1)
+    assert same(groth16.prove_resident(pk2, inst2.w, inst2.px, r, s), want2) and capi.last_timing()["window_bits"] != free_width
+    # pipelined tickets straight through a third key's whole transient (three in flight, host-buffer tickets included)
+    inst3 = synth.sqchain_setup_instance(n, 0x8502)
+    pk3 = inst3.device_pk()
+    want3 = groth16.prove_resident(pk3, inst3.w, inst3.px, r, s)
+    dr = r1csqap.DeviceR1CS(*inst3.r1cs, inst3.m)
+    for lap in range(6):
+        t = [groth16.prove_begin(pk3, inst3.w, inst3.px, r, s), groth16.prove_witness_host_begin(pk3, dr, inst3.w_host, r, s),
+             groth16.prove_host_begin(pk3, inst3.w_host, inst3.px_host, r, s)]
+        assert all(same(groth16.prove_end(x), want3) for x in t), lap
+    assert capi.handle_bytes(pk3.handle)[1] >= 8 * 5 * n * 64
+
+
+def test_auto_key_slices_and_base_arrays_switch_routes_without_changing_their_sums():
+    """a key SLICE (gs_groth16_pk_shard) under `auto` goes table-free -> instalments -> tables, and
+    gs_groth16_prove_partials returns the same five sums all the way; the same for a plain base array under gs_msm_g1 / gs_msm_g2
+    (blocking and tickets), whose table arrives with the second or third call at this size (the credit's floor of 2^18 points)."""
+    n = 1 << 13
+    inst = synth.sqchain_setup_instance(n, 0x8600)
+    pk = inst.device_pk()
+    slices = [groth16.ShardPk(pk, k, 2) for k in range(2)]
+    want = [groth16.prove_partials(slices[k], inst.w, inst.px, k, 2)[0] for k in range(2)]
+    assert all(capi.handle_bytes(sl.handle)[1] == 0 for sl in slices)
+    for i in range(40):
+        got = [groth16.prove_partials(slices[k], inst.w, inst.px, k, 2)[0] for k in range(2)]
+        assert got == want, i
+        if all(capi.handle_bytes(sl.handle)[1] >= 8 * 5 * (n // 2) * 64 for sl in slices) and i >= 20:
+            break
+    assert all(capi.handle_bytes(sl.handle)[1] >= 8 * 5 * (n // 2) * 64 for sl in slices)
+    from gosnark_amd import parallel
+    r, s = synth.field_elems(2, 86)
+    full = groth16.prove_resident(pk, inst.w, inst.px, r, s)
+    assert same(groth16.finish(pk, parallel.combine_partials(want, groth16.SUM_IS_G2), r, s), full)
+    for g2 in (False, True):
+        m = 150000
+        ks, sc = U.rand_scalars_u64(m, 8610 + g2), U.rand_scalars_u64(m, 8612 + g2)
+        bases = capi.g2_fixed_base(ks) if g2 else capi.g1_fixed_base(ks)
+        tot = int(np.sum(np.array(U.u64_rows_to_ints(ks), dtype=object) * np.array(U.u64_rows_to_ints(sc), dtype=object))) % O.R
+        want_m = C.g2_affine(C.g2_mul_scalar(O.G2_GEN, tot)) if g2 else C.g1_affine(C.g1_mul_scalar(O.G1_GEN, tot))
+        h = capi.scalars_upload(sc)
+        assert capi.msm(bases, sc, g2=g2) == want_m and capi.handle_bytes(bases)[1] == 0
+        free_width, calls = capi.last_timing()["window_bits"], 0
+        while capi.last_timing()["window_bits"] == free_width and calls < 60:
+            assert capi.msm(bases, sc, g2=g2) == want_m, (g2, calls)
+            assert capi.msm_end(capi.msm_begin(bases, h, m, g2=g2)) == want_m
+            calls += 1
+        assert 1 <= calls < 60 and capi.handle_bytes(bases)[1] >= 8 * m * (128 if g2 else 64), (g2, calls)
+        assert capi.msm(bases, sc, g2=g2) == want_m and capi.last_timing()["window_bits"] != free_width
 
 
 @pytest.mark.parametrize("c", [9, 10, 11, 12, 13, 14, 15, 16, 8, 20])

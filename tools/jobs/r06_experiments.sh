@@ -35,5 +35,39 @@ PY
     done 2>&1 | tee $OUT/ubench_issue_cu_mask.txt ;;
   placement)             # r06_ubench_placement.txt: where and when the waves of the ubench launches run
     ./tools/ubench_placement 2>&1 | tee $OUT/ubench_placement.txt ;;
+  auto_transient)        # r06_auto_instalments.txt: every blocking proof of a fresh 2^20 key under `auto` at several build budgets, `always` beside it
+    for pct in 100 50 200 400 100000; do echo "== GS_TABLE_BUDGET_PCT=$pct"; GS_TABLE_BUDGET_PCT=$pct timeout 300 python tools/time_first_proof.py auto 20 40; done 2>&1 | grep -v "^$" | tee $OUT/auto_instalments.txt
+    echo "== policy always"; timeout 300 python tools/time_first_proof.py always 20 12 2>&1 | tee -a $OUT/auto_instalments.txt
+    echo "== auto, 2^16 and 2^18"; for l in 16 18; do timeout 300 python tools/time_first_proof.py auto $l 40; done 2>&1 | tee -a $OUT/auto_instalments.txt ;;
+  c_producer)            # r06_c_producer.txt: the C ABI's ingest ceiling (tests/c/stream_producer.c at 2^20, 8 witnesses) beside bench.py's Python-driven streams
+    gcc -std=c99 -O2 -Wall -Wextra -I include -I tests/c tests/c/stream_producer.c -o /tmp/stream_producer -L go-snark-study_amd -lgosnark_hip -Wl,-rpath,$PWD/go-snark-study_amd -lpthread || exit 1
+    timeout 900 /tmp/stream_producer 20 8 4 1 2>&1 | tee $OUT/c_producer.txt
+    gcc -O2 -pthread tools/pack_cost.c -o /tmp/pack_cost && /tmp/pack_cost 20 2>&1 | tee $OUT/pack_cost.txt
+    timeout 900 python bench.py --steps 10 --warmup 3 --reps 3 --cpu-log2n 0 --no-check 2>/dev/null | tail -1 > $OUT/bench_line.json
+    python - $OUT/bench_line.json <<'PY' | tee -a $OUT/c_producer.txt
+import json, sys
+d = json.loads(open(sys.argv[1]).read())
+s = d.get("extras", d).get("stream_distinct_host", d.get("stream_distinct_host"))
+print("bench.py (Python-driven, same box, same call):", json.dumps({k: (v if not isinstance(v, dict) else {"ms_per_proof": v.get("ms_per_proof"), "reps": v.get("ms_per_proof_reps")}) for k, v in (s or {}).items()}))
+print("bench.py headline: %.3f ms per proof" % d["ms_per_step"])
+PY
+    ;;
+  suite)                 # the GPU suite + smoke
+    ( timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 ) | tee $OUT/pytest.txt
+    python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | tee $OUT/smoke.txt ;;
+  quick)                 # the tests of what round 6 touched
+    ( timeout 1500 python -m pytest tests/test_gpu_table_policy.py tests/test_gpu_c_drivers.py tests/test_gpu_stream_host.py tests/test_gpu_prove.py -m gpu -x -q 2>&1 | tail -15 ) | tee $OUT/pytest.txt ;;
+  slot_streams)          # r06_ab_slot_streams.txt: every pipelined proof's side work on its own slot's stream (GS_SLOT_STREAMS=1) vs the shared plan / polynomial stream
+    for inst in sqchain realistic gates; do for wl in prove prove_witness; do
+      bash tools/gpu_run.sh $T env GS_SLOT_STREAMS=1 : --instance $inst --workload $wl --steps 12 --warmup 3 --reps 3
+    done; done
+    bash tools/gpu_run.sh $T env GS_SLOT_STREAMS=1 : --log2n 16 --steps 100 --warmup 10 --reps 3
+    bash tools/gpu_run.sh $T env GS_SLOT_STREAMS=1 : --log2n 18 --steps 40 --warmup 5 --reps 3
+    bash tools/gpu_run.sh $T env GS_SLOT_STREAMS=1 : --log2n 22 --steps 4 --warmup 1 --reps 3
+    bash tools/gpu_run.sh $T env GS_SLOT_STREAMS=1 : --workload prove_pinocchio --instance gates --steps 8 --warmup 2 --reps 3 ;;
+  add_latency)           # r06_timeline_msm_2p16_critical_path.txt: what one dependent addition costs a lone wave + the blocking 2^16 MSM's timeline
+    ./tools/ubench_add_latency 2>&1 | tee $OUT/add_latency.txt
+    bash tools/gpu_run.sh $T trace msm_2p16_blocking --workload msm_g1 --log2n 16 --pipeline 1 --steps 20 --warmup 5 --reps 1 --cpu-log2n 0 --no-extras --no-check
+    bash tools/gpu_run.sh $T trace prove_2p16_pipelined --log2n 16 --steps 20 --warmup 5 --reps 1 --cpu-log2n 0 --no-extras --no-check ;;
   *) echo "unknown experiment $NAME" >&2; exit 2 ;;
 esac
