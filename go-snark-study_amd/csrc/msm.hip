@@ -535,9 +535,12 @@ static void msm_enqueue(Ctx& c, const MsmPlan& plan, const std::vector<MsmBase>&
   const bool alone = plan.n < (1ull << alone_below_log2);
   auto launch_tails = [&](auto alone_tag) {
     constexpr bool kAlone = decltype(alone_tag)::value;
-    hipLaunchKernelGGL((k_heavy_combine<T, kAlone>), dim3(64, njobs), dim3(kHeavyBlock), 0, ts,
+    // (the two heavy-bucket kernels always in their SHARING form: with uniform scalars they find nothing to do, and the one-wave-per-SIMD
+    //  form -- registers padded to 512 -- cannot even start until whole SIMDs are empty: 0.15 ms per G2 group of a pipelined 2^16 proof
+    //  spent waiting to do nothing, on the tail stream that sets that proof's pace; profiles/r06_timeline_msm_2p16_critical_path.txt)
+    hipLaunchKernelGGL((k_heavy_combine<T, false>), dim3(64, njobs), dim3(kHeavyBlock), 0, ts,
                        jobs, plan.offsets, plan.heavy_list, plan.heavy_count, plan.chunk);
-    hipLaunchKernelGGL((k_heavy_finish<T, kAlone>), dim3(16, njobs), dim3(kHeavyBlock), 0, ts,
+    hipLaunchKernelGGL((k_heavy_finish<T, false>), dim3(16, njobs), dim3(kHeavyBlock), 0, ts,
                        jobs, plan.offsets, plan.heavy_list, plan.heavy_count, plan.chunk);
     hipLaunchKernelGGL((k_bucket_combine<T, kAlone>), dim3((plan.nbuckets + 255) / 256, njobs), dim3(256), 0, ts, jobs, plan.offsets, plan.nbuckets,
                        plan.chunk, plan.heavy_count, stats);

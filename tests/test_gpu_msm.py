@@ -508,7 +508,7 @@ def test_hostile_environment_cannot_change_a_result():
                "GS_NO_PRIORITY": "1",
                # round 5's switches: staging of host buffers, table policy and background builds, the sparse-B threshold
                "GS_HOST_STAGE": "9", "GS_STAGE_MIB": "0", "GS_STAGE_BUFFERS": "99", "GS_TABLE_POLICY": "7", "GS_TABLE_BG_SLAB_LOG2": "40",
-               "GS_TABLE_STREAM_LOW": "-1", "GS_SPLIT_B_PERCENT": "1000", "GS_CHUNK_MODEL": "5"}
+               "GS_TABLE_STREAM_LOW": "-1", "GS_SPLIT_B_PERCENT": "1000", "GS_CHUNK_MODEL": "5", "GS_TABLE_BUDGET_PCT": "-7", "GS_SLOT_STREAMS": "9"}
 
     def run(env):
         out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, **env), timeout=600)

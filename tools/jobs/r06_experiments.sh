@@ -69,5 +69,12 @@ PY
     ./tools/ubench_add_latency 2>&1 | tee $OUT/add_latency.txt
     bash tools/gpu_run.sh $T trace msm_2p16_blocking --workload msm_g1 --log2n 16 --pipeline 1 --steps 20 --warmup 5 --reps 1 --cpu-log2n 0 --no-extras --no-check
     bash tools/gpu_run.sh $T trace prove_2p16_pipelined --log2n 16 --steps 20 --warmup 5 --reps 1 --cpu-log2n 0 --no-extras --no-check ;;
+  heavy_sharing)         # r06_ab_heavy_kernels_sharing.txt: the two heavy-bucket kernels always in their sharing form (default) vs one wave per SIMD below 2^19 terms (lib_heavyalone.so = the library before the change)
+    bash tools/gpu_run.sh $T ab heavyalone : --log2n 16 --steps 100 --warmup 10 --reps 5
+    bash tools/gpu_run.sh $T ab heavyalone : --log2n 17 --steps 60 --warmup 10 --reps 5
+    bash tools/gpu_run.sh $T ab heavyalone : --log2n 18 --steps 40 --warmup 5 --reps 5
+    bash tools/gpu_run.sh $T ab heavyalone : --log2n 18 --instance realistic --steps 40 --warmup 5 --reps 5
+    bash tools/gpu_run.sh $T ab heavyalone : --workload msm_g1 --log2n 16 --steps 200 --warmup 20 --reps 5
+    bash tools/gpu_run.sh $T ab heavyalone : --workload msm_g1 --log2n 16 --pipeline 1 --steps 200 --warmup 20 --reps 5 ;;
   *) echo "unknown experiment $NAME" >&2; exit 2 ;;
 esac

@@ -218,6 +218,22 @@ def main():
         return "%d proofs, %.3f ms each" % (done, (time.perf_counter() - t0) * 1e3 / max(done + len(tickets), 1))
 
     phase(sampler, "G1 MSM stream, 2^%d terms, three in flight" % LOGN, msm_stream)
+    # the G2 sum alone (39 % of a proof's device time; 256 VGPRs, two waves per SIMD): does IT pull the PLL down?
+    bases2 = capi.g2_fixed_base(synth.scalars_u64(n // 2, 9))
+    capi.msm_resident(bases2, sc, n // 2, g2=True)
+
+    def msm2_stream():
+        t_end = time.perf_counter() + SECONDS
+        tickets, done, t0 = [], 0, time.perf_counter()
+        while time.perf_counter() < t_end:
+            while len(tickets) < 3:
+                tickets.append(capi.msm_begin(bases2, sc, n // 2, g2=True))
+            capi.msm_end(tickets.pop(0))
+            done += 1
+        for t in tickets:
+            capi.msm_end(t)
+        return "%d G2 MSMs of 2^%d terms, %.3f ms each" % (done, LOGN - 1, (time.perf_counter() - t0) * 1e3 / max(done + len(tickets), 1))
+    phase(sampler, "G2 MSM stream, 2^%d terms, three in flight" % (LOGN - 1), msm2_stream)
     phase(sampler, "Groth16 proof stream, 2^%d, three in flight" % LOGN, proof_stream)
     phase(sampler, "idle again", lambda: time.sleep(2.0))
     sampler.stop_flag = True
