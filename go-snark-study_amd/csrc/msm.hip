@@ -514,7 +514,7 @@ static void msm_enqueue(Ctx& c, const MsmPlan& plan, const std::vector<MsmBase>&
   }
   p.tacc = std::make_shared<PhaseTimer>(c.stream);
   p.tker = std::make_shared<PhaseTimer>(c.stream);
-  hipLaunchKernelGGL(k_bucket_accumulate<T>, dim3((plan.maxchunks + 255) / 256, njobs), dim3(256), 0, c.stream,
+  hipLaunchKernelGGL(k_bucket_accumulate<T>, dim3((plan.maxchunks + kAccBlock - 1) / kAccBlock, njobs), dim3(kAccBlock), 0, c.stream,
                      jobs, plan.offsets, plan.entries, plan.chunk_bucket, plan.nbuckets, plan.chunk);
   p.tker->stop();
   p.tacc->stop();
@@ -535,12 +535,12 @@ static void msm_enqueue(Ctx& c, const MsmPlan& plan, const std::vector<MsmBase>&
   const bool alone = plan.n < (1ull << alone_below_log2);
   auto launch_tails = [&](auto alone_tag) {
     constexpr bool kAlone = decltype(alone_tag)::value;
-    // (the two heavy-bucket kernels always in their SHARING form: with uniform scalars they find nothing to do, and the one-wave-per-SIMD
-    //  form -- registers padded to 512 -- cannot even start until whole SIMDs are empty: 0.15 ms per G2 group of a pipelined 2^16 proof
-    //  spent waiting to do nothing, on the tail stream that sets that proof's pace; profiles/r06_timeline_msm_2p16_critical_path.txt)
-    hipLaunchKernelGGL((k_heavy_combine<T, false>), dim3(64, njobs), dim3(kHeavyBlock), 0, ts,
+    // (round 6 tried the two heavy-bucket kernels always in their sharing form -- with uniform scalars they find nothing to do, and the
+    //  one-wave-per-SIMD form must wait for empty SIMDs: no change at 2^16-2^18 with uniform scalars, +2 % on a realistic 2^18 witness,
+    //  where they do have work: profiles/r06_ab_heavy_kernels_sharing.txt.  Not adopted.)
+    hipLaunchKernelGGL((k_heavy_combine<T, kAlone>), dim3(64, njobs), dim3(kHeavyBlock), 0, ts,
                        jobs, plan.offsets, plan.heavy_list, plan.heavy_count, plan.chunk);
-    hipLaunchKernelGGL((k_heavy_finish<T, false>), dim3(16, njobs), dim3(kHeavyBlock), 0, ts,
+    hipLaunchKernelGGL((k_heavy_finish<T, kAlone>), dim3(16, njobs), dim3(kHeavyBlock), 0, ts,
                        jobs, plan.offsets, plan.heavy_list, plan.heavy_count, plan.chunk);
     hipLaunchKernelGGL((k_bucket_combine<T, kAlone>), dim3((plan.nbuckets + 255) / 256, njobs), dim3(256), 0, ts, jobs, plan.offsets, plan.nbuckets,
                        plan.chunk, plan.heavy_count, stats);

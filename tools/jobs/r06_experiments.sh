@@ -76,5 +76,16 @@ PY
     bash tools/gpu_run.sh $T ab heavyalone : --log2n 18 --instance realistic --steps 40 --warmup 5 --reps 5
     bash tools/gpu_run.sh $T ab heavyalone : --workload msm_g1 --log2n 16 --steps 200 --warmup 20 --reps 5
     bash tools/gpu_run.sh $T ab heavyalone : --workload msm_g1 --log2n 16 --pipeline 1 --steps 200 --warmup 20 --reps 5 ;;
+  proof_clock)           # r06_power_clock_streams.txt: which part of a proof pulls the PLL down (the MSM streams run at 2.30-2.34 GHz, the proof stream at 2.03-2.08)
+    timeout 600 python tools/power_trace.py 4 20 --streams-only 2>&1 | grep -v "^        \|^    \|^GPU\|^\$\|^====\|amdgpu.ids" | tee $OUT/streams_default.txt
+    GS_NO_OVERLAP=1 timeout 600 python tools/power_trace.py 4 20 --streams-only 2>&1 | grep "stream\|proofs\|idle" | tee $OUT/streams_no_overlap.txt ;;
+  acc_block)             # r06_ab_accumulate_block.txt: 64- / 128-thread workgroups for the accumulation kernels (no LDS, no barrier: the group is only the dispatcher's unit)
+    bash tools/gpu_run.sh $T ab acc64 acc128 : --steps 10 --warmup 3 --reps 5
+    bash tools/gpu_run.sh $T ab acc64 acc128 : --workload msm_g1 --steps 40 --warmup 5 --reps 5
+    bash tools/gpu_run.sh $T ab acc64 acc128 : --log2n 16 --steps 100 --warmup 10 --reps 5
+    bash tools/gpu_run.sh $T ab acc64 acc128 : --log2n 18 --steps 40 --warmup 5 --reps 5
+    bash tools/gpu_run.sh $T ab acc64 acc128 : --log2n 22 --steps 4 --warmup 1 --reps 3
+    bash tools/gpu_run.sh $T ab acc64 acc128 : --instance realistic --steps 12 --warmup 3 --reps 3
+    bash tools/gpu_run.sh $T ab acc64 acc128 : --workload msm_g1 --log2n 16 --pipeline 1 --steps 200 --warmup 20 --reps 5 ;;
   *) echo "unknown experiment $NAME" >&2; exit 2 ;;
 esac

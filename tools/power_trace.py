@@ -25,8 +25,10 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-SECONDS = float(sys.argv[1]) if len(sys.argv) > 1 else 4.0
-LOGN = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+STREAMS_ONLY = "--streams-only" in sys.argv       # only the library's streams (and a few more of them): which part of a proof pulls the PLL down?
+_args = [a for a in sys.argv[1:] if not a.startswith("--")]
+SECONDS = float(_args[0]) if len(_args) > 0 else 4.0
+LOGN = int(_args[1]) if len(_args) > 1 else 20
 
 
 def read_int(path):
@@ -169,13 +171,14 @@ def main():
         print("no hwmon power / clock files: sampling through amd-smi / rocm-smi (a few Hz)")
     sampler.start()
     phase(sampler, "idle", lambda: time.sleep(2.0))
-    phase(sampler, "s_nop loop (ubench_issue 11)", ubench("ubench_issue", 11, SECONDS))
-    phase(sampler, "v_mad_u64_u32, 8 chains (ubench_issue 0)", ubench("ubench_issue", 0, SECONDS))
-    phase(sampler, "fp29 dots3 products, bare loop (ubench_mulmod 2)", ubench("ubench_mulmod", 2, SECONDS))
-    phase(sampler, "fp29 dots2 products, bare loop (ubench_mulmod 1)", ubench("ubench_mulmod", 1, SECONDS))
-    phase(sampler, "G1-addition instruction mix (ubench_issue 9)", ubench("ubench_issue", 9, SECONDS))
-    phase(sampler, "v_fma_f64 (ubench_issue 18)", ubench("ubench_issue", 18, SECONDS))
-    phase(sampler, "v_and_b32 VOP2 (ubench_issue 6)", ubench("ubench_issue", 6, SECONDS))
+    if not STREAMS_ONLY:
+      phase(sampler, "s_nop loop (ubench_issue 11)", ubench("ubench_issue", 11, SECONDS))
+      phase(sampler, "v_mad_u64_u32, 8 chains (ubench_issue 0)", ubench("ubench_issue", 0, SECONDS))
+      phase(sampler, "fp29 dots3 products, bare loop (ubench_mulmod 2)", ubench("ubench_mulmod", 2, SECONDS))
+      phase(sampler, "fp29 dots2 products, bare loop (ubench_mulmod 1)", ubench("ubench_mulmod", 1, SECONDS))
+      phase(sampler, "G1-addition instruction mix (ubench_issue 9)", ubench("ubench_issue", 9, SECONDS))
+      phase(sampler, "v_fma_f64 (ubench_issue 18)", ubench("ubench_issue", 18, SECONDS))
+      phase(sampler, "v_and_b32 VOP2 (ubench_issue 6)", ubench("ubench_issue", 6, SECONDS))
 
     import torch  # noqa: F401  (device memory / streams for the library's Python side)
     import gosnark_amd  # noqa: F401
@@ -235,6 +238,40 @@ def main():
         return "%d G2 MSMs of 2^%d terms, %.3f ms each" % (done, LOGN - 1, (time.perf_counter() - t0) * 1e3 / max(done + len(tickets), 1))
     phase(sampler, "G2 MSM stream, 2^%d terms, three in flight" % (LOGN - 1), msm2_stream)
     phase(sampler, "Groth16 proof stream, 2^%d, three in flight" % LOGN, proof_stream)
+    if STREAMS_ONLY:
+        from gosnark_amd import r1csqap
+        dr = r1csqap.DeviceR1CS(*inst.r1cs, inst.m)
+
+        def px_stream():                      # sparse mat-vecs + three interpolations + a size-2n product: NTT passes and point-wise kernels only
+            t_end, done, t0 = time.perf_counter() + SECONDS, 0, time.perf_counter()
+            ph = dr.ComputePxResident(inst.w)
+            while time.perf_counter() < t_end:
+                ph = dr.ComputePxResident(inst.w, ph)
+                done += 1
+            return "%d x gs_r1cs_px (NTT passes, no curve arithmetic), %.3f ms each" % (done, (time.perf_counter() - t0) * 1e3 / max(done, 1))
+
+        def witness_stream():
+            t_end = time.perf_counter() + SECONDS
+            tickets, done, t0 = [], 0, time.perf_counter()
+            while time.perf_counter() < t_end:
+                while len(tickets) < 3:
+                    tickets.append(groth16.prove_witness_begin(pk, dr, inst.w, r, s))
+                groth16.prove_end(tickets.pop(0))
+                done += 1
+            for t in tickets:
+                groth16.prove_end(t)
+            return "%d witness -> proof, %.3f ms each" % (done, (time.perf_counter() - t0) * 1e3 / max(done + len(tickets), 1))
+
+        def blocking_stream():
+            t_end, done, t0 = time.perf_counter() + SECONDS, 0, time.perf_counter()
+            while time.perf_counter() < t_end:
+                groth16.prove_resident(pk, inst.w, inst.px, r, s)
+                done += 1
+            return "%d blocking proofs, %.3f ms each" % (done, (time.perf_counter() - t0) * 1e3 / max(done, 1))
+        phase(sampler, "gs_r1cs_px stream (NTT passes only)", px_stream)
+        phase(sampler, "witness -> proof stream, three in flight", witness_stream)
+        phase(sampler, "blocking proofs back to back", blocking_stream)
+        phase(sampler, "Groth16 proof stream again", proof_stream)
     phase(sampler, "idle again", lambda: time.sleep(2.0))
     sampler.stop_flag = True
     sampler.join(timeout=2)
