@@ -514,6 +514,8 @@ static void msm_enqueue(Ctx& c, const MsmPlan& plan, const std::vector<MsmBase>&
   }
   p.tacc = std::make_shared<PhaseTimer>(c.stream);
   p.tker = std::make_shared<PhaseTimer>(c.stream);
+  // (round 6 tried one launch per base array instead of grid.y = njobs -- the proof stream runs at sclk 2.10 GHz where an MSM stream, one
+  //  array per launch, runs at 2.31: no change in time or clock, profiles/r06_power_clock_streams.txt)
   hipLaunchKernelGGL(k_bucket_accumulate<T>, dim3((plan.maxchunks + kAccBlock - 1) / kAccBlock, njobs), dim3(kAccBlock), 0, c.stream,
                      jobs, plan.offsets, plan.entries, plan.chunk_bucket, plan.nbuckets, plan.chunk);
   p.tker->stop();

@@ -198,3 +198,71 @@ def test_pinocchio_host_tickets_equal_the_resident_proofs(n):
     with pytest.raises(capi.GosnarkHipError) as e:
         snark.prove_host_begin(pk, pin.w_host[:-1], pin.px_host)
     assert e.value.code == -4
+
+
+def test_streaming_prover_mirrors_submit_collect_in_order():
+    """Round 6: the streaming drop-in (go/groth16hip.Prover / snarkhip.Prover; here their Python mirrors groth16.Prover / snark.Prover and
+    GenerateProofsFromWitnessWithRS).  20 distinct witnesses through Submit / Collect with three in flight come back in submission order,
+    each equal to the blocking proof of ITS witness (same r, s) and accepted by the verifier for its own public input only; a Submit on a
+    full pipeline collects the oldest ticket into the done-queue instead of failing; px route and witness route give the same proofs; the
+    Pinocchio twin does the same; Close cancels what is left and frees the slots."""
+    n = 1 << 11
+    inst = synth.sqchain_setup_instance(n, 0x7600)
+    pk = inst.device_pk()
+    dr = r1csqap.DeviceR1CS(*inst.r1cs, inst.m)
+    circ = groth16.Circuit(pk.nvars, pk.npublic)
+    xs = synth.field_elems(20, 0x7601)
+    ws = [synth.sqchain_witness(n, x) for x in xs]
+    rs = [synth.field_elems(2, 0x7700 + k) for k in range(20)]
+    want = [groth16.prove_from_witness_host(pk, dr, w, *rs[k]) for k, w in enumerate(ws)]
+    p = groth16.NewProver(circ, pk, dr)
+    got = []
+    for k, w in enumerate(ws):
+        p.SubmitWithRS(w, None, *rs[k])                      # never GS_ERR_BUSY: the fourth Submit parks the first proof in the done-queue
+        assert p.InFlight() == k + 1 - len(got)
+        if k % 5 == 4:
+            while p.InFlight():
+                got.append(p.Collect())
+    assert len(got) == 20 and all(same(a, b) for a, b in zip(got, want))
+    for k in (0, 7, 19):
+        assert groth16.VerifyProof(inst.vk, got[k], [xs[k]]) and not groth16.VerifyProof(inst.vk, got[k], [xs[(k + 1) % 20]])
+    with pytest.raises(ValueError):
+        p.Collect()
+    # the px route through the same prover object, ints instead of limb arrays for one of them, and the one-call forms
+    h = capi.scalars_upload(ws[3])
+    ph = dr.ComputePxResident(h)
+    px3 = capi.scalars_download(ph)
+    p.SubmitWithRS(ws[3], px3, *rs[3])
+    p.SubmitWithRS(capi.u64_to_ints(ws[4]), None, *rs[4])
+    assert same(p.Collect(), want[3]) and same(p.Collect(), want[4])
+    assert same(groth16.GenerateProofsWithRS(circ, pk, ws[3], px3, *rs[3]), want[3])
+    assert same(groth16.GenerateProofsFromWitnessWithRS(circ, pk, dr, ws[5], *rs[5]), want[5])
+    # three tickets of ANOTHER owner occupy the device: the one-call forms fall back to the blocking entry points, the prover makes room by itself
+    held = [groth16.prove_witness_host_begin(pk, dr, ws[k], *rs[k]) for k in range(3)]
+    assert same(groth16.GenerateProofsFromWitnessWithRS(circ, pk, dr, ws[6], *rs[6]), want[6])
+    assert same(groth16.GenerateProofsWithRS(circ, pk, ws[3], px3, *rs[3]), want[3])
+    with pytest.raises(capi.GosnarkHipError) as e:
+        groth16.NewProver(circ, pk, dr).SubmitWithRS(ws[7], None, *rs[7])     # nothing of its own to collect: the busy device is reported
+    assert e.value.code == -6
+    assert all(same(groth16.prove_end(t), want[k]) for k, t in enumerate(held))
+    # Close abandons what is in flight; the slots are free again
+    p.SubmitWithRS(ws[8], None, *rs[8]); p.SubmitWithRS(ws[9], None, *rs[9])
+    p.Close()
+    assert p.InFlight() == 0
+    t = [groth16.prove_witness_host_begin(pk, dr, ws[k], *rs[k]) for k in range(3)]
+    assert all(same(groth16.prove_end(x), want[k]) for k, x in enumerate(t))
+    h.free(); ph.free()
+    # snark.Prover
+    pin = synth.sqchain_pinocchio_instance(n, 0x7602)
+    ppk = pin.device_pk()
+    pdr = r1csqap.DeviceR1CS(*pin.r1cs, pin.m)
+    pwant = snark.prove_resident(ppk, pin.w, pin.px)
+    sp = snark.NewProver(snark.Circuit(ppk.nvars, ppk.npublic) if hasattr(snark, "Circuit") else None, ppk, pdr)
+    for _ in range(5):
+        sp.Submit(pin.w_host)
+    sp.Submit(pin.w_host, pin.px_host)
+    outs = []
+    while sp.InFlight():
+        outs.append(sp.Collect())
+    assert len(outs) == 6 and all(all(getattr(o, f) == getattr(pwant, f) for f in snark.Proof.FIELDS) for o in outs)
+    assert all(getattr(snark.GenerateProofsFromWitness(None, ppk, pdr, pin.w_host), f) == getattr(pwant, f) for f in snark.Proof.FIELDS)

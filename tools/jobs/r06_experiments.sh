@@ -87,5 +87,10 @@ PY
     bash tools/gpu_run.sh $T ab acc64 acc128 : --log2n 22 --steps 4 --warmup 1 --reps 3
     bash tools/gpu_run.sh $T ab acc64 acc128 : --instance realistic --steps 12 --warmup 3 --reps 3
     bash tools/gpu_run.sh $T ab acc64 acc128 : --workload msm_g1 --log2n 16 --pipeline 1 --steps 200 --warmup 20 --reps 5 ;;
+  split_jobs)            # (in r06_power_clock_streams.txt) one accumulation launch per base array (GS_ACC_SPLIT_JOBS=1, a knob that existed for this experiment only) vs one launch with grid.y = jobs
+    bash tools/gpu_run.sh $T env GS_ACC_SPLIT_JOBS=1 : --steps 10 --warmup 3 --reps 5
+    bash tools/gpu_run.sh $T env GS_ACC_SPLIT_JOBS=1 : --workload prove_pinocchio --steps 8 --warmup 2 --reps 3
+    bash tools/gpu_run.sh $T env GS_ACC_SPLIT_JOBS=1 : --log2n 18 --steps 40 --warmup 5 --reps 5
+    GS_ACC_SPLIT_JOBS=1 timeout 600 python tools/power_trace.py 4 20 --streams-only 2>&1 | grep "stream\|proofs\|idle" | tee $OUT/streams_split_jobs.txt ;;
   *) echo "unknown experiment $NAME" >&2; exit 2 ;;
 esac

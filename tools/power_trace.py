@@ -268,10 +268,55 @@ def main():
                 groth16.prove_resident(pk, inst.w, inst.px, r, s)
                 done += 1
             return "%d blocking proofs, %.3f ms each" % (done, (time.perf_counter() - t0) * 1e3 / max(done, 1))
+        def alt_msm_stream():                 # G1 and G2 MSM tickets alternating: is it the CHANGE between the two accumulation kernels?
+            t_end = time.perf_counter() + SECONDS
+            tickets, done, t0, k = [], 0, time.perf_counter(), 0
+            while time.perf_counter() < t_end:
+                while len(tickets) < 3:
+                    tickets.append(capi.msm_begin(bases2, sc, n // 2, g2=True) if k % 2 else capi.msm_begin(bases, sc, n))
+                    k += 1
+                capi.msm_end(tickets.pop(0))
+                done += 1
+            for t in tickets:
+                capi.msm_end(t)
+            return "%d MSMs (G1 2^%d / G2 2^%d alternating), %.3f ms each" % (done, LOGN, LOGN - 1, (time.perf_counter() - t0) * 1e3 / max(done + len(tickets), 1))
+
+        def msm_px_stream():                  # G1 MSM tickets with a gs_r1cs_px between them: curve arithmetic and NTT passes alternating
+            t_end = time.perf_counter() + SECONDS
+            tickets, done, t0 = [], 0, time.perf_counter()
+            ph = dr.ComputePxResident(inst.w)
+            while time.perf_counter() < t_end:
+                while len(tickets) < 3:
+                    tickets.append(capi.msm_begin(bases, sc, n))
+                ph = dr.ComputePxResident(inst.w, ph)
+                capi.msm_end(tickets.pop(0))
+                done += 1
+            for t in tickets:
+                capi.msm_end(t)
+            return "%d x (G1 MSM + gs_r1cs_px), %.3f ms each" % (done, (time.perf_counter() - t0) * 1e3 / max(done + len(tickets), 1))
+
+        def pin_stream():
+            pin = synth.sqchain_pinocchio_instance(n, 4)
+            from gosnark_amd import snark
+            ppk = pin.device_pk()
+            snark.prove_resident(ppk, pin.w, pin.px)
+            t_end = time.perf_counter() + SECONDS
+            tickets, done, t0 = [], 0, time.perf_counter()
+            while time.perf_counter() < t_end:
+                while len(tickets) < 3:
+                    tickets.append(snark.prove_begin(ppk, pin.w, pin.px))
+                snark.prove_end(tickets.pop(0))
+                done += 1
+            for t in tickets:
+                snark.prove_end(t)
+            return "%d Pinocchio proofs (7 G1 sums, 1 G2), %.3f ms each" % (done, (time.perf_counter() - t0) * 1e3 / max(done + len(tickets), 1))
+        phase(sampler, "G1 / G2 MSM tickets alternating", alt_msm_stream)
+        phase(sampler, "G1 MSM tickets + gs_r1cs_px alternating", msm_px_stream)
         phase(sampler, "gs_r1cs_px stream (NTT passes only)", px_stream)
         phase(sampler, "witness -> proof stream, three in flight", witness_stream)
         phase(sampler, "blocking proofs back to back", blocking_stream)
         phase(sampler, "Groth16 proof stream again", proof_stream)
+        phase(sampler, "Pinocchio proof stream, three in flight", pin_stream)
     phase(sampler, "idle again", lambda: time.sleep(2.0))
     sampler.stop_flag = True
     sampler.join(timeout=2)
