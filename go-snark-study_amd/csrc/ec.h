@@ -351,6 +351,50 @@ GS_HD void xyzz_dbl(Xyzz<T>& acc) {
   acc.x = relax<9>(X3);
 }
 
+// ---- Jacobian doublings for the window-table builder (round 6) ------------------------------------------------------------------
+// A table row is 2^(c j) P: 14 x 17 doublings of ONE point, never an addition -- and a Jacobian doubling on an a = 0 curve is 3M + 4S
+// (A = X^2, B = Y^2, C = B^2, D = 4 X B, E = 3 A, X3 = E^2 - 2 D, Y3 = E (D - X3) - 8 C, Z3 = 2 Y Z: dbl-2009-l with its (X + B)^2 trick
+// undone, a product is cheaper here than the squaring plus the bound growth of the two subtractions) = 990 multiply-adds against the 1350 of
+// the XYZZ doubling (6M + 3S) the accumulators use.  Z = 0 <=> infinity.  The bounds are kept where the next doubling squares them
+// without a reduction of its own; smul / ssqr insert one wherever a type says so (Fq2 squares need bound <= 6).
+template <class T>
+struct Jac {
+  typename T::template E<7> x;
+  typename T::template E<5> y;
+  typename T::template E<4> z;
+};
+template <class T> GS_HD bool is_inf(const Jac<T>& p) { return T::limbs_all_zero(p.z); }
+template <class T>
+GS_HD Jac<T> jac_from_affine(const Affine<T>& a) {      // a finite
+  Jac<T> r;
+  r.x = relax<7>(a.x); r.y = relax<5>(a.y); r.z = relax<4>(T::one());
+  return r;
+}
+template <class T>
+GS_HD void jac_dbl(Jac<T>& p) {
+  const auto A = ssqr<T>(p.x);
+  const auto B = ssqr<T>(p.y);
+  const auto C = ssqr<T>(B);
+  const auto D = reduce2(dbl(dbl(smul<T>(p.x, B))));    // 4 X Y^2, back to bound 2: X3 and D - X3 stay small
+  const auto E = add(dbl(A), A);                        // 6
+  const auto F = ssqr<T>(E);
+  const auto X3 = sub(F, dbl(D));                       // 2 + 4 + 1 = 7
+  p.z = dbl(smul<T>(p.y, p.z));                         // 4 (the old y)
+  const auto t = smul<T>(E, sub(D, X3));                // 6 x 10
+  p.y = relax<5>(reduce2(sub(t, dbl(dbl(dbl(C))))));    // 2 + 16 + 1 = 19 -> 2
+  p.x = X3;
+}
+// (X, Y, Z) -> affine with 1 / Z given
+template <class T, class EI>
+GS_HD Affine<T> jac_to_affine_with_inverse(const Jac<T>& p, const EI& zinv) {
+  const auto i2 = ssqr<T>(zinv);
+  const auto i3 = smul<T>(i2, zinv);
+  Affine<T> r;
+  r.x = canon(smul<T>(p.x, i2));
+  r.y = canon(smul<T>(p.y, i3));
+  return r;
+}
+
 // acc += b   [add-2008-s: 12M + 2S], complete
 template <class T>
 GS_HD void xyzz_add(Xyzz<T>& acc, const Xyzz<T>& b) {

@@ -76,11 +76,11 @@ struct TableRef { BaseTable* t; const uint32_t* row0; size_t n; bool g2; };
 // Decides how the group is summed THIS time and prepares it: true = window tables, all of width *cbits and resident (built now
 // under policy `always`, or found); false = table-free with *cbits from choose_window_bits_free.  Under policy `auto` an array that
 // has been used twice gets its table IN INSTALMENTS: every call enqueues, in front of its own accumulations, as many slabs of the
-// pending table as `*credit` pays for (in G1-point builds; a G2 point costs kG2BuildCost of them; the caller grants ~0.05 points per
-// (job-unit x term) of its own work, i.e. a proof pays ~65 % of its own table-free time on top) and takes what it spent off
+// pending table as `*credit` pays for (in G1-point builds; a G2 point costs kG2BuildCost of them; the caller grants ~0.055 points per
+// (job-unit x term) of its own work, i.e. a proof pays ~60 % of its own table-free time on top) and takes what it spent off
 // *credit.  Stamps the tables for the LRU.
-constexpr double kG2BuildCost = 2.3;              // a G2 row costs 2.3 G1 rows (45 vs 20 ms per 2^20 points)
-constexpr double kBuildCreditPerUnitTerm = 0.05;  // 20 ms per 2^20 G1 points built / 1.5 ms per 2^20 (job-unit x term) summed table-free: 0.05 -> +65 % (6.7 ms per 2^20 proof)
+constexpr double kG2BuildCost = 2.3;              // a G2 row costs 2.3 G1 rows (40 vs 17.5 ms per 2^20 points)
+constexpr double kBuildCreditPerUnitTerm = 0.055; // 17.5 ms per 2^20 G1 points built (Jacobian doublings) / 1.5 ms per 2^20 (job-unit x term) summed table-free: 0.055 -> +60 % (6.5 ms per 2^20 proof)
 // The credit a call of `units` job-units (a G1 sum = 1, a G2 sum = 2.76) over n terms grants itself; never less than 2^18 G1 points
 // (~5 ms of building): the tables of a 2^16 key cost 9 ms in all while its table-free proofs take 5.5 ms instead of 2, so small keys are
 // warm after two or three calls instead of sixteen.

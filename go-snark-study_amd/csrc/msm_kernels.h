@@ -794,22 +794,25 @@ __global__ void __launch_bounds__(256) k_build_table_batched(const uint32_t* __r
     for (int j = 1; j < W; ++j) PointIO<T>::store_affine(rows + ((size_t)j * n + i) * aw, a);
     return;
   }
-  Xyzz<T> x = xyzz_dbl_affine<T>(a.x, relax<2>(a.y));
-  for (int k = 1; k < c; ++k) xyzz_dbl(x);
+  // Round 6: JACOBIAN doublings (ec.h, jac_dbl: 3M + 4S = 990 multiply-adds against the XYZZ doubling's 1350) -- a table row is 14 x 17
+  // doublings of one point and never an addition; per row the point is parked as (X, Y, Z) with the running product of the Z's, one
+  // inversion per point turns all rows affine (x = X / Z^2, y = Y / Z^3).
+  constexpr int cw = pw / 4;                                     // words per coordinate; a parked row = X | Y | Z | prefix (4 of the sw = 5 cw)
+  Jac<T> x = jac_from_affine<T>(a);
+  for (int k = 0; k < c; ++k) jac_dbl(x);
   bool degenerate = is_inf(x);
-  E2 pref = x.zzz;
-  {
-    uint32_t* s = scratch + (size_t)t * sw;                      // slab of row 1
-    store_xyzz<T>(s, x);
-    PointIO<T>::store_limbs(s + pw, pref);
-  }
-  for (int j = 2; j < W && !degenerate; ++j) {
-    for (int k = 0; k < c; ++k) xyzz_dbl(x);
-    degenerate = is_inf(x);
-    pref = smul<T>(pref, x.zzz);
+  E2 pref = reduce2(x.z);
+  auto park = [&](int j) {
     uint32_t* s = scratch + ((size_t)(j - 1) * count + t) * sw;
-    store_xyzz<T>(s, x);
-    PointIO<T>::store_limbs(s + pw, pref);
+    PointIO<T>::store_limbs(s, x.x); PointIO<T>::store_limbs(s + cw, x.y); PointIO<T>::store_limbs(s + 2 * cw, x.z);
+    PointIO<T>::store_limbs(s + 3 * cw, pref);
+  };
+  park(1);
+  for (int j = 2; j < W && !degenerate; ++j) {
+    for (int k = 0; k < c; ++k) jac_dbl(x);
+    degenerate = is_inf(x);
+    pref = smul<T>(pref, x.z);
+    park(j);
   }
   if (degenerate) {                                             // rare: redo this point row by row
     for (int j = 1; j < W; ++j) {
@@ -822,23 +825,19 @@ __global__ void __launch_bounds__(256) k_build_table_batched(const uint32_t* __r
     }
     return;
   }
-  E2 itot = inv(pref);                                          // 1 / (zzz_1 ... zzz_{W-1})
+  E2 itot = inv(pref);                                          // 1 / (Z_1 ... Z_{W-1})
   for (int j = W - 1; j >= 1; --j) {
     const uint32_t* s = scratch + ((size_t)(j - 1) * count + t) * sw;
-    const Xyzz<T> xj = load_xyzz<T>(s);
-    E2 izzz = itot;                                             // 1 / zzz_j
+    Jac<T> xj;
+    PointIO<T>::load_limbs(s, xj.x); PointIO<T>::load_limbs(s + cw, xj.y); PointIO<T>::load_limbs(s + 2 * cw, xj.z);
+    E2 iz = itot;                                               // 1 / Z_j
     if (j > 1) {
       E2 before;
-      PointIO<T>::load_limbs(scratch + ((size_t)(j - 2) * count + t) * sw + pw, before);
-      izzz = smul<T>(itot, before);
-      itot = smul<T>(itot, xj.zzz);
+      PointIO<T>::load_limbs(scratch + ((size_t)(j - 2) * count + t) * sw + 3 * cw, before);
+      iz = smul<T>(itot, before);
+      itot = smul<T>(itot, xj.z);
     }
-    const auto zi = smul<T>(xj.zz, izzz);                       // zz / zzz, whose square is 1 / zz
-    const auto i2 = ssqr<T>(zi);
-    Affine<T> r;
-    r.x = canon(smul<T>(xj.x, i2));
-    r.y = canon(smul<T>(xj.y, izzz));
-    PointIO<T>::store_affine(rows + ((size_t)j * n + i) * aw, r);
+    PointIO<T>::store_affine(rows + ((size_t)j * n + i) * aw, jac_to_affine_with_inverse<T>(xj, iz));
   }
 }
 

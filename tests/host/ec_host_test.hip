@@ -5,6 +5,7 @@
 //   op = lincomb : sum_i mul_words(P_i, k_i)  (xyzz_dbl / xyzz_add)
 //   op = maddsum : sum_i (sign ? -P_i : P_i)  (xyzz_madd)
 //   op = small   : sum_i mul_u32(P_i, k_i & 0xffffffff)
+//   op = jacdbl  : sum_i 2^(k_i & 0xffff) P_i, every power by repeated jac_dbl (the window-table builder's doubling, round 6), one inversion each
 #include <cstdio>
 #include <cstring>
 #include <iostream>
@@ -69,6 +70,12 @@ static void run(const std::string& op, int n) {
       xyzz_madd(acc, a, sign != 0);
     } else if (op == "maddacc") {          // the same chain through the kernel's accumulator type
       xyzz_madd(tight, a, sign != 0);
+    } else if (op == "jacdbl") {
+      if (!is_inf(a)) {
+        Jac<T> j = jac_from_affine<T>(a);
+        for (uint32_t d = 0; d < (k[0] & 0xffffu); ++d) jac_dbl(j);
+        if (!is_inf(j)) xyzz_madd(acc, jac_to_affine_with_inverse<T>(j, inv(reduce2(j.z))), sign != 0);
+      }
     } else if (op == "small") {
       const uint32_t small[8] = {k[0], 0, 0, 0, 0, 0, 0, 0};
       xyzz_add(acc, xyzz_mul_words_w4(xyzz_from_affine(a), small));

@@ -116,6 +116,19 @@ def test_small_scalar_mul(exe, g):
     assert ask(exe, g, "small", terms, G) == ref_sum(G, terms)
 
 
+@pytest.mark.parametrize("g", ["g1", "g2"])
+def test_jacobian_doubling_chain_of_the_table_builder(exe, g):
+    """Round 6: the window-table builder walks every point through 14 x 17 Jacobian doublings (ec.h jac_dbl: 3M + 4S on a = 0, bounds kept
+    where the next doubling squares them) instead of XYZZ ones.  2^k P for k = 0, 1, 2, 17, 34, 238, 255 doublings of random points (also
+    negated, also the generator), summed, against the oracle's MulScalar."""
+    G, gen = (O.G1, O.G1_GEN) if g == "g1" else (O.G2, O.G2_GEN)
+    rng = random.Random(15)
+    terms = [(rand_pt(rng, G, gen, 0.0), k, rng.randrange(2)) for k in (0, 1, 2, 17, 34, 238, 255)] + [(gen, 17, 0), (gen, 238, 1)]
+    want = ref_sum(G, [(p, 1 << k, s) for p, k, s in terms])
+    assert ask(exe, g, "jacdbl", terms, G) == want
+    assert ask(exe, g, "jacdbl", [(rand_pt(rng, G, gen, 1.0), 5, 0)], G) is None          # infinity in, nothing out
+
+
 def test_g1_77G_reference_kat(exe):
     """bn128/g1_test.go:29-30"""
     got = ask(exe, "g1", "lincomb", [(O.G1_GEN, 33, 0), (O.G1_GEN, 44, 0)], O.G1)

@@ -255,3 +255,13 @@ def test_stream_producer_c_sequence(tmp_path):
     lines = [l for l in out.splitlines() if l.startswith("route ")]
     assert out.strip().endswith("OK") and len(lines) == 4, out
     assert all(" 0 mismatches" in l and " 0 hipMalloc 0 hipFree" in l for l in lines), out
+
+
+def test_stream_stress_c_threads_of_four_kinds_on_one_device(tmp_path):
+    """Round 6 changed two things about concurrency: gs_*_end waits for the device OUTSIDE the context's lock (on its own reference to the
+    in-flight record) and blocking entry points work in a FREE ticket slot.  tests/c/stream_stress.c: three producers (host-buffer tickets,
+    both routes), two blockers (gs_groth16_prove / _prove_witness_host), one canceller (gs_ticket_cancel) and two bystanders (uploads, gs_r1cs_px,
+    downloads, frees, memory queries) hammer one key from eight threads for two seconds; every proof and every px equals its single-threaded
+    value, and three fresh tickets fit afterwards."""
+    out = c_util.build_and_run("stream_stress.c", ["11", "6", "2.0", "3", "2", "1", "2"], tmp_path, timeout=300)
+    assert out.strip().endswith("OK") and "differ from the single-threaded ones: 0" in out, out

@@ -21,6 +21,9 @@ import gpu_util as U  # noqa: E402
 from oracle import c_oracle as C  # noqa: E402
 from oracle import ref_py as O  # noqa: E402
 
+if os.environ.get("GS_STRESS_DUMP"):          # a hang shows where: dump every thread's stack after that many seconds and exit
+    import faulthandler
+    faulthandler.dump_traceback_later(float(os.environ["GS_STRESS_DUMP"]), exit=True)
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = random.Random(seed)
