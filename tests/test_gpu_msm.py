@@ -525,5 +525,15 @@ def test_randomised_degenerate_sums_equal_their_closed_form():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_msm_random.py"), "8", "7"], capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0 and "all equal the closed form" in out.stdout, (out.stdout[-500:], out.stderr[-1500:])
+    # (GS_STRESS_DUMP: should the tool ever stall, it dumps its Python stack and exits instead of sitting in the pipe until the timeout -- one run of
+    #  the suite in round 6 lost this test to a 600 s timeout on a box that was also 5 % slow on every bench line; it could not be reproduced in
+    #  three further suite runs nor standalone with this and two other seeds.  One retry, so that a stalled BOX does not fail the suite; a stalled
+    #  LIBRARY fails twice and shows where.)
+    env = dict(os.environ, GS_STRESS_DUMP="150")
+    out = None
+    for attempt in range(2):
+        out = subprocess.run([sys.executable, "-X", "faulthandler", os.path.join(root, "tools", "stress_msm_random.py"), "8", "7"], capture_output=True, text=True,
+                             timeout=400, env=env)
+        if out.returncode == 0:
+            break
+    assert out.returncode == 0 and "all equal the closed form" in out.stdout, (out.stdout[-500:], out.stderr[-2500:])
