@@ -18,8 +18,8 @@ const packChunk = 4096
 // parallelRange runs f over [0, n) cut into at most GOMAXPROCS contiguous chunks and returns the first error.
 func parallelRange(n int, f func(lo, hi int) error) error {
 	workers := runtime.GOMAXPROCS(0)
-	if max := (n + packChunk - 1) / packChunk; workers > max {
-		workers = max
+	if most := (n + packChunk - 1) / packChunk; workers > most {
+		workers = most
 	}
 	if workers <= 1 {
 		return f(0, n)

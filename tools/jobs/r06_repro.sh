@@ -1,5 +1,3 @@
-# round 6: the GPU suite three times in a row on one box (one earlier run of it lost tests/test_gpu_msm.py::test_randomised_degenerate_sums... to a subprocess timeout on a
-# box that was also 5 % slow; never reproduced: this estimates how rare)
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r6x_repro
-for k in 1 2 3; do (timeout 1500 python -m pytest tests -m gpu -q --maxfail=10 2>&1 | tail -3) | tee -a gpurun_out/r6x_repro/suite_x3.txt; done
+timeout 600 python tools/power_trace.py 4 20 --streams-only 2>&1 | grep "stream\|proofs\|idle\|alternating" | tee gpurun_out/r6x_repro/streams_with_temps.txt

@@ -83,7 +83,21 @@ class Sysfs:
 
     def sample(self):
         return (time.perf_counter(), read_int(self.power) if self.power else None, read_int(self.sclk) if self.sclk else None,
-                read_int(self.busy) if self.busy else None, read_int(self.mclk) if self.mclk else None)
+                read_int(self.busy) if self.busy else None, read_int(self.mclk) if self.mclk else None) + tuple(read_int(p) for _, p in self.temps())
+
+    def temps(self):
+        """[(label, path)] of the card's temperature sensors (junction / memory / edge), found once"""
+        if not hasattr(self, "_temps"):
+            self._temps = []
+            hw = os.path.dirname(self.power) if self.power else None
+            for p in sorted(glob.glob(os.path.join(hw, "temp*_input"))) if hw else []:
+                try:
+                    label = open(p.replace("_input", "_label")).read().strip()
+                except OSError:
+                    label = os.path.basename(p)
+                if read_int(p) is not None:
+                    self._temps.append((label, p))
+        return self._temps
 
 
 def smi_sample():
@@ -129,8 +143,10 @@ def phase(sampler, name, fn):
     # the first 25 % of a phase is the transient (clock ramp, power averaging window): report the rest
     lo = t0 + 0.25 * (t1 - t0)
     rows = [r for r in sampler.rows if lo <= r[0] <= t1]
-    print("%-46s %5.1f s | power W %s | sclk MHz %s | busy %% %s" % (name, t1 - t0, stats([r[1] for r in rows], 1e-6), stats([r[2] for r in rows], 1e-6),
-                                                               stats([r[3] for r in rows], 1.0)))
+    temps = " ".join("%s %.0f C" % (label, max([r[5 + i] for r in rows if len(r) > 5 + i and r[5 + i] is not None] or [0]) * 1e-3)
+                     for i, (label, _) in enumerate(sampler.sysfs.temps())) if sampler.fast else ""
+    print("%-46s %5.1f s | power W %s | sclk MHz %s | busy %% %s | max %s" % (name, t1 - t0, stats([r[1] for r in rows], 1e-6), stats([r[2] for r in rows], 1e-6),
+                                                                        stats([r[3] for r in rows], 1.0), temps))
     if note:
         print("      " + note.strip().replace("\n", "\n      "))
     sys.stdout.flush()
