@@ -474,8 +474,8 @@ TABLE_POLICY = {"auto": 0, "always": 1, "never": 2}
 
 
 def set_table_policy(policy):
-    """gs_set_table_policy: "auto" (table-free until a base array's second use, then a background build), "always" (build inside
-    the first call), "never" (table-free only).  Results never depend on it."""
+    """gs_set_table_policy: "auto" (table-free until a base array's second use, then a build in instalments paid by the calls
+    that follow), "always" (build inside the first call), "never" (table-free only).  Results never depend on it."""
     init()
     check(load_library().gs_set_table_policy(TABLE_POLICY[policy] if isinstance(policy, str) else int(policy)))
 

@@ -146,7 +146,7 @@ func (k *PinocchioKey) ProveWitnessHost(q *R1CS, w []*big.Int, order *big.Int) (
 type TablePolicy int
 
 const (
-	TablesAuto   TablePolicy = 0 // table-free until an array's second use, then a background build (default)
+	TablesAuto   TablePolicy = 0 // table-free until an array's second use, then a build in instalments (default)
 	TablesAlways TablePolicy = 1 // inside the first call that needs them (~140 ms per 2^20 Groth16 key)
 	TablesNever  TablePolicy = 2 // table-free only: 0.4 GiB per 2^20 key instead of 6
 )

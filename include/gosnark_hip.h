@@ -490,8 +490,9 @@ int gs_release_tables(gs_handle h);
  *   0 auto (default)  the reference proves once per key load (cli/main.go:330-349), and the tables of a 2^20 key cost ~140 ms and
  *                     5.6 GiB -- fifteen proofs' worth -- before the first proof.  An array without a table is summed TABLE-FREE
  *                     (a bucket set per window, every window adds the base point itself, the window sums recombined by Horner:
- *                     ~1.2x the additions); from its second use on its table is built in the background on a low-priority
- *                     stream while proofs keep running table-free, and the first call that finds it complete switches over.
+ *                     ~1.2x the additions); from its second use on its table is built in INSTALMENTS: every call buys slabs of
+ *                     the table in proportion to its own work (~+60-100% of a table-free proof; GS_TABLE_BUDGET_PCT scales it),
+ *                     enqueued ahead of its own accumulations, and the first call that finds the table complete switches over.
  *   1 always          the table is built inside the first call that needs it (rounds 1-4)
  *   2 never           table-free only (0.4 GiB per 2^20 key instead of 6; what 2^24 constraints on one GPU use)
  * gs_build_tables builds them NOW (blocking, whatever the policy): a server warming a key it will prove with for hours, and what
