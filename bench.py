@@ -71,8 +71,10 @@ VALU_PER_MIXED_ADD = 2090      # SQ_INSTS_VALU per G1 mixed addition (profiles/r
 # 1.2-1.35 GHz": a SIMD issues oldest-first, so the MEAN wave span round 5 divided by all three waves' instructions covers 70 % of the
 # time they were issued in, and mean span / kernel time is not a clock; s_memtime ticks at sclk, 2.38-2.40 GHz in every sustained loop).
 # Cycles per wave64 instruction per SIMD on the whole chip: v_mad_u64_u32 4.47, the other VOP3 / multiplier classes 4.4-4.8, VOP2 2.9,
-# s_nop 1.35 -- against 1.9 / 1.8 / 1.8 / 1.35 on a stream restricted to 32 CUs: a socket-level throttle of the ISSUE rate (the socket draws
-# 0.95-1.37 kW of its 1.4 kW cap in these loops, the PLL only drops in the real workloads).  fp29.h's own products (dots3, random data)
+# s_nop 1.35 -- and the SAME on a stream confined to 8 / 32 / 128 CUs (profiles/r06_ubench_placement_cu_mask.txt, which corrects a first
+# reading of masked runs as a socket-level throttle: that mask did not confine the waves): it is the pipe's own rate, sixteen lanes per
+# clock = 4 cycles per wave for the 64-bit / multiplier classes (the data sheet's FP64 vector peak), of which three waves per SIMD reach
+# 89 %.  The socket draws 0.95-1.37 kW of its 1.4 kW cap in these loops; the PLL only drops in the real workloads.  fp29.h's own products (dots3, random data)
 # run at 876 cycles per product per SIMD = 4.23 per VALU instruction: 745 200 VALU instructions per SIMD per 1.357 ms launch in a sustained
 # loop.  That rate, chip-wide, is the peak below.
 ISSUE_PEAK_G = 1024 * 0.5492   # G wave-instructions/s: 1024 SIMDs x 549.2 M/s (the dots3 product loop, sustained; round 5: 463 from a one-shot launch)
@@ -1492,9 +1494,9 @@ def main():
                                              "Montgomery products (dots3, random data) in a bare loop without loads, SUSTAINED: 207 VALU instructions per 377 ns per SIMD "
                                              "(tools/ubench_mulmod.hip 2 4: 876 cycles per product per SIMD at sclk 2.39 GHz).  Per class the G1 addition sums to 9.3 k "
                                              "cycles (1474 multiply-adds x 4.47 + 313 other VOP3 x 4.6 + 337 VOP2 x 2.9 + 249 s_nop x 1.35); the kernel takes 11.1 k at the "
-                                             "2.27 GHz the MSM stream runs at (socket 1365 W of its 1400 W cap): 0.81-0.84 in cycles, 0.76-0.78 in time.  The chip's issue rate "
-                                             "under full load is set by a socket-level throttle (a multiply-add issues every 1.9 cycles per SIMD on 32 CUs, every 4.5 on 256), "
-                                             "not by the clock round 5 derived: profiles/r06_power_clock_trace.txt"}
+                                             "2.27 GHz the MSM stream runs at (socket 1365 W of its 1400 W cap): 0.81-0.84 in cycles, 0.76-0.78 in time.  4.47 cycles per multiply-add is "
+                                             "the SIMD's own rate at three waves per SIMD, on 8 CUs as on 256 (a sixteen-lane pipe: 4 cycles per wave at best, 7.8 k cycles per "
+                                             "addition architecturally), not a clock or a socket-wide limit: profiles/r06_power_clock_trace.txt, r06_ubench_placement_cu_mask.txt"}
             out["roofline_whole_step"] = {"bound": "hbm", "algorithmic_bytes_per_step": step_bytes,
                                           "achieved": step_bytes / (elapsed / args.steps) / 1e9,
                                           "peak": HBM_PEAK_GBS, "unit": "GB/s",

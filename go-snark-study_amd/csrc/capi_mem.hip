@@ -151,7 +151,7 @@ int gs_set_table_policy(int policy) {
   std::lock_guard<std::mutex> rl(r.mu);
   if (r.ctxs.empty()) return fail(GS_ERR_NOT_INIT, "gs_init has not been called (or failed)");
   for (auto& pc : r.ctxs) {
-    std::lock_guard<std::mutex> lk(pc->mu);
+    std::lock_guard<FairMutex> lk(pc->mu);
     pc->table_policy = policy;
   }
   return GS_OK;

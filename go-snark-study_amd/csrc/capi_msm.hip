@@ -282,7 +282,7 @@ static void ctx_create(Ctx& c, int logical, int device) {
 }
 
 static void ctx_destroy(Ctx& c) {
-  std::lock_guard<std::mutex> lk(c.mu);
+  std::lock_guard<FairMutex> lk(c.mu);
   if (!c.ready) return;
   (void)hipSetDevice(c.device);
   (void)hipDeviceSynchronize();
@@ -566,7 +566,7 @@ int gs_device_timing(int logical_device, gs_timing* out) {
   std::shared_ptr<Ctx> pc = ctx_ref(logical_device);
   if (!pc) return fail(GS_ERR_ARG, "gs_device_timing: no logical device %d", logical_device);
   Ctx& c = *pc;
-  std::lock_guard<std::mutex> lk(c.mu);
+  std::lock_guard<FairMutex> lk(c.mu);
   if (!c.ready) return fail(GS_ERR_NOT_INIT, "the library was shut down");
   *out = c.timing;
   return GS_OK;
@@ -593,7 +593,7 @@ int gs_set_window_bits(int cbits) {
   std::lock_guard<std::mutex> rl(r.mu);
   if (r.ctxs.empty()) return fail(GS_ERR_NOT_INIT, "gs_init has not been called (or failed)");
   for (auto& pc : r.ctxs) {
-    std::lock_guard<std::mutex> lk(pc->mu);
+    std::lock_guard<FairMutex> lk(pc->mu);
     pc->window_bits = cbits;
   }
   return GS_OK;
@@ -606,7 +606,7 @@ int gs_set_eval_basis(int enabled) {
   std::lock_guard<std::mutex> rl(r.mu);
   if (r.ctxs.empty()) return fail(GS_ERR_NOT_INIT, "gs_init has not been called (or failed)");
   for (auto& pc : r.ctxs) {
-    std::lock_guard<std::mutex> lk(pc->mu);
+    std::lock_guard<FairMutex> lk(pc->mu);
     pc->eval_basis = enabled != 0;
   }
   return GS_OK;

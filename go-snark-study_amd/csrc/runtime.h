@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include <atomic>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -183,6 +184,35 @@ inline int handle_device(gs_handle h) { return (int)(h >> kHandleDevShift); }
 inline std::atomic<uint64_t>& handle_counter() { static std::atomic<uint64_t> v{1}; return v; }
 inline std::atomic<uint64_t>& ticket_counter() { static std::atomic<uint64_t> v{1}; return v; }
 
+// The context's lock: first come, first served.  std::mutex is not fair -- the thread that releases it and asks again at once beats
+// every waiter that first has to be woken -- and entry points hold a context for as long as a blocking proof: two threads calling
+// gs_groth16_prove in a loop locked three pipelined producers, a canceller and two bystanders out for a whole minute (round 6,
+// tests/c/stream_stress.c: 27 434 blocking proofs against ONE operation of every other thread).  Tickets are served in the order of
+// arrival; uncontended it costs two uncontended std::mutex round trips.
+class FairMutex {
+ public:
+  void lock() {
+    std::unique_lock<std::mutex> lk(m_);
+    const uint64_t mine = next_++;
+    while (mine != serving_) cv_.wait(lk);
+  }
+  bool try_lock() {
+    std::lock_guard<std::mutex> lk(m_);
+    if (next_ != serving_) return false;
+    next_ += 1;
+    return true;
+  }
+  void unlock() {
+    bool waiters;
+    { std::lock_guard<std::mutex> lk(m_); serving_ += 1; waiters = next_ != serving_; }
+    if (waiters) cv_.notify_all();
+  }
+ private:
+  std::mutex m_;
+  std::condition_variable cv_;
+  uint64_t next_ = 0, serving_ = 0;
+};
+
 struct Ctx {
   int logical = 0;                // index in gs_init's device list (several entries may name the same physical device)
   int device = -1;                // HIP ordinal
@@ -229,7 +259,7 @@ struct Ctx {
   // sets of bucket / partial workspaces (17 GB each at 2^24 constraints); now the fourth exists only if it is ever needed.
   int blocking_slot() const { const int p = free_parity(); return p >= 0 ? p : kBlockingSlot; }
   static constexpr size_t kPinnedBytes = 256 * 1024;
-  std::mutex mu;
+  FairMutex mu;
   std::unordered_map<uint64_t, std::shared_ptr<Object>> objs;     // in-flight operations hold references: gs_free defers
   uint64_t call_clock = 0;       // one tick per entry-point call on this context: window tables stamp it when a call uses them (LRU
                                  // order for evict_tables_for; a table stamped with the running call's tick is never its victim)
@@ -343,7 +373,7 @@ int guarded(F&& f, bool need_init = true, bool allow_inflight = false, gs_handle
   const int logical = route ? handle_device(route) : current_logical();
   std::shared_ptr<Ctx> pc = ctx_ref(logical, &ndev);
   Ctx& c = pc ? *pc : none_ctx();
-  std::lock_guard<std::mutex> lk(c.mu);
+  std::lock_guard<FairMutex> lk(c.mu);
   if (need_init && !c.ready) {
     if (ndev == 0) return fail(GS_ERR_NOT_INIT, "gs_init has not been called (or failed)");
     return fail(GS_ERR_ARG, "no logical device %d (gs_init listed %zu)", logical, ndev);
@@ -375,7 +405,7 @@ inline void wait_ticket_unlocked(uint64_t ticket) {
   if (!pc) return;
   std::shared_ptr<InFlightBase> op;
   {
-    std::lock_guard<std::mutex> lk(pc->mu);
+    std::lock_guard<FairMutex> lk(pc->mu);
     if (!pc->ready) return;
     for (auto& f : pc->inflight) if (f && f->ticket == ticket) op = f;
   }
@@ -395,7 +425,7 @@ int guarded_pair(gs_handle route, int target, F&& f) {
   if (!pd) return fail(GS_ERR_ARG, "no logical device %d (gs_init listed %zu)", target, ndev);
   Ctx& src = *ps;
   Ctx& dst = *pd;
-  std::unique_lock<std::mutex> l1(src.mu, std::defer_lock), l2(dst.mu, std::defer_lock);
+  std::unique_lock<FairMutex> l1(src.mu, std::defer_lock), l2(dst.mu, std::defer_lock);
   if (&src == &dst) l1.lock(); else std::lock(l1, l2);
   if (!src.ready || !dst.ready) return fail(GS_ERR_NOT_INIT, "the library was shut down");
   CurrentCtxScope scope(&dst);                  // allocations of a pair call land on the target

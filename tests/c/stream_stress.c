@@ -153,11 +153,18 @@ int main(int argc, char** argv) {
   for (int i = 0; i < total; ++i) if (pthread_create(&th[i], NULL, work, &ws[i]) != 0) return 7;
   for (int i = 0; i < total; ++i) pthread_join(th[i], NULL);
   const char* names[4] = {"producers", "blockers", "cancellers", "bystanders"};
-  long bad = 0, ops[4] = {0, 0, 0, 0}, busy = 0;
-  for (int i = 0; i < total; ++i) { if (ws[i].status) return 4; bad += ws[i].bad; ops[ws[i].kind] += ws[i].ops; busy += ws[i].busy; }
-  for (int kind = 0; kind < 4; ++kind) printf("%s %d: %ld operations\n", names[kind], counts[kind], ops[kind]);
+  long bad = 0, ops[4] = {0, 0, 0, 0}, fewest[4] = {-1, -1, -1, -1}, busy = 0;
+  for (int i = 0; i < total; ++i) {
+    if (ws[i].status) return 4;
+    bad += ws[i].bad; ops[ws[i].kind] += ws[i].ops; busy += ws[i].busy;
+    if (fewest[ws[i].kind] < 0 || ws[i].ops < fewest[ws[i].kind]) fewest[ws[i].kind] = ws[i].ops;
+  }
+  for (int kind = 0; kind < 4; ++kind) printf("%s %d: %ld operations (the slowest thread: %ld)\n", names[kind], counts[kind], ops[kind], fewest[kind] < 0 ? 0 : fewest[kind]);
   printf("GS_ERR_BUSY answers: %ld; results that differ from the single-threaded ones: %ld\n", busy, bad);
   if (bad) { printf("FAIL\n"); return 5; }
+  /* nobody may be locked out: the context's lock is first come, first served (runtime.h, FairMutex) */
+  for (int kind = 0; kind < 4; ++kind)
+    if (counts[kind] && seconds >= 2.0 && fewest[kind] < 5) { printf("FAIL: a thread of the %s was starved (%ld operations in %.0f s)\n", names[kind], fewest[kind], seconds); return 10; }
   /* nothing may be left in flight: three fresh tickets fit */
   uint64_t t[3], got[32];
   int inf[3];

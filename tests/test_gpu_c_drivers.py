@@ -262,6 +262,7 @@ def test_stream_stress_c_threads_of_four_kinds_on_one_device(tmp_path):
     in-flight record) and blocking entry points work in a FREE ticket slot.  tests/c/stream_stress.c: three producers (host-buffer tickets,
     both routes), two blockers (gs_groth16_prove / _prove_witness_host), one canceller (gs_ticket_cancel) and two bystanders (uploads, gs_r1cs_px,
     downloads, frees, memory queries) hammer one key from eight threads for two seconds; every proof and every px equals its single-threaded
-    value, and three fresh tickets fit afterwards."""
+    value, three fresh tickets fit afterwards, and NO thread is locked out (the context's lock is first come, first served: with
+    std::mutex the two blockers did 27 434 proofs in a minute against one operation of every other thread)."""
     out = c_util.build_and_run("stream_stress.c", ["11", "6", "2.0", "3", "2", "1", "2"], tmp_path, timeout=300)
-    assert out.strip().endswith("OK") and "differ from the single-threaded ones: 0" in out, out
+    assert out.strip().endswith("OK") and "differ from the single-threaded ones: 0" in out and "starved" not in out, out

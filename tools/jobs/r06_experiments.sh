@@ -35,6 +35,9 @@ PY
     done 2>&1 | tee $OUT/ubench_issue_cu_mask.txt ;;
   placement)             # r06_ubench_placement.txt: where and when the waves of the ubench launches run
     ./tools/ubench_placement 2>&1 | tee $OUT/ubench_placement.txt ;;
+  mask_placement)        # r06_ubench_placement_cu_mask.txt: do CU-masked streams confine the waves (HW_ID / XCC_ID of every wave)?
+    ./tools/ubench_placement masked 2>&1 | tee $OUT/ubench_placement_cu_mask.txt
+    ./tools/ubench_placement 2>&1 | tee $OUT/ubench_placement.txt ;;
   auto_transient)        # r06_auto_instalments.txt: every blocking proof of a fresh 2^20 key under `auto` at several build budgets, `always` beside it
     for pct in 100 50 200 400 100000; do echo "== GS_TABLE_BUDGET_PCT=$pct"; GS_TABLE_BUDGET_PCT=$pct timeout 300 python tools/time_first_proof.py auto 20 40; done 2>&1 | grep -v "^$" | tee $OUT/auto_instalments.txt
     echo "== policy always"; timeout 300 python tools/time_first_proof.py always 20 12 2>&1 | tee -a $OUT/auto_instalments.txt

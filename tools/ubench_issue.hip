@@ -206,8 +206,8 @@ __global__ void __launch_bounds__(256, 3) k_issue(uint32_t* out, unsigned long l
 static double g_seconds = 0;
 static int g_only = -1;
 // argv[3] = CUs: run on a stream restricted to that many CUs (hipExtStreamCreateWithCUMask; 3 workgroups = 3 waves per SIMD on each of
-// them, the rest of the chip idle).  Round 6: if an instruction costs the same WALL time on 8 CUs as on 256, its price is not set by a
-// chip-wide power or current limit.
+// them, the rest of the chip idle).  Round 6: an instruction costs the same cycles on 8 CUs as on 256 -- its price is the SIMD's own
+// rate for its class, not a chip-wide power or current limit.
 static hipStream_t g_stream = nullptr;
 static unsigned long long* g_real = nullptr;
 template <int MODE>
@@ -255,10 +255,11 @@ int main(int argc, char** argv) {
   if (argc >= 4 && atoi(argv[3]) > 0) {
     const int cus = atoi(argv[3]);
     std::vector<uint32_t> mask((prop.multiProcessorCount + 31) / 32, 0u);
-    for (int i = 0; i < cus; ++i) {                         // spread over the mask: one CU per XCD first (the mask interleaves XCDs)
-      const int bit = (int)((long long)i * prop.multiProcessorCount / cus);
-      mask[bit / 32] |= 1u << (bit % 32);
-    }
+    // the FIRST `cus` bits.  (Until late in round 6 the bits were spread over the mask, one every 256 / cus: tools/ubench_placement.hip
+    // `masked` shows that such a mask does NOT confine the launch -- 8 spread bits put the 24 workgroups on 24 CUs, one wave per SIMD --
+    // so the "1.8-1.9 cycles per instruction on 8 / 32 CUs" of that form were a lone wave's 5.5-5.8 cycles divided by three.  With
+    // the first bits the waves sit 3 per SIMD on exactly `cus` CUs, and every class costs what it costs on the full chip.)
+    for (int i = 0; i < cus; ++i) mask[i / 32] |= 1u << (i % 32);
     CK(hipExtStreamCreateWithCUMask(&g_stream, (uint32_t)mask.size(), mask.data()));
     blocks = cus * 3;
     printf("stream restricted to %d of %d CUs, %d workgroups\n", cus, prop.multiProcessorCount, blocks);

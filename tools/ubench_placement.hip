@@ -10,6 +10,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <map>
+#include <string>
 #include <vector>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 constexpr int ITERS = 1000;
@@ -38,21 +39,43 @@ __global__ void __launch_bounds__(256, 3) k_mad(uint32_t* out, Rec* rec, uint32_
   out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)(a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7);
 }
 
-int main() {
+// `ubench_placement masked`: the same launch (3 workgroups per CU of the mask) on CU-masked streams of 8 / 32 / 128 CUs, mask bits
+// spread over the whole mask ("spread", what ubench_issue's argv[3] builds) or the first bits ("first"): does the mask restrict the
+// placement, i.e. do three waves really share every SIMD of the masked CUs?
+int main(int argc, char** argv) {
   CK(hipSetDevice(0));
   hipDeviceProp_t prop;
   CK(hipGetDeviceProperties(&prop, 0));
-  const int cus = prop.multiProcessorCount;
-  for (int per_cu : {1, 2, 3, 4, 6}) {
+  const int all_cus = prop.multiProcessorCount;
+  const bool masked = argc >= 2 && std::string(argv[1]) == "masked";
+  struct Case { int cus, per_cu; int layout; };             // layout 0: no mask, 1: spread bits, 2: first bits
+  std::vector<Case> cases;
+  if (!masked) for (int per_cu : {1, 2, 3, 4, 6}) cases.push_back({all_cus, per_cu, 0});
+  else for (int layout : {1, 2}) for (int c : {8, 32, 128, 256}) cases.push_back({c, 3, layout});
+  for (const Case& cs_ : cases) {
+    const int cus = cs_.cus, per_cu = cs_.per_cu;
+    hipStream_t stream = nullptr;
+    if (cs_.layout) {
+      std::vector<uint32_t> mask((all_cus + 31) / 32, 0u);
+      for (int i = 0; i < cus; ++i) {
+        const int bit = cs_.layout == 1 ? (int)((long long)i * all_cus / cus) : i;
+        mask[bit / 32] |= 1u << (bit % 32);
+      }
+      CK(hipExtStreamCreateWithCUMask(&stream, (uint32_t)mask.size(), mask.data()));
+      std::vector<uint32_t> back(mask.size(), 0u);
+      hipError_t ge = hipExtStreamGetCUMask(stream, (uint32_t)back.size(), back.data());
+      int set = 0; for (uint32_t w : back) set += __builtin_popcount(w);
+      printf("CU mask of %d CUs, %s bits; hipExtStreamGetCUMask: %s, %d bits set\n", cus, cs_.layout == 1 ? "spread" : "first", hipGetErrorString(ge), set);
+    }
     const int blocks = cus * per_cu, waves = blocks * 4;
     uint32_t* dout; Rec* drec;
     CK(hipMalloc(&dout, (size_t)blocks * 256 * 4)); CK(hipMalloc(&drec, (size_t)waves * sizeof(Rec)));
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     float ms = 0;
     for (int rep = 0; rep < 3; ++rep) {
-      CK(hipEventRecord(a));
-      hipLaunchKernelGGL(k_mad, dim3(blocks), dim3(256), 0, 0, dout, drec, 777u + rep);
-      CK(hipEventRecord(b)); CK(hipEventSynchronize(b)); CK(hipEventElapsedTime(&ms, a, b));
+      CK(hipEventRecord(a, stream));
+      hipLaunchKernelGGL(k_mad, dim3(blocks), dim3(256), 0, stream, dout, drec, 777u + rep);
+      CK(hipEventRecord(b, stream)); CK(hipEventSynchronize(b)); CK(hipEventElapsedTime(&ms, a, b));
     }
     std::vector<Rec> h(waves);
     CK(hipMemcpy(h.data(), drec, waves * sizeof(Rec), hipMemcpyDeviceToHost));
@@ -72,10 +95,11 @@ int main() {
     double cs = 0; for (double v : cyc) cs += v;
     printf("%d workgroups per CU (%d waves): kernel %.1f us (events); waves on %zu CUs / %zu SIMDs; waves per SIMD histogram:", per_cu, waves, ms * 1e3, per_cu_count.size(), per_simd.size());
     for (auto& kv : hist) printf(" %dx%d", kv.first, kv.second);
-    printf("\n    starts us p0 %.1f p50 %.1f p90 %.1f p100 %.1f | ends us p0 %.1f p50 %.1f p100 %.1f | wave span us p5 %.1f p50 %.1f p95 %.1f | s_memtime cycles per wave mean %.0f -> %.3f cycles per mad per wave\n",
+    printf("\n    starts us p0 %.1f p50 %.1f p90 %.1f p100 %.1f | ends us p0 %.1f p50 %.1f p100 %.1f | wave span us p5 %.1f p50 %.1f p95 %.1f | s_memtime cycles per wave mean %.0f -> %.3f cycles per mad per wave (longest wave %.3f, shortest %.3f)\n",
            pct(starts, 0), pct(starts, 0.5), pct(starts, 0.9), pct(starts, 1.0), pct(ends, 0), pct(ends, 0.5), pct(ends, 1.0), pct(spans, 0.05), pct(spans, 0.5), pct(spans, 0.95),
-           cs / waves, cs / waves / (64.0 * ITERS));
+           cs / waves, cs / waves / (64.0 * ITERS), pct(cyc, 1.0) / (64.0 * ITERS), pct(cyc, 0) / (64.0 * ITERS));
     CK(hipFree(dout)); CK(hipFree(drec));
+    if (stream) CK(hipStreamDestroy(stream));
   }
   return 0;
 }
