@@ -64,6 +64,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E, /opt/skills/guides/MI355X_MICROAR
 MAD_PEAK_T = 34.4              # T lane-mad/s, v_mad_u64_u32 on 8 chains, 3 waves per SIMD, whole chip, SUSTAINED (4 s of launches at sclk 2.39 GHz: 4.47
                                # cycles per instruction per SIMD; tools/ubench_issue.hip 0 4 -> profiles/r06_power_clock_trace.txt).  Rounds 1-5 used 31.5, from
                                # a single launch out of idle, i.e. on a clock still ramping (2.1 GHz by s_memtime / s_memrealtime)
+MAD_PIPE_T = 1024 * 16 * 2.4e9 / 1e12   # T lane-mad/s: the multiplier pipe, sixteen lanes per clock per SIMD (v_mad_u64_u32 and v_fma_f64 alike: the data sheet's FP64 vector peak)
 G1_TERM_BYTES = 96             # 32 B scalar + 64 B affine base per G1 MSM term
 MADS_PER_MIXED_ADD = 1467      # 6 products (162 mads) + 2 squarings (126) + one two-term product (243)
 VALU_PER_MIXED_ADD = 2090      # SQ_INSTS_VALU per G1 mixed addition (profiles/r03_/r04_pmc_sq_accumulate_prove.txt)
@@ -1483,8 +1484,11 @@ def main():
             # addition = 1467 mads; a term takes one addition per digit position (floor(254 / c) + 1 of them).
             out["roofline_valu"] = {"bound": "valu-int-mad", "kernel": "k_bucket_accumulate<G1>", "achieved": mads, "peak": MAD_PEAK_T,
                                     "unit": "T lane-mad/s", "frac": mads / MAD_PEAK_T,
+                                    "peak_architectural": MAD_PIPE_T, "frac_of_architectural": mads / MAD_PIPE_T,
                                     "note": "mixed additions per launch (gs_timing.acc_g1_adds: the non-zero digits the plan counted) x 1467 v_mad_u64_u32; window width "
-                                            "c = %d -> at most %d additions per term; peak = the sustained full-chip rate of tools/ubench_issue.hip (profiles/r06_power_clock_trace.txt; 31.5 in rounds 1-5)" % (cbits, 254 // max(cbits, 1) + 1)}
+                                            "c = %d -> at most %d additions per term; peak = the sustained full-chip rate of tools/ubench_issue.hip at the kernel's three waves "
+                                            "per SIMD (profiles/r06_power_clock_trace.txt; 31.5 in rounds 1-5); peak_architectural = 1024 SIMDs x 16 lanes per clock x 2.4 GHz, "
+                                            "the multiplier pipe itself (profiles/r06_ubench_placement_cu_mask.txt: 89 %% of it at three waves per SIMD, 95 %% at six)" % (cbits, 254 // max(cbits, 1) + 1)}
             # ... and the limit under that one: a 64-wide wave occupies its 16-lane SIMD for 4 cycles per VALU instruction, whatever the
             # instruction; the G1 mixed addition is 2090 of them (SQ_INSTS_VALU, profiles/r04_pmc_sq_accumulate_prove.txt)
             wave_instr = tm_acc["acc_g1_adds"] / launches / 64.0 * VALU_PER_MIXED_ADD / avg_launch_s if avg_launch_s > 0 else 0.0
