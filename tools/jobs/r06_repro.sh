@@ -1,16 +1,11 @@
 cd $GRAFT_REPO_ROOT
-# round 6, late: the context's lock made first come, first served (runtime.h FairMutex) -- the eight-thread stress at two sizes, the C producers,
-# and where the waves of a CU-masked stream really run
-O=gpurun_out/r6x_fair; mkdir -p $O
-gcc -std=c99 -O2 -Wall -Wextra -I include -I tests/c tests/c/stream_stress.c -o /tmp/stream_stress -L go-snark-study_amd -lgosnark_hip -Wl,-rpath,$PWD/go-snark-study_amd -lpthread || exit 1
-for args in "11 6 2 3 2 1 2" "16 8 20 3 2 1 2" "20 4 20 3 2 1 2"; do echo "== stream_stress $args"; timeout 600 /tmp/stream_stress $args 2>&1 | tail -8; done | tee $O/stream_stress.txt
-gcc -std=c99 -O2 -Wall -Wextra -I include -I tests/c tests/c/stream_producer.c -o /tmp/stream_producer -L go-snark-study_amd -lgosnark_hip -Wl,-rpath,$PWD/go-snark-study_amd -lpthread || exit 1
-timeout 900 /tmp/stream_producer 20 8 4 1 2>&1 | tee $O/c_producer.txt
-./tools/ubench_placement masked 2>&1 | tee $O/ubench_placement_cu_mask.txt
-timeout 900 python -m pytest tests/test_gpu_c_drivers.py tests/test_gpu_stream_host.py -x -q -m gpu 2>&1 | tail -3 | tee $O/pytest_c_drivers.txt
-timeout 600 python bench.py --steps 10 --warmup 3 --reps 5 --cpu-log2n 0 --no-check 2>/dev/null | tail -1 > $O/bench_line.json
-python - $O/bench_line.json <<'PY' | tee $O/bench_summary.txt
+# round 6, late: is the slow first / second proof of a fresh key under `auto` (52 / 208 ms in one bench call instead of 23 / 18) reproducible?
+O=gpurun_out/r6x_cold; mkdir -p $O
+for i in 1; do echo "== fresh process $i"; timeout 300 python tools/time_first_proof.py auto 20 6 2>&1 | grep -v amdgpu.ids | tail -4; done | tee $O/first_proofs.txt
+for i in 1 2 3 4 5; do timeout 600 python bench.py --steps 10 --warmup 3 --reps 3 --cpu-log2n 0 --no-check 2>/dev/null | tail -1 > $O/bench_line_$i.json; python - $O/bench_line_$i.json <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[1]).read())
-print("ms_per_step", d["ms_per_step"], "value", d["value"], "build", d.get("build"))
+a = d["cold"]["auto"]
+print("bench", round(d["ms_per_step"], 3), "auto", a["proofs_ms"][:4], a["time_to_steady_ms"], a["slowest_proof_after_the_first_over_steady"], a["which_run"][:8], "other", a["other_run"]["proofs_ms"][:4], a["other_run"]["time_to_steady_ms"], "always", d["cold"]["always"]["first_proof_ms"])
 PY
+done | tee $O/bench_cold_summary.txt
