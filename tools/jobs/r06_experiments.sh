@@ -82,6 +82,12 @@ PY
   proof_clock)           # r06_power_clock_streams.txt: which part of a proof pulls the PLL down (the MSM streams run at 2.30-2.34 GHz, the proof stream at 2.03-2.08)
     timeout 600 python tools/power_trace.py 4 20 --streams-only 2>&1 | grep -v "^        \|^    \|^GPU\|^\$\|^====\|amdgpu.ids" | tee $OUT/streams_default.txt
     GS_NO_OVERLAP=1 timeout 600 python tools/power_trace.py 4 20 --streams-only 2>&1 | grep "stream\|proofs\|idle" | tee $OUT/streams_no_overlap.txt ;;
+  box_spread)            # r06_box_spread.txt: the same library takes 8.5-9.2 ms per proof from box to box -- the bench line beside the box's power / sclk under the streams
+    (timeout 600 python bench.py --steps 10 --warmup 3 --reps 5 --cpu-log2n 0 --no-check --no-extras 2>/dev/null | tail -1) > $OUT/bench_line.json
+    python -c "import json,sys; d=json.load(open('$OUT/bench_line.json')); print('bench line: %.3f ms per proof, G1 accumulation launch %.3f ms, valu frac %.3f' % (d['ms_per_step'], d['roofline']['avg_launch_ms'], d['roofline_valu']['frac']))" | tee $OUT/box_spread.txt
+    timeout 600 python tools/power_trace.py 4 20 --streams-only 2>&1 | grep "^idle\|^G1 MSM stream\|^G2 MSM stream\|^Groth16 proof stream, \|^gs_r1cs_px" | tee -a $OUT/box_spread.txt
+    ./tools/ubench_issue 0 2 0 | grep -v "^gfx" | tee -a $OUT/box_spread.txt
+    ./tools/ubench_mulmod 2 2 2>&1 | tail -2 | tee -a $OUT/box_spread.txt ;;
   acc_block)             # r06_ab_accumulate_block.txt: 64- / 128-thread workgroups for the accumulation kernels (no LDS, no barrier: the group is only the dispatcher's unit)
     bash tools/gpu_run.sh $T ab acc64 acc128 : --steps 10 --warmup 3 --reps 5
     bash tools/gpu_run.sh $T ab acc64 acc128 : --workload msm_g1 --steps 40 --warmup 5 --reps 5
