@@ -88,6 +88,14 @@ PY
     timeout 600 python tools/power_trace.py 4 20 --streams-only 2>&1 | grep "^idle\|^G1 MSM stream\|^G2 MSM stream\|^Groth16 proof stream, \|^gs_r1cs_px" | tee -a $OUT/box_spread.txt
     ./tools/ubench_issue 0 2 0 | grep -v "^gfx" | tee -a $OUT/box_spread.txt
     ./tools/ubench_mulmod 2 2 2>&1 | tail -2 | tee -a $OUT/box_spread.txt ;;
+  acc_waves)             # r06_ab_accumulate_fourth_wave.txt: k_bucket_accumulate<G1> capped at 128 VGPRs = four waves per SIMD (w4: 168 B of scratch per lane; w4np: without the
+                         # register prefetch of the next point, 92 B) against the shipped 160 VGPRs = three.  make EXTRA="-DGS_G1_WAVES=4 [-DGS_G1_PREFETCH=0]" BUILD=build_w4[np] LIB=../../gpurun_variants/lib_w4[np].so
+    bash tools/gpu_run.sh $T ab w4np w4 : --steps 10 --warmup 3 --reps 5
+    bash tools/gpu_run.sh $T ab w4np w4 : --workload msm_g1 --steps 40 --warmup 5 --reps 5
+    bash tools/gpu_run.sh $T ab w4np w4 : --log2n 18 --steps 40 --warmup 5 --reps 5
+    bash tools/gpu_run.sh $T ab w4np w4 : --log2n 22 --steps 4 --warmup 1 --reps 3
+    bash tools/gpu_run.sh $T ab w4np w4 : --instance realistic --steps 12 --warmup 3 --reps 3
+    bash tools/gpu_run.sh $T ab w4np w4 : --workload prove_pinocchio --steps 8 --warmup 2 --reps 3 ;;
   acc_block)             # r06_ab_accumulate_block.txt: 64- / 128-thread workgroups for the accumulation kernels (no LDS, no barrier: the group is only the dispatcher's unit)
     bash tools/gpu_run.sh $T ab acc64 acc128 : --steps 10 --warmup 3 --reps 5
     bash tools/gpu_run.sh $T ab acc64 acc128 : --workload msm_g1 --steps 40 --warmup 5 --reps 5
