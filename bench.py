@@ -1124,7 +1124,7 @@ def main():
                          "CalculateWitness produces (circuit.go:158-182: about half zeros and ones, most of the rest below 2^32, few full-width "
                          "values); gates: flattened `*` / `+` gates in the shape of the reference's circuit compiler (circuit.go:84-139): two thirds of "
                          "the key's B points are infinity, full-width witness; sqchain: same R1CS with key points k_i*G; random: uniform w / px")
-    ap.add_argument("--pipeline", type=int, default=3, choices=[1, 2, 3],
+    ap.add_argument("--pipeline", type=int, default=3, choices=[1, 2, 3, 4],
                     help="operations in flight per GPU (prove / msm_g1 workloads): >= 2 = gs_groth16_prove_begin/_end (gs_msm_g1_begin/"
                          "gs_msm_end), the next operation's plan and accumulations are queued behind the current one's; 1 = one "
                          "blocking call per step")

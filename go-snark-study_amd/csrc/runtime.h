@@ -223,7 +223,10 @@ struct Ctx {
   // them share a hardware queue, and the sort of the next proof then queues behind a reduction tail.)
   static constexpr int kAuxStreams = 3;
   hipStream_t aux_stream[kAuxStreams] = {nullptr, nullptr, nullptr};
-  static constexpr int kMaxInFlight = 3;             // pipelined operations (tickets); each owns one set of workspaces
+#ifndef GS_MAX_IN_FLIGHT
+#define GS_MAX_IN_FLIGHT 3                           // (a build-time constant: profiles/r06_ab_four_in_flight.txt measured 4)
+#endif
+  static constexpr int kMaxInFlight = GS_MAX_IN_FLIGHT;   // pipelined operations (tickets); each owns one set of workspaces
   static constexpr int kSlots = kMaxInFlight + 1;    // + one set for the blocking entry points (serialised by `mu`), so a blocking
   static constexpr int kBlockingSlot = kMaxInFlight; //   call made while tickets are outstanding never touches their result staging
   void* pinned[4 * kSlots] = {};                     // host staging of the result downloads: 3 per slot, then one more per slot

@@ -96,6 +96,15 @@ PY
     bash tools/gpu_run.sh $T ab w4np w4 : --log2n 22 --steps 4 --warmup 1 --reps 3
     bash tools/gpu_run.sh $T ab w4np w4 : --instance realistic --steps 12 --warmup 3 --reps 3
     bash tools/gpu_run.sh $T ab w4np w4 : --workload prove_pinocchio --steps 8 --warmup 2 --reps 3 ;;
+  four_in_flight)        # r06_ab_four_in_flight.txt: four ticket slots instead of three (make EXTRA=-DGS_MAX_IN_FLIGHT=4 LIB=../../gpurun_variants/lib_inflight4.so), bench --pipeline 4
+    line() { python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); t=d.get('device_ms_per_step',{}); print('%s: median %.3f min %.3f ms/step | value %.4g %s | in flight %s | acc g1 %.2f g2 %.2f' % (sys.argv[1], d['ms_per_step'], d['ms_per_step_min'], d['value'], d['unit'], d['config'].get('proofs_in_flight'), t.get('acc_g1_ms',0), t.get('acc_g2_ms',0)))" "$1"; }
+    for args in "--steps 12 --warmup 4 --reps 5" "--workload msm_g1 --steps 40 --warmup 5 --reps 5" "--log2n 18 --steps 40 --warmup 5 --reps 5" "--log2n 16 --steps 100 --warmup 10 --reps 5" "--instance realistic --steps 12 --warmup 4 --reps 3" "--workload prove_pinocchio --steps 8 --warmup 4 --reps 3" "--workload prove_witness --steps 12 --warmup 4 --reps 3"; do
+      for round in 1 2; do
+        timeout 600 python bench.py $args --pipeline 3 --cpu-log2n 0 --no-extras --no-check 2>/dev/null | line "$args, shipped library, 3 in flight"
+        GS_LIB=$PWD/gpurun_variants/lib_inflight4.so timeout 600 python bench.py $args --pipeline 4 --cpu-log2n 0 --no-extras --no-check 2>/dev/null | line "$args, four slots, 4 in flight"
+        GS_LIB=$PWD/gpurun_variants/lib_inflight4.so timeout 600 python bench.py $args --pipeline 3 --cpu-log2n 0 --no-extras --no-check 2>/dev/null | line "$args, four slots, 3 in flight"
+      done
+    done 2>&1 | tee $OUT/ab.txt ;;
   acc_block)             # r06_ab_accumulate_block.txt: 64- / 128-thread workgroups for the accumulation kernels (no LDS, no barrier: the group is only the dispatcher's unit)
     bash tools/gpu_run.sh $T ab acc64 acc128 : --steps 10 --warmup 3 --reps 5
     bash tools/gpu_run.sh $T ab acc64 acc128 : --workload msm_g1 --steps 40 --warmup 5 --reps 5
