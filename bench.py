@@ -1525,8 +1525,9 @@ def main():
                                      "note": "2090 VALU instructions per mixed addition x additions / 64 lanes; peak = the rate at which the chip executes fp29.h's own "
                                              "Montgomery products (dots3, random data) in a bare loop without loads, SUSTAINED: 207 VALU instructions per 377 ns per SIMD "
                                              "(tools/ubench_mulmod.hip 2 4: 876 cycles per product per SIMD at sclk 2.39 GHz).  Per class the G1 addition sums to 9.3 k "
-                                             "cycles (1474 multiply-adds x 4.47 + 313 other VOP3 x 4.6 + 337 VOP2 x 2.9 + 249 s_nop x 1.35); the kernel takes 11.1 k at the "
-                                             "2.27 GHz the MSM stream runs at (socket 1365 W of its 1400 W cap): 0.81-0.84 in cycles, 0.76-0.78 in time.  4.47 cycles per multiply-add is "
+                                             "cycles (1474 multiply-adds x 4.47 + 313 other VOP3 x 4.6 + 337 VOP2 x 2.9 + 249 s_nop x 1.35); the kernel takes 9.9-10.1 k at the "
+                                             "2.01-2.05 GHz a probe wave reads beside the proof stream (profiles/r06_clock_timeline.txt: the accumulation kernels, and only they, are "
+                                             "limited to ~2.0 GHz after 2-3 ms): 0.92-0.94 in cycles, 0.78-0.80 in time.  4.47 cycles per multiply-add is "
                                              "the SIMD's own rate at three waves per SIMD, on 8 CUs as on 256 (a sixteen-lane pipe: 4 cycles per wave at best, 7.8 k cycles per "
                                              "addition architecturally), not a clock or a socket-wide limit: profiles/r06_power_clock_trace.txt, r06_ubench_placement_cu_mask.txt"}
             out["roofline_whole_step"] = {"bound": "hbm", "algorithmic_bytes_per_step": step_bytes,

@@ -105,6 +105,41 @@ PY
         GS_LIB=$PWD/gpurun_variants/lib_inflight4.so timeout 600 python bench.py $args --pipeline 3 --cpu-log2n 0 --no-extras --no-check 2>/dev/null | line "$args, four slots, 3 in flight"
       done
     done 2>&1 | tee $OUT/ab.txt ;;
+  proof_kernel_clocks)   # r06_pmc_kernel_clocks.txt: GRBM_GUI_ACTIVE / duration per kernel (= the clock the kernel ran at; PMC passes serialise the kernels) in a proof
+                         # stream and in a G1 MSM stream -- which kernels of a proof run at the low clock the hwmon trace sees?
+    for wl in "prove" "msm_g1" "prove_pinocchio"; do
+      D=/tmp/pmc_clk_$wl; rm -rf $D
+      ( cd /tmp && timeout 900 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $D -o p -- python $OLDPWD/bench.py --workload $wl --steps 8 --warmup 3 --reps 1 --cpu-log2n 0 --no-extras --no-check > /dev/null 2>&1 )
+      echo "== workload $wl"
+      python - $D <<'PY'
+import csv, glob, sys, collections
+cc = glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True)
+kt = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)
+if not cc or not kt:
+    print("no rocprofv3 output", cc, kt); sys.exit(0)
+dur = {}
+for r in csv.DictReader(open(kt[0])):
+    dur[r["Dispatch_Id"]] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), int(r["Start_Timestamp"]))
+rows = []
+for r in csv.DictReader(open(cc[0])):
+    if r["Counter_Name"] != "GRBM_GUI_ACTIVE" or r["Dispatch_Id"] not in dur:
+        continue
+    d, t0 = dur[r["Dispatch_Id"]]
+    rows.append((t0, r["Kernel_Name"], float(r["Counter_Value"]), d))
+rows.sort()
+rows = rows[len(rows) // 3:]                      # the steady part of the run
+agg = collections.defaultdict(lambda: [0.0, 0, 0])
+for _, name, v, d in rows:
+    a = agg[name.split("(")[0][:70]]
+    a[0] += v; a[1] += d; a[2] += 1
+print("%-72s %8s %10s %9s" % ("kernel (steady two thirds of the run)", "launches", "avg us", "GHz"))
+for name, (v, d, k) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:14]:
+    ghz = v / d
+    print("%-72s %8d %10.1f %9.3f%s" % (name, k, d / k / 1e3, ghz / 8 if ghz > 4 else ghz, " (counter summed over 8 XCDs: / 8)" if ghz > 4 else ""))
+PY
+    done 2>&1 | tee $OUT/pmc_kernel_clocks.txt ;;
+  clock_timeline)        # r06_clock_timeline.txt: the shader clock at 20 us resolution beside each of the library's streams (tools/clock_probe.hip: one wave, s_memtime against s_memrealtime)
+    timeout 600 python tools/clock_timeline.py 20 60 20 2>&1 | grep -v amdgpu.ids | tee $OUT/clock_timeline.txt ;;
   acc_block)             # r06_ab_accumulate_block.txt: 64- / 128-thread workgroups for the accumulation kernels (no LDS, no barrier: the group is only the dispatcher's unit)
     bash tools/gpu_run.sh $T ab acc64 acc128 : --steps 10 --warmup 3 --reps 5
     bash tools/gpu_run.sh $T ab acc64 acc128 : --workload msm_g1 --steps 40 --warmup 5 --reps 5
