@@ -113,3 +113,13 @@ def test_host_copy_pool_copies_every_byte():
     exe = hostbuild.build("hostcopy_test")
     out = subprocess.run([exe, "6000"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and out.stdout.startswith("OK"), out.stdout + out.stderr
+
+
+def test_context_lock_is_first_come_first_served():
+    """go-snark-study_amd/csrc/runtime.h FairMutex (round 6): try_lock, service in the order of arrival, mutual exclusion, and no starvation of
+    polite threads by two threads that release the lock and ask again at once -- the std::mutex of rounds 1-5 let two blocking-proof loops keep
+    six other threads of tests/c/stream_stress.c at one operation each for a minute (profiles/r06_stream_stress_fair_lock.txt)."""
+    import subprocess
+    exe = hostbuild.build("fair_mutex_test")
+    out = subprocess.run([exe, "400"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.strip().endswith("OK"), out.stdout + out.stderr
