@@ -27,7 +27,10 @@ int upload_bases(Ctx& c, Kind kind, const uint64_t* jac, size_t n, gs_handle* ou
   b->buf.alloc(std::max<size_t>(n, 1) * 2 * cw * 4);
   if (n) {
     DevBuf tmp(n * 3 * cw * 4);
-    GS_HIP(hipMemcpyAsync(tmp.p, jac, n * 3 * cw * 4, hipMemcpyHostToDevice, c.stream));
+    // pageable caller memory: through the pinned staging buffers and the copy threads (hostcopy.h), like the witnesses of host-buffer
+    // tickets -- hipMemcpyAsync stages pageable memory on the calling thread at ~15 GB/s, which made the five arrays of a 2^20 key
+    // (0.6 GB of Jacobian triples) 39 ms of a CLI's load-a-key-prove-once (cli/main.go:330-349) next to a 23 ms first proof
+    staged_h2d(c, tmp.p, jac, n * 3 * cw * 4, c.stream);
     uint32_t first_bad = 0;
     const uint32_t bad = kind == Kind::G1Bases ? jacobian_to_affine_g1(c, tmp.as<uint32_t>(), (uint32_t)n, b->buf.as<uint32_t>(), &first_bad)
                                                : jacobian_to_affine_g2(c, tmp.as<uint32_t>(), (uint32_t)n, b->buf.as<uint32_t>(), &first_bad);
