@@ -26,14 +26,9 @@ int upload_bases(Ctx& c, Kind kind, const uint64_t* jac, size_t n, gs_handle* ou
   b->n = n;
   b->buf.alloc(std::max<size_t>(n, 1) * 2 * cw * 4);
   if (n) {
-    DevBuf tmp(n * 3 * cw * 4);
-    // pageable caller memory: through the pinned staging buffers and the copy threads (hostcopy.h), like the witnesses of host-buffer
-    // tickets -- hipMemcpyAsync stages pageable memory on the calling thread at ~15 GB/s, which made the five arrays of a 2^20 key
-    // (0.6 GB of Jacobian triples) 39 ms of a CLI's load-a-key-prove-once (cli/main.go:330-349) next to a 23 ms first proof
-    staged_h2d(c, tmp.p, jac, n * 3 * cw * 4, c.stream);
     uint32_t first_bad = 0;
-    const uint32_t bad = kind == Kind::G1Bases ? jacobian_to_affine_g1(c, tmp.as<uint32_t>(), (uint32_t)n, b->buf.as<uint32_t>(), &first_bad)
-                                               : jacobian_to_affine_g2(c, tmp.as<uint32_t>(), (uint32_t)n, b->buf.as<uint32_t>(), &first_bad);
+    const uint32_t bad = kind == Kind::G1Bases ? upload_jacobian_g1(c, jac, (uint32_t)n, b->buf.as<uint32_t>(), &first_bad)
+                                               : upload_jacobian_g2(c, jac, (uint32_t)n, b->buf.as<uint32_t>(), &first_bad);
     if (bad) return fail(GS_ERR_ARG, "%u of the %zu points are not on the curve (first at index %u)", bad, n, first_bad);
   }
   *out = c.put(std::move(b));

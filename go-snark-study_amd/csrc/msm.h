@@ -144,6 +144,9 @@ void msm_run_g2(Ctx& c, const MsmPlan& plan, const std::vector<MsmBase>& bases, 
 // -> number of points off their curve (first such index in *first_bad); synchronises the stream
 uint32_t jacobian_to_affine_g1(Ctx& c, const uint32_t* jac_dev, uint32_t n, uint32_t* out_dev, uint32_t* first_bad = nullptr);
 uint32_t jacobian_to_affine_g2(Ctx& c, const uint32_t* jac_dev, uint32_t n, uint32_t* out_dev, uint32_t* first_bad = nullptr);
+// the same from caller memory (gs_g1_upload / gs_g2_upload): staged through pinned buffers into a scratch the context keeps
+uint32_t upload_jacobian_g1(Ctx& c, const uint64_t* jac_host, uint32_t n, uint32_t* out_dev, uint32_t* first_bad = nullptr);
+uint32_t upload_jacobian_g2(Ctx& c, const uint64_t* jac_host, uint32_t n, uint32_t* out_dev, uint32_t* first_bad = nullptr);
 void affine_to_jacobian_std_g1(Ctx& c, const uint32_t* aff_dev, uint32_t n, uint32_t* out_dev);
 void affine_to_jacobian_std_g2(Ctx& c, const uint32_t* aff_dev, uint32_t n, uint32_t* out_dev);
 void fixed_base_g1(Ctx& c, const uint32_t* scalars_dev, uint32_t n, uint32_t* out_dev);

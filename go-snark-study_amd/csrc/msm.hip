@@ -1,5 +1,6 @@
 // MSM engine: host orchestration of the kernels in msm_kernels.h + the O(1) serial combination.
 #include "msm.h"
+#include "hostcopy.h"
 
 #include <algorithm>
 #include <cmath>
@@ -65,6 +66,8 @@ struct MsmState {                                  // per context (device memory
   PlanBuffers plan_slots[3 * Ctx::kSlots];         // (w, h) x slots, then one more per slot: the masked plan over w of keys with sparse B arrays
   DevBuf table_scratch;                            // slab of the batched window-table builder
   DevBuf table_scratch_bg;                         // ... and of the builds that run in the background on the table stream
+  DevBuf upload_scratch;                           // Jacobian triples of a base array on their way in (upload_jacobian), kept up to kUploadScratchKeep
+  DevBuf upload_flag;                              // {points off the curve, first such index} of the conversion kernel
   bool lds_attr_set = false;
 };
 static MsmState& msm_state(Ctx& c) { return c.state<MsmState>(c.msm_state); }
@@ -654,7 +657,8 @@ void msm_run_g2(Ctx& c, const MsmPlan& plan, const std::vector<MsmBase>& bases, 
 template <class T>
 static uint32_t jacobian_to_affine_checked(Ctx& c, const uint32_t* jac, uint32_t n, uint32_t* out, uint32_t* first_bad) {
   if (!n) return 0;
-  DevBuf flag(8);
+  DevBuf& flag = msm_state(c).upload_flag;          // (the context's: a hipMalloc and a hipFree -- a device-wide wait -- per call otherwise)
+  flag.ensure(8);
   const uint32_t init[2] = {0u, 0xffffffffu};
   GS_HIP(hipMemcpyAsync(flag.p, init, 8, hipMemcpyHostToDevice, c.stream));
   hipLaunchKernelGGL(k_jacobian_to_affine<T>, grid1(n), dim3(256), 0, c.stream, jac, n, out, flag.as<uint32_t>());
@@ -665,6 +669,22 @@ static uint32_t jacobian_to_affine_checked(Ctx& c, const uint32_t* jac, uint32_t
   if (first_bad) *first_bad = res[1];
   return res[0];
 }
+// gs_g1_upload / gs_g2_upload: n Jacobian triples (standard form) in caller memory -> packed affine Montgomery points at `out`.  The
+// triples come in through the pinned staging buffers and the copy threads (hostcopy.h) into a scratch the context keeps while it is small:
+// a 2^20 key is five such uploads, and each used to pay three hipMalloc and two hipFree (each a device-wide wait) around 2 ms of copying.
+constexpr size_t kUploadScratchKeep = (size_t)256 << 20;
+template <class T>
+static uint32_t upload_jacobian(Ctx& c, const uint64_t* jac_host, uint32_t n, uint32_t* out, uint32_t* first_bad) {
+  if (!n) return 0;
+  const size_t bytes = (size_t)n * 3 * T::kWords * 4;
+  DevBuf once;
+  DevBuf& scratch = bytes <= kUploadScratchKeep ? msm_state(c).upload_scratch : once;
+  scratch.ensure(bytes);
+  staged_h2d(c, scratch.p, jac_host, bytes, c.stream);
+  return jacobian_to_affine_checked<T>(c, scratch.as<uint32_t>(), n, out, first_bad);       // synchronises the stream: `once` may go
+}
+uint32_t upload_jacobian_g1(Ctx& c, const uint64_t* jac_host, uint32_t n, uint32_t* out, uint32_t* first_bad) { return upload_jacobian<FqTag>(c, jac_host, n, out, first_bad); }
+uint32_t upload_jacobian_g2(Ctx& c, const uint64_t* jac_host, uint32_t n, uint32_t* out, uint32_t* first_bad) { return upload_jacobian<Fq2Tag>(c, jac_host, n, out, first_bad); }
 uint32_t jacobian_to_affine_g1(Ctx& c, const uint32_t* jac, uint32_t n, uint32_t* out, uint32_t* first_bad) {
   return jacobian_to_affine_checked<FqTag>(c, jac, n, out, first_bad);
 }
