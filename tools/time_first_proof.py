@@ -1,5 +1,5 @@
 """Time from a fresh resident key to its first proofs -- dev tool.
-    python tools/time_first_proof.py [policy=auto] [log2n=20] [proofs=40]
+    python tools/time_first_proof.py [policy=auto] [log2n=20] [proofs=40] [log2n of the warm-up key=10]
 Prints every blocking proof's wall time and the window width it ran on (gs_timing.window_bits: the table-free route's differs from
 the table route's), i.e. the whole warm-up transient of a key under the table policy: first proof, the proofs that share the chip
 with the background builds (GS_TABLE_BG_SLAB_LOG2), the switch-over."""
@@ -13,7 +13,8 @@ logn = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 count = int(sys.argv[3]) if len(sys.argv) > 3 else 40
 capi.init()
 capi.set_table_policy(policy)
-warm = synth.sqchain_setup_instance(1 << 10, 1)
+warm_logn = int(sys.argv[4]) if len(sys.argv) > 4 else 10      # 20: the process has proven at this size before (workspaces exist): what is left is per KEY
+warm = synth.sqchain_setup_instance(1 << warm_logn, 1)
 groth16.prove_resident(warm.device_pk(), warm.w, warm.px, *synth.field_elems(2, 4))
 inst = synth.sqchain_setup_instance(1 << logn, 3)
 r, s = synth.field_elems(2, 5)
